@@ -1,0 +1,79 @@
+"""ctypes binding of libbsmi.so (include/bsmi.h).  There is no fallback: if the
+library is missing or a symbol is absent, importing this module raises."""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libbsmi.so")
+
+MAX_LEVELS, MAX_CONVS, MAX_HEADS, NAME_LEN = 8, 4, 4, 32
+PREC_F32, PREC_BF16 = 0, 1
+RAW_U8, RAW_F32 = 0, 1
+ERR_INVALID, ERR_HIP, ERR_STATE, ERR_MISSING, ERR_OVERFLOW = -1, -2, -3, -4, -5
+
+
+class UNetConfig(C.Structure):
+    _fields_ = [
+        ("in_channels", C.c_int32),
+        ("num_fmaps", C.c_int32),
+        ("fmap_inc_factor", C.c_int32),
+        ("num_levels", C.c_int32),
+        ("downsample_factors", (C.c_int32 * 3) * MAX_LEVELS),
+        ("n_convs_down", C.c_int32 * MAX_LEVELS),
+        ("kernel_size_down", ((C.c_int32 * 3) * MAX_CONVS) * MAX_LEVELS),
+        ("n_convs_up", C.c_int32 * MAX_LEVELS),
+        ("kernel_size_up", ((C.c_int32 * 3) * MAX_CONVS) * MAX_LEVELS),
+        ("num_heads", C.c_int32),
+        ("head_name", (C.c_char * NAME_LEN) * MAX_HEADS),
+        ("head_dims", C.c_int32 * MAX_HEADS),
+    ]
+
+
+class BsmiError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"libbsmi error {code}: {msg}")
+        self.code = code
+        self.msg = msg
+
+
+def _load():
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(or `make -C bootstrapper_amd/csrc`).  There is no CPU fallback.")
+    lib = C.CDLL(LIB_PATH)
+    p, i32, i64p, vp = C.c_void_p, C.c_int, C.POINTER(C.c_int64), C.c_void_p
+    sigs = {
+        "bsmi_last_error": (C.c_char_p, []),
+        "bsmi_version": (i32, []),
+        "bsmi_unet_create": (i32, [C.POINTER(UNetConfig), i32, C.POINTER(p)]),
+        "bsmi_unet_destroy": (i32, [p]),
+        "bsmi_unet_load_weight": (i32, [p, C.c_char_p, vp, i64p, i32]),
+        "bsmi_unet_finalize": (i32, [p, i32]),
+        "bsmi_unet_output_shape": (i32, [p, i64p, i64p]),
+        "bsmi_unet_flops": (i32, [p, i64p, C.POINTER(C.c_double)]),
+        "bsmi_unet_forward": (i32, [p, i32, vp, i32, i64p, C.POINTER(vp), C.POINTER(vp), vp]),
+        "bsmi_extract_block_reflect_u8": (i32, [vp, i64p, i64p, i64p, vp, vp]),
+        "bsmi_seg_create": (i32, [i32, i64p, C.POINTER(p)]),
+        "bsmi_seg_destroy": (i32, [p]),
+        "bsmi_ws_fragments_u8": (i32, [p, vp, i64p, i32, i32, vp, vp, vp]),
+        "bsmi_agglomerate_mean_u8": (i32, [p, vp, vp, i64p, C.POINTER(C.c_float), i32, vp, vp]),
+        "bsmi_seg_status": (i32, [p, vp]),
+    }
+    for name, (res, args) in sigs.items():
+        fn = getattr(lib, name)  # AttributeError if the symbol is missing: fail loudly
+        fn.restype = res
+        fn.argtypes = args
+    return lib, sorted(sigs)
+
+
+lib, SYMBOLS = _load()
+
+
+def check(rc):
+    if rc != 0:
+        raise BsmiError(rc, lib.bsmi_last_error().decode(errors="replace"))
+
+
+def i64x3(v):
+    return (C.c_int64 * 3)(*[int(x) for x in v])

@@ -1,0 +1,723 @@
+// Host side of the U-Net engine: network description, weight packing, shape planning and
+// the C-ABI entry points declared in include/bsmi.h.
+//
+// The planner restates the control flow of the reference UNet.rec_forward
+// (models/3d_affs/unet.py:440-469) once per input shape and lowers it to a flat list of
+// launches: every ConvPass stage (unet.py:7-76) becomes ONE implicit-GEMM launch whose
+// K-steps cover the kernel taps of all concatenated inputs plus, for the last stage, the
+// cropped 1x1x1 residual branch; max-pool and trilinear-upsample+crop are separate
+// memory-bound launches; the crop of the skip connection (unet.py:203-213) is pure index
+// arithmetic folded into the K-step offsets.
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <map>
+#include <memory>
+#include <vector>
+
+#include "conv_igemm.h"
+#include "unet_ops.h"
+
+namespace bsmi {
+
+static thread_local std::string g_err;
+void set_error(const char* fmt, ...) {
+  char buf[1024];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof buf, fmt, ap);
+  va_end(ap);
+  g_err = buf;
+}
+
+static inline uint16_t host_f32_to_bf16(float f) {
+  uint32_t u;
+  memcpy(&u, &f, 4);
+  if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40);  // NaN stays NaN
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return (uint16_t)(u >> 16);
+}
+
+struct HostWeight {
+  std::vector<int64_t> shape;
+  std::vector<float> data;
+  bool loaded = false;
+};
+
+struct PackEntry {
+  int slot;        // tensor slot of the launch
+  int dz, dy, dx;  // tap offset (voxels) relative to the slot's origin
+  int c0, nsub;    // channel chunk start (elements) and valid 32-byte sub-steps
+  int wsrc;        // 0 = this stage's conv weight, 1 = residual 1x1x1 weight
+  int tap;         // flat tap index into the weight's kernel dims
+  int cin_base;    // first input channel of this slot inside the weight's Cin dim
+  int creal;       // real channels of the slot
+};
+
+struct PackedConv {
+  bool ready = false;
+  std::vector<PackEntry> entries;
+  void* w = nullptr;
+  float* bias = nullptr;
+  int Npad = 0;
+  TileCfg tile = TILE_256x32;
+};
+
+struct PassSite {
+  std::string prefix;
+  int nslots = 1;
+  int cin[2] = {0, 0};
+  int cout = 0;
+  int nconv = 0;
+  int k[BSMI_MAX_CONVS][3];
+  PackedConv packed[2][BSMI_MAX_CONVS];
+};
+
+struct HeadSite {
+  std::string prefix;
+  int cin = 0, cout = 0;
+  float* hw = nullptr;  // device [cout][2][cin]
+  float* hb = nullptr;  // device [cout][2]
+};
+
+struct TDesc {
+  void* ptr = nullptr;
+  int C = 0, Cpad = 0, D = 0, H = 0, W = 0;
+};
+
+struct PlanStep {
+  enum Type { INPUT, CONV, POOL, UP, HEAD } type;
+  ConvArgs conv;
+  TileCfg tile;
+  TDesc in, out;
+  int f[3], o[3];
+  int head = 0;
+};
+
+struct Plan {
+  std::vector<void*> allocs;
+  std::vector<PlanStep> steps;
+  int64_t out_shape[3] = {0, 0, 0};
+  double flops = 0;
+  size_t bytes = 0;
+};
+
+}  // namespace bsmi
+
+using namespace bsmi;
+
+struct bsmi_unet {
+  bsmi_unet_config cfg;
+  int device = 0;
+  int nl = 0;
+  std::vector<PassSite> l_conv, r_conv;
+  std::vector<HeadSite> heads;
+  int crop_factor[BSMI_MAX_LEVELS][3];
+  std::map<std::string, HostWeight> weights;
+  bool finalized[2] = {false, false};
+  std::map<std::vector<int64_t>, std::unique_ptr<Plan>> plans;  // key: prec, D, H, W
+};
+
+namespace bsmi {
+
+static int esize(int prec) { return prec == BSMI_PREC_F32 ? 4 : 2; }
+static int bke(int prec) { return 128 / esize(prec); }   // elements per K-step row
+static int sube(int prec) { return 32 / esize(prec); }   // elements per 32-byte sub-step
+
+static void expect_weight(bsmi_unet* h, const std::string& key, std::vector<int64_t> shape) {
+  HostWeight hw;
+  hw.shape = std::move(shape);
+  h->weights[key] = std::move(hw);
+}
+
+static void register_pass(bsmi_unet* h, const PassSite& p) {
+  int cin_total = p.cin[0] + (p.nslots > 1 ? p.cin[1] : 0);
+  int cin = cin_total;
+  for (int i = 0; i < p.nconv; ++i) {
+    const std::string base = p.prefix + ".conv_pass." + std::to_string(2 * i);
+    expect_weight(h, base + ".weight", {p.cout, cin, p.k[i][0], p.k[i][1], p.k[i][2]});
+    expect_weight(h, base + ".bias", {p.cout});
+    cin = p.cout;
+  }
+  expect_weight(h, p.prefix + ".residual.0.weight", {p.cout, cin_total, 1, 1, 1});
+  expect_weight(h, p.prefix + ".residual.0.bias", {p.cout});
+}
+
+// Build the K-step entry list of stage `ci` of a ConvPass (precision dependent chunking).
+static void build_entries(const PassSite& p, int ci, int prec, std::vector<PackEntry>& out) {
+  const int BKE = bke(prec), SUB = sube(prec);
+  const bool last = ci == p.nconv - 1;
+  auto add_chunks = [&](int slot, int dz, int dy, int dx, int wsrc, int tap, int cin_base, int creal) {
+    const int cpad = round_up(creal, kChanPad);
+    for (int c0 = 0; c0 < cpad; c0 += BKE) {
+      PackEntry e;
+      e.slot = slot; e.dz = dz; e.dy = dy; e.dx = dx; e.c0 = c0;
+      e.nsub = std::min(BKE / SUB, (cpad - c0) / SUB);
+      e.wsrc = wsrc; e.tap = tap; e.cin_base = cin_base; e.creal = creal;
+      out.push_back(e);
+    }
+  };
+  const int* k = p.k[ci];
+  if (ci == 0) {
+    int base = 0;
+    for (int s = 0; s < p.nslots; ++s) {
+      for (int z = 0; z < k[0]; ++z)
+        for (int y = 0; y < k[1]; ++y)
+          for (int x = 0; x < k[2]; ++x) add_chunks(s, z, y, x, 0, (z * k[1] + y) * k[2] + x, base, p.cin[s]);
+      base += p.cin[s];
+    }
+  } else {
+    for (int z = 0; z < k[0]; ++z)
+      for (int y = 0; y < k[1]; ++y)
+        for (int x = 0; x < k[2]; ++x) add_chunks(0, z, y, x, 0, (z * k[1] + y) * k[2] + x, 0, p.cout);
+  }
+  if (last) {
+    int crop[3] = {0, 0, 0};
+    for (int i = 0; i < p.nconv; ++i)
+      for (int d = 0; d < 3; ++d) crop[d] += p.k[i][d] - 1;
+    const int first_slot = ci == 0 ? 0 : 1;
+    int base = 0;
+    for (int s = 0; s < p.nslots; ++s) {
+      add_chunks(first_slot + s, crop[0] / 2, crop[1] / 2, crop[2] / 2, 1, 0, base, p.cin[s]);
+      base += p.cin[s];
+    }
+  }
+}
+
+static int pack_conv(bsmi_unet* h, PassSite& p, int ci, int prec) {
+  PackedConv& pc = p.packed[prec][ci];
+  if (pc.ready) return BSMI_OK;
+  pc.entries.clear();
+  build_entries(p, ci, prec, pc.entries);
+  pc.tile = choose_tile(p.cout);
+  pc.Npad = round_up(p.cout, tile_bn(pc.tile));
+  const int BKE = bke(prec);
+  const bool last = ci == p.nconv - 1;
+  const HostWeight& wm = h->weights[p.prefix + ".conv_pass." + std::to_string(2 * ci) + ".weight"];
+  const HostWeight& bm = h->weights[p.prefix + ".conv_pass." + std::to_string(2 * ci) + ".bias"];
+  const HostWeight& wr = h->weights[p.prefix + ".residual.0.weight"];
+  const HostWeight& br = h->weights[p.prefix + ".residual.0.bias"];
+  const int64_t cin_m = wm.shape[1], ntap_m = wm.shape[2] * wm.shape[3] * wm.shape[4];
+  const int64_t cin_r = wr.shape[1];
+  const size_t nsteps = pc.entries.size();
+  const size_t nelem = nsteps * (size_t)pc.Npad * BKE;
+  std::vector<float> bias(pc.Npad, 0.f);
+  for (int n = 0; n < p.cout; ++n) bias[n] = bm.data[n] + (last ? br.data[n] : 0.f);
+
+  std::vector<uint8_t> packed(nelem * esize(prec), 0);
+  for (size_t s = 0; s < nsteps; ++s) {
+    const PackEntry& e = pc.entries[s];
+    for (int n = 0; n < p.cout; ++n) {
+      for (int kk = 0; kk < BKE; ++kk) {
+        const int c = e.c0 + kk;
+        if (c >= e.creal) break;
+        float v;
+        if (e.wsrc == 0) v = wm.data[((size_t)n * cin_m + (e.cin_base + c)) * ntap_m + e.tap];
+        else v = wr.data[(size_t)n * cin_r + (e.cin_base + c)];
+        const size_t idx = (s * pc.Npad + n) * BKE + kk;
+        if (prec == BSMI_PREC_F32) ((float*)packed.data())[idx] = v;
+        else ((uint16_t*)packed.data())[idx] = host_f32_to_bf16(v);
+      }
+    }
+  }
+  BSMI_HIP(hipMalloc(&pc.w, packed.size()));
+  BSMI_HIP(hipMemcpy(pc.w, packed.data(), packed.size(), hipMemcpyHostToDevice));
+  BSMI_HIP(hipMalloc((void**)&pc.bias, bias.size() * sizeof(float)));
+  BSMI_HIP(hipMemcpy(pc.bias, bias.data(), bias.size() * sizeof(float), hipMemcpyHostToDevice));
+  pc.ready = true;
+  return BSMI_OK;
+}
+
+struct Planner {
+  bsmi_unet* h;
+  int prec;
+  Plan* plan;
+  bool dry;  // shape / flop arithmetic only: no allocation, no device traffic
+
+  int alloc(TDesc& t) {
+    t.Cpad = round_up(t.C, kChanPad);
+    const size_t bytes = (size_t)t.D * t.H * t.W * t.Cpad * esize(prec);
+    plan->bytes += bytes;
+    if (bytes >= ((size_t)1 << 32) / 2 * (size_t)esize(prec))
+      BSMI_FAIL(BSMI_ERR_INVALID, "activation tensor of %zu bytes exceeds 32-bit element offsets", bytes);
+    if (dry) return BSMI_OK;
+    BSMI_HIP(hipMalloc(&t.ptr, bytes));
+    plan->allocs.push_back(t.ptr);
+    return BSMI_OK;
+  }
+
+  // One ConvPass (reference unet.py:63-76).  in[s] with per-slot origin org[s]; `sp` is the
+  // logical input extent (the extent of the concatenated, cropped input).
+  int pass(PassSite& p, const TDesc* in, const int (*org)[3], const int sp_in[3], TDesc& out) {
+    int sp[3] = {sp_in[0], sp_in[1], sp_in[2]};
+    int crop[3] = {0, 0, 0};
+    for (int i = 0; i < p.nconv; ++i)
+      for (int d = 0; d < 3; ++d) crop[d] += p.k[i][d] - 1;
+    TDesc cur;
+    for (int ci = 0; ci < p.nconv; ++ci) {
+      const bool last = ci == p.nconv - 1;
+      TDesc o;
+      o.C = p.cout;
+      o.D = sp[0] - (p.k[ci][0] - 1);
+      o.H = sp[1] - (p.k[ci][1] - 1);
+      o.W = sp[2] - (p.k[ci][2] - 1);
+      if (o.D <= 0 || o.H <= 0 || o.W <= 0)
+        BSMI_FAIL(BSMI_ERR_INVALID, "%s: input extent (%d,%d,%d) too small for kernel (%d,%d,%d)",
+                  p.prefix.c_str(), sp[0], sp[1], sp[2], p.k[ci][0], p.k[ci][1], p.k[ci][2]);
+      int rc = alloc(o);
+      if (rc) return rc;
+
+      // tensor slots of this launch and their origins
+      TDesc slots[kMaxConvTensors];
+      int so[kMaxConvTensors][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}};
+      int nsl = 0;
+      if (ci == 0) {
+        for (int s = 0; s < p.nslots; ++s) {
+          slots[nsl] = in[s];
+          for (int d = 0; d < 3; ++d) so[nsl][d] = org[s][d];
+          ++nsl;
+        }
+      } else {
+        slots[nsl++] = cur;
+        if (last)
+          for (int s = 0; s < p.nslots; ++s) {
+            slots[nsl] = in[s];
+            for (int d = 0; d < 3; ++d) so[nsl][d] = org[s][d];
+            ++nsl;
+          }
+      }
+
+      // flops: 2 * M * Cout * K_real
+      const double M = (double)o.D * o.H * o.W;
+      double kreal = 0;
+      {
+        std::vector<PackEntry> ents;
+        build_entries(p, ci, prec, ents);
+        for (auto& e : ents) kreal += std::max(0, std::min(e.creal - e.c0, bke(prec)));
+      }
+      plan->flops += 2.0 * M * p.cout * kreal;
+
+      if (!dry) {
+        PackedConv& pc = p.packed[prec][ci];
+        PlanStep st;
+        st.type = PlanStep::CONV;
+        st.tile = pc.tile;
+        ConvArgs& a = st.conv;
+        memset(&a, 0, sizeof a);
+        for (int s = 0; s < kMaxConvTensors; ++s) {
+          if (s < nsl) a.t[s] = ConvTensor{slots[s].ptr, slots[s].D, slots[s].H, slots[s].W, slots[s].Cpad};
+          else a.t[s] = ConvTensor{slots[0].ptr, 0, 0, 0, 0};
+        }
+        std::vector<KStep> ks(pc.entries.size());
+        for (size_t s = 0; s < pc.entries.size(); ++s) {
+          const PackEntry& e = pc.entries[s];
+          const TDesc& t = slots[e.slot];
+          const int64_t off = ((((int64_t)(e.dz + so[e.slot][0]) * t.H) + (e.dy + so[e.slot][1])) * t.W +
+                               (e.dx + so[e.slot][2])) * t.Cpad + e.c0;
+          // last voxel row read by the last output voxel stays inside the tensor by
+          // construction of the valid conv; guard the 32-bit offset range anyway
+          if (off < 0 || off + (int64_t)t.D * t.H * t.W * t.Cpad >= ((int64_t)1 << 31))
+            BSMI_FAIL(BSMI_ERR_INVALID, "%s: K-step offset out of 32-bit range", p.prefix.c_str());
+          ks[s] = KStep{e.slot, (int32_t)off, e.nsub, 0};
+        }
+        KStep* dks = nullptr;
+        BSMI_HIP(hipMalloc((void**)&dks, ks.size() * sizeof(KStep)));
+        plan->allocs.push_back(dks);
+        BSMI_HIP(hipMemcpy(dks, ks.data(), ks.size() * sizeof(KStep), hipMemcpyHostToDevice));
+        a.steps = dks;
+        a.nsteps = (int)ks.size();
+        a.w = pc.w;
+        a.bias = pc.bias;
+        a.out = o.ptr;
+        a.Do = o.D; a.Ho = o.H; a.Wo = o.W; a.Co = o.Cpad;
+        a.M = o.D * o.H * o.W;
+        a.Npad = pc.Npad;
+        a.relu = 1;  // trunk activation is ReLU (model.py passes activation default "ReLU")
+        plan->steps.push_back(st);
+      }
+      cur = o;
+      sp[0] = o.D; sp[1] = o.H; sp[2] = o.W;
+    }
+    out = cur;
+    (void)crop;
+    return BSMI_OK;
+  }
+
+  int rec(int level, const TDesc& f_in, TDesc& f_out) {
+    const int i = h->nl - level - 1;
+    TDesc f_left;
+    const int org0[1][3] = {{0, 0, 0}};
+    const int sp[3] = {f_in.D, f_in.H, f_in.W};
+    int rc = pass(h->l_conv[i], &f_in, org0, sp, f_left);
+    if (rc) return rc;
+    if (level == 0) {
+      f_out = f_left;
+      return BSMI_OK;
+    }
+    const int* f = h->cfg.downsample_factors[i];
+    const int dims[3] = {f_left.D, f_left.H, f_left.W};
+    for (int d = 2; d >= 0; --d)
+      if (dims[d] % f[d] != 0)
+        BSMI_FAIL(BSMI_ERR_INVALID,
+                  "Can not downsample shape (%d, %d, %d) with factor (%d, %d, %d), mismatch in spatial dimension %d",
+                  dims[0], dims[1], dims[2], f[0], f[1], f[2], d);
+    TDesc g_in;
+    g_in.C = f_left.C; g_in.D = f_left.D / f[0]; g_in.H = f_left.H / f[1]; g_in.W = f_left.W / f[2];
+    rc = alloc(g_in);
+    if (rc) return rc;
+    if (!dry) {
+      PlanStep st;
+      st.type = PlanStep::POOL;
+      st.in = f_left; st.out = g_in;
+      for (int d = 0; d < 3; ++d) st.f[d] = f[d];
+      plan->steps.push_back(st);
+    }
+    TDesc g_out;
+    rc = rec(level - 1, g_in, g_out);
+    if (rc) return rc;
+
+    // Upsample.forward (unet.py:215-223): upsample, crop_to_factor, crop skip, concat
+    PassSite& rp = h->r_conv[i];
+    const int up[3] = {g_out.D * f[0], g_out.H * f[1], g_out.W * f[2]};
+    int conv_crop[3] = {0, 0, 0};
+    for (int c = 0; c < rp.nconv; ++c)
+      for (int d = 0; d < 3; ++d) conv_crop[d] += rp.k[c][d] - 1;
+    int target[3];
+    for (int d = 0; d < 3; ++d) {
+      const int cf = h->crop_factor[i][d];
+      const int n = (int)std::floor((double)(up[d] - conv_crop[d]) / cf);
+      target[d] = n * cf + conv_crop[d];
+      if (target[d] != up[d] && target[d] <= conv_crop[d])
+        BSMI_FAIL(BSMI_ERR_INVALID,
+                  "Feature map with shape (%d, %d, %d) is too small to ensure translation equivariance",
+                  up[0], up[1], up[2]);
+    }
+    TDesc g_c;
+    g_c.C = g_out.C; g_c.D = target[0]; g_c.H = target[1]; g_c.W = target[2];
+    rc = alloc(g_c);
+    if (rc) return rc;
+    int so[2][3];
+    for (int d = 0; d < 3; ++d) {
+      so[0][d] = (dims[d] - target[d]) / 2;
+      so[1][d] = 0;
+      if (dims[d] < target[d])
+        BSMI_FAIL(BSMI_ERR_INVALID, "skip connection (%d,%d,%d) smaller than upsampled map (%d,%d,%d)",
+                  dims[0], dims[1], dims[2], target[0], target[1], target[2]);
+    }
+    if (!dry) {
+      PlanStep st;
+      st.type = PlanStep::UP;
+      st.in = g_out; st.out = g_c;
+      for (int d = 0; d < 3; ++d) { st.f[d] = f[d]; st.o[d] = (up[d] - target[d]) / 2; }
+      plan->steps.push_back(st);
+    }
+    const TDesc ins[2] = {f_left, g_c};
+    return pass(rp, ins, so, target, f_out);
+  }
+
+  int run(const int64_t in_shape[3]) {
+    TDesc x;
+    x.C = h->cfg.in_channels; x.D = (int)in_shape[0]; x.H = (int)in_shape[1]; x.W = (int)in_shape[2];
+    int rc = alloc(x);
+    if (rc) return rc;
+    if (!dry) {
+      PlanStep st;
+      st.type = PlanStep::INPUT;
+      st.out = x;
+      plan->steps.push_back(st);
+    }
+    TDesc z;
+    rc = rec(h->nl - 1, x, z);
+    if (rc) return rc;
+    plan->out_shape[0] = z.D; plan->out_shape[1] = z.H; plan->out_shape[2] = z.W;
+    for (size_t hd = 0; hd < h->heads.size(); ++hd) {
+      plan->flops += 2.0 * 2.0 * (double)z.D * z.H * z.W * h->heads[hd].cin * h->heads[hd].cout;
+      if (!dry) {
+        PlanStep st;
+        st.type = PlanStep::HEAD;
+        st.in = z;
+        st.head = (int)hd;
+        plan->steps.push_back(st);
+      }
+    }
+    return BSMI_OK;
+  }
+};
+
+static void free_plan(Plan* p) {
+  for (void* a : p->allocs) (void)hipFree(a);
+  p->allocs.clear();
+}
+
+static int check_shape_arg(const int64_t s[3]) {
+  for (int d = 0; d < 3; ++d)
+    if (s[d] <= 0 || s[d] > 4096) BSMI_FAIL(BSMI_ERR_INVALID, "bad input shape (%lld,%lld,%lld)", (long long)s[0], (long long)s[1], (long long)s[2]);
+  return BSMI_OK;
+}
+
+}  // namespace bsmi
+
+extern "C" {
+
+const char* bsmi_last_error(void) { return g_err.c_str(); }
+int bsmi_version(void) { return 1; }
+
+int bsmi_unet_create(const bsmi_unet_config* cfg, int device, bsmi_unet** out) {
+  if (!cfg || !out) BSMI_FAIL(BSMI_ERR_INVALID, "null argument");
+  if (cfg->num_levels < 1 || cfg->num_levels > BSMI_MAX_LEVELS) BSMI_FAIL(BSMI_ERR_INVALID, "num_levels %d out of range", cfg->num_levels);
+  if (cfg->num_heads < 1 || cfg->num_heads > BSMI_MAX_HEADS) BSMI_FAIL(BSMI_ERR_INVALID, "num_heads %d out of range", cfg->num_heads);
+  if (cfg->in_channels < 1 || cfg->num_fmaps < 1 || cfg->fmap_inc_factor < 1) BSMI_FAIL(BSMI_ERR_INVALID, "bad channel configuration");
+  // no HIP call here: shape / flop arithmetic must work on a host without a GPU
+  std::unique_ptr<bsmi_unet> h(new bsmi_unet);
+  h->cfg = *cfg;
+  h->device = device;
+  h->nl = cfg->num_levels;
+  auto fm = [&](int level) {
+    int64_t c = cfg->num_fmaps;
+    for (int i = 0; i < level; ++i) c *= cfg->fmap_inc_factor;
+    return (int)c;
+  };
+  auto fill_k = [&](PassSite& p, int n, const int32_t (*k)[3]) -> int {
+    if (n < 1 || n > BSMI_MAX_CONVS) BSMI_FAIL(BSMI_ERR_INVALID, "%s: %d convolutions per pass unsupported", p.prefix.c_str(), n);
+    p.nconv = n;
+    for (int i = 0; i < n; ++i)
+      for (int d = 0; d < 3; ++d) {
+        if (k[i][d] < 1 || k[i][d] > 7) BSMI_FAIL(BSMI_ERR_INVALID, "%s: kernel size %d unsupported", p.prefix.c_str(), k[i][d]);
+        p.k[i][d] = k[i][d];
+      }
+    return BSMI_OK;
+  };
+  for (int l = 0; l < h->nl; ++l) {
+    PassSite p;
+    p.prefix = "unet.l_conv." + std::to_string(l);
+    p.nslots = 1;
+    p.cin[0] = l == 0 ? cfg->in_channels : fm(l - 1);
+    p.cout = fm(l);
+    int rc = fill_k(p, cfg->n_convs_down[l], cfg->kernel_size_down[l]);
+    if (rc) return rc;
+    h->l_conv.push_back(p);
+  }
+  for (int l = 0; l < h->nl - 1; ++l) {
+    PassSite p;
+    p.prefix = "unet.r_conv.0." + std::to_string(l);
+    p.nslots = 2;
+    p.cin[0] = fm(l);      // skip connection first (torch.cat([f_cropped, g_cropped]), unet.py:223)
+    p.cin[1] = fm(l + 1);
+    p.cout = fm(l);
+    int rc = fill_k(p, cfg->n_convs_up[l], cfg->kernel_size_up[l]);
+    if (rc) return rc;
+    h->r_conv.push_back(p);
+  }
+  // crop factors (unet.py:353-362): running product of the downsample factors from the bottom
+  {
+    int prod[3] = {1, 1, 1};
+    for (int l = h->nl - 2; l >= 0; --l) {
+      for (int d = 0; d < 3; ++d) {
+        if (cfg->downsample_factors[l][d] < 1) BSMI_FAIL(BSMI_ERR_INVALID, "bad downsample factor");
+        prod[d] *= cfg->downsample_factors[l][d];
+        h->crop_factor[l][d] = prod[d];
+      }
+    }
+  }
+  for (auto& p : h->l_conv) register_pass(h.get(), p);
+  for (auto& p : h->r_conv) register_pass(h.get(), p);
+  for (int i = 0; i < cfg->num_heads; ++i) {
+    HeadSite hs;
+    hs.prefix = std::string(cfg->head_name[i], strnlen(cfg->head_name[i], BSMI_NAME_LEN));
+    hs.cin = cfg->num_fmaps;
+    hs.cout = cfg->head_dims[i];
+    if (hs.cout < 1 || hs.cout > 64) BSMI_FAIL(BSMI_ERR_INVALID, "head %s: dims %d unsupported", hs.prefix.c_str(), hs.cout);
+    expect_weight(h.get(), hs.prefix + ".conv_pass.0.weight", {hs.cout, hs.cin, 1, 1, 1});
+    expect_weight(h.get(), hs.prefix + ".conv_pass.0.bias", {hs.cout});
+    expect_weight(h.get(), hs.prefix + ".residual.0.weight", {hs.cout, hs.cin, 1, 1, 1});
+    expect_weight(h.get(), hs.prefix + ".residual.0.bias", {hs.cout});
+    h->heads.push_back(hs);
+  }
+  *out = h.release();
+  return BSMI_OK;
+}
+
+int bsmi_unet_destroy(bsmi_unet* h) {
+  if (!h) return BSMI_OK;
+  (void)hipSetDevice(h->device);
+  for (auto& kv : h->plans) free_plan(kv.second.get());
+  auto free_site = [](PassSite& p) {
+    for (int pr = 0; pr < 2; ++pr)
+      for (int c = 0; c < BSMI_MAX_CONVS; ++c) {
+        if (p.packed[pr][c].w) (void)hipFree(p.packed[pr][c].w);
+        if (p.packed[pr][c].bias) (void)hipFree(p.packed[pr][c].bias);
+      }
+  };
+  for (auto& p : h->l_conv) free_site(p);
+  for (auto& p : h->r_conv) free_site(p);
+  for (auto& hd : h->heads) {
+    if (hd.hw) (void)hipFree(hd.hw);
+    if (hd.hb) (void)hipFree(hd.hb);
+  }
+  delete h;
+  return BSMI_OK;
+}
+
+int bsmi_unet_load_weight(bsmi_unet* h, const char* key, const float* data, const int64_t* shape, int ndim) {
+  if (!h || !key || !data || !shape) BSMI_FAIL(BSMI_ERR_INVALID, "null argument");
+  auto it = h->weights.find(key);
+  if (it == h->weights.end()) BSMI_FAIL(BSMI_ERR_MISSING, "Unexpected key(s) in state_dict: \"%s\"", key);
+  HostWeight& w = it->second;
+  bool ok = (size_t)ndim == w.shape.size();
+  for (int i = 0; ok && i < ndim; ++i) ok = shape[i] == w.shape[i];
+  if (!ok) {
+    std::string got, want;
+    for (int i = 0; i < ndim; ++i) got += std::to_string(shape[i]) + (i + 1 < ndim ? ", " : "");
+    for (size_t i = 0; i < w.shape.size(); ++i) want += std::to_string(w.shape[i]) + (i + 1 < w.shape.size() ? ", " : "");
+    BSMI_FAIL(BSMI_ERR_INVALID, "size mismatch for %s: copying a param with shape (%s), the shape in current model is (%s)",
+              key, got.c_str(), want.c_str());
+  }
+  size_t n = 1;
+  for (auto s : w.shape) n *= (size_t)s;
+  w.data.assign(data, data + n);
+  w.loaded = true;
+  // weights changed: packed copies are stale
+  for (int pr = 0; pr < 2; ++pr) h->finalized[pr] = false;
+  return BSMI_OK;
+}
+
+int bsmi_unet_finalize(bsmi_unet* h, int precision) {
+  if (!h) BSMI_FAIL(BSMI_ERR_INVALID, "null handle");
+  if (precision != BSMI_PREC_F32 && precision != BSMI_PREC_BF16) BSMI_FAIL(BSMI_ERR_INVALID, "unknown precision %d", precision);
+  std::string missing;
+  for (auto& kv : h->weights)
+    if (!kv.second.loaded) missing += (missing.empty() ? "\"" : ", \"") + kv.first + "\"";
+  if (!missing.empty()) BSMI_FAIL(BSMI_ERR_MISSING, "Missing key(s) in state_dict: %s", missing.c_str());
+  BSMI_HIP(hipSetDevice(h->device));
+  auto repack = [&](PassSite& p) -> int {
+    for (int c = 0; c < p.nconv; ++c) {
+      PackedConv& pc = p.packed[precision][c];
+      if (pc.w) { (void)hipFree(pc.w); pc.w = nullptr; }
+      if (pc.bias) { (void)hipFree(pc.bias); pc.bias = nullptr; }
+      pc.ready = false;
+      int rc = pack_conv(h, p, c, precision);
+      if (rc) return rc;
+    }
+    return BSMI_OK;
+  };
+  for (auto& p : h->l_conv) { int rc = repack(p); if (rc) return rc; }
+  for (auto& p : h->r_conv) { int rc = repack(p); if (rc) return rc; }
+  for (auto& hd : h->heads) {
+    std::vector<float> hw((size_t)hd.cout * 2 * hd.cin), hb((size_t)hd.cout * 2);
+    const HostWeight& w1 = h->weights[hd.prefix + ".conv_pass.0.weight"];
+    const HostWeight& b1 = h->weights[hd.prefix + ".conv_pass.0.bias"];
+    const HostWeight& w2 = h->weights[hd.prefix + ".residual.0.weight"];
+    const HostWeight& b2 = h->weights[hd.prefix + ".residual.0.bias"];
+    for (int o = 0; o < hd.cout; ++o) {
+      for (int c = 0; c < hd.cin; ++c) {
+        hw[((size_t)o * 2 + 0) * hd.cin + c] = w1.data[(size_t)o * hd.cin + c];
+        hw[((size_t)o * 2 + 1) * hd.cin + c] = w2.data[(size_t)o * hd.cin + c];
+      }
+      hb[o * 2] = b1.data[o];
+      hb[o * 2 + 1] = b2.data[o];
+    }
+    if (!hd.hw) BSMI_HIP(hipMalloc((void**)&hd.hw, hw.size() * sizeof(float)));
+    if (!hd.hb) BSMI_HIP(hipMalloc((void**)&hd.hb, hb.size() * sizeof(float)));
+    BSMI_HIP(hipMemcpy(hd.hw, hw.data(), hw.size() * sizeof(float), hipMemcpyHostToDevice));
+    BSMI_HIP(hipMemcpy(hd.hb, hb.data(), hb.size() * sizeof(float), hipMemcpyHostToDevice));
+  }
+  // plans hold pointers to packed weights: drop those of this precision
+  for (auto it = h->plans.begin(); it != h->plans.end();) {
+    if (it->first[0] == precision) { free_plan(it->second.get()); it = h->plans.erase(it); }
+    else ++it;
+  }
+  h->finalized[precision] = true;
+  return BSMI_OK;
+}
+
+static int dry_plan(bsmi_unet* h, const int64_t in_shape[3], Plan& plan) {
+  int rc = check_shape_arg(in_shape);
+  if (rc) return rc;
+  Planner pl{h, BSMI_PREC_BF16, &plan, true};
+  return pl.run(in_shape);
+}
+
+int bsmi_unet_output_shape(bsmi_unet* h, const int64_t in_shape[3], int64_t out_shape[3]) {
+  if (!h || !in_shape || !out_shape) BSMI_FAIL(BSMI_ERR_INVALID, "null argument");
+  Plan plan;
+  int rc = dry_plan(h, in_shape, plan);
+  if (rc) return rc;
+  for (int d = 0; d < 3; ++d) out_shape[d] = plan.out_shape[d];
+  return BSMI_OK;
+}
+
+int bsmi_unet_flops(bsmi_unet* h, const int64_t in_shape[3], double* flops) {
+  if (!h || !in_shape || !flops) BSMI_FAIL(BSMI_ERR_INVALID, "null argument");
+  Plan plan;
+  int rc = dry_plan(h, in_shape, plan);
+  if (rc) return rc;
+  *flops = plan.flops;
+  return BSMI_OK;
+}
+
+int bsmi_unet_forward(bsmi_unet* h, int precision, const void* raw_dev, int raw_dtype,
+                      const int64_t in_shape[3], float* const* out_f32_dev,
+                      uint8_t* const* out_u8_dev, void* stream) {
+  if (!h || !raw_dev || !in_shape) BSMI_FAIL(BSMI_ERR_INVALID, "null argument");
+  if (precision != BSMI_PREC_F32 && precision != BSMI_PREC_BF16) BSMI_FAIL(BSMI_ERR_INVALID, "unknown precision %d", precision);
+  if (raw_dtype != BSMI_RAW_U8 && raw_dtype != BSMI_RAW_F32) BSMI_FAIL(BSMI_ERR_INVALID, "unknown raw dtype %d", raw_dtype);
+  if (!h->finalized[precision]) BSMI_FAIL(BSMI_ERR_STATE, "bsmi_unet_finalize(precision=%d) has not been called", precision);
+  int rc = check_shape_arg(in_shape);
+  if (rc) return rc;
+  BSMI_HIP(hipSetDevice(h->device));
+  hipStream_t s = (hipStream_t)stream;
+  const std::vector<int64_t> key = {precision, in_shape[0], in_shape[1], in_shape[2]};
+  auto it = h->plans.find(key);
+  if (it == h->plans.end()) {
+    std::unique_ptr<Plan> plan(new Plan);
+    Planner pl{h, precision, plan.get(), false};
+    rc = pl.run(in_shape);
+    if (rc) {
+      free_plan(plan.get());
+      return rc;
+    }
+    it = h->plans.emplace(key, std::move(plan)).first;
+  }
+  Plan& plan = *it->second;
+  for (const PlanStep& st : plan.steps) {
+    switch (st.type) {
+      case PlanStep::INPUT:
+        rc = launch_input_prep(precision, raw_dev, raw_dtype, st.out.ptr, st.out.C, st.out.Cpad,
+                               (size_t)st.out.D * st.out.H * st.out.W, s);
+        break;
+      case PlanStep::CONV:
+        rc = launch_conv_igemm(st.conv, precision, st.tile, s);
+        break;
+      case PlanStep::POOL:
+        rc = launch_maxpool(precision, st.in.ptr, st.out.ptr, st.in.D, st.in.H, st.in.W, st.in.Cpad,
+                            st.f[0], st.f[1], st.f[2], s);
+        break;
+      case PlanStep::UP:
+        rc = launch_upsample_crop(precision, st.in.ptr, st.out.ptr, st.in.D, st.in.H, st.in.W, st.in.Cpad,
+                                  st.out.D, st.out.H, st.out.W, st.f[0], st.f[1], st.f[2], st.o[0], st.o[1], st.o[2], s);
+        break;
+      case PlanStep::HEAD: {
+        const HeadSite& hd = h->heads[st.head];
+        float* of = out_f32_dev ? out_f32_dev[st.head] : nullptr;
+        uint8_t* ou = out_u8_dev ? out_u8_dev[st.head] : nullptr;
+        if (of || ou)
+          rc = launch_head(precision, st.in.ptr, st.in.Cpad, hd.cin, hd.cout, hd.hw, hd.hb, of, ou,
+                           (size_t)st.in.D * st.in.H * st.in.W, s);
+        break;
+      }
+    }
+    if (rc) return rc;
+  }
+  return BSMI_OK;
+}
+
+int bsmi_extract_block_reflect_u8(const uint8_t* vol_dev, const int64_t vol_shape[3], const int64_t offset[3],
+                                  const int64_t block_shape[3], uint8_t* block_dev, void* stream) {
+  if (!vol_dev || !vol_shape || !offset || !block_shape || !block_dev) BSMI_FAIL(BSMI_ERR_INVALID, "null argument");
+  for (int d = 0; d < 3; ++d)
+    if (vol_shape[d] <= 0 || block_shape[d] <= 0 || vol_shape[d] > (1 << 20) || block_shape[d] > (1 << 20))
+      BSMI_FAIL(BSMI_ERR_INVALID, "bad shape");
+  return launch_extract_block_reflect(vol_dev, vol_shape, offset, block_shape, block_dev, (hipStream_t)stream);
+}
+
+}  // extern "C"

@@ -1,0 +1,296 @@
+// Memory-bound U-Net operators around the implicit-GEMM conv (gfx950):
+// input normalisation, max-pool, trilinear upsample + crop, sigmoid heads, and the
+// reflect-padded block extraction of the predict worker.  All activation tensors are
+// channels-last [D][H][W][Cpad]; every thread moves one 16-byte channel vector.
+#include "unet_ops.h"
+
+namespace bsmi {
+
+typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ float bf16_to_f32(uint16_t h) { return __uint_as_float((uint32_t)h << 16); }
+__device__ __forceinline__ uint16_t f32_to_bf16(float f) {
+  __bf16 h = (__bf16)f;
+  return __builtin_bit_cast(uint16_t, h);
+}
+
+template <typename T>
+struct Vec;  // 16-byte vector of T, unpacked to floats
+template <>
+struct Vec<float> {
+  static constexpr int N = 4;
+  static __device__ __forceinline__ void unpack(u32x4_t v, float* f) {
+    f[0] = __uint_as_float(v.x); f[1] = __uint_as_float(v.y);
+    f[2] = __uint_as_float(v.z); f[3] = __uint_as_float(v.w);
+  }
+  static __device__ __forceinline__ u32x4_t pack(const float* f) {
+    u32x4_t v = {__float_as_uint(f[0]), __float_as_uint(f[1]), __float_as_uint(f[2]), __float_as_uint(f[3])};
+    return v;
+  }
+};
+template <>
+struct Vec<uint16_t> {
+  static constexpr int N = 8;
+  static __device__ __forceinline__ void unpack(u32x4_t v, float* f) {
+    const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      f[2 * i] = __uint_as_float(w[i] << 16);
+      f[2 * i + 1] = __uint_as_float(w[i] & 0xffff0000u);
+    }
+  }
+  static __device__ __forceinline__ u32x4_t pack(const float* f) {
+    uint32_t w[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) w[i] = (uint32_t)f32_to_bf16(f[2 * i]) | ((uint32_t)f32_to_bf16(f[2 * i + 1]) << 16);
+    u32x4_t v = {w[0], w[1], w[2], w[3]};
+    return v;
+  }
+};
+
+// ---- input: raw [Cin][D][H][W] (u8 or f32) -> [D][H][W][Cpad] ---------------------
+// u8 path restates gp.Normalize + IntensityScaleShift(raw, 2, -1)
+// (reference models/3d_affs/predict.py:147-149): x = u8 * (1/255) * 2 - 1 in f32.
+template <typename T, typename RAW>
+__global__ void input_prep_kernel(const RAW* raw, T* out, int cin, int cpad, size_t nvox) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t total = nvox * cpad;
+  if (i >= total) return;
+  const int c = (int)(i % cpad);
+  const size_t v = i / cpad;
+  float x = 0.f;
+  if (c < cin) {
+    if constexpr (sizeof(RAW) == 1) {
+      x = (float)raw[(size_t)c * nvox + v] * (1.0f / 255.0f);
+      x = x * 2.0f + -1.0f;
+    } else {
+      x = (float)raw[(size_t)c * nvox + v];
+    }
+  }
+  if constexpr (sizeof(T) == 4) out[i] = x; else out[i] = f32_to_bf16(x);
+}
+
+int launch_input_prep(int precision, const void* raw, int raw_dtype, void* out, int cin, int cpad,
+                      size_t nvox, hipStream_t s) {
+  const size_t total = nvox * cpad;
+  const int bs = 256;
+  const unsigned grid = (unsigned)ceil_div64((int64_t)total, bs);
+  if (precision == BSMI_PREC_F32) {
+    if (raw_dtype == BSMI_RAW_U8)
+      hipLaunchKernelGGL((input_prep_kernel<float, uint8_t>), dim3(grid), dim3(bs), 0, s, (const uint8_t*)raw, (float*)out, cin, cpad, nvox);
+    else
+      hipLaunchKernelGGL((input_prep_kernel<float, float>), dim3(grid), dim3(bs), 0, s, (const float*)raw, (float*)out, cin, cpad, nvox);
+  } else {
+    if (raw_dtype == BSMI_RAW_U8)
+      hipLaunchKernelGGL((input_prep_kernel<uint16_t, uint8_t>), dim3(grid), dim3(bs), 0, s, (const uint8_t*)raw, (uint16_t*)out, cin, cpad, nvox);
+    else
+      hipLaunchKernelGGL((input_prep_kernel<uint16_t, float>), dim3(grid), dim3(bs), 0, s, (const float*)raw, (uint16_t*)out, cin, cpad, nvox);
+  }
+  BSMI_HIP(hipGetLastError());
+  return BSMI_OK;
+}
+
+// ---- max-pool (reference unet.py:79-106 Downsample, MaxPool3d kernel=stride=factor) ---
+template <typename T>
+__global__ void maxpool_kernel(const T* in, T* out, int H, int W, int C, int Do, int Ho, int Wo,
+                               int fz, int fy, int fx) {
+  constexpr int N = Vec<T>::N;
+  const int cv = C / N;
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t total = (size_t)Do * Ho * Wo * cv;
+  if (i >= total) return;
+  const int c = (int)(i % cv);
+  size_t v = i / cv;
+  const int x = (int)(v % Wo); v /= Wo;
+  const int y = (int)(v % Ho);
+  const int z = (int)(v / Ho);
+  float m[N];
+#pragma unroll
+  for (int k = 0; k < N; ++k) m[k] = -INFINITY;
+  for (int dz = 0; dz < fz; ++dz)
+    for (int dy = 0; dy < fy; ++dy)
+      for (int dx = 0; dx < fx; ++dx) {
+        const size_t src = ((size_t)((z * fz + dz) * H + (y * fy + dy)) * W + (x * fx + dx)) * C + c * N;
+        float f[N];
+        Vec<T>::unpack(*(const u32x4_t*)(in + src), f);
+#pragma unroll
+        for (int k = 0; k < N; ++k) m[k] = fmaxf(m[k], f[k]);
+      }
+  *(u32x4_t*)(out + i * N) = Vec<T>::pack(m);
+}
+
+int launch_maxpool(int precision, const void* in, void* out, int D, int H, int W, int C, int fz,
+                   int fy, int fx, hipStream_t s) {
+  const int Do = D / fz, Ho = H / fy, Wo = W / fx;
+  const int bs = 256;
+  if (precision == BSMI_PREC_F32) {
+    const size_t total = (size_t)Do * Ho * Wo * (C / 4);
+    hipLaunchKernelGGL(maxpool_kernel<float>, dim3((unsigned)ceil_div64(total, bs)), dim3(bs), 0, s,
+                       (const float*)in, (float*)out, H, W, C, Do, Ho, Wo, fz, fy, fx);
+  } else {
+    const size_t total = (size_t)Do * Ho * Wo * (C / 8);
+    hipLaunchKernelGGL(maxpool_kernel<uint16_t>, dim3((unsigned)ceil_div64(total, bs)), dim3(bs), 0, s,
+                       (const uint16_t*)in, (uint16_t*)out, H, W, C, Do, Ho, Wo, fz, fy, fx);
+  }
+  BSMI_HIP(hipGetLastError());
+  return BSMI_OK;
+}
+
+// ---- trilinear upsample (align_corners=False) fused with the centre crop -------------
+// reference unet.py:143 torch.nn.Upsample(scale_factor, mode="trilinear") followed by
+// crop_to_factor (unet.py:147-201).  out voxel (z,y,x) = upsampled voxel (z+oz, y+oy, x+ox).
+// Source index rule of torch (area_pixel_compute_source_index, align_corners=False):
+//   src = (dst + 0.5) / f - 0.5, clamped at 0; i0 = floor(src), i1 = min(i0+1, n-1),
+//   w1 = src - i0, w0 = 1 - w1.
+__device__ __forceinline__ void lin_src(int dst, int f, int n, int& i0, int& i1, float& w0, float& w1) {
+  float src = ((float)dst + 0.5f) * (1.0f / (float)f) - 0.5f;
+  src = src < 0.f ? 0.f : src;
+  i0 = (int)src;
+  i0 = i0 < n - 1 ? i0 : n - 1;
+  i1 = i0 + 1 < n ? i0 + 1 : n - 1;
+  w1 = src - (float)i0;
+  w1 = w1 < 0.f ? 0.f : (w1 > 1.f ? 1.f : w1);
+  w0 = 1.f - w1;
+}
+
+template <typename T>
+__global__ void upsample_crop_kernel(const T* in, T* out, int D, int H, int W, int C, int Do, int Ho,
+                                     int Wo, int fz, int fy, int fx, int oz, int oy, int ox) {
+  constexpr int N = Vec<T>::N;
+  const int cv = C / N;
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t total = (size_t)Do * Ho * Wo * cv;
+  if (i >= total) return;
+  const int c = (int)(i % cv);
+  size_t v = i / cv;
+  const int x = (int)(v % Wo); v /= Wo;
+  const int y = (int)(v % Ho);
+  const int z = (int)(v / Ho);
+  int z0, z1, y0, y1, x0, x1;
+  float wz0, wz1, wy0, wy1, wx0, wx1;
+  lin_src(z + oz, fz, D, z0, z1, wz0, wz1);
+  lin_src(y + oy, fy, H, y0, y1, wy0, wy1);
+  lin_src(x + ox, fx, W, x0, x1, wx0, wx1);
+  auto ld = [&](int zz, int yy, int xx, float* f) {
+    Vec<T>::unpack(*(const u32x4_t*)(in + ((size_t)(zz * H + yy) * W + xx) * C + c * N), f);
+  };
+  float a[N], b[N], r[N], acc[N];
+  auto plane = [&](int zz, float* o) {
+    float p[N], q[N];
+    ld(zz, y0, x0, a); ld(zz, y0, x1, b);
+#pragma unroll
+    for (int k = 0; k < N; ++k) p[k] = wx0 * a[k] + wx1 * b[k];
+    ld(zz, y1, x0, a); ld(zz, y1, x1, b);
+#pragma unroll
+    for (int k = 0; k < N; ++k) q[k] = wx0 * a[k] + wx1 * b[k];
+#pragma unroll
+    for (int k = 0; k < N; ++k) o[k] = wy0 * p[k] + wy1 * q[k];
+  };
+  plane(z0, r);
+  if (z1 != z0) {
+    float r1[N];
+    plane(z1, r1);
+#pragma unroll
+    for (int k = 0; k < N; ++k) acc[k] = wz0 * r[k] + wz1 * r1[k];
+  } else {
+#pragma unroll
+    for (int k = 0; k < N; ++k) acc[k] = wz0 * r[k] + wz1 * r[k];
+  }
+  *(u32x4_t*)(out + i * N) = Vec<T>::pack(acc);
+}
+
+int launch_upsample_crop(int precision, const void* in, void* out, int D, int H, int W, int C, int Do,
+                         int Ho, int Wo, int fz, int fy, int fx, int oz, int oy, int ox, hipStream_t s) {
+  const int bs = 256;
+  if (precision == BSMI_PREC_F32) {
+    const size_t total = (size_t)Do * Ho * Wo * (C / 4);
+    hipLaunchKernelGGL(upsample_crop_kernel<float>, dim3((unsigned)ceil_div64(total, bs)), dim3(bs), 0, s,
+                       (const float*)in, (float*)out, D, H, W, C, Do, Ho, Wo, fz, fy, fx, oz, oy, ox);
+  } else {
+    const size_t total = (size_t)Do * Ho * Wo * (C / 8);
+    hipLaunchKernelGGL(upsample_crop_kernel<uint16_t>, dim3((unsigned)ceil_div64(total, bs)), dim3(bs), 0, s,
+                       (const uint16_t*)in, (uint16_t*)out, D, H, W, C, Do, Ho, Wo, fz, fy, fx, oz, oy, ox);
+  }
+  BSMI_HIP(hipGetLastError());
+  return BSMI_OK;
+}
+
+// ---- sigmoid head: ConvPass(C, dims, [[1,1,1]], "Sigmoid") ----------------------------
+// reference model.py:54-56 + unet.py:63-76: sigmoid((W1 z + b1) + (W2 z + b2)); f32 math.
+// hw: [cout][2][cin] (conv_pass.0 then residual.0), hb: [cout][2].
+template <typename T>
+__global__ void head_kernel(const T* z, int cpad, int cin, int cout, const float* hw, const float* hb,
+                            float* out_f32, uint8_t* out_u8, size_t nvox) {
+  extern __shared__ float sw[];
+  float* sb = sw + cout * 2 * cin;
+  for (int i = threadIdx.x; i < cout * 2 * cin; i += blockDim.x) sw[i] = hw[i];
+  for (int i = threadIdx.x; i < cout * 2; i += blockDim.x) sb[i] = hb[i];
+  __syncthreads();
+  const size_t v = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (v >= nvox) return;
+  float f[64];
+  constexpr int N = Vec<T>::N;
+  for (int c = 0; c < cpad && c < 64; c += N) Vec<T>::unpack(*(const u32x4_t*)(z + v * cpad + c), f + c);
+  for (int o = 0; o < cout; ++o) {
+    float s1 = 0.f, s2 = 0.f;
+    for (int c = 0; c < cin; ++c) {
+      s1 = fmaf(sw[(o * 2 + 0) * cin + c], f[c], s1);
+      s2 = fmaf(sw[(o * 2 + 1) * cin + c], f[c], s2);
+    }
+    const float y = (s1 + sb[o * 2]) + (s2 + sb[o * 2 + 1]);
+    const float sg = 1.0f / (1.0f + expf(-y));
+    if (out_f32) out_f32[(size_t)o * nvox + v] = sg;
+    // IntensityScaleShift(pred, 255, 0) then the uint8 dataset cast (truncation)
+    if (out_u8) out_u8[(size_t)o * nvox + v] = (uint8_t)(sg * 255.0f);
+  }
+}
+
+int launch_head(int precision, const void* z, int cpad, int cin, int cout, const float* hw,
+                const float* hb, float* out_f32, uint8_t* out_u8, size_t nvox, hipStream_t s) {
+  if (cpad > 64) BSMI_FAIL(BSMI_ERR_INVALID, "head kernel supports at most 64 input channels (got %d)", cpad);
+  const int bs = 256;
+  const size_t smem = (size_t)(cout * 2 * cin + cout * 2) * sizeof(float);
+  const unsigned grid = (unsigned)ceil_div64((int64_t)nvox, bs);
+  if (precision == BSMI_PREC_F32)
+    hipLaunchKernelGGL(head_kernel<float>, dim3(grid), dim3(bs), smem, s, (const float*)z, cpad, cin, cout, hw, hb, out_f32, out_u8, nvox);
+  else
+    hipLaunchKernelGGL(head_kernel<uint16_t>, dim3(grid), dim3(bs), smem, s, (const uint16_t*)z, cpad, cin, cout, hw, hb, out_f32, out_u8, nvox);
+  BSMI_HIP(hipGetLastError());
+  return BSMI_OK;
+}
+
+// ---- reflect-padded block read ---------------------------------------------------------
+__device__ __forceinline__ int reflect_idx(int i, int n) {
+  // numpy.pad mode='reflect' (edge not repeated), iterated for offsets larger than n
+  if (n == 1) return 0;
+  const int p = 2 * (n - 1);
+  i %= p;
+  if (i < 0) i += p;
+  return i < n ? i : p - i;
+}
+
+__global__ void extract_block_reflect_kernel(const uint8_t* vol, int VD, int VH, int VW, int oz, int oy,
+                                             int ox, int BD, int BH, int BW, uint8_t* block) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t total = (size_t)BD * BH * BW;
+  if (i >= total) return;
+  const int x = (int)(i % BW);
+  const size_t v = i / BW;
+  const int y = (int)(v % BH);
+  const int z = (int)(v / BH);
+  const int sz = reflect_idx(z + oz, VD), sy = reflect_idx(y + oy, VH), sx = reflect_idx(x + ox, VW);
+  block[i] = vol[((size_t)sz * VH + sy) * VW + sx];
+}
+
+int launch_extract_block_reflect(const uint8_t* vol, const int64_t vs[3], const int64_t off[3],
+                                 const int64_t bs3[3], uint8_t* block, hipStream_t s) {
+  const size_t total = (size_t)bs3[0] * bs3[1] * bs3[2];
+  const int bs = 256;
+  hipLaunchKernelGGL(extract_block_reflect_kernel, dim3((unsigned)ceil_div64((int64_t)total, bs)), dim3(bs), 0, s,
+                     vol, (int)vs[0], (int)vs[1], (int)vs[2], (int)off[0], (int)off[1], (int)off[2],
+                     (int)bs3[0], (int)bs3[1], (int)bs3[2], block);
+  BSMI_HIP(hipGetLastError());
+  return BSMI_OK;
+}
+
+}  // namespace bsmi

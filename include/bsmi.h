@@ -1,0 +1,138 @@
+/* bsmi.h -- C ABI of libbsmi.so, the MI355X (gfx950) engine behind the
+ * `bs predict` / `bs segment --ws` hot path of ucsdmanorlab/bootstrapper.
+ *
+ * Plain pointers and sizes only; no torch / numpy types.  All functions return
+ * 0 on success and a negative code on failure; the message for the calling
+ * thread is available from bsmi_last_error().  No exception crosses this
+ * boundary.  Pointers suffixed _dev are device (HBM) pointers on the handle's
+ * device, _host are host pointers.  `stream` is a hipStream_t passed as void*
+ * (NULL = the null stream); calls are asynchronous on it unless stated.
+ *
+ * Every entry point names the reference interface it replaces (paths relative
+ * to /root/reference/bootstrapper).
+ */
+#ifndef BSMI_H
+#define BSMI_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define BSMI_MAX_LEVELS 8
+#define BSMI_MAX_CONVS 4
+#define BSMI_MAX_HEADS 4
+#define BSMI_NAME_LEN 32
+
+#define BSMI_OK 0
+#define BSMI_ERR_INVALID (-1)   /* bad argument / shape the network cannot take */
+#define BSMI_ERR_HIP (-2)       /* HIP runtime error                            */
+#define BSMI_ERR_STATE (-3)     /* call order (e.g. forward before finalize)    */
+#define BSMI_ERR_MISSING (-4)   /* missing / unexpected state-dict key          */
+#define BSMI_ERR_OVERFLOW (-5)  /* a fixed-capacity device structure overflowed */
+
+/* arithmetic type of the U-Net contraction */
+#define BSMI_PREC_F32 0   /* f32 MFMA (exact f32 products, f32 accumulate): parity mode */
+#define BSMI_PREC_BF16 1  /* bf16 MFMA operands, f32 accumulate: throughput mode        */
+
+/* dtype of the raw input handed to bsmi_unet_forward */
+#define BSMI_RAW_U8 0     /* uint8 [Cin][D][H][W]; normalised on device as u8/255*2-1    */
+#define BSMI_RAW_F32 1    /* float [Cin][D][H][W]; already normalised                    */
+
+const char *bsmi_last_error(void);
+int bsmi_version(void);
+
+/* ------------------------------------------------------------------------ */
+/* 3-D U-Net (reference: models/3d_affs/unet.py:226-478 UNet, :7-76 ConvPass,
+ * :79-106 Downsample, :109-223 Upsample; models/3d_affs/model.py:28-64 Model;
+ * models/3d_mtlsd/model.py:28-68).                                            */
+
+/* Mirrors the keys of net_config.json that Model() consumes
+ * (models/3d_affs/model.py:10-25, net_config.json) plus the head list the
+ * Model class hard-codes (model.py:54-56; mtlsd model.py:54-59).             */
+typedef struct bsmi_unet_config {
+  int32_t in_channels;
+  int32_t num_fmaps;
+  int32_t fmap_inc_factor;
+  int32_t num_levels; /* len(downsample_factors) + 1 */
+  int32_t downsample_factors[BSMI_MAX_LEVELS][3];
+  int32_t n_convs_down[BSMI_MAX_LEVELS];
+  int32_t kernel_size_down[BSMI_MAX_LEVELS][BSMI_MAX_CONVS][3];
+  int32_t n_convs_up[BSMI_MAX_LEVELS];
+  int32_t kernel_size_up[BSMI_MAX_LEVELS][BSMI_MAX_CONVS][3];
+  int32_t num_heads;
+  char head_name[BSMI_MAX_HEADS][BSMI_NAME_LEN]; /* state-dict prefix, forward() return order */
+  int32_t head_dims[BSMI_MAX_HEADS];
+} bsmi_unet_config;
+
+typedef struct bsmi_unet bsmi_unet;
+
+/* replaces Model.__init__ (model.py:30-56) on `device` */
+int bsmi_unet_create(const bsmi_unet_config *cfg, int device, bsmi_unet **out);
+int bsmi_unet_destroy(bsmi_unet *h);
+
+/* replaces Model.load_state_dict (models/3d_affs/predict.py:103-107): one call per
+ * state-dict entry, `key` WITHOUT the Lightning "model." prefix, data OIDHW fp32. */
+int bsmi_unet_load_weight(bsmi_unet *h, const char *key, const float *data_host,
+                          const int64_t *shape, int ndim);
+/* strict check (every expected key loaded) + pack/upload weights for `precision`;
+ * may be called once per precision. */
+int bsmi_unet_finalize(bsmi_unet *h, int precision);
+
+/* valid-conv shape arithmetic (unet.py:96-104 divisibility, :147-201 crop_to_factor) */
+int bsmi_unet_output_shape(bsmi_unet *h, const int64_t in_shape[3], int64_t out_shape[3]);
+/* algorithmic multiply-add count x2 for one forward at in_shape (SURVEY 8a table:
+ * residual 1x1x1 counted on the cropped extent) */
+int bsmi_unet_flops(bsmi_unet *h, const int64_t in_shape[3], double *flops);
+
+/* replaces Model.forward (model.py:58-64) + the predict worker's arithmetic around
+ * it (models/3d_affs/predict.py:145-154): raw -> heads.  For each head i either
+ * output pointer may be NULL:
+ *   out_f32_dev[i]: float  [head_dims[i]][d][h][w]  sigmoid outputs
+ *   out_u8_dev[i] : uint8  [head_dims[i]][d][h][w]  (uint8)(sigmoid*255), truncation
+ * Device workspace for the given in_shape is allocated on first use and cached. */
+int bsmi_unet_forward(bsmi_unet *h, int precision, const void *raw_dev, int raw_dtype,
+                      const int64_t in_shape[3], float *const *out_f32_dev,
+                      uint8_t *const *out_u8_dev, void *stream);
+
+/* Reflect-padded block extraction (gp.Pad(raw, None, mode="reflect") +
+ * ArraySource ROI read, models/3d_affs/predict.py:145-148): copies the window
+ * [offset, offset+block_shape) of vol (uint8 [D][H][W]) into block, mirroring
+ * coordinates outside the volume (numpy 'reflect': edge voxel not repeated). */
+int bsmi_extract_block_reflect_u8(const uint8_t *vol_dev, const int64_t vol_shape[3],
+                                  const int64_t offset[3], const int64_t block_shape[3],
+                                  uint8_t *block_dev, void *stream);
+
+/* ------------------------------------------------------------------------ */
+/* Seeded watershed fragments (reference: post/ws.py:38-112
+ * watershed_from_affinities, :8-35 watershed_from_boundary_distance).
+ * affs_dev: uint8 [3][D][H][W] (z,y,x nearest-neighbour affinities).
+ * frags_dev: uint64 [D][H][W].  max_id_dev: uint64[1] (ws.py return value n+id_offset).
+ * Only fragments_in_xy != 0 and max_affinity_value = 255 are implemented.        */
+typedef struct bsmi_seg bsmi_seg;
+int bsmi_seg_create(int device, const int64_t max_shape[3], bsmi_seg **out);
+int bsmi_seg_destroy(bsmi_seg *h);
+
+int bsmi_ws_fragments_u8(bsmi_seg *h, const uint8_t *affs_dev, const int64_t shape[3],
+                         int fragments_in_xy, int min_seed_distance, uint64_t *frags_dev,
+                         uint64_t *max_id_dev, void *stream);
+
+/* Mean-affinity hierarchical agglomeration (reference call site
+ * post/watershed.py:333-338 waterz.agglomerate(affs, thresholds, fragments,
+ * "OneMinus<MeanAffinity<RegionGraphType, ScoreValue>>"); algorithm restated in
+ * oracle/seg_ref.c).  For each threshold t (ascending) writes
+ * segs_dev + t*D*H*W: uint64 [D][H][W].  frags_dev is not modified.               */
+int bsmi_agglomerate_mean_u8(bsmi_seg *h, const uint8_t *affs_dev, const uint64_t *frags_dev,
+                             const int64_t shape[3], const float *thresholds_host,
+                             int n_thresholds, uint64_t *segs_dev, void *stream);
+
+/* status of the last asynchronous seg call on this handle (reads a device flag;
+ * synchronises `stream`): BSMI_OK or BSMI_ERR_OVERFLOW */
+int bsmi_seg_status(bsmi_seg *h, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* BSMI_H */
