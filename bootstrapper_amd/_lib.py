@@ -53,6 +53,10 @@ def _load():
         "bsmi_unet_output_shape": (i32, [p, i64p, i64p]),
         "bsmi_unet_flops": (i32, [p, i64p, C.POINTER(C.c_double)]),
         "bsmi_unet_forward": (i32, [p, i32, vp, i32, i64p, C.POINTER(vp), C.POINTER(vp), vp]),
+        "bsmi_unet_profile_enable": (i32, [p, i32]),
+        "bsmi_unet_profile_read": (i32, [p, i32, C.POINTER(i32), C.POINTER(C.c_int32), C.POINTER(C.c_double),
+                                         C.POINTER(C.c_double)]),
+        "bsmi_unet_profile_totals": (i32, [p, C.POINTER(C.c_double), C.POINTER(C.c_double), i64p, i32]),
         "bsmi_extract_block_reflect_u8": (i32, [vp, i64p, i64p, i64p, vp, vp]),
         "bsmi_seg_create": (i32, [i32, i64p, C.POINTER(p)]),
         "bsmi_seg_destroy": (i32, [p]),

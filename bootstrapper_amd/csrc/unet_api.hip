@@ -92,14 +92,19 @@ struct PlanStep {
   TDesc in, out;
   int f[3], o[3];
   int head = 0;
+  double flops = 0;  // algorithmic FLOPs of this launch
 };
 
 struct Plan {
+  std::vector<float> last_ms;  // per-step durations of the last harvested forward
+  bool pending = false;        // events recorded but not yet harvested
   std::vector<void*> allocs;
   std::vector<PlanStep> steps;
   int64_t out_shape[3] = {0, 0, 0};
   double flops = 0;
   size_t bytes = 0;
+  std::vector<hipEvent_t> events;  // 2 per step, created on demand (profiling)
+  bool profiled = false;           // last forward recorded events
 };
 
 }  // namespace bsmi
@@ -115,6 +120,10 @@ struct bsmi_unet {
   int crop_factor[BSMI_MAX_LEVELS][3];
   std::map<std::string, HostWeight> weights;
   bool finalized[2] = {false, false};
+  bool profiling = false;
+  Plan* last_plan = nullptr;
+  double prof_ms[5] = {0, 0, 0, 0, 0}, prof_flops[5] = {0, 0, 0, 0, 0};
+  int64_t prof_launches[5] = {0, 0, 0, 0, 0};
   std::map<std::vector<int64_t>, std::unique_ptr<Plan>> plans;  // key: prec, D, H, W
 };
 
@@ -333,6 +342,7 @@ struct Planner {
         a.M = o.D * o.H * o.W;
         a.Npad = pc.Npad;
         a.relu = 1;  // trunk activation is ReLU (model.py passes activation default "ReLU")
+        st.flops = 2.0 * M * p.cout * kreal;
         plan->steps.push_back(st);
       }
       cur = o;
@@ -437,6 +447,7 @@ struct Planner {
         st.type = PlanStep::HEAD;
         st.in = z;
         st.head = (int)hd;
+        st.flops = 2.0 * 2.0 * (double)z.D * z.H * z.W * h->heads[hd].cin * h->heads[hd].cout;
         plan->steps.push_back(st);
       }
     }
@@ -447,6 +458,27 @@ struct Planner {
 static void free_plan(Plan* p) {
   for (void* a : p->allocs) (void)hipFree(a);
   p->allocs.clear();
+  for (hipEvent_t e : p->events) (void)hipEventDestroy(e);
+  p->events.clear();
+}
+
+// Wait for the events of the last profiled forward of `plan` and fold them into the totals.
+static int harvest(bsmi_unet* h, Plan* plan) {
+  if (!plan || !plan->pending) return BSMI_OK;
+  const size_t n = plan->steps.size();
+  plan->last_ms.assign(n, 0.f);
+  BSMI_HIP(hipEventSynchronize(plan->events[2 * n - 1]));
+  for (size_t i = 0; i < n; ++i) {
+    float t = 0.f;
+    BSMI_HIP(hipEventElapsedTime(&t, plan->events[2 * i], plan->events[2 * i + 1]));
+    plan->last_ms[i] = t;
+    const int ty = (int)plan->steps[i].type;
+    h->prof_ms[ty] += t;
+    h->prof_flops[ty] += plan->steps[i].flops;
+    h->prof_launches[ty] += 1;
+  }
+  plan->pending = false;
+  return BSMI_OK;
 }
 
 static int check_shape_arg(const int64_t s[3]) {
@@ -622,6 +654,7 @@ int bsmi_unet_finalize(bsmi_unet* h, int precision) {
     BSMI_HIP(hipMemcpy(hd.hb, hb.data(), hb.size() * sizeof(float), hipMemcpyHostToDevice));
   }
   // plans hold pointers to packed weights: drop those of this precision
+  h->last_plan = nullptr;
   for (auto it = h->plans.begin(); it != h->plans.end();) {
     if (it->first[0] == precision) { free_plan(it->second.get()); it = h->plans.erase(it); }
     else ++it;
@@ -679,7 +712,21 @@ int bsmi_unet_forward(bsmi_unet* h, int precision, const void* raw_dev, int raw_
     it = h->plans.emplace(key, std::move(plan)).first;
   }
   Plan& plan = *it->second;
+  if (h->profiling) {
+    rc = harvest(h, &plan);  // previous forward on this plan must be read before its events are reused
+    if (rc) return rc;
+  }
+  h->last_plan = &plan;
+  plan.profiled = h->profiling;
+  plan.pending = h->profiling;
+  if (h->profiling && plan.events.size() != 2 * plan.steps.size()) {
+    for (hipEvent_t e : plan.events) (void)hipEventDestroy(e);
+    plan.events.assign(2 * plan.steps.size(), nullptr);
+    for (auto& e : plan.events) BSMI_HIP(hipEventCreate(&e));
+  }
+  size_t step_idx = 0;
   for (const PlanStep& st : plan.steps) {
+    if (h->profiling) BSMI_HIP(hipEventRecord(plan.events[2 * step_idx], s));
     switch (st.type) {
       case PlanStep::INPUT:
         rc = launch_input_prep(precision, raw_dev, raw_dtype, st.out.ptr, st.out.C, st.out.Cpad,
@@ -707,6 +754,44 @@ int bsmi_unet_forward(bsmi_unet* h, int precision, const void* raw_dev, int raw_
       }
     }
     if (rc) return rc;
+    if (h->profiling) BSMI_HIP(hipEventRecord(plan.events[2 * step_idx + 1], s));
+    ++step_idx;
+  }
+  return BSMI_OK;
+}
+
+int bsmi_unet_profile_enable(bsmi_unet* h, int on) {
+  if (!h) BSMI_FAIL(BSMI_ERR_INVALID, "null handle");
+  h->profiling = on != 0;
+  return BSMI_OK;
+}
+
+int bsmi_unet_profile_read(bsmi_unet* h, int max_n, int* n, int32_t* types, double* ms, double* flops) {
+  if (!h || !n) BSMI_FAIL(BSMI_ERR_INVALID, "null argument");
+  Plan* plan = h->last_plan;
+  if (!plan || !plan->profiled) BSMI_FAIL(BSMI_ERR_STATE, "no profiled forward to read");
+  int rc = harvest(h, plan);
+  if (rc) return rc;
+  const int cnt = (int)plan->steps.size();
+  *n = cnt;
+  for (int i = 0; i < cnt && i < max_n; ++i) {
+    if (types) types[i] = (int32_t)plan->steps[i].type;
+    if (ms) ms[i] = plan->last_ms[i];
+    if (flops) flops[i] = plan->steps[i].flops;
+  }
+  return BSMI_OK;
+}
+
+int bsmi_unet_profile_totals(bsmi_unet* h, double ms_by_type[5], double flops_by_type[5],
+                             int64_t launches_by_type[5], int reset) {
+  if (!h) BSMI_FAIL(BSMI_ERR_INVALID, "null handle");
+  int rc = harvest(h, h->last_plan);
+  if (rc) return rc;
+  for (int i = 0; i < 5; ++i) {
+    if (ms_by_type) ms_by_type[i] = h->prof_ms[i];
+    if (flops_by_type) flops_by_type[i] = h->prof_flops[i];
+    if (launches_by_type) launches_by_type[i] = h->prof_launches[i];
+    if (reset) { h->prof_ms[i] = 0; h->prof_flops[i] = 0; h->prof_launches[i] = 0; }
   }
   return BSMI_OK;
 }

@@ -149,6 +149,31 @@ class Model:
         check(lib.bsmi_unet_flops(self._h, _lib.i64x3(in_shape), C.byref(f)))
         return f.value
 
+    # -- profiling ---------------------------------------------------------------------
+    def profile(self, on=True):
+        check(lib.bsmi_unet_profile_enable(self._h, 1 if on else 0))
+        return self
+
+    def read_profile(self):
+        """[(type, ms, flops)] per launch of the last forward (types: 0 input, 1 conv,
+        2 pool, 3 upsample, 4 head).  Synchronises on the recorded events."""
+        n = C.c_int()
+        cap = 256
+        types = (C.c_int32 * cap)()
+        ms = (C.c_double * cap)()
+        fl = (C.c_double * cap)()
+        check(lib.bsmi_unet_profile_read(self._h, cap, C.byref(n), types, ms, fl))
+        return [(types[i], ms[i], fl[i]) for i in range(min(n.value, cap))]
+
+    def profile_totals(self, reset=False):
+        """{type_name: (ms, flops, launches)} summed over profiled forwards since the last reset."""
+        ms = (C.c_double * 5)()
+        fl = (C.c_double * 5)()
+        cnt = (C.c_int64 * 5)()
+        check(lib.bsmi_unet_profile_totals(self._h, ms, fl, cnt, 1 if reset else 0))
+        names = ["input", "conv", "pool", "upsample", "head"]
+        return {names[i]: (ms[i], fl[i], cnt[i]) for i in range(5)}
+
     # -- forward -----------------------------------------------------------------------
     def _run(self, raw, raw_dtype, in_shape, want_f32, want_u8):
         dev = torch.device("cuda", self.device)

@@ -97,6 +97,18 @@ int bsmi_unet_forward(bsmi_unet *h, int precision, const void *raw_dev, int raw_
                       const int64_t in_shape[3], float *const *out_f32_dev,
                       uint8_t *const *out_u8_dev, void *stream);
 
+/* Per-launch timing of the forward pass with HIP events recorded on the caller's stream
+ * (bench.py's roofline leg).  After enabling, every bsmi_unet_forward brackets each launch
+ * with events; bsmi_unet_profile_read synchronises on them and returns, for the last
+ * forward, the launch type (0 input, 1 implicit-GEMM conv, 2 max-pool, 3 upsample+crop,
+ * 4 head), its duration in ms and its algorithmic FLOPs. */
+int bsmi_unet_profile_enable(bsmi_unet *h, int on);
+int bsmi_unet_profile_read(bsmi_unet *h, int max_n, int *n, int32_t *types, double *ms,
+                           double *flops);
+/* totals over every profiled forward since the last reset, indexed by launch type */
+int bsmi_unet_profile_totals(bsmi_unet *h, double ms_by_type[5], double flops_by_type[5],
+                             int64_t launches_by_type[5], int reset);
+
 /* Reflect-padded block extraction (gp.Pad(raw, None, mode="reflect") +
  * ArraySource ROI read, models/3d_affs/predict.py:145-148): copies the window
  * [offset, offset+block_shape) of vol (uint8 [D][H][W]) into block, mirroring
