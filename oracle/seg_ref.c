@@ -1,0 +1,467 @@
+/* ORACLE (test infrastructure, not product code): plain-C CPU restatement of the
+ * segmentation half of the hot path.  Only tests/, __graft_entry__.smoke() and
+ * bench.py's cpu_baseline leg may load this; bootstrapper_amd/ never does.
+ *
+ * Restated reference code (paths relative to /root/reference/bootstrapper):
+ *   post/ws.py:8-35    watershed_from_boundary_distance
+ *   post/ws.py:38-112  watershed_from_affinities
+ *   post/watershed.py:333-338 waterz.agglomerate(affs, thresholds, fragments,
+ *                      "OneMinus<MeanAffinity<RegionGraphType, ScoreValue>>")
+ * and the third-party routines those call, restated from their observed behaviour
+ * (SURVEY.md Appendix A): scipy.ndimage distance_transform_edt / maximum_filter / label
+ * and skimage.segmentation.watershed (0.18.3).
+ *
+ * PINNING: seg_ws_fragments_u8 is pinned bit-for-bit by tests/golden/ws_cases.npz, which
+ * tools/gen_goldens_ws.py produced by running the reference post/ws.py itself.
+ * seg_agglomerate_mean_u8 restates waterz (ZettaAI/waterz, unpinned git dependency of the
+ * reference, pyproject.toml:52-56), whose source is NOT in /root/reference and which is not
+ * installed here: **parity unpinned** for that function.  Its queue order is specified
+ * here (total order (score, initial edge key)) and the HIP kernels are held to this file.
+ *
+ * Integer formulation used throughout (exactly equivalent to the float one for uint8
+ * affinities): xy foreground mask a_y + a_x >= 256; 3-D mask
+ * a_z + a_y + a_x >= 383; distances are kept as exact squared integers d2 (the reference's
+ * float64 sqrt and max(D) - D are strictly monotone in d2 for d2 < 2^24).
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+#define BIG 0x3fffffff
+
+/* ---- exact squared EDT -------------------------------------------------------------- */
+/* 1-D lower envelope pass (Felzenszwalb & Huttenlocher) over the finite samples of
+ * f[0..n); BIG marks "no site".  Exact for integer inputs of this size: an intersection
+ * abscissa is either an integer (both parabolas tie there) or at least 1/(2n) away from one. */
+static void dt1d(const int64_t *f, int n, int64_t *d, int *v, double *z) {
+  int k = -1;
+  for (int q = 0; q < n; q++) {
+    if (f[q] >= BIG) continue;
+    if (k < 0) { k = 0; v[0] = q; z[0] = -1e30; z[1] = 1e30; continue; }
+    double s;
+    for (;;) {
+      s = ((double)(f[q] + (int64_t)q * q) - (double)(f[v[k]] + (int64_t)v[k] * v[k])) / (2.0 * (q - v[k]));
+      if (s <= z[k]) k--; else break; /* z[0] = -inf keeps k >= 0 */
+    }
+    k++;
+    v[k] = q;
+    z[k] = s;
+    z[k + 1] = 1e30;
+  }
+  if (k < 0) { for (int q = 0; q < n; q++) d[q] = BIG; return; }
+  k = 0;
+  for (int q = 0; q < n; q++) {
+    while (z[k + 1] < q) k++;
+    const int64_t dq = q - v[k];
+    d[q] = dq * dq + f[v[k]];
+  }
+}
+
+static void edt_axis(int64_t *d2, int n0, int n1, int n2, int axis) {
+  /* in-place min over the given axis of d2[..j..] + (i-j)^2 ; array dims (n0,n1,n2) */
+  const int dims[3] = {n0, n1, n2};
+  const int64_t strides[3] = {(int64_t)n1 * n2, n2, 1};
+  const int n = dims[axis];
+  int64_t *line = (int64_t *)malloc(sizeof(int64_t) * n);
+  int64_t *outl = (int64_t *)malloc(sizeof(int64_t) * n);
+  int *v = (int *)malloc(sizeof(int) * (n + 1));
+  double *z = (double *)malloc(sizeof(double) * (n + 2));
+  const int a1 = (axis + 1) % 3, a2 = (axis + 2) % 3;
+  for (int i = 0; i < dims[a1]; i++)
+    for (int j = 0; j < dims[a2]; j++) {
+      int64_t base = i * strides[a1] + j * strides[a2];
+      for (int q = 0; q < n; q++) line[q] = d2[base + q * strides[axis]];
+      dt1d(line, n, outl, v, z);
+      for (int q = 0; q < n; q++) d2[base + q * strides[axis]] = outl[q];
+    }
+  free(line); free(outl); free(v); free(z);
+}
+
+/* scipy.ndimage.distance_transform_edt(mask) squared.  With no background voxel at all,
+ * scipy behaves as if the only background voxel sat at index (-1, 0[, 0]) of the array
+ * (measured, scipy 1.7.1 and 1.15.3): d2 = (i0+1)^2 + i1^2 (+ i2^2). */
+static void edt_sq(const uint8_t *mask, int n0, int n1, int n2, int32_t *out) {
+  const int64_t n = (int64_t)n0 * n1 * n2;
+  int any_bg = 0;
+  for (int64_t i = 0; i < n; i++) any_bg |= !mask[i];
+  if (!any_bg) {
+    for (int a = 0; a < n0; a++)
+      for (int b = 0; b < n1; b++)
+        for (int c = 0; c < n2; c++) {
+          /* leading axis of the array scipy sees: for a 2-D slice (n0 == 1) it is axis 1 */
+          int64_t d;
+          if (n0 == 1) d = (int64_t)(b + 1) * (b + 1) + (int64_t)c * c;
+          else d = (int64_t)(a + 1) * (a + 1) + (int64_t)b * b + (int64_t)c * c;
+          out[((int64_t)a * n1 + b) * n2 + c] = (int32_t)d;
+        }
+    return;
+  }
+  int64_t *d2 = (int64_t *)malloc(sizeof(int64_t) * n);
+  for (int64_t i = 0; i < n; i++) d2[i] = mask[i] ? BIG : 0;
+  edt_axis(d2, n0, n1, n2, 2);
+  edt_axis(d2, n0, n1, n2, 1);
+  if (n0 > 1) edt_axis(d2, n0, n1, n2, 0);
+  for (int64_t i = 0; i < n; i++) out[i] = (int32_t)d2[i];
+  free(d2);
+}
+
+/* ---- scipy.ndimage.maximum_filter(size), mode='reflect' ------------------------------- */
+static inline int reflect_dup(int i, int n) {
+  /* (d c b a | a b c d | d c b a): edge value duplicated, period 2n */
+  const int p = 2 * n;
+  i %= p;
+  if (i < 0) i += p;
+  return i < n ? i : p - 1 - i;
+}
+
+static void maxfilter_axis(int32_t *a, int n0, int n1, int n2, int axis, int size) {
+  const int dims[3] = {n0, n1, n2};
+  const int64_t strides[3] = {(int64_t)n1 * n2, n2, 1};
+  const int n = dims[axis];
+  const int left = size / 2, right = size - 1 - size / 2; /* window [i-left, i+right] */
+  int32_t *line = (int32_t *)malloc(sizeof(int32_t) * n);
+  const int a1 = (axis + 1) % 3, a2 = (axis + 2) % 3;
+  for (int i = 0; i < dims[a1]; i++)
+    for (int j = 0; j < dims[a2]; j++) {
+      int64_t base = i * strides[a1] + j * strides[a2];
+      for (int q = 0; q < n; q++) line[q] = a[base + q * strides[axis]];
+      for (int q = 0; q < n; q++) {
+        int32_t m = INT32_MIN;
+        for (int k = q - left; k <= q + right; k++) {
+          const int32_t v = line[reflect_dup(k, n)];
+          if (v > m) m = v;
+        }
+        a[base + q * strides[axis]] = m;
+      }
+    }
+  free(line);
+}
+
+/* ---- scipy.ndimage.label (4-/6-connectivity), ids in raster order of first voxel ------- */
+static int uf_find(int32_t *p, int x) {
+  while (p[x] != x) {
+    p[x] = p[p[x]];
+    x = p[x];
+  }
+  return x;
+}
+
+static int label_cc(const uint8_t *fg, int n0, int n1, int n2, int32_t *lab) {
+  const int64_t n = (int64_t)n0 * n1 * n2;
+  int32_t *p = (int32_t *)malloc(sizeof(int32_t) * n);
+  for (int64_t i = 0; i < n; i++) p[i] = (int32_t)i;
+  for (int a = 0; a < n0; a++)
+    for (int b = 0; b < n1; b++)
+      for (int c = 0; c < n2; c++) {
+        const int64_t i = ((int64_t)a * n1 + b) * n2 + c;
+        if (!fg[i]) continue;
+        if (c > 0 && fg[i - 1]) { int x = uf_find(p, (int)i), y = uf_find(p, (int)(i - 1)); if (x != y) p[x > y ? x : y] = x > y ? y : x; }
+        if (b > 0 && fg[i - n2]) { int x = uf_find(p, (int)i), y = uf_find(p, (int)(i - n2)); if (x != y) p[x > y ? x : y] = x > y ? y : x; }
+        if (a > 0 && fg[i - (int64_t)n1 * n2]) { int x = uf_find(p, (int)i), y = uf_find(p, (int)(i - (int64_t)n1 * n2)); if (x != y) p[x > y ? x : y] = x > y ? y : x; }
+      }
+  /* roots are the minimum raster index of their component: number them in raster order */
+  int count = 0;
+  for (int64_t i = 0; i < n; i++) {
+    if (!fg[i]) { lab[i] = 0; continue; }
+    const int r = uf_find(p, (int)i);
+    if (r == i) lab[i] = ++count; else lab[i] = lab[r];
+  }
+  free(p);
+  return count;
+}
+
+/* ---- skimage.segmentation.watershed(image, markers, mask=mask), connectivity 1 --------- */
+/* Sequential priority flood, SURVEY.md Appendix A.1.  `prio` = d2 (larger d2 = smaller
+ * image value max(D)-D).  lab: in = markers (already multiplied by mask), out = labels. */
+typedef struct { int32_t d2; uint32_t age; int32_t idx; } hitem;
+
+static inline int h_smaller(const hitem *a, const hitem *b) {
+  if (a->d2 != b->d2) return a->d2 > b->d2;
+  return a->age < b->age;
+}
+
+static void flood(const int32_t *d2, const uint8_t *mask, int n0, int n1, int n2, int32_t *lab) {
+  const int64_t n = (int64_t)n0 * n1 * n2;
+  hitem *heap = (hitem *)malloc(sizeof(hitem) * (n + 1));
+  int64_t items = 0;
+#define PUSH(it) do { int64_t c_ = items++; heap[c_] = (it); \
+    while (c_ > 0) { int64_t p_ = (c_ + 1) / 2 - 1; if (h_smaller(&heap[c_], &heap[p_])) { hitem t_ = heap[c_]; heap[c_] = heap[p_]; heap[p_] = t_; c_ = p_; } else break; } } while (0)
+  for (int64_t i = 0; i < n; i++)
+    if (lab[i] != 0) { hitem it = {d2[i], 0u, (int32_t)i}; PUSH(it); }
+  uint32_t age = 0;
+  const int64_t s0 = (int64_t)n1 * n2, s1 = n2;
+  while (items > 0) {
+    const hitem e = heap[0];
+    items--;
+    heap[0] = heap[items];
+    { /* sift down */
+      int64_t i = 0;
+      for (;;) {
+        int64_t c1 = 2 * i + 1, c2 = c1 + 1, sm = i;
+        if (c1 < items && h_smaller(&heap[c1], &heap[sm])) sm = c1;
+        if (c2 < items && h_smaller(&heap[c2], &heap[sm])) sm = c2;
+        if (sm == i) break;
+        hitem t = heap[i]; heap[i] = heap[sm]; heap[sm] = t;
+        i = sm;
+      }
+    }
+    const int64_t idx = e.idx;
+    const int c = (int)(idx % n2), b = (int)((idx / n2) % n1), a = (int)(idx / s0);
+    /* neighbour order [-HW, -W, -1, +1, +W, +HW] (2-D: [-W, -1, +1, +W]) */
+    const int64_t nb[6] = {idx - s0, idx - s1, idx - 1, idx + 1, idx + s1, idx + s0};
+    const int ok[6] = {a > 0, b > 0, c > 0, c < n2 - 1, b < n1 - 1, a < n0 - 1};
+    for (int k = 0; k < 6; k++) {
+      if (!ok[k]) continue;
+      const int64_t q = nb[k];
+      if (!mask[q] || lab[q] != 0) continue;
+      age++;
+      lab[q] = lab[idx];
+      hitem it = {d2[q], age, (int32_t)q};
+      PUSH(it);
+    }
+  }
+#undef PUSH
+  free(heap);
+}
+
+/* post/ws.py:8-35 on one domain (a 2-D slice when n0 == 1, else a 3-D volume).
+ * Returns n (number of maxima components, including those outside the mask). */
+static int ws_domain(const uint8_t *mask, int n0, int n1, int n2, int msd, uint64_t id_offset,
+                     uint64_t *frags, uint64_t *seeds_out) {
+  const int64_t n = (int64_t)n0 * n1 * n2;
+  int32_t *d2 = (int32_t *)malloc(sizeof(int32_t) * n);
+  int32_t *mf = (int32_t *)malloc(sizeof(int32_t) * n);
+  uint8_t *mx = (uint8_t *)malloc(n);
+  int32_t *lab = (int32_t *)malloc(sizeof(int32_t) * n);
+  edt_sq(mask, n0, n1, n2, d2);
+  memcpy(mf, d2, sizeof(int32_t) * n);
+  maxfilter_axis(mf, n0, n1, n2, 2, msd);
+  maxfilter_axis(mf, n0, n1, n2, 1, msd);
+  if (n0 > 1) maxfilter_axis(mf, n0, n1, n2, 0, msd);
+  for (int64_t i = 0; i < n; i++) mx[i] = mf[i] == d2[i];
+  const int cnt = label_cc(mx, n0, n1, n2, lab);
+  /* ws.py:21-22: n == 0 -> zeros (cannot happen for a non-empty array: the global maximum
+   * always equals its own filter response) */
+  if (seeds_out)
+    for (int64_t i = 0; i < n; i++) seeds_out[i] = lab[i] ? (uint64_t)lab[i] + id_offset : 0;
+  /* markers outside the mask vanish inside skimage (markers * mask) */
+  for (int64_t i = 0; i < n; i++) if (!mask[i]) lab[i] = 0;
+  flood(d2, mask, n0, n1, n2, lab);
+  for (int64_t i = 0; i < n; i++) frags[i] = lab[i] ? (uint64_t)lab[i] + id_offset : 0;
+  free(d2); free(mf); free(mx); free(lab);
+  return cnt;
+}
+
+/* post/ws.py:38-112 for uint8 affinities [3][D][H][W] (max_affinity_value 255). */
+int seg_ws_fragments_u8(const uint8_t *affs, int D, int H, int W, int fragments_in_xy,
+                        int min_seed_distance, uint64_t *frags, uint64_t *max_id, uint64_t *seeds) {
+  const int64_t hw = (int64_t)H * W, n = hw * D;
+  const uint8_t *az = affs, *ay = affs + n, *ax = affs + 2 * n;
+  uint8_t *mask = (uint8_t *)malloc(n);
+  if (fragments_in_xy) {
+    /* 0.5*(affs[-1]+affs[-2]) > 0.5  <=>  a_y + a_x >= 256 */
+    for (int64_t i = 0; i < n; i++) mask[i] = (int)ay[i] + (int)ax[i] >= 256;
+    uint64_t id_offset = 0;
+    for (int z = 0; z < D; z++) {
+      const int cnt = ws_domain(mask + z * hw, 1, H, W, min_seed_distance, id_offset, frags + z * hw,
+                                seeds ? seeds + z * hw : NULL);
+      id_offset += (uint64_t)cnt;
+    }
+    *max_id = id_offset;
+  } else {
+    /* mean(affs, axis=0) > 0.5  <=>  a_z + a_y + a_x >= 383 */
+    for (int64_t i = 0; i < n; i++) mask[i] = (int)az[i] + (int)ay[i] + (int)ax[i] >= 383;
+    const int cnt = ws_domain(mask, D, H, W, min_seed_distance, 0, frags, seeds);
+    *max_id = (uint64_t)cnt;
+  }
+  free(mask);
+  return 0;
+}
+
+/* ---- mean-affinity hierarchical agglomeration (waterz restatement; parity unpinned) ---- */
+/* Specification (also the contract of the HIP kernels):
+ *  nodes   = distinct non-zero fragment ids.
+ *  edges   = unordered pairs {u < v} of nodes that are 6-adjacent somewhere; each adjacent
+ *            voxel pair (p, p - e_d), d in {z,y,x}, contributes affinity affs[d][p]
+ *            (channel d at the higher-index voxel) to (sum, count) of its edge.
+ *  score   = 1.0f - (float)((double)sum / (255.0 * count))          (OneMinus<MeanAffinity>)
+ *  queue   = min-queue over the total order (score, key0) where key0 = (u0 << 32 | v0) packs
+ *            the edge's INITIAL endpoints as ranks in the sorted node list.  Every edge sits
+ *            in the queue exactly once with the score it had when it was (re)inserted.
+ *  for each threshold t (ascending), continuing from the previous state:
+ *    while queue not empty and top.score < t:
+ *      pop e; if e deleted: continue
+ *      if e stale: stale = false; reinsert with fresh score; continue
+ *      merge: a = min(u,v), b = max(u,v) of e's current endpoints; b is absorbed by a
+ *        for every live edge f != e incident to b with other endpoint n:
+ *          if a live edge g = {a, n} exists: g.sum += f.sum; g.count += f.count; delete f; g stale
+ *          else: f becomes {a, n}; f stale
+ *        delete e; parent[b] = a
+ *    seg_t[p] = id of root(frag[p])   (0 stays 0)
+ */
+typedef struct { float score; uint32_t e; } qitem;
+typedef struct {
+  uint32_t u, v;      /* current endpoints (node ranks) */
+  uint64_t key0;      /* initial (u << 32 | v) */
+  uint64_t sum;
+  uint32_t cnt;
+  uint8_t deleted, stale;
+} edge_t;
+
+static edge_t *g_edges;
+static inline int q_less(const qitem *a, const qitem *b) {
+  if (a->score != b->score) return a->score < b->score;
+  return g_edges[a->e].key0 < g_edges[b->e].key0;
+}
+static inline float edge_score(const edge_t *e) {
+  return 1.0f - (float)((double)e->sum / (255.0 * (double)e->cnt));
+}
+
+/* open-addressing hash map (u64 key -> u32 value) with tombstones */
+typedef struct { uint64_t *keys; uint32_t *vals; uint64_t cap; } hmap;
+#define HEMPTY 0xffffffffffffffffull
+#define HTOMB 0xfffffffffffffffeull
+static inline uint64_t hmix(uint64_t k) { k ^= k >> 33; k *= 0xff51afd7ed558ccdull; k ^= k >> 33; k *= 0xc4ceb9fe1a85ec53ull; k ^= k >> 33; return k; }
+static void hm_init(hmap *m, uint64_t n) { m->cap = 64; while (m->cap < 4 * n + 16) m->cap <<= 1; m->keys = (uint64_t *)malloc(8 * m->cap); m->vals = (uint32_t *)malloc(4 * m->cap); memset(m->keys, 0xff, 8 * m->cap); }
+static void hm_free(hmap *m) { free(m->keys); free(m->vals); }
+static int64_t hm_find(const hmap *m, uint64_t k) { uint64_t i = hmix(k) & (m->cap - 1); for (;;) { if (m->keys[i] == k) return (int64_t)i; if (m->keys[i] == HEMPTY) return -1; i = (i + 1) & (m->cap - 1); } }
+static void hm_put(hmap *m, uint64_t k, uint32_t v) { uint64_t i = hmix(k) & (m->cap - 1); while (m->keys[i] != HEMPTY && m->keys[i] != HTOMB && m->keys[i] != k) i = (i + 1) & (m->cap - 1); m->keys[i] = k; m->vals[i] = v; }
+static void hm_del(hmap *m, uint64_t k) { int64_t i = hm_find(m, k); if (i >= 0) m->keys[i] = HTOMB; }
+
+static int cmp_u64(const void *a, const void *b) { uint64_t x = *(const uint64_t *)a, y = *(const uint64_t *)b; return x < y ? -1 : x > y; }
+
+int seg_agglomerate_mean_u8(const uint8_t *affs, const uint64_t *frags, int D, int H, int W,
+                            const float *thresholds, int nthr, uint64_t *segs) {
+  const int64_t hw = (int64_t)H * W, n = hw * D;
+  /* nodes: sorted distinct non-zero ids */
+  uint64_t *ids = (uint64_t *)malloc(8 * (n + 1));
+  int64_t nid = 0;
+  for (int64_t i = 0; i < n; i++) if (frags[i]) ids[nid++] = frags[i];
+  qsort(ids, nid, 8, cmp_u64);
+  int64_t nn = 0;
+  for (int64_t i = 0; i < nid; i++) if (i == 0 || ids[i] != ids[i - 1]) ids[nn++] = ids[i];
+  /* rank of each voxel */
+  uint32_t *rank = (uint32_t *)malloc(4 * n);
+  {
+    hmap m; hm_init(&m, nn);
+    for (int64_t i = 0; i < nn; i++) hm_put(&m, ids[i], (uint32_t)i);
+    for (int64_t i = 0; i < n; i++) rank[i] = frags[i] ? m.vals[hm_find(&m, frags[i])] : 0xffffffffu;
+    hm_free(&m);
+  }
+  /* edges */
+  int64_t ecap = 1024, ne = 0;
+  edge_t *E = (edge_t *)malloc(sizeof(edge_t) * ecap);
+  hmap em; hm_init(&em, 1024);
+  int64_t em_n = 0;
+  const int64_t strides[3] = {hw, W, 1};
+  for (int z = 0; z < D; z++)
+    for (int y = 0; y < H; y++)
+      for (int x = 0; x < W; x++) {
+        const int64_t p = (z * (int64_t)H + y) * W + x;
+        const uint32_t r1 = rank[p];
+        if (r1 == 0xffffffffu) continue;
+        const int ok[3] = {z > 0, y > 0, x > 0};
+        for (int d = 0; d < 3; d++) {
+          if (!ok[d]) continue;
+          const uint32_t r2 = rank[p - strides[d]];
+          if (r2 == 0xffffffffu || r2 == r1) continue;
+          const uint32_t u = r1 < r2 ? r1 : r2, v = r1 < r2 ? r2 : r1;
+          const uint64_t key = ((uint64_t)u << 32) | v;
+          int64_t s = hm_find(&em, key);
+          uint32_t e;
+          if (s < 0) {
+            if (ne == ecap) { ecap *= 2; E = (edge_t *)realloc(E, sizeof(edge_t) * ecap); }
+            if (4 * (em_n + 1) + 16 > (int64_t)em.cap) { /* grow */
+              hmap nm; hm_init(&nm, 4 * em_n + 64);
+              for (uint64_t i = 0; i < em.cap; i++) if (em.keys[i] != HEMPTY && em.keys[i] != HTOMB) hm_put(&nm, em.keys[i], em.vals[i]);
+              hm_free(&em); em = nm;
+            }
+            e = (uint32_t)ne++;
+            E[e].u = u; E[e].v = v; E[e].key0 = key; E[e].sum = 0; E[e].cnt = 0; E[e].deleted = 0; E[e].stale = 0;
+            hm_put(&em, key, e); em_n++;
+          } else e = em.vals[s];
+          E[e].sum += affs[(int64_t)d * n + p];
+          E[e].cnt += 1;
+        }
+      }
+  g_edges = E;
+  /* adjacency: per-node growable lists of edge ids */
+  uint32_t **adj = (uint32_t **)calloc(nn ? nn : 1, sizeof(uint32_t *));
+  uint32_t *adjn = (uint32_t *)calloc(nn ? nn : 1, 4), *adjc = (uint32_t *)calloc(nn ? nn : 1, 4);
+#define ADJ_PUSH(node, e_) do { if (adjn[node] == adjc[node]) { adjc[node] = adjc[node] ? 2 * adjc[node] : 4; adj[node] = (uint32_t *)realloc(adj[node], 4 * adjc[node]); } adj[node][adjn[node]++] = (e_); } while (0)
+  for (int64_t e = 0; e < ne; e++) { ADJ_PUSH(E[e].u, (uint32_t)e); ADJ_PUSH(E[e].v, (uint32_t)e); }
+  /* queue: binary heap (any correct priority queue gives the same result: the order is total) */
+  qitem *heap = (qitem *)malloc(sizeof(qitem) * (ne + 1));
+  int64_t hn = 0;
+#define QPUSH(it) do { int64_t c_ = hn++; heap[c_] = (it); while (c_ > 0) { int64_t p_ = (c_ - 1) / 2; if (q_less(&heap[c_], &heap[p_])) { qitem t_ = heap[c_]; heap[c_] = heap[p_]; heap[p_] = t_; c_ = p_; } else break; } } while (0)
+  for (int64_t e = 0; e < ne; e++) { qitem it = {edge_score(&E[e]), (uint32_t)e}; QPUSH(it); }
+  uint32_t *parent = (uint32_t *)malloc(4 * (nn ? nn : 1));
+  for (int64_t i = 0; i < nn; i++) parent[i] = (uint32_t)i;
+
+  for (int t = 0; t < nthr; t++) {
+    const float thr = thresholds[t];
+    while (hn > 0 && heap[0].score < thr) {
+      const qitem top = heap[0];
+      hn--;
+      heap[0] = heap[hn];
+      for (int64_t i = 0;;) {
+        int64_t c1 = 2 * i + 1, c2 = c1 + 1, sm = i;
+        if (c1 < hn && q_less(&heap[c1], &heap[sm])) sm = c1;
+        if (c2 < hn && q_less(&heap[c2], &heap[sm])) sm = c2;
+        if (sm == i) break;
+        qitem tt = heap[i]; heap[i] = heap[sm]; heap[sm] = tt; i = sm;
+      }
+      edge_t *e = &E[top.e];
+      if (e->deleted) continue;
+      if (e->stale) { e->stale = 0; qitem it = {edge_score(e), top.e}; QPUSH(it); continue; }
+      const uint32_t a = e->u < e->v ? e->u : e->v, b = e->u < e->v ? e->v : e->u;
+      for (uint32_t k = 0; k < adjn[b]; k++) {
+        const uint32_t fi = adj[b][k];
+        edge_t *f = &E[fi];
+        if (fi == top.e || f->deleted) continue;
+        if (f->u != b && f->v != b) continue; /* moved away earlier (cannot happen: b only dies once) */
+        const uint32_t nb = f->u == b ? f->v : f->u;
+        const uint32_t gu = a < nb ? a : nb, gv = a < nb ? nb : a;
+        const uint64_t gkey = ((uint64_t)gu << 32) | gv;
+        const uint64_t fkey = ((uint64_t)(f->u) << 32) | f->v;
+        int64_t s = hm_find(&em, gkey);
+        if (s >= 0) {
+          edge_t *g = &E[em.vals[s]];
+          g->sum += f->sum; g->cnt += f->cnt; g->stale = 1;
+          f->deleted = 1;
+          hm_del(&em, fkey);
+        } else {
+          hm_del(&em, fkey);
+          f->u = gu; f->v = gv; f->stale = 1;
+          hm_put(&em, gkey, fi);
+          ADJ_PUSH(a, fi);
+        }
+      }
+      hm_del(&em, ((uint64_t)e->u << 32) | e->v);
+      e->deleted = 1;
+      parent[b] = a;
+    }
+    uint64_t *seg = segs + (int64_t)t * n;
+    for (int64_t i = 0; i < n; i++) {
+      if (rank[i] == 0xffffffffu) { seg[i] = 0; continue; }
+      uint32_t r = rank[i];
+      while (parent[r] != r) r = parent[r];
+      seg[i] = ids[r];
+    }
+  }
+  for (int64_t i = 0; i < nn; i++) free(adj[i]);
+  free(adj); free(adjn); free(adjc); free(heap); free(parent); free(E); hm_free(&em); free(rank); free(ids);
+  return 0;
+}
+
+/* number of distinct non-zero labels (test helper) */
+int64_t seg_count_labels(const uint64_t *lab, int64_t n) {
+  uint64_t *ids = (uint64_t *)malloc(8 * (n + 1));
+  int64_t k = 0, c = 0;
+  for (int64_t i = 0; i < n; i++) if (lab[i]) ids[k++] = lab[i];
+  qsort(ids, k, 8, cmp_u64);
+  for (int64_t i = 0; i < k; i++) if (i == 0 || ids[i] != ids[i - 1]) c++;
+  free(ids);
+  return c;
+}
