@@ -1,0 +1,762 @@
+// Segmentation half of the hot path on gfx950: seeded-watershed fragments
+// (reference post/ws.py:8-112) and mean-affinity hierarchical agglomeration (reference call
+// site post/watershed.py:333-338; algorithm specified in oracle/seg_ref.c).
+//
+// Everything is integer work held bit-exact to the oracle:
+//   fragments (fragments_in_xy): one workgroup per z-slice computes the foreground mask
+//     (a_y + a_x >= 256), the exact squared EDT, the separable reflect-border max filter,
+//     the maxima, their 4-connected components numbered in raster order; a tiny scan gives
+//     the running id offset of ws.py:74-92; then one wave per slice replays skimage's
+//     priority flood exactly (binary heap keyed (value, age), label-at-push) with the heap in
+//     LDS -- the flood order is inherently sequential per slice, the parallelism is across
+//     the slices (128 per block, 65,536 per 1024^3 volume).
+//   agglomeration: region-adjacency graph by parallel scan + device hash table (sum, count
+//     per edge), then one wave per volume replays the specified sequential merge loop
+//     (min-queue over the total order (score, initial edge key)), then a parallel relabel.
+#include <vector>
+
+#include "common.h"
+
+namespace bsmi {
+
+// ------------------------------------------------------------------------------------------
+// watershed fragments
+// ------------------------------------------------------------------------------------------
+constexpr int WS_T = 256;            // threads per slice workgroup (seeds kernel)
+constexpr int FLOOD_LDS_HEAP = 8192; // heap entries kept in LDS (8 B each); the rest spills to HBM
+
+__device__ __forceinline__ int reflect_dup(int i, int n) {
+  const int p = 2 * n;
+  i %= p;
+  if (i < 0) i += p;
+  return i < n ? i : p - 1 - i;
+}
+
+// scratch per slice (global memory, L2 resident): mask u8, g/d2/mf int32, parent int32, lab int32
+struct WsScratch {
+  uint8_t* mask;
+  int32_t* g;
+  int32_t* d2;
+  int32_t* mf;
+  int32_t* par;
+  int32_t* lab;     // local seed labels (1..n), later flood labels
+  int32_t* nseeds;  // [D]
+  uint64_t* offs;   // [D] exclusive scan of nseeds
+};
+
+__global__ __launch_bounds__(WS_T) void ws_seeds_kernel(const uint8_t* __restrict__ affs, int D, int H, int W,
+                                                        int msd, WsScratch s) {
+  const int z = blockIdx.x;
+  const int n = H * W;
+  const size_t vol = (size_t)D * n;
+  const uint8_t* ay = affs + vol + (size_t)z * n;
+  const uint8_t* ax = affs + 2 * vol + (size_t)z * n;
+  uint8_t* mask = s.mask + (size_t)z * n;
+  int32_t* g = s.g + (size_t)z * n;
+  int32_t* d2 = s.d2 + (size_t)z * n;
+  int32_t* mf = s.mf + (size_t)z * n;
+  int32_t* par = s.par + (size_t)z * n;
+  int32_t* lab = s.lab + (size_t)z * n;
+  const int tid = threadIdx.x;
+  __shared__ int sh_any_bg;
+  __shared__ int sh_cnt[WS_T];
+  if (tid == 0) sh_any_bg = 0;
+  __syncthreads();
+  // a. mask  (0.5*(a_y+a_x) > 0.5*255  <=>  a_y + a_x >= 256)
+  int bg = 0;
+  for (int i = tid; i < n; i += WS_T) {
+    const int m = (int)ay[i] + (int)ax[i] >= 256;
+    mask[i] = (uint8_t)m;
+    bg |= !m;
+  }
+  if (bg) sh_any_bg = 1;
+  __syncthreads();
+  const int any_bg = sh_any_bg;
+  constexpr int INF = 1 << 28;
+  if (any_bg) {
+    // b1. per row: distance along x to the nearest background voxel
+    for (int y = tid; y < H; y += WS_T) {
+      int last = -INF;
+      for (int x = 0; x < W; ++x) {
+        if (!mask[y * W + x]) last = x;
+        g[y * W + x] = last <= -INF ? INF : x - last;
+      }
+      last = INF;
+      for (int x = W - 1; x >= 0; --x) {
+        if (!mask[y * W + x]) last = x;
+        const int d = last >= INF ? INF : last - x;
+        if (d < g[y * W + x]) g[y * W + x] = d;
+      }
+    }
+    __syncthreads();
+    // b2. per voxel: min over y' of g(y',x)^2 + (y-y')^2   (exact, integers)
+    for (int i = tid; i < n; i += WS_T) {
+      const int y = i / W, x = i - y * W;
+      int best = INF;
+      for (int yy = 0; yy < H; ++yy) {
+        const int gg = g[yy * W + x];
+        if (gg < INF) {
+          const int dy = y - yy;
+          const int v = gg * gg + dy * dy;
+          best = v < best ? v : best;
+        }
+      }
+      d2[i] = best;
+    }
+  } else {
+    // scipy's behaviour without any background voxel: as if the only one sat at (-1, 0)
+    for (int i = tid; i < n; i += WS_T) {
+      const int y = i / W, x = i - y * W;
+      d2[i] = (y + 1) * (y + 1) + x * x;
+    }
+  }
+  __syncthreads();
+  // c. maximum_filter(size=msd), window [i - msd/2, i + msd - 1 - msd/2], reflect border
+  const int left = msd / 2, right = msd - 1 - msd / 2;
+  for (int i = tid; i < n; i += WS_T) {
+    const int y = i / W, x = i - y * W;
+    int m = INT32_MIN;
+    for (int k = x - left; k <= x + right; ++k) {
+      const int v = d2[y * W + reflect_dup(k, W)];
+      m = v > m ? v : m;
+    }
+    g[i] = m;
+  }
+  __syncthreads();
+  for (int i = tid; i < n; i += WS_T) {
+    const int y = i / W, x = i - y * W;
+    int m = INT32_MIN;
+    for (int k = y - left; k <= y + right; ++k) {
+      const int v = g[reflect_dup(k, H) * W + x];
+      m = v > m ? v : m;
+    }
+    mf[i] = m;
+  }
+  __syncthreads();
+  // d/e. maxima and their 4-connected components (union-find, smaller index wins)
+  for (int i = tid; i < n; i += WS_T) par[i] = (mf[i] == d2[i]) ? i : -1;
+  __syncthreads();
+  auto find = [&](int a) {
+    int p = par[a];
+    while (p != a) {
+      a = p;
+      p = __hip_atomic_load(&par[a], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
+    return a;
+  };
+  auto unite = [&](int a, int b) {
+    for (;;) {
+      a = find(a);
+      b = find(b);
+      if (a == b) return;
+      if (a < b) { const int t = a; a = b; b = t; }
+      const int old = atomicMin(&par[a], b);
+      if (old == a) return;
+      a = old;
+    }
+  };
+  for (int i = tid; i < n; i += WS_T) {
+    if (par[i] < 0) continue;
+    const int y = i / W, x = i - y * W;
+    if (x > 0 && par[i - 1] >= 0) unite(i, i - 1);
+    if (y > 0 && par[i - W] >= 0) unite(i, i - W);
+  }
+  __syncthreads();
+  // raster-order numbering of the roots (scipy.ndimage.label): chunked scan
+  const int chunk = (n + WS_T - 1) / WS_T;
+  const int c0 = tid * chunk, c1 = min(n, c0 + chunk);
+  int cnt = 0;
+  for (int i = c0; i < c1; ++i) cnt += (par[i] == i);
+  sh_cnt[tid] = cnt;
+  __syncthreads();
+  if (tid == 0) {
+    int acc = 0;
+    for (int t = 0; t < WS_T; ++t) { const int c = sh_cnt[t]; sh_cnt[t] = acc; acc += c; }
+    s.nseeds[z] = acc;
+  }
+  __syncthreads();
+  int id = sh_cnt[tid];
+  for (int i = c0; i < c1; ++i)
+    if (par[i] == i) g[i] = ++id;  // g reused: root index -> label
+  __syncthreads();
+  // markers = label * mask (seeds outside the mask vanish inside skimage)
+  for (int i = tid; i < n; i += WS_T) {
+    int l = 0;
+    if (par[i] >= 0 && mask[i]) l = g[find(i)];
+    lab[i] = l;
+  }
+}
+
+__global__ void ws_offsets_kernel(int D, WsScratch s, uint64_t* max_id) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) {
+    uint64_t acc = 0;
+    for (int z = 0; z < D; ++z) { s.offs[z] = acc; acc += (uint64_t)s.nseeds[z]; }
+    *max_id = acc;
+  }
+}
+
+// heap entry: [63:40] = MAXD2 - d2 (24 bit) | [39:20] = age (20 bit) | [19:0] = voxel index.
+// Ordering ignores the index bits (skimage compares (value, age) only).
+__device__ __forceinline__ bool flood_smaller(uint64_t a, uint64_t b) { return (a >> 20) < (b >> 20); }
+
+__global__ __launch_bounds__(64) void ws_flood_kernel(int D, int H, int W, WsScratch s, uint64_t* heap_spill,
+                                                     size_t spill_stride, uint64_t* __restrict__ frags, int* status) {
+  __shared__ uint64_t hl[FLOOD_LDS_HEAP];
+  const int z = blockIdx.x;
+  const int n = H * W;
+  const uint8_t* mask = s.mask + (size_t)z * n;
+  const int32_t* d2 = s.d2 + (size_t)z * n;
+  int32_t* lab = s.lab + (size_t)z * n;
+  uint64_t* hg = heap_spill + (size_t)z * spill_stride;  // entries >= FLOOD_LDS_HEAP live here
+  if (threadIdx.x == 0) {
+    constexpr uint64_t MAXD2 = (1u << 24) - 1;
+    int items = 0;
+    auto hget = [&](int i) -> uint64_t { return i < FLOOD_LDS_HEAP ? hl[i] : hg[i - FLOOD_LDS_HEAP]; };
+    auto hset = [&](int i, uint64_t v) { if (i < FLOOD_LDS_HEAP) hl[i] = v; else hg[i - FLOOD_LDS_HEAP] = v; };
+    auto push = [&](uint64_t it) {
+      int c = items++;
+      while (c > 0) {
+        const int p = (c + 1) / 2 - 1;
+        const uint64_t pv = hget(p);
+        if (flood_smaller(it, pv)) { hset(c, pv); c = p; } else break;
+      }
+      hset(c, it);
+    };
+    // seeds in raster order, age 0
+    for (int i = 0; i < n; ++i)
+      if (lab[i] != 0) push(((MAXD2 - (uint64_t)d2[i]) << 40) | (uint64_t)i);
+    uint32_t age = 0;
+    while (items > 0) {
+      const uint64_t e = hget(0);
+      --items;
+      if (items > 0) {
+        // sift the last element down from the root (skimage heappop order)
+        const uint64_t last = hget(items);
+        int i = 0;
+        for (;;) {
+          const int c1 = 2 * i + 1, c2 = c1 + 1;
+          if (c1 >= items) break;
+          uint64_t v1 = hget(c1);
+          int sm = i;
+          uint64_t smv = last;
+          if (flood_smaller(v1, smv)) { sm = c1; smv = v1; }
+          if (c2 < items) {
+            const uint64_t v2 = hget(c2);
+            if (flood_smaller(v2, smv)) { sm = c2; smv = v2; }
+          }
+          if (sm == i) break;
+          hset(i, smv);
+          i = sm;
+        }
+        hset(i, last);
+      }
+      const int idx = (int)(e & 0xfffffu);
+      const int y = idx / W, x = idx - y * W;
+      const int l = lab[idx];
+      // neighbour order [-W, -1, +1, +W]
+      const int nb[4] = {idx - W, idx - 1, idx + 1, idx + W};
+      const bool ok[4] = {y > 0, x > 0, x < W - 1, y < H - 1};
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        if (!ok[k]) continue;
+        const int q = nb[k];
+        if (!mask[q] || lab[q] != 0) continue;
+        ++age;
+        lab[q] = l;
+        push(((MAXD2 - (uint64_t)d2[q]) << 40) | ((uint64_t)age << 20) | (uint64_t)q);
+      }
+    }
+  }
+  __syncthreads();
+  const uint64_t off = s.offs[z];
+  uint64_t* out = frags + (size_t)z * n;
+  for (int i = threadIdx.x; i < n; i += 64) {
+    const int l = lab[i];
+    out[i] = l ? (uint64_t)l + off : 0ull;
+  }
+  (void)status;
+}
+
+// ------------------------------------------------------------------------------------------
+// agglomeration
+// ------------------------------------------------------------------------------------------
+constexpr uint64_t HEMPTY = 0xffffffffffffffffull;
+constexpr uint64_t HTOMB = 0xfffffffffffffffeull;
+constexpr uint32_t NOEDGE = 0xffffffffu;
+constexpr int AGG_LDS_HEAP = 12288;  // entries (8 B) of the merge queue kept in LDS
+
+__device__ __forceinline__ uint64_t hmix(uint64_t k) {
+  k ^= k >> 33; k *= 0xff51afd7ed558ccdull; k ^= k >> 33; k *= 0xc4ceb9fe1a85ec53ull; k ^= k >> 33;
+  return k;
+}
+
+struct AggWs {
+  // node table
+  uint32_t* rank_of_id;  // [id_cap]: direct-address table id -> rank (after scan), 0xffffffff = absent
+  uint32_t id_cap;
+  uint64_t* ids;         // [node_cap] rank -> id
+  uint32_t node_cap;
+  uint32_t* counters;    // [0]=nn, [1]=ne, [2]=heap_n, [3]=overflow flags
+  // hash table over edges
+  uint64_t* hkeys;       // [hcap]
+  uint32_t* hvals;       // [hcap] -> edge index
+  unsigned long long* hsum;  // [hcap] (during build)
+  uint32_t* hcnt;        // [hcap]
+  uint32_t hcap;         // power of two
+  // edge arrays [edge_cap]
+  uint32_t* eu; uint32_t* ev; uint64_t* ekey0; unsigned long long* esum; uint32_t* ecnt;
+  uint32_t* enextu; uint32_t* enextv; uint8_t* eflags;  // bit0 deleted, bit1 stale
+  uint32_t edge_cap;
+  uint32_t* head;        // [node_cap]
+  uint32_t* parent;      // [node_cap]
+  uint32_t* roots;       // [nthr_cap][node_cap]
+  uint64_t* heap_spill;  // [edge_cap]
+  uint64_t* maxid;       // [1]
+};
+
+__global__ void agg_maxid_kernel(const uint64_t* __restrict__ frags, size_t n, AggWs w) {
+  unsigned long long m = 0;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+    m = frags[i] > m ? frags[i] : m;
+  for (int o = 32; o > 0; o >>= 1) {
+    const unsigned long long t = __shfl_down(m, o);
+    m = t > m ? t : m;
+  }
+  if ((threadIdx.x & 63) == 0 && m) atomicMax((unsigned long long*)w.maxid, m);
+}
+
+__global__ void agg_mark_kernel(const uint64_t* __restrict__ frags, size_t n, AggWs w) {
+  const uint64_t maxid = *w.maxid;
+  if (maxid >= w.id_cap) {
+    if (blockIdx.x == 0 && threadIdx.x == 0) atomicOr(&w.counters[3], 1u);
+    return;
+  }
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    const uint64_t f = frags[i];
+    if (f) w.rank_of_id[f] = 1u;  // benign race: every writer stores 1
+  }
+}
+
+// single workgroup: exclusive scan of the presence flags -> ranks (ascending id = sorted order)
+__global__ __launch_bounds__(1024) void agg_rank_kernel(AggWs w) {
+  __shared__ uint32_t sh[1024];
+  if (w.counters[3]) return;
+  const uint64_t maxid = *w.maxid;
+  const uint32_t n = (uint32_t)maxid + 1;
+  const uint32_t chunk = (n + 1023) / 1024;
+  const uint32_t c0 = threadIdx.x * chunk, c1 = min(n, c0 + chunk);
+  uint32_t cnt = 0;
+  for (uint32_t i = c0; i < c1 && i < n; ++i) cnt += w.rank_of_id[i] == 1u;
+  sh[threadIdx.x] = cnt;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    uint32_t acc = 0;
+    for (int t = 0; t < 1024; ++t) { const uint32_t c = sh[t]; sh[t] = acc; acc += c; }
+    w.counters[0] = acc;
+    if (acc > w.node_cap) atomicOr(&w.counters[3], 2u);
+  }
+  __syncthreads();
+  if (w.counters[3]) return;
+  uint32_t r = sh[threadIdx.x];
+  for (uint32_t i = c0; i < c1 && i < n; ++i) {
+    if (w.rank_of_id[i] == 1u) {
+      w.rank_of_id[i] = r;
+      w.ids[r] = i;
+      w.head[r] = NOEDGE;
+      w.parent[r] = r;
+      ++r;
+    } else {
+      w.rank_of_id[i] = 0xffffffffu;
+    }
+  }
+}
+
+__global__ void agg_edges_kernel(const uint8_t* __restrict__ affs, const uint64_t* __restrict__ frags, int D, int H,
+                                 int W, AggWs w) {
+  if (w.counters[3]) return;
+  const size_t n = (size_t)D * H * W;
+  const size_t hw = (size_t)H * W;
+  for (size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x; p < n; p += (size_t)gridDim.x * blockDim.x) {
+    const uint64_t f1 = frags[p];
+    if (!f1) continue;
+    const int x = (int)(p % W);
+    const int y = (int)((p / W) % H);
+    const int z = (int)(p / hw);
+    const uint32_t r1 = w.rank_of_id[f1];
+    const bool ok[3] = {z > 0, y > 0, x > 0};
+    const size_t st[3] = {hw, (size_t)W, 1};
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+      if (!ok[d]) continue;
+      const uint64_t f2 = frags[p - st[d]];
+      if (!f2 || f2 == f1) continue;
+      const uint32_t r2 = w.rank_of_id[f2];
+      const uint32_t u = r1 < r2 ? r1 : r2, v = r1 < r2 ? r2 : r1;
+      const uint64_t key = ((uint64_t)u << 32) | v;
+      uint32_t slot = (uint32_t)hmix(key) & (w.hcap - 1);
+      bool placed = false;
+      for (uint32_t probe = 0; probe < w.hcap; ++probe) {
+        const unsigned long long old = atomicCAS((unsigned long long*)&w.hkeys[slot], HEMPTY, key);
+        if (old == HEMPTY || old == key) { placed = true; break; }
+        slot = (slot + 1) & (w.hcap - 1);
+      }
+      if (!placed) { atomicOr(&w.counters[3], 4u); return; }
+      atomicAdd(&w.hsum[slot], (unsigned long long)affs[(size_t)d * n + p]);
+      atomicAdd(&w.hcnt[slot], 1u);
+    }
+  }
+}
+
+__global__ void agg_compact_kernel(AggWs w) {
+  if (w.counters[3]) return;
+  for (uint32_t s = blockIdx.x * blockDim.x + threadIdx.x; s < w.hcap; s += gridDim.x * blockDim.x) {
+    const uint64_t key = w.hkeys[s];
+    if (key == HEMPTY) continue;
+    const uint32_t e = atomicAdd(&w.counters[1], 1u);
+    if (e >= w.edge_cap) { atomicOr(&w.counters[3], 8u); continue; }
+    const uint32_t u = (uint32_t)(key >> 32), v = (uint32_t)key;
+    w.eu[e] = u; w.ev[e] = v; w.ekey0[e] = key;
+    w.esum[e] = w.hsum[s]; w.ecnt[e] = w.hcnt[s];
+    w.eflags[e] = 0;
+    w.hvals[s] = e;
+    w.enextu[e] = atomicExch(&w.head[u], e);
+    w.enextv[e] = atomicExch(&w.head[v], e);
+  }
+}
+
+__device__ __forceinline__ float agg_score(unsigned long long sum, uint32_t cnt) {
+  return 1.0f - (float)((double)sum / (255.0 * (double)cnt));
+}
+
+// One wave per volume; lane 0 replays the sequential merge loop of oracle/seg_ref.c.
+__global__ __launch_bounds__(64) void agg_merge_kernel(AggWs w, const float* __restrict__ thresholds, int nthr) {
+  __shared__ uint64_t hl[AGG_LDS_HEAP];
+  __shared__ int sh_dummy;
+  if (w.counters[3]) return;
+  const uint32_t nn = w.counters[0];
+  const uint32_t ne = min(w.counters[1], w.edge_cap);
+  const int lane = threadIdx.x;
+  int items = 0;  // meaningful on lane 0 only
+  const float tmax = thresholds[nthr - 1];
+  // entry: [63:32] float bits of the score (scores are >= 0: bit pattern order == value order),
+  //        [31:0] edge index; ties on the score are broken by the edge's initial key.
+  auto hget = [&](int i) -> uint64_t { return i < AGG_LDS_HEAP ? hl[i] : w.heap_spill[i - AGG_LDS_HEAP]; };
+  auto hset = [&](int i, uint64_t v) { if (i < AGG_LDS_HEAP) hl[i] = v; else w.heap_spill[i - AGG_LDS_HEAP] = v; };
+  auto less = [&](uint64_t a, uint64_t b) -> bool {
+    const uint32_t sa = (uint32_t)(a >> 32), sb = (uint32_t)(b >> 32);
+    if (sa != sb) return sa < sb;
+    return w.ekey0[(uint32_t)a] < w.ekey0[(uint32_t)b];
+  };
+  auto sift_down = [&](int i, uint64_t val) {
+    for (;;) {
+      const int c1 = 2 * i + 1, c2 = c1 + 1;
+      if (c1 >= items) break;
+      int sm = c1;
+      uint64_t smv = hget(c1);
+      if (c2 < items) {
+        const uint64_t v2 = hget(c2);
+        if (less(v2, smv)) { sm = c2; smv = v2; }
+      }
+      if (!less(smv, val)) break;
+      hset(i, smv);
+      i = sm;
+    }
+    hset(i, val);
+  };
+  auto push = [&](uint64_t val) {
+    int c = items++;
+    while (c > 0) {
+      const int p = (c - 1) / 2;
+      const uint64_t pv = hget(p);
+      if (less(val, pv)) { hset(c, pv); c = p; } else break;
+    }
+    hset(c, val);
+  };
+  bool fail = false;
+  auto hfind = [&](uint64_t key) -> int64_t {
+    uint32_t s = (uint32_t)hmix(key) & (w.hcap - 1);
+    for (uint32_t probe = 0; probe < w.hcap; ++probe) {
+      const uint64_t k = w.hkeys[s];
+      if (k == key) return (int64_t)s;
+      if (k == HEMPTY) return -1;
+      s = (s + 1) & (w.hcap - 1);
+    }
+    return -1;
+  };
+  auto hput = [&](uint64_t key, uint32_t val) {
+    uint32_t s = (uint32_t)hmix(key) & (w.hcap - 1);
+    uint32_t probe = 0;
+    for (; probe < w.hcap; ++probe) {
+      const uint64_t k = w.hkeys[s];
+      if (k == HEMPTY || k == HTOMB || k == key) break;
+      s = (s + 1) & (w.hcap - 1);
+    }
+    if (probe == w.hcap) { fail = true; return; }
+    w.hkeys[s] = key;
+    w.hvals[s] = val;
+  };
+  auto norm_key = [](uint32_t x, uint32_t y) -> uint64_t {
+    return x < y ? (((uint64_t)x << 32) | y) : (((uint64_t)y << 32) | x);
+  };
+
+  if (lane == 0) {
+    // initial queue: only edges below the largest threshold can ever be popped
+    for (uint32_t e = 0; e < ne; ++e) {
+      const float sc = agg_score(w.esum[e], w.ecnt[e]);
+      if (sc < tmax) hset(items++, ((uint64_t)__float_as_uint(sc) << 32) | e);
+    }
+    for (int i = items / 2 - 1; i >= 0; --i) sift_down(i, hget(i));  // Floyd heapify
+  }
+  for (int t = 0; t < nthr; ++t) {
+    if (lane == 0) {
+      const float thr = thresholds[t];
+      while (items > 0) {
+        const uint64_t top = hget(0);
+        if (!(__uint_as_float((uint32_t)(top >> 32)) < thr)) break;
+        --items;
+        if (items > 0) sift_down(0, hget(items));
+        const uint32_t e = (uint32_t)top;
+        const uint8_t fl = w.eflags[e];
+        if (fl & 1) continue;
+        if (fl & 2) {
+          w.eflags[e] = fl & ~2;
+          const float sc = agg_score(w.esum[e], w.ecnt[e]);
+          if (sc < tmax) push(((uint64_t)__float_as_uint(sc) << 32) | e);
+          continue;
+        }
+        const uint32_t eu = w.eu[e], evv = w.ev[e];
+        const uint32_t a = eu < evv ? eu : evv, b = eu < evv ? evv : eu;
+        uint32_t f = w.head[b];
+        while (f != NOEDGE && !fail) {
+          const uint32_t fu = w.eu[f], fv = w.ev[f];
+          const bool b_in_u = fu == b;
+          const uint32_t nxt = b_in_u ? w.enextu[f] : w.enextv[f];
+          if (f != e && !(w.eflags[f] & 1)) {
+            const uint32_t nb = b_in_u ? fv : fu;
+            const uint64_t gkey = norm_key(a, nb);
+            const int64_t fs = hfind(norm_key(fu, fv));
+            if (fs >= 0) w.hkeys[fs] = HTOMB;
+            const int64_t gs = hfind(gkey);
+            if (gs >= 0) {
+              const uint32_t g = w.hvals[gs];
+              w.esum[g] += w.esum[f];
+              w.ecnt[g] += w.ecnt[f];
+              w.eflags[g] |= 2;
+              w.eflags[f] |= 1;
+            } else {
+              // f becomes {a, nb}: b is replaced IN ITS SLOT so that nb's list keeps following
+              // the link that belongs to nb's slot; f joins a's list through b's old slot
+              if (b_in_u) { w.eu[f] = a; w.enextu[f] = w.head[a]; } else { w.ev[f] = a; w.enextv[f] = w.head[a]; }
+              w.head[a] = f;
+              w.eflags[f] |= 2;
+              hput(gkey, f);
+            }
+          }
+          f = nxt;
+        }
+        if (fail) break;
+        {
+          const int64_t es = hfind(norm_key(eu, evv));
+          if (es >= 0) w.hkeys[es] = HTOMB;
+        }
+        w.eflags[e] |= 1;
+        w.parent[b] = a;
+      }
+      sh_dummy = items;
+      if (fail) atomicOr(&w.counters[3], 16u);
+    }
+    __syncthreads();
+    // snapshot of the roots at this threshold (parents always point to smaller ranks)
+    for (uint32_t i = lane; i < nn; i += 64) {
+      uint32_t r = i;
+      for (;;) {
+        const uint32_t p = __hip_atomic_load(&w.parent[r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        if (p == r) break;
+        r = p;
+      }
+      w.roots[(size_t)t * w.node_cap + i] = r;
+    }
+    __syncthreads();
+  }
+}
+
+__global__ void agg_relabel_kernel(const uint64_t* __restrict__ frags, size_t n, int nthr, AggWs w,
+                                   uint64_t* __restrict__ segs) {
+  if (w.counters[3]) return;
+  for (size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x; p < n; p += (size_t)gridDim.x * blockDim.x) {
+    const uint64_t f = frags[p];
+    if (!f) {
+      for (int t = 0; t < nthr; ++t) segs[(size_t)t * n + p] = 0;
+      continue;
+    }
+    const uint32_t r = w.rank_of_id[f];
+    for (int t = 0; t < nthr; ++t) segs[(size_t)t * n + p] = w.ids[w.roots[(size_t)t * w.node_cap + r]];
+  }
+}
+
+}  // namespace bsmi
+
+using namespace bsmi;
+
+constexpr int kMaxThresholds = 16;
+
+struct bsmi_seg {
+  int device = 0;
+  int64_t max_shape[3] = {0, 0, 0};
+  size_t max_vox = 0;
+  std::vector<void*> allocs;
+  WsScratch ws{};
+  uint64_t* flood_spill = nullptr;
+  size_t flood_spill_stride = 0;
+  AggWs agg{};
+  float* thr_dev = nullptr;
+  int* status_dev = nullptr;
+};
+
+namespace bsmi {
+template <typename T>
+static int dalloc(bsmi_seg* h, T** p, size_t count) {
+  void* q = nullptr;
+  BSMI_HIP(hipMalloc(&q, count * sizeof(T) + 16));
+  h->allocs.push_back(q);
+  *p = (T*)q;
+  return BSMI_OK;
+}
+static uint32_t next_pow2(uint64_t v) {
+  uint32_t p = 1;
+  while (p < v) p <<= 1;
+  return p;
+}
+}  // namespace bsmi
+
+extern "C" {
+
+int bsmi_seg_create(int device, const int64_t max_shape[3], bsmi_seg** out) {
+  if (!max_shape || !out) BSMI_FAIL(BSMI_ERR_INVALID, "null argument");
+  for (int d = 0; d < 3; ++d)
+    if (max_shape[d] < 1 || max_shape[d] > 4096) BSMI_FAIL(BSMI_ERR_INVALID, "bad max_shape");
+  if (max_shape[1] * max_shape[2] >= (1 << 20))
+    BSMI_FAIL(BSMI_ERR_INVALID, "slices larger than 2^20 voxels are not supported by the flood kernel");
+  BSMI_HIP(hipSetDevice(device));
+  bsmi_seg* h = new bsmi_seg;
+  h->device = device;
+  for (int d = 0; d < 3; ++d) h->max_shape[d] = max_shape[d];
+  const size_t nv = (size_t)max_shape[0] * max_shape[1] * max_shape[2];
+  const size_t ns = (size_t)max_shape[1] * max_shape[2];
+  h->max_vox = nv;
+  int rc = 0;
+#define A(ptr, cnt) if (!rc) rc = dalloc(h, &(ptr), (cnt))
+  A(h->ws.mask, nv); A(h->ws.g, nv); A(h->ws.d2, nv); A(h->ws.mf, nv); A(h->ws.par, nv); A(h->ws.lab, nv);
+  A(h->ws.nseeds, (size_t)max_shape[0]); A(h->ws.offs, (size_t)max_shape[0]);
+  h->flood_spill_stride = ns;
+  A(h->flood_spill, nv);
+  AggWs& g = h->agg;
+  g.id_cap = (uint32_t)std::min<size_t>(nv + 2, (size_t)1 << 27);
+  g.node_cap = (uint32_t)std::min<size_t>(nv / 8 + 1024, (size_t)1 << 24);
+  g.hcap = next_pow2(std::max<size_t>(nv / 2, 1024));
+  g.edge_cap = g.hcap / 2;
+  A(g.rank_of_id, (size_t)g.id_cap); A(g.ids, (size_t)g.node_cap); A(g.counters, 8);
+  A(g.hkeys, (size_t)g.hcap); A(g.hvals, (size_t)g.hcap); A(g.hsum, (size_t)g.hcap); A(g.hcnt, (size_t)g.hcap);
+  A(g.eu, (size_t)g.edge_cap); A(g.ev, (size_t)g.edge_cap); A(g.ekey0, (size_t)g.edge_cap);
+  A(g.esum, (size_t)g.edge_cap); A(g.ecnt, (size_t)g.edge_cap); A(g.enextu, (size_t)g.edge_cap);
+  A(g.enextv, (size_t)g.edge_cap); A(g.eflags, (size_t)g.edge_cap);
+  A(g.head, (size_t)g.node_cap); A(g.parent, (size_t)g.node_cap);
+  A(g.roots, (size_t)g.node_cap * kMaxThresholds); A(g.heap_spill, (size_t)g.edge_cap); A(g.maxid, 1);
+  A(h->thr_dev, kMaxThresholds); A(h->status_dev, 4);
+#undef A
+  if (rc) {
+    for (void* p : h->allocs) (void)hipFree(p);
+    delete h;
+    return rc;
+  }
+  BSMI_HIP(hipMemset(g.counters, 0, 8 * sizeof(uint32_t)));
+  *out = h;
+  return BSMI_OK;
+}
+
+int bsmi_seg_destroy(bsmi_seg* h) {
+  if (!h) return BSMI_OK;
+  (void)hipSetDevice(h->device);
+  for (void* p : h->allocs) (void)hipFree(p);
+  delete h;
+  return BSMI_OK;
+}
+
+static int check_seg_shape(bsmi_seg* h, const int64_t shape[3]) {
+  if (!h || !shape) BSMI_FAIL(BSMI_ERR_INVALID, "null argument");
+  for (int d = 0; d < 3; ++d)
+    if (shape[d] < 1) BSMI_FAIL(BSMI_ERR_INVALID, "bad shape");
+  if ((size_t)shape[0] * shape[1] * shape[2] > h->max_vox || shape[0] > h->max_shape[0] ||
+      shape[1] * shape[2] > h->max_shape[1] * h->max_shape[2])
+    BSMI_FAIL(BSMI_ERR_INVALID, "shape (%lld,%lld,%lld) exceeds the handle's max_shape (%lld,%lld,%lld)",
+              (long long)shape[0], (long long)shape[1], (long long)shape[2], (long long)h->max_shape[0],
+              (long long)h->max_shape[1], (long long)h->max_shape[2]);
+  return BSMI_OK;
+}
+
+int bsmi_ws_fragments_u8(bsmi_seg* h, const uint8_t* affs_dev, const int64_t shape[3], int fragments_in_xy,
+                         int min_seed_distance, uint64_t* frags_dev, uint64_t* max_id_dev, void* stream) {
+  int rc = check_seg_shape(h, shape);
+  if (rc) return rc;
+  if (!affs_dev || !frags_dev || !max_id_dev) BSMI_FAIL(BSMI_ERR_INVALID, "null argument");
+  if (!fragments_in_xy)
+    BSMI_FAIL(BSMI_ERR_INVALID, "fragments_in_xy=False (3-D flood) is not implemented on the device yet");
+  if (min_seed_distance < 1 || min_seed_distance > 64) BSMI_FAIL(BSMI_ERR_INVALID, "min_seed_distance out of range");
+  BSMI_HIP(hipSetDevice(h->device));
+  hipStream_t s = (hipStream_t)stream;
+  const int D = (int)shape[0], H = (int)shape[1], W = (int)shape[2];
+  hipLaunchKernelGGL(ws_seeds_kernel, dim3(D), dim3(WS_T), 0, s, affs_dev, D, H, W, min_seed_distance, h->ws);
+  hipLaunchKernelGGL(ws_offsets_kernel, dim3(1), dim3(64), 0, s, D, h->ws, max_id_dev);
+  hipLaunchKernelGGL(ws_flood_kernel, dim3(D), dim3(64), 0, s, D, H, W, h->ws, h->flood_spill, h->flood_spill_stride,
+                     frags_dev, h->status_dev);
+  BSMI_HIP(hipGetLastError());
+  return BSMI_OK;
+}
+
+int bsmi_agglomerate_mean_u8(bsmi_seg* h, const uint8_t* affs_dev, const uint64_t* frags_dev, const int64_t shape[3],
+                             const float* thresholds_host, int n_thresholds, uint64_t* segs_dev, void* stream) {
+  int rc = check_seg_shape(h, shape);
+  if (rc) return rc;
+  if (!affs_dev || !frags_dev || !thresholds_host || !segs_dev) BSMI_FAIL(BSMI_ERR_INVALID, "null argument");
+  if (n_thresholds < 1 || n_thresholds > kMaxThresholds) BSMI_FAIL(BSMI_ERR_INVALID, "1..%d thresholds supported", kMaxThresholds);
+  for (int i = 0; i < n_thresholds; ++i) {
+    if (!(thresholds_host[i] >= 0.f)) BSMI_FAIL(BSMI_ERR_INVALID, "thresholds must be >= 0");
+    if (i && thresholds_host[i] < thresholds_host[i - 1]) BSMI_FAIL(BSMI_ERR_INVALID, "thresholds must be ascending");
+  }
+  BSMI_HIP(hipSetDevice(h->device));
+  hipStream_t s = (hipStream_t)stream;
+  const int D = (int)shape[0], H = (int)shape[1], W = (int)shape[2];
+  const size_t n = (size_t)D * H * W;
+  AggWs& g = h->agg;
+  BSMI_HIP(hipMemcpyAsync(h->thr_dev, thresholds_host, sizeof(float) * n_thresholds, hipMemcpyHostToDevice, s));
+  BSMI_HIP(hipMemsetAsync(g.counters, 0, 8 * sizeof(uint32_t), s));
+  BSMI_HIP(hipMemsetAsync(g.maxid, 0, sizeof(uint64_t), s));
+  BSMI_HIP(hipMemsetAsync(g.rank_of_id, 0, (size_t)g.id_cap * sizeof(uint32_t), s));
+  BSMI_HIP(hipMemsetAsync(g.hkeys, 0xff, (size_t)g.hcap * sizeof(uint64_t), s));
+  BSMI_HIP(hipMemsetAsync(g.hsum, 0, (size_t)g.hcap * sizeof(unsigned long long), s));
+  BSMI_HIP(hipMemsetAsync(g.hcnt, 0, (size_t)g.hcap * sizeof(uint32_t), s));
+  const int bs = 256;
+  const int grid = (int)std::min<size_t>((n + bs - 1) / bs, 2048);
+  hipLaunchKernelGGL(agg_maxid_kernel, dim3(grid), dim3(bs), 0, s, frags_dev, n, g);
+  hipLaunchKernelGGL(agg_mark_kernel, dim3(grid), dim3(bs), 0, s, frags_dev, n, g);
+  hipLaunchKernelGGL(agg_rank_kernel, dim3(1), dim3(1024), 0, s, g);
+  hipLaunchKernelGGL(agg_edges_kernel, dim3(grid), dim3(bs), 0, s, affs_dev, frags_dev, D, H, W, g);
+  hipLaunchKernelGGL(agg_compact_kernel, dim3(std::min<uint32_t>(g.hcap / bs, 2048u)), dim3(bs), 0, s, g);
+  hipLaunchKernelGGL(agg_merge_kernel, dim3(1), dim3(64), 0, s, g, (const float*)h->thr_dev, n_thresholds);
+  hipLaunchKernelGGL(agg_relabel_kernel, dim3(grid), dim3(bs), 0, s, frags_dev, n, n_thresholds, g, segs_dev);
+  BSMI_HIP(hipGetLastError());
+  return BSMI_OK;
+}
+
+int bsmi_seg_status(bsmi_seg* h, void* stream) {
+  if (!h) BSMI_FAIL(BSMI_ERR_INVALID, "null handle");
+  BSMI_HIP(hipSetDevice(h->device));
+  uint32_t c[8];
+  BSMI_HIP(hipMemcpyAsync(c, h->agg.counters, sizeof c, hipMemcpyDeviceToHost, (hipStream_t)stream));
+  BSMI_HIP(hipStreamSynchronize((hipStream_t)stream));
+  if (c[3])
+    BSMI_FAIL(BSMI_ERR_OVERFLOW, "agglomeration workspace overflow (flags 0x%x: 1 id range, 2 nodes, 4 hash, 8 edges, 16 hash churn)", c[3]);
+  return BSMI_OK;
+}
+
+}  // extern "C"

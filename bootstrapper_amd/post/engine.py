@@ -1,0 +1,57 @@
+"""Handle around the libbsmi segmentation workspace (one per host thread per GPU)."""
+import ctypes as C
+
+import torch
+
+from .. import _lib
+from .._lib import lib, check
+
+
+class SegEngine:
+    def __init__(self, max_shape, device=0):
+        self.device = int(device)
+        self.max_shape = tuple(int(s) for s in max_shape)
+        self._h = C.c_void_p()
+        check(lib.bsmi_seg_create(self.device, _lib.i64x3(self.max_shape), C.byref(self._h)))
+
+    def __del__(self):
+        h = getattr(self, "_h", None)
+        if h:
+            lib.bsmi_seg_destroy(h)
+            self._h = None
+
+    def _stream(self):
+        return C.c_void_p(torch.cuda.current_stream(torch.device("cuda", self.device)).cuda_stream)
+
+    def ws_fragments(self, affs_u8, fragments_in_xy=True, min_seed_distance=10):
+        """affs_u8: uint8 CUDA tensor [3][D][H][W] -> (fragments int64 [D][H][W] holding the
+        uint64 ids, max_id tensor int64[1]); asynchronous on the current stream."""
+        if affs_u8.dtype != torch.uint8 or not affs_u8.is_cuda or affs_u8.dim() != 4 or affs_u8.shape[0] != 3:
+            raise ValueError("affs must be a uint8 CUDA tensor of shape (3, D, H, W)")
+        a = affs_u8.contiguous()
+        shape = a.shape[1:]
+        frags = torch.empty(tuple(shape), dtype=torch.int64, device=a.device)
+        max_id = torch.zeros(1, dtype=torch.int64, device=a.device)
+        check(lib.bsmi_ws_fragments_u8(self._h, C.c_void_p(a.data_ptr()), _lib.i64x3(shape),
+                                       1 if fragments_in_xy else 0, int(min_seed_distance),
+                                       C.c_void_p(frags.data_ptr()), C.c_void_p(max_id.data_ptr()), self._stream()))
+        return frags, max_id
+
+    def agglomerate_mean(self, affs_u8, frags, thresholds):
+        """-> int64 CUDA tensor [len(thresholds)][D][H][W]; asynchronous on the current stream
+        (call status() to synchronise and check the workspace did not overflow)."""
+        if affs_u8.dtype != torch.uint8 or not affs_u8.is_cuda or affs_u8.dim() != 4 or affs_u8.shape[0] != 3:
+            raise ValueError("affs must be a uint8 CUDA tensor of shape (3, D, H, W)")
+        if frags.dtype != torch.int64 or tuple(frags.shape) != tuple(affs_u8.shape[1:]):
+            raise ValueError("fragments must be an int64 tensor of shape (D, H, W)")
+        a = affs_u8.contiguous()
+        f = frags.contiguous()
+        thr = (C.c_float * len(thresholds))(*[float(t) for t in thresholds])
+        segs = torch.empty((len(thresholds),) + tuple(f.shape), dtype=torch.int64, device=a.device)
+        check(lib.bsmi_agglomerate_mean_u8(self._h, C.c_void_p(a.data_ptr()), C.c_void_p(f.data_ptr()),
+                                           _lib.i64x3(f.shape), thr, len(thresholds),
+                                           C.c_void_p(segs.data_ptr()), self._stream()))
+        return segs
+
+    def status(self):
+        check(lib.bsmi_seg_status(self._h, self._stream()))

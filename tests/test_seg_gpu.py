@@ -1,0 +1,125 @@
+"""Bit-exact parity of the HIP segmentation kernels (through the C ABI) with the golden
+fragments produced by the reference post/ws.py and with the C oracle.  Needs an MI355X."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _blobby(rng, shape, sigma):
+    from scipy.ndimage import gaussian_filter
+    a = gaussian_filter(rng.random((3,) + shape), sigma=(0,) + sigma)
+    a = (a - a.min()) / (a.max() - a.min())
+    return (a * 255).astype(np.uint8)
+
+
+def test_fragments_bit_exact_vs_reference_goldens(golden_dir):
+    from bootstrapper_amd.post.ws import watershed_from_affinities
+    d = np.load(os.path.join(golden_dir, "ws_cases.npz"))
+    names = sorted({k.split("/")[0] for k in d.files})
+    n_checked = 0
+    for name in names:
+        xy, msd, max_id = (int(v) for v in d[name + "/meta"])
+        if not xy:
+            continue  # 3-D flood mode: not implemented on the device (raises, tested below)
+        affs = torch.from_numpy(d[name + "/affs"]).cuda()
+        frags, mx = watershed_from_affinities(affs, fragments_in_xy=True, min_seed_distance=msd)
+        assert mx == max_id, name
+        assert np.array_equal(frags.cpu().numpy().astype(np.uint64), d[name + "/frags"].astype(np.uint64)), name
+        n_checked += 1
+    assert n_checked >= 12
+
+
+def test_fragments_3d_mode_raises():
+    from bootstrapper_amd.post.ws import watershed_from_affinities
+    from bootstrapper_amd._lib import BsmiError
+    with pytest.raises(BsmiError):
+        watershed_from_affinities(torch.zeros(3, 4, 8, 8, dtype=torch.uint8, device="cuda"), fragments_in_xy=False)
+
+
+@pytest.mark.parametrize("shape,sigma,msd", [((16, 128, 128), (1, 4, 4), 10), ((5, 160, 160), (1, 6, 6), 10),
+                                             ((3, 97, 131), (1, 2, 2), 7), ((2, 200, 64), (0, 1, 1), 10)])
+def test_fragments_bit_exact_vs_oracle(shape, sigma, msd):
+    from bootstrapper_amd.post.engine import SegEngine
+    from oracle import seg_ref as S
+    rng = np.random.default_rng(shape[1])
+    affs = _blobby(rng, shape, sigma)
+    ref, ref_max = S.ws_fragments_u8(affs, True, msd)
+    eng = SegEngine(shape)
+    frags, mx = eng.ws_fragments(torch.from_numpy(affs).cuda(), True, msd)
+    assert int(mx.item()) == ref_max
+    assert np.array_equal(frags.cpu().numpy().astype(np.uint64), ref)
+
+
+def test_fragments_white_noise_heap_spill():
+    """White-noise affinities: thousands of one-voxel seeds per slice -> exercises large heaps."""
+    from bootstrapper_amd.post.engine import SegEngine
+    from oracle import seg_ref as S
+    rng = np.random.default_rng(2)
+    affs = rng.integers(0, 256, size=(3, 2, 160, 160), dtype=np.uint8)
+    ref, ref_max = S.ws_fragments_u8(affs, True, 2)
+    eng = SegEngine(affs.shape[1:])
+    frags, mx = eng.ws_fragments(torch.from_numpy(affs).cuda(), True, 2)
+    assert int(mx.item()) == ref_max
+    assert np.array_equal(frags.cpu().numpy().astype(np.uint64), ref)
+
+
+@pytest.mark.parametrize("shape,sigma", [((12, 64, 64), (1, 3, 3)), ((32, 128, 128), (1, 4, 4)), ((4, 50, 70), (0, 1, 1))])
+def test_agglomeration_bit_exact_vs_oracle(shape, sigma):
+    from bootstrapper_amd.post.engine import SegEngine
+    from oracle import seg_ref as S
+    rng = np.random.default_rng(shape[0])
+    affs = _blobby(rng, shape, sigma)
+    frags, _ = S.ws_fragments_u8(affs, True, 10)
+    thresholds = [0.2, 0.35, 0.5]
+    ref = S.agglomerate_mean_u8(affs, frags, thresholds)
+    eng = SegEngine(shape)
+    segs = eng.agglomerate_mean(torch.from_numpy(affs).cuda(), torch.from_numpy(frags.astype(np.int64)).cuda(), thresholds)
+    eng.status()
+    got = segs.cpu().numpy().astype(np.uint64)
+    for t in range(len(thresholds)):
+        assert np.array_equal(got[t], ref[t]), f"threshold {thresholds[t]}"
+    # the segmentations are non-trivial on this input
+    assert len(np.unique(ref[2])) < len(np.unique(frags))
+
+
+def test_agglomeration_edge_cases():
+    from bootstrapper_amd.post.engine import SegEngine
+    from oracle import seg_ref as S
+    eng = SegEngine((4, 16, 16))
+    # no fragments at all; one fragment; sparse ids with gaps
+    affs = np.full((3, 4, 16, 16), 200, dtype=np.uint8)
+    for frags in (np.zeros((4, 16, 16), np.uint64), np.full((4, 16, 16), 7, np.uint64)):
+        ref = S.agglomerate_mean_u8(affs, frags, [0.5])
+        segs = eng.agglomerate_mean(torch.from_numpy(affs).cuda(), torch.from_numpy(frags.astype(np.int64)).cuda(), [0.5])
+        eng.status()
+        assert np.array_equal(segs[0].cpu().numpy().astype(np.uint64), ref[0])
+    frags = np.zeros((4, 16, 16), np.uint64)
+    frags[:, :8, :8] = 3; frags[:, :8, 8:] = 900; frags[:, 8:, :8] = 41; frags[:, 8:, 8:] = 40
+    affs = np.random.default_rng(0).integers(0, 256, size=(3, 4, 16, 16), dtype=np.uint8)
+    for thr in ([0.0], [0.3, 0.6, 0.9], [2.0]):
+        ref = S.agglomerate_mean_u8(affs, frags, thr)
+        segs = eng.agglomerate_mean(torch.from_numpy(affs).cuda(), torch.from_numpy(frags.astype(np.int64)).cuda(), thr)
+        eng.status()
+        for t in range(len(thr)):
+            assert np.array_equal(segs[t].cpu().numpy().astype(np.uint64), ref[t])
+
+
+def test_mirror_api_generator():
+    from bootstrapper_amd.post.ws import watershed_from_affinities
+    from bootstrapper_amd.post.waterz import agglomerate
+    from oracle import seg_ref as S
+    rng = np.random.default_rng(9)
+    affs = _blobby(rng, (6, 48, 48), (1, 3, 3))
+    a = torch.from_numpy(affs).cuda()
+    frags, n = watershed_from_affinities(a, fragments_in_xy=True, min_seed_distance=10)
+    ref_frags, ref_n = S.ws_fragments_u8(affs, True, 10)
+    assert n == ref_n
+    ref = S.agglomerate_mean_u8(affs, ref_frags, [0.2, 0.5])
+    for seg, r in zip(agglomerate(a, [0.2, 0.5], fragments=frags), ref):
+        assert np.array_equal(seg.cpu().numpy().astype(np.uint64), r)
+    with pytest.raises(NotImplementedError):
+        next(agglomerate(a, [0.2], fragments=frags, scoring_function="OneMinus<HistogramQuantileAffinity<RegionGraphType, 50, ScoreValue, 256, false>>"))
