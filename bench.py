@@ -1,0 +1,216 @@
+#!/usr/bin/env python3
+"""Headline benchmark: Mvoxels/s of predict + segment on a synthetic 1024^3 uint8 volume
+processed in 128^3 output blocks (BASELINE.json metric), one process per GPU.
+
+A "step" is one 128^3 output block taken through the whole hot path with its input already
+resident in HBM: reflect-padded (156,220,220) read -> 3-D U-Net (bf16 MFMA) -> uint8
+affinities -> seeded-watershed fragments -> mean-affinity agglomeration at thresholds
+[0.2, 0.35, 0.5].  Blocks are independent: with N ranks every rank takes its own K blocks
+(weak scaling, no data-path collective); the only collectives are the timing barrier and
+the max-over-ranks reduction.
+
+  python bench.py --gpus 1 --steps 32 --warmup 2
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+      --master-port P bench.py --gpus N --steps K --warmup W
+
+Prints ONE JSON line (rank 0) with the driver's contract fields plus `roofline` (implicit-GEMM
+conv kernels, HIP-event timed inside the timed region) and `cpu_baseline` (the repo's CPU
+restatement timed on this node's host cores; N=1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+NET_CONFIG = {  # reference models/3d_affs/net_config.json
+    "in_channels": 1, "num_fmaps": 12, "fmap_inc_factor": 5,
+    "downsample_factors": [[1, 2, 2], [1, 2, 2], [1, 2, 2]],
+    "kernel_size_down": [[[3, 3, 3], [3, 3, 3]]] * 4,
+    "kernel_size_up": [[[3, 3, 3], [3, 3, 3]]] * 3,
+    "outputs": {"3d_affs": {"dtype": "uint8", "dims": 6}},
+}
+OUT_BLOCK = (128, 128, 128)
+CONTEXT = (14, 46, 46)          # (input - output) / 2 of the 3-D nets (reference predict.py:127-131)
+THRESHOLDS = [0.2, 0.35, 0.5]   # reference segment.py:17
+BF16_DENSE_PEAK_TFLOPS = 2500.0  # /opt/skills/guides/MI355X_MICROARCH.md, dense bf16 MFMA
+
+
+def host_cores():
+    """Cores this process may really use: affinity mask, capped by the cgroup CPU quota and by
+    the per-GPU share of the box (16 host cores per GPU on the benchmark pool)."""
+    n = len(os.sched_getaffinity(0))
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return max(1, min(n, int(os.environ.get("BSMI_BENCH_CORES", "16"))))
+
+
+def cpu_baseline(model_flops_per_voxel, affs_u8_host):
+    """CPU restatement (oracle/) timed on this node's host cores on a bounded sample.
+
+    predict: torch-CPU fp32 network on one (32,196,196)->(4,104,104) block (1.53 TFLOP, the
+    reference's training block shape), all cores; converted to 128^3-block voxels/s through the
+    measured FLOP/s (the small block has a worse halo ratio than the benchmark's).
+    segment: C restatement of ws.py fragments + specified mean-affinity agglomeration on
+    (32,128,128) slabs of the affinities the GPU predicted, one slab per core concurrently."""
+    from concurrent.futures import ThreadPoolExecutor
+    from oracle import unet_ref as R
+    from oracle import seg_ref as S
+    from bootstrapper_amd.synth import synthetic_state_dict
+    cores = host_cores()
+    torch.set_num_threads(cores)
+    sd = synthetic_state_dict(NET_CONFIG, 0)
+    cfg = R.default_cfg(12, 5)
+    rng = np.random.default_rng(0)
+    raw = rng.integers(0, 256, size=(32, 196, 196), dtype=np.uint8)
+    # flops of the sample block, same accounting as the device planner (algorithmic)
+    from bootstrapper_amd.unet import Model
+    m = Model(NET_CONFIG)
+    sample_flops = m.flops(raw.shape)
+    t0 = time.perf_counter()
+    R.predict_block(cfg, sd, raw, ["affs_head"])
+    t_pred = time.perf_counter() - t0
+    cpu_flops = sample_flops / t_pred
+    pred_vox_s = cpu_flops / model_flops_per_voxel
+
+    slabs = [np.ascontiguousarray(affs_u8_host[:, z:z + 32]) for z in range(0, 128, 32)]
+    work = [slabs[i % len(slabs)] for i in range(cores)]
+
+    def seg_one(a):
+        frags, _ = S.ws_fragments_u8(a, True, 10)
+        S.agglomerate_mean_u8(a, frags, THRESHOLDS)
+        return a[0].size
+
+    t0 = time.perf_counter()
+    with ThreadPoolExecutor(max_workers=cores) as ex:
+        nvox = sum(ex.map(seg_one, work))
+    t_seg = time.perf_counter() - t0
+    seg_vox_s = nvox / t_seg
+    both = 1.0 / (1.0 / pred_vox_s + 1.0 / seg_vox_s)
+    return {
+        "value": both / 1e6, "unit": "Mvoxels/s", "cores": cores, "kind": "port",
+        "sample": (f"predict: torch-CPU fp32 restatement, 1 block (32,196,196)->(4,104,104), {t_pred:.1f} s, "
+                   f"{cpu_flops / 1e9:.0f} GFLOP/s -> {pred_vox_s / 1e3:.2f} kvox/s at 128^3 blocks; "
+                   f"segment: C restatement on {cores} (32,128,128) slabs of GPU-predicted affinities, one per core, "
+                   f"{t_seg:.1f} s -> {seg_vox_s / 1e6:.2f} Mvox/s"),
+        "predict_kvox_s": pred_vox_s / 1e3, "segment_Mvox_s": seg_vox_s / 1e6,
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=32)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--precision", default="bf16", choices=["bf16", "f32"])
+    ap.add_argument("--volume", type=int, default=1024, help="edge of the synthetic cubic volume")
+    ap.add_argument("--seg-lanes", type=int, default=4)
+    ap.add_argument("--no-segment", action="store_true", help="predict only (diagnostic; not the headline metric)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: there is no CPU fallback for the HIP path")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    from bootstrapper_amd.unet import Model
+    from bootstrapper_amd.synth import synthetic_state_dict, synthetic_volume
+    from bootstrapper_amd.pipeline import BlockPipeline, block_grid
+
+    model = Model(NET_CONFIG, device=local_rank, precision=args.precision).load_state_dict(synthetic_state_dict(NET_CONFIG, 0))
+    in_block = tuple(o + 2 * c for o, c in zip(OUT_BLOCK, CONTEXT))
+    flops_block = model.flops(in_block)
+    nvox_block = int(np.prod(OUT_BLOCK))
+
+    vol_shape = (args.volume,) * 3
+    vol = synthetic_volume(vol_shape, seed=0, device=dev)  # every rank holds the same volume in HBM
+    grid = block_grid(vol_shape, OUT_BLOCK)
+    # interleaved block -> rank map (reference predict.py:46-49: worker_id % num_gpus)
+    mine = [grid[(rank + i * world) % len(grid)] for i in range(args.warmup + args.steps)]
+
+    pipe = BlockPipeline(model, OUT_BLOCK, CONTEXT, THRESHOLDS, n_seg_lanes=args.seg_lanes,
+                         segment=not args.no_segment, device=local_rank)
+
+    def barrier():
+        torch.cuda.synchronize(dev)
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    # warmup (also allocates every workspace and the profiling events)
+    model.profile(True)
+    pipe.run(vol, mine[:args.warmup])
+    pipe.finish()
+    model.profile_totals(reset=True)
+    barrier()
+    t0 = time.perf_counter()
+    pipe.run(vol, mine[args.warmup:])
+    pipe.finish()
+    barrier()
+    dt = time.perf_counter() - t0
+    totals = model.profile_totals(reset=True)
+    model.profile(False)
+
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    conv_ms, conv_flops, conv_launches = totals["conv"]
+    achieved = conv_flops / (conv_ms * 1e-3) / 1e12 if conv_ms > 0 else 0.0
+    value = world * args.steps * nvox_block / dt / 1e6
+    out = {
+        "metric": "Mvoxels/s predict+segment, 1024^3 vol in 128^3 blocks" if not args.no_segment else "Mvoxels/s predict only (diagnostic)",
+        "value": value, "unit": "Mvoxels/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": args.precision, "data": "synthetic",
+        "config": {"workload": f"synthetic {args.volume}^3 uint8 volume, 128^3 output blocks (156,220,220 reads, reflect padded), "
+                               "3d_affs U-Net (94.7M params, seeded random weights) + xy seeded watershed + mean-affinity "
+                               "agglomeration at [0.2,0.35,0.5]",
+                   "blocks_per_gpu": args.steps, "parallelism": f"blocks interleaved over {world} GPU(s), no collectives",
+                   "seg_lanes": args.seg_lanes},
+        "roofline": {"bound": "mfma", "achieved": achieved, "peak": BF16_DENSE_PEAK_TFLOPS if args.precision == "bf16" else 157.3,
+                     "unit": "TFLOP/s", "frac": achieved / (BF16_DENSE_PEAK_TFLOPS if args.precision == "bf16" else 157.3),
+                     "traffic": None,
+                     "kernel": "bsmi::conv_igemm_kernel (all implicit-GEMM launches of the U-Net)",
+                     "launches": int(conv_launches), "avg_launch_ms": conv_ms / max(conv_launches, 1),
+                     "algorithmic_tflop_per_block": flops_block / 1e12,
+                     "other_unet_ms_per_block": sum(totals[k][0] for k in ("input", "pool", "upsample", "head")) / max(args.steps, 1)},
+    }
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        # affinities of one block for the CPU segment sample
+        raw = torch.empty(0)
+        from bootstrapper_amd.unet import extract_block_reflect
+        raw = extract_block_reflect(vol, [o - c for o, c in zip(mine[0], CONTEXT)], in_block)
+        affs = model.predict_u8(raw)[0][:3].cpu().numpy()
+        out["cpu_baseline"] = cpu_baseline(flops_block / nvox_block, affs)
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,91 @@
+"""Per-GPU block pipeline: the HIP-stream replacement of the reference's chunk scheduler
+for one worker.
+
+Reference being replaced (paths relative to /root/reference/bootstrapper):
+  predict.py:22-49      daisy task per block, one worker process per GPU
+  models/3d_affs/predict.py:128-162  gp.Scan / DaisyRequestBlocks loop: one model(input)
+                        per block, reflect-padded reads, uint8 writes into the block's write ROI
+  post/watershed.py:206-354  fragments + agglomeration on the predicted affinities
+
+Blocks are independent (read_write_conflict=False, predict.py:37): block i's U-Net runs on
+the predict stream while the sequential-at-heart segmentation kernels of blocks i-1, i-2, ...
+run on `n_seg_lanes` other streams, each with its own workspace.  No collectives.
+"""
+import torch
+
+from .unet import extract_block_reflect
+from .post.engine import SegEngine
+
+
+class BlockPipeline:
+    def __init__(self, model, out_block, context, thresholds=(0.2, 0.35, 0.5), min_seed_distance=10,
+                 n_seg_lanes=4, segment=True, device=0, keep_outputs=False):
+        self.model = model
+        self.out_block = tuple(out_block)
+        self.context = tuple(context)
+        self.in_block = tuple(o + 2 * c for o, c in zip(out_block, context))
+        if model.output_shape(self.in_block) != self.out_block:
+            raise ValueError(f"network maps {self.in_block} to {model.output_shape(self.in_block)}, not {self.out_block}")
+        self.thresholds = list(thresholds)
+        self.msd = int(min_seed_distance)
+        self.segment = bool(segment)
+        self.dev = torch.device("cuda", device)
+        self.keep = keep_outputs
+        self.pred_stream = torch.cuda.Stream(self.dev)
+        self.lanes = []
+        if self.segment:
+            for _ in range(n_seg_lanes):
+                self.lanes.append(dict(engine=SegEngine(self.out_block, device), stream=torch.cuda.Stream(self.dev),
+                                       done=None, affs=None))
+        self.n_done = 0
+        self.results = []
+
+    def run(self, volume_u8, block_offsets):
+        """volume_u8: uint8 CUDA tensor (D,H,W) resident in HBM; block_offsets: output-block
+        origins (z,y,x) in voxels.  Returns after all work is queued; call finish()."""
+        for i, off in enumerate(block_offsets):
+            lane = self.lanes[i % len(self.lanes)] if self.segment else None
+            with torch.cuda.stream(self.pred_stream):
+                if lane is not None and lane["done"] is not None:
+                    # the lane's previous affinity buffer is recycled by the allocator only after
+                    # its segmentation finished
+                    self.pred_stream.wait_event(lane["done"])
+                raw = extract_block_reflect(volume_u8, [o - c for o, c in zip(off, self.context)], self.in_block)
+                u8 = self.model.predict_u8(raw)
+                ready = torch.cuda.Event()
+                ready.record(self.pred_stream)
+            if lane is None:
+                if self.keep:
+                    self.results.append((off, u8, None, None))
+                continue
+            with torch.cuda.stream(lane["stream"]):
+                lane["stream"].wait_event(ready)
+                affs = u8[0][:3]
+                frags, max_id = lane["engine"].ws_fragments(affs, True, self.msd)
+                segs = lane["engine"].agglomerate_mean(affs, frags, self.thresholds)
+                for t in (raw, affs, frags, segs) + tuple(u8):
+                    t.record_stream(lane["stream"])
+                done = torch.cuda.Event()
+                done.record(lane["stream"])
+                lane["done"] = done
+            if self.keep:
+                self.results.append((off, u8, frags, segs))
+            self.n_done += 1
+
+    def finish(self):
+        self.pred_stream.synchronize()
+        for lane in self.lanes:
+            lane["stream"].synchronize()
+            lane["engine"].status()
+        out, self.results = self.results, []
+        return out
+
+
+def block_grid(vol_shape, out_block):
+    """Output-block origins covering vol_shape (fit='overhang', predict.py:39), z-major."""
+    offs = []
+    for z in range(0, vol_shape[0], out_block[0]):
+        for y in range(0, vol_shape[1], out_block[1]):
+            for x in range(0, vol_shape[2], out_block[2]):
+                offs.append((z, y, x))
+    return offs

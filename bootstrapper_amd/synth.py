@@ -52,12 +52,12 @@ def synthetic_volume(shape, seed=0, device="cuda", corr=(2, 8, 8)):
     fine = torch.nn.functional.interpolate(coarse[None, None], size=tuple(int(l * c) for l, c in zip(lo, corr)),
                                            mode="trilinear", align_corners=False)[0, 0]
     fine = fine[: shape[0], : shape[1], : shape[2]]
-    g2 = torch.Generator(device="cpu").manual_seed(seed + 1)
-    # white noise generated in z-slabs to bound host memory
+    g2 = torch.Generator(device=device).manual_seed(seed + 1)
+    # white noise generated slice by slice to bound memory
     out = torch.empty(shape, dtype=torch.uint8, device=device)
     lo_v, hi_v = float(fine.min()), float(fine.max())
     for z in range(shape[0]):
-        n = torch.rand(shape[1:], generator=g2, dtype=torch.float32).to(device)
+        n = torch.rand(shape[1:], generator=g2, dtype=torch.float32, device=device)
         v = (fine[z] - lo_v) / max(hi_v - lo_v, 1e-6) * 0.9 + n * 0.1
         out[z] = (v.clamp(0, 1) * 255).to(torch.uint8)
     return out

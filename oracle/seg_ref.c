@@ -309,7 +309,7 @@ typedef struct {
   uint8_t deleted, stale;
 } edge_t;
 
-static edge_t *g_edges;
+static __thread edge_t *g_edges; /* per-thread: the cpu_baseline leg runs one volume per core */
 static inline int q_less(const qitem *a, const qitem *b) {
   if (a->score != b->score) return a->score < b->score;
   return g_edges[a->e].key0 < g_edges[b->e].key0;
