@@ -11,20 +11,23 @@ struct ConvTensor {
   int D, H, W, C;
 };
 
-// One K-step of the implicit GEMM: `nsub` 32-byte sub-steps (16 bf16 / 8 f32
-// channels each) of tensor `tensor`, starting `a_off` elements after the row's
-// base voxel (tap offset + crop origin + channel-chunk start, folded on the host).
+// One K-step of the implicit GEMM = 4 "units" of 32 bytes of K (16 bf16 / 8 f32 channels
+// each) taken from ONE source tensor.  Unit j of the row of output voxel (z,y,x) is read at
+//   base + z*sz + y*sy + x*sx + delta[j]          (all in bytes)
+// where delta[j] folds the unit's kernel tap, crop origin and channel offset (host side).
+// A many-channel layer has delta = {c, c+32, c+64, c+96}; a 16-channel layer packs four
+// kernel taps into one K-step.  Unused units point at delta 0 and meet all-zero weights.
 struct KStep {
-  int32_t tensor;
-  int32_t a_off;
-  int32_t nsub;
+  uint64_t base;
+  int32_t sz, sy, sx;
+  int32_t delta[4];
   int32_t pad;
 };
+static_assert(sizeof(KStep) == 40, "KStep layout");
 
 constexpr int kMaxConvTensors = 3;
 
 struct ConvArgs {
-  ConvTensor t[kMaxConvTensors];
   const KStep* steps;  // device
   int nsteps;
   const void* w;      // device, packed [nsteps][Npad][128 bytes]

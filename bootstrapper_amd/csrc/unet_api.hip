@@ -44,14 +44,17 @@ struct HostWeight {
   bool loaded = false;
 };
 
+// One 32-byte unit of K: 16 (bf16) / 8 (f32) consecutive channels of one kernel tap of one
+// source tensor.  Four units of the same tensor slot form a K-step.
 struct PackEntry {
   int slot;        // tensor slot of the launch
   int dz, dy, dx;  // tap offset (voxels) relative to the slot's origin
-  int c0, nsub;    // channel chunk start (elements) and valid 32-byte sub-steps
+  int c0;          // first channel of the unit
   int wsrc;        // 0 = this stage's conv weight, 1 = residual 1x1x1 weight
   int tap;         // flat tap index into the weight's kernel dims
   int cin_base;    // first input channel of this slot inside the weight's Cin dim
   int creal;       // real channels of the slot
+  bool dummy;      // filler: delta 0, all-zero weights
 };
 
 struct PackedConv {
@@ -152,33 +155,37 @@ static void register_pass(bsmi_unet* h, const PassSite& p) {
   expect_weight(h, p.prefix + ".residual.0.bias", {p.cout});
 }
 
-// Build the K-step entry list of stage `ci` of a ConvPass (precision dependent chunking).
+// Build the unit list of stage `ci` of a ConvPass: 4 consecutive entries = one K-step, all
+// from the same tensor slot.  Units are ordered 64-channel-chunk-major with the kernel taps
+// inside, so consecutive K-steps re-read the same channel chunk of neighbouring voxels
+// (L1/L2 hits); a 16-channel tensor packs four taps per K-step.
 static void build_entries(const PassSite& p, int ci, int prec, std::vector<PackEntry>& out) {
-  const int BKE = bke(prec), SUB = sube(prec);
+  const int SUB = sube(prec);
   const bool last = ci == p.nconv - 1;
-  auto add_chunks = [&](int slot, int dz, int dy, int dx, int wsrc, int tap, int cin_base, int creal) {
+  std::vector<PackEntry> per_slot[kMaxConvTensors];
+  auto add_taps = [&](int slot, const int* k, int cin_base, int creal) {
     const int cpad = round_up(creal, kChanPad);
-    for (int c0 = 0; c0 < cpad; c0 += BKE) {
-      PackEntry e;
-      e.slot = slot; e.dz = dz; e.dy = dy; e.dx = dx; e.c0 = c0;
-      e.nsub = std::min(BKE / SUB, (cpad - c0) / SUB);
-      e.wsrc = wsrc; e.tap = tap; e.cin_base = cin_base; e.creal = creal;
-      out.push_back(e);
-    }
+    for (int c64 = 0; c64 < cpad; c64 += 4 * SUB)
+      for (int z = 0; z < k[0]; ++z)
+        for (int y = 0; y < k[1]; ++y)
+          for (int x = 0; x < k[2]; ++x)
+            for (int c0 = c64; c0 < std::min(cpad, c64 + 4 * SUB); c0 += SUB)
+              per_slot[slot].push_back(PackEntry{slot, z, y, x, c0, 0, (z * k[1] + y) * k[2] + x, cin_base, creal, false});
+  };
+  auto add_residual = [&](int slot, const int* crop, int cin_base, int creal) {
+    const int cpad = round_up(creal, kChanPad);
+    for (int c0 = 0; c0 < cpad; c0 += SUB)
+      per_slot[slot].push_back(PackEntry{slot, crop[0] / 2, crop[1] / 2, crop[2] / 2, c0, 1, 0, cin_base, creal, false});
   };
   const int* k = p.k[ci];
   if (ci == 0) {
     int base = 0;
     for (int s = 0; s < p.nslots; ++s) {
-      for (int z = 0; z < k[0]; ++z)
-        for (int y = 0; y < k[1]; ++y)
-          for (int x = 0; x < k[2]; ++x) add_chunks(s, z, y, x, 0, (z * k[1] + y) * k[2] + x, base, p.cin[s]);
+      add_taps(s, k, base, p.cin[s]);
       base += p.cin[s];
     }
   } else {
-    for (int z = 0; z < k[0]; ++z)
-      for (int y = 0; y < k[1]; ++y)
-        for (int x = 0; x < k[2]; ++x) add_chunks(0, z, y, x, 0, (z * k[1] + y) * k[2] + x, 0, p.cout);
+    add_taps(0, k, 0, p.cout);
   }
   if (last) {
     int crop[3] = {0, 0, 0};
@@ -187,9 +194,14 @@ static void build_entries(const PassSite& p, int ci, int prec, std::vector<PackE
     const int first_slot = ci == 0 ? 0 : 1;
     int base = 0;
     for (int s = 0; s < p.nslots; ++s) {
-      add_chunks(first_slot + s, crop[0] / 2, crop[1] / 2, crop[2] / 2, 1, 0, base, p.cin[s]);
+      add_residual(first_slot + s, crop, base, p.cin[s]);
       base += p.cin[s];
     }
+  }
+  for (int s = 0; s < kMaxConvTensors; ++s) {
+    auto& v = per_slot[s];
+    while (v.size() % 4) v.push_back(PackEntry{s, 0, 0, 0, 0, 0, 0, 0, 0, true});
+    out.insert(out.end(), v.begin(), v.end());
   }
 }
 
@@ -208,22 +220,25 @@ static int pack_conv(bsmi_unet* h, PassSite& p, int ci, int prec) {
   const HostWeight& br = h->weights[p.prefix + ".residual.0.bias"];
   const int64_t cin_m = wm.shape[1], ntap_m = wm.shape[2] * wm.shape[3] * wm.shape[4];
   const int64_t cin_r = wr.shape[1];
-  const size_t nsteps = pc.entries.size();
+  const int SUB = sube(prec);
+  const size_t nsteps = pc.entries.size() / 4;
   const size_t nelem = nsteps * (size_t)pc.Npad * BKE;
   std::vector<float> bias(pc.Npad, 0.f);
   for (int n = 0; n < p.cout; ++n) bias[n] = bm.data[n] + (last ? br.data[n] : 0.f);
 
   std::vector<uint8_t> packed(nelem * esize(prec), 0);
-  for (size_t s = 0; s < nsteps; ++s) {
-    const PackEntry& e = pc.entries[s];
+  for (size_t u = 0; u < pc.entries.size(); ++u) {
+    const PackEntry& e = pc.entries[u];
+    if (e.dummy) continue;
+    const size_t s = u / 4, j = u % 4;
     for (int n = 0; n < p.cout; ++n) {
-      for (int kk = 0; kk < BKE; ++kk) {
+      for (int kk = 0; kk < SUB; ++kk) {
         const int c = e.c0 + kk;
         if (c >= e.creal) break;
         float v;
         if (e.wsrc == 0) v = wm.data[((size_t)n * cin_m + (e.cin_base + c)) * ntap_m + e.tap];
         else v = wr.data[(size_t)n * cin_r + (e.cin_base + c)];
-        const size_t idx = (s * pc.Npad + n) * BKE + kk;
+        const size_t idx = (s * pc.Npad + n) * BKE + j * SUB + kk;
         if (prec == BSMI_PREC_F32) ((float*)packed.data())[idx] = v;
         else ((uint16_t*)packed.data())[idx] = host_f32_to_bf16(v);
       }
@@ -247,8 +262,8 @@ struct Planner {
     t.Cpad = round_up(t.C, kChanPad);
     const size_t bytes = (size_t)t.D * t.H * t.W * t.Cpad * esize(prec);
     plan->bytes += bytes;
-    if (bytes >= ((size_t)1 << 32) / 2 * (size_t)esize(prec))
-      BSMI_FAIL(BSMI_ERR_INVALID, "activation tensor of %zu bytes exceeds 32-bit element offsets", bytes);
+    if (bytes >= ((size_t)1 << 31))
+      BSMI_FAIL(BSMI_ERR_INVALID, "activation tensor of %zu bytes exceeds the 31-bit byte offsets of the conv kernel", bytes);
     if (dry) return BSMI_OK;
     BSMI_HIP(hipMalloc(&t.ptr, bytes));
     plan->allocs.push_back(t.ptr);
@@ -302,7 +317,7 @@ struct Planner {
       {
         std::vector<PackEntry> ents;
         build_entries(p, ci, prec, ents);
-        for (auto& e : ents) kreal += std::max(0, std::min(e.creal - e.c0, bke(prec)));
+        for (auto& e : ents) if (!e.dummy) kreal += std::max(0, std::min(e.creal - e.c0, sube(prec)));
       }
       plan->flops += 2.0 * M * p.cout * kreal;
 
@@ -313,21 +328,25 @@ struct Planner {
         st.tile = pc.tile;
         ConvArgs& a = st.conv;
         memset(&a, 0, sizeof a);
-        for (int s = 0; s < kMaxConvTensors; ++s) {
-          if (s < nsl) a.t[s] = ConvTensor{slots[s].ptr, slots[s].D, slots[s].H, slots[s].W, slots[s].Cpad};
-          else a.t[s] = ConvTensor{slots[0].ptr, 0, 0, 0, 0};
-        }
-        std::vector<KStep> ks(pc.entries.size());
-        for (size_t s = 0; s < pc.entries.size(); ++s) {
-          const PackEntry& e = pc.entries[s];
-          const TDesc& t = slots[e.slot];
-          const int64_t off = ((((int64_t)(e.dz + so[e.slot][0]) * t.H) + (e.dy + so[e.slot][1])) * t.W +
-                               (e.dx + so[e.slot][2])) * t.Cpad + e.c0;
-          // last voxel row read by the last output voxel stays inside the tensor by
-          // construction of the valid conv; guard the 32-bit offset range anyway
-          if (off < 0 || off + (int64_t)t.D * t.H * t.W * t.Cpad >= ((int64_t)1 << 31))
-            BSMI_FAIL(BSMI_ERR_INVALID, "%s: K-step offset out of 32-bit range", p.prefix.c_str());
-          ks[s] = KStep{e.slot, (int32_t)off, e.nsub, 0};
+        std::vector<KStep> ks(pc.entries.size() / 4);
+        const int64_t es = esize(prec);
+        for (size_t s = 0; s < ks.size(); ++s) {
+          const int slot = pc.entries[4 * s].slot;
+          const TDesc& t = slots[slot];
+          KStep k;
+          memset(&k, 0, sizeof k);
+          k.base = (uint64_t)(uintptr_t)t.ptr;
+          k.sz = (int32_t)((int64_t)t.H * t.W * t.Cpad * es);
+          k.sy = (int32_t)((int64_t)t.W * t.Cpad * es);
+          k.sx = (int32_t)((int64_t)t.Cpad * es);
+          for (int j = 0; j < 4; ++j) {
+            const PackEntry& e = pc.entries[4 * s + j];
+            if (e.dummy) continue;
+            const int64_t off = ((((int64_t)(e.dz + so[slot][0]) * t.H) + (e.dy + so[slot][1])) * t.W +
+                                 (e.dx + so[slot][2])) * t.Cpad + e.c0;
+            k.delta[j] = (int32_t)(off * es);
+          }
+          ks[s] = k;
         }
         KStep* dks = nullptr;
         BSMI_HIP(hipMalloc((void**)&dks, ks.size() * sizeof(KStep)));
