@@ -4,7 +4,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libbsmi.so")
+# BSMI_LIB: developer knob to A/B another build of the same library (never a fallback)
+LIB_PATH = os.environ.get("BSMI_LIB") or os.path.join(_HERE, "libbsmi.so")
 
 MAX_LEVELS, MAX_CONVS, MAX_HEADS, NAME_LEN = 8, 4, 4, 32
 PREC_F32, PREC_BF16 = 0, 1

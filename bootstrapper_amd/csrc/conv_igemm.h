@@ -11,26 +11,37 @@ struct ConvTensor {
   int D, H, W, C;
 };
 
-// One K-step of the implicit GEMM = 4 "units" of 32 bytes of K (16 bf16 / 8 f32 channels
-// each) taken from ONE source tensor.  Unit j of the row of output voxel (z,y,x) is read at
-//   base + z*sz + y*sy + x*sx + delta[j]          (all in bytes)
+// One K-step of the implicit GEMM = 2 "units" of 32 bytes of K (16 bf16 / 8 f32 channels
+// each) taken from ONE source tensor (`tensor` indexes ConvArgs::t).  Unit j of the row of
+// output voxel (z,y,x) is read at
+//   t.base + z*t.sz + y*t.sy + x*t.sx + delta[j]          (all in bytes)
 // where delta[j] folds the unit's kernel tap, crop origin and channel offset (host side).
-// A many-channel layer has delta = {c, c+32, c+64, c+96}; a 16-channel layer packs four
-// kernel taps into one K-step.  Unused units point at delta 0 and meet all-zero weights.
+// A many-channel layer walks its channels 32 at a time; a 16-channel layer packs two kernel
+// taps into one K-step.  An unused unit points at delta 0 and meets all-zero weights.
 struct KStep {
-  uint64_t base;
-  int32_t sz, sy, sx;
-  int32_t delta[4];
+  int32_t tensor;
+  int32_t delta[2];
   int32_t pad;
 };
-static_assert(sizeof(KStep) == 40, "KStep layout");
+static_assert(sizeof(KStep) == 16, "KStep layout");
+
+struct ConvSrc {
+  uint64_t base;       // device pointer of the channels-last source tensor
+  int32_t sz, sy, sx;  // byte strides of one step in z, y, x
+  int32_t pad;
+};
+
+constexpr int kUnitsPerStep = 2;
+constexpr int kStepRowBytes = 64;   // bytes of K per tile row per K-step
+constexpr int kWeightRowSlack = 64; // weight rows readable past Npad (tile loads are padded to 64 rows)
 
 constexpr int kMaxConvTensors = 3;
 
 struct ConvArgs {
+  ConvSrc t[kMaxConvTensors];
   const KStep* steps;  // device
   int nsteps;
-  const void* w;      // device, packed [nsteps][Npad][128 bytes]
+  const void* w;      // device, packed [nsteps][Npad][64 bytes] (+ kWeightRowSlack rows)
   const float* bias;  // device [Npad]
   void* out;          // device [Do][Ho][Wo][Co]
   int Do, Ho, Wo, Co;

@@ -3,15 +3,15 @@
 // GEMM view of a ConvPass layer (reference models/3d_affs/unet.py:7-76):
 //   out[m][n] = act( bias[n] + sum_{step} sum_{k} A_step[m][k] * W_step[n][k] )
 // where m runs over output voxels (z,y,x raster order), n over output channels and
-// each K-step is four 32-byte units (kernel tap, 16-channel group) of one source tensor.  The cropped
+// each K-step is two 32-byte units (kernel tap, 16-channel group) of one source tensor.  The cropped
 // 1x1x1 residual branch of ConvPass (unet.py:38-41,67-71) and the channel concat of
 // Upsample.forward (unet.py:223) are just more K-steps reading other tensors, so a
 // whole ConvPass stage is one launch with a fused bias(+ReLU) epilogue.
 //
 // Data layout: activations channels-last [D][H][W][Cpad]; weights pre-packed on the
-// host as [step][Npad][128 B] (k contiguous), zero padded.  Tiles are staged
-// HBM/L2 -> LDS by LDS-DMA as [row][128 B] images with a 16-byte-chunk XOR swizzle
-// (chunk ^= (row>>1)&7) so that the ds_read_b128 fragment reads of
+// host as [step][Npad][64 B] (k contiguous), zero padded.  Tiles are staged
+// HBM/L2 -> LDS by LDS-DMA as [row][64 B] images with a 16-byte-chunk XOR swizzle
+// (chunk ^= (row>>2)&3) so that the ds_read_b128 fragment reads of
 // v_mfma_f32_32x32x16_bf16 / v_mfma_f32_32x32x2_f32 are bank-conflict free.
 #include "conv_igemm.h"
 
@@ -58,37 +58,44 @@ typedef const __attribute__((address_space(1))) char* gptr_t;
 typedef __attribute__((address_space(3))) char* lptr_t;
 typedef const __attribute__((address_space(4))) int32_t* cint_ptr_t;  // constant AS: scalar loads
 
-// T: element type; BM x BN block tile; WM x WN waves (4 waves = one per SIMD, so each wave
-// may use the whole 512-register file: large register tiles, few LDS reads per MFMA).
+// T: element type; BM x BN block tile; WM x WN = 4 waves (one per SIMD, so each wave may use
+// the whole 512-register file: 128x128 register tiles, few LDS reads per MFMA).
 //
-// Staging is LDS-DMA (global_load_lds_dwordx4): one wave instruction moves 8 tile rows x
-// 128 B = 1 KiB; lane l lands at row (l>>3), 16-byte slot (l&7) of that KiB, and FETCHES the
-// source chunk (l&7) ^ ((row>>1)&7): the swizzle is applied on the per-lane source address,
-// the LDS image stays lane-linear.  Two LDS stages; stage s+1 is in flight while stage s is
-// multiplied; one barrier per K-step, placed before the last sub-step's MFMAs so that the
-// fragment reads of the next K-step are issued under them.
+// Staging is LDS-DMA (global_load_lds_dwordx4) into a ring of NSLOT = 4 K-step slots of
+// [BM + BNL rows][64 B].  One wave instruction moves 16 tile rows x 64 B = 1 KiB: lane l lands
+// at row (l>>2), 16-byte slot (l&3) of that KiB and FETCHES the source chunk
+// (l&3) ^ ((row>>2)&3): the bank swizzle is applied on the per-lane source address, the LDS
+// image stays lane-linear, and the ds_read_b128 fragment reads (same XOR) are conflict free.
+// The loads of K-steps h+2..h+4 are in flight while K-step h is multiplied (counted vmcnt,
+// raw s_barrier); the single barrier of a K-step sits between its two MFMA groups.
 template <typename T, int BM, int BN, int WM, int WN>
 __global__ __launch_bounds__(64 * WM * WN, 1) void conv_igemm_kernel(const ConvArgs a) {
   constexpr int NW = WM * WN;
-  constexpr int ROWB = 128;  // bytes per tile row per K-step
+  static_assert(NW == 4, "one wave per SIMD");
+  constexpr int ROWB = kStepRowBytes;
+  constexpr int NSLOT = 4;
   constexpr int WTM = BM / WM, WTN = BN / WN;
   constexpr int FM = WTM / 32, FN = WTN / 32;
-  constexpr int A_INSTR = BM / 8 / NW, B_INSTR = BN / 8 / NW;  // LDS-DMA instructions per wave per K-step
-  constexpr int STAGE = (BM + BN) * ROWB;
-  static_assert(BM % (8 * NW) == 0 && BN % (8 * NW) == 0, "tile/wave mismatch");
+  constexpr int BNL = (BN + 63) / 64 * 64;                       // weight rows staged per K-step
+  constexpr int A_INSTR = BM / 16 / NW, B_INSTR = BNL / 16 / NW;  // LDS-DMA instructions per wave per K-step
+  constexpr int G = A_INSTR + B_INSTR;
+  constexpr int SLOT = (BM + BNL) * ROWB;
+  static_assert(BM % (16 * NW) == 0, "tile/wave mismatch");
   static_assert(WTM % 32 == 0 && WTN % 32 == 0, "wave tile must be a multiple of 32");
+  static_assert(3 * G <= 63, "vmcnt range");
 
-  extern __shared__ __attribute__((aligned(16))) char smem[];  // [2][A: BM rows | B: BN rows][128 B]
+  extern __shared__ __attribute__((aligned(16))) char smem[];  // [NSLOT][A: BM rows | B: BNL rows][64 B]
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave / WN, wn = wave % WN;
-  const cint_ptr_t steps = (cint_ptr_t)a.steps;  // 10 dwords per K-step
+  const cint_ptr_t steps = (cint_ptr_t)a.steps;  // 4 dwords per K-step
   const int nsteps = a.nsteps;
 
   // XCD-aware tile map: consecutive block ids are dealt round-robin to the 8 XCDs, so give
-  // each XCD a contiguous run of tiles (same weight panel, neighbouring row panels -> L2 hits)
+  // each XCD a contiguous run of tiles; n fastest, so the blocks resident on one XCD cover few
+  // row panels x all weight panels and the tap re-reads of an activation line hit its L2.
   const int mt = (a.M + BM - 1) / BM, ntn = a.Npad / BN;
   const int ntiles = mt * ntn;
   int tile;
@@ -97,29 +104,36 @@ __global__ __launch_bounds__(64 * WM * WN, 1) void conv_igemm_kernel(const ConvA
     const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
     tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + j;
   }
-  const int tile_n = tile / mt, tile_m = tile - tile_n * mt;
+  const int tile_m = tile / ntn, tile_n = tile - tile_m * ntn;
   const int m0 = tile_m * BM, n0 = tile_n * BN;
 
-  const int lrow = lane >> 3, lchunk = lane & 7;
-  // tile rows staged by this lane: row(i) = (i*NW + wave)*8 + lrow.  NW*8 is a multiple of 16,
-  // so the swizzle key (row>>1)&7 -- hence the source chunk, its unit and 16-byte half -- is
-  // the same for every i.
-  static_assert((NW * 8) % 16 == 0, "swizzle key must not depend on the instruction index");
-  const int skey = ((wave * 8 + lrow) >> 1) & 7;
-  const int g = lchunk ^ skey;            // source chunk that lands in LDS slot lchunk
-  const int unit = g >> 1;                // which of the K-step's 4 units this lane fetches
+  // rows staged by this lane: row(i) = (i*NW + wave)*16 + (lane>>2); the swizzle key
+  // (row>>2)&3 = (lane>>4)&3 does not depend on i or on the wave.
+  const int lrow = lane >> 2, lchunk = lane & 3;
+  const int skey = (lane >> 4) & 3;
+  const int g = lchunk ^ skey;             // source chunk that lands in LDS slot lchunk
+  const bool unit1 = (g >> 1) != 0;        // which of the K-step's 2 units this lane fetches
   const uint32_t hoff = (uint32_t)((g & 1) << 4);
-  uint32_t zyx[A_INSTR];                  // output voxel of row(i), packed z:10 | y:11 | x:11
+  // byte offset of row(i)'s output voxel inside each source tensor
+  uint32_t rowoff[kMaxConvTensors][A_INSTR];
 #pragma unroll
   for (int i = 0; i < A_INSTR; ++i) {
-    const int row = (i * NW + wave) * 8 + lrow;
+    const int row = (i * NW + wave) * 16 + lrow;
     int m = m0 + row;
     m = m < a.M ? m : a.M - 1;
     const int x = m % a.Wo;
     const int zy = m / a.Wo;
-    zyx[i] = ((uint32_t)(zy / a.Ho) << 22) | ((uint32_t)(zy % a.Ho) << 11) | (uint32_t)x;
+    const int y = zy % a.Ho, z = zy / a.Ho;
+#pragma unroll
+    for (int t = 0; t < kMaxConvTensors; ++t)
+      rowoff[t][i] = (uint32_t)(z * a.t[t].sz + y * a.t[t].sy + x * a.t[t].sx);
   }
-  const uint32_t offb = (uint32_t)((n0 + wave * 8 + lrow) * ROWB + ((lchunk ^ skey) << 4));
+  uint32_t cur[A_INSTR];  // rowoff of the tensor the K-steps currently read
+#pragma unroll
+  for (int i = 0; i < A_INSTR; ++i) cur[i] = rowoff[0][i];
+  int cur_t = 0;
+  uint64_t cur_base = a.t[0].base;
+  const uint32_t offb = (uint32_t)((n0 + wave * 16 + lrow) * ROWB + ((lchunk ^ skey) << 4));
   const size_t wstep = (size_t)a.Npad * ROWB;
 
   f32x16_t acc[FM][FN];
@@ -130,26 +144,33 @@ __global__ __launch_bounds__(64 * WM * WN, 1) void conv_igemm_kernel(const ConvA
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  auto issue = [&](int s, int buf) {
-    const cint_ptr_t d = steps + s * 10;
-    const uint64_t base = (uint64_t)(uint32_t)d[0] | ((uint64_t)(uint32_t)d[1] << 32);
-    const int sz = d[2], sy = d[3], sx = d[4];
-    const int d0 = d[5], d1 = d[6], d2 = d[7], d3 = d[8];
-    const gptr_t abase = (gptr_t)base;
-    const gptr_t wbase = (gptr_t)a.w + (size_t)s * wstep;
-    const lptr_t la = (lptr_t)(smem + buf * STAGE);
-    const lptr_t lb = la + BM * ROWB;
-    const int dl = unit == 0 ? d0 : (unit == 1 ? d1 : (unit == 2 ? d2 : d3));
-    const uint32_t lofs = (uint32_t)dl + hoff;
+  // descriptor of K-step h (clamped), as three scalars
+  struct Desc { int t, d0, d1; };
+  auto fetch = [&](int h) -> Desc {
+    const cint_ptr_t d = steps + (h < nsteps ? h : nsteps - 1) * 4;
+    return Desc{d[0], d[1], d[2]};
+  };
+  auto issue = [&](int h, const Desc& ds) {
+#ifdef BSMI_ABLATE_NOLOAD  // timing experiment: multiply whatever is in LDS
+    if (h > 3) return;
+#endif
+    if (ds.t != cur_t) {  // wave-uniform, rare: the K-steps moved on to another source tensor
+      cur_t = ds.t;
+      cur_base = ds.t == 1 ? a.t[1].base : (ds.t == 2 ? a.t[2].base : a.t[0].base);
 #pragma unroll
-    for (int i = 0; i < A_INSTR; ++i) {
-      const int z = (int)(zyx[i] >> 22), y = (int)((zyx[i] >> 11) & 0x7ff), x = (int)(zyx[i] & 0x7ff);
-      const uint32_t voff = (uint32_t)(z * sz + y * sy + x * sx) + lofs;
-      __builtin_amdgcn_global_load_lds(abase + voff, la + (i * NW + wave) * 1024, 16, 0, 0);
+      for (int i = 0; i < A_INSTR; ++i) cur[i] = ds.t == 1 ? rowoff[1][i] : (ds.t == 2 ? rowoff[2][i] : rowoff[0][i]);
     }
+    const uint32_t lofs = (uint32_t)(unit1 ? ds.d1 : ds.d0) + hoff;
+    const gptr_t abase = (gptr_t)cur_base;
+    const gptr_t wbase = (gptr_t)a.w + (size_t)h * wstep;
+    const lptr_t la = (lptr_t)(smem + (h & (NSLOT - 1)) * SLOT);
+    const lptr_t lb = la + BM * ROWB;
+#pragma unroll
+    for (int i = 0; i < A_INSTR; ++i)
+      __builtin_amdgcn_global_load_lds(abase + (size_t)(cur[i] + lofs), la + (i * NW + wave) * 1024, 16, 0, 0);
 #pragma unroll
     for (int i = 0; i < B_INSTR; ++i)
-      __builtin_amdgcn_global_load_lds(wbase + (size_t)i * NW * 8 * ROWB + offb, lb + (i * NW + wave) * 1024, 16, 0, 0);
+      __builtin_amdgcn_global_load_lds(wbase + (size_t)i * NW * 16 * ROWB + offb, lb + (i * NW + wave) * 1024, 16, 0, 0);
   };
 
   const int lr = lane & 31, lh = lane >> 5;
@@ -159,13 +180,13 @@ __global__ __launch_bounds__(64 * WM * WN, 1) void conv_igemm_kernel(const ConvA
   for (int i = 0; i < FM; ++i) {
     const int row = wm * WTM + i * 32 + lr;
     arow[i] = row * ROWB;
-    akey[i] = (row >> 1) & 7;
+    akey[i] = (row >> 2) & 3;
   }
 #pragma unroll
   for (int j = 0; j < FN; ++j) {
     const int row = wn * WTN + j * 32 + lr;
     brow[j] = BM * ROWB + row * ROWB;
-    bkey[j] = (row >> 1) & 7;
+    bkey[j] = (row >> 2) & 3;
   }
 
   u32x4_t fa[2][FM], fb[2][FN];  // fragment double buffer, indexed by compile-time constants only
@@ -177,43 +198,46 @@ __global__ __launch_bounds__(64 * WM * WN, 1) void conv_igemm_kernel(const ConvA
     for (int j = 0; j < FN; ++j) pb[j] = *(const u32x4_t*)(st + brow[j] + ((c ^ bkey[j]) << 4));
   };
   auto mma = [&](const u32x4_t* pa, const u32x4_t* pb) {
+#ifdef BSMI_ABLATE_NOMMA  // timing experiment: keep the fragment reads alive, skip the MFMAs
+#pragma unroll
+    for (int i = 0; i < FM; ++i) asm volatile("" ::"v"(pa[i]));
+#pragma unroll
+    for (int j = 0; j < FN; ++j) asm volatile("" ::"v"(pb[j]));
+    return;
+#endif
 #pragma unroll
     for (int i = 0; i < FM; ++i)
 #pragma unroll
       for (int j = 0; j < FN; ++j) acc[i][j] = Elem<T>::mfma(pa[i], pb[j], acc[i][j]);
   };
-  // K-step boundary: stage s+1 has landed everywhere and everybody is done reading stage s;
-  // refill this stage's buffer with stage s+2 and fetch the first fragments of stage s+1.
-  auto boundary = [&](int s) {
-    if (s + 1 < nsteps) {
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __builtin_amdgcn_s_barrier();
-      if (s + 2 < nsteps) issue(s + 2, s & 1);
-      load_frags(smem + ((s + 1) & 1) * STAGE, 0, fa[0], fb[0]);
-    }
-  };
 
-  issue(0, 0);
-  if (nsteps > 1) {
-    issue(1, 1);
-    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(A_INSTR + B_INSTR) : "memory");
-  } else {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  }
+  // prologue: K-steps 0..2 in flight, wait for K-step 0
+  issue(0, fetch(0));
+  if (nsteps > 1) issue(1, fetch(1));
+  if (nsteps > 2) issue(2, fetch(2));
+  if (nsteps > 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * G) : "memory");
+  else if (nsteps > 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(G) : "memory");
+  else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
   load_frags(smem, 0, fa[0], fb[0]);
+  if (nsteps > 3) issue(3, fetch(3));
+  Desc dnext = fetch(4);
 
-  for (int s = 0; s < nsteps; ++s) {
-    const char* st = smem + (s & 1) * STAGE;
+  for (int h = 0; h < nsteps; ++h) {
+    const char* st = smem + (h & (NSLOT - 1)) * SLOT;
     load_frags(st, 1, fa[1], fb[1]);
     mma(fa[0], fb[0]);
-    load_frags(st, 2, fa[0], fb[0]);
-    mma(fa[1], fb[1]);
-    load_frags(st, 3, fa[1], fb[1]);
-    mma(fa[0], fb[0]);
-    // fa[1]/fb[1] (sub-step 3) must be in registers before anyone may overwrite the stage
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    boundary(s);
+    // K-step boundary.  fa[1]/fb[1] must be in registers before anyone may overwrite this
+    // slot; K-step h+1 must have landed everywhere before it is read.  Loads issued after
+    // K-step h+1 (h+2, h+3) may stay in flight.
+    const int later = nsteps - 2 - h;  // K-steps issued after h+1
+    if (later >= 2) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(2 * G) : "memory");
+    else if (later == 1) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(G) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (h + 4 < nsteps) issue(h + 4, dnext);
+    dnext = fetch(h + 5);
+    if (h + 1 < nsteps) load_frags(smem + ((h + 1) & (NSLOT - 1)) * SLOT, 0, fa[0], fb[0]);
     mma(fa[1], fb[1]);
   }
 
@@ -273,7 +297,7 @@ TileCfg choose_tile(int cout) {
 
 template <typename T, int BM, int BN, int WM, int WN>
 static int launch_one(const ConvArgs& a, hipStream_t stream) {
-  constexpr int smem = 2 * (BM + BN) * 128;
+  constexpr int smem = 4 * (BM + (BN + 63) / 64 * 64) * kStepRowBytes;
   static bool attr_set = false;
   auto kern = conv_igemm_kernel<T, BM, BN, WM, WN>;
   if (!attr_set) {

@@ -45,7 +45,7 @@ struct HostWeight {
 };
 
 // One 32-byte unit of K: 16 (bf16) / 8 (f32) consecutive channels of one kernel tap of one
-// source tensor.  Four units of the same tensor slot form a K-step.
+// source tensor.  kUnitsPerStep units of the same tensor slot form a K-step.
 struct PackEntry {
   int slot;        // tensor slot of the launch
   int dz, dy, dx;  // tap offset (voxels) relative to the slot's origin
@@ -133,7 +133,7 @@ struct bsmi_unet {
 namespace bsmi {
 
 static int esize(int prec) { return prec == BSMI_PREC_F32 ? 4 : 2; }
-static int bke(int prec) { return 128 / esize(prec); }   // elements per K-step row
+static int bke(int prec) { return kStepRowBytes / esize(prec); }   // elements per K-step row
 static int sube(int prec) { return 32 / esize(prec); }   // elements per 32-byte sub-step
 
 static void expect_weight(bsmi_unet* h, const std::string& key, std::vector<int64_t> shape) {
@@ -155,21 +155,21 @@ static void register_pass(bsmi_unet* h, const PassSite& p) {
   expect_weight(h, p.prefix + ".residual.0.bias", {p.cout});
 }
 
-// Build the unit list of stage `ci` of a ConvPass: 4 consecutive entries = one K-step, all
-// from the same tensor slot.  Units are ordered 64-channel-chunk-major with the kernel taps
-// inside, so consecutive K-steps re-read the same channel chunk of neighbouring voxels
-// (L1/L2 hits); a 16-channel tensor packs four taps per K-step.
+// Build the unit list of stage `ci` of a ConvPass: kUnitsPerStep consecutive entries = one
+// K-step, all from the same tensor slot.  Units are ordered channel-chunk-major with the
+// kernel taps inside, so consecutive K-steps re-read the same channel chunk of neighbouring
+// voxels (L2 hits); a 16-channel tensor packs two taps per K-step.
 static void build_entries(const PassSite& p, int ci, int prec, std::vector<PackEntry>& out) {
   const int SUB = sube(prec);
   const bool last = ci == p.nconv - 1;
   std::vector<PackEntry> per_slot[kMaxConvTensors];
   auto add_taps = [&](int slot, const int* k, int cin_base, int creal) {
     const int cpad = round_up(creal, kChanPad);
-    for (int c64 = 0; c64 < cpad; c64 += 4 * SUB)
+    for (int c64 = 0; c64 < cpad; c64 += kUnitsPerStep * SUB)
       for (int z = 0; z < k[0]; ++z)
         for (int y = 0; y < k[1]; ++y)
           for (int x = 0; x < k[2]; ++x)
-            for (int c0 = c64; c0 < std::min(cpad, c64 + 4 * SUB); c0 += SUB)
+            for (int c0 = c64; c0 < std::min(cpad, c64 + kUnitsPerStep * SUB); c0 += SUB)
               per_slot[slot].push_back(PackEntry{slot, z, y, x, c0, 0, (z * k[1] + y) * k[2] + x, cin_base, creal, false});
   };
   auto add_residual = [&](int slot, const int* crop, int cin_base, int creal) {
@@ -200,7 +200,7 @@ static void build_entries(const PassSite& p, int ci, int prec, std::vector<PackE
   }
   for (int s = 0; s < kMaxConvTensors; ++s) {
     auto& v = per_slot[s];
-    while (v.size() % 4) v.push_back(PackEntry{s, 0, 0, 0, 0, 0, 0, 0, 0, true});
+    while (v.size() % kUnitsPerStep) v.push_back(PackEntry{s, 0, 0, 0, 0, 0, 0, 0, 0, true});
     out.insert(out.end(), v.begin(), v.end());
   }
 }
@@ -221,8 +221,8 @@ static int pack_conv(bsmi_unet* h, PassSite& p, int ci, int prec) {
   const int64_t cin_m = wm.shape[1], ntap_m = wm.shape[2] * wm.shape[3] * wm.shape[4];
   const int64_t cin_r = wr.shape[1];
   const int SUB = sube(prec);
-  const size_t nsteps = pc.entries.size() / 4;
-  const size_t nelem = nsteps * (size_t)pc.Npad * BKE;
+  const size_t nsteps = pc.entries.size() / kUnitsPerStep;
+  const size_t nelem = (nsteps * (size_t)pc.Npad + kWeightRowSlack) * BKE;  // slack rows: padded tile loads
   std::vector<float> bias(pc.Npad, 0.f);
   for (int n = 0; n < p.cout; ++n) bias[n] = bm.data[n] + (last ? br.data[n] : 0.f);
 
@@ -230,7 +230,7 @@ static int pack_conv(bsmi_unet* h, PassSite& p, int ci, int prec) {
   for (size_t u = 0; u < pc.entries.size(); ++u) {
     const PackEntry& e = pc.entries[u];
     if (e.dummy) continue;
-    const size_t s = u / 4, j = u % 4;
+    const size_t s = u / kUnitsPerStep, j = u % kUnitsPerStep;
     for (int n = 0; n < p.cout; ++n) {
       for (int kk = 0; kk < SUB; ++kk) {
         const int c = e.c0 + kk;
@@ -328,19 +328,23 @@ struct Planner {
         st.tile = pc.tile;
         ConvArgs& a = st.conv;
         memset(&a, 0, sizeof a);
-        std::vector<KStep> ks(pc.entries.size() / 4);
+        std::vector<KStep> ks(pc.entries.size() / kUnitsPerStep);
         const int64_t es = esize(prec);
+        for (int sl = 0; sl < kMaxConvTensors; ++sl) {
+          const TDesc& t = slots[sl < nsl ? sl : 0];
+          a.t[sl].base = (uint64_t)(uintptr_t)t.ptr;
+          a.t[sl].sz = (int32_t)((int64_t)t.H * t.W * t.Cpad * es);
+          a.t[sl].sy = (int32_t)((int64_t)t.W * t.Cpad * es);
+          a.t[sl].sx = (int32_t)((int64_t)t.Cpad * es);
+        }
         for (size_t s = 0; s < ks.size(); ++s) {
-          const int slot = pc.entries[4 * s].slot;
+          const int slot = pc.entries[kUnitsPerStep * s].slot;
           const TDesc& t = slots[slot];
           KStep k;
           memset(&k, 0, sizeof k);
-          k.base = (uint64_t)(uintptr_t)t.ptr;
-          k.sz = (int32_t)((int64_t)t.H * t.W * t.Cpad * es);
-          k.sy = (int32_t)((int64_t)t.W * t.Cpad * es);
-          k.sx = (int32_t)((int64_t)t.Cpad * es);
-          for (int j = 0; j < 4; ++j) {
-            const PackEntry& e = pc.entries[4 * s + j];
+          k.tensor = slot;
+          for (int j = 0; j < kUnitsPerStep; ++j) {
+            const PackEntry& e = pc.entries[kUnitsPerStep * s + j];
             if (e.dummy) continue;
             const int64_t off = ((((int64_t)(e.dz + so[slot][0]) * t.H) + (e.dy + so[slot][1])) * t.W +
                                  (e.dx + so[slot][2])) * t.Cpad + e.c0;
