@@ -116,6 +116,7 @@ def main():
     ap.add_argument("--precision", default="bf16", choices=["bf16", "f32"])
     ap.add_argument("--volume", type=int, default=1024, help="edge of the synthetic cubic volume")
     ap.add_argument("--seg-lanes", type=int, default=4)
+    ap.add_argument("--pred-lanes", type=int, default=2, help="U-Net replicas / predict streams per GPU")
     ap.add_argument("--no-segment", action="store_true", help="predict only (diagnostic; not the headline metric)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
@@ -138,7 +139,10 @@ def main():
     from bootstrapper_amd.synth import synthetic_state_dict, synthetic_volume
     from bootstrapper_amd.pipeline import BlockPipeline, block_grid
 
-    model = Model(NET_CONFIG, device=local_rank, precision=args.precision).load_state_dict(synthetic_state_dict(NET_CONFIG, 0))
+    sd = synthetic_state_dict(NET_CONFIG, 0)
+    models = [Model(NET_CONFIG, device=local_rank, precision=args.precision).load_state_dict(sd)
+              for _ in range(max(1, args.pred_lanes))]
+    model = models[0]
     in_block = tuple(o + 2 * c for o, c in zip(OUT_BLOCK, CONTEXT))
     flops_block = model.flops(in_block)
     nvox_block = int(np.prod(OUT_BLOCK))
@@ -147,10 +151,11 @@ def main():
     vol = synthetic_volume(vol_shape, seed=0, device=dev)  # every rank holds the same volume in HBM
     grid = block_grid(vol_shape, OUT_BLOCK)
     # interleaved block -> rank map (reference predict.py:46-49: worker_id % num_gpus)
-    mine = [grid[(rank + i * world) % len(grid)] for i in range(args.warmup + args.steps)]
+    n_warm = max(args.warmup, max(1, args.pred_lanes))
+    mine = [grid[(rank + i * world) % len(grid)] for i in range(n_warm + args.steps)]
 
     pipe = BlockPipeline(model, OUT_BLOCK, CONTEXT, THRESHOLDS, n_seg_lanes=args.seg_lanes,
-                         segment=not args.no_segment, device=local_rank)
+                         segment=not args.no_segment, device=local_rank, models=models)
 
     def barrier():
         torch.cuda.synchronize(dev)
@@ -159,18 +164,23 @@ def main():
         torch.cuda.synchronize(dev)
 
     # warmup (also allocates every workspace and the profiling events)
-    model.profile(True)
-    pipe.run(vol, mine[:args.warmup])
+    for m in models:
+        m.profile(True)
+    pipe.run(vol, mine[:n_warm])
     pipe.finish()
-    model.profile_totals(reset=True)
+    for m in models:
+        m.profile_totals(reset=True)
     barrier()
     t0 = time.perf_counter()
-    pipe.run(vol, mine[args.warmup:])
+    pipe.run(vol, mine[n_warm:])
     pipe.finish()
     barrier()
     dt = time.perf_counter() - t0
-    totals = model.profile_totals(reset=True)
-    model.profile(False)
+    totals = None
+    for m in models:
+        t = m.profile_totals(reset=True)
+        m.profile(False)
+        totals = t if totals is None else {k: tuple(a + b for a, b in zip(totals[k], t[k])) for k in t}
 
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
@@ -189,7 +199,7 @@ def main():
                                "3d_affs U-Net (94.7M params, seeded random weights) + xy seeded watershed + mean-affinity "
                                "agglomeration at [0.2,0.35,0.5]",
                    "blocks_per_gpu": args.steps, "parallelism": f"blocks interleaved over {world} GPU(s), no collectives",
-                   "seg_lanes": args.seg_lanes},
+                   "seg_lanes": args.seg_lanes, "pred_lanes": len(models)},
         "roofline": {"bound": "mfma", "achieved": achieved, "peak": BF16_DENSE_PEAK_TFLOPS if args.precision == "bf16" else 157.3,
                      "unit": "TFLOP/s", "frac": achieved / (BF16_DENSE_PEAK_TFLOPS if args.precision == "bf16" else 157.3),
                      "traffic": None,

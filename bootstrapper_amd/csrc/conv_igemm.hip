@@ -114,8 +114,10 @@ __global__ __launch_bounds__(64 * WM * WN, 1) void conv_igemm_kernel(const ConvA
   const int g = lchunk ^ skey;             // source chunk that lands in LDS slot lchunk
   const bool unit1 = (g >> 1) != 0;        // which of the K-step's 2 units this lane fetches
   const uint32_t hoff = (uint32_t)((g & 1) << 4);
-  // byte offset of row(i)'s output voxel inside each source tensor
-  uint32_t rowoff[kMaxConvTensors][A_INSTR];
+  // byte offset of row(i)'s output voxel inside each source tensor (three named arrays: a
+  // runtime-indexed array would live in scratch and its reload would drain vmcnt every K-step)
+  static_assert(kMaxConvTensors == 3, "three source slots");
+  uint32_t ro0[A_INSTR], ro1[A_INSTR], ro2[A_INSTR];
 #pragma unroll
   for (int i = 0; i < A_INSTR; ++i) {
     const int row = (i * NW + wave) * 16 + lrow;
@@ -124,15 +126,16 @@ __global__ __launch_bounds__(64 * WM * WN, 1) void conv_igemm_kernel(const ConvA
     const int x = m % a.Wo;
     const int zy = m / a.Wo;
     const int y = zy % a.Ho, z = zy / a.Ho;
-#pragma unroll
-    for (int t = 0; t < kMaxConvTensors; ++t)
-      rowoff[t][i] = (uint32_t)(z * a.t[t].sz + y * a.t[t].sy + x * a.t[t].sx);
+    ro0[i] = (uint32_t)(z * a.t[0].sz + y * a.t[0].sy + x * a.t[0].sx);
+    ro1[i] = (uint32_t)(z * a.t[1].sz + y * a.t[1].sy + x * a.t[1].sx);
+    ro2[i] = (uint32_t)(z * a.t[2].sz + y * a.t[2].sy + x * a.t[2].sx);
   }
-  uint32_t cur[A_INSTR];  // rowoff of the tensor the K-steps currently read
+  uint32_t cur[A_INSTR];  // row offsets of the tensor the K-steps currently read
 #pragma unroll
-  for (int i = 0; i < A_INSTR; ++i) cur[i] = rowoff[0][i];
+  for (int i = 0; i < A_INSTR; ++i) cur[i] = ro0[i];
   int cur_t = 0;
-  uint64_t cur_base = a.t[0].base;
+  const uint64_t base0 = a.t[0].base, base1 = a.t[1].base, base2 = a.t[2].base;
+  uint64_t cur_base = base0;
   const uint32_t offb = (uint32_t)((n0 + wave * 16 + lrow) * ROWB + ((lchunk ^ skey) << 4));
   const size_t wstep = (size_t)a.Npad * ROWB;
 
@@ -156,9 +159,19 @@ __global__ __launch_bounds__(64 * WM * WN, 1) void conv_igemm_kernel(const ConvA
 #endif
     if (ds.t != cur_t) {  // wave-uniform, rare: the K-steps moved on to another source tensor
       cur_t = ds.t;
-      cur_base = ds.t == 1 ? a.t[1].base : (ds.t == 2 ? a.t[2].base : a.t[0].base);
+      if (ds.t == 0) {
+        cur_base = base0;
 #pragma unroll
-      for (int i = 0; i < A_INSTR; ++i) cur[i] = ds.t == 1 ? rowoff[1][i] : (ds.t == 2 ? rowoff[2][i] : rowoff[0][i]);
+        for (int i = 0; i < A_INSTR; ++i) cur[i] = ro0[i];
+      } else if (ds.t == 1) {
+        cur_base = base1;
+#pragma unroll
+        for (int i = 0; i < A_INSTR; ++i) cur[i] = ro1[i];
+      } else {
+        cur_base = base2;
+#pragma unroll
+        for (int i = 0; i < A_INSTR; ++i) cur[i] = ro2[i];
+      }
     }
     const uint32_t lofs = (uint32_t)(unit1 ? ds.d1 : ds.d0) + hoff;
     const gptr_t abase = (gptr_t)cur_base;

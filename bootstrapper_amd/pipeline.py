@@ -19,8 +19,12 @@ from .post.engine import SegEngine
 
 class BlockPipeline:
     def __init__(self, model, out_block, context, thresholds=(0.2, 0.35, 0.5), min_seed_distance=10,
-                 n_seg_lanes=4, segment=True, device=0, keep_outputs=False):
-        self.model = model
+                 n_seg_lanes=4, segment=True, device=0, keep_outputs=False, models=None):
+        # `models`: optional list of Model replicas (same weights), one per predict stream.  Two
+        # predict streams let the last, partially filled round of workgroups of one block's
+        # conv launch overlap with the other block's launches (each replica owns its activations).
+        self.models = list(models) if models else [model]
+        self.model = model = self.models[0]
         self.out_block = tuple(out_block)
         self.context = tuple(context)
         self.in_block = tuple(o + 2 * c for o, c in zip(out_block, context))
@@ -31,7 +35,7 @@ class BlockPipeline:
         self.segment = bool(segment)
         self.dev = torch.device("cuda", device)
         self.keep = keep_outputs
-        self.pred_stream = torch.cuda.Stream(self.dev)
+        self.pred_streams = [torch.cuda.Stream(self.dev) for _ in self.models]
         self.lanes = []
         if self.segment:
             for _ in range(n_seg_lanes):
@@ -45,15 +49,15 @@ class BlockPipeline:
         origins (z,y,x) in voxels.  Returns after all work is queued; call finish()."""
         for i, off in enumerate(block_offsets):
             lane = self.lanes[i % len(self.lanes)] if self.segment else None
-            with torch.cuda.stream(self.pred_stream):
+            pstream = self.pred_streams[i % len(self.models)]
+            with torch.cuda.stream(pstream):
                 if lane is not None and lane["done"] is not None:
-                    # the lane's previous affinity buffer is recycled by the allocator only after
-                    # its segmentation finished
-                    self.pred_stream.wait_event(lane["done"])
+                    # bound the run-ahead: a lane takes a new block only after its previous one
+                    pstream.wait_event(lane["done"])
                 raw = extract_block_reflect(volume_u8, [o - c for o, c in zip(off, self.context)], self.in_block)
-                u8 = self.model.predict_u8(raw)
+                u8 = self.models[i % len(self.models)].predict_u8(raw)
                 ready = torch.cuda.Event()
-                ready.record(self.pred_stream)
+                ready.record(pstream)
             if lane is None:
                 if self.keep:
                     self.results.append((off, u8, None, None))
@@ -73,7 +77,8 @@ class BlockPipeline:
             self.n_done += 1
 
     def finish(self):
-        self.pred_stream.synchronize()
+        for ps in self.pred_streams:
+            ps.synchronize()
         for lane in self.lanes:
             lane["stream"].synchronize()
             lane["engine"].status()
