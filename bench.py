@@ -23,6 +23,11 @@ import os
 import sys
 import time
 
+# one hardware queue per HIP stream of the pipeline (predict lanes + segmentation lanes): with
+# the runtime default of 4, streams share queues and a long sequential segmentation kernel
+# stalls the predict stream queued behind it.  Must be set before the HIP runtime starts.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "24")
+
 import numpy as np
 import torch
 
@@ -115,7 +120,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--precision", default="bf16", choices=["bf16", "f32"])
     ap.add_argument("--volume", type=int, default=1024, help="edge of the synthetic cubic volume")
-    ap.add_argument("--seg-lanes", type=int, default=4)
+    ap.add_argument("--seg-lanes", type=int, default=8)
     ap.add_argument("--pred-lanes", type=int, default=2, help="U-Net replicas / predict streams per GPU")
     ap.add_argument("--no-segment", action="store_true", help="predict only (diagnostic; not the headline metric)")
     ap.add_argument("--no-cpu-baseline", action="store_true")

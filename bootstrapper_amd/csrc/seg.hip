@@ -23,7 +23,8 @@ namespace bsmi {
 // watershed fragments
 // ------------------------------------------------------------------------------------------
 constexpr int WS_T = 256;            // threads per slice workgroup (seeds kernel)
-constexpr int FLOOD_LDS_HEAP = 8192; // heap entries kept in LDS (8 B each); the rest spills to HBM
+constexpr int FLOOD_WAVES = 16;     // slices per flood workgroup (one wave each): a workgroup pins its CU, so pack it
+constexpr int FLOOD_LDS_HEAP = 1024; // heap entries per slice kept in LDS (8 B each); the rest spills to HBM
 
 __device__ __forceinline__ int reflect_dup(int i, int n) {
   const int p = 2 * n;
@@ -133,8 +134,22 @@ __global__ __launch_bounds__(WS_T) void ws_seeds_kernel(const uint8_t* __restric
     mf[i] = m;
   }
   __syncthreads();
-  // d/e. maxima and their 4-connected components (union-find, smaller index wins)
-  for (int i = tid; i < n; i += WS_T) par[i] = (mf[i] == d2[i]) ? i : -1;
+  // d/e. maxima and their 4-connected components.  Rows are labelled as runs first (each
+  // maximum points at the first voxel of its run), then vertically adjacent runs are united
+  // once, at the first column where they overlap (union-find, smaller index wins).
+  for (int y = tid; y < H; y += WS_T) {
+    int start = -1;
+    for (int x = 0; x < W; ++x) {
+      const int i = y * W + x;
+      if (mf[i] == d2[i]) {
+        if (start < 0) start = i;
+        par[i] = start;
+      } else {
+        par[i] = -1;
+        start = -1;
+      }
+    }
+  }
   __syncthreads();
   auto find = [&](int a) {
     int p = par[a];
@@ -156,10 +171,10 @@ __global__ __launch_bounds__(WS_T) void ws_seeds_kernel(const uint8_t* __restric
     }
   };
   for (int i = tid; i < n; i += WS_T) {
-    if (par[i] < 0) continue;
-    const int y = i / W, x = i - y * W;
-    if (x > 0 && par[i - 1] >= 0) unite(i, i - 1);
-    if (y > 0 && par[i - W] >= 0) unite(i, i - W);
+    if (i < W || par[i] < 0 || par[i - W] < 0) continue;
+    const int x = i % W;
+    if (x > 0 && par[i - 1] >= 0 && par[i - W - 1] >= 0) continue;  // this run pair was united further left
+    unite(i, i - W);
   }
   __syncthreads();
   // raster-order numbering of the roots (scipy.ndimage.label): chunked scan
@@ -199,16 +214,19 @@ __global__ void ws_offsets_kernel(int D, WsScratch s, uint64_t* max_id) {
 // Ordering ignores the index bits (skimage compares (value, age) only).
 __device__ __forceinline__ bool flood_smaller(uint64_t a, uint64_t b) { return (a >> 20) < (b >> 20); }
 
-__global__ __launch_bounds__(64) void ws_flood_kernel(int D, int H, int W, WsScratch s, uint64_t* heap_spill,
+__global__ __launch_bounds__(64 * FLOOD_WAVES) void ws_flood_kernel(int D, int H, int W, WsScratch s, uint64_t* heap_spill,
                                                      size_t spill_stride, uint64_t* __restrict__ frags, int* status) {
-  __shared__ uint64_t hl[FLOOD_LDS_HEAP];
-  const int z = blockIdx.x;
+  __shared__ uint64_t hl_all[FLOOD_WAVES][FLOOD_LDS_HEAP];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int z = blockIdx.x * FLOOD_WAVES + wave;
+  if (z >= D) return;  // whole wave exits; no workgroup barrier is used below
+  uint64_t* hl = hl_all[wave];
   const int n = H * W;
   const uint8_t* mask = s.mask + (size_t)z * n;
   const int32_t* d2 = s.d2 + (size_t)z * n;
   int32_t* lab = s.lab + (size_t)z * n;
   uint64_t* hg = heap_spill + (size_t)z * spill_stride;  // entries >= FLOOD_LDS_HEAP live here
-  if (threadIdx.x == 0) {
+  if (lane == 0) {
     constexpr uint64_t MAXD2 = (1u << 24) - 1;
     int items = 0;
     auto hget = [&](int i) -> uint64_t { return i < FLOOD_LDS_HEAP ? hl[i] : hg[i - FLOOD_LDS_HEAP]; };
@@ -267,10 +285,13 @@ __global__ __launch_bounds__(64) void ws_flood_kernel(int D, int H, int W, WsScr
       }
     }
   }
-  __syncthreads();
+  // lane 0's label writes become visible to the other lanes of its wave in program order
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
   const uint64_t off = s.offs[z];
   uint64_t* out = frags + (size_t)z * n;
-  for (int i = threadIdx.x; i < n; i += 64) {
+  for (int i = lane; i < n; i += 64) {
     const int l = lab[i];
     out[i] = l ? (uint64_t)l + off : 0ull;
   }
@@ -707,7 +728,7 @@ int bsmi_ws_fragments_u8(bsmi_seg* h, const uint8_t* affs_dev, const int64_t sha
   const int D = (int)shape[0], H = (int)shape[1], W = (int)shape[2];
   hipLaunchKernelGGL(ws_seeds_kernel, dim3(D), dim3(WS_T), 0, s, affs_dev, D, H, W, min_seed_distance, h->ws);
   hipLaunchKernelGGL(ws_offsets_kernel, dim3(1), dim3(64), 0, s, D, h->ws, max_id_dev);
-  hipLaunchKernelGGL(ws_flood_kernel, dim3(D), dim3(64), 0, s, D, H, W, h->ws, h->flood_spill, h->flood_spill_stride,
+  hipLaunchKernelGGL(ws_flood_kernel, dim3((D + FLOOD_WAVES - 1) / FLOOD_WAVES), dim3(64 * FLOOD_WAVES), 0, s, D, H, W, h->ws, h->flood_spill, h->flood_spill_stride,
                      frags_dev, h->status_dev);
   BSMI_HIP(hipGetLastError());
   return BSMI_OK;

@@ -35,7 +35,8 @@ class BlockPipeline:
         self.segment = bool(segment)
         self.dev = torch.device("cuda", device)
         self.keep = keep_outputs
-        self.pred_streams = [torch.cuda.Stream(self.dev) for _ in self.models]
+        # conv launches first: predict streams get the high priority
+        self.pred_streams = [torch.cuda.Stream(self.dev, priority=-1) for _ in self.models]
         self.lanes = []
         if self.segment:
             for _ in range(n_seg_lanes):
