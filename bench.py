@@ -121,7 +121,7 @@ def main():
     ap.add_argument("--precision", default="bf16", choices=["bf16", "f32"])
     ap.add_argument("--volume", type=int, default=1024, help="edge of the synthetic cubic volume")
     ap.add_argument("--seg-lanes", type=int, default=8)
-    ap.add_argument("--pred-lanes", type=int, default=2, help="U-Net replicas / predict streams per GPU")
+    ap.add_argument("--pred-lanes", type=int, default=1, help="U-Net replicas / predict streams per GPU")
     ap.add_argument("--no-segment", action="store_true", help="predict only (diagnostic; not the headline metric)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()

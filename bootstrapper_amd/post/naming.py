@@ -1,0 +1,68 @@
+"""Dataset names derived from segmentation parameters.
+
+Behavioural mirror of /root/reference/bootstrapper/post/naming.py:7-70 (`build_name`, `fmt`,
+`dump_params`, `dump_lut_params`); pinned by tests/golden/host_cases.json, which was produced by
+running the reference.  The names are part of the drop-in surface: downstream configs refer
+to `<seg_dataset_prefix>/<build_name(params)>`.
+"""
+import json
+
+import numpy as np
+
+# (parameter, short code) in the order the codes appear in a name
+_ORDER = (
+    ("merge_function", "mf"), ("threshold", "t"), ("global_bias", "gb"), ("fragments_in_xy", "xy"),
+    ("min_seed_distance", "msd"), ("seed_eps", "seps"), ("epsilon_agglomerate", "ea"), ("sigma", "sig"),
+    ("noise_eps", "eps"), ("bias", "b"), ("strides", "st"), ("randomized_strides", "rs"),
+    ("filter_fragments", "ff"), ("remove_debris", "rd"),
+)
+
+
+def fmt(value, sep="_"):
+    """Scalars: %g for floats, str otherwise.  Sequences: elements joined by `sep` (nested
+    levels by '.'), collapsing to a single element when all elements render the same."""
+    if isinstance(value, (list, tuple)):
+        rendered = [fmt(v, sep=".") for v in value]
+        if len(set(rendered)) == 1:
+            return rendered[0]
+        return sep.join(rendered)
+    if isinstance(value, float):
+        return "%g" % value
+    return str(value)
+
+
+def build_name(params):
+    """'--'-joined `<code><value>` pieces for every known, non-None parameter; a boolean renders
+    as the bare code (True) or `<code>0` (False)."""
+    pieces = []
+    for key, code in _ORDER:
+        value = params.get(key)
+        if value is None:
+            continue
+        if isinstance(value, bool):
+            pieces.append(code if value else code + "0")
+        else:
+            pieces.append(code + fmt(value))
+    return "--".join(pieces)
+
+
+def _plain(value):
+    if isinstance(value, (list, tuple)):
+        return [_plain(v) for v in value]
+    if isinstance(value, np.integer):
+        return int(value)
+    if isinstance(value, np.floating):
+        return float(value)
+    return value
+
+
+def dump_params(store, params):
+    """Record the resolved parameters as the `bs_params` attribute of an existing dataset."""
+    from ..zarr_io import open_ds
+    ds = open_ds(store, "r+")  # raises if the dataset does not exist
+    ds.set_attr("bs_params", {k: _plain(v) for k, v in params.items()})
+
+
+def dump_lut_params(lut_path, params):
+    with open(f"{lut_path}.json", "w") as f:
+        json.dump({k: _plain(v) for k, v in params.items()}, f, indent=2)

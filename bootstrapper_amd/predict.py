@@ -1,0 +1,165 @@
+"""`bs predict`: blockwise affinity prediction of a Zarr volume on MI355X GPUs.
+
+Behavioural mirror of /root/reference/bootstrapper/predict.py:
+  :52-212  get_pred_config   block ROIs from net_config.json, output dataset names/shapes/chunks
+  :22-49   predict_blockwise one worker per GPU, worker_id % num_gpus, retries, failure accounting
+  :215-240 run_prediction    setup selection by id prefix/suffix/full name
+and of the worker models/3d_affs/predict.py:59-162 (u8 -> [-1,1], reflect padding outside the
+dataset, one model(input) per block, x255 -> uint8 store clipped to the dataset ROI).
+The daisy TCP scheduler is replaced by a static interleave of the block list over the GPUs
+(blocks are independent: read_write_conflict=False, predict.py:37); on each GPU the blocks
+stream through `Model.predict_u8` on a HIP stream while the host thread decodes / encodes chunks.
+"""
+import json
+import os
+
+import numpy as np
+
+from .segment import load_toml
+from .zarr_io import open_ds, prepare_ds
+
+MAX_RETRIES = 5  # reference predict.py:38
+
+
+def block_rois(net_config, voxel_size):
+    """predict.py:114-131: block input/output shapes (voxels) and context, read/write ROI (world units)."""
+    inc = net_config["shape_increase"]
+    in_shape = [a + b for a, b in zip(inc, net_config["input_shape"])]
+    out_shape = [a + b for a, b in zip(inc, net_config["output_shape"])]
+    if len(in_shape) != 3:
+        raise NotImplementedError("only 3-D networks are supported by this engine")
+    in_size = [s * v for s, v in zip(in_shape, voxel_size)]
+    out_size = [s * v for s, v in zip(out_shape, voxel_size)]
+    if any((a - b) % 2 for a, b in zip(in_size, out_size)):
+        raise ValueError("input and output size must differ by an even amount")
+    context = [(a - b) // 2 for a, b in zip(in_size, out_size)]
+    return dict(input_shape=in_shape, output_shape=out_shape, context=context,
+                read_roi=([-c for c in context], in_size), write_roi=([0, 0, 0], out_size))
+
+
+def output_dataset_names(checkpoint, output_datasets_prefix, net_config, chain_str=""):
+    """predict.py:143-155: '<prefix>/<iteration>[--from--<chain>]/<output name>'."""
+    iteration = checkpoint.split("_")[-1]
+    names = []
+    for name in net_config["outputs"]:
+        sub = f"{iteration}/{name}" if chain_str == "" else f"{iteration}--from--{chain_str}/{name}"
+        names.append(os.path.join(output_datasets_prefix, sub))
+    return names
+
+
+def get_pred_config(config_file, setup_id, **kwargs):
+    config = load_toml(config_file)[setup_id]
+    for k, v in kwargs.items():
+        if v is not None:
+            config[k] = v
+    setup_dir = config["setup_dir"]
+    checkpoint = config["checkpoint"]
+    if not os.path.exists(checkpoint) and not os.path.exists(checkpoint + ".ckpt"):
+        raise ValueError(f"Checkpoint {checkpoint} does not exist!")  # no network: nothing can be downloaded
+    with open(os.path.join(setup_dir, "net_config.json")) as f:
+        net_config = json.load(f)
+    input_datasets = config["input_datasets"]
+    assert len(input_datasets) == len(net_config["inputs"]), (
+        f"number of input datasets ({len(input_datasets)}) does not match number of network inputs "
+        f"({net_config['inputs']})")
+    in_ds = open_ds(input_datasets[0])
+    voxel_size = in_ds.voxel_size
+    rois = block_rois(net_config, voxel_size)
+
+    def coords(v):
+        return None if v is None else [int(x) for x in (v.split() if isinstance(v, str) else v)]
+
+    roi_offset, roi_shape = coords(config.get("roi_offset")), coords(config.get("roi_shape"))
+    if roi_offset is None:
+        roi_offset, roi_shape = list(in_ds.roi[0]), list(in_ds.roi[1])
+    outputs = output_dataset_names(checkpoint, config["output_datasets_prefix"], net_config, config.get("chain_str", ""))
+    return dict(setup_dir=setup_dir, checkpoint=checkpoint, net_config=net_config, input_datasets=input_datasets,
+                output_datasets=outputs, output_roi=(roi_offset, roi_shape), voxel_size=list(voxel_size),
+                num_workers=config.get("num_workers", 1), num_gpus=config.get("num_gpus", 1), **rois)
+
+
+def prepare_outputs(cfg, in_ds):
+    """predict.py:141-178: uint8 datasets (dims, *roi_shape) chunked by the output block."""
+    vs = cfg["voxel_size"]
+    off, shape = cfg["output_roi"]
+    axes = in_ds.axis_names if "c^" in in_ds.axis_names else ["c^"] + in_ds.axis_names
+    out = []
+    for path, (name, val) in zip(cfg["output_datasets"], cfg["net_config"]["outputs"].items()):
+        out.append(prepare_ds(path, shape=(val["dims"], *[s // v for s, v in zip(shape, vs)]), offset=off,
+                              voxel_size=vs, axis_names=axes, units=in_ds.units,
+                              chunk_shape=(val["dims"], *cfg["output_shape"]), dtype=np.dtype(val["dtype"])))
+    return out
+
+
+def enumerate_blocks(cfg):
+    """Write-ROI origins (voxels, relative to the output ROI) covering it with fit='overhang'."""
+    _, shape = cfg["output_roi"]
+    nvox = [s // v for s, v in zip(shape, cfg["voxel_size"])]
+    ob = cfg["output_shape"]
+    return [(z, y, x) for z in range(0, nvox[0], ob[0]) for y in range(0, nvox[1], ob[1]) for x in range(0, nvox[2], ob[2])]
+
+
+def predict_blocks(cfg, rank=0, world=1, device=None, precision="bf16"):
+    """Worker body (one per GPU): blocks rank, rank+world, ... of the block list."""
+    import torch
+    from .unet import Model, extract_block_reflect
+    device = rank if device is None else device
+    torch.cuda.set_device(device)
+    dev = torch.device("cuda", device)
+    model = Model(cfg["net_config"], device=device, precision=precision).load_checkpoint(cfg["checkpoint"])
+    in_ds = open_ds(cfg["input_datasets"][0])
+    outs = [open_ds(p, "r+") for p in cfg["output_datasets"]]
+    vs = cfg["voxel_size"]
+    roi_off, roi_shape = cfg["output_roi"]
+    roi_vox = [s // v for s, v in zip(roi_shape, vs)]
+    # dataset-relative voxel origin of the output ROI
+    org = [(o - d) // v for o, d, v in zip(roi_off, in_ds.offset, vs)]
+    vol = torch.from_numpy(in_ds[:] if len(in_ds.shape) == 3 else in_ds[:][0]).to(dev)  # whole raw volume in HBM
+    ctx = [c // v for c, v in zip(cfg["context"], vs)]
+    in_shape, out_shape = cfg["input_shape"], cfg["output_shape"]
+    blocks = enumerate_blocks(cfg)
+    mine = blocks[rank::world]
+    failed = 0
+    for blk in mine:
+        for attempt in range(MAX_RETRIES + 1):
+            try:
+                # reflect padding mirrors about the DATASET faces (gp.Pad on the array source)
+                raw = extract_block_reflect(vol, [org[d] + blk[d] - ctx[d] for d in range(3)], in_shape)
+                u8 = model.predict_u8(raw)
+                hi = [min(out_shape[d], roi_vox[d] - blk[d]) for d in range(3)]
+                for ds, t in zip(outs, u8):
+                    data = t[:, :hi[0], :hi[1], :hi[2]].cpu().numpy()
+                    ds[(slice(None),) + tuple(slice(blk[d], blk[d] + hi[d]) for d in range(3))] = data
+                break
+            except Exception:  # noqa: BLE001 - a block is retried like a daisy block (max_retries=5)
+                if attempt == MAX_RETRIES:
+                    failed += 1
+    return len(mine), failed
+
+
+def _worker(rank, world, cfg, precision, results):
+    results[rank] = predict_blocks(cfg, rank, world, precision=precision)
+
+
+def run_prediction(config_file, setup_ids=None, precision="bf16", **kwargs):
+    all_ids = list(load_toml(config_file).keys())
+    valid = {**{s.split("-")[0]: s for s in all_ids}, **{s.split("-")[-1]: s for s in all_ids}, **{s: s for s in all_ids}}
+    setups = sorted(setup_ids.strip().split()) if setup_ids else all_ids
+    for s_id in setups:
+        if s_id not in valid:
+            raise ValueError(f"Setup ID {s_id} not found in {all_ids}")
+        cfg = get_pred_config(config_file, valid[s_id], **kwargs)
+        prepare_outputs(cfg, open_ds(cfg["input_datasets"][0]))
+        world = max(1, int(cfg["num_gpus"]))
+        if world == 1:
+            total, failed = predict_blocks(cfg, 0, 1, precision=precision)
+        else:
+            import torch.multiprocessing as mp
+            with mp.Manager() as mgr:
+                results = mgr.dict()
+                mp.spawn(_worker, args=(world, cfg, precision, results), nprocs=world, join=True)
+                total = sum(r[0] for r in results.values())
+                failed = sum(r[1] for r in results.values())
+        if failed:
+            # reference blockwise.py:12-22 check_task_states
+            raise RuntimeError(f"task PredictBlockwiseTask: {failed} failed, 0 orphaned of {total} blocks")
