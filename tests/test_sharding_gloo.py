@@ -1,0 +1,51 @@
+"""N>1 path on CPU: two gloo ranks shard the block list exactly as the GPU workers do
+(bootstrapper_amd.predict.predict_blocks: blocks[rank::world]; bench.py: grid[(rank + i*world) % len]),
+the shards are disjoint and cover the volume, and the max-over-ranks timing reduction works.
+No collective touches the data path."""
+import os
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+
+def _rank_main(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from bootstrapper_amd.pipeline import block_grid
+    from bootstrapper_amd.predict import enumerate_blocks
+    grid = block_grid((512, 512, 512), (128, 128, 128))
+    steps = len(grid) // world
+    mine = [grid[(rank + i * world) % len(grid)] for i in range(steps)]
+    cfg = {"output_roi": ([0, 0, 0], [125 * 40, 1250 * 4, 1250 * 4]), "voxel_size": [40, 4, 4], "output_shape": [4, 320, 320]}
+    blocks = enumerate_blocks(cfg)
+    shard = blocks[rank::world]
+    # exchange shard sizes + a checksum of block ids, and reduce a fake per-rank time with MAX
+    ids = torch.tensor([sum(hash(b) % 1000003 for b in mine), len(mine), len(shard)], dtype=torch.int64)
+    gathered = [torch.zeros_like(ids) for _ in range(world)]
+    dist.all_gather(gathered, ids)
+    t = torch.tensor([1.0 + rank], dtype=torch.float64)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    dist.barrier()
+    q.put((rank, mine, shard, [g.tolist() for g in gathered], float(t.item()), len(grid), len(blocks)))
+    dist.destroy_process_group()
+
+
+def test_two_rank_block_sharding():
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + os.getpid() % 2000
+    procs = [ctx.Process(target=_rank_main, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    (_, m0, s0, g0, t0, ngrid, nblocks), (_, m1, s1, g1, t1, _, _) = res
+    assert not set(m0) & set(m1) and len(set(m0) | set(m1)) == ngrid == 64
+    assert not set(s0) & set(s1) and len(s0) + len(s1) == nblocks == 512
+    assert g0 == g1 and t0 == t1 == 2.0
