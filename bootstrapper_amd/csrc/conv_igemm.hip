@@ -130,12 +130,7 @@ __global__ __launch_bounds__(64 * WM * WN, 1) void conv_igemm_kernel(const ConvA
     ro1[i] = (uint32_t)(z * a.t[1].sz + y * a.t[1].sy + x * a.t[1].sx);
     ro2[i] = (uint32_t)(z * a.t[2].sz + y * a.t[2].sy + x * a.t[2].sx);
   }
-  uint32_t cur[A_INSTR];  // row offsets of the tensor the K-steps currently read
-#pragma unroll
-  for (int i = 0; i < A_INSTR; ++i) cur[i] = ro0[i];
-  int cur_t = 0;
   const uint64_t base0 = a.t[0].base, base1 = a.t[1].base, base2 = a.t[2].base;
-  uint64_t cur_base = base0;
   const uint32_t offb = (uint32_t)((n0 + wave * 16 + lrow) * ROWB + ((lchunk ^ skey) << 4));
   const size_t wstep = (size_t)a.Npad * ROWB;
 
@@ -153,34 +148,25 @@ __global__ __launch_bounds__(64 * WM * WN, 1) void conv_igemm_kernel(const ConvA
     const cint_ptr_t d = steps + (h < nsteps ? h : nsteps - 1) * 4;
     return Desc{d[0], d[1], d[2]};
   };
+  // Issue the LDS-DMA loads of K-step h (descriptor ds) into ring slot h & 3.  Branch free, so
+  // that the whole K-loop body is one scheduling region; h past the end re-loads the last K-step
+  // into a slot nobody reads any more.
   auto issue = [&](int h, const Desc& ds) {
 #ifdef BSMI_ABLATE_NOLOAD  // timing experiment: multiply whatever is in LDS
     if (h > 3) return;
 #endif
-    if (ds.t != cur_t) {  // wave-uniform, rare: the K-steps moved on to another source tensor
-      cur_t = ds.t;
-      if (ds.t == 0) {
-        cur_base = base0;
-#pragma unroll
-        for (int i = 0; i < A_INSTR; ++i) cur[i] = ro0[i];
-      } else if (ds.t == 1) {
-        cur_base = base1;
-#pragma unroll
-        for (int i = 0; i < A_INSTR; ++i) cur[i] = ro1[i];
-      } else {
-        cur_base = base2;
-#pragma unroll
-        for (int i = 0; i < A_INSTR; ++i) cur[i] = ro2[i];
-      }
-    }
+    const bool t1 = ds.t == 1, t2 = ds.t == 2;
+    const uint64_t tbase = t1 ? base1 : (t2 ? base2 : base0);
     const uint32_t lofs = (uint32_t)(unit1 ? ds.d1 : ds.d0) + hoff;
-    const gptr_t abase = (gptr_t)cur_base;
-    const gptr_t wbase = (gptr_t)a.w + (size_t)h * wstep;
+    const gptr_t abase = (gptr_t)tbase;
+    const gptr_t wbase = (gptr_t)a.w + (size_t)(h < nsteps ? h : nsteps - 1) * wstep;
     const lptr_t la = (lptr_t)(smem + (h & (NSLOT - 1)) * SLOT);
     const lptr_t lb = la + BM * ROWB;
 #pragma unroll
-    for (int i = 0; i < A_INSTR; ++i)
-      __builtin_amdgcn_global_load_lds(abase + (size_t)(cur[i] + lofs), la + (i * NW + wave) * 1024, 16, 0, 0);
+    for (int i = 0; i < A_INSTR; ++i) {
+      const uint32_t ro = t1 ? ro1[i] : (t2 ? ro2[i] : ro0[i]);
+      __builtin_amdgcn_global_load_lds(abase + (size_t)(ro + lofs), la + (i * NW + wave) * 1024, 16, 0, 0);
+    }
 #pragma unroll
     for (int i = 0; i < B_INSTR; ++i)
       __builtin_amdgcn_global_load_lds(wbase + (size_t)i * NW * 16 * ROWB + offb, lb + (i * NW + wave) * 1024, 16, 0, 0);
@@ -226,33 +212,50 @@ __global__ __launch_bounds__(64 * WM * WN, 1) void conv_igemm_kernel(const ConvA
 
   // prologue: K-steps 0..2 in flight, wait for K-step 0
   issue(0, fetch(0));
-  if (nsteps > 1) issue(1, fetch(1));
-  if (nsteps > 2) issue(2, fetch(2));
-  if (nsteps > 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * G) : "memory");
-  else if (nsteps > 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(G) : "memory");
-  else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  issue(1, fetch(1));
+  issue(2, fetch(2));
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * G) : "memory");
   __builtin_amdgcn_s_barrier();
   load_frags(smem, 0, fa[0], fb[0]);
-  if (nsteps > 3) issue(3, fetch(3));
+  issue(3, fetch(3));
   Desc dnext = fetch(4);
 
   for (int h = 0; h < nsteps; ++h) {
     const char* st = smem + (h & (NSLOT - 1)) * SLOT;
     load_frags(st, 1, fa[1], fb[1]);
     mma(fa[0], fb[0]);
+#ifndef BSMI_NO_SCHED_HINTS
+#pragma unroll
+    for (int k = 0; k < FM + FN; ++k) {
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  // 1 MFMA
+      __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);  // 1 DS read
+    }
+#endif
     // K-step boundary.  fa[1]/fb[1] must be in registers before anyone may overwrite this
-    // slot; K-step h+1 must have landed everywhere before it is read.  Loads issued after
-    // K-step h+1 (h+2, h+3) may stay in flight.
-    const int later = nsteps - 2 - h;  // K-steps issued after h+1
-    if (later >= 2) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(2 * G) : "memory");
-    else if (later == 1) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(G) : "memory");
-    else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    // slot; K-step h+1 must have landed everywhere before it is read.  The loads of K-steps
+    // h+2 and h+3 stay in flight.
+    asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(2 * G) : "memory");
     __builtin_amdgcn_s_barrier();
-    if (h + 4 < nsteps) issue(h + 4, dnext);
+    issue(h + 4, dnext);
     dnext = fetch(h + 5);
-    if (h + 1 < nsteps) load_frags(smem + ((h + 1) & (NSLOT - 1)) * SLOT, 0, fa[0], fb[0]);
+    load_frags(smem + ((h + 1) & (NSLOT - 1)) * SLOT, 0, fa[0], fb[0]);
     mma(fa[1], fb[1]);
+#ifndef BSMI_NO_SCHED_HINTS
+    // interleave the LDS-DMA issue and the next fragment reads with this MFMA group instead
+    // of letting them form a clump in front of it (one memory instruction per MFMA gap)
+#pragma unroll
+    for (int k = 0; k < G; ++k) {
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 1);  // 1 MFMA
+      __builtin_amdgcn_sched_group_barrier(0x020, 1, 1);  // 1 VMEM read (LDS-DMA)
+    }
+#pragma unroll
+    for (int k = 0; k < FM + FN; ++k) {
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 1);  // 1 MFMA
+      __builtin_amdgcn_sched_group_barrier(0x100, 1, 1);  // 1 DS read
+    }
+#endif
   }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // drain the run-ahead loads before the wave ends
 
   // epilogue: bias (+ReLU), convert, store channels-last
   T* out = (T*)a.out;
