@@ -45,8 +45,13 @@ struct WsScratch {
   uint64_t* offs;   // [D] exclusive scan of nseeds
 };
 
+// LDS = true: the row distances / filter intermediates (uint16) and the squared distances
+// (int32) of the slice live in LDS ([H][W+2] uint16 + [H*W] int32, <= 160 KiB for slices up to
+// 160 x 160); LDS = false: same algorithm on the global scratch arrays (any slice size).
+template <bool LDS>
 __global__ __launch_bounds__(WS_T) void ws_seeds_kernel(const uint8_t* __restrict__ affs, int D, int H, int W,
                                                         int msd, WsScratch s) {
+  extern __shared__ __attribute__((aligned(16))) char ws_smem[];
   const int z = blockIdx.x;
   const int n = H * W;
   const size_t vol = (size_t)D * n;
@@ -74,6 +79,70 @@ __global__ __launch_bounds__(WS_T) void ws_seeds_kernel(const uint8_t* __restric
   __syncthreads();
   const int any_bg = sh_any_bg;
   constexpr int INF = 1 << 28;
+  if constexpr (LDS) {
+    // ---- LDS path: sg = row distances, later the x-filtered d2 (all values < 65535) ----------
+    const int Wp = W + 2;  // row stride in uint16: consecutive rows fall into different banks
+    uint16_t* sg = (uint16_t*)ws_smem;
+    int32_t* sd2 = (int32_t*)(ws_smem + (((size_t)H * Wp * 2 + 15) & ~(size_t)15));
+    constexpr int GINF = 0xffff;
+    if (any_bg) {
+      for (int y = tid; y < H; y += WS_T) {
+        int last = -INF;
+        for (int x = 0; x < W; ++x) {
+          if (!mask[y * W + x]) last = x;
+          sg[y * Wp + x] = (uint16_t)(last <= -INF ? GINF : x - last);
+        }
+        last = INF;
+        for (int x = W - 1; x >= 0; --x) {
+          if (!mask[y * W + x]) last = x;
+          const int d = last >= INF ? GINF : last - x;
+          if (d < (int)sg[y * Wp + x]) sg[y * Wp + x] = (uint16_t)d;
+        }
+      }
+      __syncthreads();
+      for (int i = tid; i < n; i += WS_T) {
+        const int y = i / W, x = i - y * W;
+        int best = INF;
+        for (int yy = 0; yy < H; ++yy) {
+          const int gg = sg[yy * Wp + x];
+          const int dy = y - yy;
+          const int v = gg == GINF ? INF : gg * gg + dy * dy;
+          best = v < best ? v : best;
+        }
+        sd2[i] = best;
+        d2[i] = best;
+      }
+    } else {
+      for (int i = tid; i < n; i += WS_T) {
+        const int y = i / W, x = i - y * W;
+        const int v = (y + 1) * (y + 1) + x * x;
+        sd2[i] = v;
+        d2[i] = v;
+      }
+    }
+    __syncthreads();
+    const int left = msd / 2, right = msd - 1 - msd / 2;
+    for (int i = tid; i < n; i += WS_T) {
+      const int y = i / W, x = i - y * W;
+      int m = INT32_MIN;
+      for (int k = x - left; k <= x + right; ++k) {
+        const int v = sd2[y * W + reflect_dup(k, W)];
+        m = v > m ? v : m;
+      }
+      sg[y * Wp + x] = (uint16_t)m;
+    }
+    __syncthreads();
+    for (int i = tid; i < n; i += WS_T) {
+      const int y = i / W, x = i - y * W;
+      int m = INT32_MIN;
+      for (int k = y - left; k <= y + right; ++k) {
+        const int v = sg[reflect_dup(k, H) * Wp + x];
+        m = v > m ? v : m;
+      }
+      mf[i] = m;
+    }
+    __syncthreads();
+  } else {
   if (any_bg) {
     // b1. per row: distance along x to the nearest background voxel
     for (int y = tid; y < H; y += WS_T) {
@@ -134,6 +203,7 @@ __global__ __launch_bounds__(WS_T) void ws_seeds_kernel(const uint8_t* __restric
     mf[i] = m;
   }
   __syncthreads();
+  }
   // d/e. maxima and their 4-connected components.  Rows are labelled as runs first (each
   // maximum points at the first voxel of its run), then vertically adjacent runs are united
   // once, at the first column where they overlap (union-find, smaller index wins).
@@ -726,7 +796,21 @@ int bsmi_ws_fragments_u8(bsmi_seg* h, const uint8_t* affs_dev, const int64_t sha
   BSMI_HIP(hipSetDevice(h->device));
   hipStream_t s = (hipStream_t)stream;
   const int D = (int)shape[0], H = (int)shape[1], W = (int)shape[2];
-  hipLaunchKernelGGL(ws_seeds_kernel, dim3(D), dim3(WS_T), 0, s, affs_dev, D, H, W, min_seed_distance, h->ws);
+  {
+    // squared distances must fit the uint16 intermediates of the LDS path: H^2 + W^2 < 65535
+    const size_t lds = (((size_t)H * (W + 2) * 2 + 15) & ~(size_t)15) + (size_t)H * W * 4;
+    const bool use_lds = lds <= 158 * 1024 && (size_t)H * H + (size_t)W * W < 65535 && (H + 1) * (H + 1) + W * W < 65535;
+    if (use_lds) {
+      static bool attr_set = false;
+      if (!attr_set) {
+        BSMI_HIP(hipFuncSetAttribute((const void*)ws_seeds_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 158 * 1024));
+        attr_set = true;
+      }
+      hipLaunchKernelGGL(ws_seeds_kernel<true>, dim3(D), dim3(WS_T), lds, s, affs_dev, D, H, W, min_seed_distance, h->ws);
+    } else {
+      hipLaunchKernelGGL(ws_seeds_kernel<false>, dim3(D), dim3(WS_T), 0, s, affs_dev, D, H, W, min_seed_distance, h->ws);
+    }
+  }
   hipLaunchKernelGGL(ws_offsets_kernel, dim3(1), dim3(64), 0, s, D, h->ws, max_id_dev);
   hipLaunchKernelGGL(ws_flood_kernel, dim3((D + FLOOD_WAVES - 1) / FLOOD_WAVES), dim3(64 * FLOOD_WAVES), 0, s, D, H, W, h->ws, h->flood_spill, h->flood_spill_stride,
                      frags_dev, h->status_dev);
