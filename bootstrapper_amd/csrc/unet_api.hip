@@ -10,11 +10,13 @@
 // arithmetic folded into the K-step offsets.
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <memory>
 #include <vector>
 
+#include "conv_halo.h"
 #include "conv_igemm.h"
 #include "unet_ops.h"
 
@@ -55,11 +57,19 @@ struct PackEntry {
   int cin_base;    // first input channel of this slot inside the weight's Cin dim
   int creal;       // real channels of the slot
   bool dummy;      // filler: delta 0, all-zero weights
+  int phase;       // index into PackedConv::phases
+};
+
+// A phase groups the units that read one staged halo (conv_halo.hip): LONG = all kernel taps of
+// one 16-channel slice, SHORT = the residual tap of one 32-channel slice.
+struct PackPhase {
+  int slot, c0, kind, first_unit, nunits;
 };
 
 struct PackedConv {
   bool ready = false;
   std::vector<PackEntry> entries;
+  std::vector<PackPhase> phases;
   void* w = nullptr;
   float* bias = nullptr;
   int Npad = 0;
@@ -91,6 +101,8 @@ struct TDesc {
 struct PlanStep {
   enum Type { INPUT, CONV, POOL, UP, HEAD } type;
   ConvArgs conv;
+  HaloArgs halo;
+  bool use_halo = false;
   TileCfg tile;
   TDesc in, out;
   int f[3], o[3];
@@ -155,27 +167,55 @@ static void register_pass(bsmi_unet* h, const PassSite& p) {
   expect_weight(h, p.prefix + ".residual.0.bias", {p.cout});
 }
 
-// Build the unit list of stage `ci` of a ConvPass: kUnitsPerStep consecutive entries = one
-// K-step, all from the same tensor slot.  Units are ordered channel-chunk-major with the
-// kernel taps inside, so consecutive K-steps re-read the same channel chunk of neighbouring
-// voxels (L2 hits); a 16-channel tensor packs two taps per K-step.
-static void build_entries(const PassSite& p, int ci, int prec, std::vector<PackEntry>& out) {
+// Build the unit list of stage `ci` of a ConvPass.  kUnitsPerStep consecutive entries = one
+// K-step.  Units are grouped in phases (one staged halo each, conv_halo.hip): for every source
+// slot and 16-channel slice all kernel taps (two taps per K-step), then, for the last stage, the
+// cropped 1x1x1 residual in 32-channel slices (two 16-channel halves per K-step).  Phases are
+// padded to whole K-steps with dummy units (delta 0, zero weights).
+static void build_entries(const PassSite& p, int ci, int prec, std::vector<PackEntry>& out,
+                          std::vector<PackPhase>* phases_out = nullptr) {
   const int SUB = sube(prec);
   const bool last = ci == p.nconv - 1;
-  std::vector<PackEntry> per_slot[kMaxConvTensors];
+  std::vector<PackPhase> phases;
+  auto close_phase = [&](PackPhase ph) {
+    while ((out.size() - ph.first_unit) % kUnitsPerStep) out.push_back(PackEntry{ph.slot, 0, 0, 0, 0, 0, 0, 0, 0, true, (int)phases.size()});
+    ph.nunits = (int)out.size() - ph.first_unit;
+    phases.push_back(ph);
+  };
+  // BSMI_USE_HALO (experimental, see conv_halo.hip): phase-structured order, two kernel taps of one
+  // 16-channel slice per K-step.  Default: one tap x 32 channels per K-step (64 contiguous bytes
+  // per gathered row), channel-chunk major with the taps inside; a 16-channel tensor packs two taps.
+  static const bool halo_order = getenv("BSMI_USE_HALO") != nullptr;
   auto add_taps = [&](int slot, const int* k, int cin_base, int creal) {
     const int cpad = round_up(creal, kChanPad);
-    for (int c64 = 0; c64 < cpad; c64 += kUnitsPerStep * SUB)
+    if (!halo_order) {
+      const size_t first = out.size();
+      for (int c32 = 0; c32 < cpad; c32 += kUnitsPerStep * SUB)
+        for (int z = 0; z < k[0]; ++z)
+          for (int y = 0; y < k[1]; ++y)
+            for (int x = 0; x < k[2]; ++x)
+              for (int c0 = c32; c0 < std::min(cpad, c32 + kUnitsPerStep * SUB); c0 += SUB)
+                out.push_back(PackEntry{slot, z, y, x, c0, 0, (z * k[1] + y) * k[2] + x, cin_base, creal, false, -1});
+      while ((out.size() - first) % kUnitsPerStep) out.push_back(PackEntry{slot, 0, 0, 0, 0, 0, 0, 0, 0, true, -1});
+      return;
+    }
+    for (int c0 = 0; c0 < cpad; c0 += SUB) {
+      PackPhase ph{slot, c0, 0, (int)out.size(), 0};
       for (int z = 0; z < k[0]; ++z)
         for (int y = 0; y < k[1]; ++y)
           for (int x = 0; x < k[2]; ++x)
-            for (int c0 = c64; c0 < std::min(cpad, c64 + kUnitsPerStep * SUB); c0 += SUB)
-              per_slot[slot].push_back(PackEntry{slot, z, y, x, c0, 0, (z * k[1] + y) * k[2] + x, cin_base, creal, false});
+            out.push_back(PackEntry{slot, z, y, x, c0, 0, (z * k[1] + y) * k[2] + x, cin_base, creal, false, (int)phases.size()});
+      close_phase(ph);
+    }
   };
   auto add_residual = [&](int slot, const int* crop, int cin_base, int creal) {
     const int cpad = round_up(creal, kChanPad);
-    for (int c0 = 0; c0 < cpad; c0 += SUB)
-      per_slot[slot].push_back(PackEntry{slot, crop[0] / 2, crop[1] / 2, crop[2] / 2, c0, 1, 0, cin_base, creal, false});
+    for (int c32 = 0; c32 < cpad; c32 += kUnitsPerStep * SUB) {
+      PackPhase ph{slot, c32, 1, (int)out.size(), 0};
+      for (int c0 = c32; c0 < std::min(cpad, c32 + kUnitsPerStep * SUB); c0 += SUB)
+        out.push_back(PackEntry{slot, crop[0] / 2, crop[1] / 2, crop[2] / 2, c0, 1, 0, cin_base, creal, false, (int)phases.size()});
+      close_phase(ph);
+    }
   };
   const int* k = p.k[ci];
   if (ci == 0) {
@@ -198,18 +238,15 @@ static void build_entries(const PassSite& p, int ci, int prec, std::vector<PackE
       base += p.cin[s];
     }
   }
-  for (int s = 0; s < kMaxConvTensors; ++s) {
-    auto& v = per_slot[s];
-    while (v.size() % kUnitsPerStep) v.push_back(PackEntry{s, 0, 0, 0, 0, 0, 0, 0, 0, true});
-    out.insert(out.end(), v.begin(), v.end());
-  }
+  if (!halo_order) phases.clear();
+  if (phases_out) *phases_out = phases;
 }
 
 static int pack_conv(bsmi_unet* h, PassSite& p, int ci, int prec) {
   PackedConv& pc = p.packed[prec][ci];
   if (pc.ready) return BSMI_OK;
   pc.entries.clear();
-  build_entries(p, ci, prec, pc.entries);
+  build_entries(p, ci, prec, pc.entries, &pc.phases);
   pc.tile = choose_tile(p.cout);
   pc.Npad = round_up(p.cout, tile_bn(pc.tile));
   const int BKE = bke(prec);
@@ -267,6 +304,122 @@ struct Planner {
     if (dry) return BSMI_OK;
     BSMI_HIP(hipMalloc(&t.ptr, bytes));
     plan->allocs.push_back(t.ptr);
+    return BSMI_OK;
+  }
+
+  // Halo-tiled launch of one ConvPass stage (conv_halo.hip) when an output box with a halo of at
+  // most kHaloLongRows rows exists; otherwise st.use_halo stays false (generic gather kernel).
+  int plan_halo(const PassSite& p, int ci, const PackedConv& pc, const TDesc* slots, const int (*so)[3], int nsl,
+                const TDesc& o, PlanStep& st) {
+    st.use_halo = false;
+    if (pc.phases.empty() || st.tile == TILE_256x320) return BSMI_OK;  // halo path is opt-in (BSMI_USE_HALO)
+    const int* k = p.k[ci];
+    int box[3];
+    if (!halo_choose_box(o.D, o.H, o.W, k, box)) return BSMI_OK;
+    const int64_t es = esize(prec);
+    HaloArgs& ha = st.halo;
+    memset(&ha, 0, sizeof ha);
+    int crop[3] = {0, 0, 0};
+    for (int i = 0; i < p.nconv; ++i)
+      for (int d = 0; d < 3; ++d) crop[d] += p.k[i][d] - 1;
+    for (int sl = 0; sl < kMaxConvTensors; ++sl) {
+      const int q = sl < nsl ? sl : 0;
+      const TDesc& t = slots[q];
+      HaloSrc& hs = ha.t[sl];
+      hs.base = (uint64_t)(uintptr_t)t.ptr;
+      hs.sz = (int32_t)((int64_t)t.H * t.W * t.Cpad * es);
+      hs.sy = (int32_t)((int64_t)t.W * t.Cpad * es);
+      hs.sx = (int32_t)((int64_t)t.Cpad * es);
+      hs.D = t.D; hs.H = t.H; hs.W = t.W;
+      hs.oz = so[q][0]; hs.oy = so[q][1]; hs.ox = so[q][2];
+      hs.rz = so[q][0] + crop[0] / 2; hs.ry = so[q][1] + crop[1] / 2; hs.rx = so[q][2] + crop[2] / 2;
+    }
+    ha.TZ = box[0]; ha.TY = box[1]; ha.TX = box[2];
+    ha.NBZ = ceil_div(o.D, box[0]); ha.NBY = ceil_div(o.H, box[1]); ha.NBX = ceil_div(o.W, box[2]);
+    const int HZ = box[0] + k[0] - 1;
+    ha.HY = box[1] + k[1] - 1; ha.HX = box[2] + k[2] - 1;
+    ha.hv_long = HZ * ha.HY * ha.HX;
+
+    const int BI = round_up(tile_bn(st.tile), 64) / 16 / 4;
+    const int HL = kHaloLongInstr, HS = kHaloShortInstr;
+    const size_t S = pc.entries.size() / kUnitsPerStep, P = pc.phases.size();
+    std::vector<HaloPhase> phases(P);
+    std::vector<HaloStep> steps(S);
+    std::vector<int> phase_of_step(S), last_of_phase(P, -1), first_of_phase(P, -1);
+    for (size_t ph = 0; ph < P; ++ph) {
+      const PackPhase& pp = pc.phases[ph];
+      phases[ph] = HaloPhase{pp.slot, (int32_t)(pp.c0 * es), pp.kind, (int32_t)((ph & 1) * kHaloBufBytes)};
+      first_of_phase[ph] = pp.first_unit / kUnitsPerStep;
+      last_of_phase[ph] = (pp.first_unit + pp.nunits) / kUnitsPerStep - 1;
+      for (int u = pp.first_unit; u < pp.first_unit + pp.nunits; u += kUnitsPerStep) {
+        const size_t sidx = u / kUnitsPerStep;
+        phase_of_step[sidx] = (int)ph;
+        HaloStep hs;
+        memset(&hs, 0, sizeof hs);
+        hs.bufbase = phases[ph].bufbase;
+        hs.issue = -1;
+        if (pp.kind == 0) {
+          for (int j = 0; j < kUnitsPerStep; ++j) {
+            const PackEntry& e = pc.entries[u + j];
+            hs.trow[j] = e.dummy ? 0 : (e.dz * ha.HY + e.dy) * ha.HX + e.dx;
+          }
+          hs.fmt = 0 | (0 << 8) | (5 << 16) | (3 << 20) | (1 << 24);
+        } else {
+          hs.fmt = 0 | (2 << 8) | (6 << 16) | (2 << 20) | (3 << 24);
+        }
+        steps[sidx] = hs;
+      }
+    }
+    // issue points and counted waits: simulate the wave's in-order vector-memory queue
+    struct Op { int kind, id, count; };  // kind 0 = weights of K-step id, 1 = halo of phase id
+    std::vector<Op> queue;
+    queue.push_back(Op{0, 3, BI});  // after the prologue (everything else landed) K-step 3 is in flight
+    const int variants[7][2] = {{2 * BI + HL, 1}, {2 * BI + HS, 2}, {2 * BI, 0}, {BI + HL, 6}, {BI + HS, 5}, {BI, 3}, {0, 4}};
+    for (size_t h = 0; h < S; ++h) {
+      // requirements of the boundary after step h
+      int need_pos = -1;
+      auto require = [&](int kind, int id) {
+        for (int i = (int)queue.size() - 1; i >= 0; --i)
+          if (queue[i].kind == kind && queue[i].id == id) { need_pos = std::max(need_pos, i); return; }
+      };
+      if (h + 1 < S) {
+        require(0, (int)h + 1);
+        const int q = phase_of_step[h + 1];
+        if (first_of_phase[q] == (int)h + 1) require(1, q);
+      }
+      int n_ok = 0;
+      for (int i = need_pos + 1; i < (int)queue.size(); ++i) n_ok += queue[i].count;
+      int kind = 4;
+      int best = -1;
+      for (auto& v : variants)
+        if (v[0] <= n_ok && v[0] > best) { best = v[0]; kind = v[1]; }
+      steps[h].wait = kind;
+      // the wait leaves at most `best` of the youngest operations outstanding
+      int keep = 0, cut = (int)queue.size();
+      while (cut > 0 && keep + queue[cut - 1].count <= best) keep += queue[--cut].count;
+      queue.erase(queue.begin(), queue.begin() + cut);
+      // issues at this boundary: the halo two phases ahead once this phase's buffer is free, then weights
+      const int ph = phase_of_step[h];
+      if (last_of_phase[ph] == (int)h && (size_t)ph + 2 < P) {
+        steps[h].issue = ph + 2;
+        queue.push_back(Op{1, ph + 2, phases[ph + 2].kind == 0 ? HL : HS});
+      }
+      queue.push_back(Op{0, (int)h + 4, BI});
+    }
+    HaloStep* dsteps = nullptr;
+    HaloPhase* dphases = nullptr;
+    BSMI_HIP(hipMalloc((void**)&dsteps, steps.size() * sizeof(HaloStep)));
+    plan->allocs.push_back(dsteps);
+    BSMI_HIP(hipMalloc((void**)&dphases, phases.size() * sizeof(HaloPhase)));
+    plan->allocs.push_back(dphases);
+    BSMI_HIP(hipMemcpy(dsteps, steps.data(), steps.size() * sizeof(HaloStep), hipMemcpyHostToDevice));
+    BSMI_HIP(hipMemcpy(dphases, phases.data(), phases.size() * sizeof(HaloPhase), hipMemcpyHostToDevice));
+    ha.steps = dsteps; ha.phases = dphases;
+    ha.nsteps = (int)S; ha.nphases = (int)P;
+    ha.w = pc.w; ha.bias = pc.bias; ha.out = o.ptr;
+    ha.Do = o.D; ha.Ho = o.H; ha.Wo = o.W; ha.Co = o.Cpad;
+    ha.Npad = pc.Npad; ha.relu = 1;
+    st.use_halo = true;
     return BSMI_OK;
   }
 
@@ -366,6 +519,8 @@ struct Planner {
         a.Npad = pc.Npad;
         a.relu = 1;  // trunk activation is ReLU (model.py passes activation default "ReLU")
         st.flops = 2.0 * M * p.cout * kreal;
+        rc = plan_halo(p, ci, pc, slots, so, nsl, o, st);
+        if (rc) return rc;
         plan->steps.push_back(st);
       }
       cur = o;
@@ -756,7 +911,7 @@ int bsmi_unet_forward(bsmi_unet* h, int precision, const void* raw_dev, int raw_
                                (size_t)st.out.D * st.out.H * st.out.W, s);
         break;
       case PlanStep::CONV:
-        rc = launch_conv_igemm(st.conv, precision, st.tile, s);
+        rc = st.use_halo ? launch_conv_halo(st.halo, precision, st.tile, s) : launch_conv_igemm(st.conv, precision, st.tile, s);
         break;
       case PlanStep::POOL:
         rc = launch_maxpool(precision, st.in.ptr, st.out.ptr, st.in.D, st.in.H, st.in.W, st.in.Cpad,

@@ -1,0 +1,91 @@
+"""BASELINE-size checks (one 128^3 output block of the full 3d_affs network, 94.7 M parameters):
+bf16 throughput mode against the f32 parity mode of the same engine, run-to-run determinism,
+the opt-in halo kernel, and bit-exact segmentation against the oracle at full block size."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def full_block():
+    from bootstrapper_amd.unet import Model
+    from bootstrapper_amd.synth import synthetic_state_dict, synthetic_volume
+    from tests.test_lib_cpu import AFFS_NET_CONFIG as NC
+    sd = synthetic_state_dict(NC, 0)
+    raw = synthetic_volume((156, 220, 220), 0)
+    m = Model(NC, precision="bf16").load_state_dict(sd)
+    u8_a, f_a = m.predict_u8(raw, want_f32=True)
+    u8_b, f_b = m.predict_u8(raw, want_f32=True)
+    m.set_precision("f32")
+    u8_f, f_f = m.predict_u8(raw, want_f32=True)
+    torch.cuda.synchronize()
+    return dict(bf16=(u8_a[0], f_a[0]), bf16_again=(u8_b[0], f_b[0]), f32=(u8_f[0], f_f[0]))
+
+
+def test_full_block_shapes_and_determinism(full_block):
+    u8, f = full_block["bf16"]
+    assert tuple(u8.shape) == (6, 128, 128, 128) and u8.dtype == torch.uint8
+    assert torch.equal(u8, full_block["bf16_again"][0]) and torch.equal(f, full_block["bf16_again"][1])
+    # the synthetic weights give structured affinities (needed for a meaningful segmentation stage)
+    assert 20 < float(u8.float().std()) < 90
+
+
+def test_full_block_bf16_close_to_f32(full_block):
+    """bf16 operands / f32 accumulate vs exact-f32 MFMA at the full 16-layer depth and K up to 48 600."""
+    d = (full_block["bf16"][1] - full_block["f32"][1]).abs()
+    print("bf16 vs f32 at 128^3: max", float(d.max()), "mean", float(d.mean()))
+    assert float(d.max()) < 3e-2 and float(d.mean()) < 3e-3
+    du = (full_block["bf16"][0].int() - full_block["f32"][0].int()).abs()
+    assert int(du.max()) <= 8 and float((du <= 1).float().mean()) > 0.9
+
+
+def test_full_block_segmentation_bit_exact(full_block):
+    from bootstrapper_amd.post.engine import SegEngine
+    from oracle import seg_ref as S
+    affs = full_block["bf16"][0][:3].contiguous()
+    eng = SegEngine((128, 128, 128))
+    frags, mx = eng.ws_fragments(affs, True, 10)
+    segs = eng.agglomerate_mean(affs, frags, [0.2, 0.35, 0.5])
+    eng.status()
+    a = affs.cpu().numpy()
+    ref_frags, ref_max = S.ws_fragments_u8(a, True, 10)
+    assert int(mx.item()) == ref_max
+    assert np.array_equal(frags.cpu().numpy().astype(np.uint64), ref_frags)
+    ref = S.agglomerate_mean_u8(a, ref_frags, [0.2, 0.35, 0.5])
+    got = segs.cpu().numpy().astype(np.uint64)
+    for t in range(3):
+        assert np.array_equal(got[t], ref[t])
+    assert len(np.unique(ref[2])) < len(np.unique(ref_frags)) / 2
+
+
+def test_halo_kernel_parity_in_subprocess(golden_dir):
+    """conv_halo.hip is opt-in through BSMI_USE_HALO (read once per process): run the golden
+    comparison in a child process with the variable set."""
+    code = r'''
+import json, os, sys, numpy as np, torch
+sys.path.insert(0, %r)
+from bootstrapper_amd.unet import Model
+from oracle import unet_ref as R
+d = np.load(os.path.join(%r, "unet_affs_f3i3.npz"))
+sd = {k[2:]: d[k] for k in d.files if k.startswith("w:")}
+meta = json.loads(bytes(d["config"]).decode())
+nc = {"in_channels": 1, "num_fmaps": 3, "fmap_inc_factor": 3, "downsample_factors": [[1, 2, 2]] * 3,
+      "kernel_size_down": [[[3, 3, 3], [3, 3, 3]]] * 4, "kernel_size_up": [[[3, 3, 3], [3, 3, 3]]] * 3,
+      "outputs": {"3d_affs": {"dims": 6}}}
+m = Model(nc, precision="f32").load_state_dict(sd)
+y = m(torch.from_numpy(R.normalize_raw(d["raw_u8"]))[None, None].cuda())[0].cpu().numpy()
+err = float(np.abs(y - d["out0"]).max())
+print("halo f32 err", err)
+assert err < 1e-4
+''' % (ROOT, golden_dir)
+    env = dict(os.environ, BSMI_USE_HALO="1")
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
