@@ -1,23 +1,28 @@
 // Halo-tiled implicit-GEMM 3-D convolution on MFMA (gfx950).
 //
 // Same GEMM as conv_igemm.hip, but the M tile is a 3-D box of output voxels (TZ x TY x TX <= 256)
-// and the activation operand is not gathered per kernel tap: for every 16-channel slice of a
+// and the activation operand is not gathered per kernel tap: for every 32-channel chunk of a
 // source tensor the box's input halo ((TZ+kz-1) x (TY+ky-1) x (TX+kx-1) voxels x 32 B) is staged
 // ONCE into LDS and all kz*ky*kx taps read their A fragments from it at a per-tap row offset.
 // This cuts the activation traffic into the CU by ~10x (the kernel is bound by the L2 -> LDS
 // fill rate, not by MFMA issue); the weight tiles still stream through a 4-slot LDS-DMA ring.
 //
-// LDS: [halo buffer 0 | halo buffer 1 | 4 x weight slot (BNL rows x 64 B)].
-// A "phase" is one staged halo; its K-steps pair two kernel taps (2 x 16 channels of K).  The
-// 1x1x1 residual branch uses SHORT phases: the box's own 256 voxels x 32 channels (64-B rows).
+// LDS: [halo buffer 0 | halo buffer 1 | 3-4 x weight slot (BNL rows x 64 B)].
+// A "phase" is one staged halo; a K-step is one kernel tap x 32 channels.  The 1x1x1 residual
+// branch uses SHORT phases: the box's own 256 voxels x 32 channels.
 // Halo p+2 is issued at the boundary that ends phase p (its buffer is free from then on); the
 // host simulates the in-order vmcnt queue and stores, per boundary, which counted wait is safe.
 //
-// STATUS (round 1): numerically verified (all U-Net parity tests pass with BSMI_USE_HALO=1) but
-// 1.4-2.5x SLOWER than the gather kernel: the A-fragment reads of non-contiguous halo rows hit
-// 20-50 % LDS bank conflicts (32-byte rows leave one swizzle bit) and the per-tile set-up divides
-// dominate short K loops.  Opt-in only; the fix (64-byte halo rows, row pitches chosen so that the
-// 16 lanes of a ds_read_b128 group fall on 16 distinct rows mod 16) is next round's work.
+// Halo rows are 64 bytes (32 channels) at LDS row jz*PZ + jy*PY + jx; the host picks the pitches
+// so that the 16 lanes of a ds_read_b128 lane group fall on rows that are distinct mod 16, which
+// makes the (row>>2)&3 chunk swizzle bank-conflict free (halo_choose_geometry).
+//
+// STATUS (round 1): opt-in (BSMI_USE_HALO=1).  Numerically verified -- every U-Net parity test
+// passes on this path -- but not yet faster than the gather kernel: measured on the 128^3 block,
+// 7.3 ms vs 6.4 ms on the two largest layers and ~2.4x slower on the short-K layers, where the
+// per-tile set-up (halo address tables, full drain before the first K-step) is not amortised.
+// Next steps: several boxes per workgroup with the next halo prefetched, cheaper per-read
+// addressing, and box shapes that are both coalescing- and bank-friendly.
 #include "conv_halo.h"
 
 #include <algorithm>
@@ -55,24 +60,59 @@ template <> struct HElem<hbf16> {
   }
 };
 
-// wait variants of a K-step boundary (HaloStep::wait); BI = weight LDS-DMA instructions per wave
-// per K-step, HL / HS = instructions per wave of a LONG / SHORT halo
-enum { W_2B = 0, W_2B_HL = 1, W_2B_HS = 2, W_1B = 3, W_ALL = 4, W_1B_HS = 5, W_1B_HL = 6 };
+// wait variants of a K-step boundary (HaloStep::wait).  D = NSLOT - 2 weight K-steps may stay in
+// flight across a boundary; BI = weight LDS-DMA instructions per wave per K-step, HL / HS =
+// instructions per wave of a LONG / SHORT halo.
+enum { W_D = 0, W_D_HL = 1, W_D_HS = 2, W_DM1 = 3, W_ALL = 4, W_DM1_HS = 5, W_DM1_HL = 6 };
 
-template <typename T, int BN, int WM, int WN>
+// x / d for small x, d with magic = ceil(2^32 / d) (0 encodes d == 1)
+__device__ __forceinline__ uint32_t udiv_small(uint32_t x, uint32_t magic) { return magic ? __umulhi(x, magic) : x; }
+
+// Stage the halo of phase p: HL (LONG) or HS (SHORT) LDS-DMA instructions per wave.  A free
+// force-inlined function rather than a lambda: a lambda with several call sites is kept as an
+// out-of-line call whose closure (and every captured array) lives in scratch memory.
+template <int HL, int HS, int NW>
+__device__ __forceinline__ void halo_issue(cint_ptr_t phases, int p_in, const uint32_t (&l0)[HL], const uint32_t (&l1)[HL],
+                                           const uint32_t (&l2)[HL], const uint32_t (&s0)[HS], const uint32_t (&s1)[HS],
+                                           const uint32_t (&s2)[HS], uint64_t base0, uint64_t base1, uint64_t base2,
+                                           uint32_t hsrc, char* smem, int wave) {
+  const int p = __builtin_amdgcn_readfirstlane(p_in);
+  const cint_ptr_t d = phases + p * 4;
+  const int t = d[0], c0 = d[1], kind = d[2], bufbase = d[3];
+  const bool t1 = t == 1, t2 = t == 2;
+  const gptr_t hb = (gptr_t)(t1 ? base1 : (t2 ? base2 : base0));
+  const lptr_t lh = (lptr_t)(smem + bufbase);
+  const uint32_t co = (uint32_t)c0 + hsrc;
+  if (kind == 0) {
+#pragma unroll
+    for (int q = 0; q < HL; ++q) {
+      const uint32_t ro = t1 ? l1[q] : (t2 ? l2[q] : l0[q]);
+      __builtin_amdgcn_global_load_lds(hb + (size_t)(ro + co), lh + (q * NW + wave) * 1024, 16, 0, 0);
+    }
+  } else {
+#pragma unroll
+    for (int q = 0; q < HS; ++q) {
+      const uint32_t ro = t1 ? s1[q] : (t2 ? s2[q] : s0[q]);
+      __builtin_amdgcn_global_load_lds(hb + (size_t)(ro + co), lh + (q * NW + wave) * 1024, 16, 0, 0);
+    }
+  }
+}
+
+template <typename T, int BN, int WM, int WN, int NSLOT>
 __global__ __launch_bounds__(256, 1) void conv_halo_kernel(const HaloArgs a) {
   constexpr int BM = 256, NW = 4;
   static_assert(WM * WN == NW, "one wave per SIMD");
   constexpr int ROWB = kStepRowBytes;
-  constexpr int NSLOT = 4;
   constexpr int WTM = BM / WM, WTN = BN / WN;
   constexpr int FM = WTM / 32, FN = WTN / 32;
   constexpr int BNL = (BN + 63) / 64 * 64;
   constexpr int BI = BNL / 16 / NW;
   constexpr int HL = kHaloLongInstr, HS = kHaloShortInstr;
+  constexpr int D = NSLOT - 2;
   constexpr int SLOT = BNL * ROWB;
   constexpr int BRING = 2 * kHaloBufBytes;  // LDS offset of the weight ring
-  static_assert(2 * BI + HL <= 63, "vmcnt range");
+  static_assert(D * BI + HL <= 63, "vmcnt range");
+  static_assert(D >= 1, "ring depth");
 
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
@@ -99,69 +139,60 @@ __global__ __launch_bounds__(256, 1) void conv_halo_kernel(const HaloArgs a) {
   const int by = byz % a.NBY, bz = byz / a.NBY;
   const int z0 = bz * a.TZ, y0 = by * a.TY, x0 = bx * a.TX;
   const int boxrows = a.TZ * a.TY * a.TX;
+  const int TYX = a.TY * a.TX;
 
-  // ---- per-lane source offsets of the halo rows this lane stages (computed once per tile) ----
-  // LONG: instruction q covers halo rows (q*NW + wave)*32 .. +32, lane -> row (lane>>1), half lane&1
-  const int HYX = a.HY * a.HX;
+  // box row m -> (tz, ty, tx); rows past the box map to row 0 (their results are never stored)
+  auto box_coords = [&](int m, int& tz, int& ty, int& tx) __attribute__((always_inline)) {
+    m = m < boxrows ? m : 0;
+    tz = (int)udiv_small((uint32_t)m, a.mTYX);
+    const int mr = m - tz * TYX;
+    ty = (int)udiv_small((uint32_t)mr, a.mTX);
+    tx = mr - ty * a.TX;
+  };
+
+  // ---- per-lane source offsets of the halo rows this lane stages (once per tile) ----------------
+  // An LDS-DMA instruction covers 16 halo rows x 64 B: lane -> row (lane>>2), 16-byte slot lane&3,
+  // fetching source chunk (lane&3) ^ ((row>>2)&3) (swizzle on the source side).
+  // (no references / pointers into the kernel-argument struct: they would force it, and the
+  //  arrays below, into scratch memory)
+#define BSMI_SRC_OFF(T, Z, Y, X)                                                            \
+  ((uint32_t)(min((Z), a.t[T].D - 1) * a.t[T].sz + min((Y), a.t[T].H - 1) * a.t[T].sy + \
+              min((X), a.t[T].W - 1) * a.t[T].sx))
   uint32_t lofs0[HL], lofs1[HL], lofs2[HL];
   {
+    const int hv = a.HZ * a.PZ;
 #pragma unroll
     for (int q = 0; q < HL; ++q) {
-      int j = (q * NW + wave) * 32 + (lane >> 1);
-      j = j < a.hv_long ? j : a.hv_long - 1;
-      const int jz = j / HYX, jr = j - jz * HYX;
-      const int jy = jr / a.HX, jx = jr - jy * a.HX;
-      auto off = [&](const HaloSrc& t) -> uint32_t {
-        int z = z0 + t.oz + jz, y = y0 + t.oy + jy, x = x0 + t.ox + jx;
-        z = z < t.D ? z : t.D - 1; y = y < t.H ? y : t.H - 1; x = x < t.W ? x : t.W - 1;
-        return (uint32_t)(z * t.sz + y * t.sy + x * t.sx);
-      };
-      lofs0[q] = off(a.t[0]); lofs1[q] = off(a.t[1]); lofs2[q] = off(a.t[2]);
+      int j = (q * NW + wave) * 16 + (lane >> 2);
+      j = j < hv ? j : hv - 1;
+      const int jz = (int)udiv_small((uint32_t)j, a.mPZ);
+      const int jr = j - jz * a.PZ;
+      int jy = (int)udiv_small((uint32_t)jr, a.mPY);
+      int jx = jr - jy * a.PY;
+      jy = jy < a.HY ? jy : a.HY - 1;  // pitch padding: any valid voxel, never read
+      jx = jx < a.HX ? jx : a.HX - 1;
+      lofs0[q] = BSMI_SRC_OFF(0, z0 + a.t[0].oz + jz, y0 + a.t[0].oy + jy, x0 + a.t[0].ox + jx);
+      lofs1[q] = BSMI_SRC_OFF(1, z0 + a.t[1].oz + jz, y0 + a.t[1].oy + jy, x0 + a.t[1].ox + jx);
+      lofs2[q] = BSMI_SRC_OFF(2, z0 + a.t[2].oz + jz, y0 + a.t[2].oy + jy, x0 + a.t[2].ox + jx);
     }
   }
-  // SHORT: instruction q covers box rows (q*NW + wave)*16 .. +16, lane -> row (lane>>2), chunk lane&3
   uint32_t sofs0[HS], sofs1[HS], sofs2[HS];
   {
 #pragma unroll
     for (int q = 0; q < HS; ++q) {
-      int m = (q * NW + wave) * 16 + (lane >> 2);
-      m = m < boxrows ? m : 0;
-      const int tz = m / (a.TY * a.TX), mr = m - tz * (a.TY * a.TX);
-      const int ty = mr / a.TX, tx = mr - ty * a.TX;
-      auto off = [&](const HaloSrc& t) -> uint32_t {
-        int z = z0 + t.rz + tz, y = y0 + t.ry + ty, x = x0 + t.rx + tx;
-        z = z < t.D ? z : t.D - 1; y = y < t.H ? y : t.H - 1; x = x < t.W ? x : t.W - 1;
-        return (uint32_t)(z * t.sz + y * t.sy + x * t.sx);
-      };
-      sofs0[q] = off(a.t[0]); sofs1[q] = off(a.t[1]); sofs2[q] = off(a.t[2]);
+      int tz, ty, tx;
+      box_coords((q * NW + wave) * 16 + (lane >> 2), tz, ty, tx);
+      sofs0[q] = BSMI_SRC_OFF(0, z0 + a.t[0].rz + tz, y0 + a.t[0].ry + ty, x0 + a.t[0].rx + tx);
+      sofs1[q] = BSMI_SRC_OFF(1, z0 + a.t[1].rz + tz, y0 + a.t[1].ry + ty, x0 + a.t[1].rx + tx);
+      sofs2[q] = BSMI_SRC_OFF(2, z0 + a.t[2].rz + tz, y0 + a.t[2].ry + ty, x0 + a.t[2].rx + tx);
     }
   }
+#undef BSMI_SRC_OFF
   const uint64_t base0 = a.t[0].base, base1 = a.t[1].base, base2 = a.t[2].base;
-  // source sub-chunk this lane fetches (swizzle on the source side; LDS image lane-linear)
-  const uint32_t lsrc = (uint32_t)(((lane & 1) ^ (((lane >> 1) >> 3) & 1)) << 4);        // LONG: half ^ (row>>3)&1
-  const uint32_t ssrc = (uint32_t)(((lane & 3) ^ (((lane >> 2) >> 2) & 3)) << 4);        // SHORT: chunk ^ (row>>2)&3
-  // (row>>3)&1 / (row>>2)&3 of the staged row only depend on the lane: the per-instruction row
-  // offsets (q*NW+wave)*32 resp. *16 are multiples of 16.
+  const uint32_t hsrc = (uint32_t)(((lane & 3) ^ ((lane >> 4) & 3)) << 4);
 
-  auto issue_halo = [&](int p) {
-    const cint_ptr_t d = phases + p * 4;
-    const int t = d[0], c0 = d[1], kind = d[2], bufbase = d[3];
-    const bool t1 = t == 1, t2 = t == 2;
-    const gptr_t hb = (gptr_t)(t1 ? base1 : (t2 ? base2 : base0));
-    const lptr_t lh = (lptr_t)(smem + bufbase);
-    if (kind == 0) {
-#pragma unroll
-      for (int q = 0; q < HL; ++q) {
-        const uint32_t ro = t1 ? lofs1[q] : (t2 ? lofs2[q] : lofs0[q]);
-        __builtin_amdgcn_global_load_lds(hb + (size_t)(ro + (uint32_t)c0 + lsrc), lh + (q * NW + wave) * 1024, 16, 0, 0);
-      }
-    } else {
-#pragma unroll
-      for (int q = 0; q < HS; ++q) {
-        const uint32_t ro = t1 ? sofs1[q] : (t2 ? sofs2[q] : sofs0[q]);
-        __builtin_amdgcn_global_load_lds(hb + (size_t)(ro + (uint32_t)c0 + ssrc), lh + (q * NW + wave) * 1024, 16, 0, 0);
-      }
-    }
+  auto issue_halo = [&](int p_in) __attribute__((always_inline)) {
+    halo_issue<HL, HS, NW>(phases, p_in, lofs0, lofs1, lofs2, sofs0, sofs1, sofs2, base0, base1, base2, hsrc, smem, wave);
   };
 
   // ---- weight ring ------------------------------------------------------------------------------
@@ -169,9 +200,9 @@ __global__ __launch_bounds__(256, 1) void conv_halo_kernel(const HaloArgs a) {
   const int skey = (lane >> 4) & 3;
   const uint32_t offb = (uint32_t)((n0 + wave * 16 + lrow) * ROWB + ((lchunk ^ skey) << 4));
   const size_t wstep = (size_t)a.Npad * ROWB;
-  auto issue_b = [&](int h) {
+  auto issue_b = [&](int h) __attribute__((always_inline)) {
     const gptr_t wbase = (gptr_t)a.w + (size_t)(h < nsteps ? h : nsteps - 1) * wstep;
-    const lptr_t lb = (lptr_t)(smem + BRING + (h & (NSLOT - 1)) * SLOT);
+    const lptr_t lb = (lptr_t)(smem + BRING + (h % NSLOT) * SLOT);
 #pragma unroll
     for (int i = 0; i < BI; ++i)
       __builtin_amdgcn_global_load_lds(wbase + (size_t)i * NW * 16 * ROWB + offb, lb + (i * NW + wave) * 1024, 16, 0, 0);
@@ -184,9 +215,9 @@ __global__ __launch_bounds__(256, 1) void conv_halo_kernel(const HaloArgs a) {
   for (int i = 0; i < FM; ++i) {
     int m = wm * WTM + i * 32 + lr;
     m = m < boxrows ? m : 0;
-    const int tz = m / (a.TY * a.TX), mr = m - tz * (a.TY * a.TX);
-    const int ty = mr / a.TX, tx = mr - ty * a.TX;
-    hrowL[i] = (tz * a.HY + ty) * a.HX + tx;
+    int tz, ty, tx;
+    box_coords(m, tz, ty, tx);
+    hrowL[i] = tz * a.PZ + ty * a.PY + tx;
     hrowS[i] = m;
   }
   uint32_t brow[FN], bkey[FN];
@@ -205,68 +236,66 @@ __global__ __launch_bounds__(256, 1) void conv_halo_kernel(const HaloArgs a) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  struct SDesc { int trow0, trow1, fmt, bufbase, wait, issue; };
-  auto fetch = [&](int h) -> SDesc {
-    const cint_ptr_t d = steps + (h < nsteps ? h : nsteps - 1) * 8;
-    return SDesc{d[0], d[1], d[2], d[3], d[4], d[5]};
-  };
-
+  // K-step descriptors are kept as plain wave-uniform scalars (a struct passed through lambdas
+  // ends up in scratch memory, whose reloads drain the vmcnt queue of the LDS-DMA loads)
   u32x4_t fa[2][FM], fb[2][FN];
-  auto load_frags = [&](const SDesc& ds, int h, int sub, u32x4_t* pa, u32x4_t* pb) {
-    const int trow = sub ? ds.trow1 : ds.trow0;
-    const int cb = (sub ? (ds.fmt >> 8) : ds.fmt) & 0xff;
-    const int rsh = (ds.fmt >> 16) & 0xf, ksh = (ds.fmt >> 20) & 0xf, kmask = (ds.fmt >> 24) & 0xf;
-    const bool is_short = rsh == 6;
-    const char* hbuf = smem + ds.bufbase;
+  auto load_frags = [&](int trow, int cbu, bool is_short, int bufbase, int h, int sub, u32x4_t* pa, u32x4_t* pb) __attribute__((always_inline)) {
+    const int cb = cbu + lh;
+    const char* hbuf = smem + bufbase;
 #pragma unroll
     for (int i = 0; i < FM; ++i) {
-      const int row = (is_short ? hrowS[i] : hrowL[i]) + trow;
-      const int chunk = (cb + lh) ^ ((row >> ksh) & kmask);
-      pa[i] = *(const u32x4_t*)(hbuf + ((uint32_t)row << rsh) + (chunk << 4));
+      const int row = is_short ? hrowS[i] : hrowL[i] + trow;
+      const int chunk = cb ^ ((row >> 2) & 3);
+      pa[i] = *(const u32x4_t*)(hbuf + ((uint32_t)row << 6) + (chunk << 4));
     }
-    const char* bs = smem + BRING + (h & (NSLOT - 1)) * SLOT;
+    const char* bs = smem + BRING + (h % NSLOT) * SLOT;
     const uint32_t c = 2 * sub + lh;
 #pragma unroll
     for (int j = 0; j < FN; ++j) pb[j] = *(const u32x4_t*)(bs + brow[j] + ((c ^ bkey[j]) << 4));
   };
-  auto mma = [&](const u32x4_t* pa, const u32x4_t* pb) {
+  auto mma = [&](const u32x4_t* pa, const u32x4_t* pb) __attribute__((always_inline)) {
 #pragma unroll
     for (int i = 0; i < FM; ++i)
 #pragma unroll
       for (int j = 0; j < FN; ++j) acc[i][j] = HElem<T>::mfma(pa[i], pb[j], acc[i][j]);
   };
 
-  // prologue: halos of phases 0 and 1, weight K-steps 0..2; everything must land
+  // prologue: halos of phases 0 and 1, weight K-steps 0 .. NSLOT-2; everything must land
   issue_halo(0);
   if (a.nphases > 1) issue_halo(1);
-  issue_b(0);
-  issue_b(1);
-  issue_b(2);
+#pragma unroll
+  for (int h = 0; h < NSLOT - 1; ++h) issue_b(h);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
-  SDesc dcur = fetch(0), dnext = fetch(1);
-  load_frags(dcur, 0, 0, fa[0], fb[0]);
-  issue_b(3);
+  // descriptor of the current (c_*) and the next (n_*) K-step
+  auto clamp_step = [&](int h) __attribute__((always_inline)) { return (h < nsteps ? h : nsteps - 1) * 8; };
+  int c_trow0 = steps[0], c_trow1 = steps[1], c_cb = steps[2], c_buf = steps[3], c_wait = steps[4], c_issue = steps[5];
+  int n_trow0, n_trow1, n_cb, n_buf, n_wait, n_issue;
+  {
+    const cint_ptr_t d = steps + clamp_step(1);
+    n_trow0 = d[0]; n_trow1 = d[1]; n_cb = d[2]; n_buf = d[3]; n_wait = d[4]; n_issue = d[5];
+  }
+  load_frags(c_trow0, c_cb & 0xff, (c_cb >> 16) & 1, c_buf, 0, 0, fa[0], fb[0]);
+  issue_b(NSLOT - 1);
 
   for (int h = 0; h < nsteps; ++h) {
-    load_frags(dcur, h, 1, fa[1], fb[1]);
+    load_frags(c_trow1, (c_cb >> 8) & 0xff, (c_cb >> 16) & 1, c_buf, h, 1, fa[1], fb[1]);
     mma(fa[0], fb[0]);
     // boundary: fa[1]/fb[1] are in registers; weight K-step h+1 (and a halo first used by step
     // h+1) must have landed everywhere.  The host picked the counted wait that guarantees it.
-    switch (dcur.wait) {
-      case W_2B:    asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(2 * BI) : "memory"); break;
-      case W_2B_HL: asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(2 * BI + HL) : "memory"); break;
-      case W_2B_HS: asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(2 * BI + HS) : "memory"); break;
-      case W_1B:    asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(BI) : "memory"); break;
-      case W_1B_HS: asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(BI + HS) : "memory"); break;
-      case W_1B_HL: asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(BI + HL) : "memory"); break;
-      default:      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); break;
-    }
+    if (c_wait == W_D)           asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(D * BI) : "memory");
+    else if (c_wait == W_D_HL)   asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(D * BI + HL) : "memory");
+    else if (c_wait == W_D_HS)   asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(D * BI + HS) : "memory");
+    else if (c_wait == W_DM1)    asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"((D - 1) * BI) : "memory");
+    else if (c_wait == W_DM1_HS) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"((D - 1) * BI + HS) : "memory");
+    else if (c_wait == W_DM1_HL) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"((D - 1) * BI + HL) : "memory");
+    else                         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
-    if (dcur.issue >= 0) issue_halo(dcur.issue);
-    issue_b(h + 4);
-    const SDesc dn2 = fetch(h + 2);
-    load_frags(dnext, h + 1, 0, fa[0], fb[0]);
+    if (c_issue >= 0) issue_halo(c_issue);
+    issue_b(h + NSLOT);
+    const cint_ptr_t d2 = steps + clamp_step(h + 2);
+    const int f_trow0 = d2[0], f_trow1 = d2[1], f_cb = d2[2], f_buf = d2[3], f_wait = d2[4], f_issue = d2[5];
+    load_frags(n_trow0, n_cb & 0xff, (n_cb >> 16) & 1, n_buf, h + 1, 0, fa[0], fb[0]);
     mma(fa[1], fb[1]);
 #pragma unroll
     for (int k = 0; k < BI; ++k) {
@@ -278,8 +307,8 @@ __global__ __launch_bounds__(256, 1) void conv_halo_kernel(const HaloArgs a) {
       __builtin_amdgcn_sched_group_barrier(0x008, 1, 1);
       __builtin_amdgcn_sched_group_barrier(0x100, 1, 1);
     }
-    dcur = dnext;
-    dnext = dn2;
+    c_trow0 = n_trow0; c_trow1 = n_trow1; c_cb = n_cb; c_buf = n_buf; c_wait = n_wait; c_issue = n_issue;
+    n_trow0 = f_trow0; n_trow1 = f_trow1; n_cb = f_cb; n_buf = f_buf; n_wait = f_wait; n_issue = f_issue;
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 
@@ -291,8 +320,8 @@ __global__ __launch_bounds__(256, 1) void conv_halo_kernel(const HaloArgs a) {
     for (int r = 0; r < 16; ++r) {
       const int m = wm * WTM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
       if (m >= boxrows) continue;
-      const int tz = m / (a.TY * a.TX), mr = m - tz * (a.TY * a.TX);
-      const int ty = mr / a.TX, tx = mr - ty * a.TX;
+      int tz, ty, tx;
+      box_coords(m, tz, ty, tx);
       const int z = z0 + tz, y = y0 + ty, x = x0 + tx;
       if (z >= a.Do || y >= a.Ho || x >= a.Wo) continue;
       const size_t vox = ((size_t)z * a.Ho + y) * a.Wo + x;
@@ -308,32 +337,70 @@ __global__ __launch_bounds__(256, 1) void conv_halo_kernel(const HaloArgs a) {
   }
 }
 
-bool halo_choose_box(int Do, int Ho, int Wo, const int k[3], int box[3]) {
-  long best = -1;
-  long best_halo = 0;
+// number of extra LDS cycles (bank conflicts) of the A-fragment reads of one K-step for a given
+// box / pitch: for every 32-row fragment and every ds_read_b128 lane group count how many of the
+// 16 rows coincide mod 16 (64-byte rows, chunk swizzle (row>>2)&3)
+static int halo_conflicts(const int box[3], int PZ, int PY, int wm_count) {
+  static const int groups[2][16] = {{0, 1, 2, 3, 12, 13, 14, 15, 20, 21, 22, 23, 24, 25, 26, 27},
+                                    {4, 5, 6, 7, 8, 9, 10, 11, 16, 17, 18, 19, 28, 29, 30, 31}};
+  const int boxrows = box[0] * box[1] * box[2];
+  int cost = 0;
+  for (int f = 0; f < 256 / 32; ++f)
+    for (int g = 0; g < 2; ++g) {
+      int seen[16] = {0};
+      for (int l = 0; l < 16; ++l) {
+        int m = f * 32 + groups[g][l];
+        if (m >= boxrows) m = 0;
+        const int tz = m / (box[1] * box[2]), mr = m % (box[1] * box[2]);
+        const int row = tz * PZ + (mr / box[2]) * PY + mr % box[2];
+        cost += seen[row & 15]++;
+      }
+    }
+  (void)wm_count;
+  return cost;
+}
+
+bool halo_choose_geometry(int Do, int Ho, int Wo, const int k[3], int wm, int box[3], int pitch[2]) {
+  // score = number of boxes (tile padding waste) inflated by the LDS bank-conflict cost of the
+  // A-fragment reads: a conflict-free box that needs a few more tiles beats a conflicting one
+  double best_score = -1;
   for (int tz = 1; tz <= 16 && tz <= Do; ++tz)
     for (int ty = 1; ty <= 64 && ty <= Ho; ++ty) {
       if (tz * ty > 256) break;
       const int txmax = std::min(256 / (tz * ty), Wo);
       for (int tx = 1; tx <= txmax; ++tx) {
-        const long halo = (long)(tz + k[0] - 1) * (ty + k[1] - 1) * (tx + k[2] - 1);
-        if (halo > kHaloLongRows) break;
+        const int hz = tz + k[0] - 1, hy = ty + k[1] - 1, hx = tx + k[2] - 1;
+        if ((long)hz * hy * hx > kHaloRows) break;
         const long boxes = (long)ceil_div(Do, tz) * ceil_div(Ho, ty) * ceil_div(Wo, tx);
-        if (best < 0 || boxes < best || (boxes == best && halo < best_halo)) {
-          best = boxes; best_halo = halo;
+        if (best_score >= 0 && (double)boxes > best_score) continue;  // cannot win even conflict free
+        const int b[3] = {tz, ty, tx};
+        int c_best = -1, py_best = 0, pz_best = 0;
+        for (int py = hx; py < hx + 16; ++py)
+          for (int pz = hy * py; pz < hy * py + 16; ++pz) {
+            if ((long)hz * pz > kHaloRows) break;
+            const int c = halo_conflicts(b, pz, py, wm);
+            if (c_best < 0 || c < c_best) { c_best = c; py_best = py; pz_best = pz; }
+          }
+        if (c_best < 0) continue;
+        // 256 lane reads per K-step half; every extra conflict cycle costs about as much as a read
+        const double score = (double)boxes * (1.0 + 0.5 * c_best / 128.0);
+        if (best_score < 0 || score < best_score) {
+          best_score = score;
           box[0] = tz; box[1] = ty; box[2] = tx;
+          pitch[0] = pz_best; pitch[1] = py_best;
         }
       }
     }
-  return best > 0;
+  return best_score > 0;
 }
 
-template <typename T, int BN, int WM, int WN>
+template <typename T, int BN, int WM, int WN, int NSLOT>
 static int launch_halo_one(const HaloArgs& a, hipStream_t stream) {
   constexpr int BNL = (BN + 63) / 64 * 64;
-  constexpr int smem = 2 * kHaloBufBytes + 4 * BNL * kStepRowBytes;
+  constexpr int smem = 2 * kHaloBufBytes + NSLOT * BNL * kStepRowBytes;
+  static_assert(smem <= 160 * 1024, "LDS budget");
   static bool attr_set = false;
-  auto kern = conv_halo_kernel<T, BN, WM, WN>;
+  auto kern = conv_halo_kernel<T, BN, WM, WN, NSLOT>;
   if (!attr_set) {
     BSMI_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
     attr_set = true;
@@ -344,19 +411,21 @@ static int launch_halo_one(const HaloArgs& a, hipStream_t stream) {
   return BSMI_OK;
 }
 
+int halo_ring_slots(TileCfg cfg) { return cfg == TILE_256x256 ? 3 : 4; }
+
 template <typename T>
 static int launch_halo_cfg(const HaloArgs& a, TileCfg cfg, hipStream_t stream) {
   switch (cfg) {
-    case TILE_256x32: return launch_halo_one<T, 32, 4, 1>(a, stream);
-    case TILE_256x64: return launch_halo_one<T, 64, 4, 1>(a, stream);
-    case TILE_256x160: return launch_halo_one<T, 160, 4, 1>(a, stream);
-    case TILE_256x256: return launch_halo_one<T, 256, 2, 2>(a, stream);
+    case TILE_256x32: return launch_halo_one<T, 32, 4, 1, 4>(a, stream);
+    case TILE_256x64: return launch_halo_one<T, 64, 4, 1, 4>(a, stream);
+    case TILE_256x160: return launch_halo_one<T, 160, 4, 1, 4>(a, stream);
+    case TILE_256x256: return launch_halo_one<T, 256, 2, 2, 3>(a, stream);
     default: BSMI_FAIL(BSMI_ERR_INVALID, "halo kernel: unsupported tile config %d", (int)cfg);
   }
 }
 
 int launch_conv_halo(const HaloArgs& a, int precision, TileCfg cfg, hipStream_t stream) {
-  if (a.nsteps <= 0 || a.nphases <= 0 || a.Npad % tile_bn(cfg) != 0 || a.TZ * a.TY * a.TX > 256 || a.hv_long > kHaloLongRows)
+  if (a.nsteps <= 0 || a.nphases <= 0 || a.Npad % tile_bn(cfg) != 0 || a.TZ * a.TY * a.TX > 256 || a.HZ * a.PZ > kHaloRows)
     BSMI_FAIL(BSMI_ERR_INVALID, "halo conv launch: bad geometry");
   if (precision == BSMI_PREC_F32) return launch_halo_cfg<float>(a, cfg, stream);
   if (precision == BSMI_PREC_BF16) return launch_halo_cfg<hbf16>(a, cfg, stream);

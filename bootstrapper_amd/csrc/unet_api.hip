@@ -168,10 +168,11 @@ static void register_pass(bsmi_unet* h, const PassSite& p) {
 }
 
 // Build the unit list of stage `ci` of a ConvPass.  kUnitsPerStep consecutive entries = one
-// K-step.  Units are grouped in phases (one staged halo each, conv_halo.hip): for every source
-// slot and 16-channel slice all kernel taps (two taps per K-step), then, for the last stage, the
-// cropped 1x1x1 residual in 32-channel slices (two 16-channel halves per K-step).  Phases are
-// padded to whole K-steps with dummy units (delta 0, zero weights).
+// K-step.  Order: for every source slot, 32-channel chunk major with the kernel taps inside (one
+// tap x 32 channels per K-step, i.e. 64 contiguous bytes per gathered row; a 16-channel tensor
+// packs two taps per K-step), then, for the last stage, the cropped 1x1x1 residual in 32-channel
+// chunks.  Each (slot, 32-channel chunk) is also one "phase" of the halo kernel (conv_halo.hip):
+// LONG = all kernel taps of the chunk, SHORT = its residual tap.
 static void build_entries(const PassSite& p, int ci, int prec, std::vector<PackEntry>& out,
                           std::vector<PackPhase>* phases_out = nullptr) {
   const int SUB = sube(prec);
@@ -182,29 +183,15 @@ static void build_entries(const PassSite& p, int ci, int prec, std::vector<PackE
     ph.nunits = (int)out.size() - ph.first_unit;
     phases.push_back(ph);
   };
-  // BSMI_USE_HALO (experimental, see conv_halo.hip): phase-structured order, two kernel taps of one
-  // 16-channel slice per K-step.  Default: one tap x 32 channels per K-step (64 contiguous bytes
-  // per gathered row), channel-chunk major with the taps inside; a 16-channel tensor packs two taps.
-  static const bool halo_order = getenv("BSMI_USE_HALO") != nullptr;
   auto add_taps = [&](int slot, const int* k, int cin_base, int creal) {
     const int cpad = round_up(creal, kChanPad);
-    if (!halo_order) {
-      const size_t first = out.size();
-      for (int c32 = 0; c32 < cpad; c32 += kUnitsPerStep * SUB)
-        for (int z = 0; z < k[0]; ++z)
-          for (int y = 0; y < k[1]; ++y)
-            for (int x = 0; x < k[2]; ++x)
-              for (int c0 = c32; c0 < std::min(cpad, c32 + kUnitsPerStep * SUB); c0 += SUB)
-                out.push_back(PackEntry{slot, z, y, x, c0, 0, (z * k[1] + y) * k[2] + x, cin_base, creal, false, -1});
-      while ((out.size() - first) % kUnitsPerStep) out.push_back(PackEntry{slot, 0, 0, 0, 0, 0, 0, 0, 0, true, -1});
-      return;
-    }
-    for (int c0 = 0; c0 < cpad; c0 += SUB) {
-      PackPhase ph{slot, c0, 0, (int)out.size(), 0};
+    for (int c32 = 0; c32 < cpad; c32 += kUnitsPerStep * SUB) {
+      PackPhase ph{slot, c32, 0, (int)out.size(), 0};
       for (int z = 0; z < k[0]; ++z)
         for (int y = 0; y < k[1]; ++y)
           for (int x = 0; x < k[2]; ++x)
-            out.push_back(PackEntry{slot, z, y, x, c0, 0, (z * k[1] + y) * k[2] + x, cin_base, creal, false, (int)phases.size()});
+            for (int c0 = c32; c0 < std::min(cpad, c32 + kUnitsPerStep * SUB); c0 += SUB)
+              out.push_back(PackEntry{slot, z, y, x, c0, 0, (z * k[1] + y) * k[2] + x, cin_base, creal, false, (int)phases.size()});
       close_phase(ph);
     }
   };
@@ -238,7 +225,6 @@ static void build_entries(const PassSite& p, int ci, int prec, std::vector<PackE
       base += p.cin[s];
     }
   }
-  if (!halo_order) phases.clear();
   if (phases_out) *phases_out = phases;
 }
 
@@ -307,15 +293,17 @@ struct Planner {
     return BSMI_OK;
   }
 
-  // Halo-tiled launch of one ConvPass stage (conv_halo.hip) when an output box with a halo of at
-  // most kHaloLongRows rows exists; otherwise st.use_halo stays false (generic gather kernel).
+  // Halo-tiled launch of one ConvPass stage (conv_halo.hip) when an output box whose halo fits the
+  // LDS halo buffer exists; otherwise st.use_halo stays false (gather kernel, conv_igemm.hip).
   int plan_halo(const PassSite& p, int ci, const PackedConv& pc, const TDesc* slots, const int (*so)[3], int nsl,
                 const TDesc& o, PlanStep& st) {
     st.use_halo = false;
-    if (pc.phases.empty() || st.tile == TILE_256x320) return BSMI_OK;  // halo path is opt-in (BSMI_USE_HALO)
+    static const bool enabled = getenv("BSMI_USE_HALO") != nullptr;  // opt-in while it is being tuned
+    if (!enabled || pc.phases.empty() || st.tile == TILE_256x320) return BSMI_OK;
     const int* k = p.k[ci];
-    int box[3];
-    if (!halo_choose_box(o.D, o.H, o.W, k, box)) return BSMI_OK;
+    int box[3], pitch[2];
+    const int wm = st.tile == TILE_256x256 ? 2 : 4;
+    if (!halo_choose_geometry(o.D, o.H, o.W, k, wm, box, pitch)) return BSMI_OK;
     const int64_t es = esize(prec);
     HaloArgs& ha = st.halo;
     memset(&ha, 0, sizeof ha);
@@ -334,12 +322,15 @@ struct Planner {
       hs.oz = so[q][0]; hs.oy = so[q][1]; hs.ox = so[q][2];
       hs.rz = so[q][0] + crop[0] / 2; hs.ry = so[q][1] + crop[1] / 2; hs.rx = so[q][2] + crop[2] / 2;
     }
+    auto magic = [](int d) -> uint32_t { return d <= 1 ? 0u : (uint32_t)((((uint64_t)1 << 32) + d - 1) / d); };
     ha.TZ = box[0]; ha.TY = box[1]; ha.TX = box[2];
     ha.NBZ = ceil_div(o.D, box[0]); ha.NBY = ceil_div(o.H, box[1]); ha.NBX = ceil_div(o.W, box[2]);
-    const int HZ = box[0] + k[0] - 1;
-    ha.HY = box[1] + k[1] - 1; ha.HX = box[2] + k[2] - 1;
-    ha.hv_long = HZ * ha.HY * ha.HX;
+    ha.HZ = box[0] + k[0] - 1; ha.HY = box[1] + k[1] - 1; ha.HX = box[2] + k[2] - 1;
+    ha.PZ = pitch[0]; ha.PY = pitch[1];
+    ha.mPZ = magic(ha.PZ); ha.mPY = magic(ha.PY); ha.mTX = magic(ha.TX); ha.mTYX = magic(ha.TY * ha.TX);
 
+    const int NSLOT = halo_ring_slots(st.tile);
+    const int D = NSLOT - 2;
     const int BI = round_up(tile_bn(st.tile), 64) / 16 / 4;
     const int HL = kHaloLongInstr, HS = kHaloShortInstr;
     const size_t S = pc.entries.size() / kUnitsPerStep, P = pc.phases.size();
@@ -358,25 +349,24 @@ struct Planner {
         memset(&hs, 0, sizeof hs);
         hs.bufbase = phases[ph].bufbase;
         hs.issue = -1;
-        if (pp.kind == 0) {
-          for (int j = 0; j < kUnitsPerStep; ++j) {
-            const PackEntry& e = pc.entries[u + j];
-            hs.trow[j] = e.dummy ? 0 : (e.dz * ha.HY + e.dy) * ha.HX + e.dx;
-          }
-          hs.fmt = 0 | (0 << 8) | (5 << 16) | (3 << 20) | (1 << 24);
-        } else {
-          hs.fmt = 0 | (2 << 8) | (6 << 16) | (2 << 20) | (3 << 24);
+        int cb[2] = {0, 0};
+        for (int j = 0; j < kUnitsPerStep; ++j) {
+          const PackEntry& e = pc.entries[u + j];
+          if (e.dummy) continue;
+          cb[j] = (int)((e.c0 - pp.c0) * es / 16);
+          if (pp.kind == 0) hs.trow[j] = e.dz * ha.PZ + e.dy * ha.PY + e.dx;
         }
+        hs.cb = cb[0] | (cb[1] << 8) | (pp.kind << 16);
         steps[sidx] = hs;
       }
     }
     // issue points and counted waits: simulate the wave's in-order vector-memory queue
     struct Op { int kind, id, count; };  // kind 0 = weights of K-step id, 1 = halo of phase id
     std::vector<Op> queue;
-    queue.push_back(Op{0, 3, BI});  // after the prologue (everything else landed) K-step 3 is in flight
-    const int variants[7][2] = {{2 * BI + HL, 1}, {2 * BI + HS, 2}, {2 * BI, 0}, {BI + HL, 6}, {BI + HS, 5}, {BI, 3}, {0, 4}};
+    queue.push_back(Op{0, NSLOT - 1, BI});  // after the prologue only this K-step's weights are in flight
+    const int variants[7][2] = {{D * BI + HL, 1}, {D * BI + HS, 2}, {D * BI, 0}, {(D - 1) * BI + HL, 6},
+                                {(D - 1) * BI + HS, 5}, {(D - 1) * BI, 3}, {0, 4}};
     for (size_t h = 0; h < S; ++h) {
-      // requirements of the boundary after step h
       int need_pos = -1;
       auto require = [&](int kind, int id) {
         for (int i = (int)queue.size() - 1; i >= 0; --i)
@@ -389,22 +379,26 @@ struct Planner {
       }
       int n_ok = 0;
       for (int i = need_pos + 1; i < (int)queue.size(); ++i) n_ok += queue[i].count;
-      int kind = 4;
-      int best = -1;
+      int kind = 4, best = -1;
       for (auto& v : variants)
         if (v[0] <= n_ok && v[0] > best) { best = v[0]; kind = v[1]; }
       steps[h].wait = kind;
-      // the wait leaves at most `best` of the youngest operations outstanding
       int keep = 0, cut = (int)queue.size();
       while (cut > 0 && keep + queue[cut - 1].count <= best) keep += queue[--cut].count;
       queue.erase(queue.begin(), queue.begin() + cut);
-      // issues at this boundary: the halo two phases ahead once this phase's buffer is free, then weights
       const int ph = phase_of_step[h];
       if (last_of_phase[ph] == (int)h && (size_t)ph + 2 < P) {
         steps[h].issue = ph + 2;
         queue.push_back(Op{1, ph + 2, phases[ph + 2].kind == 0 ? HL : HS});
       }
-      queue.push_back(Op{0, (int)h + 4, BI});
+      queue.push_back(Op{0, (int)h + NSLOT, BI});
+    }
+    if (getenv("BSMI_HALO_DEBUG")) {
+      int hist[7] = {0, 0, 0, 0, 0, 0, 0};
+      for (auto& st2 : steps) hist[st2.wait]++;
+      fprintf(stderr, "[halo] %s.%d out (%d,%d,%d) box (%d,%d,%d) halo (%d,%d,%d) pitch (%d,%d) boxes %d steps %zu phases %zu waits D:%d D+HL:%d D+HS:%d D-1:%d ALL:%d D-1+HS:%d D-1+HL:%d\n",
+              p.prefix.c_str(), ci, o.D, o.H, o.W, box[0], box[1], box[2], ha.HZ, ha.HY, ha.HX, ha.PZ, ha.PY,
+              ha.NBZ * ha.NBY * ha.NBX, S, P, hist[0], hist[1], hist[2], hist[3], hist[4], hist[5], hist[6]);
     }
     HaloStep* dsteps = nullptr;
     HaloPhase* dphases = nullptr;
