@@ -685,6 +685,166 @@ __global__ void agg_relabel_kernel(const uint64_t* __restrict__ frags, size_t n,
   }
 }
 
+// ------------------------------------------------------------------------------------------
+// blockwise fragment post-processing (reference post/blockwise/watershed_frags.py:148-156,181-224)
+// ------------------------------------------------------------------------------------------
+struct FragWs {
+  unsigned long long* lsum;  // [id_cap] sum of a_z + a_y + a_x over the voxels of a fragment
+  uint32_t* lcnt;            // [id_cap] voxel count
+  uint32_t id_cap;
+  int32_t* par;              // [max_vox] union-find parent (crop volume)
+  int32_t* rank;             // [max_vox] raster-order rank of a root
+  uint32_t* blk;             // [max_vox / 1024 + 2] per-block root counts / offsets
+  uint32_t* flags;           // [0] overflow (id >= id_cap)
+};
+
+__global__ void frag_stats_kernel(const uint8_t* __restrict__ affs, const uint64_t* __restrict__ frags, size_t n, FragWs w) {
+  for (size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x; p < n; p += (size_t)gridDim.x * blockDim.x) {
+    const uint64_t f = frags[p];
+    if (!f) continue;
+    if (f >= w.id_cap) { atomicOr(w.flags, 1u); continue; }
+    atomicAdd(&w.lsum[f], (unsigned long long)((uint32_t)affs[p] + affs[n + p] + affs[2 * n + p]));
+    atomicAdd(&w.lcnt[f], 1u);
+  }
+}
+
+// filter_avg_fragments: mean of the 3-channel average affinity (u8 / 255) below filter_value;
+// remove_small_objects: fewer than min_size voxels.  Both decided per fragment on the read ROI.
+__global__ void frag_filter_kernel(uint64_t* __restrict__ frags, size_t n, FragWs w, double filter_value, long long min_size) {
+  for (size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x; p < n; p += (size_t)gridDim.x * blockDim.x) {
+    const uint64_t f = frags[p];
+    if (!f || f >= w.id_cap) continue;
+    const uint32_t c = w.lcnt[f];
+    bool drop = false;
+    if (filter_value > 0.0) drop = (double)w.lsum[f] / (765.0 * (double)c) < filter_value;
+    if (min_size > 0) drop = drop || (long long)c < min_size;
+    if (drop) frags[p] = 0;
+  }
+}
+
+__global__ void crop_u64_kernel(const uint64_t* __restrict__ in, int H, int W, int oz, int oy, int ox, int cd, int ch,
+                                int cw, uint64_t* __restrict__ out) {
+  const size_t n = (size_t)cd * ch * cw;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    const int x = (int)(i % cw);
+    const int y = (int)((i / cw) % ch);
+    const int z = (int)(i / ((size_t)cw * ch));
+    out[i] = in[((size_t)(z + oz) * H + (y + oy)) * W + (x + ox)];
+  }
+}
+
+__device__ __forceinline__ int cc_find(int32_t* par, int a) {
+  int p = __hip_atomic_load(&par[a], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  while (p != a) {
+    a = p;
+    p = __hip_atomic_load(&par[a], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  return a;
+}
+
+__global__ void cc26_init_kernel(const uint64_t* __restrict__ x, size_t n, FragWs w) {
+  for (size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x; p < n; p += (size_t)gridDim.x * blockDim.x)
+    w.par[p] = x[p] ? (int32_t)p : -1;
+}
+
+// unite every voxel with its 13 raster-preceding neighbours of equal value (26-connectivity)
+__global__ void cc26_union_kernel(const uint64_t* __restrict__ x, int D, int H, int W, FragWs w) {
+  const size_t n = (size_t)D * H * W;
+  for (size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x; p < n; p += (size_t)gridDim.x * blockDim.x) {
+    const uint64_t v = x[p];
+    if (!v) continue;
+    const int xx = (int)(p % W);
+    const int y = (int)((p / W) % H);
+    const int z = (int)(p / ((size_t)W * H));
+    for (int dz = -1; dz <= 0; ++dz)
+      for (int dy = -1; dy <= 1; ++dy)
+        for (int dx = -1; dx <= 1; ++dx) {
+          if (dz == 0 && (dy > 0 || (dy == 0 && dx >= 0))) continue;
+          const int zz = z + dz, yy = y + dy, x2 = xx + dx;
+          if (zz < 0 || yy < 0 || yy >= H || x2 < 0 || x2 >= W) continue;
+          const size_t q = ((size_t)zz * H + yy) * W + x2;
+          if (x[q] != v) continue;
+          int a = (int)p, b = (int)q;
+          for (;;) {
+            a = cc_find(w.par, a);
+            b = cc_find(w.par, b);
+            if (a == b) break;
+            if (a < b) { const int t = a; a = b; b = t; }
+            const int old = atomicMin(&w.par[a], b);
+            if (old == a) break;
+            a = old;
+          }
+        }
+  }
+}
+
+// roots per 1024-voxel block (raster order), then one workgroup scans the block counts
+__global__ __launch_bounds__(1024) void cc26_count_kernel(size_t n, FragWs w) {
+  __shared__ uint32_t cnt;
+  if (threadIdx.x == 0) cnt = 0;
+  __syncthreads();
+  const size_t p = (size_t)blockIdx.x * 1024 + threadIdx.x;
+  if (p < n && w.par[p] == (int32_t)p) atomicAdd(&cnt, 1u);
+  __syncthreads();
+  if (threadIdx.x == 0) w.blk[blockIdx.x] = cnt;
+}
+
+__global__ __launch_bounds__(1024) void cc26_scan_kernel(uint32_t nblk, FragWs w, uint64_t* num_out) {
+  __shared__ uint32_t sh[1024];
+  const uint32_t chunk = (nblk + 1023) / 1024;
+  const uint32_t c0 = threadIdx.x * chunk, c1 = min(nblk, c0 + chunk);
+  uint32_t s = 0;
+  for (uint32_t i = c0; i < c1; ++i) s += w.blk[i];
+  sh[threadIdx.x] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    uint32_t acc = 0;
+    for (int t = 0; t < 1024; ++t) { const uint32_t c = sh[t]; sh[t] = acc; acc += c; }
+    *num_out = acc;
+  }
+  __syncthreads();
+  uint32_t acc = sh[threadIdx.x];
+  for (uint32_t i = c0; i < c1; ++i) { const uint32_t c = w.blk[i]; w.blk[i] = acc; acc += c; }
+}
+
+// rank of every root = number of roots before it in raster order (+1)
+__global__ __launch_bounds__(1024) void cc26_rank_kernel(size_t n, FragWs w) {
+  __shared__ uint32_t sh[1024];
+  const size_t p = (size_t)blockIdx.x * 1024 + threadIdx.x;
+  const uint32_t flag = (p < n && w.par[p] == (int32_t)p) ? 1u : 0u;
+  sh[threadIdx.x] = flag;
+  __syncthreads();
+  for (int o = 1; o < 1024; o <<= 1) {  // inclusive Hillis-Steele scan
+    const uint32_t v = threadIdx.x >= (unsigned)o ? sh[threadIdx.x - o] : 0u;
+    __syncthreads();
+    sh[threadIdx.x] += v;
+    __syncthreads();
+  }
+  if (flag) w.rank[p] = (int32_t)(w.blk[blockIdx.x] + sh[threadIdx.x]);
+}
+
+__global__ void cc26_write_kernel(const uint64_t* __restrict__ x, size_t n, FragWs w, uint64_t id_offset, uint64_t* __restrict__ out) {
+  for (size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x; p < n; p += (size_t)gridDim.x * blockDim.x) {
+    if (!x[p]) { out[p] = 0; continue; }
+    out[p] = id_offset + (uint64_t)w.rank[cc_find(w.par, (int)p)];
+  }
+}
+
+// per-label voxel count and coordinate sums (RAG node attributes, watershed_frags.py:230-246)
+__global__ void label_stats_kernel(const uint64_t* __restrict__ lab, int D, int H, int W, uint64_t id_offset, uint64_t num,
+                                   unsigned long long* __restrict__ size, unsigned long long* __restrict__ sums) {
+  const size_t n = (size_t)D * H * W;
+  for (size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x; p < n; p += (size_t)gridDim.x * blockDim.x) {
+    const uint64_t l = lab[p];
+    if (l <= id_offset || l - id_offset > num) continue;
+    const uint64_t k = l - id_offset - 1;
+    atomicAdd(&size[k], 1ull);
+    atomicAdd(&sums[3 * k + 0], (unsigned long long)(p / ((size_t)W * H)));
+    atomicAdd(&sums[3 * k + 1], (unsigned long long)((p / W) % H));
+    atomicAdd(&sums[3 * k + 2], (unsigned long long)(p % W));
+  }
+}
+
 }  // namespace bsmi
 
 using namespace bsmi;
@@ -700,6 +860,8 @@ struct bsmi_seg {
   uint64_t* flood_spill = nullptr;
   size_t flood_spill_stride = 0;
   AggWs agg{};
+  FragWs frag{};
+  uint64_t* crop_tmp = nullptr;  // [max_vox] cropped fragments before relabelling
   float* thr_dev = nullptr;
   int* status_dev = nullptr;
 };
@@ -754,6 +916,11 @@ int bsmi_seg_create(int device, const int64_t max_shape[3], bsmi_seg** out) {
   A(g.head, (size_t)g.node_cap); A(g.parent, (size_t)g.node_cap);
   A(g.roots, (size_t)g.node_cap * kMaxThresholds); A(g.heap_spill, (size_t)g.edge_cap); A(g.maxid, 1);
   A(h->thr_dev, kMaxThresholds); A(h->status_dev, 4);
+  FragWs& f = h->frag;
+  f.id_cap = (uint32_t)std::min<size_t>(nv + 2, (size_t)1 << 27);
+  A(f.lsum, (size_t)f.id_cap); A(f.lcnt, (size_t)f.id_cap); A(f.rank, nv); A(f.blk, nv / 1024 + 2); A(f.flags, 4);
+  f.par = h->ws.par;
+  A(h->crop_tmp, nv);
 #undef A
   if (rc) {
     for (void* p : h->allocs) (void)hipFree(p);
@@ -853,12 +1020,73 @@ int bsmi_agglomerate_mean_u8(bsmi_seg* h, const uint8_t* affs_dev, const uint64_
   return BSMI_OK;
 }
 
+int bsmi_frag_postprocess_u8(bsmi_seg* h, const uint8_t* affs_dev, uint64_t* frags_dev, const int64_t shape[3],
+                             double filter_value, int64_t min_size, const int64_t crop_offset[3],
+                             const int64_t crop_shape[3], uint64_t id_offset, uint64_t* out_dev, uint64_t* num_labels_dev,
+                             void* stream) {
+  int rc = check_seg_shape(h, shape);
+  if (rc) return rc;
+  if (!affs_dev || !frags_dev || !crop_offset || !crop_shape || !out_dev || !num_labels_dev) BSMI_FAIL(BSMI_ERR_INVALID, "null argument");
+  for (int d = 0; d < 3; ++d)
+    if (crop_offset[d] < 0 || crop_shape[d] < 1 || crop_offset[d] + crop_shape[d] > shape[d])
+      BSMI_FAIL(BSMI_ERR_INVALID, "crop outside the fragment volume");
+  BSMI_HIP(hipSetDevice(h->device));
+  hipStream_t s = (hipStream_t)stream;
+  const size_t n = (size_t)shape[0] * shape[1] * shape[2];
+  const size_t nc = (size_t)crop_shape[0] * crop_shape[1] * crop_shape[2];
+  FragWs& f = h->frag;
+  const int bs = 256;
+  const int grid = (int)std::min<size_t>((n + bs - 1) / bs, 4096);
+  const int gridc = (int)std::min<size_t>((nc + bs - 1) / bs, 4096);
+  BSMI_HIP(hipMemsetAsync(f.flags, 0, 4 * sizeof(uint32_t), s));
+  if (filter_value > 0.0 || min_size > 0) {
+    BSMI_HIP(hipMemsetAsync(f.lsum, 0, (size_t)f.id_cap * sizeof(unsigned long long), s));
+    BSMI_HIP(hipMemsetAsync(f.lcnt, 0, (size_t)f.id_cap * sizeof(uint32_t), s));
+    hipLaunchKernelGGL(frag_stats_kernel, dim3(grid), dim3(bs), 0, s, affs_dev, (const uint64_t*)frags_dev, n, f);
+    hipLaunchKernelGGL(frag_filter_kernel, dim3(grid), dim3(bs), 0, s, frags_dev, n, f, filter_value, (long long)min_size);
+  }
+  hipLaunchKernelGGL(crop_u64_kernel, dim3(gridc), dim3(bs), 0, s, (const uint64_t*)frags_dev, (int)shape[1], (int)shape[2],
+                     (int)crop_offset[0], (int)crop_offset[1], (int)crop_offset[2], (int)crop_shape[0], (int)crop_shape[1],
+                     (int)crop_shape[2], h->crop_tmp);
+  const uint32_t nblk = (uint32_t)((nc + 1023) / 1024);
+  hipLaunchKernelGGL(cc26_init_kernel, dim3(gridc), dim3(bs), 0, s, (const uint64_t*)h->crop_tmp, nc, f);
+  hipLaunchKernelGGL(cc26_union_kernel, dim3(gridc), dim3(bs), 0, s, (const uint64_t*)h->crop_tmp, (int)crop_shape[0],
+                     (int)crop_shape[1], (int)crop_shape[2], f);
+  hipLaunchKernelGGL(cc26_count_kernel, dim3(nblk), dim3(1024), 0, s, nc, f);
+  hipLaunchKernelGGL(cc26_scan_kernel, dim3(1), dim3(1024), 0, s, nblk, f, num_labels_dev);
+  hipLaunchKernelGGL(cc26_rank_kernel, dim3(nblk), dim3(1024), 0, s, nc, f);
+  hipLaunchKernelGGL(cc26_write_kernel, dim3(gridc), dim3(bs), 0, s, (const uint64_t*)h->crop_tmp, nc, f, id_offset, out_dev);
+  BSMI_HIP(hipGetLastError());
+  return BSMI_OK;
+}
+
+int bsmi_label_stats(bsmi_seg* h, const uint64_t* labels_dev, const int64_t shape[3], uint64_t id_offset, uint64_t num,
+                     uint64_t* size_dev, uint64_t* sums_dev, void* stream) {
+  int rc = check_seg_shape(h, shape);
+  if (rc) return rc;
+  if (!labels_dev || !size_dev || !sums_dev) BSMI_FAIL(BSMI_ERR_INVALID, "null argument");
+  BSMI_HIP(hipSetDevice(h->device));
+  hipStream_t s = (hipStream_t)stream;
+  const size_t n = (size_t)shape[0] * shape[1] * shape[2];
+  BSMI_HIP(hipMemsetAsync(size_dev, 0, num * sizeof(uint64_t), s));
+  BSMI_HIP(hipMemsetAsync(sums_dev, 0, 3 * num * sizeof(uint64_t), s));
+  const int bs = 256;
+  hipLaunchKernelGGL(label_stats_kernel, dim3((int)std::min<size_t>((n + bs - 1) / bs, 4096)), dim3(bs), 0, s, labels_dev,
+                     (int)shape[0], (int)shape[1], (int)shape[2], id_offset, num, (unsigned long long*)size_dev,
+                     (unsigned long long*)sums_dev);
+  BSMI_HIP(hipGetLastError());
+  return BSMI_OK;
+}
+
 int bsmi_seg_status(bsmi_seg* h, void* stream) {
   if (!h) BSMI_FAIL(BSMI_ERR_INVALID, "null handle");
   BSMI_HIP(hipSetDevice(h->device));
   uint32_t c[8];
   BSMI_HIP(hipMemcpyAsync(c, h->agg.counters, sizeof c, hipMemcpyDeviceToHost, (hipStream_t)stream));
   BSMI_HIP(hipStreamSynchronize((hipStream_t)stream));
+  uint32_t ff[4];
+  BSMI_HIP(hipMemcpy(ff, h->frag.flags, sizeof ff, hipMemcpyDeviceToHost));
+  if (ff[0]) BSMI_FAIL(BSMI_ERR_OVERFLOW, "fragment id exceeds the post-processing table (ids must stay below %u)", h->frag.id_cap);
   if (c[3])
     BSMI_FAIL(BSMI_ERR_OVERFLOW, "agglomeration workspace overflow (flags 0x%x: 1 id range, 2 nodes, 4 hash, 8 edges, 16 hash churn)", c[3]);
   return BSMI_OK;

@@ -53,5 +53,39 @@ class SegEngine:
                                            C.c_void_p(segs.data_ptr()), self._stream()))
         return segs
 
+    def postprocess_fragments(self, affs_u8, frags, filter_value=0.0, min_size=0, crop_offset=(0, 0, 0),
+                              crop_shape=None, id_offset=0):
+        """Blockwise fragment clean-up (reference post/blockwise/watershed_frags.py:181-224): filter
+        by mean affinity, drop debris, crop to the write ROI, relabel 26-connected components in
+        raster order and add `id_offset`.  `frags` is filtered in place.  -> (labels int64
+        [crop_shape], num_labels int64[1]); asynchronous on the current stream."""
+        if affs_u8.dtype != torch.uint8 or not affs_u8.is_cuda or affs_u8.dim() != 4 or affs_u8.shape[0] != 3:
+            raise ValueError("affs must be a uint8 CUDA tensor of shape (3, D, H, W)")
+        if frags.dtype != torch.int64 or tuple(frags.shape) != tuple(affs_u8.shape[1:]) or not frags.is_contiguous():
+            raise ValueError("fragments must be a contiguous int64 tensor of shape (D, H, W)")
+        a = affs_u8.contiguous()
+        shape = tuple(frags.shape)
+        crop_shape = tuple(shape) if crop_shape is None else tuple(int(c) for c in crop_shape)
+        out = torch.empty(crop_shape, dtype=torch.int64, device=a.device)
+        num = torch.zeros(1, dtype=torch.int64, device=a.device)
+        check(lib.bsmi_frag_postprocess_u8(self._h, C.c_void_p(a.data_ptr()), C.c_void_p(frags.data_ptr()),
+                                           _lib.i64x3(shape), float(filter_value), int(min_size),
+                                           _lib.i64x3(crop_offset), _lib.i64x3(crop_shape), int(id_offset),
+                                           C.c_void_p(out.data_ptr()), C.c_void_p(num.data_ptr()), self._stream()))
+        return out, num
+
+    def label_stats(self, labels, id_offset, num):
+        """Voxel count and z/y/x index sums of labels id_offset+1..id_offset+num (RAG node
+        attributes, watershed_frags.py:230-246) -> (size int64[num], sums int64[num][3])."""
+        if labels.dtype != torch.int64 or labels.dim() != 3 or not labels.is_cuda:
+            raise ValueError("labels must be an int64 CUDA tensor of shape (D, H, W)")
+        lab = labels.contiguous()
+        num = int(num)
+        size = torch.empty(max(num, 1), dtype=torch.int64, device=lab.device)
+        sums = torch.empty((max(num, 1), 3), dtype=torch.int64, device=lab.device)
+        check(lib.bsmi_label_stats(self._h, C.c_void_p(lab.data_ptr()), _lib.i64x3(lab.shape), int(id_offset), num,
+                                   C.c_void_p(size.data_ptr()), C.c_void_p(sums.data_ptr()), self._stream()))
+        return size[:num], sums[:num]
+
     def status(self):
         check(lib.bsmi_seg_status(self._h, self._stream()))

@@ -140,6 +140,25 @@ int bsmi_agglomerate_mean_u8(bsmi_seg *h, const uint8_t *affs_dev, const uint64_
                              const int64_t shape[3], const float *thresholds_host,
                              int n_thresholds, uint64_t *segs_dev, void *stream);
 
+/* Blockwise fragment post-processing (reference post/blockwise/watershed_frags.py:148-156 filter_avg_fragments,
+ * :188-192 remove_small_objects, :221-224 crop to the write ROI + skimage.measure.label + global id offset).
+ * frags_dev (the read-ROI fragments of bsmi_ws_fragments_u8) is filtered IN PLACE: a fragment is removed
+ * if the mean of its 3-channel average affinity (u8/255) is < filter_value (skipped when <= 0) or if it has
+ * fewer than min_size voxels (skipped when <= 0).  The crop [crop_offset, +crop_shape) is then relabelled:
+ * connected components of equal value under 26-connectivity, numbered id_offset+1.. in raster order of
+ * their first voxel; *num_labels_dev receives the count. */
+int bsmi_frag_postprocess_u8(bsmi_seg *h, const uint8_t *affs_dev, uint64_t *frags_dev,
+                             const int64_t shape[3], double filter_value, int64_t min_size,
+                             const int64_t crop_offset[3], const int64_t crop_shape[3],
+                             uint64_t id_offset, uint64_t *out_dev, uint64_t *num_labels_dev,
+                             void *stream);
+
+/* RAG node attributes of a labelled block (watershed_frags.py:230-246): for labels id_offset+1 ..
+ * id_offset+num, size_dev[k] = voxel count and sums_dev[3k..3k+2] = sums of the z, y, x voxel indices
+ * (centre of mass = sums / size). */
+int bsmi_label_stats(bsmi_seg *h, const uint64_t *labels_dev, const int64_t shape[3], uint64_t id_offset,
+                     uint64_t num, uint64_t *size_dev, uint64_t *sums_dev, void *stream);
+
 /* status of the last asynchronous seg call on this handle (reads a device flag;
  * synchronises `stream`): BSMI_OK or BSMI_ERR_OVERFLOW */
 int bsmi_seg_status(bsmi_seg *h, void *stream);

@@ -465,3 +465,97 @@ int64_t seg_count_labels(const uint64_t *lab, int64_t n) {
   free(ids);
   return c;
 }
+
+/* ======================================================================================
+ * Blockwise fragment post-processing (reference post/blockwise/watershed_frags.py).
+ * The reference file cannot be imported here (volara / funlib absent); these functions restate
+ * the library calls it makes and are pinned by tests/golden/blockwise_cases.npz, produced by
+ * running those calls (scipy.ndimage.mean, skimage.morphology.remove_small_objects,
+ * skimage.measure.label; skimage 0.18.3) in tools/gen_goldens_blockwise.py.
+ * ====================================================================================== */
+
+/* watershed_frags.py:148-156 filter_avg_fragments on uint8 affinities taken through the
+ * float64 path of watershed_in_block (:198-205): average = mean(affs[0:3] / 255, axis=0),
+ * means = ndi.mean(average, fragments, ids).  ids must be sorted ascending (np.unique). */
+void seg_fragment_means_u8(const uint8_t *affs, const uint64_t *frags, int64_t n, const uint64_t *ids, int64_t m,
+                           double *means) {
+  double *sum = (double *)calloc(m ? m : 1, sizeof(double));
+  int64_t *cnt = (int64_t *)calloc(m ? m : 1, sizeof(int64_t));
+  for (int64_t i = 0; i < n; i++) {
+    /* binary search of the label */
+    int64_t lo = 0, hi = m - 1, k = -1;
+    while (lo <= hi) { int64_t mid = (lo + hi) / 2; if (ids[mid] == frags[i]) { k = mid; break; } if (ids[mid] < frags[i]) lo = mid + 1; else hi = mid - 1; }
+    if (k < 0) continue;
+    const double a0 = (double)affs[i] / 255.0, a1 = (double)affs[n + i] / 255.0, a2 = (double)affs[2 * n + i] / 255.0;
+    sum[k] += ((a0 + a1) + a2) / 3.0;
+    cnt[k]++;
+  }
+  for (int64_t k = 0; k < m; k++) means[k] = cnt[k] ? sum[k] / (double)cnt[k] : 0.0;
+  free(sum); free(cnt);
+}
+
+/* filter (mean < filter_value -> 0; skipped if filter_value <= 0) then remove_small_objects
+ * (label count < min_size -> 0; skipped if min_size <= 0), in place.  watershed_frags.py:181-192. */
+void seg_filter_fragments_u8(const uint8_t *affs, uint64_t *frags, int64_t n, double filter_value, int64_t min_size) {
+  uint64_t *ids = (uint64_t *)malloc(8 * (n + 1));
+  int64_t k = 0, m = 0;
+  for (int64_t i = 0; i < n; i++) ids[k++] = frags[i];
+  qsort(ids, k, 8, cmp_u64);
+  for (int64_t i = 0; i < k; i++) if (i == 0 || ids[i] != ids[i - 1]) ids[m++] = ids[i];
+  if (filter_value > 0) {
+    double *means = (double *)malloc(8 * (m ? m : 1));
+    seg_fragment_means_u8(affs, frags, n, ids, m, means);
+    for (int64_t i = 0; i < n; i++) {
+      int64_t lo = 0, hi = m - 1;
+      while (lo <= hi) { int64_t mid = (lo + hi) / 2; if (ids[mid] == frags[i]) { if (means[mid] < filter_value) frags[i] = 0; break; } if (ids[mid] < frags[i]) lo = mid + 1; else hi = mid - 1; }
+    }
+    free(means);
+  }
+  if (min_size > 0) {
+    int64_t *cnt = (int64_t *)calloc(m ? m : 1, sizeof(int64_t));
+    for (int64_t i = 0; i < n; i++) {
+      int64_t lo = 0, hi = m - 1;
+      while (lo <= hi) { int64_t mid = (lo + hi) / 2; if (ids[mid] == frags[i]) { cnt[mid]++; break; } if (ids[mid] < frags[i]) lo = mid + 1; else hi = mid - 1; }
+    }
+    for (int64_t i = 0; i < n; i++) {
+      if (!frags[i]) continue;
+      int64_t lo = 0, hi = m - 1;
+      while (lo <= hi) { int64_t mid = (lo + hi) / 2; if (ids[mid] == frags[i]) { if (cnt[mid] < min_size) frags[i] = 0; break; } if (ids[mid] < frags[i]) lo = mid + 1; else hi = mid - 1; }
+    }
+    free(cnt);
+  }
+  free(ids);
+}
+
+/* skimage.measure.label(x, return_num=True): components of equal non-zero value under full
+ * (26-) connectivity, numbered 1.. in raster order of their first voxel.  watershed_frags.py:222. */
+int64_t seg_label26(const uint64_t *x, int D, int H, int W, uint32_t *lab) {
+  const int64_t n = (int64_t)D * H * W;
+  int32_t *p = (int32_t *)malloc(sizeof(int32_t) * (n ? n : 1));
+  for (int64_t i = 0; i < n; i++) p[i] = (int32_t)i;
+  for (int z = 0; z < D; z++)
+    for (int y = 0; y < H; y++)
+      for (int xx = 0; xx < W; xx++) {
+        const int64_t i = ((int64_t)z * H + y) * W + xx;
+        if (!x[i]) continue;
+        for (int dz = -1; dz <= 0; dz++)
+          for (int dy = -1; dy <= 1; dy++)
+            for (int dx = -1; dx <= 1; dx++) {
+              if (dz == 0 && (dy > 0 || (dy == 0 && dx >= 0))) continue; /* only preceding neighbours */
+              const int zz = z + dz, yy = y + dy, x2 = xx + dx;
+              if (zz < 0 || yy < 0 || yy >= H || x2 < 0 || x2 >= W) continue;
+              const int64_t j = ((int64_t)zz * H + yy) * W + x2;
+              if (x[j] != x[i]) continue;
+              int a = uf_find(p, (int)i), b = uf_find(p, (int)j);
+              if (a != b) p[a > b ? a : b] = a > b ? b : a;
+            }
+      }
+  int64_t count = 0;
+  for (int64_t i = 0; i < n; i++) {
+    if (!x[i]) { lab[i] = 0; continue; }
+    const int r = uf_find(p, (int)i);
+    if (r == i) lab[i] = (uint32_t)(++count); else lab[i] = lab[r];
+  }
+  free(p);
+  return count;
+}

@@ -20,6 +20,12 @@ def _load():
     lib.seg_ws_fragments_u8.restype = C.c_int
     lib.seg_agglomerate_mean_u8.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int, vp, C.c_int, vp]
     lib.seg_agglomerate_mean_u8.restype = C.c_int
+    lib.seg_fragment_means_u8.argtypes = [vp, vp, C.c_int64, vp, C.c_int64, vp]
+    lib.seg_fragment_means_u8.restype = None
+    lib.seg_filter_fragments_u8.argtypes = [vp, vp, C.c_int64, C.c_double, C.c_int64]
+    lib.seg_filter_fragments_u8.restype = None
+    lib.seg_label26.argtypes = [vp, C.c_int, C.c_int, C.c_int, vp]
+    lib.seg_label26.restype = C.c_int64
     lib.seg_count_labels.argtypes = [vp, C.c_int64]
     lib.seg_count_labels.restype = C.c_int64
     return lib
@@ -53,3 +59,29 @@ def agglomerate_mean_u8(affs_u8, frags, thresholds):
                                       segs.ctypes.data)
     assert rc == 0
     return [segs[i] for i in range(len(thr))]
+
+
+def fragment_means_u8(affs_u8, frags, ids):
+    """watershed_frags.py:148-152: per-fragment mean of the 3-channel average affinity (float64)."""
+    a = np.ascontiguousarray(affs_u8[:3], dtype=np.uint8)
+    f = np.ascontiguousarray(frags, dtype=np.uint64)
+    ids = np.ascontiguousarray(ids, dtype=np.uint64)
+    means = np.zeros(len(ids), dtype=np.float64)
+    _lib.seg_fragment_means_u8(a.ctypes.data, f.ctypes.data, f.size, ids.ctypes.data, len(ids), means.ctypes.data)
+    return means
+
+
+def filter_fragments_u8(affs_u8, frags, filter_value, min_size):
+    """filter_avg_fragments + remove_small_objects (watershed_frags.py:181-192); returns a copy."""
+    a = np.ascontiguousarray(affs_u8[:3], dtype=np.uint8)
+    f = np.array(frags, dtype=np.uint64, order="C", copy=True)
+    _lib.seg_filter_fragments_u8(a.ctypes.data, f.ctypes.data, f.size, float(filter_value), int(min_size))
+    return f
+
+
+def label26(x):
+    """skimage.measure.label(x, return_num=True) -> (labels uint32, num)."""
+    x = np.ascontiguousarray(x, dtype=np.uint64)
+    lab = np.zeros(x.shape, dtype=np.uint32)
+    n = _lib.seg_label26(x.ctypes.data, x.shape[0], x.shape[1], x.shape[2], lab.ctypes.data)
+    return lab, int(n)

@@ -49,3 +49,27 @@ def test_agglomeration_invariants():
     n = [len(np.unique(s)) for s in segs]
     assert n[0] >= n[1] >= n[2] >= n[3]
     assert n[3] < n[0]
+
+
+def test_blockwise_primitives_vs_library_goldens(golden_dir):
+    """seg_fragment_means / filter / remove-small / label26 against scipy + skimage outputs
+    (tools/gen_goldens_blockwise.py)."""
+    d = np.load(os.path.join(golden_dir, "blockwise_cases.npz"))
+    for name in ("a", "b", "c"):
+        frags, affs, ids = d[name + "/frags"], d[name + "/affs"], d[name + "/ids"]
+        means = S.fragment_means_u8(affs, frags, ids)
+        assert np.array_equal(means, d[name + "/means"]), name  # bit-exact float64
+        for thr in (0.1, 0.35, 0.5):
+            got = S.filter_fragments_u8(affs, frags, thr, 0)
+            ref = frags.copy()
+            ref[np.isin(ref, d[name + f"/filtered_{thr}"])] = 0
+            assert np.array_equal(got, ref), (name, thr)
+        for ms in (1, 8, 40, 200):
+            got = S.filter_fragments_u8(affs, frags, 0.0, ms)
+            assert np.array_equal(got, d[name + f"/debris_{ms}"]), (name, ms)
+        lab, num = S.label26(frags[1:-1, 2:-3, 3:-2])
+        assert num == int(d[name + "/crop_num"][0])
+        assert np.array_equal(lab, d[name + "/crop_label"])
+    for name in ("checker", "diag"):
+        lab, num = S.label26(d[name + "/frags"])
+        assert num == int(d[name + "/num"][0]) and np.array_equal(lab, d[name + "/label"])

@@ -123,3 +123,63 @@ def test_mirror_api_generator():
         assert np.array_equal(seg.cpu().numpy().astype(np.uint64), r)
     with pytest.raises(NotImplementedError):
         next(agglomerate(a, [0.2], fragments=frags, scoring_function="OneMinus<HistogramQuantileAffinity<RegionGraphType, 50, ScoreValue, 256, false>>"))
+
+
+@pytest.mark.parametrize("shape,crop,filt,min_size", [
+    ((12, 96, 96), ((2, 16, 16), (8, 64, 64)), 0.5, 64),
+    ((6, 130, 70), ((0, 0, 0), (6, 130, 70)), 0.45, 0),
+    ((9, 64, 80), ((1, 3, 5), (7, 50, 61)), 0.0, 30),
+    ((4, 40, 40), ((0, 0, 0), (4, 40, 40)), 0.0, 0),
+])
+def test_fragment_postprocess_bit_exact_vs_oracle(shape, crop, filt, min_size):
+    """filter_avg_fragments + remove_small_objects + crop + measure.label + offset (watershed_frags.py:181-224)."""
+    from bootstrapper_amd.post.engine import SegEngine
+    from oracle import seg_ref as S
+    rng = np.random.default_rng(shape[2])
+    affs = _blobby(rng, shape, (1, 3, 3))
+    ref_frags, _ = S.ws_fragments_u8(affs, True, 5)
+    ref_f = S.filter_fragments_u8(affs, ref_frags, filt, min_size)
+    (oz, oy, ox), (cd, ch, cw) = crop
+    ref_lab, ref_n = S.label26(np.ascontiguousarray(ref_f[oz:oz + cd, oy:oy + ch, ox:ox + cw]))
+    offset = 7_000_000_000
+    ref_lab = np.where(ref_lab > 0, ref_lab + np.uint64(offset), np.uint64(0))
+
+    eng = SegEngine(shape)
+    a = torch.from_numpy(affs).cuda()
+    frags, _ = eng.ws_fragments(a, True, 5)
+    lab, num = eng.postprocess_fragments(a, frags, filt, min_size, crop[0], crop[1], offset)
+    eng.status()
+    assert int(num.item()) == ref_n
+    assert np.array_equal(frags.cpu().numpy().astype(np.uint64), ref_f)        # filtered in place
+    assert np.array_equal(lab.cpu().numpy().astype(np.uint64), ref_lab)
+
+    size, sums = eng.label_stats(lab, offset, ref_n)
+    torch.cuda.synchronize()
+    l = lab.cpu().numpy() - offset
+    idx = np.indices(l.shape)
+    for k in rng.choice(ref_n, size=min(ref_n, 20), replace=False):
+        m = l == k + 1
+        assert int(size[k]) == int(m.sum())
+        assert [int(v) for v in sums[k]] == [int(idx[d][m].sum()) for d in range(3)]
+
+
+def test_fragment_postprocess_serpentine_components():
+    """Union-find stress: one-voxel-wide spirals and equal ids split by the crop into several components."""
+    from bootstrapper_amd.post.engine import SegEngine
+    from oracle import seg_ref as S
+    rng = np.random.default_rng(3)
+    shape = (5, 64, 64)
+    frags = rng.integers(0, 4, size=shape).astype(np.uint64)      # few ids -> percolating, tangled components
+    frags[2] = 0
+    frags[3, ::2, :] = 9
+    frags[3, 1::2, :] = 0
+    frags[3, 1::4, 0] = 9
+    frags[3, 3::4, -1] = 9                                          # a serpentine of id 9 through the slice
+    affs = np.full((3,) + shape, 200, np.uint8)
+    ref_lab, ref_n = S.label26(frags)
+    eng = SegEngine(shape)
+    f = torch.from_numpy(frags.astype(np.int64)).cuda()
+    lab, num = eng.postprocess_fragments(torch.from_numpy(affs).cuda(), f, 0.0, 0)
+    eng.status()
+    assert int(num.item()) == ref_n
+    assert np.array_equal(lab.cpu().numpy().astype(np.uint64), ref_lab)
