@@ -65,6 +65,8 @@ def _load():
         "bsmi_agglomerate_mean_u8": (i32, [p, vp, vp, i64p, C.POINTER(C.c_float), i32, vp, vp]),
         "bsmi_frag_postprocess_u8": (i32, [p, vp, vp, i64p, C.c_double, C.c_int64, i64p, i64p, C.c_uint64, vp, vp, vp]),
         "bsmi_label_stats": (i32, [p, vp, i64p, C.c_uint64, C.c_uint64, vp, vp, vp]),
+        "bsmi_rag_merge_scores_u8": (i32, [p, vp, vp, i64p, C.c_float, C.c_int, vp, vp, C.c_uint64, vp, vp, vp, vp]),
+        "bsmi_lut_relabel": (i32, [C.c_int, vp, C.c_uint64, vp, vp, C.c_uint64, vp, vp]),
         "bsmi_seg_status": (i32, [p, vp]),
     }
     for name, (res, args) in sigs.items():

@@ -15,6 +15,8 @@
 //     (min-queue over the total order (score, initial edge key)), then a parallel relabel.
 #include <vector>
 
+#include <hipcub/hipcub.hpp>
+
 #include "common.h"
 
 namespace bsmi {
@@ -403,6 +405,19 @@ struct AggWs {
   uint32_t* roots;       // [nthr_cap][node_cap]
   uint64_t* heap_spill;  // [edge_cap]
   uint64_t* maxid;       // [1]
+  // RAG scoring path (arbitrary 64-bit ids): id hash, sorted edge numbering, bin queue, merge tree
+  uint64_t* idkeys;      // [icap] open-addressing set of fragment ids
+  uint32_t* idvals;      // [icap] -> rank
+  uint32_t icap;         // power of two
+  uint64_t* idu;         // [node_cap] distinct ids before sorting
+  uint64_t* skeys;       // [hcap] edge keys sorted
+  uint32_t* sslot;       // [hcap] hash slot of the sorted key
+  uint32_t* iota;        // [hcap]
+  uint32_t* qnext;       // [edge_cap] FIFO links of the bin queue
+  uint32_t* tnext;       // [2 * node_cap] merge tree parent
+  float* tscore;         // [2 * node_cap]
+  uint32_t* cur;         // [node_cap] tree node of a cluster root
+  uint32_t* ha; uint32_t* hb;  // [node_cap] merge history (ranks)
 };
 
 __global__ void agg_maxid_kernel(const uint64_t* __restrict__ frags, size_t n, AggWs w) {
@@ -462,6 +477,20 @@ __global__ __launch_bounds__(1024) void agg_rank_kernel(AggWs w) {
   }
 }
 
+template <bool HASH>
+__device__ __forceinline__ uint32_t agg_rank(const AggWs& w, uint64_t f) {
+  if constexpr (!HASH) return w.rank_of_id[f];
+  uint32_t s = (uint32_t)hmix(f) & (w.icap - 1);
+  for (uint32_t probe = 0; probe < w.icap; ++probe) {
+    const uint64_t k = w.idkeys[s];
+    if (k == f) return w.idvals[s];
+    if (k == HEMPTY) break;
+    s = (s + 1) & (w.icap - 1);
+  }
+  return 0;  // unreachable: every voxel id was inserted by rag_ids_kernel
+}
+
+template <bool HASH>
 __global__ void agg_edges_kernel(const uint8_t* __restrict__ affs, const uint64_t* __restrict__ frags, int D, int H,
                                  int W, AggWs w) {
   if (w.counters[3]) return;
@@ -473,7 +502,7 @@ __global__ void agg_edges_kernel(const uint8_t* __restrict__ affs, const uint64_
     const int x = (int)(p % W);
     const int y = (int)((p / W) % H);
     const int z = (int)(p / hw);
-    const uint32_t r1 = w.rank_of_id[f1];
+    const uint32_t r1 = agg_rank<HASH>(w, f1);
     const bool ok[3] = {z > 0, y > 0, x > 0};
     const size_t st[3] = {hw, (size_t)W, 1};
 #pragma unroll
@@ -481,7 +510,7 @@ __global__ void agg_edges_kernel(const uint8_t* __restrict__ affs, const uint64_
       if (!ok[d]) continue;
       const uint64_t f2 = frags[p - st[d]];
       if (!f2 || f2 == f1) continue;
-      const uint32_t r2 = w.rank_of_id[f2];
+      const uint32_t r2 = agg_rank<HASH>(w, f2);
       const uint32_t u = r1 < r2 ? r1 : r2, v = r1 < r2 ? r2 : r1;
       const uint64_t key = ((uint64_t)u << 32) | v;
       uint32_t slot = (uint32_t)hmix(key) & (w.hcap - 1);
@@ -686,6 +715,252 @@ __global__ void agg_relabel_kernel(const uint64_t* __restrict__ frags, size_t n,
 }
 
 // ------------------------------------------------------------------------------------------
+// per-block RAG edge scoring (reference post/blockwise/waterz_agglom.py:106-170); restated in
+// oracle/seg_ref.c seg_rag_merge_scores_u8
+// ------------------------------------------------------------------------------------------
+__global__ void rag_ids_kernel(const uint64_t* __restrict__ frags, size_t n, int W, AggWs w) {
+  for (size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x; p < n; p += (size_t)gridDim.x * blockDim.x) {
+    const uint64_t f = frags[p];
+    if (!f) continue;
+    if (p % W != 0 && frags[p - 1] == f) continue;  // the run's first voxel inserts the id
+    if (f >= HTOMB) { atomicOr(&w.counters[3], 1u); continue; }
+    uint32_t s = (uint32_t)hmix(f) & (w.icap - 1);
+    bool done = false;
+    for (uint32_t probe = 0; probe < w.icap; ++probe) {
+      const unsigned long long old = atomicCAS((unsigned long long*)&w.idkeys[s], HEMPTY, f);
+      if (old == HEMPTY) {
+        const uint32_t i = atomicAdd(&w.counters[0], 1u);
+        if (i < w.node_cap) w.idu[i] = f; else atomicOr(&w.counters[3], 2u);
+        done = true;
+        break;
+      }
+      if (old == f) { done = true; break; }
+      s = (s + 1) & (w.icap - 1);
+    }
+    if (!done) atomicOr(&w.counters[3], 2u);
+  }
+}
+
+__global__ void rag_pad_kernel(AggWs w) {
+  const uint32_t nn = min(w.counters[0], w.node_cap);
+  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < w.node_cap; i += gridDim.x * blockDim.x)
+    if (i >= nn) w.idu[i] = HEMPTY;
+}
+
+__global__ void rag_rank_kernel(AggWs w) {
+  if (w.counters[3]) return;
+  const uint32_t nn = w.counters[0];
+  for (uint32_t r = blockIdx.x * blockDim.x + threadIdx.x; r < nn; r += gridDim.x * blockDim.x) {
+    const uint64_t f = w.ids[r];
+    uint32_t s = (uint32_t)hmix(f) & (w.icap - 1);
+    while (w.idkeys[s] != f) s = (s + 1) & (w.icap - 1);
+    w.idvals[s] = r;
+    w.head[r] = NOEDGE;
+    w.parent[r] = r;
+    w.cur[r] = r;
+    w.tnext[r] = NOEDGE;
+  }
+}
+
+__global__ void rag_iota_kernel(AggWs w) {
+  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < w.hcap; i += gridDim.x * blockDim.x) w.iota[i] = i;
+}
+
+// edges numbered in ascending (u, v) order: edge e = position of its key in the sorted table
+__global__ void rag_compact_kernel(AggWs w) {
+  if (w.counters[3]) return;
+  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < w.hcap; i += gridDim.x * blockDim.x) {
+    const uint64_t key = w.skeys[i];
+    if (key == HEMPTY) continue;
+    if (i >= w.edge_cap) { atomicOr(&w.counters[3], 8u); continue; }
+    const uint32_t e = i, slot = w.sslot[i];
+    const uint32_t u = (uint32_t)(key >> 32), v = (uint32_t)key;
+    w.eu[e] = u; w.ev[e] = v; w.ekey0[e] = key;
+    w.esum[e] = w.hsum[slot]; w.ecnt[e] = w.hcnt[slot];
+    w.eflags[e] = 0;
+    w.hvals[slot] = e;
+    w.enextu[e] = atomicExch(&w.head[u], e);
+    w.enextv[e] = atomicExch(&w.head[v], e);
+    atomicMax(&w.counters[1], i + 1);
+  }
+}
+
+__device__ __forceinline__ int64_t agg_hfind(const AggWs& w, uint64_t key) {
+  uint32_t s = (uint32_t)hmix(key) & (w.hcap - 1);
+  for (uint32_t probe = 0; probe < w.hcap; ++probe) {
+    const uint64_t k = w.hkeys[s];
+    if (k == key) return (int64_t)s;
+    if (k == HEMPTY) return -1;
+    s = (s + 1) & (w.hcap - 1);
+  }
+  return -1;
+}
+
+__device__ __forceinline__ bool agg_hput(const AggWs& w, uint64_t key, uint32_t val) {
+  uint32_t s = (uint32_t)hmix(key) & (w.hcap - 1);
+  uint32_t probe = 0;
+  for (; probe < w.hcap; ++probe) {
+    const uint64_t k = w.hkeys[s];
+    if (k == HEMPTY || k == HTOMB || k == key) break;
+    s = (s + 1) & (w.hcap - 1);
+  }
+  if (probe == w.hcap) return false;
+  w.hkeys[s] = key;
+  w.hvals[s] = val;
+  return true;
+}
+
+__device__ __forceinline__ uint64_t agg_norm_key(uint32_t x, uint32_t y) {
+  return x < y ? (((uint64_t)x << 32) | y) : (((uint64_t)y << 32) | x);
+}
+
+// contract live edge e: b = larger endpoint is absorbed by a (same rewiring as agg_merge_kernel)
+__device__ __forceinline__ bool agg_contract(const AggWs& w, uint32_t e, uint32_t& a_out, uint32_t& b_out) {
+  const uint32_t eu = w.eu[e], evv = w.ev[e];
+  const uint32_t a = eu < evv ? eu : evv, b = eu < evv ? evv : eu;
+  uint32_t f = w.head[b];
+  while (f != NOEDGE) {
+    const uint32_t fu = w.eu[f], fv = w.ev[f];
+    const bool b_in_u = fu == b;
+    const uint32_t nxt = b_in_u ? w.enextu[f] : w.enextv[f];
+    if (f != e && !(w.eflags[f] & 1)) {
+      const uint32_t nb = b_in_u ? fv : fu;
+      const uint64_t gkey = agg_norm_key(a, nb);
+      const int64_t fs = agg_hfind(w, agg_norm_key(fu, fv));
+      if (fs >= 0) w.hkeys[fs] = HTOMB;
+      const int64_t gs = agg_hfind(w, gkey);
+      if (gs >= 0) {
+        const uint32_t g = w.hvals[gs];
+        w.esum[g] += w.esum[f];
+        w.ecnt[g] += w.ecnt[f];
+        w.eflags[g] |= 2;
+        w.eflags[f] |= 1;
+      } else {
+        if (b_in_u) { w.eu[f] = a; w.enextu[f] = w.head[a]; } else { w.ev[f] = a; w.enextv[f] = w.head[a]; }
+        w.head[a] = f;
+        w.eflags[f] |= 2;
+        if (!agg_hput(w, gkey, f)) return false;
+      }
+    }
+    f = nxt;
+  }
+  const int64_t es = agg_hfind(w, agg_norm_key(eu, evv));
+  if (es >= 0) w.hkeys[es] = HTOMB;
+  w.eflags[e] |= 1;
+  w.parent[b] = a;
+  a_out = a;
+  b_out = b;
+  return true;
+}
+
+constexpr int kMaxQueueBins = 1024;
+
+// One lane replays the sequential bin-queue merge loop and grows the merge tree.
+__global__ __launch_bounds__(64) void rag_merge_kernel(AggWs w, float threshold, int nbins) {
+  __shared__ uint32_t bhead[kMaxQueueBins], btail[kMaxQueueBins];
+  if (w.counters[3]) return;
+  for (int b = threadIdx.x; b < nbins; b += 64) bhead[b] = btail[b] = NOEDGE;
+  __syncthreads();
+  if (threadIdx.x != 0) return;
+  const uint32_t nn = w.counters[0];
+  const uint32_t ne = min(w.counters[1], w.edge_cap);
+  int minbin = nbins;
+  const float scale = (float)(nbins - 1);
+  auto push = [&](uint32_t e, float sc) {
+    int b = (int)(sc * scale);
+    b = b < 0 ? 0 : (b > nbins - 1 ? nbins - 1 : b);
+    w.qnext[e] = NOEDGE;
+    if (bhead[b] == NOEDGE) bhead[b] = e; else w.qnext[btail[b]] = e;
+    btail[b] = e;
+    if (b < minbin) minbin = b;
+  };
+  for (uint32_t e = 0; e < ne; ++e) {
+    const float sc = agg_score(w.esum[e], w.ecnt[e]);
+    if (sc < threshold) push(e, sc);
+  }
+  uint32_t nm = 0;
+  for (;;) {
+    while (minbin < nbins && bhead[minbin] == NOEDGE) ++minbin;
+    if (minbin >= nbins) break;
+    const uint32_t e = bhead[minbin];
+    bhead[minbin] = w.qnext[e];
+    const uint8_t fl = w.eflags[e];
+    if (fl & 1) continue;
+    const float sc = agg_score(w.esum[e], w.ecnt[e]);
+    if (fl & 2) {
+      w.eflags[e] = fl & ~2;
+      if (sc < threshold) push(e, sc);
+      continue;
+    }
+    uint32_t a, b;
+    if (!agg_contract(w, e, a, b)) { atomicOr(&w.counters[3], 16u); break; }
+    const uint32_t t = nn + nm;
+    w.tnext[w.cur[a]] = t;
+    w.tnext[w.cur[b]] = t;
+    w.cur[a] = t;
+    w.tnext[t] = NOEDGE;
+    w.tscore[t] = sc;
+    w.ha[nm] = a;
+    w.hb[nm] = b;
+    ++nm;
+  }
+  w.counters[4] = nm;
+}
+
+// score of RAG edge {u, v} = score of the lowest common ancestor in the merge tree (tree nodes
+// are numbered in creation order, so the smaller index is always the one to climb)
+__global__ void rag_scores_kernel(AggWs w, uint64_t* __restrict__ edges, float* __restrict__ scores, uint64_t cap,
+                                  uint64_t* __restrict__ merges, float* __restrict__ mscores, uint64_t* __restrict__ counts) {
+  if (w.counters[3]) return;
+  const uint32_t nn = w.counters[0];
+  const uint32_t ne = min(w.counters[1], w.edge_cap);
+  const uint32_t nm = w.counters[4];
+  if (ne > cap) {
+    if (blockIdx.x == 0 && threadIdx.x == 0) atomicOr(&w.counters[3], 32u);
+    return;
+  }
+  if (blockIdx.x == 0 && threadIdx.x == 0) { counts[0] = ne; counts[1] = nm; counts[2] = nn; }
+  for (uint32_t e = blockIdx.x * blockDim.x + threadIdx.x; e < ne; e += gridDim.x * blockDim.x) {
+    const uint64_t key = w.ekey0[e];
+    uint32_t x = (uint32_t)(key >> 32), y = (uint32_t)key;
+    edges[2 * (size_t)e] = w.ids[x];
+    edges[2 * (size_t)e + 1] = w.ids[y];
+    float sc = __uint_as_float(0x7fc00000u);
+    for (;;) {
+      if (x == y) { sc = w.tscore[x]; break; }
+      if (x < y) { const uint32_t nx = w.tnext[x]; if (nx == NOEDGE) break; x = nx; }
+      else { const uint32_t ny = w.tnext[y]; if (ny == NOEDGE) break; y = ny; }
+    }
+    scores[e] = sc;
+  }
+  if (merges)
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < nm; i += gridDim.x * blockDim.x) {
+      merges[2 * (size_t)i] = w.ids[w.ha[i]];
+      merges[2 * (size_t)i + 1] = w.ids[w.hb[i]];
+      if (mscores) mscores[i] = w.tscore[nn + i];
+    }
+}
+
+// segmentation lookup: out[p] = vals[k] where keys[k] == in[p] (keys ascending), 0 stays 0, an id
+// that is not a key maps to itself.  volara Relabel + LUT (post/watershed.py:187-202).
+__global__ void lut_relabel_kernel(const uint64_t* __restrict__ in, size_t n, const uint64_t* __restrict__ keys,
+                                   const uint64_t* __restrict__ vals, uint64_t m, uint64_t* __restrict__ out) {
+  for (size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x; p < n; p += (size_t)gridDim.x * blockDim.x) {
+    const uint64_t f = in[p];
+    uint64_t r = f;
+    if (f && m) {
+      uint64_t lo = 0, hi = m;
+      while (lo < hi) {
+        const uint64_t mid = (lo + hi) >> 1;
+        if (keys[mid] < f) lo = mid + 1; else hi = mid;
+      }
+      if (lo < m && keys[lo] == f) r = vals[lo];
+    }
+    out[p] = r;
+  }
+}
+
+// ------------------------------------------------------------------------------------------
 // blockwise fragment post-processing (reference post/blockwise/watershed_frags.py:148-156,181-224)
 // ------------------------------------------------------------------------------------------
 struct FragWs {
@@ -709,16 +984,38 @@ __global__ void frag_stats_kernel(const uint8_t* __restrict__ affs, const uint64
 }
 
 // filter_avg_fragments: mean of the 3-channel average affinity (u8 / 255) below filter_value;
-// remove_small_objects: fewer than min_size voxels.  Both decided per fragment on the read ROI.
-__global__ void frag_filter_kernel(uint64_t* __restrict__ frags, size_t n, FragWs w, double filter_value, long long min_size) {
+// remove_small_objects: fewer than min_size voxels.  Both decided per fragment on the read ROI
+// and recorded in bit 31 of the count.  The reference accumulates float64 values
+// ((a0/255 + a1/255) + a2/255) / 3 in raster order (numpy mean over axis 0, scipy.ndimage.mean =
+// bincount); the exact rational S / (765 n) decides unless it lies within 1e-9 of the filter,
+// where the float64 accumulation is replayed sequentially so that the outcome is the reference's.
+__global__ void frag_decide_kernel(const uint8_t* __restrict__ affs, const uint64_t* __restrict__ frags, size_t n, FragWs w,
+                                   double filter_value, long long min_size) {
+  for (uint32_t f = blockIdx.x * blockDim.x + threadIdx.x; f < w.id_cap; f += gridDim.x * blockDim.x) {
+    const uint32_t c = w.lcnt[f];
+    if (!c || !f) continue;
+    bool drop = false;
+    if (filter_value > 0.0) {
+      double mean = (double)w.lsum[f] / (765.0 * (double)c);
+      if (fabs(mean - filter_value) <= 1e-9) {
+        double sum = 0.0;
+        for (size_t p = 0; p < n; ++p)
+          if (frags[p] == f)
+            sum += (((double)affs[p] / 255.0 + (double)affs[n + p] / 255.0) + (double)affs[2 * n + p] / 255.0) / 3.0;
+        mean = sum / (double)c;
+      }
+      drop = mean < filter_value;
+    }
+    if (min_size > 0) drop = drop || (long long)c < min_size;
+    if (drop) w.lcnt[f] = c | 0x80000000u;
+  }
+}
+
+__global__ void frag_filter_kernel(uint64_t* __restrict__ frags, size_t n, FragWs w) {
   for (size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x; p < n; p += (size_t)gridDim.x * blockDim.x) {
     const uint64_t f = frags[p];
     if (!f || f >= w.id_cap) continue;
-    const uint32_t c = w.lcnt[f];
-    bool drop = false;
-    if (filter_value > 0.0) drop = (double)w.lsum[f] / (765.0 * (double)c) < filter_value;
-    if (min_size > 0) drop = drop || (long long)c < min_size;
-    if (drop) frags[p] = 0;
+    if (w.lcnt[f] & 0x80000000u) frags[p] = 0;
   }
 }
 
@@ -862,6 +1159,9 @@ struct bsmi_seg {
   AggWs agg{};
   FragWs frag{};
   uint64_t* crop_tmp = nullptr;  // [max_vox] cropped fragments before relabelling
+  void* sort_tmp = nullptr;      // hipcub radix-sort scratch
+  size_t sort_tmp_bytes = 0;
+  uint64_t* rag_counts = nullptr;  // [4] ne, nm, nn of the last RAG call
   float* thr_dev = nullptr;
   int* status_dev = nullptr;
 };
@@ -921,6 +1221,25 @@ int bsmi_seg_create(int device, const int64_t max_shape[3], bsmi_seg** out) {
   A(f.lsum, (size_t)f.id_cap); A(f.lcnt, (size_t)f.id_cap); A(f.rank, nv); A(f.blk, nv / 1024 + 2); A(f.flags, 4);
   f.par = h->ws.par;
   A(h->crop_tmp, nv);
+  g.icap = next_pow2((size_t)g.node_cap * 2);
+  A(g.idkeys, (size_t)g.icap); A(g.idvals, (size_t)g.icap); A(g.idu, (size_t)g.node_cap);
+  A(g.skeys, (size_t)g.hcap); A(g.sslot, (size_t)g.hcap); A(g.iota, (size_t)g.hcap); A(g.qnext, (size_t)g.edge_cap);
+  A(g.tnext, (size_t)g.node_cap * 2); A(g.tscore, (size_t)g.node_cap * 2); A(g.cur, (size_t)g.node_cap);
+  A(g.ha, (size_t)g.node_cap); A(g.hb, (size_t)g.node_cap); A(h->rag_counts, 4);
+  if (!rc) {
+    size_t b1 = 0, b2 = 0;
+    if (hipcub::DeviceRadixSort::SortKeys(nullptr, b1, (const uint64_t*)nullptr, (uint64_t*)nullptr, (int)g.node_cap) != hipSuccess ||
+        hipcub::DeviceRadixSort::SortPairs(nullptr, b2, (const uint64_t*)nullptr, (uint64_t*)nullptr, (const uint32_t*)nullptr,
+                                           (uint32_t*)nullptr, (int)g.hcap) != hipSuccess) {
+      bsmi::set_error("hipcub temp-storage query failed");
+      rc = BSMI_ERR_HIP;
+    } else {
+      h->sort_tmp_bytes = std::max(b1, b2) + 256;
+      uint8_t* t = nullptr;
+      rc = dalloc(h, &t, h->sort_tmp_bytes);
+      h->sort_tmp = t;
+    }
+  }
 #undef A
   if (rc) {
     for (void* p : h->allocs) (void)hipFree(p);
@@ -1012,7 +1331,7 @@ int bsmi_agglomerate_mean_u8(bsmi_seg* h, const uint8_t* affs_dev, const uint64_
   hipLaunchKernelGGL(agg_maxid_kernel, dim3(grid), dim3(bs), 0, s, frags_dev, n, g);
   hipLaunchKernelGGL(agg_mark_kernel, dim3(grid), dim3(bs), 0, s, frags_dev, n, g);
   hipLaunchKernelGGL(agg_rank_kernel, dim3(1), dim3(1024), 0, s, g);
-  hipLaunchKernelGGL(agg_edges_kernel, dim3(grid), dim3(bs), 0, s, affs_dev, frags_dev, D, H, W, g);
+  hipLaunchKernelGGL(agg_edges_kernel<false>, dim3(grid), dim3(bs), 0, s, affs_dev, frags_dev, D, H, W, g);
   hipLaunchKernelGGL(agg_compact_kernel, dim3(std::min<uint32_t>(g.hcap / bs, 2048u)), dim3(bs), 0, s, g);
   hipLaunchKernelGGL(agg_merge_kernel, dim3(1), dim3(64), 0, s, g, (const float*)h->thr_dev, n_thresholds);
   hipLaunchKernelGGL(agg_relabel_kernel, dim3(grid), dim3(bs), 0, s, frags_dev, n, n_thresholds, g, segs_dev);
@@ -1043,7 +1362,9 @@ int bsmi_frag_postprocess_u8(bsmi_seg* h, const uint8_t* affs_dev, uint64_t* fra
     BSMI_HIP(hipMemsetAsync(f.lsum, 0, (size_t)f.id_cap * sizeof(unsigned long long), s));
     BSMI_HIP(hipMemsetAsync(f.lcnt, 0, (size_t)f.id_cap * sizeof(uint32_t), s));
     hipLaunchKernelGGL(frag_stats_kernel, dim3(grid), dim3(bs), 0, s, affs_dev, (const uint64_t*)frags_dev, n, f);
-    hipLaunchKernelGGL(frag_filter_kernel, dim3(grid), dim3(bs), 0, s, frags_dev, n, f, filter_value, (long long)min_size);
+    hipLaunchKernelGGL(frag_decide_kernel, dim3(grid), dim3(bs), 0, s, affs_dev, (const uint64_t*)frags_dev, n, f, filter_value,
+                       (long long)min_size);
+    hipLaunchKernelGGL(frag_filter_kernel, dim3(grid), dim3(bs), 0, s, frags_dev, n, f);
   }
   hipLaunchKernelGGL(crop_u64_kernel, dim3(gridc), dim3(bs), 0, s, (const uint64_t*)frags_dev, (int)shape[1], (int)shape[2],
                      (int)crop_offset[0], (int)crop_offset[1], (int)crop_offset[2], (int)crop_shape[0], (int)crop_shape[1],
@@ -1078,6 +1399,59 @@ int bsmi_label_stats(bsmi_seg* h, const uint64_t* labels_dev, const int64_t shap
   return BSMI_OK;
 }
 
+int bsmi_rag_merge_scores_u8(bsmi_seg* h, const uint8_t* affs_dev, const uint64_t* frags_dev, const int64_t shape[3],
+                             float threshold, int discretize_queue, uint64_t* edges_dev, float* scores_dev,
+                             uint64_t edge_capacity, uint64_t* merges_dev, float* merge_scores_dev, uint64_t* counts_dev,
+                             void* stream) {
+  int rc = check_seg_shape(h, shape);
+  if (rc) return rc;
+  if (!affs_dev || !frags_dev || !edges_dev || !scores_dev || !counts_dev) BSMI_FAIL(BSMI_ERR_INVALID, "null argument");
+  if (discretize_queue < 1 || discretize_queue > kMaxQueueBins)
+    BSMI_FAIL(BSMI_ERR_INVALID, "discretize_queue must be in [1, %d] (the exact-order queue is bsmi_agglomerate_mean_u8)", kMaxQueueBins);
+  if (!(threshold > 0.f)) BSMI_FAIL(BSMI_ERR_INVALID, "threshold must be positive");
+  BSMI_HIP(hipSetDevice(h->device));
+  hipStream_t s = (hipStream_t)stream;
+  const size_t n = (size_t)shape[0] * shape[1] * shape[2];
+  const int D = (int)shape[0], H = (int)shape[1], W = (int)shape[2];
+  AggWs& g = h->agg;
+  BSMI_HIP(hipMemsetAsync(g.counters, 0, 8 * sizeof(uint32_t), s));
+  BSMI_HIP(hipMemsetAsync(counts_dev, 0, 3 * sizeof(uint64_t), s));
+  BSMI_HIP(hipMemsetAsync(g.idkeys, 0xff, (size_t)g.icap * sizeof(uint64_t), s));
+  BSMI_HIP(hipMemsetAsync(g.hkeys, 0xff, (size_t)g.hcap * sizeof(uint64_t), s));
+  BSMI_HIP(hipMemsetAsync(g.hsum, 0, (size_t)g.hcap * sizeof(unsigned long long), s));
+  BSMI_HIP(hipMemsetAsync(g.hcnt, 0, (size_t)g.hcap * sizeof(uint32_t), s));
+  const int bs = 256;
+  const int grid = (int)std::min<size_t>((n + bs - 1) / bs, 4096);
+  hipLaunchKernelGGL(rag_ids_kernel, dim3(grid), dim3(bs), 0, s, frags_dev, n, W, g);
+  hipLaunchKernelGGL(rag_pad_kernel, dim3(256), dim3(bs), 0, s, g);
+  size_t tb = h->sort_tmp_bytes;
+  BSMI_HIP(hipcub::DeviceRadixSort::SortKeys(h->sort_tmp, tb, (const uint64_t*)g.idu, g.ids, (int)g.node_cap, 0, 64, s));
+  hipLaunchKernelGGL(rag_rank_kernel, dim3(256), dim3(bs), 0, s, g);
+  hipLaunchKernelGGL(agg_edges_kernel<true>, dim3(grid), dim3(bs), 0, s, affs_dev, frags_dev, D, H, W, g);
+  hipLaunchKernelGGL(rag_iota_kernel, dim3(1024), dim3(bs), 0, s, g);
+  tb = h->sort_tmp_bytes;
+  BSMI_HIP(hipcub::DeviceRadixSort::SortPairs(h->sort_tmp, tb, (const uint64_t*)g.hkeys, g.skeys, (const uint32_t*)g.iota, g.sslot,
+                                              (int)g.hcap, 0, 64, s));
+  hipLaunchKernelGGL(rag_compact_kernel, dim3(std::min<uint32_t>(g.hcap / bs, 2048u)), dim3(bs), 0, s, g);
+  hipLaunchKernelGGL(rag_merge_kernel, dim3(1), dim3(64), 0, s, g, threshold, discretize_queue);
+  hipLaunchKernelGGL(rag_scores_kernel, dim3(1024), dim3(bs), 0, s, g, edges_dev, scores_dev, edge_capacity, merges_dev,
+                     merge_scores_dev, counts_dev);
+  BSMI_HIP(hipGetLastError());
+  return BSMI_OK;
+}
+
+int bsmi_lut_relabel(int device, const uint64_t* in_dev, uint64_t n, const uint64_t* keys_dev, const uint64_t* vals_dev, uint64_t m,
+                     uint64_t* out_dev, void* stream) {
+  if (!in_dev || !out_dev || (m && (!keys_dev || !vals_dev))) BSMI_FAIL(BSMI_ERR_INVALID, "null argument");
+  BSMI_HIP(hipSetDevice(device));
+  if (!n) return BSMI_OK;
+  const int bs = 256;
+  hipLaunchKernelGGL(lut_relabel_kernel, dim3((int)std::min<uint64_t>((n + bs - 1) / bs, 8192)), dim3(bs), 0, (hipStream_t)stream,
+                     in_dev, (size_t)n, keys_dev, vals_dev, m, out_dev);
+  BSMI_HIP(hipGetLastError());
+  return BSMI_OK;
+}
+
 int bsmi_seg_status(bsmi_seg* h, void* stream) {
   if (!h) BSMI_FAIL(BSMI_ERR_INVALID, "null handle");
   BSMI_HIP(hipSetDevice(h->device));
@@ -1088,7 +1462,7 @@ int bsmi_seg_status(bsmi_seg* h, void* stream) {
   BSMI_HIP(hipMemcpy(ff, h->frag.flags, sizeof ff, hipMemcpyDeviceToHost));
   if (ff[0]) BSMI_FAIL(BSMI_ERR_OVERFLOW, "fragment id exceeds the post-processing table (ids must stay below %u)", h->frag.id_cap);
   if (c[3])
-    BSMI_FAIL(BSMI_ERR_OVERFLOW, "agglomeration workspace overflow (flags 0x%x: 1 id range, 2 nodes, 4 hash, 8 edges, 16 hash churn)", c[3]);
+    BSMI_FAIL(BSMI_ERR_OVERFLOW, "agglomeration workspace overflow (flags 0x%x: 1 id range, 2 nodes, 4 hash, 8 edges, 16 hash churn, 32 edge buffer too small)", c[3]);
   return BSMI_OK;
 }
 

@@ -87,5 +87,52 @@ class SegEngine:
                                    C.c_void_p(size.data_ptr()), C.c_void_p(sums.data_ptr()), self._stream()))
         return size[:num], sums[:num]
 
+    def rag_merge_scores(self, affs_u8, frags, threshold=1.0, discretize_queue=256, return_merges=False):
+        """Initial RAG edges of a block and the score at which each edge's fragments merge
+        (reference post/blockwise/waterz_agglom.py:106-170).  Synchronises.  -> (edges int64 [ne][2]
+        holding the uint64 ids, scores float32 [ne] with NaN = never merged[, merges int64 [nm][2],
+        merge_scores float32 [nm]]) as CUDA tensors."""
+        if affs_u8.dtype != torch.uint8 or not affs_u8.is_cuda or affs_u8.dim() != 4 or affs_u8.shape[0] != 3:
+            raise ValueError("affs must be a uint8 CUDA tensor of shape (3, D, H, W)")
+        if frags.dtype != torch.int64 or tuple(frags.shape) != tuple(affs_u8.shape[1:]):
+            raise ValueError("fragments must be an int64 tensor of shape (D, H, W)")
+        a, f = affs_u8.contiguous(), frags.contiguous()
+        cap = self._rag_cap = getattr(self, "_rag_cap", None) or max(1024, f.numel() // 4)
+        dev = a.device
+        edges = torch.empty((cap, 2), dtype=torch.int64, device=dev)
+        scores = torch.empty(cap, dtype=torch.float32, device=dev)
+        ncap = max(1024, f.numel() // 8 + 1024)
+        merges = torch.empty((ncap, 2), dtype=torch.int64, device=dev) if return_merges else None
+        mscores = torch.empty(ncap, dtype=torch.float32, device=dev) if return_merges else None
+        counts = torch.zeros(4, dtype=torch.int64, device=dev)
+        check(lib.bsmi_rag_merge_scores_u8(self._h, C.c_void_p(a.data_ptr()), C.c_void_p(f.data_ptr()), _lib.i64x3(f.shape),
+                                           float(threshold), int(discretize_queue), C.c_void_p(edges.data_ptr()),
+                                           C.c_void_p(scores.data_ptr()), cap,
+                                           C.c_void_p(merges.data_ptr()) if return_merges else None,
+                                           C.c_void_p(mscores.data_ptr()) if return_merges else None,
+                                           C.c_void_p(counts.data_ptr()), self._stream()))
+        self.status()
+        ne, nm = int(counts[0]), int(counts[1])
+        if return_merges:
+            return edges[:ne], scores[:ne], merges[:nm], mscores[:nm]
+        return edges[:ne], scores[:ne]
+
     def status(self):
         check(lib.bsmi_seg_status(self._h, self._stream()))
+
+
+def lut_relabel(labels, keys, vals, out=None):
+    """out[p] = vals[k] where keys[k] == labels[p] (keys ascending int64/uint64 ids); volara Relabel
+    (reference post/watershed.py:187-202).  CUDA int64 tensors; asynchronous on the current stream."""
+    if labels.dtype != torch.int64 or not labels.is_cuda:
+        raise ValueError("labels must be an int64 CUDA tensor")
+    lab = labels.contiguous()
+    keys = keys.to(device=lab.device, dtype=torch.int64).contiguous()
+    vals = vals.to(device=lab.device, dtype=torch.int64).contiguous()
+    if keys.numel() != vals.numel():
+        raise ValueError("keys and vals differ in length")
+    out = torch.empty_like(lab) if out is None else out
+    stream = C.c_void_p(torch.cuda.current_stream(lab.device).cuda_stream)
+    check(lib.bsmi_lut_relabel(lab.device.index, C.c_void_p(lab.data_ptr()), lab.numel(), C.c_void_p(keys.data_ptr()),
+                               C.c_void_p(vals.data_ptr()), keys.numel(), C.c_void_p(out.data_ptr()), stream))
+    return out

@@ -159,6 +159,25 @@ int bsmi_frag_postprocess_u8(bsmi_seg *h, const uint8_t *affs_dev, uint64_t *fra
 int bsmi_label_stats(bsmi_seg *h, const uint64_t *labels_dev, const int64_t shape[3], uint64_t id_offset,
                      uint64_t num, uint64_t *size_dev, uint64_t *sums_dev, void *stream);
 
+/* Per-block RAG edge scoring (reference post/blockwise/waterz_agglom.py:106-170): dense relabel of the
+ * fragment ids in ascending order (:116-120), waterz.agglomerate(thresholds=[0, threshold],
+ * discretize_queue, return_merge_history, return_region_graph) (:131-139), MergeTree replay and per-edge
+ * merge score (:153-170; post/merge_tree.py:5-113).  frags_dev may hold arbitrary 64-bit ids (< 2^64-2).
+ * Outputs: edges_dev[2e], edges_dev[2e+1] = ids (u < v) of initial RAG edge e, in ascending (u, v) order;
+ * scores_dev[e] = score of the merge that first joined u and v, NaN if they never merge below `threshold`;
+ * merges_dev[2i], [2i+1] = (surviving id, absorbed id) and merge_scores_dev[i] of merge i (both optional);
+ * counts_dev[0..2] = number of edges, merges, nodes.  bsmi_seg_status reports an edge_capacity overflow. */
+int bsmi_rag_merge_scores_u8(bsmi_seg *h, const uint8_t *affs_dev, const uint64_t *frags_dev,
+                             const int64_t shape[3], float threshold, int discretize_queue,
+                             uint64_t *edges_dev, float *scores_dev, uint64_t edge_capacity,
+                             uint64_t *merges_dev, float *merge_scores_dev, uint64_t *counts_dev,
+                             void *stream);
+
+/* LUT relabel (volara Relabel + LUT, post/watershed.py:187-202): out[p] = vals[k] where keys[k] == in[p]
+ * (keys ascending); 0 stays 0; ids without a key are copied.  in_dev == out_dev is allowed. */
+int bsmi_lut_relabel(int device, const uint64_t *in_dev, uint64_t n, const uint64_t *keys_dev,
+                     const uint64_t *vals_dev, uint64_t m, uint64_t *out_dev, void *stream);
+
 /* status of the last asynchronous seg call on this handle (reads a device flag;
  * synchronises `stream`): BSMI_OK or BSMI_ERR_OVERFLOW */
 int bsmi_seg_status(bsmi_seg *h, void *stream);

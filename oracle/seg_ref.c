@@ -559,3 +559,185 @@ int64_t seg_label26(const uint64_t *x, int D, int H, int W, uint32_t *lab) {
   free(p);
   return count;
 }
+
+/* ======================================================================================
+ * Per-block RAG edge scoring (reference post/blockwise/waterz_agglom.py:106-170).
+ *
+ * The reference relabels the block's fragments densely in ascending id order
+ * (funlib.segment.arrays.relabel, :116-120), runs waterz.agglomerate(thresholds=[0, 1.0],
+ * discretize_queue=256, return_merge_history, return_region_graph) (:131-139), takes the
+ * region graph of the first item as the initial RAG (:141-146), replays the merge history of
+ * the second into a MergeTree (:153-160) and stores for every RAG edge the score of the merge
+ * in which its two fragments first joined one segment, None if they never do (:162-170).
+ * waterz is absent (see the header): **parity unpinned**; the restatement, to which the HIP
+ * kernels are held bit for bit, is
+ *   nodes   ranks of the distinct non-zero ids in ascending order
+ *   edges   as in seg_agglomerate_mean_u8, numbered in ascending (u, v) order
+ *   queue   `nbins` FIFO bins, bin = (int)(score * (nbins - 1)) in float32; an edge enters the
+ *           queue only while its score < threshold; initial pushes in edge order
+ *   loop    take the front of the lowest non-empty bin; deleted -> drop; stale -> rescore and
+ *           push to the back of its new bin; else merge exactly as seg_agglomerate_mean_u8 and
+ *           record (a, b, score); until the queue is empty
+ *   score   of RAG edge {u, v} = score recorded by the merge that first put u and v in one
+ *           cluster (the lowest common ancestor of the merge tree, post/merge_tree.py:5-27), NaN if none.
+ * Returns the number of edges (edges_out[2e], edges_out[2e+1] = fragment ids, u < v, ascending);
+ * merges_out (a = surviving id, b) and mscores_out hold the merge history in order.
+ * ====================================================================================== */
+typedef struct { uint64_t key; uint8_t aff; } epair;
+static int cmp_epair(const void *a, const void *b) { uint64_t x = ((const epair *)a)->key, y = ((const epair *)b)->key; return x < y ? -1 : x > y; }
+
+int64_t seg_rag_merge_scores_u8(const uint8_t *affs, const uint64_t *frags, int D, int H, int W, float threshold, int nbins,
+                                uint64_t *edges_out, float *scores_out, int64_t cap, uint64_t *merges_out,
+                                float *mscores_out, int64_t *nmerges_out) {
+  const int64_t hw = (int64_t)H * W, n = hw * D;
+  uint64_t *ids = (uint64_t *)malloc(8 * (n + 1));
+  int64_t nid = 0, nn = 0;
+  for (int64_t i = 0; i < n; i++) if (frags[i]) ids[nid++] = frags[i];
+  qsort(ids, nid, 8, cmp_u64);
+  for (int64_t i = 0; i < nid; i++) if (i == 0 || ids[i] != ids[i - 1]) ids[nn++] = ids[i];
+  uint32_t *rank = (uint32_t *)malloc(4 * (n ? n : 1));
+  {
+    hmap m; hm_init(&m, nn);
+    for (int64_t i = 0; i < nn; i++) hm_put(&m, ids[i], (uint32_t)i);
+    for (int64_t i = 0; i < n; i++) rank[i] = frags[i] ? m.vals[hm_find(&m, frags[i])] : 0xffffffffu;
+    hm_free(&m);
+  }
+  /* voxel-pair contributions, sorted by edge key */
+  epair *P = (epair *)malloc(sizeof(epair) * (3 * n + 1));
+  int64_t np_ = 0;
+  const int64_t strides[3] = {hw, W, 1};
+  for (int z = 0; z < D; z++)
+    for (int y = 0; y < H; y++)
+      for (int x = 0; x < W; x++) {
+        const int64_t p = (z * (int64_t)H + y) * W + x;
+        const uint32_t r1 = rank[p];
+        if (r1 == 0xffffffffu) continue;
+        const int ok[3] = {z > 0, y > 0, x > 0};
+        for (int d = 0; d < 3; d++) {
+          if (!ok[d]) continue;
+          const uint32_t r2 = rank[p - strides[d]];
+          if (r2 == 0xffffffffu || r2 == r1) continue;
+          const uint32_t u = r1 < r2 ? r1 : r2, v = r1 < r2 ? r2 : r1;
+          P[np_].key = ((uint64_t)u << 32) | v;
+          P[np_++].aff = affs[(int64_t)d * n + p];
+        }
+      }
+  qsort(P, np_, sizeof(epair), cmp_epair);
+  int64_t ne = 0;
+  for (int64_t i = 0; i < np_; i++) if (i == 0 || P[i].key != P[i - 1].key) ne++;
+  edge_t *E = (edge_t *)calloc(ne ? ne : 1, sizeof(edge_t));
+  hmap em; hm_init(&em, ne);
+  {
+    int64_t e = -1;
+    for (int64_t i = 0; i < np_; i++) {
+      if (i == 0 || P[i].key != P[i - 1].key) {
+        e++;
+        E[e].u = (uint32_t)(P[i].key >> 32); E[e].v = (uint32_t)P[i].key; E[e].key0 = P[i].key;
+        hm_put(&em, P[i].key, (uint32_t)e);
+      }
+      E[e].sum += P[i].aff; E[e].cnt += 1;
+    }
+  }
+  free(P);
+  uint32_t **adj = (uint32_t **)calloc(nn ? nn : 1, sizeof(uint32_t *));
+  uint32_t *adjn = (uint32_t *)calloc(nn ? nn : 1, 4), *adjc = (uint32_t *)calloc(nn ? nn : 1, 4);
+  for (int64_t e = 0; e < ne; e++) { ADJ_PUSH(E[e].u, (uint32_t)e); ADJ_PUSH(E[e].v, (uint32_t)e); }
+  /* bin queue: FIFO lists threaded through qnext (an edge is queued at most once) */
+  uint32_t *qnext = (uint32_t *)malloc(4 * (ne ? ne : 1));
+  uint32_t *bhead = (uint32_t *)malloc(4 * nbins), *btail = (uint32_t *)malloc(4 * nbins);
+  for (int b = 0; b < nbins; b++) bhead[b] = btail[b] = 0xffffffffu;
+  int minbin = nbins;
+#define BPUSH(e_, sc_) do { int b_ = (int)((sc_) * (float)(nbins - 1)); if (b_ < 0) b_ = 0; if (b_ > nbins - 1) b_ = nbins - 1; \
+    qnext[e_] = 0xffffffffu; if (bhead[b_] == 0xffffffffu) bhead[b_] = (e_); else qnext[btail[b_]] = (e_); btail[b_] = (e_); \
+    if (b_ < minbin) minbin = b_; } while (0)
+  for (int64_t e = 0; e < ne; e++) { const float sc = edge_score(&E[e]); if (sc < threshold) BPUSH((uint32_t)e, sc); }
+  /* merge tree: leaves 0..nn-1, merge i creates node nn+i */
+  uint32_t *tnext = (uint32_t *)malloc(4 * (2 * nn + 1)), *cur = (uint32_t *)malloc(4 * (nn ? nn : 1));
+  float *tscore = (float *)calloc(2 * nn + 1, 4);
+  for (int64_t i = 0; i < 2 * nn + 1; i++) tnext[i] = 0xffffffffu;
+  for (int64_t i = 0; i < nn; i++) cur[i] = (uint32_t)i;
+  int64_t nm = 0;
+  for (;;) {
+    while (minbin < nbins && bhead[minbin] == 0xffffffffu) minbin++;
+    if (minbin >= nbins) break;
+    const uint32_t ei = bhead[minbin];
+    bhead[minbin] = qnext[ei];
+    edge_t *e = &E[ei];
+    if (e->deleted) continue;
+    if (e->stale) { e->stale = 0; const float sc = edge_score(e); if (sc < threshold) BPUSH(ei, sc); continue; }
+    const float sc = edge_score(e);
+    const uint32_t a = e->u < e->v ? e->u : e->v, b = e->u < e->v ? e->v : e->u;
+    for (uint32_t k = 0; k < adjn[b]; k++) {
+      const uint32_t fi = adj[b][k];
+      edge_t *f = &E[fi];
+      if (fi == ei || f->deleted) continue;
+      if (f->u != b && f->v != b) continue;
+      const uint32_t nb = f->u == b ? f->v : f->u;
+      const uint32_t gu = a < nb ? a : nb, gv = a < nb ? nb : a;
+      const uint64_t gkey = ((uint64_t)gu << 32) | gv;
+      const uint64_t fkey = ((uint64_t)(f->u) << 32) | f->v;
+      int64_t s = hm_find(&em, gkey);
+      if (s >= 0) {
+        edge_t *g = &E[em.vals[s]];
+        g->sum += f->sum; g->cnt += f->cnt; g->stale = 1;
+        f->deleted = 1;
+        hm_del(&em, fkey);
+      } else {
+        hm_del(&em, fkey);
+        f->u = gu; f->v = gv; f->stale = 1;
+        hm_put(&em, gkey, fi);
+        ADJ_PUSH(a, fi);
+      }
+    }
+    hm_del(&em, ((uint64_t)e->u << 32) | e->v);
+    e->deleted = 1;
+    const uint32_t t = (uint32_t)(nn + nm);
+    tnext[cur[a]] = t; tnext[cur[b]] = t; cur[a] = t; tscore[t] = sc;
+    if (merges_out) { merges_out[2 * nm] = ids[a]; merges_out[2 * nm + 1] = ids[b]; }
+    if (mscores_out) mscores_out[nm] = sc;
+    nm++;
+  }
+  if (nmerges_out) *nmerges_out = nm;
+  for (int64_t e = 0; e < ne && e < cap; e++) {
+    uint32_t x = (uint32_t)(E[e].key0 >> 32), y = (uint32_t)E[e].key0;
+    edges_out[2 * e] = ids[x]; edges_out[2 * e + 1] = ids[y];
+    float s = NAN;
+    for (;;) {
+      if (x == y) { s = tscore[x]; break; }
+      if (x < y) { if (tnext[x] == 0xffffffffu) break; x = tnext[x]; }
+      else { if (tnext[y] == 0xffffffffu) break; y = tnext[y]; }
+    }
+    scores_out[e] = s;
+  }
+  for (int64_t i = 0; i < nn; i++) free(adj[i]);
+  free(adj); free(adjn); free(adjc); free(qnext); free(bhead); free(btail); free(tnext); free(cur); free(tscore);
+  free(E); hm_free(&em); free(rank); free(ids);
+  return ne;
+}
+
+/* funlib.segment.graphs.impl.connected_components(nodes, edges, scores, threshold)
+ * (post/watershed.py:182; package absent: **parity unpinned**).  Choice documented in DESIGN.md:
+ * an edge joins its endpoints when score <= threshold; every component is named by its
+ * smallest node id.  nodes must be ascending; endpoints that are not nodes are ignored. */
+void seg_connected_components(const uint64_t *nodes, int64_t n, const uint64_t *edges, const float *scores, int64_t m,
+                              float threshold, uint64_t *components) {
+  int32_t *p = (int32_t *)malloc(4 * (n ? n : 1));
+  for (int64_t i = 0; i < n; i++) p[i] = (int32_t)i;
+  for (int64_t e = 0; e < m; e++) {
+    if (!(scores[e] <= threshold)) continue;
+    int64_t idx[2];
+    int ok = 1;
+    for (int k = 0; k < 2; k++) {
+      int64_t lo = 0, hi = n - 1, f = -1;
+      while (lo <= hi) { int64_t mid = (lo + hi) / 2; if (nodes[mid] == edges[2 * e + k]) { f = mid; break; } if (nodes[mid] < edges[2 * e + k]) lo = mid + 1; else hi = mid - 1; }
+      if (f < 0) ok = 0;
+      idx[k] = f;
+    }
+    if (!ok) continue;
+    int a = uf_find(p, (int)idx[0]), b = uf_find(p, (int)idx[1]);
+    if (a == b) continue;
+    if (a < b) p[b] = a; else p[a] = b;
+  }
+  for (int64_t i = 0; i < n; i++) components[i] = nodes[uf_find(p, (int)i)];
+  free(p);
+}

@@ -26,6 +26,10 @@ def _load():
     lib.seg_filter_fragments_u8.restype = None
     lib.seg_label26.argtypes = [vp, C.c_int, C.c_int, C.c_int, vp]
     lib.seg_label26.restype = C.c_int64
+    lib.seg_rag_merge_scores_u8.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int, C.c_float, C.c_int, vp, vp, C.c_int64, vp, vp, vp]
+    lib.seg_rag_merge_scores_u8.restype = C.c_int64
+    lib.seg_connected_components.argtypes = [vp, C.c_int64, vp, vp, C.c_int64, C.c_float, vp]
+    lib.seg_connected_components.restype = None
     lib.seg_count_labels.argtypes = [vp, C.c_int64]
     lib.seg_count_labels.restype = C.c_int64
     return lib
@@ -85,3 +89,33 @@ def label26(x):
     lab = np.zeros(x.shape, dtype=np.uint32)
     n = _lib.seg_label26(x.ctypes.data, x.shape[0], x.shape[1], x.shape[2], lab.ctypes.data)
     return lab, int(n)
+
+
+def rag_merge_scores_u8(affs_u8, frags, threshold=1.0, discretize_queue=256):
+    """waterz_agglom.py:106-170 for one block -> (edges uint64 [ne][2] ascending, scores float32 [ne]
+    (NaN = never merged), merges uint64 [nm][2] (survivor, absorbed), merge scores float32 [nm])."""
+    a = np.ascontiguousarray(affs_u8[:3], dtype=np.uint8)
+    f = np.ascontiguousarray(frags, dtype=np.uint64)
+    _, D, H, W = a.shape
+    cap = 3 * f.size + 1
+    edges = np.zeros((cap, 2), dtype=np.uint64)
+    scores = np.zeros(cap, dtype=np.float32)
+    merges = np.zeros((f.size + 1, 2), dtype=np.uint64)
+    mscores = np.zeros(f.size + 1, dtype=np.float32)
+    nm = C.c_int64(0)
+    ne = _lib.seg_rag_merge_scores_u8(a.ctypes.data, f.ctypes.data, D, H, W, float(threshold), int(discretize_queue),
+                                      edges.ctypes.data, scores.ctypes.data, cap, merges.ctypes.data,
+                                      mscores.ctypes.data, C.addressof(nm))
+    return edges[:ne].copy(), scores[:ne].copy(), merges[:nm.value].copy(), mscores[:nm.value].copy()
+
+
+def connected_components(nodes, edges, scores, threshold):
+    """funlib.segment connected_components restatement (score <= threshold joins; component = smallest id)."""
+    nodes = np.ascontiguousarray(nodes, dtype=np.uint64)
+    assert np.all(nodes[1:] > nodes[:-1]), "nodes must be ascending"
+    edges = np.ascontiguousarray(edges, dtype=np.uint64).reshape(-1, 2)
+    scores = np.ascontiguousarray(scores, dtype=np.float32)
+    out = np.zeros(len(nodes), dtype=np.uint64)
+    _lib.seg_connected_components(nodes.ctypes.data, len(nodes), edges.ctypes.data, scores.ctypes.data, len(scores),
+                                  float(threshold), out.ctypes.data)
+    return out

@@ -73,3 +73,54 @@ def test_blockwise_primitives_vs_library_goldens(golden_dir):
     for name in ("checker", "diag"):
         lab, num = S.label26(d[name + "/frags"])
         assert num == int(d[name + "/num"][0]) and np.array_equal(lab, d[name + "/label"])
+
+
+def test_float_boundary_mask_equals_integer_threshold():
+    """The reference drivers hand float affinities (u8/255 as float32 in post/watershed.py:245-248, float64 in
+    post/blockwise/watershed_frags.py:198-205) to post/ws.py:75 `0.5*(a_y+a_x) > 0.5`; the oracle and the device
+    threshold the u8 values `a_y + a_x >= 256`.  Check all 65536 pairs agree in both float widths."""
+    a = np.arange(256, dtype=np.uint8)
+    A, B = np.meshgrid(a, a, indexing="ij")
+    integer = (A.astype(np.int64) + B.astype(np.int64)) >= 256
+    for dt in (np.float32, np.float64):
+        fa, fb = A.astype(dt) / dt(255.0), B.astype(dt) / dt(255.0)
+        assert np.array_equal(0.5 * (fa + fb) > 0.5 * 1.0, integer)
+
+
+def test_rag_merge_scores_match_merge_tree_replay_and_cc():
+    """The oracle's per-edge merge score equals replaying its own merge history through the MergeTree mirror
+    (pinned to the reference's post/merge_tree.py by tests/golden/host_cases.json), and connected components
+    at a threshold reproduce the clusters of a full agglomeration when scores happen to be monotone."""
+    from scipy.ndimage import gaussian_filter
+    from bootstrapper_amd.post.merge_tree import MergeTree
+    rng = np.random.default_rng(5)
+    a = gaussian_filter(rng.random((3, 6, 72, 72)), sigma=(0, 1, 3, 3))
+    affs = ((a - a.min()) / (a.max() - a.min()) * 255).astype(np.uint8)
+    frags, _ = S.ws_fragments_u8(affs, True, 5)
+    edges, scores, merges, mscores = S.rag_merge_scores_u8(affs, frags, 1.0, 256)
+    nodes = np.unique(frags)
+    nodes = nodes[nodes > 0]
+    assert len(merges) <= len(nodes) - 1 and len(edges) > len(nodes)
+    assert np.all(edges[:, 0] < edges[:, 1])
+    keys = edges[:, 0].astype(object) * (1 << 64) + edges[:, 1].astype(object)
+    assert all(keys[i] < keys[i + 1] for i in range(len(keys) - 1))
+    mt = MergeTree(nodes)
+    for (x, y), sc in zip(merges, mscores):
+        mt.merge(x, y, x, sc)
+    ref = mt.find_merges(edges[:, 0], edges[:, 1])
+    assert np.array_equal(np.isnan(ref), np.isnan(scores))
+    assert np.array_equal(ref[~np.isnan(ref)].astype(np.float32), scores[~np.isnan(scores)])
+    # connected components: partition check against a tiny python union-find
+    thr = 0.4
+    comp = S.connected_components(nodes, edges, scores, thr)
+    parent = {int(n): int(n) for n in nodes}
+    def find(x):
+        while parent[x] != x:
+            x = parent[x]
+        return x
+    for (u, v), sc in zip(edges, scores):
+        if sc <= thr:
+            ru, rv = find(int(u)), find(int(v))
+            if ru != rv:
+                parent[max(ru, rv)] = min(ru, rv)
+    assert [find(int(n)) for n in nodes] == comp.tolist()

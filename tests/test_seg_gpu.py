@@ -183,3 +183,60 @@ def test_fragment_postprocess_serpentine_components():
     eng.status()
     assert int(num.item()) == ref_n
     assert np.array_equal(lab.cpu().numpy().astype(np.uint64), ref_lab)
+
+
+def _as_u64(t):
+    return t.cpu().numpy().view(np.uint64) if t.dtype == torch.int64 else t.cpu().numpy()
+
+
+@pytest.mark.parametrize("shape,sigma,msd,bins,id_base", [
+    ((8, 96, 96), (1, 3, 3), 5, 256, 0),
+    ((6, 128, 80), (1, 2, 2), 4, 256, 3 * 2_097_152),        # ids of a later block
+    ((12, 64, 64), (1, 4, 4), 6, 16, (1 << 40) + 5),           # coarse bins, ids beyond 32 bits
+    ((3, 50, 70), (0, 1, 1), 3, 1, 0),                         # one bin: pure FIFO
+])
+def test_rag_merge_scores_bit_exact_vs_oracle(shape, sigma, msd, bins, id_base):
+    """waterz_agglom.py:106-170: initial RAG, merge history and per-edge merge scores."""
+    from bootstrapper_amd.post.engine import SegEngine
+    from oracle import seg_ref as S
+    rng = np.random.default_rng(shape[1] + bins)
+    affs = _blobby(rng, shape, sigma)
+    frags, _ = S.ws_fragments_u8(affs, True, msd)
+    # scatter the ids over two id ranges the way neighbouring blocks do
+    big = frags > np.median(frags[frags > 0])
+    frags = np.where(frags > 0, frags + np.uint64(id_base) + np.where(big, np.uint64(2_097_152), np.uint64(0)), np.uint64(0))
+    e_ref, s_ref, m_ref, ms_ref = S.rag_merge_scores_u8(affs, frags, 1.0, bins)
+    eng = SegEngine(shape)
+    e, s, m, ms = eng.rag_merge_scores(torch.from_numpy(affs).cuda(), torch.from_numpy(frags.view(np.int64)).cuda(),
+                                       1.0, bins, return_merges=True)
+    assert np.array_equal(_as_u64(e), e_ref)
+    assert np.array_equal(_as_u64(m), m_ref)
+    assert np.array_equal(ms.cpu().numpy().view(np.uint32), ms_ref.view(np.uint32))
+    assert np.array_equal(s.cpu().numpy().view(np.uint32), s_ref.view(np.uint32))     # NaNs included
+
+
+def test_rag_merge_scores_threshold_leaves_unmerged_edges():
+    from bootstrapper_amd.post.engine import SegEngine
+    from oracle import seg_ref as S
+    rng = np.random.default_rng(11)
+    shape = (6, 80, 80)
+    affs = _blobby(rng, shape, (1, 3, 3))
+    frags, _ = S.ws_fragments_u8(affs, True, 5)
+    e_ref, s_ref, _, _ = S.rag_merge_scores_u8(affs, frags, 0.45, 256)
+    assert np.isnan(s_ref).any() and (~np.isnan(s_ref)).any()
+    eng = SegEngine(shape)
+    e, s = eng.rag_merge_scores(torch.from_numpy(affs).cuda(), torch.from_numpy(frags.view(np.int64)).cuda(), 0.45, 256)
+    assert np.array_equal(_as_u64(e), e_ref)
+    assert np.array_equal(s.cpu().numpy().view(np.uint32), s_ref.view(np.uint32))
+
+
+def test_lut_relabel():
+    from bootstrapper_amd.post.engine import lut_relabel
+    rng = np.random.default_rng(0)
+    keys = np.unique(rng.integers(1, 1 << 45, size=5000)).astype(np.int64)
+    vals = rng.integers(1, 1 << 45, size=keys.size).astype(np.int64)
+    lab = rng.choice(np.concatenate([keys, [0, 7, (1 << 50) + 1]]), size=(7, 33, 41)).astype(np.int64)
+    lut = dict(zip(keys.tolist(), vals.tolist()))
+    ref = np.vectorize(lambda v: lut.get(v, v))(lab)
+    out = lut_relabel(torch.from_numpy(lab).cuda(), torch.from_numpy(keys), torch.from_numpy(vals))
+    assert np.array_equal(out.cpu().numpy(), ref)
