@@ -1247,6 +1247,7 @@ int bsmi_seg_create(int device, const int64_t max_shape[3], bsmi_seg** out) {
     return rc;
   }
   BSMI_HIP(hipMemset(g.counters, 0, 8 * sizeof(uint32_t)));
+  BSMI_HIP(hipMemset(h->frag.flags, 0, 4 * sizeof(uint32_t)));
   *out = h;
   return BSMI_OK;
 }
@@ -1449,6 +1450,33 @@ int bsmi_lut_relabel(int device, const uint64_t* in_dev, uint64_t n, const uint6
   hipLaunchKernelGGL(lut_relabel_kernel, dim3((int)std::min<uint64_t>((n + bs - 1) / bs, 8192)), dim3(bs), 0, (hipStream_t)stream,
                      in_dev, (size_t)n, keys_dev, vals_dev, m, out_dev);
   BSMI_HIP(hipGetLastError());
+  return BSMI_OK;
+}
+
+// Host-side union-find over the scored RAG (reference post/watershed.py:182,
+// funlib.segment.graphs.impl.connected_components [EXT]); same contract as oracle seg_connected_components:
+// score <= threshold joins, a component is named by its smallest node id, nodes ascending.
+int bsmi_connected_components(const uint64_t* nodes, uint64_t n, const uint64_t* edges, const float* scores, uint64_t m,
+                              float threshold, uint64_t* components) {
+  if ((n && (!nodes || !components)) || (m && (!edges || !scores))) BSMI_FAIL(BSMI_ERR_INVALID, "null argument");
+  for (uint64_t i = 1; i < n; ++i)
+    if (nodes[i] <= nodes[i - 1]) BSMI_FAIL(BSMI_ERR_INVALID, "nodes must be strictly ascending");
+  std::vector<uint32_t> parent(n);
+  for (uint64_t i = 0; i < n; ++i) parent[i] = (uint32_t)i;
+  auto find = [&](uint32_t x) {
+    while (parent[x] != x) { parent[x] = parent[parent[x]]; x = parent[x]; }
+    return x;
+  };
+  for (uint64_t e = 0; e < m; ++e) {
+    if (!(scores[e] <= threshold)) continue;
+    const uint64_t* pu = std::lower_bound(nodes, nodes + n, edges[2 * e]);
+    const uint64_t* pv = std::lower_bound(nodes, nodes + n, edges[2 * e + 1]);
+    if (pu == nodes + n || *pu != edges[2 * e] || pv == nodes + n || *pv != edges[2 * e + 1]) continue;
+    const uint32_t a = find((uint32_t)(pu - nodes)), b = find((uint32_t)(pv - nodes));
+    if (a == b) continue;
+    if (a < b) parent[b] = a; else parent[a] = b;
+  }
+  for (uint64_t i = 0; i < n; ++i) components[i] = nodes[find((uint32_t)i)];
   return BSMI_OK;
 }
 

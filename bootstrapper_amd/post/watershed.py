@@ -4,8 +4,9 @@ Behavioural mirror of /root/reference/bootstrapper/post/watershed.py:206-366
 (`simple_watershed`, `watershed_segmentation`): read the first three affinity channels of the ROI,
 optional mask, fragments -> `<fragments_dataset>/<build_name(frag_params)>`, agglomeration at every
 threshold -> `<seg_dataset_prefix>/<build_name(params)>`, parameters recorded as `bs_params`.
-The arithmetic runs in libbsmi (bootstrapper_amd.post.ws / .waterz); the blockwise RAG pipeline
-(`waterz_pipeline`, post/watershed.py:8-203) is not built yet and raises.
+The arithmetic runs in libbsmi (bootstrapper_amd.post.ws / .waterz).  `waterz_pipeline` mirrors
+post/watershed.py:8-203: blockwise fragments with context, per-block RAG edge scoring, global
+thresholded connected components, LUT, relabel (bootstrapper_amd.post.blockwise).
 """
 import os
 
@@ -69,9 +70,115 @@ def simple_watershed(config, device=0):
     return written
 
 
+def connected_components(nodes, edges, scores, threshold):
+    """`funlib.segment.graphs.impl.connected_components` (post/watershed.py:182) through the C ABI (host code)."""
+    import ctypes as C
+    from .._lib import lib, check
+    nodes = np.ascontiguousarray(nodes, dtype=np.uint64)
+    edges = np.ascontiguousarray(edges, dtype=np.uint64).reshape(-1, 2)
+    scores = np.ascontiguousarray(scores, dtype=np.float32)
+    out = np.zeros(len(nodes), dtype=np.uint64)
+    check(lib.bsmi_connected_components(C.c_void_p(nodes.ctypes.data), len(nodes), C.c_void_p(edges.ctypes.data),
+                                        C.c_void_p(scores.ctypes.data), len(scores), float(threshold),
+                                        C.c_void_p(out.ctypes.data)))
+    return out
+
+
+def waterz_pipeline(config, device=0):
+    """post/watershed.py:8-203.  Returns the list of datasets written (fragments first)."""
+    import torch
+    from .blockwise import RagStore, WatershedFrags, WaterzAgglom
+    from .engine import lut_relabel
+    from .naming import dump_lut_params
+
+    affs = open_ds(config["affs_dataset"])
+    if affs.dtype != np.uint8:
+        raise NotImplementedError("the device path takes uint8 affinities (what `bs predict` stores)")
+    thresholds = config.get("thresholds", [0.2, 0.35, 0.5])
+    merge_function = config.get("merge_function", "mean")
+    blockwise = config.get("blockwise", False)
+    frag_params = {
+        "fragments_in_xy": config.get("fragments_in_xy", True),
+        "min_seed_distance": config.get("min_seed_distance", 10),
+        "seed_eps": config.get("seed_eps"),
+        "epsilon_agglomerate": config.get("epsilon_agglomerate", 0.0),
+        "sigma": config.get("sigma"),
+        "noise_eps": config.get("noise_eps"),
+        "bias": config.get("bias"),
+        "filter_fragments": config.get("filter_fragments", 0.0),
+        "remove_debris": config.get("remove_debris", 0),
+    }
+    voxel_size = affs.voxel_size
+    if config.get("roi_offset") is not None:
+        roi = (list(config["roi_offset"]), list(config["roi_shape"]))
+    else:
+        roi = (list(affs.roi[0]), list(affs.roi[1]))
+    sl = affs.roi_to_slices(*roi)[-3:]
+    origin = tuple(s.start for s in sl)
+    total_shape = tuple(s.stop - s.start for s in sl)
+    if blockwise:
+        block_size = tuple(config["block_shape"]) if config.get("block_shape") else tuple(affs.chunks[1:])
+        ctx = tuple(config["context"]) if config.get("context") else tuple(max(1, b // 8) for b in block_size)
+    else:
+        block_size, ctx = total_shape, (0, 0, 0)
+    block_size = tuple(min(int(b), t) for b, t in zip(block_size, total_shape))
+
+    mask = open_ds(config["mask_dataset"]) if config.get("mask_dataset") else None
+    rag = RagStore()
+    frags_vol = np.zeros(total_shape, dtype=np.uint64)
+
+    # fragments via seeded watershed (post/watershed.py:118-139)
+    frags_task = WatershedFrags(block_size, ctx, total_shape, device=device, origin=origin, **frag_params)
+    for b in range(len(frags_task.blocks)):
+        frags_task.watershed_in_block(b, affs, frags_vol, rag, offset=roi[0], voxel_size=voxel_size, mask=mask)
+    frags_name = os.path.join(config["fragments_dataset"], build_name(frag_params))
+    common = dict(offset=roi[0], voxel_size=voxel_size, axis_names=affs.axis_names[1:], units=affs.units, dtype=np.uint64,
+                  chunk_shape=block_size)
+    out = prepare_ds(frags_name, shape=total_shape, **common)
+    out[:] = frags_vol
+    dump_params(frags_name, {"method": "ws", "blockwise": blockwise, **frag_params})
+    del frags_task
+
+    # score RAG edges (post/watershed.py:141-153)
+    agglom = WaterzAgglom(block_size, ctx, total_shape, merge_function=merge_function, device=device, origin=origin)
+    for b in range(len(agglom.blocks)):
+        agglom.agglomerate_in_block(b, affs, frags_vol, rag)
+    del agglom
+    db = config.get("db") or {}
+    if "db_file" in db:
+        rag.to_sqlite(db["db_file"])
+
+    # global segmentation: thresholded connected components -> LUT -> relabel (post/watershed.py:155-203)
+    written = [frags_name]
+    nodes, _, _ = rag.nodes()
+    if nodes.size == 0:
+        return written
+    edges, scores = rag.scored_edges()
+    lut_dir = config["lut_dir"]
+    os.makedirs(lut_dir, exist_ok=True)
+    dev = torch.device("cuda", device)
+    frags_dev = torch.from_numpy(frags_vol.view(np.int64)).to(dev)
+    for threshold in thresholds:
+        components = nodes.copy() if edges.shape[0] == 0 else connected_components(nodes, edges, scores, threshold)
+        params = {"merge_function": merge_function, "threshold": threshold, **frag_params}
+        name = build_name(params)
+        recorded = {"method": "ws", "blockwise": blockwise, **params}
+        lut_path = os.path.join(lut_dir, name)
+        np.savez_compressed(lut_path + ".npz", fragment_segment_lut=np.array([nodes, components]))
+        dump_lut_params(lut_path, recorded)
+        seg = lut_relabel(frags_dev, torch.from_numpy(nodes.view(np.int64)), torch.from_numpy(components.view(np.int64)))
+        seg_name = os.path.join(config["seg_dataset_prefix"], name)
+        out = prepare_ds(seg_name, shape=total_shape, **common)
+        out[:] = seg.cpu().numpy().view(np.uint64)
+        dump_params(seg_name, recorded)
+        written.append(seg_name)
+    return written
+
+
 def watershed_segmentation(config):
+    """post/watershed.py:357-366"""
     if config.get("blockwise", False):
-        raise NotImplementedError(
-            "blockwise watershed (fragments with context + per-block agglomeration + global RAG stitch, "
-            "reference post/watershed.py:8-203) is not built yet; run with blockwise = false")
+        if config.get("block_shape") == "roi":
+            config["blockwise"] = False
+        return waterz_pipeline(config)
     return simple_watershed(config)

@@ -178,6 +178,13 @@ int bsmi_rag_merge_scores_u8(bsmi_seg *h, const uint8_t *affs_dev, const uint64_
 int bsmi_lut_relabel(int device, const uint64_t *in_dev, uint64_t n, const uint64_t *keys_dev,
                      const uint64_t *vals_dev, uint64_t m, uint64_t *out_dev, void *stream);
 
+/* Global thresholded connected components of the scored RAG on the HOST (plain host pointers; reference
+ * post/watershed.py:182 calls funlib.segment.graphs.impl.connected_components, a host C++ routine).
+ * nodes strictly ascending; an edge joins its endpoints when score <= threshold; components[i] = smallest
+ * node id of node i's component.  Edges naming unknown nodes are ignored. */
+int bsmi_connected_components(const uint64_t *nodes, uint64_t n, const uint64_t *edges,
+                              const float *scores, uint64_t m, float threshold, uint64_t *components);
+
 /* status of the last asynchronous seg call on this handle (reads a device flag;
  * synchronises `stream`): BSMI_OK or BSMI_ERR_OVERFLOW */
 int bsmi_seg_status(bsmi_seg *h, void *stream);

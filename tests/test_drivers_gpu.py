@@ -93,6 +93,131 @@ min_seed_distance = 4
         assert np.array_equal(open_ds(w)[:], r)
     with pytest.raises(ValueError, match="Blockwise requires a database config"):
         run_segmentation(str(seg_cfg), "ws", blockwise=True, param=())
-    from bootstrapper_amd.post.watershed import watershed_segmentation
-    with pytest.raises(NotImplementedError):
-        watershed_segmentation({"blockwise": True})
+
+
+def _pad_read(vol, begin, end, lead=False):
+    """zeros outside the volume, like `to_ndarray(roi, fill_value=0)`"""
+    shape = vol.shape[1:] if lead else vol.shape
+    out = np.zeros((vol.shape[:1] if lead else ()) + tuple(e - b for b, e in zip(begin, end)), vol.dtype)
+    src = tuple(slice(max(b, 0), min(e, n)) for b, e, n in zip(begin, end, shape))
+    dst = tuple(slice(s.start - b, s.stop - b) for s, b in zip(src, begin))
+    if lead:
+        out[(slice(None),) + dst] = vol[(slice(None),) + src]
+    else:
+        out[dst] = vol[src]
+    return out
+
+
+def _cpu_blockwise(affs, block, ctx, msd, ff, rd, thresholds, bins=256):
+    """The blockwise pipeline (reference post/watershed.py:8-203) composed from the oracle's pieces."""
+    from oracle import seg_ref as S
+    total = affs.shape[1:]
+    grid = [range(0, t, b) for t, b in zip(total, block)]
+    boxes = [((z, y, x), (min(z + block[0], total[0]), min(y + block[1], total[1]), min(x + block[2], total[2])))
+             for z in grid[0] for y in grid[1] for x in grid[2]]
+    nv = int(np.prod(block))
+    frags = np.zeros(total, np.uint64)
+    sizes = {}
+    for bi, (b, e) in enumerate(boxes):
+        rb, re = tuple(v - c for v, c in zip(b, ctx)), tuple(v + c for v, c in zip(e, ctx))
+        a = _pad_read(affs, rb, re, lead=True)
+        if a.max() == 0:
+            continue
+        fr, _ = S.ws_fragments_u8(a, True, msd)
+        fr = S.filter_fragments_u8(a, fr, ff, rd)
+        crop = np.ascontiguousarray(fr[tuple(slice(ctx[d], ctx[d] + e[d] - b[d]) for d in range(3))])
+        lab, n = S.label26(crop)
+        assert n < nv
+        frags[tuple(slice(b[d], e[d]) for d in range(3))] = np.where(lab > 0, lab.astype(np.uint64) + np.uint64(bi * nv), np.uint64(0))
+    E, Sc = [], []
+    for bi, (b, e) in enumerate(boxes):
+        rb, re = tuple(v - c for v, c in zip(b, ctx)), tuple(v + c for v, c in zip(e, ctx))
+        f = _pad_read(frags, rb, re)
+        if not f.any():
+            continue
+        ed, sc, _, _ = S.rag_merge_scores_u8(_pad_read(affs, rb, re, lead=True), f, 1.0, bins)
+        own = (ed[:, 0] - np.uint64(1)) // np.uint64(nv) == np.uint64(bi)
+        E.append(ed[own])
+        Sc.append(sc[own])
+    E, Sc = np.concatenate(E), np.concatenate(Sc)
+    nodes = np.unique(frags)
+    nodes = nodes[nodes > 0]
+    keep = ~np.isnan(Sc)
+    segs = []
+    for thr in thresholds:
+        comp = S.connected_components(nodes, E[keep], Sc[keep], thr)
+        idx = np.searchsorted(nodes, frags)
+        idx[idx >= len(nodes)] = 0
+        segs.append(np.where(frags > 0, comp[idx], np.uint64(0)))
+    return frags, nodes, E, Sc, segs
+
+
+def test_blockwise_segmentation_driver(tmp_path):
+    """`bs segment --ws` with blockwise = true: fragments with context, per-block RAG scoring, global connected
+    components, LUT and relabel, bit-equal to the oracle composition; default block = chunk shape, context = block/8."""
+    import sqlite3
+    from scipy.ndimage import gaussian_filter
+    from bootstrapper_amd.segment import run_segmentation
+    from bootstrapper_amd.zarr_io import open_ds, prepare_ds
+    rng = np.random.default_rng(21)
+    shape = (20, 150, 130)
+    a = gaussian_filter(rng.random((3,) + shape), sigma=(0, 1, 3, 3))
+    affs = ((a - a.min()) / (a.max() - a.min()) * 255).astype(np.uint8)
+    affs[:, :, :40, :50] = 0                                   # an empty corner: blocks that return early
+    store = str(tmp_path / "vol.zarr")
+    ds = prepare_ds(store + "/affs", affs.shape, offset=(40, 8, 16), voxel_size=(40, 4, 4), chunk_shape=(3, 8, 64, 64),
+                    dtype=np.uint8, axis_names=["c^", "z", "y", "x"], units=["nm"] * 3, compressor="zlib")
+    ds[:] = affs
+    cfg = tmp_path / "seg.toml"
+    cfg.write_text(f"""affs_dataset = "{store}/affs"
+fragments_dataset = "{store}/fragments"
+seg_dataset_prefix = "{store}/segmentations"
+blockwise = true
+[db]
+db_file = "{tmp_path}/rag.db"
+[ws_params]
+thresholds = [0.3, 0.45]
+min_seed_distance = 4
+filter_fragments = 0.35
+remove_debris = 12
+""")
+    written = run_segmentation(str(cfg), "ws")
+    names = [os.path.relpath(w, store) for w in written]
+    assert names == ["fragments/xy--msd4--ea0--ff0.35--rd12", "segmentations/mfmean--t0.3--xy--msd4--ea0--ff0.35--rd12",
+                     "segmentations/mfmean--t0.45--xy--msd4--ea0--ff0.35--rd12"]
+    frags_ref, nodes, E, Sc, segs_ref = _cpu_blockwise(affs, (8, 64, 64), (1, 8, 8), 4, 0.35, 12, [0.3, 0.45])
+    f = open_ds(written[0])
+    assert f.dtype == np.uint64 and f.chunks == (8, 64, 64) and f.offset == (40, 8, 16)
+    assert f.attrs["bs_params"]["blockwise"] is True and f.attrs["bs_params"]["filter_fragments"] == 0.35
+    got = f[:]
+    assert np.array_equal(got, frags_ref)
+    assert len(nodes) > 100 and len(np.unique(((nodes - 1) // (8 * 64 * 64)))) > 10     # many blocks own fragments
+    for w, r in zip(written[1:], segs_ref):
+        seg = open_ds(w)[:]
+        assert np.array_equal(seg, r)
+        assert len(np.unique(seg)) < len(nodes)                                         # something merged
+    lut = np.load(os.path.join(store, "luts", names[1].split("/")[1] + ".npz"))["fragment_segment_lut"]
+    assert np.array_equal(lut[0], nodes)
+    assert os.path.exists(os.path.join(store, "luts", names[1].split("/")[1] + ".json"))
+    con = sqlite3.connect(str(tmp_path / "rag.db"))
+    rows = con.execute("SELECT id, z, y, x, size FROM nodes ORDER BY id").fetchall()
+    assert [r[0] for r in rows] == nodes.tolist()
+    k = len(rows) // 2
+    m = frags_ref == rows[k][0]
+    idx = np.argwhere(m)
+    assert rows[k][4] == int(m.sum())
+    assert np.allclose(rows[k][1:4], np.array([40, 8, 16]) + idx.mean(axis=0) * np.array([40, 4, 4]))
+    n_edges = con.execute("SELECT COUNT(*) FROM edges").fetchone()[0]
+    n_null = con.execute("SELECT COUNT(*) FROM edges WHERE merge_score IS NULL").fetchone()[0]
+    assert n_edges == len(E) and n_null == int(np.isnan(Sc).sum())
+    con.close()
+
+    # block_shape = "roi": one block, no context (post/watershed.py:357-363), same machinery
+    cfg2 = tmp_path / "seg2.toml"
+    cfg2.write_text(cfg.read_text().replace("blockwise = true", 'blockwise = true\nblock_shape = "roi"')
+                    .replace("fragments\"", "fragments_roi\"").replace("segmentations\"", "segmentations_roi\""))
+    written2 = run_segmentation(str(cfg2), "ws")
+    fr2, _, _, _, segs2 = _cpu_blockwise(affs, shape, (0, 0, 0), 4, 0.35, 12, [0.3, 0.45])
+    assert open_ds(written2[0]).attrs["bs_params"]["blockwise"] is False
+    assert np.array_equal(open_ds(written2[0])[:], fr2)
+    assert np.array_equal(open_ds(written2[2])[:], segs2[1])
