@@ -15,7 +15,9 @@
 // v_mfma_f32_32x32x16_bf16 / v_mfma_f32_32x32x2_f32 are bank-conflict free.
 #include "conv_igemm.h"
 
+#include <cstdio>
 #include <cstdlib>
+#include <type_traits>
 
 namespace bsmi {
 
@@ -68,23 +70,24 @@ typedef const __attribute__((address_space(4))) int32_t* cint_ptr_t;  // constan
 // image stays lane-linear, and the ds_read_b128 fragment reads (same XOR) are conflict free.
 // The loads of K-steps h+2..h+4 are in flight while K-step h is multiplied (counted vmcnt,
 // raw s_barrier); the single barrier of a K-step sits between its two MFMA groups.
-template <typename T, int BM, int BN, int WM, int WN>
-__global__ __launch_bounds__(64 * WM * WN, 1) void conv_igemm_kernel(const ConvArgs a) {
+// B_INSTR: weight pieces (16 rows x 64 B) this wave stages per K-step.  The BN / 16 pieces of a
+// K-step are dealt round-robin to the waves, so B_INSTR may differ by one between the low and the
+// high waves: the kernel runs one of two instantiations of this body per wave (the counted
+// vmcnt immediates depend on it; the barrier count does not).
+template <typename T, int BM, int BN, int WM, int WN, int B_INSTR, bool LATE>
+__device__ __forceinline__ void conv_igemm_body(const ConvArgs& a, char* smem) {
   constexpr int NW = WM * WN;
-  static_assert(NW == 4, "one wave per SIMD");
+  static_assert(NW == 4 || NW == 8, "one or two waves per SIMD");
   constexpr int ROWB = kStepRowBytes;
   constexpr int NSLOT = 4;
   constexpr int WTM = BM / WM, WTN = BN / WN;
   constexpr int FM = WTM / 32, FN = WTN / 32;
-  constexpr int BNL = (BN + 63) / 64 * 64;                       // weight rows staged per K-step
-  constexpr int A_INSTR = BM / 16 / NW, B_INSTR = BNL / 16 / NW;  // LDS-DMA instructions per wave per K-step
+  constexpr int A_INSTR = BM / 16 / NW;  // LDS-DMA instructions per wave per K-step
   constexpr int G = A_INSTR + B_INSTR;
-  constexpr int SLOT = (BM + BNL) * ROWB;
+  constexpr int SLOT = (BM + BN) * ROWB;
   static_assert(BM % (16 * NW) == 0, "tile/wave mismatch");
   static_assert(WTM % 32 == 0 && WTN % 32 == 0, "wave tile must be a multiple of 32");
   static_assert(3 * G <= 63, "vmcnt range");
-
-  extern __shared__ __attribute__((aligned(16))) char smem[];  // [NSLOT][A: BM rows | B: BNL rows][64 B]
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -217,14 +220,31 @@ __global__ __launch_bounds__(64 * WM * WN, 1) void conv_igemm_kernel(const ConvA
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * G) : "memory");
   __builtin_amdgcn_s_barrier();
   load_frags(smem, 0, fa[0], fb[0]);
-  issue(3, fetch(3));
-  Desc dnext = fetch(4);
+  // A K-step is two MFMA groups with the barrier between them.  An early wave (the only kind
+  // in the 4-wave kernels) stages K-step h+4 in the second group of K-step h; a LATE wave
+  // (waves 4-7 of an 8-wave kernel) stages K-step h+3 in the first group instead: the two waves
+  // of a SIMD then never sit in their LDS-DMA issue stalls at the same time, one of them is
+  // always in a pure fragment-read + MFMA group (MI355X_MICROARCH.md, two waves per SIMD, item 9).
+  // Either way K-steps h+2 and h+3 are what may still be in flight at the barrier of K-step h.
+  if constexpr (!LATE) issue(3, fetch(3));
+  Desc dnext = fetch(LATE ? 3 : 4);
 
   for (int h = 0; h < nsteps; ++h) {
     const char* st = smem + (h & (NSLOT - 1)) * SLOT;
+    if constexpr (LATE) {
+      issue(h + 3, dnext);
+      dnext = fetch(h + 4);
+    }
     load_frags(st, 1, fa[1], fb[1]);
     mma(fa[0], fb[0]);
 #ifndef BSMI_NO_SCHED_HINTS
+    if constexpr (LATE) {
+#pragma unroll
+      for (int k = 0; k < G; ++k) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  // 1 MFMA
+        __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);  // 1 VMEM read (LDS-DMA)
+      }
+    }
 #pragma unroll
     for (int k = 0; k < FM + FN; ++k) {
       __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  // 1 MFMA
@@ -236,17 +256,21 @@ __global__ __launch_bounds__(64 * WM * WN, 1) void conv_igemm_kernel(const ConvA
     // h+2 and h+3 stay in flight.
     asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(2 * G) : "memory");
     __builtin_amdgcn_s_barrier();
-    issue(h + 4, dnext);
-    dnext = fetch(h + 5);
+    if constexpr (!LATE) {
+      issue(h + 4, dnext);
+      dnext = fetch(h + 5);
+    }
     load_frags(smem + ((h + 1) & (NSLOT - 1)) * SLOT, 0, fa[0], fb[0]);
     mma(fa[1], fb[1]);
 #ifndef BSMI_NO_SCHED_HINTS
     // interleave the LDS-DMA issue and the next fragment reads with this MFMA group instead
     // of letting them form a clump in front of it (one memory instruction per MFMA gap)
+    if constexpr (!LATE) {
 #pragma unroll
-    for (int k = 0; k < G; ++k) {
-      __builtin_amdgcn_sched_group_barrier(0x008, 1, 1);  // 1 MFMA
-      __builtin_amdgcn_sched_group_barrier(0x020, 1, 1);  // 1 VMEM read (LDS-DMA)
+      for (int k = 0; k < G; ++k) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 1);  // 1 MFMA
+        __builtin_amdgcn_sched_group_barrier(0x020, 1, 1);  // 1 VMEM read (LDS-DMA)
+      }
     }
 #pragma unroll
     for (int k = 0; k < FM + FN; ++k) {
@@ -279,6 +303,247 @@ __global__ __launch_bounds__(64 * WM * WN, 1) void conv_igemm_kernel(const ConvA
   }
 }
 
+// T: element type; BM x BN block tile; WM x WN waves: 4 (one per SIMD, up to 512 registers
+// each: 128x128 register tiles) or 8 (two per SIMD, 256 registers each: while one wave of a
+// SIMD sits in the 60-185 cycles an LDS-DMA instruction costs its issuer, the other multiplies).
+template <typename T, int BM, int BN, int WM, int WN>
+__global__ __launch_bounds__(64 * WM * WN, 1) void conv_igemm_kernel(const ConvArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];  // [NSLOT][A: BM rows | B: BN rows][64 B]
+  constexpr int NW = WM * WN, NBP = BN / 16;
+  constexpr int HI = (NBP + NW - 1) / NW, LO = NBP / NW;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  if constexpr (NW == 8) {
+    static_assert(HI == LO || NBP % NW == 4, "the uneven split must coincide with the early/late split");
+    if (wave < 4) conv_igemm_body<T, BM, BN, WM, WN, HI, false>(a, smem);
+    else conv_igemm_body<T, BM, BN, WM, WN, LO, true>(a, smem);
+  } else if constexpr (HI == LO) {
+    conv_igemm_body<T, BM, BN, WM, WN, HI, false>(a, smem);
+  } else {
+    if (wave < NBP % NW) conv_igemm_body<T, BM, BN, WM, WN, HI, false>(a, smem);
+    else conv_igemm_body<T, BM, BN, WM, WN, LO, false>(a, smem);
+  }
+}
+
+// Loader wave of conv_ws_kernel: PA activation pieces + PB weight pieces (16 rows x 64 B each)
+// per K-step; every vmcnt immediate below is a multiple of P = PA + PB.
+struct WsDesc { int t, d0, d1; };
+
+template <int BM, int BN, int PA, int PB>
+__device__ __forceinline__ void ws_issue(const ConvArgs& a, char* smem, int lw, int nsteps, int h, int slot, WsDesc ds,
+                                         const uint32_t (&ro0)[PA], const uint32_t (&ro1)[PA], const uint32_t (&ro2)[PA],
+                                         bool unit1, uint32_t hoff, uint32_t offb, size_t wstep) {
+  constexpr int ROWB = kStepRowBytes, NL = 4, SLOT = (BM + BN) * ROWB;
+  const bool t1 = ds.t == 1, t2 = ds.t == 2;
+  const uint64_t tbase = t1 ? a.t[1].base : (t2 ? a.t[2].base : a.t[0].base);
+  const uint32_t lofs = (uint32_t)(unit1 ? ds.d1 : ds.d0) + hoff;
+  const gptr_t abase = (gptr_t)tbase;
+  const gptr_t wbase = (gptr_t)a.w + (size_t)(h < nsteps ? h : nsteps - 1) * wstep;
+  const lptr_t la = (lptr_t)(smem + slot * SLOT);
+  const lptr_t lb = la + BM * ROWB;
+#pragma unroll
+  for (int i = 0; i < PA; ++i) {
+    const uint32_t ro = t1 ? ro1[i] : (t2 ? ro2[i] : ro0[i]);
+    __builtin_amdgcn_global_load_lds(abase + (size_t)(ro + lofs), la + (i * NL + lw) * 1024, 16, 0, 0);
+  }
+#pragma unroll
+  for (int i = 0; i < PB; ++i)
+    __builtin_amdgcn_global_load_lds(wbase + (size_t)i * NL * 16 * ROWB + offb, lb + (i * NL + lw) * 1024, 16, 0, 0);
+}
+
+__device__ __forceinline__ WsDesc ws_fetch(cint_ptr_t steps, int nsteps, int h) {
+  const cint_ptr_t d = steps + (h < nsteps ? h : nsteps - 1) * 4;
+  return WsDesc{d[0], d[1], d[2]};
+}
+
+template <int BM, int BN, int NSLOT, int PB>
+__device__ __forceinline__ void ws_loader(const ConvArgs& a, char* smem, int lw, int lane, int m0, int n0) {
+  constexpr int ROWB = kStepRowBytes, NL = 4;
+  constexpr int PA = BM / 16 / NL;
+  constexpr int P = PA + PB;
+  static_assert(2 * P <= 63, "vmcnt range");
+  const cint_ptr_t steps = (cint_ptr_t)a.steps;
+  const int nsteps = a.nsteps;
+  const int lrow = lane >> 2, lchunk = lane & 3;
+  const int skey = (lane >> 4) & 3;
+  const int g = lchunk ^ skey;
+  const bool unit1 = (g >> 1) != 0;
+  const uint32_t hoff = (uint32_t)((g & 1) << 4);
+  uint32_t ro0[PA], ro1[PA], ro2[PA];
+#pragma unroll
+  for (int i = 0; i < PA; ++i) {
+    const int row = (i * NL + lw) * 16 + lrow;
+    int m = m0 + row;
+    m = m < a.M ? m : a.M - 1;
+    const int x = m % a.Wo;
+    const int zy = m / a.Wo;
+    const int y = zy % a.Ho, z = zy / a.Ho;
+    ro0[i] = (uint32_t)(z * a.t[0].sz + y * a.t[0].sy + x * a.t[0].sx);
+    ro1[i] = (uint32_t)(z * a.t[1].sz + y * a.t[1].sy + x * a.t[1].sx);
+    ro2[i] = (uint32_t)(z * a.t[2].sz + y * a.t[2].sy + x * a.t[2].sx);
+  }
+  const uint32_t offb = (uint32_t)((n0 + lw * 16 + lrow) * ROWB + ((lchunk ^ skey) << 4));
+  const size_t wstep = (size_t)a.Npad * ROWB;
+#define WS_ISSUE(h_, slot_, ds_) ws_issue<BM, BN, PA, PB>(a, smem, lw, nsteps, (h_), (slot_), (ds_), ro0, ro1, ro2, unit1, hoff, offb, wstep)
+  WS_ISSUE(0, 0, ws_fetch(steps, nsteps, 0));
+  WS_ISSUE(1, 1, ws_fetch(steps, nsteps, 1));
+  WS_ISSUE(2, 2, ws_fetch(steps, nsteps, 2));
+  WS_ISSUE(3, 3, ws_fetch(steps, nsteps, 3));
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * P) : "memory");  // K-steps 0, 1 landed
+  __builtin_amdgcn_s_barrier();                                 // E_-1
+  WsDesc dnext = ws_fetch(steps, nsteps, NSLOT - 1);
+  int slot = NSLOT - 1;
+  for (int j = 0; j < nsteps; ++j) {
+    WS_ISSUE(j + NSLOT - 1, slot, dnext);
+    dnext = ws_fetch(steps, nsteps, j + NSLOT);
+    slot = slot == NSLOT - 1 ? 0 : slot + 1;
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * P) : "memory");  // K-step j+2 landed
+    __builtin_amdgcn_s_barrier();                                 // E_j
+  }
+#undef WS_ISSUE
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
+// ------------------------------------------------------------------------------------------
+// Wave-specialised variant: 8 waves per workgroup (two per SIMD).  Waves 0-3 only multiply
+// (each a 64 x BN register tile: LDS fragment reads + MFMA), waves 4-7 only stage (scalar
+// descriptors + LDS-DMA).  An LDS-DMA instruction costs its issuing wave 60-185 cycles
+// (MI355X_MICROARCH.md, "LDS-DMA piece issue cost"): with 26 of them per K-step that is as much
+// time as the K-step's MFMAs, and in the 4-wave kernel above both come out of the same
+// instruction stream.  Here the loader wave of a SIMD stalls on its own, and the multiplier
+// wave next to it keeps the matrix pipe busy.
+//
+// Ring of NSLOT = 5 slots of [BM + BN rows][64 B].  One barrier E_h per K-step, after which
+// (a) the multipliers have finished reading slot h, (b) K-steps <= h+2 have landed.  The
+// loaders then issue K-step h+5 into slot h and wait (counted vmcnt) for K-step h+3; the
+// multipliers read the second half of slot h+1 and the first half of slot h+2.
+template <typename T, int BM, int BN>
+__global__ __launch_bounds__(512, 1) void conv_ws_kernel(const ConvArgs a) {
+  constexpr int ROWB = kStepRowBytes;
+  constexpr int NSLOT = 5;
+  constexpr int NL = 4;                        // loader waves = multiplier waves
+  constexpr int WTM = BM / NL;                 // 64 rows per multiplier wave
+  constexpr int FM = WTM / 32, FN = BN / 32;
+  constexpr int PA = BM / 16 / NL;             // A pieces (16 rows x 64 B) per loader wave per K-step
+  constexpr int NBP = BN / 16;                 // B pieces per K-step, dealt round-robin to the loaders
+  constexpr int SLOT = (BM + BN) * ROWB;
+  static_assert(BM == 256 && BN % 32 == 0, "tile shape");
+
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int nsteps = a.nsteps;
+
+  const int mt = (a.M + BM - 1) / BM, ntn = a.Npad / BN;
+  const int ntiles = mt * ntn;
+  int tile;
+  {
+    const int q = ntiles >> 3, r = ntiles & 7;
+    const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
+    tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + j;
+  }
+  const int tile_m = tile / ntn, tile_n = tile - tile_m * ntn;
+  const int m0 = tile_m * BM, n0 = tile_n * BN;
+
+  if (wave >= NL) {
+    const int lw = wave - NL;
+    constexpr int PB_HI = (NBP + NL - 1) / NL, PB_LO = NBP / NL;
+    if ((NBP - lw + NL - 1) / NL == PB_HI) ws_loader<BM, BN, NSLOT, PB_HI>(a, smem, lw, lane, m0, n0);
+    else ws_loader<BM, BN, NSLOT, PB_LO>(a, smem, lw, lane, m0, n0);
+    return;
+  }
+
+  // ---------------------------------------------------------------- multiplier
+  const int wm = wave;
+  const int lr = lane & 31, lh = lane >> 5;
+  uint32_t arow[FM], akey[FM], brow[FN], bkey[FN];
+#pragma unroll
+  for (int i = 0; i < FM; ++i) {
+    const int row = wm * WTM + i * 32 + lr;
+    arow[i] = row * ROWB;
+    akey[i] = (row >> 2) & 3;
+  }
+#pragma unroll
+  for (int j = 0; j < FN; ++j) {
+    const int row = j * 32 + lr;
+    brow[j] = BM * ROWB + row * ROWB;
+    bkey[j] = (row >> 2) & 3;
+  }
+  f32x16_t acc[FM][FN];
+#pragma unroll
+  for (int i = 0; i < FM; ++i)
+#pragma unroll
+    for (int j = 0; j < FN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  u32x4_t fa[2][FM], fb[2][FN];
+  auto load_frags = [&](const char* st, int sub, u32x4_t* pa, u32x4_t* pb) {
+    const uint32_t c = 2 * sub + lh;
+#pragma unroll
+    for (int i = 0; i < FM; ++i) pa[i] = *(const u32x4_t*)(st + arow[i] + ((c ^ akey[i]) << 4));
+#pragma unroll
+    for (int j = 0; j < FN; ++j) pb[j] = *(const u32x4_t*)(st + brow[j] + ((c ^ bkey[j]) << 4));
+  };
+  auto mma = [&](const u32x4_t* pa, const u32x4_t* pb) {
+#pragma unroll
+    for (int i = 0; i < FM; ++i)
+#pragma unroll
+      for (int j = 0; j < FN; ++j) acc[i][j] = Elem<T>::mfma(pa[i], pb[j], acc[i][j]);
+  };
+
+  __builtin_amdgcn_s_barrier();  // E_-1: K-steps 0 and 1 have landed
+  load_frags(smem, 0, fa[0], fb[0]);
+  int slot = 0;
+  for (int h = 0; h < nsteps; ++h) {
+    const char* st = smem + slot * SLOT;
+    slot = slot == NSLOT - 1 ? 0 : slot + 1;
+    load_frags(st, 1, fa[1], fb[1]);
+    mma(fa[0], fb[0]);
+#ifndef BSMI_NO_SCHED_HINTS
+#pragma unroll
+    for (int k = 0; k < FM + FN; ++k) {
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+      __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+    }
+#endif
+    load_frags(smem + slot * SLOT, 0, fa[0], fb[0]);  // K-step h+1 (a slot nobody wrote past the end: unused)
+    mma(fa[1], fb[1]);
+#ifndef BSMI_NO_SCHED_HINTS
+#pragma unroll
+    for (int k = 0; k < FM + FN; ++k) {
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 1);
+      __builtin_amdgcn_sched_group_barrier(0x100, 1, 1);
+    }
+#endif
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // every read of slot h has returned
+    __builtin_amdgcn_s_barrier();                       // E_h
+  }
+
+  T* out = (T*)a.out;
+#pragma unroll
+  for (int j = 0; j < FN; ++j) {
+    const int n = n0 + j * 32 + lr;
+    if (n >= a.Co) continue;
+    const float bv = a.bias[n];
+#pragma unroll
+    for (int i = 0; i < FM; ++i) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = m0 + wm * WTM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        if (m < a.M) {
+          float v = acc[i][j][r] + bv;
+          if (a.relu) v = v > 0.f ? v : 0.f;
+          Elem<T>::store(out + (size_t)m * a.Co + n, v);
+        }
+      }
+    }
+  }
+}
+
+bool use_wave_specialised();
+bool two_waves_per_simd();
 int tile_bm(TileCfg) { return 256; }
 int tile_bn(TileCfg c) {
   switch (c) {
@@ -295,9 +560,10 @@ TileCfg choose_tile(int cout) {
   // minimise padded N weighted by how well each tile keeps the MFMA pipe fed
   const TileCfg cands[] = {TILE_256x32, TILE_256x64, TILE_256x160, TILE_256x256, TILE_256x320};
   double eff[] = {0.35, 0.6, 0.85, 1.0, 1.0};
-  // the 128x160 register tile of TILE_256x320 spills (320 accumulators exceed the 256 AGPRs);
-  // keep it out of the choice unless asked for (experiments only)
-  if (!getenv("BSMI_USE_320")) eff[4] = 0.01;
+  // TILE_256x320 exists only as the 8-wave kernel (4 x 2 waves of 64 x 160 register tiles)
+  if (!two_waves_per_simd()) eff[4] = 0.01;
+  if (const char* e = getenv("BSMI_TILE_EFF")) sscanf(e, "%lf,%lf,%lf,%lf,%lf", &eff[0], &eff[1], &eff[2], &eff[3], &eff[4]);  // experiments
+  if (use_wave_specialised()) eff[3] = 0.01;  // its 64 x BN register tiles stop at BN = 160
   TileCfg best = TILE_256x32;
   double bestc = 1e30;
   for (int i = 0; i < 5; ++i) {
@@ -313,7 +579,7 @@ TileCfg choose_tile(int cout) {
 
 template <typename T, int BM, int BN, int WM, int WN>
 static int launch_one(const ConvArgs& a, hipStream_t stream) {
-  constexpr int smem = 4 * (BM + (BN + 63) / 64 * 64) * kStepRowBytes;
+  constexpr int smem = 4 * (BM + BN) * kStepRowBytes;
   static bool attr_set = false;
   auto kern = conv_igemm_kernel<T, BM, BN, WM, WN>;
   if (!attr_set) {
@@ -326,14 +592,49 @@ static int launch_one(const ConvArgs& a, hipStream_t stream) {
   return BSMI_OK;
 }
 
+template <typename T, int BM, int BN>
+static int launch_ws(const ConvArgs& a, hipStream_t stream) {
+  constexpr int smem = 5 * (BM + BN) * kStepRowBytes;
+  static bool attr_set = false;
+  auto kern = conv_ws_kernel<T, BM, BN>;
+  if (!attr_set) {
+    BSMI_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
+    attr_set = true;
+  }
+  const int grid = ceil_div(a.M, BM) * (a.Npad / BN);
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(512), smem, stream, a);
+  BSMI_HIP(hipGetLastError());
+  return BSMI_OK;
+}
+
+bool two_waves_per_simd() {
+  static const bool on = [] { const char* e = getenv("BSMI_WAVES8"); return !e || e[0] != '0'; }();
+  return on;
+}
+
+bool use_wave_specialised() {
+  static const bool on = [] { const char* e = getenv("BSMI_USE_WS"); return e && e[0] == '1'; }();
+  return on;
+}
+
 template <typename T>
 static int launch_cfg(const ConvArgs& a, TileCfg cfg, hipStream_t stream) {
+  if (use_wave_specialised()) {
+    switch (cfg) {
+      case TILE_256x32: return launch_ws<T, 256, 32>(a, stream);
+      case TILE_256x64: return launch_ws<T, 256, 64>(a, stream);
+      case TILE_256x160: return launch_ws<T, 256, 160>(a, stream);
+      default: break;
+    }
+  }
   switch (cfg) {
     case TILE_256x32: return launch_one<T, 256, 32, 4, 1>(a, stream);
     case TILE_256x64: return launch_one<T, 256, 64, 4, 1>(a, stream);
     case TILE_256x160: return launch_one<T, 256, 160, 4, 1>(a, stream);
-    case TILE_256x320: return launch_one<T, 256, 320, 2, 2>(a, stream);
-    case TILE_256x256: return launch_one<T, 256, 256, 2, 2>(a, stream);
+    case TILE_256x320: return launch_one<T, 256, 320, 4, 2>(a, stream);
+    case TILE_256x256:
+      if (two_waves_per_simd()) return launch_one<T, 256, 256, 4, 2>(a, stream);
+      return launch_one<T, 256, 256, 2, 2>(a, stream);
     default: BSMI_FAIL(BSMI_ERR_INVALID, "unknown tile config %d", (int)cfg);
   }
 }

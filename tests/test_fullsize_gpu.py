@@ -66,6 +66,51 @@ def test_full_block_segmentation_bit_exact(full_block):
     assert len(np.unique(ref[2])) < len(np.unique(ref_frags)) / 2
 
 
+def test_full_block_blockwise_stages_bit_exact(full_block):
+    """One blockwise block at BASELINE size: read box 160^3 (128^3 write + 16 context) built by
+    mirror-tiling the predicted affinities; fragment clean-up, 26-connected relabel and RAG edge scoring
+    against the oracle, with the timings the DESIGN.md table quotes."""
+    import time
+    from bootstrapper_amd.post.engine import SegEngine
+    from oracle import seg_ref as S
+    a128 = full_block["bf16"][0][:3]
+    affs = torch.nn.functional.pad(a128[None].float(), (16, 16, 16, 16, 16, 16), mode="reflect")[0].to(torch.uint8).contiguous()
+    assert tuple(affs.shape) == (3, 160, 160, 160)
+    eng = SegEngine((160, 160, 160))
+    nv = 128 ** 3
+    t = {}
+
+    def timed(name, fn):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        out = fn()
+        torch.cuda.synchronize()
+        t[name] = (time.perf_counter() - t0) * 1e3
+        return out
+    frags, _ = timed("ws_fragments", lambda: eng.ws_fragments(affs, True, 10))
+    frags_raw = frags.clone()
+    labels, num = timed("postprocess", lambda: eng.postprocess_fragments(affs, frags, 0.1, 64, (16, 16, 16), (128, 128, 128), 5 * nv))
+    eng.status()
+    # the neighbours' fragments are not available in a one-block test: score the RAG of the read box's own fragments
+    frags_read, _ = eng.postprocess_fragments(affs, frags_raw, 0.1, 64, (0, 0, 0), (160, 160, 160), 5 * nv)
+    edges, scores = timed("rag_merge_scores", lambda: eng.rag_merge_scores(affs, frags_read, 1.0, 256))
+    print("blockwise stage timings (ms):", {k: round(v, 2) for k, v in t.items()}, "fragments", int(num.item()), "edges", len(edges))
+
+    a = affs.cpu().numpy()
+    ref_frags, _ = S.ws_fragments_u8(a, True, 10)
+    ref_f = S.filter_fragments_u8(a, ref_frags, 0.1, 64)
+    ref_lab, ref_n = S.label26(np.ascontiguousarray(ref_f[16:144, 16:144, 16:144]))
+    assert int(num.item()) == ref_n and ref_n > 1000
+    got = labels.cpu().numpy().view(np.uint64)
+    assert np.array_equal(got, np.where(ref_lab > 0, ref_lab.astype(np.uint64) + np.uint64(5 * nv), np.uint64(0)))
+    ref_read, _ = S.label26(ref_f)
+    ref_read = np.where(ref_read > 0, ref_read.astype(np.uint64) + np.uint64(5 * nv), np.uint64(0))
+    assert np.array_equal(frags_read.cpu().numpy().view(np.uint64), ref_read)
+    e_ref, s_ref, _, _ = S.rag_merge_scores_u8(a, ref_read, 1.0, 256)
+    assert np.array_equal(edges.cpu().numpy().view(np.uint64), e_ref)
+    assert np.array_equal(scores.cpu().numpy().view(np.uint32), s_ref.view(np.uint32))
+
+
 def test_halo_kernel_parity_in_subprocess(golden_dir):
     """conv_halo.hip is opt-in through BSMI_USE_HALO (read once per process): run the golden
     comparison in a child process with the variable set."""
