@@ -57,6 +57,14 @@ int tile_bn(TileCfg c);
 // pick the tile for `cout` real output channels
 TileCfg choose_tile(int cout);
 
-int launch_conv_igemm(const ConvArgs& a, int precision, TileCfg cfg, hipStream_t stream);
+// Split-K tail workspace: one partial tile of at most kStreamKTileElems floats per persistent workgroup.
+constexpr size_t kStreamKTileElems = 256 * 320;
+// followed by the 8 per-XCD work-queue counters (zero between launches)
+inline size_t stream_k_ws_bytes(int sk_grid) { return (size_t)sk_grid * kStreamKTileElems * sizeof(float) + 64; }
+
+// sk_ws / sk_grid: optional split-K-tail workspace and persistent grid (a multiple of 8, normally the CU
+// count); with them, big-tile launches whose tile count is not a multiple of the grid run persistently.
+int launch_conv_igemm(const ConvArgs& a, int precision, TileCfg cfg, hipStream_t stream, float* sk_ws = nullptr,
+                      int sk_grid = 0);
 
 }  // namespace bsmi

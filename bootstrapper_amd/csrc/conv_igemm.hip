@@ -17,7 +17,6 @@
 
 #include <cstdio>
 #include <cstdlib>
-#include <type_traits>
 
 namespace bsmi {
 
@@ -75,7 +74,7 @@ typedef const __attribute__((address_space(4))) int32_t* cint_ptr_t;  // constan
 // high waves: the kernel runs one of two instantiations of this body per wave (the counted
 // vmcnt immediates depend on it; the barrier count does not).
 template <typename T, int BM, int BN, int WM, int WN, int B_INSTR, bool LATE>
-__device__ __forceinline__ void conv_igemm_body(const ConvArgs& a, char* smem) {
+__device__ __forceinline__ void conv_igemm_body(const ConvArgs& a, char* smem, int tile, int s0, int s1, float* part) {
   constexpr int NW = WM * WN;
   static_assert(NW == 4 || NW == 8, "one or two waves per SIMD");
   constexpr int ROWB = kStepRowBytes;
@@ -96,17 +95,9 @@ __device__ __forceinline__ void conv_igemm_body(const ConvArgs& a, char* smem) {
   const cint_ptr_t steps = (cint_ptr_t)a.steps;  // 4 dwords per K-step
   const int nsteps = a.nsteps;
 
-  // XCD-aware tile map: consecutive block ids are dealt round-robin to the 8 XCDs, so give
-  // each XCD a contiguous run of tiles; n fastest, so the blocks resident on one XCD cover few
-  // row panels x all weight panels and the tap re-reads of an activation line hit its L2.
-  const int mt = (a.M + BM - 1) / BM, ntn = a.Npad / BN;
-  const int ntiles = mt * ntn;
-  int tile;
-  {
-    const int q = ntiles >> 3, r = ntiles & 7;
-    const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
-    tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + j;
-  }
+  // the K-steps [s0, s1) of output tile `tile`; part != nullptr: raw f32 partial sums instead of the epilogue
+  const int ntn = a.Npad / BN;
+  const int nloc = s1 - s0;
   const int tile_m = tile / ntn, tile_n = tile - tile_m * ntn;
   const int m0 = tile_m * BM, n0 = tile_n * BN;
 
@@ -147,8 +138,9 @@ __device__ __forceinline__ void conv_igemm_body(const ConvArgs& a, char* smem) {
 
   // descriptor of K-step h (clamped), as three scalars
   struct Desc { int t, d0, d1; };
-  auto fetch = [&](int h) -> Desc {
-    const cint_ptr_t d = steps + (h < nsteps ? h : nsteps - 1) * 4;
+  auto fetch = [&](int h) -> Desc {  // h: K-step relative to s0
+    const int ha = s0 + h;
+    const cint_ptr_t d = steps + (ha < nsteps ? ha : nsteps - 1) * 4;
     return Desc{d[0], d[1], d[2]};
   };
   // Issue the LDS-DMA loads of K-step h (descriptor ds) into ring slot h & 3.  Branch free, so
@@ -162,7 +154,7 @@ __device__ __forceinline__ void conv_igemm_body(const ConvArgs& a, char* smem) {
     const uint64_t tbase = t1 ? base1 : (t2 ? base2 : base0);
     const uint32_t lofs = (uint32_t)(unit1 ? ds.d1 : ds.d0) + hoff;
     const gptr_t abase = (gptr_t)tbase;
-    const gptr_t wbase = (gptr_t)a.w + (size_t)(h < nsteps ? h : nsteps - 1) * wstep;
+    const gptr_t wbase = (gptr_t)a.w + (size_t)(s0 + h < nsteps ? s0 + h : nsteps - 1) * wstep;
     const lptr_t la = (lptr_t)(smem + (h & (NSLOT - 1)) * SLOT);
     const lptr_t lb = la + BM * ROWB;
 #pragma unroll
@@ -229,7 +221,7 @@ __device__ __forceinline__ void conv_igemm_body(const ConvArgs& a, char* smem) {
   if constexpr (!LATE) issue(3, fetch(3));
   Desc dnext = fetch(LATE ? 3 : 4);
 
-  for (int h = 0; h < nsteps; ++h) {
+  for (int h = 0; h < nloc; ++h) {
     const char* st = smem + (h & (NSLOT - 1)) * SLOT;
     if constexpr (LATE) {
       issue(h + 3, dnext);
@@ -281,6 +273,16 @@ __device__ __forceinline__ void conv_igemm_body(const ConvArgs& a, char* smem) {
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // drain the run-ahead loads before the wave ends
 
+  if (part) {
+    // stream-K: this workgroup multiplied only part of the tile's K range; leave the raw sums
+    // (register order, 64 contiguous bytes per lane) for conv_fixup_kernel
+#pragma unroll
+    for (int i = 0; i < FM; ++i)
+#pragma unroll
+      for (int j = 0; j < FN; ++j) *(f32x16_t*)(part + ((size_t)(i * FN + j) * (64 * NW) + tid) * 16) = acc[i][j];
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    return;
+  }
   // epilogue: bias (+ReLU), convert, store channels-last
   T* out = (T*)a.out;
 #pragma unroll
@@ -301,6 +303,25 @@ __device__ __forceinline__ void conv_igemm_body(const ConvArgs& a, char* smem) {
       }
     }
   }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // a persistent workgroup stages its next tile after this
+}
+
+// wave -> (weight-piece count, early/late) instantiation of the body
+template <typename T, int BM, int BN, int WM, int WN>
+__device__ __forceinline__ void conv_igemm_dispatch(const ConvArgs& a, char* smem, int tile, int s0, int s1, float* part) {
+  constexpr int NW = WM * WN, NBP = BN / 16;
+  constexpr int HI = (NBP + NW - 1) / NW, LO = NBP / NW;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  if constexpr (NW == 8) {
+    static_assert(HI == LO || NBP % NW == 4, "the uneven split must coincide with the early/late split");
+    if (wave < 4) conv_igemm_body<T, BM, BN, WM, WN, HI, false>(a, smem, tile, s0, s1, part);
+    else conv_igemm_body<T, BM, BN, WM, WN, LO, true>(a, smem, tile, s0, s1, part);
+  } else if constexpr (HI == LO) {
+    conv_igemm_body<T, BM, BN, WM, WN, HI, false>(a, smem, tile, s0, s1, part);
+  } else {
+    if (wave < NBP % NW) conv_igemm_body<T, BM, BN, WM, WN, HI, false>(a, smem, tile, s0, s1, part);
+    else conv_igemm_body<T, BM, BN, WM, WN, LO, false>(a, smem, tile, s0, s1, part);
+  }
 }
 
 // T: element type; BM x BN block tile; WM x WN waves: 4 (one per SIMD, up to 512 registers
@@ -309,231 +330,109 @@ __device__ __forceinline__ void conv_igemm_body(const ConvArgs& a, char* smem) {
 template <typename T, int BM, int BN, int WM, int WN>
 __global__ __launch_bounds__(64 * WM * WN, 1) void conv_igemm_kernel(const ConvArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];  // [NSLOT][A: BM rows | B: BN rows][64 B]
-  constexpr int NW = WM * WN, NBP = BN / 16;
-  constexpr int HI = (NBP + NW - 1) / NW, LO = NBP / NW;
-  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  if constexpr (NW == 8) {
-    static_assert(HI == LO || NBP % NW == 4, "the uneven split must coincide with the early/late split");
-    if (wave < 4) conv_igemm_body<T, BM, BN, WM, WN, HI, false>(a, smem);
-    else conv_igemm_body<T, BM, BN, WM, WN, LO, true>(a, smem);
-  } else if constexpr (HI == LO) {
-    conv_igemm_body<T, BM, BN, WM, WN, HI, false>(a, smem);
-  } else {
-    if (wave < NBP % NW) conv_igemm_body<T, BM, BN, WM, WN, HI, false>(a, smem);
-    else conv_igemm_body<T, BM, BN, WM, WN, LO, false>(a, smem);
-  }
+  // XCD-aware tile map: consecutive block ids are dealt round-robin to the 8 XCDs, so give
+  // each XCD a contiguous run of tiles; n fastest, so the blocks resident on one XCD cover few
+  // row panels x all weight panels and the tap re-reads of an activation line hit its L2.
+  const int ntiles = ((a.M + BM - 1) / BM) * (a.Npad / BN);
+  const int q = ntiles >> 3, r = ntiles & 7;
+  const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
+  const int tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + j;
+  conv_igemm_dispatch<T, BM, BN, WM, WN>(a, smem, tile, 0, a.nsteps, nullptr);
 }
 
-// Loader wave of conv_ws_kernel: PA activation pieces + PB weight pieces (16 rows x 64 B each)
-// per K-step; every vmcnt immediate below is a multiple of P = PA + PB.
-struct WsDesc { int t, d0, d1; };
-
-template <int BM, int BN, int PA, int PB>
-__device__ __forceinline__ void ws_issue(const ConvArgs& a, char* smem, int lw, int nsteps, int h, int slot, WsDesc ds,
-                                         const uint32_t (&ro0)[PA], const uint32_t (&ro1)[PA], const uint32_t (&ro2)[PA],
-                                         bool unit1, uint32_t hoff, uint32_t offb, size_t wstep) {
-  constexpr int ROWB = kStepRowBytes, NL = 4, SLOT = (BM + BN) * ROWB;
-  const bool t1 = ds.t == 1, t2 = ds.t == 2;
-  const uint64_t tbase = t1 ? a.t[1].base : (t2 ? a.t[2].base : a.t[0].base);
-  const uint32_t lofs = (uint32_t)(unit1 ? ds.d1 : ds.d0) + hoff;
-  const gptr_t abase = (gptr_t)tbase;
-  const gptr_t wbase = (gptr_t)a.w + (size_t)(h < nsteps ? h : nsteps - 1) * wstep;
-  const lptr_t la = (lptr_t)(smem + slot * SLOT);
-  const lptr_t lb = la + BM * ROWB;
-#pragma unroll
-  for (int i = 0; i < PA; ++i) {
-    const uint32_t ro = t1 ? ro1[i] : (t2 ? ro2[i] : ro0[i]);
-    __builtin_amdgcn_global_load_lds(abase + (size_t)(ro + lofs), la + (i * NL + lw) * 1024, 16, 0, 0);
-  }
-#pragma unroll
-  for (int i = 0; i < PB; ++i)
-    __builtin_amdgcn_global_load_lds(wbase + (size_t)i * NL * 16 * ROWB + offb, lb + (i * NL + lw) * 1024, 16, 0, 0);
+// Persistent form with a split-K tail: one workgroup per CU.  A plain launch of 779 tiles on 256
+// CUs runs 4 rounds for 3.04 rounds of work.  Here the tiles keep the XCD-contiguous order of
+// conv_igemm_kernel (the 32 workgroups of an XCD multiply 32 neighbouring tiles at any time, so
+// an activation panel and the weight panels are shared through that XCD's L2); every workgroup
+// multiplies its whole rounds of full tiles, and the `rem` (< 32) tiles an XCD has left over are
+// each cut along K into P = min(32 / rem, 16) parts.  The raw partial sums go
+// to `ws` ([xcd][32 slots][BM x BN] f32) and conv_fixup_kernel finishes those tiles.
+struct SkGeom {
+  int base, count, per, rounds, rem, P;  // this XCD's first tile, tile count, workgroups, full rounds, tail tiles, parts per tail tile
+};
+__device__ __forceinline__ SkGeom sk_geom(int ntiles, int xcd, int G) {
+  SkGeom g;
+  const int q = ntiles >> 3, r = ntiles & 7;
+  g.base = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+  g.count = q + (xcd < r ? 1 : 0);
+  g.per = G >> 3;
+  g.rounds = g.count / g.per;
+  g.rem = g.count - g.rounds * g.per;
+  g.P = g.rem ? (g.per / g.rem < 16 ? g.per / g.rem : 16) : 1;
+  return g;
 }
 
-__device__ __forceinline__ WsDesc ws_fetch(cint_ptr_t steps, int nsteps, int h) {
-  const cint_ptr_t d = steps + (h < nsteps ? h : nsteps - 1) * 4;
-  return WsDesc{d[0], d[1], d[2]};
-}
-
-template <int BM, int BN, int NSLOT, int PB>
-__device__ __forceinline__ void ws_loader(const ConvArgs& a, char* smem, int lw, int lane, int m0, int n0) {
-  constexpr int ROWB = kStepRowBytes, NL = 4;
-  constexpr int PA = BM / 16 / NL;
-  constexpr int P = PA + PB;
-  static_assert(2 * P <= 63, "vmcnt range");
-  const cint_ptr_t steps = (cint_ptr_t)a.steps;
-  const int nsteps = a.nsteps;
-  const int lrow = lane >> 2, lchunk = lane & 3;
-  const int skey = (lane >> 4) & 3;
-  const int g = lchunk ^ skey;
-  const bool unit1 = (g >> 1) != 0;
-  const uint32_t hoff = (uint32_t)((g & 1) << 4);
-  uint32_t ro0[PA], ro1[PA], ro2[PA];
-#pragma unroll
-  for (int i = 0; i < PA; ++i) {
-    const int row = (i * NL + lw) * 16 + lrow;
-    int m = m0 + row;
-    m = m < a.M ? m : a.M - 1;
-    const int x = m % a.Wo;
-    const int zy = m / a.Wo;
-    const int y = zy % a.Ho, z = zy / a.Ho;
-    ro0[i] = (uint32_t)(z * a.t[0].sz + y * a.t[0].sy + x * a.t[0].sx);
-    ro1[i] = (uint32_t)(z * a.t[1].sz + y * a.t[1].sy + x * a.t[1].sx);
-    ro2[i] = (uint32_t)(z * a.t[2].sz + y * a.t[2].sy + x * a.t[2].sx);
-  }
-  const uint32_t offb = (uint32_t)((n0 + lw * 16 + lrow) * ROWB + ((lchunk ^ skey) << 4));
-  const size_t wstep = (size_t)a.Npad * ROWB;
-#define WS_ISSUE(h_, slot_, ds_) ws_issue<BM, BN, PA, PB>(a, smem, lw, nsteps, (h_), (slot_), (ds_), ro0, ro1, ro2, unit1, hoff, offb, wstep)
-  WS_ISSUE(0, 0, ws_fetch(steps, nsteps, 0));
-  WS_ISSUE(1, 1, ws_fetch(steps, nsteps, 1));
-  WS_ISSUE(2, 2, ws_fetch(steps, nsteps, 2));
-  WS_ISSUE(3, 3, ws_fetch(steps, nsteps, 3));
-  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * P) : "memory");  // K-steps 0, 1 landed
-  __builtin_amdgcn_s_barrier();                                 // E_-1
-  WsDesc dnext = ws_fetch(steps, nsteps, NSLOT - 1);
-  int slot = NSLOT - 1;
-  for (int j = 0; j < nsteps; ++j) {
-    WS_ISSUE(j + NSLOT - 1, slot, dnext);
-    dnext = ws_fetch(steps, nsteps, j + NSLOT);
-    slot = slot == NSLOT - 1 ? 0 : slot + 1;
-    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * P) : "memory");  // K-step j+2 landed
-    __builtin_amdgcn_s_barrier();                                 // E_j
-  }
-#undef WS_ISSUE
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-}
-
-// ------------------------------------------------------------------------------------------
-// Wave-specialised variant: 8 waves per workgroup (two per SIMD).  Waves 0-3 only multiply
-// (each a 64 x BN register tile: LDS fragment reads + MFMA), waves 4-7 only stage (scalar
-// descriptors + LDS-DMA).  An LDS-DMA instruction costs its issuing wave 60-185 cycles
-// (MI355X_MICROARCH.md, "LDS-DMA piece issue cost"): with 26 of them per K-step that is as much
-// time as the K-step's MFMAs, and in the 4-wave kernel above both come out of the same
-// instruction stream.  Here the loader wave of a SIMD stalls on its own, and the multiplier
-// wave next to it keeps the matrix pipe busy.
-//
-// Ring of NSLOT = 5 slots of [BM + BN rows][64 B].  One barrier E_h per K-step, after which
-// (a) the multipliers have finished reading slot h, (b) K-steps <= h+2 have landed.  The
-// loaders then issue K-step h+5 into slot h and wait (counted vmcnt) for K-step h+3; the
-// multipliers read the second half of slot h+1 and the first half of slot h+2.
-template <typename T, int BM, int BN>
-__global__ __launch_bounds__(512, 1) void conv_ws_kernel(const ConvArgs a) {
-  constexpr int ROWB = kStepRowBytes;
-  constexpr int NSLOT = 5;
-  constexpr int NL = 4;                        // loader waves = multiplier waves
-  constexpr int WTM = BM / NL;                 // 64 rows per multiplier wave
-  constexpr int FM = WTM / 32, FN = BN / 32;
-  constexpr int PA = BM / 16 / NL;             // A pieces (16 rows x 64 B) per loader wave per K-step
-  constexpr int NBP = BN / 16;                 // B pieces per K-step, dealt round-robin to the loaders
-  constexpr int SLOT = (BM + BN) * ROWB;
-  static_assert(BM == 256 && BN % 32 == 0, "tile shape");
-
+// Work is handed out dynamically: per XCD a queue (an atomic counter in `counters`) of that XCD's
+// full tiles followed by its tail parts.  A workgroup drains the queue of the XCD it runs on, then
+// helps the others, so a CU that other streams keep busy (the segmentation lanes of the block
+// pipeline) only delays its own share by one tile; a workgroup that becomes resident late finds
+// the queues empty and leaves.  conv_fixup_kernel re-zeroes the counters for the next launch.
+template <typename T, int BM, int BN, int WM, int WN>
+__global__ __launch_bounds__(64 * WM * WN, 1) void conv_igemm_sk_kernel(const ConvArgs a, float* ws, int* counters) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-
-  const int tid = threadIdx.x;
-  const int lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int nsteps = a.nsteps;
-
-  const int mt = (a.M + BM - 1) / BM, ntn = a.Npad / BN;
-  const int ntiles = mt * ntn;
-  int tile;
-  {
-    const int q = ntiles >> 3, r = ntiles & 7;
-    const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
-    tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + j;
+  __shared__ int sh_item;
+  const int ntiles = ((a.M + BM - 1) / BM) * (a.Npad / BN);
+  const int S = a.nsteps;
+  for (int k = 0; k < 8; ++k) {
+    const int xcd = (blockIdx.x + k) & 7;
+    const SkGeom g = sk_geom(ntiles, xcd, gridDim.x);
+    const int nfull = g.rounds * g.per, nitems = nfull + g.rem * g.P;
+    for (;;) {
+      __syncthreads();
+      if (threadIdx.x == 0) sh_item = atomicAdd(&counters[xcd], 1);
+      __syncthreads();
+      const int it = __builtin_amdgcn_readfirstlane(sh_item);
+      if (it >= nitems) break;
+      if (it < nfull) {
+        conv_igemm_dispatch<T, BM, BN, WM, WN>(a, smem, g.base + it, 0, S, nullptr);
+      } else {
+        const int r = it - nfull;
+        const int rt = r / g.P, part = r - rt * g.P;
+        const int sa = (int)((long long)S * part / g.P), sb = (int)((long long)S * (part + 1) / g.P);
+        float* dst = g.P == 1 ? nullptr : ws + ((size_t)xcd * g.per + r) * (BM * BN);
+        if (sb > sa) conv_igemm_dispatch<T, BM, BN, WM, WN>(a, smem, g.base + nfull + rt, sa, sb, dst);
+      }
+    }
   }
+}
+
+// Finishes the tail tiles of conv_igemm_sk_kernel: sum of the P partial tiles in part order
+// (deterministic), bias, ReLU, store.  Grid (32, 8): (tail tile, xcd); same thread -> element map
+// as the epilogue.
+template <typename T, int BM, int BN, int WM, int WN>
+__global__ __launch_bounds__(64 * WM * WN) void conv_fixup_kernel(const ConvArgs a, const float* ws, int G, int* counters) {
+  if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x < 8) counters[threadIdx.x] = 0;
+  constexpr int NW = WM * WN, WTM = BM / WM, WTN = BN / WN, FM = WTM / 32, FN = WTN / 32;
+  const int xcd = blockIdx.y, rt = blockIdx.x;
+  const int ntn = a.Npad / BN;
+  const SkGeom g = sk_geom(((a.M + BM - 1) / BM) * ntn, xcd, G);
+  if (rt >= g.rem || g.P == 1) return;
+  const int S = a.nsteps;
+  const int tile = g.base + g.rounds * g.per + rt;
   const int tile_m = tile / ntn, tile_n = tile - tile_m * ntn;
   const int m0 = tile_m * BM, n0 = tile_n * BN;
-
-  if (wave >= NL) {
-    const int lw = wave - NL;
-    constexpr int PB_HI = (NBP + NL - 1) / NL, PB_LO = NBP / NL;
-    if ((NBP - lw + NL - 1) / NL == PB_HI) ws_loader<BM, BN, NSLOT, PB_HI>(a, smem, lw, lane, m0, n0);
-    else ws_loader<BM, BN, NSLOT, PB_LO>(a, smem, lw, lane, m0, n0);
-    return;
-  }
-
-  // ---------------------------------------------------------------- multiplier
-  const int wm = wave;
-  const int lr = lane & 31, lh = lane >> 5;
-  uint32_t arow[FM], akey[FM], brow[FN], bkey[FN];
-#pragma unroll
-  for (int i = 0; i < FM; ++i) {
-    const int row = wm * WTM + i * 32 + lr;
-    arow[i] = row * ROWB;
-    akey[i] = (row >> 2) & 3;
-  }
-#pragma unroll
-  for (int j = 0; j < FN; ++j) {
-    const int row = j * 32 + lr;
-    brow[j] = BM * ROWB + row * ROWB;
-    bkey[j] = (row >> 2) & 3;
-  }
-  f32x16_t acc[FM][FN];
-#pragma unroll
-  for (int i = 0; i < FM; ++i)
-#pragma unroll
-    for (int j = 0; j < FN; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-
-  u32x4_t fa[2][FM], fb[2][FN];
-  auto load_frags = [&](const char* st, int sub, u32x4_t* pa, u32x4_t* pb) {
-    const uint32_t c = 2 * sub + lh;
-#pragma unroll
-    for (int i = 0; i < FM; ++i) pa[i] = *(const u32x4_t*)(st + arow[i] + ((c ^ akey[i]) << 4));
-#pragma unroll
-    for (int j = 0; j < FN; ++j) pb[j] = *(const u32x4_t*)(st + brow[j] + ((c ^ bkey[j]) << 4));
-  };
-  auto mma = [&](const u32x4_t* pa, const u32x4_t* pb) {
-#pragma unroll
-    for (int i = 0; i < FM; ++i)
-#pragma unroll
-      for (int j = 0; j < FN; ++j) acc[i][j] = Elem<T>::mfma(pa[i], pb[j], acc[i][j]);
-  };
-
-  __builtin_amdgcn_s_barrier();  // E_-1: K-steps 0 and 1 have landed
-  load_frags(smem, 0, fa[0], fb[0]);
-  int slot = 0;
-  for (int h = 0; h < nsteps; ++h) {
-    const char* st = smem + slot * SLOT;
-    slot = slot == NSLOT - 1 ? 0 : slot + 1;
-    load_frags(st, 1, fa[1], fb[1]);
-    mma(fa[0], fb[0]);
-#ifndef BSMI_NO_SCHED_HINTS
-#pragma unroll
-    for (int k = 0; k < FM + FN; ++k) {
-      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-      __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-    }
-#endif
-    load_frags(smem + slot * SLOT, 0, fa[0], fb[0]);  // K-step h+1 (a slot nobody wrote past the end: unused)
-    mma(fa[1], fb[1]);
-#ifndef BSMI_NO_SCHED_HINTS
-#pragma unroll
-    for (int k = 0; k < FM + FN; ++k) {
-      __builtin_amdgcn_sched_group_barrier(0x008, 1, 1);
-      __builtin_amdgcn_sched_group_barrier(0x100, 1, 1);
-    }
-#endif
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // every read of slot h has returned
-    __builtin_amdgcn_s_barrier();                       // E_h
-  }
-
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave / WN, wn = wave % WN, lr = lane & 31, lh = lane >> 5;
+  const float* p0 = ws + ((size_t)xcd * g.per + rt * g.P) * (BM * BN);
   T* out = (T*)a.out;
-#pragma unroll
   for (int j = 0; j < FN; ++j) {
-    const int n = n0 + j * 32 + lr;
-    if (n >= a.Co) continue;
-    const float bv = a.bias[n];
-#pragma unroll
+    const int n = n0 + wn * WTN + j * 32 + lr;
+    const float bv = n < a.Co ? a.bias[n] : 0.f;
     for (int i = 0; i < FM; ++i) {
+      const size_t o = ((size_t)(i * FN + j) * (64 * NW) + tid) * 16;
+      f32x16_t x;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) x[r] = 0.f;
+      for (int part = 0; part < g.P; ++part) {
+        if ((long long)S * (part + 1) / g.P == (long long)S * part / g.P) continue;  // empty K range: nothing was written
+        x += *(const f32x16_t*)(p0 + (size_t)part * (BM * BN) + o);
+      }
+      if (n >= a.Co) continue;
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int m = m0 + wm * WTM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
         if (m < a.M) {
-          float v = acc[i][j][r] + bv;
+          float v = x[r] + bv;
           if (a.relu) v = v > 0.f ? v : 0.f;
           Elem<T>::store(out + (size_t)m * a.Co + n, v);
         }
@@ -542,7 +441,6 @@ __global__ __launch_bounds__(512, 1) void conv_ws_kernel(const ConvArgs a) {
   }
 }
 
-bool use_wave_specialised();
 bool two_waves_per_simd();
 int tile_bm(TileCfg) { return 256; }
 int tile_bn(TileCfg c) {
@@ -563,7 +461,6 @@ TileCfg choose_tile(int cout) {
   // TILE_256x320 exists only as the 8-wave kernel (4 x 2 waves of 64 x 160 register tiles)
   if (!two_waves_per_simd()) eff[4] = 0.01;
   if (const char* e = getenv("BSMI_TILE_EFF")) sscanf(e, "%lf,%lf,%lf,%lf,%lf", &eff[0], &eff[1], &eff[2], &eff[3], &eff[4]);  // experiments
-  if (use_wave_specialised()) eff[3] = 0.01;  // its 64 x BN register tiles stop at BN = 160
   TileCfg best = TILE_256x32;
   double bestc = 1e30;
   for (int i = 0; i < 5; ++i) {
@@ -578,31 +475,29 @@ TileCfg choose_tile(int cout) {
 }
 
 template <typename T, int BM, int BN, int WM, int WN>
-static int launch_one(const ConvArgs& a, hipStream_t stream) {
+static int launch_one(const ConvArgs& a, hipStream_t stream, float* sk_ws, int sk_grid) {
   constexpr int smem = 4 * (BM + BN) * kStepRowBytes;
   static bool attr_set = false;
   auto kern = conv_igemm_kernel<T, BM, BN, WM, WN>;
+  auto kern_sk = conv_igemm_sk_kernel<T, BM, BN, WM, WN>;
   if (!attr_set) {
     BSMI_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
+    BSMI_HIP(hipFuncSetAttribute((const void*)kern_sk, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
     attr_set = true;
   }
-  const int grid = ceil_div(a.M, BM) * (a.Npad / BN);
-  hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * WM * WN), smem, stream, a);
-  BSMI_HIP(hipGetLastError());
-  return BSMI_OK;
-}
-
-template <typename T, int BM, int BN>
-static int launch_ws(const ConvArgs& a, hipStream_t stream) {
-  constexpr int smem = 5 * (BM + BN) * kStepRowBytes;
-  static bool attr_set = false;
-  auto kern = conv_ws_kernel<T, BM, BN>;
-  if (!attr_set) {
-    BSMI_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
-    attr_set = true;
+  const int ntiles = ceil_div(a.M, BM) * (a.Npad / BN);
+  // persistent + split-K tail when whole rounds would leave a large share of the last one idle
+  const bool big_tile = BN >= 256;
+  const int rounds = ceil_div(ntiles, sk_grid > 0 ? sk_grid : 1);
+  if (sk_ws && sk_grid >= 8 && big_tile && ntiles % sk_grid != 0 && rounds <= 16 && (size_t)BM * BN <= kStreamKTileElems &&
+      !(WM == 2 && WN == 2)) {  // the 2x2 (512-register) body has no room for the round loop
+    int* counters = (int*)(sk_ws + (size_t)sk_grid * kStreamKTileElems);
+    hipLaunchKernelGGL(kern_sk, dim3(sk_grid), dim3(64 * WM * WN), smem, stream, a, sk_ws, counters);
+    hipLaunchKernelGGL((conv_fixup_kernel<T, BM, BN, WM, WN>), dim3(sk_grid / 8, 8), dim3(64 * WM * WN), 0, stream, a,
+                       (const float*)sk_ws, sk_grid, counters);
+  } else {
+    hipLaunchKernelGGL(kern, dim3(ntiles), dim3(64 * WM * WN), smem, stream, a);
   }
-  const int grid = ceil_div(a.M, BM) * (a.Npad / BN);
-  hipLaunchKernelGGL(kern, dim3(grid), dim3(512), smem, stream, a);
   BSMI_HIP(hipGetLastError());
   return BSMI_OK;
 }
@@ -612,38 +507,25 @@ bool two_waves_per_simd() {
   return on;
 }
 
-bool use_wave_specialised() {
-  static const bool on = [] { const char* e = getenv("BSMI_USE_WS"); return e && e[0] == '1'; }();
-  return on;
-}
-
 template <typename T>
-static int launch_cfg(const ConvArgs& a, TileCfg cfg, hipStream_t stream) {
-  if (use_wave_specialised()) {
-    switch (cfg) {
-      case TILE_256x32: return launch_ws<T, 256, 32>(a, stream);
-      case TILE_256x64: return launch_ws<T, 256, 64>(a, stream);
-      case TILE_256x160: return launch_ws<T, 256, 160>(a, stream);
-      default: break;
-    }
-  }
+static int launch_cfg(const ConvArgs& a, TileCfg cfg, hipStream_t stream, float* sk_ws, int sk_grid) {
   switch (cfg) {
-    case TILE_256x32: return launch_one<T, 256, 32, 4, 1>(a, stream);
-    case TILE_256x64: return launch_one<T, 256, 64, 4, 1>(a, stream);
-    case TILE_256x160: return launch_one<T, 256, 160, 4, 1>(a, stream);
-    case TILE_256x320: return launch_one<T, 256, 320, 4, 2>(a, stream);
+    case TILE_256x32: return launch_one<T, 256, 32, 4, 1>(a, stream, sk_ws, sk_grid);
+    case TILE_256x64: return launch_one<T, 256, 64, 4, 1>(a, stream, sk_ws, sk_grid);
+    case TILE_256x160: return launch_one<T, 256, 160, 4, 1>(a, stream, sk_ws, sk_grid);
+    case TILE_256x320: return launch_one<T, 256, 320, 4, 2>(a, stream, sk_ws, sk_grid);
     case TILE_256x256:
-      if (two_waves_per_simd()) return launch_one<T, 256, 256, 4, 2>(a, stream);
-      return launch_one<T, 256, 256, 2, 2>(a, stream);
+      if (two_waves_per_simd()) return launch_one<T, 256, 256, 4, 2>(a, stream, sk_ws, sk_grid);
+      return launch_one<T, 256, 256, 2, 2>(a, stream, sk_ws, sk_grid);
     default: BSMI_FAIL(BSMI_ERR_INVALID, "unknown tile config %d", (int)cfg);
   }
 }
 
-int launch_conv_igemm(const ConvArgs& a, int precision, TileCfg cfg, hipStream_t stream) {
+int launch_conv_igemm(const ConvArgs& a, int precision, TileCfg cfg, hipStream_t stream, float* sk_ws, int sk_grid) {
   if (a.M <= 0 || a.nsteps <= 0 || a.Npad % tile_bn(cfg) != 0)
     BSMI_FAIL(BSMI_ERR_INVALID, "conv launch: bad geometry M=%d nsteps=%d Npad=%d", a.M, a.nsteps, a.Npad);
-  if (precision == BSMI_PREC_F32) return launch_cfg<float>(a, cfg, stream);
-  if (precision == BSMI_PREC_BF16) return launch_cfg<bf16_elem>(a, cfg, stream);
+  if (precision == BSMI_PREC_F32) return launch_cfg<float>(a, cfg, stream, sk_ws, sk_grid);
+  if (precision == BSMI_PREC_BF16) return launch_cfg<bf16_elem>(a, cfg, stream, sk_ws, sk_grid);
   BSMI_FAIL(BSMI_ERR_INVALID, "unknown precision %d", precision);
 }
 

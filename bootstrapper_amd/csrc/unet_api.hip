@@ -140,6 +140,8 @@ struct bsmi_unet {
   double prof_ms[5] = {0, 0, 0, 0, 0}, prof_flops[5] = {0, 0, 0, 0, 0};
   int64_t prof_launches[5] = {0, 0, 0, 0, 0};
   std::map<std::vector<int64_t>, std::unique_ptr<Plan>> plans;  // key: prec, D, H, W
+  float* sk_ws = nullptr;  // stream-K partial tiles (conv_igemm.h)
+  int sk_grid = 0;
 };
 
 namespace bsmi {
@@ -754,6 +756,7 @@ int bsmi_unet_destroy(bsmi_unet* h) {
   };
   for (auto& p : h->l_conv) free_site(p);
   for (auto& p : h->r_conv) free_site(p);
+  if (h->sk_ws) (void)hipFree(h->sk_ws);
   for (auto& hd : h->heads) {
     if (hd.hw) (void)hipFree(hd.hw);
     if (hd.hb) (void)hipFree(hd.hb);
@@ -896,6 +899,19 @@ int bsmi_unet_forward(bsmi_unet* h, int precision, const void* raw_dev, int raw_
     plan.events.assign(2 * plan.steps.size(), nullptr);
     for (auto& e : plan.events) BSMI_HIP(hipEventCreate(&e));
   }
+  if (!h->sk_grid) {
+    const char* e = getenv("BSMI_STREAMK");
+    if (e && e[0] == '0') {
+      h->sk_grid = -1;
+    } else {
+      hipDeviceProp_t prop;
+      BSMI_HIP(hipGetDeviceProperties(&prop, h->device));
+      h->sk_grid = prop.multiProcessorCount / 8 * 8;
+      if (const char* g = getenv("BSMI_SK_GRID")) h->sk_grid = std::max(8, atoi(g) / 8 * 8);  // tests: force cuts on small nets
+      BSMI_HIP(hipMalloc((void**)&h->sk_ws, stream_k_ws_bytes(h->sk_grid)));
+      BSMI_HIP(hipMemset((char*)h->sk_ws + stream_k_ws_bytes(h->sk_grid) - 64, 0, 64));
+    }
+  }
   size_t step_idx = 0;
   for (const PlanStep& st : plan.steps) {
     if (h->profiling) BSMI_HIP(hipEventRecord(plan.events[2 * step_idx], s));
@@ -905,7 +921,7 @@ int bsmi_unet_forward(bsmi_unet* h, int precision, const void* raw_dev, int raw_
                                (size_t)st.out.D * st.out.H * st.out.W, s);
         break;
       case PlanStep::CONV:
-        rc = st.use_halo ? launch_conv_halo(st.halo, precision, st.tile, s) : launch_conv_igemm(st.conv, precision, st.tile, s);
+        rc = st.use_halo ? launch_conv_halo(st.halo, precision, st.tile, s) : launch_conv_igemm(st.conv, precision, st.tile, s, h->sk_ws, h->sk_grid);
         break;
       case PlanStep::POOL:
         rc = launch_maxpool(precision, st.in.ptr, st.out.ptr, st.in.D, st.in.H, st.in.W, st.in.Cpad,
