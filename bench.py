@@ -122,6 +122,7 @@ def main():
     ap.add_argument("--volume", type=int, default=1024, help="edge of the synthetic cubic volume")
     ap.add_argument("--seg-lanes", type=int, default=8)
     ap.add_argument("--pred-lanes", type=int, default=1, help="U-Net replicas / predict streams per GPU")
+    ap.add_argument("--seg-cus", type=int, default=0, help="CUs reserved for the segmentation lanes (0: shared CUs)")
     ap.add_argument("--no-segment", action="store_true", help="predict only (diagnostic; not the headline metric)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
@@ -160,7 +161,7 @@ def main():
     mine = [grid[(rank + i * world) % len(grid)] for i in range(n_warm + args.steps)]
 
     pipe = BlockPipeline(model, OUT_BLOCK, CONTEXT, THRESHOLDS, n_seg_lanes=args.seg_lanes,
-                         segment=not args.no_segment, device=local_rank, models=models)
+                         segment=not args.no_segment, device=local_rank, models=models, seg_cus=args.seg_cus)
 
     def barrier():
         torch.cuda.synchronize(dev)
@@ -204,7 +205,7 @@ def main():
                                "3d_affs U-Net (94.7M params, seeded random weights) + xy seeded watershed + mean-affinity "
                                "agglomeration at [0.2,0.35,0.5]",
                    "blocks_per_gpu": args.steps, "parallelism": f"blocks interleaved over {world} GPU(s), no collectives",
-                   "seg_lanes": args.seg_lanes, "pred_lanes": len(models)},
+                   "seg_lanes": args.seg_lanes, "pred_lanes": len(models), "seg_cus": pipe.seg_cus},
         "roofline": {"bound": "mfma", "achieved": achieved, "peak": BF16_DENSE_PEAK_TFLOPS if args.precision == "bf16" else 157.3,
                      "unit": "TFLOP/s", "frac": achieved / (BF16_DENSE_PEAK_TFLOPS if args.precision == "bf16" else 157.3),
                      "traffic": None,

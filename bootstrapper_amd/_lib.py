@@ -69,6 +69,9 @@ def _load():
         "bsmi_lut_relabel": (i32, [C.c_int, vp, C.c_uint64, vp, vp, C.c_uint64, vp, vp]),
         "bsmi_connected_components": (i32, [vp, C.c_uint64, vp, vp, C.c_uint64, C.c_float, vp]),
         "bsmi_seg_status": (i32, [p, vp]),
+        "bsmi_unet_set_persistent_grid": (i32, [p, C.c_int]),
+        "bsmi_stream_create_cu_mask": (i32, [C.c_int, vp, C.c_int, C.POINTER(C.c_void_p)]),
+        "bsmi_stream_destroy": (i32, [C.c_int, vp]),
     }
     for name, (res, args) in sigs.items():
         fn = getattr(lib, name)  # AttributeError if the symbol is missing: fail loudly

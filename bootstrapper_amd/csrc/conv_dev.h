@@ -1,0 +1,65 @@
+// Device-side pieces shared by the convolution kernels (conv_igemm.hip, conv_rh.hip).
+#pragma once
+#include "conv_igemm.h"
+
+namespace bsmi {
+
+typedef __attribute__((__vector_size__(8 * sizeof(__bf16)))) __bf16 bf16x8_t;
+typedef __attribute__((__vector_size__(16 * sizeof(float)))) float f32x16_t;
+typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
+
+struct bf16_elem {
+  uint16_t v;
+};
+
+template <typename T>
+struct Elem;
+template <>
+struct Elem<float> {
+  static __device__ __forceinline__ f32x16_t mfma(u32x4_t a, u32x4_t b, f32x16_t acc) {
+    // 4 x v_mfma_f32_32x32x2_f32: lane half h holds k = 4h..4h+3 of this 8-wide sub-step;
+    // instruction t contracts k in {t, 4+t}.  Same permutation on A and B.
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(a.x), __uint_as_float(b.x), acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(a.y), __uint_as_float(b.y), acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(a.z), __uint_as_float(b.z), acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(a.w), __uint_as_float(b.w), acc, 0, 0, 0);
+    return acc;
+  }
+  static __device__ __forceinline__ void store(float* p, float v) { *p = v; }
+};
+template <>
+struct Elem<bf16_elem> {
+  static __device__ __forceinline__ f32x16_t mfma(u32x4_t a, u32x4_t b, f32x16_t acc) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, a),
+                                                   __builtin_bit_cast(bf16x8_t, b), acc, 0, 0, 0);
+  }
+  static __device__ __forceinline__ void store(bf16_elem* p, float v) {
+    __bf16 h = (__bf16)v;
+    p->v = __builtin_bit_cast(uint16_t, h);
+  }
+};
+
+// 16-byte store of finished output rows.  Streaming (nt): the 0.1-0.2 GB a layer writes should not
+// compete for L2 with the panels the K-loops of the other workgroups are re-reading; measured
+// on the 128^3 block, the two largest layers 5.39 -> 5.15 ms and 4.82 -> 4.63 ms, sc1 and sc0 sc1 the
+// same within 1 %.  BSMI_STORE_POLICY (dev builds): 0 plain, 1 sc1, 2 nt, 3 sc0 sc1.
+#ifndef BSMI_STORE_POLICY
+#define BSMI_STORE_POLICY 2
+#endif
+__device__ __forceinline__ void store_stream16(void* p, u32x4_t v) {
+#if BSMI_STORE_POLICY == 1
+  asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(p), "v"(v) : "memory");
+#elif BSMI_STORE_POLICY == 2
+  asm volatile("global_store_dwordx4 %0, %1, off nt" ::"v"(p), "v"(v) : "memory");
+#elif BSMI_STORE_POLICY == 3
+  asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(p), "v"(v) : "memory");
+#else
+  *(u32x4_t*)p = v;
+#endif
+}
+
+typedef const __attribute__((address_space(1))) char* gptr_t;
+typedef __attribute__((address_space(3))) char* lptr_t;
+typedef const __attribute__((address_space(4))) int32_t* cint_ptr_t;  // constant AS: scalar loads
+
+}  // namespace bsmi

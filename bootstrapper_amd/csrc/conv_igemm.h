@@ -56,6 +56,8 @@ int tile_bm(TileCfg c);
 int tile_bn(TileCfg c);
 // pick the tile for `cout` real output channels
 TileCfg choose_tile(int cout);
+// 8-wave kernels enabled (BSMI_WAVES8 != 0)
+bool two_waves_per_simd();
 
 // Split-K tail workspace: one partial tile of at most kStreamKTileElems floats per persistent workgroup.
 constexpr size_t kStreamKTileElems = 256 * 320;

@@ -13,62 +13,33 @@
 // HBM/L2 -> LDS by LDS-DMA as [row][64 B] images with a 16-byte-chunk XOR swizzle
 // (chunk ^= (row>>2)&3) so that the ds_read_b128 fragment reads of
 // v_mfma_f32_32x32x16_bf16 / v_mfma_f32_32x32x2_f32 are bank-conflict free.
-#include "conv_igemm.h"
+#include "conv_dev.h"
 
 #include <cstdio>
 #include <cstdlib>
 
 namespace bsmi {
 
-typedef __attribute__((__vector_size__(8 * sizeof(__bf16)))) __bf16 bf16x8_t;
-typedef __attribute__((__vector_size__(16 * sizeof(float)))) float f32x16_t;
-typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
-
-struct bf16_elem {
-  uint16_t v;
-};
-
-template <typename T>
-struct Elem;
-template <>
-struct Elem<float> {
-  static __device__ __forceinline__ f32x16_t mfma(u32x4_t a, u32x4_t b, f32x16_t acc) {
-    // 4 x v_mfma_f32_32x32x2_f32: lane half h holds k = 4h..4h+3 of this 8-wide sub-step;
-    // instruction t contracts k in {t, 4+t}.  Same permutation on A and B.
-    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(a.x), __uint_as_float(b.x), acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(a.y), __uint_as_float(b.y), acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(a.z), __uint_as_float(b.z), acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(a.w), __uint_as_float(b.w), acc, 0, 0, 0);
-    return acc;
+#ifdef BSMI_STAMP  // dev build: time spent per tile in [loop, drain+barrier, epilogue, store drain] (100 MHz ticks)
+__device__ unsigned long long g_stamp[8];
+extern "C" int bsmi_debug_stamps(unsigned long long* out, int reset) {
+  if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_stamp), sizeof(unsigned long long) * 8) != hipSuccess) return -1;
+  if (reset) {
+    unsigned long long z[8] = {0};
+    if (hipMemcpyToSymbol(HIP_SYMBOL(g_stamp), z, sizeof z) != hipSuccess) return -1;
   }
-  static __device__ __forceinline__ void store(float* p, float v) { *p = v; }
-};
-template <>
-struct Elem<bf16_elem> {
-  static __device__ __forceinline__ f32x16_t mfma(u32x4_t a, u32x4_t b, f32x16_t acc) {
-    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, a),
-                                                   __builtin_bit_cast(bf16x8_t, b), acc, 0, 0, 0);
-  }
-  static __device__ __forceinline__ void store(bf16_elem* p, float v) {
-    __bf16 h = (__bf16)v;
-    p->v = __builtin_bit_cast(uint16_t, h);
-  }
-};
+  return 0;
+}
+#endif
 
-typedef const __attribute__((address_space(1))) char* gptr_t;
-typedef __attribute__((address_space(3))) char* lptr_t;
-typedef const __attribute__((address_space(4))) int32_t* cint_ptr_t;  // constant AS: scalar loads
-
-// T: element type; BM x BN block tile; WM x WN = 4 waves (one per SIMD, so each wave may use
-// the whole 512-register file: 128x128 register tiles, few LDS reads per MFMA).
-//
 // Staging is LDS-DMA (global_load_lds_dwordx4) into a ring of NSLOT = 4 K-step slots of
-// [BM + BNL rows][64 B].  One wave instruction moves 16 tile rows x 64 B = 1 KiB: lane l lands
+// [BM + BN rows][64 B].  One wave instruction moves 16 tile rows x 64 B = 1 KiB: lane l lands
 // at row (l>>2), 16-byte slot (l&3) of that KiB and FETCHES the source chunk
 // (l&3) ^ ((row>>2)&3): the bank swizzle is applied on the per-lane source address, the LDS
 // image stays lane-linear, and the ds_read_b128 fragment reads (same XOR) are conflict free.
 // The loads of K-steps h+2..h+4 are in flight while K-step h is multiplied (counted vmcnt,
 // raw s_barrier); the single barrier of a K-step sits between its two MFMA groups.
+//
 // B_INSTR: weight pieces (16 rows x 64 B) this wave stages per K-step.  The BN / 16 pieces of a
 // K-step are dealt round-robin to the waves, so B_INSTR may differ by one between the low and the
 // high waves: the kernel runs one of two instantiations of this body per wave (the counted
@@ -88,6 +59,9 @@ __device__ __forceinline__ void conv_igemm_body(const ConvArgs& a, char* smem, i
   static_assert(WTM % 32 == 0 && WTN % 32 == 0, "wave tile must be a multiple of 32");
   static_assert(3 * G <= 63, "vmcnt range");
 
+#ifdef BSMI_STAMP
+  const unsigned long long st_begin = wall_clock64();
+#endif
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -271,10 +245,18 @@ __device__ __forceinline__ void conv_igemm_body(const ConvArgs& a, char* smem, i
     }
 #endif
   }
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // drain the run-ahead loads before the wave ends
+#ifdef BSMI_STAMP
+  const unsigned long long st0 = wall_clock64();
+#endif
+  // drain the run-ahead loads; after the barrier nobody reads or writes the LDS ring any more
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+#ifdef BSMI_STAMP
+  const unsigned long long st1 = wall_clock64();
+#endif
 
   if (part) {
-    // stream-K: this workgroup multiplied only part of the tile's K range; leave the raw sums
+    // split-K: this workgroup multiplied only part of the tile's K range; leave the raw sums
     // (register order, 64 contiguous bytes per lane) for conv_fixup_kernel
 #pragma unroll
     for (int i = 0; i < FM; ++i)
@@ -283,27 +265,69 @@ __device__ __forceinline__ void conv_igemm_body(const ConvArgs& a, char* smem, i
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     return;
   }
-  // epilogue: bias (+ReLU), convert, store channels-last
+#ifdef BSMI_ABLATE_NOSTORE  // timing experiment
+  if (a.relu != 12345) return;
+#endif
+  // Epilogue: bias (+ReLU), convert, store channels-last.  A lane of the 32x32 accumulator holds
+  // 16 rows of ONE channel, so storing from registers would write 2-byte pieces (64-byte runs per
+  // row: partial cache lines, measured at ~170 GB/s).  Instead every wave transposes 16 rows of
+  // its tile at a time through a private LDS strip and writes 16 bytes per lane, whole rows of
+  // WTN channels (256-640 contiguous bytes) per few lanes.
+  constexpr int ESZ = (int)sizeof(T);
+  constexpr int PITCH = WTN * ESZ + 16;       // +16: the two lane halves (rows +4) fall on different banks
+  constexpr int CPR = WTN * ESZ / 16;         // 16-byte chunks per row
+  constexpr int NCH = 16 * CPR;               // chunks per 16-row strip
+  static_assert(NW * 16 * PITCH <= NSLOT * SLOT, "epilogue strips fit in the ring");
+  char* strip = smem + wave * (16 * PITCH);
   T* out = (T*)a.out;
+  float bv[FN];
 #pragma unroll
   for (int j = 0; j < FN; ++j) {
     const int n = n0 + wn * WTN + j * 32 + lr;
-    if (n >= a.Co) continue;
-    const float bv = a.bias[n];
+    bv[j] = n < a.Npad ? a.bias[n] : 0.f;
+  }
 #pragma unroll
-    for (int i = 0; i < FM; ++i) {
+  for (int i = 0; i < FM; ++i) {
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int m = m0 + wm * WTM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-        if (m < a.M) {
-          float v = acc[i][j][r] + bv;
+    for (int hf = 0; hf < 2; ++hf) {
+#pragma unroll
+      for (int j = 0; j < FN; ++j) {
+#pragma unroll
+        for (int rr = 0; rr < 8; ++rr) {
+          const int row = (rr & 3) + 8 * (rr >> 2) + 4 * lh;
+          float v = acc[i][j][hf * 8 + rr] + bv[j];
           if (a.relu) v = v > 0.f ? v : 0.f;
-          Elem<T>::store(out + (size_t)m * a.Co + n, v);
+          Elem<T>::store((T*)(strip + row * PITCH) + j * 32 + lr, v);
         }
       }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+      for (int k = 0; k < (NCH + 63) / 64; ++k) {
+        const int c = lane + 64 * k;
+        if (c >= NCH) break;
+        const int row = c / CPR, cc = c - row * CPR;
+        const u32x4_t v = *(const u32x4_t*)(strip + row * PITCH + cc * 16);
+        const int m = m0 + wm * WTM + i * 32 + hf * 16 + row;
+        const int n = n0 + wn * WTN + cc * (16 / ESZ);
+        if (m < a.M && n < a.Co) store_stream16(out + (size_t)m * a.Co + n, v);
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     }
   }
+#ifdef BSMI_STAMP
+  const unsigned long long st2 = wall_clock64();
+#endif
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // a persistent workgroup stages its next tile after this
+#ifdef BSMI_STAMP
+  if (tid == 0) {
+    const unsigned long long st3 = wall_clock64();
+    atomicAdd(&g_stamp[0], st1 - st0);
+    atomicAdd(&g_stamp[1], st2 - st1);
+    atomicAdd(&g_stamp[2], st3 - st2);
+    atomicAdd(&g_stamp[3], 1ull);
+    atomicAdd(&g_stamp[4], st0 - st_begin);
+  }
+#endif
 }
 
 // wave -> (weight-piece count, early/late) instantiation of the body

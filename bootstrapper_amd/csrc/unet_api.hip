@@ -16,7 +16,7 @@
 #include <memory>
 #include <vector>
 
-#include "conv_halo.h"
+#include "conv_rh.h"
 #include "conv_igemm.h"
 #include "unet_ops.h"
 
@@ -60,8 +60,8 @@ struct PackEntry {
   int phase;       // index into PackedConv::phases
 };
 
-// A phase groups the units that read one staged halo (conv_halo.hip): LONG = all kernel taps of
-// one 16-channel slice, SHORT = the residual tap of one 32-channel slice.
+// A phase groups the units of one (slot, 32-channel chunk): kind 0 = all kernel taps, kind 1 = the
+// residual tap (bookkeeping of build_entries; conv_rh.hip splits kind 0 further by z-tap).
 struct PackPhase {
   int slot, c0, kind, first_unit, nunits;
 };
@@ -101,8 +101,8 @@ struct TDesc {
 struct PlanStep {
   enum Type { INPUT, CONV, POOL, UP, HEAD } type;
   ConvArgs conv;
-  HaloArgs halo;
-  bool use_halo = false;
+  RhArgs rh;
+  bool use_rh = false;
   TileCfg tile;
   TDesc in, out;
   int f[3], o[3];
@@ -140,8 +140,9 @@ struct bsmi_unet {
   double prof_ms[5] = {0, 0, 0, 0, 0}, prof_flops[5] = {0, 0, 0, 0, 0};
   int64_t prof_launches[5] = {0, 0, 0, 0, 0};
   std::map<std::vector<int64_t>, std::unique_ptr<Plan>> plans;  // key: prec, D, H, W
-  float* sk_ws = nullptr;  // stream-K partial tiles (conv_igemm.h)
-  int sk_grid = 0;
+  float* sk_ws = nullptr;  // split-K tail partial tiles + work-queue counters (conv_igemm.h)
+  int sk_grid = 0;         // 0: not set up yet, -1: disabled
+  int sk_request = -1;     // bsmi_unet_set_persistent_grid: -1 = CU count of the device, 0 = off
 };
 
 namespace bsmi {
@@ -173,7 +174,7 @@ static void register_pass(bsmi_unet* h, const PassSite& p) {
 // K-step.  Order: for every source slot, 32-channel chunk major with the kernel taps inside (one
 // tap x 32 channels per K-step, i.e. 64 contiguous bytes per gathered row; a 16-channel tensor
 // packs two taps per K-step), then, for the last stage, the cropped 1x1x1 residual in 32-channel
-// chunks.  Each (slot, 32-channel chunk) is also one "phase" of the halo kernel (conv_halo.hip):
+// chunks.  Each (slot, 32-channel chunk) is also one PackPhase:
 // LONG = all kernel taps of the chunk, SHORT = its residual tap.
 static void build_entries(const PassSite& p, int ci, int prec, std::vector<PackEntry>& out,
                           std::vector<PackPhase>* phases_out = nullptr) {
@@ -187,13 +188,32 @@ static void build_entries(const PassSite& p, int ci, int prec, std::vector<PackE
   };
   auto add_taps = [&](int slot, const int* k, int cin_base, int creal) {
     const int cpad = round_up(creal, kChanPad);
+    if (cpad == SUB) {
+      // a voxel is one 32-byte unit: a K-step takes two x-adjacent taps (dx, dx+1), which are 64
+      // contiguous bytes of the channels-last tensor (conv_rh.hip reads them as one halo row)
+      PackPhase ph{slot, 0, 0, (int)out.size(), 0};
+      for (int z = 0; z < k[0]; ++z)
+        for (int y = 0; y < k[1]; ++y)
+          for (int x = 0; x < k[2]; x += kUnitsPerStep)
+            for (int j = 0; j < kUnitsPerStep; ++j) {
+              if (x + j < k[2])
+                out.push_back(PackEntry{slot, z, y, x + j, 0, 0, (z * k[1] + y) * k[2] + x + j, cin_base, creal, false, (int)phases.size()});
+              else
+                out.push_back(PackEntry{slot, 0, 0, 0, 0, 0, 0, 0, 0, true, (int)phases.size()});
+            }
+      close_phase(ph);
+      return;
+    }
     for (int c32 = 0; c32 < cpad; c32 += kUnitsPerStep * SUB) {
       PackPhase ph{slot, c32, 0, (int)out.size(), 0};
       for (int z = 0; z < k[0]; ++z)
         for (int y = 0; y < k[1]; ++y)
-          for (int x = 0; x < k[2]; ++x)
+          for (int x = 0; x < k[2]; ++x) {
             for (int c0 = c32; c0 < std::min(cpad, c32 + kUnitsPerStep * SUB); c0 += SUB)
               out.push_back(PackEntry{slot, z, y, x, c0, 0, (z * k[1] + y) * k[2] + x, cin_base, creal, false, (int)phases.size()});
+            while ((out.size() - ph.first_unit) % kUnitsPerStep)  // half chunk: the K-step's second unit is padding
+              out.push_back(PackEntry{slot, 0, 0, 0, 0, 0, 0, 0, 0, true, (int)phases.size()});
+          }
       close_phase(ph);
     }
   };
@@ -290,132 +310,121 @@ struct Planner {
     if (bytes >= ((size_t)1 << 31))
       BSMI_FAIL(BSMI_ERR_INVALID, "activation tensor of %zu bytes exceeds the 31-bit byte offsets of the conv kernel", bytes);
     if (dry) return BSMI_OK;
-    BSMI_HIP(hipMalloc(&t.ptr, bytes));
+    // slack: the raster-halo kernel stages whole rows of the input raster, and the rows it drops
+    // (xx >= Wo, yy >= Ho) may lie a few lines past the end of a cropped source tensor
+    const size_t slack = (size_t)8 * t.W * t.Cpad * esize(prec) + 4096;
+    BSMI_HIP(hipMalloc(&t.ptr, bytes + slack));
+    BSMI_HIP(hipMemsetAsync((char*)t.ptr + bytes, 0, slack, nullptr));
     plan->allocs.push_back(t.ptr);
     return BSMI_OK;
   }
 
-  // Halo-tiled launch of one ConvPass stage (conv_halo.hip) when an output box whose halo fits the
-  // LDS halo buffer exists; otherwise st.use_halo stays false (gather kernel, conv_igemm.hip).
-  int plan_halo(const PassSite& p, int ci, const PackedConv& pc, const TDesc* slots, const int (*so)[3], int nsl,
-                const TDesc& o, PlanStep& st) {
-    st.use_halo = false;
-    static const bool enabled = getenv("BSMI_USE_HALO") != nullptr;  // opt-in while it is being tuned
-    if (!enabled || pc.phases.empty() || st.tile == TILE_256x320) return BSMI_OK;
+  // Raster-halo launch of one ConvPass stage (conv_rh.hip) when the tile's halo buffer holds
+  // 256 + (ky-1)*Win + (kx-1) rows; otherwise st.use_rh stays false (gather kernel, conv_igemm.hip).
+  int plan_rh(const PassSite& p, int ci, const PackedConv& pc, const TDesc* slots, const int (*so)[3], int nsl,
+              const TDesc& o, PlanStep& st) {
+    st.use_rh = false;
+    // opt-in (BSMI_USE_RH=1): parity-verified, but on the 128^3 block only the 360->60 channel layer gains
+    // (1.38 -> 1.04 ms); the rows it computes and drops cost the small-plane layers 8-17 %
+    static const bool enabled = [] { const char* e = getenv("BSMI_USE_RH"); return e && e[0] == '1'; }();
     const int* k = p.k[ci];
-    int box[3], pitch[2];
-    const int wm = st.tile == TILE_256x256 ? 2 : 4;
-    if (!halo_choose_geometry(o.D, o.H, o.W, k, wm, box, pitch)) return BSMI_OK;
+    const int Hin = o.H + k[1] - 1, Win = o.W + k[2] - 1;
+    if (!enabled || !two_waves_per_simd() || !rh_supported(st.tile, Win, k[1], k[2])) return BSMI_OK;
     const int64_t es = esize(prec);
-    HaloArgs& ha = st.halo;
-    memset(&ha, 0, sizeof ha);
-    int crop[3] = {0, 0, 0};
-    for (int i = 0; i < p.nconv; ++i)
-      for (int d = 0; d < 3; ++d) crop[d] += p.k[i][d] - 1;
-    for (int sl = 0; sl < kMaxConvTensors; ++sl) {
-      const int q = sl < nsl ? sl : 0;
-      const TDesc& t = slots[q];
-      HaloSrc& hs = ha.t[sl];
-      hs.base = (uint64_t)(uintptr_t)t.ptr;
-      hs.sz = (int32_t)((int64_t)t.H * t.W * t.Cpad * es);
-      hs.sy = (int32_t)((int64_t)t.W * t.Cpad * es);
-      hs.sx = (int32_t)((int64_t)t.Cpad * es);
-      hs.D = t.D; hs.H = t.H; hs.W = t.W;
-      hs.oz = so[q][0]; hs.oy = so[q][1]; hs.ox = so[q][2];
-      hs.rz = so[q][0] + crop[0] / 2; hs.ry = so[q][1] + crop[1] / 2; hs.rx = so[q][2] + crop[2] / 2;
-    }
-    auto magic = [](int d) -> uint32_t { return d <= 1 ? 0u : (uint32_t)((((uint64_t)1 << 32) + d - 1) / d); };
-    ha.TZ = box[0]; ha.TY = box[1]; ha.TX = box[2];
-    ha.NBZ = ceil_div(o.D, box[0]); ha.NBY = ceil_div(o.H, box[1]); ha.NBX = ceil_div(o.W, box[2]);
-    ha.HZ = box[0] + k[0] - 1; ha.HY = box[1] + k[1] - 1; ha.HX = box[2] + k[2] - 1;
-    ha.PZ = pitch[0]; ha.PY = pitch[1];
-    ha.mPZ = magic(ha.PZ); ha.mPY = magic(ha.PY); ha.mTX = magic(ha.TX); ha.mTYX = magic(ha.TY * ha.TX);
-
-    const int NSLOT = halo_ring_slots(st.tile);
-    const int D = NSLOT - 2;
-    const int BI = round_up(tile_bn(st.tile), 64) / 16 / 4;
-    const int HL = kHaloLongInstr, HS = kHaloShortInstr;
-    const size_t S = pc.entries.size() / kUnitsPerStep, P = pc.phases.size();
-    std::vector<HaloPhase> phases(P);
-    std::vector<HaloStep> steps(S);
-    std::vector<int> phase_of_step(S), last_of_phase(P, -1), first_of_phase(P, -1);
-    for (size_t ph = 0; ph < P; ++ph) {
-      const PackPhase& pp = pc.phases[ph];
-      phases[ph] = HaloPhase{pp.slot, (int32_t)(pp.c0 * es), pp.kind, (int32_t)((ph & 1) * kHaloBufBytes)};
-      first_of_phase[ph] = pp.first_unit / kUnitsPerStep;
-      last_of_phase[ph] = (pp.first_unit + pp.nunits) / kUnitsPerStep - 1;
-      for (int u = pp.first_unit; u < pp.first_unit + pp.nunits; u += kUnitsPerStep) {
-        const size_t sidx = u / kUnitsPerStep;
-        phase_of_step[sidx] = (int)ph;
-        HaloStep hs;
-        memset(&hs, 0, sizeof hs);
-        hs.bufbase = phases[ph].bufbase;
-        hs.issue = -1;
-        int cb[2] = {0, 0};
-        for (int j = 0; j < kUnitsPerStep; ++j) {
-          const PackEntry& e = pc.entries[u + j];
-          if (e.dummy) continue;
-          cb[j] = (int)((e.c0 - pp.c0) * es / 16);
-          if (pp.kind == 0) hs.trow[j] = e.dz * ha.PZ + e.dy * ha.PY + e.dx;
-        }
-        hs.cb = cb[0] | (cb[1] << 8) | (pp.kind << 16);
-        steps[sidx] = hs;
+    const int SUB = sube(prec);
+    const size_t nsteps = pc.entries.size() / kUnitsPerStep;
+    std::vector<RhStep> steps(nsteps);
+    std::vector<RhPhase> phases;
+    std::vector<int> first_step;  // per phase
+    // phase key of the previous K-step
+    int pslot = -1, pc32 = -1, pz = -1, pkind = -1;
+    for (size_t s = 0; s < nsteps; ++s) {
+      const PackEntry& e0 = pc.entries[kUnitsPerStep * s];
+      const PackEntry& e1 = pc.entries[kUnitsPerStep * s + 1];
+      if (e0.dummy) BSMI_FAIL(BSMI_ERR_STATE, "raster-halo plan: K-step %zu starts with a padding unit", s);
+      const TDesc& t = slots[e0.slot];
+      const int c32 = e0.c0 / (kUnitsPerStep * SUB) * (kUnitsPerStep * SUB);
+      const int kind = e0.wsrc;
+      if (!e1.dummy) {
+        const bool same_tap = e1.dz == e0.dz && e1.dy == e0.dy && e1.dx == e0.dx && e1.c0 == e0.c0 + SUB && e1.slot == e0.slot;
+        const bool x_pair = t.Cpad == SUB && e1.slot == e0.slot && e1.dz == e0.dz && e1.dy == e0.dy && e1.dx == e0.dx + 1 &&
+                            e1.c0 == e0.c0 && kind == 0 && e1.wsrc == 0;
+        if (!same_tap && !x_pair) return BSMI_OK;  // unit order the halo rows cannot serve: gather kernel
       }
-    }
-    // issue points and counted waits: simulate the wave's in-order vector-memory queue
-    struct Op { int kind, id, count; };  // kind 0 = weights of K-step id, 1 = halo of phase id
-    std::vector<Op> queue;
-    queue.push_back(Op{0, NSLOT - 1, BI});  // after the prologue only this K-step's weights are in flight
-    const int variants[7][2] = {{D * BI + HL, 1}, {D * BI + HS, 2}, {D * BI, 0}, {(D - 1) * BI + HL, 6},
-                                {(D - 1) * BI + HS, 5}, {(D - 1) * BI, 3}, {0, 4}};
-    for (size_t h = 0; h < S; ++h) {
-      int need_pos = -1;
-      auto require = [&](int kind, int id) {
-        for (int i = (int)queue.size() - 1; i >= 0; --i)
-          if (queue[i].kind == kind && queue[i].id == id) { need_pos = std::max(need_pos, i); return; }
-      };
-      if (h + 1 < S) {
-        require(0, (int)h + 1);
-        const int q = phase_of_step[h + 1];
-        if (first_of_phase[q] == (int)h + 1) require(1, q);
+      if (e0.slot != pslot || c32 != pc32 || e0.dz != pz || kind != pkind) {
+        RhPhase ph;
+        ph.tensor = e0.slot;
+        const int oz = so[e0.slot][0] + e0.dz;
+        const int oy = so[e0.slot][1] + (kind ? e0.dy : 0);
+        const int ox = so[e0.slot][2] + (kind ? e0.dx : 0);
+        ph.delta = (int32_t)(((((int64_t)oz * t.H + oy) * t.W + ox) * t.Cpad + c32) * es);
+        ph.buf = (int32_t)(phases.size() & 1);
+        ph.issue_step = -1;
+        phases.push_back(ph);
+        first_step.push_back((int)s);
+        pslot = e0.slot; pc32 = c32; pz = e0.dz; pkind = kind;
       }
-      int n_ok = 0;
-      for (int i = need_pos + 1; i < (int)queue.size(); ++i) n_ok += queue[i].count;
-      int kind = 4, best = -1;
-      for (auto& v : variants)
-        if (v[0] <= n_ok && v[0] > best) { best = v[0]; kind = v[1]; }
-      steps[h].wait = kind;
-      int keep = 0, cut = (int)queue.size();
-      while (cut > 0 && keep + queue[cut - 1].count <= best) keep += queue[--cut].count;
-      queue.erase(queue.begin(), queue.begin() + cut);
-      const int ph = phase_of_step[h];
-      if (last_of_phase[ph] == (int)h && (size_t)ph + 2 < P) {
-        steps[h].issue = ph + 2;
-        queue.push_back(Op{1, ph + 2, phases[ph + 2].kind == 0 ? HL : HS});
-      }
-      queue.push_back(Op{0, (int)h + NSLOT, BI});
+      RhStep& r = steps[s];
+      r.rowoff = kind ? 0 : e0.dy * Win + e0.dx;
+      r.buf_phase = (int32_t)(((phases.size() - 1) & 1) | ((phases.size() - 1) << 8));
+      r.wait = 0;
+      r.issue = -1;
     }
-    if (getenv("BSMI_HALO_DEBUG")) {
-      int hist[7] = {0, 0, 0, 0, 0, 0, 0};
-      for (auto& st2 : steps) hist[st2.wait]++;
-      fprintf(stderr, "[halo] %s.%d out (%d,%d,%d) box (%d,%d,%d) halo (%d,%d,%d) pitch (%d,%d) boxes %d steps %zu phases %zu waits D:%d D+HL:%d D+HS:%d D-1:%d ALL:%d D-1+HS:%d D-1+HL:%d\n",
-              p.prefix.c_str(), ci, o.D, o.H, o.W, box[0], box[1], box[2], ha.HZ, ha.HY, ha.HX, ha.PZ, ha.PY,
-              ha.NBZ * ha.NBY * ha.NBX, S, P, hist[0], hist[1], hist[2], hist[3], hist[4], hist[5], hist[6]);
+    const int np = (int)phases.size();
+    // the halo of phase p >= 2 is staged with the weights of K-step issue_step + 4, as soon as
+    // phase p-2 (same buffer) has been read; phases 0 and 1 in the prologue
+    for (int q = 2; q < np; ++q) {
+      const int is = first_step[q - 1] - 1;
+      phases[q].issue_step = is;
+      if (steps[is].issue >= 0) BSMI_FAIL(BSMI_ERR_STATE, "raster-halo plan: two halos on one staging slot");
+      steps[is].issue = q;
     }
-    HaloStep* dsteps = nullptr;
-    HaloPhase* dphases = nullptr;
-    BSMI_HIP(hipMalloc((void**)&dsteps, steps.size() * sizeof(HaloStep)));
+    // in-order queue of one wave: H0 [H1] W0 W1 W2 W3 {[H(issue[h])] W(h+4)}...
+    std::vector<int> posW(nsteps + 8, 0), posH(np, 0);
+    std::vector<char> isH;  // per queue position
+    auto push = [&](bool halo) { isH.push_back(halo ? 1 : 0); return (int)isH.size() - 1; };
+    posH[0] = push(true);
+    if (np > 1) posH[1] = push(true);
+    for (int w = 0; w < 4; ++w) posW[w] = push(false);
+    for (size_t hh = 0; hh < nsteps; ++hh) {
+      if (steps[hh].issue >= 0) posH[steps[hh].issue] = push(true);
+      posW[hh + 4] = push(false);
+    }
+    for (size_t hh = 0; hh < nsteps; ++hh) {
+      const int upto = posW[hh + 3];
+      int need = posW[hh + 1];
+      if (hh + 1 < nsteps) need = std::max(need, posH[steps[hh + 1].buf_phase >> 8]);
+      if (need > upto) BSMI_FAIL(BSMI_ERR_STATE, "raster-halo plan: halo of K-step %zu staged too late", hh + 1);
+      int aw = 0, bh = 0;
+      for (int q = need + 1; q <= upto; ++q) (isH[q] ? bh : aw)++;
+      if (aw > 2 || bh > 2) BSMI_FAIL(BSMI_ERR_STATE, "raster-halo plan: wait code out of range");
+      steps[hh].wait = aw * 3 + bh;
+    }
+    RhArgs& a = st.rh;
+    memset(&a, 0, sizeof a);
+    for (int sl = 0; sl < kMaxConvTensors; ++sl) a.t[sl] = st.conv.t[sl];
+    RhStep* dsteps = nullptr;
+    RhPhase* dphases = nullptr;
+    BSMI_HIP(hipMalloc((void**)&dsteps, steps.size() * sizeof(RhStep)));
     plan->allocs.push_back(dsteps);
-    BSMI_HIP(hipMalloc((void**)&dphases, phases.size() * sizeof(HaloPhase)));
+    BSMI_HIP(hipMalloc((void**)&dphases, phases.size() * sizeof(RhPhase)));
     plan->allocs.push_back(dphases);
-    BSMI_HIP(hipMemcpy(dsteps, steps.data(), steps.size() * sizeof(HaloStep), hipMemcpyHostToDevice));
-    BSMI_HIP(hipMemcpy(dphases, phases.data(), phases.size() * sizeof(HaloPhase), hipMemcpyHostToDevice));
-    ha.steps = dsteps; ha.phases = dphases;
-    ha.nsteps = (int)S; ha.nphases = (int)P;
-    ha.w = pc.w; ha.bias = pc.bias; ha.out = o.ptr;
-    ha.Do = o.D; ha.Ho = o.H; ha.Wo = o.W; ha.Co = o.Cpad;
-    ha.Npad = pc.Npad; ha.relu = 1;
-    st.use_halo = true;
+    BSMI_HIP(hipMemcpy(dsteps, steps.data(), steps.size() * sizeof(RhStep), hipMemcpyHostToDevice));
+    BSMI_HIP(hipMemcpy(dphases, phases.data(), phases.size() * sizeof(RhPhase), hipMemcpyHostToDevice));
+    a.steps = dsteps;
+    a.phases = dphases;
+    a.nsteps = (int)nsteps;
+    a.nphases = np;
+    a.w = pc.w;
+    a.bias = pc.bias;
+    a.out = o.ptr;
+    a.Do = o.D; a.Ho = o.H; a.Wo = o.W; a.Co = o.Cpad;
+    a.Hin = Hin; a.Win = Win;
+    a.Q = o.D * Hin * Win;
+    a.Npad = pc.Npad;
+    a.relu = 1;
+    st.use_rh = true;
+    (void)nsl;
     return BSMI_OK;
   }
 
@@ -515,8 +524,11 @@ struct Planner {
         a.Npad = pc.Npad;
         a.relu = 1;  // trunk activation is ReLU (model.py passes activation default "ReLU")
         st.flops = 2.0 * M * p.cout * kreal;
-        rc = plan_halo(p, ci, pc, slots, so, nsl, o, st);
+        rc = plan_rh(p, ci, pc, slots, so, nsl, o, st);
         if (rc) return rc;
+        if (getenv("BSMI_PLAN_DEBUG"))
+          fprintf(stderr, "[bsmi plan] %s conv %d: out (%d,%d,%d)x%d tile BN=%d K-steps %d %s\n", p.prefix.c_str(), ci, o.D, o.H, o.W,
+                  p.cout, tile_bn(st.tile), a.nsteps, st.use_rh ? "raster-halo" : "gather");
         plan->steps.push_back(st);
       }
       cur = o;
@@ -743,6 +755,36 @@ int bsmi_unet_create(const bsmi_unet_config* cfg, int device, bsmi_unet** out) {
   return BSMI_OK;
 }
 
+int bsmi_stream_create_cu_mask(int device, const uint32_t* cu_mask, int n_words, void** stream_out) {
+  if (!cu_mask || n_words < 1 || !stream_out) BSMI_FAIL(BSMI_ERR_INVALID, "null argument");
+  BSMI_HIP(hipSetDevice(device));
+  hipStream_t s = nullptr;
+  BSMI_HIP(hipExtStreamCreateWithCUMask(&s, (uint32_t)n_words, cu_mask));
+  *stream_out = (void*)s;
+  return BSMI_OK;
+}
+
+int bsmi_stream_destroy(int device, void* stream) {
+  if (!stream) return BSMI_OK;
+  BSMI_HIP(hipSetDevice(device));
+  BSMI_HIP(hipStreamDestroy((hipStream_t)stream));
+  return BSMI_OK;
+}
+
+int bsmi_unet_set_persistent_grid(bsmi_unet* h, int n_cus) {
+  if (!h) BSMI_FAIL(BSMI_ERR_INVALID, "null handle");
+  if (n_cus < -1) BSMI_FAIL(BSMI_ERR_INVALID, "n_cus must be >= -1");
+  BSMI_HIP(hipSetDevice(h->device));
+  if (h->sk_ws) {
+    BSMI_HIP(hipDeviceSynchronize());
+    BSMI_HIP(hipFree(h->sk_ws));
+    h->sk_ws = nullptr;
+  }
+  h->sk_grid = 0;
+  h->sk_request = n_cus < 0 ? -1 : n_cus / 8 * 8;
+  return BSMI_OK;
+}
+
 int bsmi_unet_destroy(bsmi_unet* h) {
   if (!h) return BSMI_OK;
   (void)hipSetDevice(h->device);
@@ -901,12 +943,12 @@ int bsmi_unet_forward(bsmi_unet* h, int precision, const void* raw_dev, int raw_
   }
   if (!h->sk_grid) {
     const char* e = getenv("BSMI_STREAMK");
-    if (e && e[0] == '0') {
+    if ((e && e[0] == '0') || h->sk_request == 0) {
       h->sk_grid = -1;
     } else {
       hipDeviceProp_t prop;
       BSMI_HIP(hipGetDeviceProperties(&prop, h->device));
-      h->sk_grid = prop.multiProcessorCount / 8 * 8;
+      h->sk_grid = h->sk_request >= 0 ? h->sk_request : prop.multiProcessorCount / 8 * 8;
       if (const char* g = getenv("BSMI_SK_GRID")) h->sk_grid = std::max(8, atoi(g) / 8 * 8);  // tests: force cuts on small nets
       BSMI_HIP(hipMalloc((void**)&h->sk_ws, stream_k_ws_bytes(h->sk_grid)));
       BSMI_HIP(hipMemset((char*)h->sk_ws + stream_k_ws_bytes(h->sk_grid) - 64, 0, 64));
@@ -921,7 +963,8 @@ int bsmi_unet_forward(bsmi_unet* h, int precision, const void* raw_dev, int raw_
                                (size_t)st.out.D * st.out.H * st.out.W, s);
         break;
       case PlanStep::CONV:
-        rc = st.use_halo ? launch_conv_halo(st.halo, precision, st.tile, s) : launch_conv_igemm(st.conv, precision, st.tile, s, h->sk_ws, h->sk_grid);
+        rc = st.use_rh ? launch_conv_rh(st.rh, precision, st.tile, s, h->sk_ws, h->sk_grid)
+                       : launch_conv_igemm(st.conv, precision, st.tile, s, h->sk_ws, h->sk_grid);
         break;
       case PlanStep::POOL:
         rc = launch_maxpool(precision, st.in.ptr, st.out.ptr, st.in.D, st.in.H, st.in.W, st.in.Cpad,

@@ -138,6 +138,11 @@ class Model:
     def eval(self):
         return self
 
+    def set_persistent_grid(self, n_cus):
+        """CUs available to the stream `forward` runs on (-1: the whole device, 0: no persistent launches)."""
+        check(lib.bsmi_unet_set_persistent_grid(self._h, int(n_cus)))
+        return self
+
     # -- shapes ------------------------------------------------------------------------
     def output_shape(self, in_shape):
         out = (C.c_int64 * 3)()

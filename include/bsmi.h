@@ -97,6 +97,17 @@ int bsmi_unet_forward(bsmi_unet *h, int precision, const void *raw_dev, int raw_
                       const int64_t in_shape[3], float *const *out_f32_dev,
                       uint8_t *const *out_u8_dev, void *stream);
 
+/* Number of CUs the stream bsmi_unet_forward is called on may use (a multiple of 8; -1 restores the
+ * default = all CUs of the device, 0 disables the persistent launches).  The big-tile conv layers run
+ * as that many persistent workgroups (conv_igemm.hip); set it when the stream carries a CU mask. */
+int bsmi_unet_set_persistent_grid(bsmi_unet *h, int n_cus);
+
+/* HIP stream restricted to the CUs of `cu_mask` (hipExtStreamCreateWithCUMask; on MI355X bit i selects a
+ * CU of XCD i % 8, so the first 8k bits give k CUs in every XCD).  The block pipeline keeps its
+ * latency-bound segmentation kernels and the U-Net on disjoint CU sets this way. */
+int bsmi_stream_create_cu_mask(int device, const uint32_t *cu_mask, int n_words, void **stream_out);
+int bsmi_stream_destroy(int device, void *stream);
+
 /* Per-launch timing of the forward pass with HIP events recorded on the caller's stream
  * (bench.py's roofline leg).  After enabling, every bsmi_unet_forward brackets each launch
  * with events; bsmi_unet_profile_read synchronises on them and returns, for the last

@@ -111,26 +111,17 @@ def test_full_block_blockwise_stages_bit_exact(full_block):
     assert np.array_equal(scores.cpu().numpy().view(np.uint32), s_ref.view(np.uint32))
 
 
-def test_halo_kernel_parity_in_subprocess(golden_dir):
-    """conv_halo.hip is opt-in through BSMI_USE_HALO (read once per process): run the golden
-    comparison in a child process with the variable set."""
-    code = r'''
-import json, os, sys, numpy as np, torch
-sys.path.insert(0, %r)
-from bootstrapper_amd.unet import Model
-from oracle import unet_ref as R
-d = np.load(os.path.join(%r, "unet_affs_f3i3.npz"))
-sd = {k[2:]: d[k] for k in d.files if k.startswith("w:")}
-meta = json.loads(bytes(d["config"]).decode())
-nc = {"in_channels": 1, "num_fmaps": 3, "fmap_inc_factor": 3, "downsample_factors": [[1, 2, 2]] * 3,
-      "kernel_size_down": [[[3, 3, 3], [3, 3, 3]]] * 4, "kernel_size_up": [[[3, 3, 3], [3, 3, 3]]] * 3,
-      "outputs": {"3d_affs": {"dims": 6}}}
-m = Model(nc, precision="f32").load_state_dict(sd)
-y = m(torch.from_numpy(R.normalize_raw(d["raw_u8"]))[None, None].cuda())[0].cpu().numpy()
-err = float(np.abs(y - d["out0"]).max())
-print("halo f32 err", err)
-assert err < 1e-4
-''' % (ROOT, golden_dir)
-    env = dict(os.environ, BSMI_USE_HALO="1")
-    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
-    assert r.returncode == 0, r.stdout + r.stderr
+@pytest.mark.parametrize("variant,env", [
+    ("raster-halo kernel", {"BSMI_USE_RH": "1"}),
+    ("raster-halo kernel, persistent split-K tail", {"BSMI_USE_RH": "1", "BSMI_SK_GRID": "8", "BSMI_TILE_EFF": "0.01,0.01,0.01,1,0.01"}),
+    ("persistent split-K tail, 256x256 tiles", {"BSMI_SK_GRID": "8", "BSMI_TILE_EFF": "0.01,0.01,0.01,1,0.01"}),
+    ("persistent split-K tail, 256x320 tiles", {"BSMI_SK_GRID": "16", "BSMI_TILE_EFF": "0.01,0.01,0.01,0.01,1"}),
+    ("4-wave kernels", {"BSMI_WAVES8": "0"}),
+])
+def test_conv_kernel_variants_in_subprocess(variant, env):
+    """The conv kernel variants that the golden nets do not reach by themselves (they are chosen by layer
+    size, or opt-in) are selected through environment variables read once per process: run the whole U-Net
+    parity module in a child process per variant."""
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(ROOT, "tests", "test_unet_gpu.py"), "-x", "-q"],
+                       env=dict(os.environ, **env), capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert r.returncode == 0, f"{variant}:\n" + r.stdout[-3000:] + r.stderr[-2000:]
