@@ -7,6 +7,12 @@ namespace bsmi {
 typedef __attribute__((__vector_size__(8 * sizeof(__bf16)))) __bf16 bf16x8_t;
 typedef __attribute__((__vector_size__(16 * sizeof(float)))) float f32x16_t;
 typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
+typedef float f32x4_t __attribute__((ext_vector_type(4)));
+
+// chunk-swizzle key of the 16 x 16 x 32 fragment reads: a ds_read_b128 lane group covers rows 0-3 and
+// 12-15 at one 16-byte chunk and rows 4-11 at the next; XOR keys {0, 2, 3, 1} per 4-row group keep
+// the 16 lanes of every group on 16 different bank quads
+__device__ __forceinline__ int swz16(int g) { return (0x78 >> (2 * g)) & 3; }
 
 struct bf16_elem {
   uint16_t v;

@@ -17,6 +17,7 @@
 
 #include <cstdio>
 #include <cstdlib>
+#include <type_traits>
 
 namespace bsmi {
 
@@ -330,28 +331,307 @@ __device__ __forceinline__ void conv_igemm_body(const ConvArgs& a, char* smem, i
 #endif
 }
 
-// wave -> (weight-piece count, early/late) instantiation of the body
-template <typename T, int BM, int BN, int WM, int WN>
+template <int BM, int BN, int WM, int WN, int B_INSTR, bool LATE>
+__device__ __forceinline__ void conv_igemm_body16(const ConvArgs& a, char* smem, int tile, int s0, int s1, float* part) {
+  constexpr int NW = WM * WN;
+  static_assert(NW == 4 || NW == 8, "one or two waves per SIMD");
+  constexpr int ROWB = kStepRowBytes;
+  constexpr int NSLOT = 4;
+  constexpr int WTM = BM / WM, WTN = BN / WN;
+  using T = bf16_elem;
+  constexpr int FM = WTM / 16, FN = WTN / 16;  // 16 x 16 accumulator fragments
+  constexpr int NH0 = FN / 2, NH1 = FN - NH0;   // the two MFMA groups of a K-step split the B fragments
+  constexpr int A_INSTR = BM / 16 / NW;  // LDS-DMA instructions per wave per K-step
+  constexpr int G = A_INSTR + B_INSTR;
+  constexpr int SLOT = (BM + BN) * ROWB;
+  static_assert(BM % (16 * NW) == 0, "tile/wave mismatch");
+  static_assert(WTM % 16 == 0 && WTN % 32 == 0, "wave tile shape");
+  static_assert(3 * G <= 63, "vmcnt range");
+
+#ifdef BSMI_STAMP
+  const unsigned long long st_begin = wall_clock64();
+#endif
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave / WN, wn = wave % WN;
+  const cint_ptr_t steps = (cint_ptr_t)a.steps;  // 4 dwords per K-step
+  const int nsteps = a.nsteps;
+
+  // the K-steps [s0, s1) of output tile `tile`; part != nullptr: raw f32 partial sums instead of the epilogue
+  const int ntn = a.Npad / BN;
+  const int nloc = s1 - s0;
+  const int tile_m = tile / ntn, tile_n = tile - tile_m * ntn;
+  const int m0 = tile_m * BM, n0 = tile_n * BN;
+
+  // rows staged by this lane: row(i) = (i*NW + wave)*16 + (lane>>2); the swizzle key
+  // (row>>2)&3 = (lane>>4)&3 does not depend on i or on the wave.
+  const int lrow = lane >> 2, lchunk = lane & 3;
+  const int skey = swz16((lane >> 4) & 3);
+  const int g = lchunk ^ skey;             // source chunk that lands in LDS slot lchunk
+  const bool unit1 = (g >> 1) != 0;        // which of the K-step's 2 units this lane fetches
+  const uint32_t hoff = (uint32_t)((g & 1) << 4);
+  // byte offset of row(i)'s output voxel inside each source tensor (three named arrays: a
+  // runtime-indexed array would live in scratch and its reload would drain vmcnt every K-step)
+  static_assert(kMaxConvTensors == 3, "three source slots");
+  uint32_t ro0[A_INSTR], ro1[A_INSTR], ro2[A_INSTR];
+#pragma unroll
+  for (int i = 0; i < A_INSTR; ++i) {
+    const int row = (i * NW + wave) * 16 + lrow;
+    int m = m0 + row;
+    m = m < a.M ? m : a.M - 1;
+    const int x = m % a.Wo;
+    const int zy = m / a.Wo;
+    const int y = zy % a.Ho, z = zy / a.Ho;
+    ro0[i] = (uint32_t)(z * a.t[0].sz + y * a.t[0].sy + x * a.t[0].sx);
+    ro1[i] = (uint32_t)(z * a.t[1].sz + y * a.t[1].sy + x * a.t[1].sx);
+    ro2[i] = (uint32_t)(z * a.t[2].sz + y * a.t[2].sy + x * a.t[2].sx);
+  }
+  const uint64_t base0 = a.t[0].base, base1 = a.t[1].base, base2 = a.t[2].base;
+  const uint32_t offb = (uint32_t)((n0 + wave * 16 + lrow) * ROWB + ((lchunk ^ skey) << 4));
+  const size_t wstep = (size_t)a.Npad * ROWB;
+
+  f32x4_t acc[FM][FN];
+#pragma unroll
+  for (int i = 0; i < FM; ++i)
+#pragma unroll
+    for (int j = 0; j < FN; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) acc[i][j][r] = 0.f;
+
+  // descriptor of K-step h (clamped), as three scalars
+  struct Desc { int t, d0, d1; };
+  auto fetch = [&](int h) -> Desc {  // h: K-step relative to s0
+    const int ha = s0 + h;
+    const cint_ptr_t d = steps + (ha < nsteps ? ha : nsteps - 1) * 4;
+    return Desc{d[0], d[1], d[2]};
+  };
+  // Issue the LDS-DMA loads of K-step h (descriptor ds) into ring slot h & 3.  Branch free, so
+  // that the whole K-loop body is one scheduling region; h past the end re-loads the last K-step
+  // into a slot nobody reads any more.
+  auto issue = [&](int h, const Desc& ds) {
+#ifdef BSMI_ABLATE_NOLOAD  // timing experiment: multiply whatever is in LDS
+    if (h > 3) return;
+#endif
+    const bool t1 = ds.t == 1, t2 = ds.t == 2;
+    const uint64_t tbase = t1 ? base1 : (t2 ? base2 : base0);
+    const uint32_t lofs = (uint32_t)(unit1 ? ds.d1 : ds.d0) + hoff;
+    const gptr_t abase = (gptr_t)tbase;
+    const gptr_t wbase = (gptr_t)a.w + (size_t)(s0 + h < nsteps ? s0 + h : nsteps - 1) * wstep;
+    const lptr_t la = (lptr_t)(smem + (h & (NSLOT - 1)) * SLOT);
+    const lptr_t lb = la + BM * ROWB;
+#pragma unroll
+    for (int i = 0; i < A_INSTR; ++i) {
+      const uint32_t ro = t1 ? ro1[i] : (t2 ? ro2[i] : ro0[i]);
+      __builtin_amdgcn_global_load_lds(abase + (size_t)(ro + lofs), la + (i * NW + wave) * 1024, 16, 0, 0);
+    }
+#pragma unroll
+    for (int i = 0; i < B_INSTR; ++i)
+      __builtin_amdgcn_global_load_lds(wbase + (size_t)i * NW * 16 * ROWB + offb, lb + (i * NW + wave) * 1024, 16, 0, 0);
+  };
+
+  // v_mfma_f32_16x16x32_bf16: lane l supplies row (l & 15), K bytes 16 * (l >> 4) .. +15 of the 64-byte
+  // K-step row for A and for B, and receives rows 4 * (l >> 4) + r, column (l & 15) of the 16 x 16 block
+  const int lr = lane & 15, lq = lane >> 4;
+  uint32_t aoff[FM], boff[FN];  // loop-invariant LDS offsets of this lane's fragment pieces
+#pragma unroll
+  for (int i = 0; i < FM; ++i) {
+    const int row = wm * WTM + i * 16 + lr;
+    aoff[i] = row * ROWB + ((lq ^ swz16((row >> 2) & 3)) << 4);
+  }
+#pragma unroll
+  for (int j = 0; j < FN; ++j) {
+    const int row = wn * WTN + j * 16 + lr;
+    boff[j] = BM * ROWB + row * ROWB + ((lq ^ swz16((row >> 2) & 3)) << 4);
+  }
+  // A is used by both MFMA groups of its K-step, so the next K-step's A goes to the other buffer
+  // (the K loop is unrolled by two to keep every register index a constant); the B halves alternate
+  u32x4_t fa[2][FM], fb[2][NH1];
+#define LOAD_A(st_, buf_) _Pragma("unroll") for (int i = 0; i < FM; ++i) fa[buf_][i] = *(const u32x4_t*)((st_) + aoff[i])
+#define LOAD_B0(st_) _Pragma("unroll") for (int j = 0; j < NH0; ++j) fb[0][j] = *(const u32x4_t*)((st_) + boff[j])
+#define LOAD_B1(st_) _Pragma("unroll") for (int j = 0; j < NH1; ++j) fb[1][j] = *(const u32x4_t*)((st_) + boff[NH0 + j])
+#define MMA0(buf_) _Pragma("unroll") for (int i = 0; i < FM; ++i) _Pragma("unroll") for (int j = 0; j < NH0; ++j) \
+    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, fa[buf_][i]), __builtin_bit_cast(bf16x8_t, fb[0][j]), acc[i][j], 0, 0, 0)
+#define MMA1(buf_) _Pragma("unroll") for (int i = 0; i < FM; ++i) _Pragma("unroll") for (int j = 0; j < NH1; ++j) \
+    acc[i][NH0 + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, fa[buf_][i]), __builtin_bit_cast(bf16x8_t, fb[1][j]), acc[i][NH0 + j], 0, 0, 0)
+
+  // prologue: K-steps 0..2 in flight, wait for K-step 0
+  issue(0, fetch(0));
+  issue(1, fetch(1));
+  issue(2, fetch(2));
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * G) : "memory");
+  __builtin_amdgcn_s_barrier();
+  LOAD_A(smem, 0);
+  LOAD_B0(smem);
+  // A K-step is two MFMA groups with the barrier between them.  An early wave (the only kind
+  // in the 4-wave kernels) stages K-step h+4 in the second group of K-step h; a LATE wave
+  // (waves 4-7 of an 8-wave kernel) stages K-step h+3 in the first group instead: the two waves
+  // of a SIMD then never sit in their LDS-DMA issue stalls at the same time, one of them is
+  // always in a pure fragment-read + MFMA group (MI355X_MICROARCH.md, two waves per SIMD, item 9).
+  // Either way K-steps h+2 and h+3 are what may still be in flight at the barrier of K-step h.
+  if constexpr (!LATE) issue(3, fetch(3));
+  Desc dnext = fetch(LATE ? 3 : 4);
+
+#ifndef BSMI_NO_SCHED_HINTS
+#define HINTS(n_mfma_ds_, with_dma_, grp_)                                     \
+  if (with_dma_) {                                                              \
+    _Pragma("unroll") for (int k = 0; k < G; ++k) {                           \
+      __builtin_amdgcn_sched_group_barrier(0x008, 2, grp_);                     \
+      __builtin_amdgcn_sched_group_barrier(0x020, 1, grp_);                     \
+    }                                                                           \
+  }                                                                             \
+  _Pragma("unroll") for (int k = 0; k < (n_mfma_ds_); ++k) {                  \
+    __builtin_amdgcn_sched_group_barrier(0x008, 2, grp_);                       \
+    __builtin_amdgcn_sched_group_barrier(0x100, 1, grp_);                       \
+  }
+#else
+#define HINTS(n_mfma_ds_, with_dma_, grp_)
+#endif
+  // one K-step with A in fa[AC], the next K-step's A into fa[AN]
+#define KSTEP(h_, AC, AN)                                                       \
+  {                                                                             \
+    const char* st = smem + ((h_) & (NSLOT - 1)) * SLOT;                        \
+    if constexpr (LATE) {                                                       \
+      issue((h_) + 3, dnext);                                                   \
+      dnext = fetch((h_) + 4);                                                  \
+    }                                                                           \
+    LOAD_B1(st);                                                                \
+    MMA0(AC);                                                                   \
+    HINTS(NH1, LATE, 0)                                                         \
+    asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(2 * G) : "memory");    \
+    __builtin_amdgcn_s_barrier();                                               \
+    if constexpr (!LATE) {                                                      \
+      issue((h_) + 4, dnext);                                                   \
+      dnext = fetch((h_) + 5);                                                  \
+    }                                                                           \
+    const char* stn = smem + (((h_) + 1) & (NSLOT - 1)) * SLOT;                 \
+    LOAD_A(stn, AN);                                                            \
+    LOAD_B0(stn);                                                               \
+    MMA1(AC);                                                                   \
+    HINTS(FM + NH0, !LATE, 1)                                                   \
+  }
+  for (int h = 0; h < nloc; h += 2) {  // nloc is even (host: K-step lists and split-K ranges are padded / cut to pairs)
+    KSTEP(h, 0, 1)
+    KSTEP(h + 1, 1, 0)
+  }
+#undef KSTEP
+#undef HINTS
+#undef LOAD_A
+#undef LOAD_B0
+#undef LOAD_B1
+#undef MMA0
+#undef MMA1
+#ifdef BSMI_STAMP
+  const unsigned long long st0 = wall_clock64();
+#endif
+  // drain the run-ahead loads; after the barrier nobody reads or writes the LDS ring any more
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+#ifdef BSMI_STAMP
+  const unsigned long long st1 = wall_clock64();
+#endif
+
+  if (part) {
+    // split-K: this workgroup multiplied only part of the tile's K range; leave the raw sums
+    // (register order, 64 contiguous bytes per lane) for conv_fixup_kernel
+#pragma unroll
+    for (int i = 0; i < FM; ++i)
+#pragma unroll
+      for (int j = 0; j < FN; ++j) *(f32x4_t*)(part + ((size_t)(i * FN + j) * (64 * NW) + tid) * 4) = acc[i][j];
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    return;
+  }
+#ifdef BSMI_ABLATE_NOSTORE  // timing experiment
+  if (a.relu != 12345) return;
+#endif
+  // Epilogue: bias (+ReLU), convert, store channels-last.  A lane of the 32x32 accumulator holds
+  // 16 rows of ONE channel, so storing from registers would write 2-byte pieces (64-byte runs per
+  // row: partial cache lines, measured at ~170 GB/s).  Instead every wave transposes 16 rows of
+  // its tile at a time through a private LDS strip and writes 16 bytes per lane, whole rows of
+  // WTN channels (256-640 contiguous bytes) per few lanes.
+  constexpr int ESZ = (int)sizeof(T);
+  constexpr int PITCH = WTN * ESZ + 16;       // +16: the two lane halves (rows +4) fall on different banks
+  constexpr int CPR = WTN * ESZ / 16;         // 16-byte chunks per row
+  constexpr int NCH = 16 * CPR;               // chunks per 16-row strip
+  static_assert(NW * 16 * PITCH <= NSLOT * SLOT, "epilogue strips fit in the ring");
+  char* strip = smem + wave * (16 * PITCH);
+  T* out = (T*)a.out;
+  float bv[FN];
+#pragma unroll
+  for (int j = 0; j < FN; ++j) {
+    const int n = n0 + wn * WTN + j * 16 + lr;
+    bv[j] = n < a.Npad ? a.bias[n] : 0.f;
+  }
+#pragma unroll
+  for (int i = 0; i < FM; ++i) {  // one 16-row strip per fragment row
+#pragma unroll
+    for (int j = 0; j < FN; ++j) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        float v = acc[i][j][r] + bv[j];
+        if (a.relu) v = v > 0.f ? v : 0.f;
+        Elem<T>::store((T*)(strip + (4 * lq + r) * PITCH) + j * 16 + lr, v);
+      }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int k = 0; k < (NCH + 63) / 64; ++k) {
+      const int c = lane + 64 * k;
+      if (c >= NCH) break;
+      const int row = c / CPR, cc = c - row * CPR;
+      const u32x4_t v = *(const u32x4_t*)(strip + row * PITCH + cc * 16);
+      const int m = m0 + wm * WTM + i * 16 + row;
+      const int n = n0 + wn * WTN + cc * (16 / ESZ);
+      if (m < a.M && n < a.Co) store_stream16(out + (size_t)m * a.Co + n, v);
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  }
+#ifdef BSMI_STAMP
+  const unsigned long long st2 = wall_clock64();
+#endif
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // a persistent workgroup stages its next tile after this
+#ifdef BSMI_STAMP
+  if (tid == 0) {
+    const unsigned long long st3 = wall_clock64();
+    atomicAdd(&g_stamp[0], st1 - st0);
+    atomicAdd(&g_stamp[1], st2 - st1);
+    atomicAdd(&g_stamp[2], st3 - st2);
+    atomicAdd(&g_stamp[3], 1ull);
+    atomicAdd(&g_stamp[4], st0 - st_begin);
+  }
+#endif
+}
+
+// wave -> (weight-piece count, early/late) instantiation of the body; MS = MFMA shape (32: 32x32x16 /
+// 32x32x2, 16: v_mfma_f32_16x16x32_bf16, which holds a ~12 % higher clock on real data: MI355X_MICROARCH.md,
+// DVFS give-back item 7)
+template <typename T, int BM, int BN, int WM, int WN, int MS, int BI, bool LATE>
+__device__ __forceinline__ void conv_igemm_body_ms(const ConvArgs& a, char* smem, int tile, int s0, int s1, float* part) {
+  if constexpr (MS == 16) conv_igemm_body16<BM, BN, WM, WN, BI, LATE>(a, smem, tile, s0, s1, part);
+  else conv_igemm_body<T, BM, BN, WM, WN, BI, LATE>(a, smem, tile, s0, s1, part);
+}
+
+template <typename T, int BM, int BN, int WM, int WN, int MS>
 __device__ __forceinline__ void conv_igemm_dispatch(const ConvArgs& a, char* smem, int tile, int s0, int s1, float* part) {
   constexpr int NW = WM * WN, NBP = BN / 16;
   constexpr int HI = (NBP + NW - 1) / NW, LO = NBP / NW;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   if constexpr (NW == 8) {
     static_assert(HI == LO || NBP % NW == 4, "the uneven split must coincide with the early/late split");
-    if (wave < 4) conv_igemm_body<T, BM, BN, WM, WN, HI, false>(a, smem, tile, s0, s1, part);
-    else conv_igemm_body<T, BM, BN, WM, WN, LO, true>(a, smem, tile, s0, s1, part);
+    if (wave < 4) conv_igemm_body_ms<T, BM, BN, WM, WN, MS, HI, false>(a, smem, tile, s0, s1, part);
+    else conv_igemm_body_ms<T, BM, BN, WM, WN, MS, LO, true>(a, smem, tile, s0, s1, part);
   } else if constexpr (HI == LO) {
-    conv_igemm_body<T, BM, BN, WM, WN, HI, false>(a, smem, tile, s0, s1, part);
+    conv_igemm_body_ms<T, BM, BN, WM, WN, MS, HI, false>(a, smem, tile, s0, s1, part);
   } else {
-    if (wave < NBP % NW) conv_igemm_body<T, BM, BN, WM, WN, HI, false>(a, smem, tile, s0, s1, part);
-    else conv_igemm_body<T, BM, BN, WM, WN, LO, false>(a, smem, tile, s0, s1, part);
+    if (wave < NBP % NW) conv_igemm_body_ms<T, BM, BN, WM, WN, MS, HI, false>(a, smem, tile, s0, s1, part);
+    else conv_igemm_body_ms<T, BM, BN, WM, WN, MS, LO, false>(a, smem, tile, s0, s1, part);
   }
 }
 
 // T: element type; BM x BN block tile; WM x WN waves: 4 (one per SIMD, up to 512 registers
 // each: 128x128 register tiles) or 8 (two per SIMD, 256 registers each: while one wave of a
 // SIMD sits in the 60-185 cycles an LDS-DMA instruction costs its issuer, the other multiplies).
-template <typename T, int BM, int BN, int WM, int WN>
+template <typename T, int BM, int BN, int WM, int WN, int MS>
 __global__ __launch_bounds__(64 * WM * WN, 1) void conv_igemm_kernel(const ConvArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];  // [NSLOT][A: BM rows | B: BN rows][64 B]
   // XCD-aware tile map: consecutive block ids are dealt round-robin to the 8 XCDs, so give
@@ -361,7 +641,7 @@ __global__ __launch_bounds__(64 * WM * WN, 1) void conv_igemm_kernel(const ConvA
   const int q = ntiles >> 3, r = ntiles & 7;
   const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
   const int tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + j;
-  conv_igemm_dispatch<T, BM, BN, WM, WN>(a, smem, tile, 0, a.nsteps, nullptr);
+  conv_igemm_dispatch<T, BM, BN, WM, WN, MS>(a, smem, tile, 0, a.nsteps, nullptr);
 }
 
 // Persistent form with a split-K tail: one workgroup per CU.  A plain launch of 779 tiles on 256
@@ -391,7 +671,7 @@ __device__ __forceinline__ SkGeom sk_geom(int ntiles, int xcd, int G) {
 // helps the others, so a CU that other streams keep busy (the segmentation lanes of the block
 // pipeline) only delays its own share by one tile; a workgroup that becomes resident late finds
 // the queues empty and leaves.  conv_fixup_kernel re-zeroes the counters for the next launch.
-template <typename T, int BM, int BN, int WM, int WN>
+template <typename T, int BM, int BN, int WM, int WN, int MS>
 __global__ __launch_bounds__(64 * WM * WN, 1) void conv_igemm_sk_kernel(const ConvArgs a, float* ws, int* counters) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   __shared__ int sh_item;
@@ -408,13 +688,14 @@ __global__ __launch_bounds__(64 * WM * WN, 1) void conv_igemm_sk_kernel(const Co
       const int it = __builtin_amdgcn_readfirstlane(sh_item);
       if (it >= nitems) break;
       if (it < nfull) {
-        conv_igemm_dispatch<T, BM, BN, WM, WN>(a, smem, g.base + it, 0, S, nullptr);
+        conv_igemm_dispatch<T, BM, BN, WM, WN, MS>(a, smem, g.base + it, 0, S, nullptr);
       } else {
         const int r = it - nfull;
         const int rt = r / g.P, part = r - rt * g.P;
-        const int sa = (int)((long long)S * part / g.P), sb = (int)((long long)S * (part + 1) / g.P);
+        const int sa = (int)((long long)(S / 2) * part / g.P) * 2;  // K ranges in whole pairs of K-steps (16x16x32 body)
+        const int sb = part + 1 == g.P ? S : (int)((long long)(S / 2) * (part + 1) / g.P) * 2;
         float* dst = g.P == 1 ? nullptr : ws + ((size_t)xcd * g.per + r) * (BM * BN);
-        if (sb > sa) conv_igemm_dispatch<T, BM, BN, WM, WN>(a, smem, g.base + nfull + rt, sa, sb, dst);
+        if (sb > sa) conv_igemm_dispatch<T, BM, BN, WM, WN, MS>(a, smem, g.base + nfull + rt, sa, sb, dst);
       }
     }
   }
@@ -423,11 +704,13 @@ __global__ __launch_bounds__(64 * WM * WN, 1) void conv_igemm_sk_kernel(const Co
 // Finishes the tail tiles of conv_igemm_sk_kernel: sum of the P partial tiles in part order
 // (deterministic), bias, ReLU, store.  Grid (32, 8): (tail tile, xcd); same thread -> element map
 // as the epilogue.
-template <typename T, int BM, int BN, int WM, int WN>
+template <typename T, int BM, int BN, int WM, int WN, int MS>
 __global__ __launch_bounds__(64 * WM * WN) void conv_fixup_kernel(const ConvArgs a, const float* ws, int G, int* counters) {
-  if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x < 8) counters[threadIdx.x] = 0;
-  constexpr int NW = WM * WN, WTM = BM / WM, WTN = BN / WN, FM = WTM / 32, FN = WTN / 32;
-  const int xcd = blockIdx.y, rt = blockIdx.x;
+  if (blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && threadIdx.x < 8) counters[threadIdx.x] = 0;
+  constexpr int NW = WM * WN, WTM = BM / WM, WTN = BN / WN, FN = WTN / MS;
+  constexpr int NR = MS == 16 ? 4 : 16;  // accumulator registers of one fragment
+  const int xcd = blockIdx.y, rt = blockIdx.x, frag = blockIdx.z;  // grid: (tail tile, xcd, fragment)
+  const int i = frag / FN, j = frag - i * FN;
   const int ntn = a.Npad / BN;
   const SkGeom g = sk_geom(((a.M + BM - 1) / BM) * ntn, xcd, G);
   if (rt >= g.rem || g.P == 1) return;
@@ -436,36 +719,37 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_fixup_kernel(const ConvArgs
   const int tile_m = tile / ntn, tile_n = tile - tile_m * ntn;
   const int m0 = tile_m * BM, n0 = tile_n * BN;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wm = wave / WN, wn = wave % WN, lr = lane & 31, lh = lane >> 5;
+  const int wm = wave / WN, wn = wave % WN;
   const float* p0 = ws + ((size_t)xcd * g.per + rt * g.P) * (BM * BN);
+  const size_t o = ((size_t)frag * (64 * NW) + tid) * NR;
+  float x[NR];
+#pragma unroll
+  for (int r = 0; r < NR; ++r) x[r] = 0.f;
+  for (int part = 0; part < g.P; ++part) {
+    const int sa = (int)((long long)(S / 2) * part / g.P) * 2;
+    const int sb = part + 1 == g.P ? S : (int)((long long)(S / 2) * (part + 1) / g.P) * 2;
+    if (sb <= sa) continue;  // empty K range: nothing was written
+#pragma unroll
+    for (int r = 0; r < NR; ++r) x[r] += p0[(size_t)part * (BM * BN) + o + r];
+  }
+  const int n = n0 + wn * WTN + j * MS + (MS == 16 ? (lane & 15) : (lane & 31));
+  if (n >= a.Co) return;
+  const float bv = a.bias[n];
   T* out = (T*)a.out;
-  for (int j = 0; j < FN; ++j) {
-    const int n = n0 + wn * WTN + j * 32 + lr;
-    const float bv = n < a.Co ? a.bias[n] : 0.f;
-    for (int i = 0; i < FM; ++i) {
-      const size_t o = ((size_t)(i * FN + j) * (64 * NW) + tid) * 16;
-      f32x16_t x;
 #pragma unroll
-      for (int r = 0; r < 16; ++r) x[r] = 0.f;
-      for (int part = 0; part < g.P; ++part) {
-        if ((long long)S * (part + 1) / g.P == (long long)S * part / g.P) continue;  // empty K range: nothing was written
-        x += *(const f32x16_t*)(p0 + (size_t)part * (BM * BN) + o);
-      }
-      if (n >= a.Co) continue;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int m = m0 + wm * WTM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-        if (m < a.M) {
-          float v = x[r] + bv;
-          if (a.relu) v = v > 0.f ? v : 0.f;
-          Elem<T>::store(out + (size_t)m * a.Co + n, v);
-        }
-      }
+  for (int r = 0; r < NR; ++r) {
+    const int row = MS == 16 ? 4 * (lane >> 4) + r : (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+    const int m = m0 + wm * WTM + i * MS + row;
+    if (m < a.M) {
+      float v = x[r] + bv;
+      if (a.relu) v = v > 0.f ? v : 0.f;
+      Elem<T>::store(out + (size_t)m * a.Co + n, v);
     }
   }
 }
 
 bool two_waves_per_simd();
+bool mfma_16x16();
 int tile_bm(TileCfg) { return 256; }
 int tile_bn(TileCfg c) {
   switch (c) {
@@ -498,32 +782,47 @@ TileCfg choose_tile(int cout) {
   return best;
 }
 
-template <typename T, int BM, int BN, int WM, int WN>
+template <typename T, int BM, int BN, int WM, int WN, int MS = 32>
 static int launch_one(const ConvArgs& a, hipStream_t stream, float* sk_ws, int sk_grid) {
   constexpr int smem = 4 * (BM + BN) * kStepRowBytes;
   static bool attr_set = false;
-  auto kern = conv_igemm_kernel<T, BM, BN, WM, WN>;
-  auto kern_sk = conv_igemm_sk_kernel<T, BM, BN, WM, WN>;
+  static bool sk_ok = true;
+  auto kern = conv_igemm_kernel<T, BM, BN, WM, WN, MS>;
+  auto kern_sk = conv_igemm_sk_kernel<T, BM, BN, WM, WN, MS>;
   if (!attr_set) {
     BSMI_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
     BSMI_HIP(hipFuncSetAttribute((const void*)kern_sk, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
+    // The K loops count their outstanding LDS-DMA groups with s_waitcnt vmcnt(N).  Scratch (spill)
+    // traffic is counted by the same counter, so a kernel body that spills would wait for the wrong
+    // loads: refuse it (the plain kernel) or do not use it (the persistent form).
+    hipFuncAttributes fa;
+    BSMI_HIP(hipFuncGetAttributes(&fa, (const void*)kern));
+    if (fa.localSizeBytes != 0)
+      BSMI_FAIL(BSMI_ERR_STATE, "conv kernel %dx%d (%d waves) was compiled with %zu bytes of scratch: counted vmcnt waits are unsafe",
+                BM, BN, WM * WN, (size_t)fa.localSizeBytes);
+    BSMI_HIP(hipFuncGetAttributes(&fa, (const void*)kern_sk));
+    sk_ok = fa.localSizeBytes == 0;
     attr_set = true;
   }
   const int ntiles = ceil_div(a.M, BM) * (a.Npad / BN);
   // persistent + split-K tail when whole rounds would leave a large share of the last one idle
   const bool big_tile = BN >= 256;
   const int rounds = ceil_div(ntiles, sk_grid > 0 ? sk_grid : 1);
-  if (sk_ws && sk_grid >= 8 && big_tile && ntiles % sk_grid != 0 && rounds <= 16 && (size_t)BM * BN <= kStreamKTileElems &&
-      !(WM == 2 && WN == 2)) {  // the 2x2 (512-register) body has no room for the round loop
+  if (sk_ws && sk_ok && sk_grid >= 8 && big_tile && ntiles % sk_grid != 0 && rounds <= 16 && (size_t)BM * BN <= kStreamKTileElems) {
     int* counters = (int*)(sk_ws + (size_t)sk_grid * kStreamKTileElems);
     hipLaunchKernelGGL(kern_sk, dim3(sk_grid), dim3(64 * WM * WN), smem, stream, a, sk_ws, counters);
-    hipLaunchKernelGGL((conv_fixup_kernel<T, BM, BN, WM, WN>), dim3(sk_grid / 8, 8), dim3(64 * WM * WN), 0, stream, a,
-                       (const float*)sk_ws, sk_grid, counters);
+    hipLaunchKernelGGL((conv_fixup_kernel<T, BM, BN, WM, WN, MS>), dim3(sk_grid / 8, 8, (BM / WM / MS) * (BN / WN / MS)),
+                       dim3(64 * WM * WN), 0, stream, a, (const float*)sk_ws, sk_grid, counters);
   } else {
     hipLaunchKernelGGL(kern, dim3(ntiles), dim3(64 * WM * WN), smem, stream, a);
   }
   BSMI_HIP(hipGetLastError());
   return BSMI_OK;
+}
+
+bool mfma_16x16() {
+  static const bool on = [] { const char* e = getenv("BSMI_MFMA16"); return !e || e[0] != '0'; }();
+  return on;
 }
 
 bool two_waves_per_simd() {
@@ -539,7 +838,11 @@ static int launch_cfg(const ConvArgs& a, TileCfg cfg, hipStream_t stream, float*
     case TILE_256x160: return launch_one<T, 256, 160, 4, 1>(a, stream, sk_ws, sk_grid);
     case TILE_256x320: return launch_one<T, 256, 320, 4, 2>(a, stream, sk_ws, sk_grid);
     case TILE_256x256:
-      if (two_waves_per_simd()) return launch_one<T, 256, 256, 4, 2>(a, stream, sk_ws, sk_grid);
+      if (two_waves_per_simd()) {
+        if constexpr (std::is_same<T, bf16_elem>::value)
+          if (mfma_16x16()) return launch_one<T, 256, 256, 4, 2, 16>(a, stream, sk_ws, sk_grid);
+        return launch_one<T, 256, 256, 4, 2>(a, stream, sk_ws, sk_grid);
+      }
       return launch_one<T, 256, 256, 2, 2>(a, stream, sk_ws, sk_grid);
     default: BSMI_FAIL(BSMI_ERR_INVALID, "unknown tile config %d", (int)cfg);
   }

@@ -247,6 +247,9 @@ static void build_entries(const PassSite& p, int ci, int prec, std::vector<PackE
       base += p.cin[s];
     }
   }
+  // an even number of K-steps: the 16x16x32 kernel body is unrolled by two
+  if ((out.size() / kUnitsPerStep) % 2)
+    for (int j = 0; j < kUnitsPerStep; ++j) out.push_back(PackEntry{0, 0, 0, 0, 0, 0, 0, 0, 0, true, (int)phases.size() - 1});
   if (phases_out) *phases_out = phases;
 }
 
@@ -341,7 +344,11 @@ struct Planner {
     for (size_t s = 0; s < nsteps; ++s) {
       const PackEntry& e0 = pc.entries[kUnitsPerStep * s];
       const PackEntry& e1 = pc.entries[kUnitsPerStep * s + 1];
-      if (e0.dummy) BSMI_FAIL(BSMI_ERR_STATE, "raster-halo plan: K-step %zu starts with a padding unit", s);
+      if (e0.dummy) {  // the all-zero K-step that makes the count even: any resident halo row will do
+        if (phases.empty() || !e1.dummy) BSMI_FAIL(BSMI_ERR_STATE, "raster-halo plan: K-step %zu starts with a padding unit", s);
+        steps[s] = RhStep{0, (int32_t)(((phases.size() - 1) & 1) | ((phases.size() - 1) << 8)), 0, -1};
+        continue;
+      }
       const TDesc& t = slots[e0.slot];
       const int c32 = e0.c0 / (kUnitsPerStep * SUB) * (kUnitsPerStep * SUB);
       const int kind = e0.wsrc;

@@ -38,13 +38,24 @@ def test_full_block_shapes_and_determinism(full_block):
     assert 20 < float(u8.float().std()) < 90
 
 
-def test_full_block_bf16_close_to_f32(full_block):
-    """bf16 operands / f32 accumulate vs exact-f32 MFMA at the full 16-layer depth and K up to 48 600."""
-    d = (full_block["bf16"][1] - full_block["f32"][1]).abs()
-    print("bf16 vs f32 at 128^3: max", float(d.max()), "mean", float(d.mean()))
-    assert float(d.max()) < 3e-2 and float(d.mean()) < 3e-3
+def test_full_block_vs_cpu_oracle(full_block):
+    """The whole 3d_affs network on one BASELINE-size block against the CPU restatement (oracle/unet_ref.py, about
+    15 s on the box's cores): exact-f32 MFMA mode within the 1e-4 parity gate -- this is the test that sees the
+    persistent split-K launches, the 8-wave kernels and K up to 48 600 at their real sizes -- and the bf16
+    throughput mode within 1e-2 (measured 4.3e-3) of the same reference."""
+    from oracle import unet_ref as R
+    from bootstrapper_amd.synth import synthetic_state_dict, synthetic_volume
+    from tests.test_lib_cpu import AFFS_NET_CONFIG as NC
+    raw = synthetic_volume((156, 220, 220), 0).cpu().numpy()
+    torch.set_num_threads(min(16, os.cpu_count() or 1))
+    ref = torch.from_numpy(R.predict_block(R.default_cfg(12, 5), synthetic_state_dict(NC, 0), raw, ["affs_head"])[0])
+    d32 = (full_block["f32"][1].cpu() - ref).abs()
+    d16 = (full_block["bf16"][1].cpu() - ref).abs()
+    print("f32 vs oracle: max", float(d32.max()), "mean", float(d32.mean()), "| bf16 vs oracle: max", float(d16.max()), "mean", float(d16.mean()))
+    assert float(d32.max()) < 1e-4
+    assert float(d16.max()) < 1e-2 and float(d16.mean()) < 2e-3
     du = (full_block["bf16"][0].int() - full_block["f32"][0].int()).abs()
-    assert int(du.max()) <= 8 and float((du <= 1).float().mean()) > 0.9
+    assert int(du.max()) <= 3 and float((du <= 1).float().mean()) > 0.95
 
 
 def test_full_block_segmentation_bit_exact(full_block):
