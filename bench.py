@@ -46,6 +46,20 @@ OUT_BLOCK = (128, 128, 128)
 CONTEXT = (14, 46, 46)          # (input - output) / 2 of the 3-D nets (reference predict.py:127-131)
 THRESHOLDS = [0.2, 0.35, 0.5]   # reference segment.py:17
 BF16_DENSE_PEAK_TFLOPS = 2500.0  # /opt/skills/guides/MI355X_MICROARCH.md, dense bf16 MFMA
+# HBM-side bytes per conv launch cannot be counted inside this process: they come from the committed
+# rocprofv3 PMC passes of the same kernels on the same block (tools/pmc_traffic.py; FETCH_SIZE and WRITE_SIZE
+# in separate passes, KiB -> bytes, FETCH_SIZE doubled for gfx950 wide reads as the guide prescribes).
+TRAFFIC_PROFILE = os.path.join(ROOT, "profiles", "r01_e_conv_traffic_pmc.json")
+
+
+def pmc_traffic(precision):
+    if precision != "bf16":
+        return None, None
+    try:
+        with open(TRAFFIC_PROFILE) as f:
+            return float(json.load(f)["traffic_bytes_per_conv_launch"]), os.path.relpath(TRAFFIC_PROFILE, ROOT)
+    except (OSError, KeyError, ValueError):
+        return None, None
 
 
 def host_cores():
@@ -194,6 +208,7 @@ def main():
         dt = float(t.item())
 
     conv_ms, conv_flops, conv_launches = totals["conv"]
+    traffic, traffic_src = pmc_traffic(args.precision)
     achieved = conv_flops / (conv_ms * 1e-3) / 1e12 if conv_ms > 0 else 0.0
     value = world * args.steps * nvox_block / dt / 1e6
     out = {
@@ -208,8 +223,9 @@ def main():
                    "seg_lanes": args.seg_lanes, "pred_lanes": len(models), "seg_cus": pipe.seg_cus},
         "roofline": {"bound": "mfma", "achieved": achieved, "peak": BF16_DENSE_PEAK_TFLOPS if args.precision == "bf16" else 157.3,
                      "unit": "TFLOP/s", "frac": achieved / (BF16_DENSE_PEAK_TFLOPS if args.precision == "bf16" else 157.3),
-                     "traffic": None,
-                     "kernel": "bsmi::conv_igemm_kernel (all implicit-GEMM launches of the U-Net)",
+                     "traffic": traffic, "traffic_unit": "bytes per launch (memory side of L2, Infinity-Cache hits included)",
+                     "traffic_source": traffic_src,
+                     "kernel": "bsmi::conv_igemm_kernel / conv_igemm_sk_kernel (all implicit-GEMM launches of the U-Net)",
                      "launches": int(conv_launches), "avg_launch_ms": conv_ms / max(conv_launches, 1),
                      "algorithmic_tflop_per_block": flops_block / 1e12,
                      "other_unet_ms_per_block": sum(totals[k][0] for k in ("input", "pool", "upsample", "head")) / max(args.steps, 1)},
