@@ -139,6 +139,7 @@ def main():
     ap.add_argument("--seg-cus", type=int, default=0, help="CUs reserved for the segmentation lanes (0: shared CUs)")
     ap.add_argument("--no-segment", action="store_true", help="predict only (diagnostic; not the headline metric)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--seg-stages", default="ws,agg", help="diagnostic: which segmentation stages the lanes run")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -175,7 +176,8 @@ def main():
     mine = [grid[(rank + i * world) % len(grid)] for i in range(n_warm + args.steps)]
 
     pipe = BlockPipeline(model, OUT_BLOCK, CONTEXT, THRESHOLDS, n_seg_lanes=args.seg_lanes,
-                         segment=not args.no_segment, device=local_rank, models=models, seg_cus=args.seg_cus)
+                         segment=not args.no_segment, device=local_rank, models=models, seg_cus=args.seg_cus,
+                         seg_stages=tuple(args.seg_stages.split(",")))
 
     def barrier():
         torch.cuda.synchronize(dev)

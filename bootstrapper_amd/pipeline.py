@@ -34,7 +34,7 @@ def cu_masked_stream(device, first_bit, n_bits, total_bits):
 
 class BlockPipeline:
     def __init__(self, model, out_block, context, thresholds=(0.2, 0.35, 0.5), min_seed_distance=10,
-                 n_seg_lanes=4, segment=True, device=0, keep_outputs=False, models=None, seg_cus=0):
+                 n_seg_lanes=4, segment=True, device=0, keep_outputs=False, models=None, seg_cus=0, seg_stages=("ws", "agg")):
         # `models`: optional list of Model replicas (same weights), one per predict stream.  Two
         # predict streams let the last, partially filled round of workgroups of one block's
         # conv launch overlap with the other block's launches (each replica owns its activations).
@@ -48,6 +48,7 @@ class BlockPipeline:
         self.thresholds = list(thresholds)
         self.msd = int(min_seed_distance)
         self.segment = bool(segment)
+        self.seg_stages = tuple(seg_stages)  # diagnostic: run only part of the segmentation half
         self.dev = torch.device("cuda", device)
         self.keep = keep_outputs
         # The U-Net's big layers run as persistent workgroups that want a whole CU each (all of its
@@ -101,8 +102,13 @@ class BlockPipeline:
             with torch.cuda.stream(lane["stream"]):
                 lane["stream"].wait_event(ready)
                 affs = u8[0][:3]
-                frags, max_id = lane["engine"].ws_fragments(affs, True, self.msd)
-                segs = lane["engine"].agglomerate_mean(affs, frags, self.thresholds)
+                if "ws" in self.seg_stages or lane.get("frags") is None:
+                    frags, max_id = lane["engine"].ws_fragments(affs, True, self.msd)
+                    lane["frags"] = frags
+                else:
+                    frags = lane["frags"]  # diagnostic mode: agglomerate the lane's first fragments again
+                segs = (lane["engine"].agglomerate_mean(affs, frags, self.thresholds) if "agg" in self.seg_stages
+                        else frags[None])
                 for t in (raw, affs, frags, segs) + tuple(u8):
                     t.record_stream(lane["stream"])
                 done = torch.cuda.Event()
