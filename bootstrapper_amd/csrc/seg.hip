@@ -13,6 +13,7 @@
 //   agglomeration: region-adjacency graph by parallel scan + device hash table (sum, count
 //     per edge), then one wave per volume replays the specified sequential merge loop
 //     (min-queue over the total order (score, initial edge key)), then a parallel relabel.
+#include <atomic>
 #include <vector>
 
 #include <hipcub/hipcub.hpp>
@@ -418,6 +419,7 @@ struct AggWs {
   float* tscore;         // [2 * node_cap]
   uint32_t* cur;         // [node_cap] tree node of a cluster root
   uint32_t* ha; uint32_t* hb;  // [node_cap] merge history (ranks)
+  int xcd_hint;          // XCD the sequential merge loop of this workspace should run on (see xcd_claim)
 };
 
 __global__ void agg_maxid_kernel(const uint64_t* __restrict__ frags, size_t n, AggWs w) {
@@ -548,10 +550,32 @@ __device__ __forceinline__ float agg_score(unsigned long long sum, uint32_t cnt)
   return 1.0f - (float)((double)sum / (255.0 * (double)cnt));
 }
 
+// The sequential merge loops hold one CU (its LDS) for tens of milliseconds.  A one-workgroup launch always lands on
+// the same XCD, so the eight lanes of the block pipeline would take eight CUs of ONE XCD away from the U-Net's
+// persistent conv workgroups (measured with dummy kernels: 8 x 98 KB of LDS held that way cost the predict stream
+// 13 %, one CU in each XCD 3 %).  So the loops are launched as 8 workgroups, which the dispatcher deals round-robin
+// to the 8 XCDs, and exactly one of them -- the one on the workspace's XCD if there is one, else the last to
+// arrive -- does the work; the others leave at once.  claim[0] = taken, claim[1] = arrivals (zero before the launch).
+__device__ __forceinline__ bool xcd_claim(uint32_t* claim, int target) {
+  __shared__ int sh_run;
+  if (threadIdx.x == 0) {
+    unsigned xcc;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    bool run = false;
+    if ((int)(xcc & 7) == target) run = atomicCAS(&claim[0], 0u, 1u) == 0u;
+    const unsigned arrived = atomicAdd(&claim[1], 1u);
+    if (!run && arrived == gridDim.x - 1) run = atomicCAS(&claim[0], 0u, 1u) == 0u;
+    sh_run = run ? 1 : 0;
+  }
+  __syncthreads();
+  return sh_run != 0;
+}
+
 // One wave per volume; lane 0 replays the sequential merge loop of oracle/seg_ref.c.
 __global__ __launch_bounds__(64) void agg_merge_kernel(AggWs w, const float* __restrict__ thresholds, int nthr) {
   __shared__ uint64_t hl[AGG_LDS_HEAP];
   __shared__ int sh_dummy;
+  if (!xcd_claim(&w.counters[5], w.xcd_hint)) return;
   if (w.counters[3]) return;
   const uint32_t nn = w.counters[0];
   const uint32_t ne = min(w.counters[1], w.edge_cap);
@@ -858,6 +882,7 @@ constexpr int kMaxQueueBins = 1024;
 // One lane replays the sequential bin-queue merge loop and grows the merge tree.
 __global__ __launch_bounds__(64) void rag_merge_kernel(AggWs w, float threshold, int nbins) {
   __shared__ uint32_t bhead[kMaxQueueBins], btail[kMaxQueueBins];
+  if (!xcd_claim(&w.counters[5], w.xcd_hint)) return;
   if (w.counters[3]) return;
   for (int b = threadIdx.x; b < nbins; b += 64) bhead[b] = btail[b] = NOEDGE;
   __syncthreads();
@@ -1142,6 +1167,22 @@ __global__ void label_stats_kernel(const uint64_t* __restrict__ lab, int D, int 
   }
 }
 
+// clears the per-call tables of the agglomeration (instead of four runtime fill kernels)
+__global__ void seg_clear_kernel(AggWs w) {
+  const size_t stride = (size_t)gridDim.x * blockDim.x, t0 = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  for (size_t i = t0; i < w.id_cap; i += stride) w.rank_of_id[i] = 0;
+  for (size_t i = t0; i < w.hcap; i += stride) {
+    w.hkeys[i] = HEMPTY;
+    w.hsum[i] = 0;
+    w.hcnt[i] = 0;
+  }
+}
+
+int seg_scan_grid() {
+  static const int g = [] { const char* e = getenv("BSMI_SEG_SCAN_GRID"); const int v = e ? atoi(e) : 32; return v < 1 ? 1 : v; }();
+  return g;
+}
+
 }  // namespace bsmi
 
 using namespace bsmi;
@@ -1204,6 +1245,8 @@ int bsmi_seg_create(int device, const int64_t max_shape[3], bsmi_seg** out) {
   h->flood_spill_stride = ns;
   A(h->flood_spill, nv);
   AggWs& g = h->agg;
+  static std::atomic<int> next_xcd{0};
+  g.xcd_hint = next_xcd.fetch_add(1) & 7;
   g.id_cap = (uint32_t)std::min<size_t>(nv + 2, (size_t)1 << 27);
   g.node_cap = (uint32_t)std::min<size_t>(nv / 8 + 1024, (size_t)1 << 24);
   g.hcap = next_pow2(std::max<size_t>(nv / 2, 1024));
@@ -1323,18 +1366,18 @@ int bsmi_agglomerate_mean_u8(bsmi_seg* h, const uint8_t* affs_dev, const uint64_
   BSMI_HIP(hipMemcpyAsync(h->thr_dev, thresholds_host, sizeof(float) * n_thresholds, hipMemcpyHostToDevice, s));
   BSMI_HIP(hipMemsetAsync(g.counters, 0, 8 * sizeof(uint32_t), s));
   BSMI_HIP(hipMemsetAsync(g.maxid, 0, sizeof(uint64_t), s));
-  BSMI_HIP(hipMemsetAsync(g.rank_of_id, 0, (size_t)g.id_cap * sizeof(uint32_t), s));
-  BSMI_HIP(hipMemsetAsync(g.hkeys, 0xff, (size_t)g.hcap * sizeof(uint64_t), s));
-  BSMI_HIP(hipMemsetAsync(g.hsum, 0, (size_t)g.hcap * sizeof(unsigned long long), s));
-  BSMI_HIP(hipMemsetAsync(g.hcnt, 0, (size_t)g.hcap * sizeof(uint32_t), s));
-  const int bs = 256;
-  const int grid = (int)std::min<size_t>((n + bs - 1) / bs, 2048);
+  // The scans run as FEW, FAT workgroups (kScanGrid x 1024 threads, grid-stride loops): a lane shares the GPU with
+  // the U-Net, whose persistent conv workgroups each need a completely free CU; a 2048-workgroup scan (or a runtime
+  // fill kernel) puts a wave on every CU and keeps them all away until it has drained.
+  const int bs = 1024;
+  const int grid = (int)std::min<size_t>((n + bs - 1) / bs, (size_t)seg_scan_grid());
+  hipLaunchKernelGGL(seg_clear_kernel, dim3(grid), dim3(bs), 0, s, g);
   hipLaunchKernelGGL(agg_maxid_kernel, dim3(grid), dim3(bs), 0, s, frags_dev, n, g);
   hipLaunchKernelGGL(agg_mark_kernel, dim3(grid), dim3(bs), 0, s, frags_dev, n, g);
   hipLaunchKernelGGL(agg_rank_kernel, dim3(1), dim3(1024), 0, s, g);
   hipLaunchKernelGGL(agg_edges_kernel<false>, dim3(grid), dim3(bs), 0, s, affs_dev, frags_dev, D, H, W, g);
-  hipLaunchKernelGGL(agg_compact_kernel, dim3(std::min<uint32_t>(g.hcap / bs, 2048u)), dim3(bs), 0, s, g);
-  hipLaunchKernelGGL(agg_merge_kernel, dim3(1), dim3(64), 0, s, g, (const float*)h->thr_dev, n_thresholds);
+  hipLaunchKernelGGL(agg_compact_kernel, dim3(grid), dim3(bs), 0, s, g);
+  hipLaunchKernelGGL(agg_merge_kernel, dim3(8), dim3(64), 0, s, g, (const float*)h->thr_dev, n_thresholds);
   hipLaunchKernelGGL(agg_relabel_kernel, dim3(grid), dim3(bs), 0, s, frags_dev, n, n_thresholds, g, segs_dev);
   BSMI_HIP(hipGetLastError());
   return BSMI_OK;
@@ -1434,7 +1477,7 @@ int bsmi_rag_merge_scores_u8(bsmi_seg* h, const uint8_t* affs_dev, const uint64_
   BSMI_HIP(hipcub::DeviceRadixSort::SortPairs(h->sort_tmp, tb, (const uint64_t*)g.hkeys, g.skeys, (const uint32_t*)g.iota, g.sslot,
                                               (int)g.hcap, 0, 64, s));
   hipLaunchKernelGGL(rag_compact_kernel, dim3(std::min<uint32_t>(g.hcap / bs, 2048u)), dim3(bs), 0, s, g);
-  hipLaunchKernelGGL(rag_merge_kernel, dim3(1), dim3(64), 0, s, g, threshold, discretize_queue);
+  hipLaunchKernelGGL(rag_merge_kernel, dim3(8), dim3(64), 0, s, g, threshold, discretize_queue);
   hipLaunchKernelGGL(rag_scores_kernel, dim3(1024), dim3(bs), 0, s, g, edges_dev, scores_dev, edge_capacity, merges_dev,
                      merge_scores_dev, counts_dev);
   BSMI_HIP(hipGetLastError());
