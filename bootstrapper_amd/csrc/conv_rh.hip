@@ -243,26 +243,52 @@ __device__ __forceinline__ void conv_rh_body(const RhArgs& a, char* smem, int ti
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     return;
   }
+  // epilogue as in conv_igemm.hip: 16 rows at a time through a per-wave LDS strip, 16-byte streaming stores;
+  // the rows of the input raster that are no output voxel (xx >= Wo, yy >= Ho) are dropped here
+  constexpr int ESZ = (int)sizeof(T);
+  constexpr int PITCH = WTN * ESZ + 16;
+  constexpr int CPR = WTN * ESZ / 16;
+  constexpr int NCH = 16 * CPR;
+  static_assert(NW * 16 * PITCH <= RING + NSLOT * SLOT, "epilogue strips fit in LDS");
+  char* strip = smem + wave * (16 * PITCH);
   T* out = (T*)a.out;
+  float bv[FN];
+#pragma unroll
+  for (int j = 0; j < FN; ++j) {
+    const int n = n0 + wn * WTN + j * 32 + lr;
+    bv[j] = n < a.Npad ? a.bias[n] : 0.f;
+  }
 #pragma unroll
   for (int i = 0; i < FM; ++i) {
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int q = q0 + wm * WTM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-      if (q >= a.Q) continue;
-      const int xx = q % a.Win;
-      const int zy = q / a.Win;
-      const int yy = zy % a.Hin, z = zy / a.Hin;
-      if (xx >= a.Wo || yy >= a.Ho) continue;
-      T* orow = out + ((size_t)(z * a.Ho + yy) * a.Wo + xx) * a.Co;
+    for (int hf = 0; hf < 2; ++hf) {
 #pragma unroll
       for (int j = 0; j < FN; ++j) {
-        const int n = n0 + wn * WTN + j * 32 + lr;
-        if (n >= a.Co) continue;
-        float v = acc[i][j][r] + a.bias[n];
-        if (a.relu) v = v > 0.f ? v : 0.f;
-        Elem<T>::store(orow + n, v);
+#pragma unroll
+        for (int rr = 0; rr < 8; ++rr) {
+          const int row = (rr & 3) + 8 * (rr >> 2) + 4 * lh;
+          float v = acc[i][j][hf * 8 + rr] + bv[j];
+          if (a.relu) v = v > 0.f ? v : 0.f;
+          Elem<T>::store((T*)(strip + row * PITCH) + j * 32 + lr, v);
+        }
       }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+      for (int k = 0; k < (NCH + 63) / 64; ++k) {
+        const int c = lane + 64 * k;
+        if (c >= NCH) break;
+        const int row = c / CPR, cc = c - row * CPR;
+        const u32x4_t v = *(const u32x4_t*)(strip + row * PITCH + cc * 16);
+        const int q = q0 + wm * WTM + i * 32 + hf * 16 + row;
+        const int n = n0 + wn * WTN + cc * (16 / ESZ);
+        if (q < a.Q && n < a.Co) {
+          const int xx = q % a.Win;
+          const int zy = q / a.Win;
+          const int yy = zy % a.Hin, z = zy / a.Hin;
+          if (xx < a.Wo && yy < a.Ho) store_stream16(out + ((size_t)(z * a.Ho + yy) * a.Wo + xx) * a.Co + n, v);
+        }
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     }
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");

@@ -327,9 +327,11 @@ struct Planner {
   int plan_rh(const PassSite& p, int ci, const PackedConv& pc, const TDesc* slots, const int (*so)[3], int nsl,
               const TDesc& o, PlanStep& st) {
     st.use_rh = false;
-    // opt-in (BSMI_USE_RH=1): parity-verified, but on the 128^3 block only the 360->60 channel layer gains
-    // (1.38 -> 1.04 ms); the rows it computes and drops cost the small-plane layers 8-17 %
-    static const bool enabled = [] { const char* e = getenv("BSMI_USE_RH"); return e && e[0] == '1'; }();
+    // BSMI_USE_RH: 1 = wherever the halo fits, 0 = never, unset = only where it was measured to win on the
+    // 128^3 block: small-Cout tiles with a long K loop (the 360->60 channel layer: 1.43 -> 1.04 ms); the rows the
+    // raster-halo form computes and drops cost the small-plane layers 8-17 %, and short-K layers do not amortise it
+    static const int mode = [] { const char* e = getenv("BSMI_USE_RH"); return !e ? 2 : (e[0] == '1' ? 1 : 0); }();
+    const bool enabled = mode == 1 || (mode == 2 && tile_bn(st.tile) <= 64 && pc.entries.size() / kUnitsPerStep >= 200);
     const int* k = p.k[ci];
     const int Hin = o.H + k[1] - 1, Win = o.W + k[2] - 1;
     if (!enabled || !two_waves_per_simd() || !rh_supported(st.tile, Win, k[1], k[2])) return BSMI_OK;
