@@ -69,6 +69,14 @@ def _load():
         "bsmi_lut_relabel": (i32, [C.c_int, vp, C.c_uint64, vp, vp, C.c_uint64, vp, vp]),
         "bsmi_connected_components": (i32, [vp, C.c_uint64, vp, vp, C.c_uint64, C.c_float, vp]),
         "bsmi_seg_status": (i32, [p, vp]),
+        "bsmi_unet_train_begin": (i32, [p, i64p]),
+        "bsmi_unet_train_forward_backward": (i32, [p, vp, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_float), vp]),
+        "bsmi_unet_train_num_params": (i32, [p, C.POINTER(C.c_uint64)]),
+        "bsmi_unet_train_buffers": (i32, [p, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p)]),
+        "bsmi_unet_train_param_info": (i32, [p, C.c_char_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
+        "bsmi_unet_train_adam_step": (i32, [p, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, vp]),
+        "bsmi_unet_train_read_param": (i32, [p, C.c_char_p, C.c_int, vp]),
+        "bsmi_unet_train_end": (i32, [p]),
         "bsmi_unet_set_persistent_grid": (i32, [p, C.c_int]),
         "bsmi_stream_create_cu_mask": (i32, [C.c_int, vp, C.c_int, C.POINTER(C.c_void_p)]),
         "bsmi_stream_destroy": (i32, [C.c_int, vp]),

@@ -1,0 +1,964 @@
+// Training step of the U-Net engine: loss, backward pass, Adam, on the device in fp32 (the reference trains
+// in fp32: models/3d_affs/train.py, training.py:96-137).
+//
+// Reference being replaced (paths relative to /root/reference/bootstrapper):
+//   models/3d_affs/train.py:152-159   training_step = loss(model(raw), gt, weights); Adam(lr = 0.5e-4)
+//   models/3d_affs/model.py:67-92     WeightedMSELoss (masked mean of w (p - t)^2)
+//   models/3d_affs/unet.py            autograd of ConvPass / Downsample / Upsample, restated here as explicit kernels
+//
+// The forward pass is the inference engine's own (bsmi_unet_forward in BSMI_PREC_F32: exact f32 MFMA, every
+// activation of the block stays resident), so the backward pass walks the same launch plan in reverse:
+//   conv stage  g = dY * [Y > 0] into a zero-bordered tensor; bias gradient = column sums; weight gradient by
+//               v_mfma_f32_32x32x2_f32 straight from global memory (g^T x, one kernel tap per workgroup); input
+//               gradient = the SAME implicit-GEMM kernel as the forward pass run over the padded g with flipped,
+//               transposed weights -- the cropped 1x1x1 residual branch rides along as one more K-step source,
+//               exactly as in the forward launch
+//   max-pool    gradient routed to the first maximum of each window; trilinear upsample: transposed interpolation
+//   head        two 1x1x1 convolutions + sigmoid, fused with the loss gradient
+// Parameters, gradients and Adam moments are flat fp32 device buffers in state_dict order (the gradient buffer
+// is what the data-parallel all-reduce runs on); after an optimizer step the packed weight images of the
+// forward and backward launches are rewritten on the device.
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+
+#include "unet_internal.h"
+#include "unet_ops.h"
+
+namespace bsmi {
+
+typedef float f32x16_t __attribute__((ext_vector_type(16)));
+
+// ------------------------------------------------------------------------------------------------------------
+// kernels
+// ------------------------------------------------------------------------------------------------------------
+
+// one unit (8 floats of K) of a packed weight image: dst[(u / 2) * Npad + n][(u % 2) * 8 + kk] =
+// src[wbase + n * sn + (c0 + kk) * sc + tap] for n < nreal, c0 + kk < creal; zero elsewhere
+struct PackUnit {
+  long long wbase;  // float offset into the flat parameter buffer, -1: padding unit
+  int sn, sc, tap, c0, creal, pad;
+};
+
+__global__ void pack_weights_kernel(const float* __restrict__ params, const PackUnit* __restrict__ units, int nunits, int Npad,
+                                    int nreal, float* __restrict__ dst) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;  // (unit, n)
+  if (i >= (size_t)nunits * Npad) return;
+  const int u = (int)(i / Npad), n = (int)(i - (size_t)u * Npad);
+  const PackUnit pu = units[u];
+  float v[8];
+#pragma unroll
+  for (int kk = 0; kk < 8; ++kk) {
+    v[kk] = 0.f;
+    if (pu.wbase >= 0 && n < nreal && pu.c0 + kk < pu.creal) v[kk] = params[pu.wbase + (long long)n * pu.sn + (long long)(pu.c0 + kk) * pu.sc + pu.tap];
+  }
+  float* d = dst + ((size_t)(u >> 1) * Npad + n) * 16 + (u & 1) * 8;
+#pragma unroll
+  for (int kk = 0; kk < 8; ++kk) d[kk] = v[kk];
+}
+
+// bias image of a forward launch: b[n] = params[b0 + n] (+ params[b1 + n])
+__global__ void pack_bias_kernel(const float* __restrict__ params, long long b0, long long b1, int nreal, int Npad, float* __restrict__ dst) {
+  const int n = blockIdx.x * blockDim.x + threadIdx.x;
+  if (n >= Npad) return;
+  float v = 0.f;
+  if (n < nreal) v = params[b0 + n] + (b1 >= 0 ? params[b1 + n] : 0.f);
+  dst[n] = v;
+}
+
+// head image [cout][2][cin] / [cout][2] from the two 1x1x1 weights
+__global__ void pack_head_kernel(const float* __restrict__ params, long long wc, long long wr, long long bc, long long br, int cout, int cin,
+                                 float* __restrict__ hw, float* __restrict__ hb) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < cout * cin) {
+    const int o = i / cin, c = i - o * cin;
+    hw[(o * 2 + 0) * cin + c] = params[wc + i];
+    hw[(o * 2 + 1) * cin + c] = params[wr + i];
+  }
+  if (i < cout) {
+    hb[i * 2 + 0] = params[bc + i];
+    hb[i * 2 + 1] = params[br + i];
+  }
+}
+
+// WeightedMSELoss, pass 1: sums[0] += sum of w (p - t)^2 over w > 0, sums[1] += count(w > 0), sums[2] += sum over all,
+// sums[3] += count(scale != 0)
+__global__ void loss_sums_kernel(const float* __restrict__ p, const float* __restrict__ t, const float* __restrict__ w, size_t n,
+                                 double* __restrict__ sums) {
+  double s_mask = 0, s_all = 0;
+  unsigned long long c_mask = 0, c_nz = 0;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    const float d = p[i] - t[i];
+    const float sc = w[i] * (d * d);
+    s_all += sc;
+    if (w[i] > 0.f) { s_mask += sc; ++c_mask; }
+    if (sc != 0.f) ++c_nz;
+  }
+  for (int o = 32; o > 0; o >>= 1) {
+    s_mask += __shfl_down(s_mask, o);
+    s_all += __shfl_down(s_all, o);
+    c_mask += __shfl_down(c_mask, o);
+    c_nz += __shfl_down(c_nz, o);
+  }
+  if ((threadIdx.x & 63) == 0) {
+    atomicAdd(&sums[0], s_mask);
+    atomicAdd(&sums[1], (double)c_mask);
+    atomicAdd(&sums[2], s_all);
+    atomicAdd(&sums[3], (double)c_nz);
+  }
+}
+
+// pass 2: loss value and dL/dp; dp = 2 w (p - t) / N with N = count(w > 0) if any weighted error is non-zero, else numel
+__global__ void loss_grad_kernel(const float* __restrict__ p, const float* __restrict__ t, const float* __restrict__ w, size_t n,
+                                 const double* __restrict__ sums, float* __restrict__ dp, float* __restrict__ loss_accum) {
+  const bool masked = sums[3] != 0.0;
+  const double denom = masked ? sums[1] : (double)n;
+  if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(loss_accum, (float)((masked ? sums[0] : sums[2]) / denom));
+  const float inv = (float)(1.0 / denom);
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    const float g = 2.f * w[i] * (p[i] - t[i]) * inv;
+    dp[i] = (masked && !(w[i] > 0.f)) ? 0.f : g;
+  }
+}
+
+// head backward: p = sigmoid((Wc + Wr) z + bc + br).  dlogit = dp p (1 - p); dz (channels-last) += (Wc + Wr)^T dlogit;
+// dWc, dWr += dlogit z^T; dbc, dbr += dlogit.  One thread per voxel, block-level reduction of the weight gradients.
+__global__ void head_bwd_kernel(const float* __restrict__ z, int zc, const float* __restrict__ p, const float* __restrict__ dp, size_t nvox,
+                                int cin, int cout, const float* __restrict__ hw, float* __restrict__ dz, float* __restrict__ gwc,
+                                float* __restrict__ gwr, float* __restrict__ gbc, float* __restrict__ gbr) {
+  extern __shared__ float red[];  // [cout * cin + cout]
+  const int nred = cout * cin + cout;
+  for (int i = threadIdx.x; i < nred; i += blockDim.x) red[i] = 0.f;
+  __syncthreads();
+  const size_t v = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (v < nvox) {
+    float zz[32], dl[16];
+    for (int c = 0; c < cin; ++c) zz[c] = z[v * zc + c];
+    for (int o = 0; o < cout; ++o) {
+      const float pp = p[(size_t)o * nvox + v];
+      dl[o] = dp[(size_t)o * nvox + v] * pp * (1.f - pp);
+    }
+    for (int c = 0; c < cin; ++c) {
+      float acc = 0.f;
+      for (int o = 0; o < cout; ++o) acc += (hw[(o * 2 + 0) * cin + c] + hw[(o * 2 + 1) * cin + c]) * dl[o];
+      dz[v * zc + c] += acc;
+    }
+    for (int o = 0; o < cout; ++o) {
+      for (int c = 0; c < cin; ++c) atomicAdd(&red[o * cin + c], dl[o] * zz[c]);
+      atomicAdd(&red[cout * cin + o], dl[o]);
+    }
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < cout * cin; i += blockDim.x) {
+    atomicAdd(&gwc[i], red[i]);
+    atomicAdd(&gwr[i], red[i]);
+  }
+  for (int i = threadIdx.x; i < cout; i += blockDim.x) {
+    atomicAdd(&gbc[i], red[cout * cin + i]);
+    atomicAdd(&gbr[i], red[cout * cin + i]);
+  }
+}
+
+// g = dY * [Y > 0], written into the interior of a zero-bordered tensor [D + 2pz][H + 2py][W + 2px][C]
+__global__ void relu_bwd_pad_kernel(const float* __restrict__ dy, const float* __restrict__ y, int D, int H, int W, int C, int pz, int py,
+                                    int px, float* __restrict__ out) {
+  const size_t total = (size_t)D * H * W * (C / 4);
+  const int Hp = H + 2 * py, Wp = W + 2 * px;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int c4 = (int)(i % (C / 4));
+    size_t v = i / (C / 4);
+    const int x = (int)(v % W); v /= W;
+    const int yy = (int)(v % H);
+    const int zz = (int)(v / H);
+    const size_t src = (((size_t)zz * H + yy) * W + x) * C + c4 * 4;
+    const float4 g = *(const float4*)(dy + src), a = *(const float4*)(y + src);
+    float4 r;
+    r.x = a.x > 0.f ? g.x : 0.f; r.y = a.y > 0.f ? g.y : 0.f; r.z = a.z > 0.f ? g.z : 0.f; r.w = a.w > 0.f ? g.w : 0.f;
+    *(float4*)(out + ((((size_t)(zz + pz) * Hp + (yy + py)) * Wp + (x + px)) * C + c4 * 4)) = r;
+  }
+}
+
+// column sums of the interior of a padded tensor: out[c0 + c] += sum over voxels of g[..][c0 + c], c < Cc (Cc <= 1024)
+__global__ void colsum_kernel(const float* __restrict__ g, int D, int H, int W, int C, int c0, int Cc, int pz, int py, int px, int nreal,
+                              float* __restrict__ out0, float* __restrict__ out1) {
+  const int Hp = H + 2 * py, Wp = W + 2 * px;
+  const int lanes = blockDim.x / Cc;  // voxels handled side by side
+  if ((int)threadIdx.x >= lanes * Cc) return;
+  const int c = c0 + (int)threadIdx.x % Cc;
+  const size_t nvox = (size_t)D * H * W;
+  float acc = 0.f;
+  for (size_t v = (size_t)blockIdx.x * lanes + threadIdx.x / Cc; v < nvox; v += (size_t)gridDim.x * lanes) {
+    const int x = (int)(v % W);
+    const size_t zy = v / W;
+    const int yy = (int)(zy % H), zz = (int)(zy / H);
+    acc += g[(((size_t)(zz + pz) * Hp + (yy + py)) * Wp + (x + px)) * C + c];
+  }
+  if (c < nreal && acc != 0.f) {
+    atomicAdd(&out0[c], acc);
+    if (out1) atomicAdd(&out1[c], acc);
+  }
+}
+
+// Weight gradient of one kernel tap: dW[n][cbase + c][tap] += sum over output voxels m of g[m][n] x[m + tap][c].
+// One wave per (32 x 32 block of (n, c), tap, chunk of output lines); v_mfma_f32_32x32x2_f32 contracts two voxels per
+// instruction, and since every lane of that instruction supplies ONE element (row lane % 32, k = lane / 32) both operands
+// are read straight from the channels-last tensors: 32 lanes = 128 contiguous bytes of one voxel.
+struct WgradArgs {
+  const float* g; long long gsz, gsy, gsx;  // interior of the padded gradient: origin pointer and strides (floats)
+  const float* x; long long xsz, xsy, xsx;  // source tensor at (slot origin + tap origin) and strides (floats)
+  int Do, Ho, Wo;
+  int N, C;            // real output / input channels of this slot
+  int kz, ky, kx;      // taps of this launch (1,1,1 for the residual)
+  float* dw;           // gradient of the weight [N][Cin_total][ntap]
+  int cin_total, cbase, ntap;
+  int lines_per_block;
+};
+
+__global__ __launch_bounds__(64) void wgrad_kernel(const WgradArgs a) {
+  const int lane = threadIdx.x, lr = lane & 31, lh = lane >> 5;
+  const int nblocks_c = (a.C + 31) / 32;
+  const int nb = blockIdx.x / nblocks_c, cb = blockIdx.x - nb * nblocks_c;
+  const int tap = blockIdx.y;
+  const int tz = tap / (a.ky * a.kx), ty = (tap / a.kx) % a.ky, tx = tap % a.kx;
+  const int n = nb * 32 + lr, c = cb * 32 + lr;
+  const bool nok = n < a.N, cok = c < a.C;
+  const float* gp = a.g + (nok ? n : 0);
+  const float* xp = a.x + (cok ? c : 0) + tz * a.xsz + ty * a.xsy + tx * a.xsx;
+  f32x16_t acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  const int nlines = a.Do * a.Ho;
+  const int l0 = blockIdx.z * a.lines_per_block, l1 = min(nlines, l0 + a.lines_per_block);
+  for (int l = l0; l < l1; ++l) {
+    const int z = l / a.Ho, y = l - z * a.Ho;
+    const float* gl = gp + z * a.gsz + y * a.gsy;
+    const float* xl = xp + z * a.xsz + y * a.xsy;
+    for (int x0 = 0; x0 < a.Wo; x0 += 2) {
+      const int xx = x0 + lh;
+      const bool ok = xx < a.Wo;
+      const float gv = (ok && nok) ? gl[xx * a.gsx] : 0.f;
+      const float xv = (ok && cok) ? xl[xx * a.xsx] : 0.f;
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(gv, xv, acc, 0, 0, 0);
+    }
+  }
+  // acc[r]: row (n) = (r & 3) + 8 (r >> 2) + 4 lh, column (c) = lr
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int nn = nb * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+    if (nn < a.N && cok && acc[r] != 0.f)
+      atomicAdd(&a.dw[((size_t)nn * a.cin_total + a.cbase + c) * a.ntap + tap], acc[r]);
+  }
+}
+
+// dst[region at (oz, oy, ox)][cdst + c] += src[..][csrc + c] for c < C (gradient of crop + concat)
+__global__ void scatter_add_kernel(const float* __restrict__ src, int D, int H, int W, int Cs, int csrc, float* __restrict__ dst, int Hd, int Wd,
+                                   int Cd, int cdst, int oz, int oy, int ox, int C) {
+  const size_t total = (size_t)D * H * W * C;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int c = (int)(i % C);
+    size_t v = i / C;
+    const int x = (int)(v % W); v /= W;
+    const int y = (int)(v % H);
+    const int z = (int)(v / H);
+    dst[(((size_t)(z + oz) * Hd + (y + oy)) * Wd + (x + ox)) * Cd + cdst + c] += src[(((size_t)z * H + y) * W + x) * Cs + csrc + c];
+  }
+}
+
+// max-pool backward: the gradient of a window goes to its first maximum (torch: strict > while scanning z, y, x)
+__global__ void maxpool_bwd_kernel(const float* __restrict__ in, const float* __restrict__ dout, float* __restrict__ din, int H, int W, int C,
+                                   int Do, int Ho, int Wo, int fz, int fy, int fx) {
+  const size_t total = (size_t)Do * Ho * Wo * C;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int c = (int)(i % C);
+    size_t v = i / C;
+    const int x = (int)(v % Wo); v /= Wo;
+    const int y = (int)(v % Ho);
+    const int z = (int)(v / Ho);
+    float best = -INFINITY;
+    size_t arg = 0;
+    for (int dz = 0; dz < fz; ++dz)
+      for (int dy = 0; dy < fy; ++dy)
+        for (int dx = 0; dx < fx; ++dx) {
+          const size_t s = ((size_t)((z * fz + dz) * H + (y * fy + dy)) * W + (x * fx + dx)) * C + c;
+          const float val = in[s];
+          if (val > best || (dz == 0 && dy == 0 && dx == 0)) { best = val; arg = s; }
+        }
+    din[arg] += dout[i];
+  }
+}
+
+// trilinear upsample (align_corners = False, integer factors) + crop, backward: every output voxel adds its gradient to
+// the up-to-8 input voxels it interpolated from (float atomics: windows of neighbouring outputs overlap)
+__global__ void upsample_bwd_kernel(const float* __restrict__ dout, float* __restrict__ din, int Di, int Hi, int Wi, int C, int Do, int Ho, int Wo,
+                                    int fz, int fy, int fx, int oz, int oy, int ox) {
+  const size_t total = (size_t)Do * Ho * Wo * C;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int c = (int)(i % C);
+    size_t v = i / C;
+    const int x = (int)(v % Wo) + ox; v /= Wo;
+    const int y = (int)(v % Ho) + oy;
+    const int z = (int)(v / Ho) + oz;
+    const float g = dout[i];
+    if (g == 0.f) continue;
+    int i0[3], i1[3];
+    float w1[3];
+    const int pos[3] = {z, y, x}, f[3] = {fz, fy, fx}, n[3] = {Di, Hi, Wi};
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+      float s = ((float)pos[d] + 0.5f) / (float)f[d] - 0.5f;  // torch area_pixel_compute_source_index, align_corners = False
+      s = s < 0.f ? 0.f : s;
+      i0[d] = (int)s;
+      i1[d] = i0[d] + (i0[d] < n[d] - 1 ? 1 : 0);
+      w1[d] = s - (float)i0[d];
+    }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const int iz = (k & 4) ? i1[0] : i0[0], iy = (k & 2) ? i1[1] : i0[1], ix = (k & 1) ? i1[2] : i0[2];
+      const float wt = ((k & 4) ? w1[0] : 1.f - w1[0]) * ((k & 2) ? w1[1] : 1.f - w1[1]) * ((k & 1) ? w1[2] : 1.f - w1[2]);
+      if (wt != 0.f) atomicAdd(&din[(((size_t)iz * Hi + iy) * Wi + ix) * C + c], g * wt);
+    }
+  }
+}
+
+// torch.optim.Adam (no weight decay, no amsgrad) on flat buffers; gscale folds the 1 / world_size of a summed all-reduce
+__global__ void adam_kernel(float* __restrict__ w, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v, size_t n, float lr,
+                            float beta1, float beta2, float eps, float bc1, float bc2_sqrt, float gscale) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    const float gi = g[i] * gscale;
+    const float mi = beta1 * m[i] + (1.f - beta1) * gi;
+    const float vi = beta2 * v[i] + (1.f - beta2) * gi * gi;
+    m[i] = mi;
+    v[i] = vi;
+    const float denom = sqrtf(vi) / bc2_sqrt + eps;
+    w[i] = w[i] - (lr / bc1) * (mi / denom);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// state
+// ------------------------------------------------------------------------------------------------------------
+struct ParamRef {
+  std::string key;
+  size_t off = 0, count = 0;
+  std::vector<int64_t> shape;
+};
+
+struct PackJob {  // one packed weight image that must follow the parameters
+  PackUnit* units = nullptr;  // device
+  int nunits = 0, Npad = 0, nreal = 0;
+  float* dst = nullptr;
+  // bias image (forward launches only)
+  long long b0 = -1, b1 = -1;
+  float* bias_dst = nullptr;
+};
+
+struct ConvBwd {  // backward data of one CONV plan step
+  const PlanStep* st = nullptr;
+  int P[3] = {0, 0, 0};  // border of the padded gradient
+  TDesc gp;              // padded gradient [D + 2P][H + 2P][W + 2P][Cpad]
+  bool need_dgrad = false;
+  ConvArgs dgrad{};      // implicit-GEMM launch of the input gradient
+  TileCfg dtile = TILE_256x32;
+  TDesc dcat;            // its output when the pass input is a crop / concat (stage 0), else the previous stage's gradient
+  bool scatter = false;
+};
+
+struct TrainState {
+  int64_t in_shape[3] = {0, 0, 0};
+  Plan* plan = nullptr;
+  std::vector<ParamRef> params;
+  std::map<std::string, size_t> index;
+  size_t nparams = 0;
+  float *w = nullptr, *g = nullptr, *m = nullptr, *v = nullptr;
+  int adam_t = 0;
+  std::map<void*, TDesc> grad_of;
+  std::vector<std::pair<void*, size_t>> zero_list;  // gradient tensors cleared at the start of every backward pass
+  std::vector<void*> allocs;
+  std::vector<PackJob> jobs;
+  std::vector<ConvBwd> convs;        // indexed like plan->steps (empty entries for other step types)
+  float* zero_bias = nullptr;        // [2048] zeros: bias operand of the dgrad launches
+  double* loss_sums = nullptr;       // [4] per head, reused
+  float* loss_dev = nullptr;         // [1]
+  std::vector<float*> head_out;      // per head: sigmoid outputs [C][D][H][W] of the last forward
+  std::vector<float*> head_dp;       // per head: dL/dp
+  size_t out_vox = 0;
+};
+
+static int talloc(TrainState* ts, void** p, size_t bytes, bool zero) {
+  BSMI_HIP(hipMalloc(p, bytes + 256));
+  ts->allocs.push_back(*p);
+  if (zero) BSMI_HIP(hipMemset(*p, 0, bytes + 256));
+  return BSMI_OK;
+}
+
+void free_train_state(bsmi_unet* h) {
+  if (!h->train) return;
+  for (void* p : h->train->allocs) (void)hipFree(p);
+  delete h->train;
+  h->train = nullptr;
+}
+
+static size_t param_off(TrainState* ts, const std::string& key) {
+  auto it = ts->index.find(key);
+  return it == ts->index.end() ? (size_t)-1 : ts->params[it->second].off;
+}
+
+// gradient tensor of an activation (same geometry, f32), created on first use
+static int grad_tensor(TrainState* ts, const TDesc& act, TDesc* out) {
+  auto it = ts->grad_of.find(act.ptr);
+  if (it != ts->grad_of.end()) {
+    *out = it->second;
+    return BSMI_OK;
+  }
+  TDesc g = act;
+  const size_t bytes = (size_t)act.D * act.H * act.W * act.Cpad * sizeof(float);
+  const size_t slack = (size_t)8 * act.W * act.Cpad * sizeof(float) + 4096;
+  int rc = talloc(ts, &g.ptr, bytes + slack, true);
+  if (rc) return rc;
+  ts->grad_of[act.ptr] = g;
+  ts->zero_list.push_back({g.ptr, bytes});
+  *out = g;
+  return BSMI_OK;
+}
+
+static int upload_units(TrainState* ts, const std::vector<PackUnit>& u, PackUnit** dev) {
+  int rc = talloc(ts, (void**)dev, u.size() * sizeof(PackUnit), false);
+  if (rc) return rc;
+  BSMI_HIP(hipMemcpy(*dev, u.data(), u.size() * sizeof(PackUnit), hipMemcpyHostToDevice));
+  return BSMI_OK;
+}
+
+// pack job of a forward launch: the unit list is the one the planner packed from (build_entries)
+static int make_forward_job(bsmi_unet* h, TrainState* ts, PassSite& p, int ci) {
+  PackedConv& pc = p.packed[BSMI_PREC_F32][ci];
+  const bool last = ci == p.nconv - 1;
+  const std::string base = p.prefix + ".conv_pass." + std::to_string(2 * ci);
+  const size_t wm = param_off(ts, base + ".weight"), bm = param_off(ts, base + ".bias");
+  const size_t wr = param_off(ts, p.prefix + ".residual.0.weight"), br = param_off(ts, p.prefix + ".residual.0.bias");
+  const HostWeight& hm = h->weights[base + ".weight"];
+  const HostWeight& hr = h->weights[p.prefix + ".residual.0.weight"];
+  const int64_t cin_m = hm.shape[1], ntap = hm.shape[2] * hm.shape[3] * hm.shape[4], cin_r = hr.shape[1];
+  std::vector<PackUnit> units(pc.entries.size());
+  for (size_t u = 0; u < pc.entries.size(); ++u) {
+    const PackEntry& e = pc.entries[u];
+    PackUnit pu{};
+    if (e.dummy) {
+      pu.wbase = -1;
+    } else if (e.wsrc == 0) {
+      pu.wbase = (long long)wm + (long long)e.cin_base * ntap;
+      pu.sn = (int)(cin_m * ntap); pu.sc = (int)ntap; pu.tap = e.tap;
+    } else {
+      pu.wbase = (long long)wr + e.cin_base;
+      pu.sn = (int)cin_r; pu.sc = 1; pu.tap = 0;
+    }
+    pu.c0 = e.c0;
+    pu.creal = e.creal;
+    units[u] = pu;
+  }
+  PackJob job;
+  int rc = upload_units(ts, units, &job.units);
+  if (rc) return rc;
+  job.nunits = (int)units.size();
+  job.Npad = pc.Npad;
+  job.nreal = p.cout;
+  job.dst = (float*)pc.w;
+  job.b0 = (long long)bm;
+  job.b1 = last ? (long long)br : -1;
+  job.bias_dst = pc.bias;
+  ts->jobs.push_back(job);
+  return BSMI_OK;
+}
+
+static int run_pack_jobs(TrainState* ts, hipStream_t s) {
+  for (const PackJob& j : ts->jobs) {
+    const size_t total = (size_t)j.nunits * j.Npad;
+    hipLaunchKernelGGL(pack_weights_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, (const float*)ts->w, (const PackUnit*)j.units,
+                       j.nunits, j.Npad, j.nreal, j.dst);
+    if (j.bias_dst)
+      hipLaunchKernelGGL(pack_bias_kernel, dim3((j.Npad + 255) / 256), dim3(256), 0, s, (const float*)ts->w, j.b0, j.b1, j.nreal, j.Npad, j.bias_dst);
+  }
+  BSMI_HIP(hipGetLastError());
+  return BSMI_OK;
+}
+
+// input-gradient launch of conv stage `ci` of pass p (see the file header).  For ci >= 1 the output is the gradient
+// of the previous stage's activation; for ci == 0 it is `dcat`, the gradient of the (cropped, concatenated) pass input.
+static int make_dgrad(bsmi_unet* h, TrainState* ts, ConvBwd& cb, const ConvBwd* last_cb) {
+  const PlanStep& st = *cb.st;
+  PassSite& p = *st.site;
+  const int ci = st.ci, n = p.nconv;
+  const int* k = p.k[ci];
+  const int ntap = k[0] * k[1] * k[2];
+  const int cin_total = ci == 0 ? p.cin[0] + (p.nslots > 1 ? p.cin[1] : 0) : p.cout;
+  const int SUB = 8;
+  const std::string base = p.prefix + ".conv_pass." + std::to_string(2 * ci);
+  const size_t wm = param_off(ts, base + ".weight"), wr = param_off(ts, p.prefix + ".residual.0.weight");
+  int crop[3] = {0, 0, 0};
+  for (int i = 0; i < n; ++i)
+    for (int d = 0; d < 3; ++d) crop[d] += p.k[i][d] - 1;
+  const bool with_res = ci == 0 && n > 1;  // the residual 1x1x1 reads the pass input, whose gradient this launch produces
+  const int cpad_g = cb.gp.Cpad;
+
+  std::vector<PackUnit> units;
+  std::vector<KStep> steps;
+  auto close_step = [&]() {
+    while (units.size() % kUnitsPerStep) {
+      PackUnit pu{};
+      pu.wbase = -1;
+      units.push_back(pu);
+    }
+  };
+  // source 0: this stage's padded gradient, all taps; the weight tap is the mirrored one
+  const int64_t es = 4;
+  const TDesc& g0 = cb.gp;
+  for (int c16 = 0; c16 < cpad_g; c16 += kUnitsPerStep * SUB)
+    for (int z = 0; z < k[0]; ++z)
+      for (int y = 0; y < k[1]; ++y)
+        for (int x = 0; x < k[2]; ++x) {
+          KStep ks{};
+          ks.tensor = 0;
+          int j = 0;
+          for (int c0 = c16; c0 < std::min(cpad_g, c16 + kUnitsPerStep * SUB); c0 += SUB, ++j) {
+            PackUnit pu{};
+            pu.wbase = (long long)wm;
+            pu.sn = ntap;                       // n of the launch = input channel of the weight
+            pu.sc = cin_total * ntap;           // K channel = output channel of the weight
+            pu.tap = ((k[0] - 1 - z) * k[1] + (k[1] - 1 - y)) * k[2] + (k[2] - 1 - x);
+            pu.c0 = c0;
+            pu.creal = p.cout;
+            units.push_back(pu);
+            const int oz = cb.P[0] - (k[0] - 1) + z, oy = cb.P[1] - (k[1] - 1) + y, ox = cb.P[2] - (k[2] - 1) + x;
+            ks.delta[j] = (int32_t)(((((int64_t)oz * g0.H + oy) * g0.W + ox) * g0.Cpad + c0) * es);
+          }
+          close_step();
+          steps.push_back(ks);
+        }
+  if (with_res) {
+    const TDesc& gl = last_cb->gp;
+    for (int c16 = 0; c16 < gl.Cpad; c16 += kUnitsPerStep * SUB) {
+      KStep ks{};
+      ks.tensor = 1;
+      int j = 0;
+      for (int c0 = c16; c0 < std::min(gl.Cpad, c16 + kUnitsPerStep * SUB); c0 += SUB, ++j) {
+        PackUnit pu{};
+        pu.wbase = (long long)wr;
+        pu.sn = 1;
+        pu.sc = cin_total;
+        pu.tap = 0;
+        pu.c0 = c0;
+        pu.creal = p.cout;
+        units.push_back(pu);
+        const int oz = last_cb->P[0] - crop[0] / 2, oy = last_cb->P[1] - crop[1] / 2, ox = last_cb->P[2] - crop[2] / 2;
+        ks.delta[j] = (int32_t)(((((int64_t)oz * gl.H + oy) * gl.W + ox) * gl.Cpad + c0) * es);
+      }
+      close_step();
+      steps.push_back(ks);
+    }
+  }
+  if (steps.size() % 2) {  // even number of K-steps (conv_igemm.hip)
+    for (int j = 0; j < kUnitsPerStep; ++j) {
+      PackUnit pu{};
+      pu.wbase = -1;
+      units.push_back(pu);
+    }
+    steps.push_back(KStep{});
+  }
+  cb.dtile = choose_tile(cin_total);
+  const int Npad = round_up(cin_total, tile_bn(cb.dtile));
+  // output tensor
+  TDesc out;
+  out.C = cin_total;
+  out.Cpad = round_up(cin_total, kChanPad);
+  out.D = st.out.D + k[0] - 1;
+  out.H = st.out.H + k[1] - 1;
+  out.W = st.out.W + k[2] - 1;
+  int rc;
+  if (ci == 0) {
+    const size_t bytes = (size_t)out.D * out.H * out.W * out.Cpad * sizeof(float);
+    rc = talloc(ts, &out.ptr, bytes, true);
+    if (rc) return rc;
+    cb.scatter = true;
+  } else {
+    // previous stage's activation is slot 0 of this launch
+    rc = grad_tensor(ts, st.slots[0], &out);
+    if (rc) return rc;
+  }
+  cb.dcat = out;
+  // packed weights + K-steps on the device
+  float* wdev = nullptr;
+  rc = talloc(ts, (void**)&wdev, (steps.size() * (size_t)Npad + kWeightRowSlack) * 16 * sizeof(float), true);
+  if (rc) return rc;
+  KStep* dks = nullptr;
+  rc = talloc(ts, (void**)&dks, steps.size() * sizeof(KStep), false);
+  if (rc) return rc;
+  BSMI_HIP(hipMemcpy(dks, steps.data(), steps.size() * sizeof(KStep), hipMemcpyHostToDevice));
+  PackJob job;
+  rc = upload_units(ts, units, &job.units);
+  if (rc) return rc;
+  job.nunits = (int)units.size();
+  job.Npad = Npad;
+  job.nreal = cin_total;
+  job.dst = wdev;
+  ts->jobs.push_back(job);
+  if (Npad > 2048) BSMI_FAIL(BSMI_ERR_INVALID, "dgrad launch wider than the zero-bias buffer");
+  ConvArgs& a = cb.dgrad;
+  memset(&a, 0, sizeof a);
+  const TDesc* srcs[kMaxConvTensors] = {&g0, with_res ? &last_cb->gp : &g0, &g0};
+  for (int sl = 0; sl < kMaxConvTensors; ++sl) {
+    const TDesc& t = *srcs[sl];
+    a.t[sl].base = (uint64_t)(uintptr_t)t.ptr;
+    a.t[sl].sz = (int32_t)((int64_t)t.H * t.W * t.Cpad * es);
+    a.t[sl].sy = (int32_t)((int64_t)t.W * t.Cpad * es);
+    a.t[sl].sx = (int32_t)((int64_t)t.Cpad * es);
+  }
+  a.steps = dks;
+  a.nsteps = (int)steps.size();
+  a.w = wdev;
+  a.bias = ts->zero_bias;
+  a.out = out.ptr;
+  a.Do = out.D; a.Ho = out.H; a.Wo = out.W; a.Co = out.Cpad;
+  a.M = out.D * out.H * out.W;
+  a.Npad = Npad;
+  a.relu = 0;
+  cb.need_dgrad = true;
+  (void)h;
+  return BSMI_OK;
+}
+
+}  // namespace bsmi
+
+using namespace bsmi;
+
+extern "C" {
+
+int bsmi_unet_train_begin(bsmi_unet* h, const int64_t in_shape[3]) {
+  if (!h || !in_shape) BSMI_FAIL(BSMI_ERR_INVALID, "null argument");
+  if (!h->finalized[BSMI_PREC_F32]) BSMI_FAIL(BSMI_ERR_STATE, "bsmi_unet_finalize(BSMI_PREC_F32) first: training runs in fp32");
+  BSMI_HIP(hipSetDevice(h->device));
+  free_train_state(h);
+  std::unique_ptr<TrainState> ts(new TrainState);
+  for (int d = 0; d < 3; ++d) ts->in_shape[d] = in_shape[d];
+  int rc = get_plan(h, BSMI_PREC_F32, in_shape, &ts->plan);
+  if (rc) return rc;
+  // flat parameter buffer in the order of the weight table (= sorted state_dict keys)
+  for (auto& kv : h->weights) {
+    ParamRef pr;
+    pr.key = kv.first;
+    pr.shape = kv.second.shape;
+    pr.count = kv.second.data.size();
+    pr.off = ts->nparams;
+    ts->nparams += (pr.count + 3) / 4 * 4;
+    ts->index[pr.key] = ts->params.size();
+    ts->params.push_back(pr);
+  }
+  const size_t pb = ts->nparams * sizeof(float);
+  if ((rc = talloc(ts.get(), (void**)&ts->w, pb, true))) return rc;
+  if ((rc = talloc(ts.get(), (void**)&ts->g, pb, true))) return rc;
+  if ((rc = talloc(ts.get(), (void**)&ts->m, pb, true))) return rc;
+  if ((rc = talloc(ts.get(), (void**)&ts->v, pb, true))) return rc;
+  for (const ParamRef& pr : ts->params)
+    BSMI_HIP(hipMemcpy(ts->w + pr.off, h->weights[pr.key].data.data(), pr.count * sizeof(float), hipMemcpyHostToDevice));
+  if ((rc = talloc(ts.get(), (void**)&ts->zero_bias, 2048 * sizeof(float), true))) return rc;
+  if ((rc = talloc(ts.get(), (void**)&ts->loss_sums, 4 * sizeof(double), true))) return rc;
+  if ((rc = talloc(ts.get(), (void**)&ts->loss_dev, sizeof(float), true))) return rc;
+
+  Plan& plan = *ts->plan;
+  ts->out_vox = (size_t)plan.out_shape[0] * plan.out_shape[1] * plan.out_shape[2];
+  for (const HeadSite& hd : h->heads) {
+    float *o = nullptr, *dp = nullptr;
+    if ((rc = talloc(ts.get(), (void**)&o, ts->out_vox * hd.cout * sizeof(float), true))) return rc;
+    if ((rc = talloc(ts.get(), (void**)&dp, ts->out_vox * hd.cout * sizeof(float), true))) return rc;
+    ts->head_out.push_back(o);
+    ts->head_dp.push_back(dp);
+  }
+  // forward pack jobs (conv stages, then heads are repacked by pack_head_kernel in the step)
+  for (auto* sites : {&h->l_conv, &h->r_conv})
+    for (PassSite& p : *sites)
+      for (int ci = 0; ci < p.nconv; ++ci)
+        if ((rc = make_forward_job(h, ts.get(), p, ci))) return rc;
+
+  // backward data of the conv steps, in plan order; the first CONV step of the plan is the net's first conv
+  ts->convs.resize(plan.steps.size());
+  bool first_conv = true;
+  for (size_t i = 0; i < plan.steps.size(); ++i) {
+    const PlanStep& st = plan.steps[i];
+    if (st.type != PlanStep::CONV) continue;
+    ConvBwd& cb = ts->convs[i];
+    cb.st = &st;
+    PassSite& p = *st.site;
+    const int n = p.nconv;
+    int crop[3] = {0, 0, 0};
+    for (int q = 0; q < n; ++q)
+      for (int d = 0; d < 3; ++d) crop[d] += p.k[q][d] - 1;
+    for (int d = 0; d < 3; ++d) cb.P[d] = st.ci == n - 1 ? std::max(p.k[st.ci][d] - 1, crop[d] / 2) : p.k[st.ci][d] - 1;
+    cb.gp = st.out;
+    cb.gp.D += 2 * cb.P[0]; cb.gp.H += 2 * cb.P[1]; cb.gp.W += 2 * cb.P[2];
+    const size_t bytes = (size_t)cb.gp.D * cb.gp.H * cb.gp.W * cb.gp.Cpad * sizeof(float);
+    const size_t slack = (size_t)8 * cb.gp.W * cb.gp.Cpad * sizeof(float) + 4096;
+    if ((rc = talloc(ts.get(), &cb.gp.ptr, bytes + slack, true))) return rc;
+    TDesc gy;
+    if ((rc = grad_tensor(ts.get(), st.out, &gy))) return rc;
+    cb.need_dgrad = !(first_conv && st.ci == 0);
+    first_conv = false;
+  }
+  // dgrad launches need the padded gradient of the pass's LAST stage (residual source): second sweep
+  for (size_t i = 0; i < plan.steps.size(); ++i) {
+    ConvBwd& cb = ts->convs[i];
+    if (!cb.st || !cb.need_dgrad) continue;
+    const ConvBwd* last_cb = nullptr;
+    for (size_t j = i; j < plan.steps.size(); ++j)
+      if (ts->convs[j].st && ts->convs[j].st->site == cb.st->site && ts->convs[j].st->ci == cb.st->site->nconv - 1) {
+        last_cb = &ts->convs[j];
+        break;
+      }
+    if (!last_cb) BSMI_FAIL(BSMI_ERR_STATE, "training plan: last stage of %s not found", cb.st->site->prefix.c_str());
+    cb.need_dgrad = false;
+    if ((rc = make_dgrad(h, ts.get(), cb, last_cb))) return rc;
+  }
+  // gradient tensors of the remaining activations (pool / upsample / head inputs and outputs)
+  for (const PlanStep& st : plan.steps) {
+    TDesc t;
+    if (st.type == PlanStep::POOL || st.type == PlanStep::UP) {
+      if ((rc = grad_tensor(ts.get(), st.in, &t))) return rc;
+      if ((rc = grad_tensor(ts.get(), st.out, &t))) return rc;
+    } else if (st.type == PlanStep::HEAD) {
+      if ((rc = grad_tensor(ts.get(), st.in, &t))) return rc;
+    }
+  }
+  h->train = ts.release();
+  return run_pack_jobs(h->train, nullptr) || hipDeviceSynchronize() != hipSuccess ? BSMI_ERR_HIP : BSMI_OK;
+}
+
+int bsmi_unet_train_num_params(bsmi_unet* h, uint64_t* count) {
+  if (!h || !h->train || !count) BSMI_FAIL(BSMI_ERR_STATE, "bsmi_unet_train_begin has not been called");
+  *count = h->train->nparams;
+  return BSMI_OK;
+}
+
+int bsmi_unet_train_buffers(bsmi_unet* h, float** params_dev, float** grads_dev) {
+  if (!h || !h->train) BSMI_FAIL(BSMI_ERR_STATE, "bsmi_unet_train_begin has not been called");
+  if (params_dev) *params_dev = h->train->w;
+  if (grads_dev) *grads_dev = h->train->g;
+  return BSMI_OK;
+}
+
+int bsmi_unet_train_param_info(bsmi_unet* h, const char* key, uint64_t* offset, uint64_t* count) {
+  if (!h || !h->train || !key) BSMI_FAIL(BSMI_ERR_STATE, "bsmi_unet_train_begin has not been called");
+  auto it = h->train->index.find(key);
+  if (it == h->train->index.end()) BSMI_FAIL(BSMI_ERR_MISSING, "no parameter \"%s\"", key);
+  if (offset) *offset = h->train->params[it->second].off;
+  if (count) *count = h->train->params[it->second].count;
+  return BSMI_OK;
+}
+
+int bsmi_unet_train_forward_backward(bsmi_unet* h, const float* raw_dev, const float* const* targets_dev, const float* const* weights_dev,
+                                     float* loss_host, void* stream) {
+  if (!h || !h->train || !raw_dev || !targets_dev || !weights_dev) BSMI_FAIL(BSMI_ERR_STATE, "bsmi_unet_train_begin has not been called / null argument");
+  TrainState* ts = h->train;
+  BSMI_HIP(hipSetDevice(h->device));
+  hipStream_t s = (hipStream_t)stream;
+  Plan& plan = *ts->plan;
+  const int nheads = (int)h->heads.size();
+  // forward (the inference engine), sigmoid outputs kept for the loss
+  int rc = bsmi_unet_forward(h, BSMI_PREC_F32, raw_dev, BSMI_RAW_F32, ts->in_shape, ts->head_out.data(), nullptr, stream);
+  if (rc) return rc;
+  // clear gradients
+  BSMI_HIP(hipMemsetAsync(ts->g, 0, ts->nparams * sizeof(float), s));
+  for (auto& z : ts->zero_list) BSMI_HIP(hipMemsetAsync(z.first, 0, z.second, s));
+  BSMI_HIP(hipMemsetAsync(ts->loss_dev, 0, sizeof(float), s));
+  // loss and dL/dp per head
+  for (int hd = 0; hd < nheads; ++hd) {
+    const size_t n = ts->out_vox * h->heads[hd].cout;
+    BSMI_HIP(hipMemsetAsync(ts->loss_sums, 0, 4 * sizeof(double), s));
+    hipLaunchKernelGGL(loss_sums_kernel, dim3(512), dim3(256), 0, s, (const float*)ts->head_out[hd], targets_dev[hd], weights_dev[hd], n, ts->loss_sums);
+    hipLaunchKernelGGL(loss_grad_kernel, dim3(512), dim3(256), 0, s, (const float*)ts->head_out[hd], targets_dev[hd], weights_dev[hd], n,
+                       (const double*)ts->loss_sums, ts->head_dp[hd], ts->loss_dev);
+  }
+  // backward through the plan
+  for (size_t i = plan.steps.size(); i-- > 0;) {
+    const PlanStep& st = plan.steps[i];
+    switch (st.type) {
+      case PlanStep::HEAD: {
+        const HeadSite& hd = h->heads[st.head];
+        TDesc dz = ts->grad_of[st.in.ptr];
+        const std::string pre = hd.prefix;
+        float* gwc = ts->g + param_off(ts, pre + ".conv_pass.0.weight");
+        float* gwr = ts->g + param_off(ts, pre + ".residual.0.weight");
+        float* gbc = ts->g + param_off(ts, pre + ".conv_pass.0.bias");
+        float* gbr = ts->g + param_off(ts, pre + ".residual.0.bias");
+        if (hd.cin > 32 || hd.cout > 16) BSMI_FAIL(BSMI_ERR_INVALID, "head backward: at most 32 input and 16 output channels");
+        const size_t nv = ts->out_vox;
+        hipLaunchKernelGGL(head_bwd_kernel, dim3((unsigned)((nv + 255) / 256)), dim3(256), (hd.cout * hd.cin + hd.cout) * sizeof(float), s,
+                           (const float*)st.in.ptr, st.in.Cpad, (const float*)ts->head_out[st.head], (const float*)ts->head_dp[st.head], nv, hd.cin,
+                           hd.cout, (const float*)hd.hw, (float*)dz.ptr, gwc, gwr, gbc, gbr);
+        break;
+      }
+      case PlanStep::UP: {
+        TDesc din = ts->grad_of[st.in.ptr], dout = ts->grad_of[st.out.ptr];
+        const size_t total = (size_t)st.out.D * st.out.H * st.out.W * st.out.Cpad;
+        hipLaunchKernelGGL(upsample_bwd_kernel, dim3((unsigned)std::min<size_t>((total + 255) / 256, 16384)), dim3(256), 0, s, (const float*)dout.ptr,
+                           (float*)din.ptr, st.in.D, st.in.H, st.in.W, st.in.Cpad, st.out.D, st.out.H, st.out.W, st.f[0], st.f[1], st.f[2], st.o[0],
+                           st.o[1], st.o[2]);
+        break;
+      }
+      case PlanStep::POOL: {
+        TDesc din = ts->grad_of[st.in.ptr], dout = ts->grad_of[st.out.ptr];
+        const size_t total = (size_t)st.out.D * st.out.H * st.out.W * st.out.Cpad;
+        hipLaunchKernelGGL(maxpool_bwd_kernel, dim3((unsigned)std::min<size_t>((total + 255) / 256, 16384)), dim3(256), 0, s, (const float*)st.in.ptr,
+                           (const float*)dout.ptr, (float*)din.ptr, st.in.H, st.in.W, st.in.Cpad, st.out.D, st.out.H, st.out.W, st.f[0], st.f[1], st.f[2]);
+        break;
+      }
+      case PlanStep::CONV: {
+        ConvBwd& cb = ts->convs[i];
+        PassSite& p = *st.site;
+        const int ci = st.ci, n = p.nconv;
+        const bool last = ci == n - 1;
+        const int* k = p.k[ci];
+        TDesc gy = ts->grad_of[st.out.ptr];
+        const size_t total4 = (size_t)st.out.D * st.out.H * st.out.W * (st.out.Cpad / 4);
+        hipLaunchKernelGGL(relu_bwd_pad_kernel, dim3((unsigned)std::min<size_t>((total4 + 255) / 256, 16384)), dim3(256), 0, s, (const float*)gy.ptr,
+                           (const float*)st.out.ptr, st.out.D, st.out.H, st.out.W, st.out.Cpad, cb.P[0], cb.P[1], cb.P[2], (float*)cb.gp.ptr);
+        const std::string base = p.prefix + ".conv_pass." + std::to_string(2 * ci);
+        float* gb = ts->g + param_off(ts, base + ".bias");
+        float* gbr = last ? ts->g + param_off(ts, p.prefix + ".residual.0.bias") : nullptr;
+        for (int c0 = 0; c0 < st.out.Cpad; c0 += 512) {
+          const int Cc = std::min(512, st.out.Cpad - c0);
+          const int threads = std::max(Cc, 256 / Cc * Cc);
+          hipLaunchKernelGGL(colsum_kernel, dim3(256), dim3(threads), 0, s, (const float*)cb.gp.ptr, st.out.D, st.out.H, st.out.W, st.out.Cpad, c0, Cc,
+                             cb.P[0], cb.P[1], cb.P[2], p.cout, gb, gbr);
+        }
+        // weight gradients
+        const int64_t gsx = cb.gp.Cpad, gsy = (int64_t)cb.gp.W * gsx, gsz = (int64_t)cb.gp.H * gsy;
+        const float* ginterior = (const float*)cb.gp.ptr + cb.P[0] * gsz + cb.P[1] * gsy + cb.P[2] * gsx;
+        const int cin_total = ci == 0 ? p.cin[0] + (p.nslots > 1 ? p.cin[1] : 0) : p.cout;
+        auto wgrad = [&](const TDesc& x, const int* org, int C, int cbase, float* dw, int ct, const int* kk) {
+          WgradArgs a;
+          a.g = ginterior; a.gsz = gsz; a.gsy = gsy; a.gsx = gsx;
+          a.xsx = x.Cpad; a.xsy = (int64_t)x.W * a.xsx; a.xsz = (int64_t)x.H * a.xsy;
+          a.x = (const float*)x.ptr + org[0] * a.xsz + org[1] * a.xsy + org[2] * a.xsx;
+          a.Do = st.out.D; a.Ho = st.out.H; a.Wo = st.out.W;
+          a.N = p.cout; a.C = C;
+          a.kz = kk[0]; a.ky = kk[1]; a.kx = kk[2];
+          a.dw = dw; a.cin_total = ct; a.cbase = cbase; a.ntap = kk[0] * kk[1] * kk[2];
+          const int nlines = a.Do * a.Ho;
+          const int blocks_nc = ((a.N + 31) / 32) * ((a.C + 31) / 32);
+          int zsplit = std::max(1, std::min(nlines, 4096 / std::max(1, blocks_nc * a.ntap)));
+          a.lines_per_block = (nlines + zsplit - 1) / zsplit;
+          zsplit = (nlines + a.lines_per_block - 1) / a.lines_per_block;
+          hipLaunchKernelGGL(wgrad_kernel, dim3(blocks_nc, a.ntap, zsplit), dim3(64), 0, s, a);
+        };
+        float* dwm = ts->g + param_off(ts, base + ".weight");
+        if (ci == 0) {
+          int cbase = 0;
+          for (int sl = 0; sl < p.nslots; ++sl) {
+            wgrad(st.slots[sl], st.so[sl], p.cin[sl], cbase, dwm, cin_total, k);
+            cbase += p.cin[sl];
+          }
+        } else {
+          wgrad(st.slots[0], st.so[0], p.cout, 0, dwm, cin_total, k);
+        }
+        if (last) {
+          int crop[3] = {0, 0, 0};
+          for (int q = 0; q < n; ++q)
+            for (int d = 0; d < 3; ++d) crop[d] += p.k[q][d] - 1;
+          float* dwr = ts->g + param_off(ts, p.prefix + ".residual.0.weight");
+          const int first_slot = ci == 0 ? 0 : 1;
+          const int ones[3] = {1, 1, 1};
+          const int rin = p.cin[0] + (p.nslots > 1 ? p.cin[1] : 0);
+          int cbase = 0;
+          for (int sl = 0; sl < p.nslots; ++sl) {
+            int org[3];
+            for (int d = 0; d < 3; ++d) org[d] = st.so[first_slot + sl][d] + crop[d] / 2;
+            wgrad(st.slots[first_slot + sl], org, p.cin[sl], cbase, dwr, rin, ones);
+            cbase += p.cin[sl];
+          }
+        }
+        // input gradient
+        if (cb.need_dgrad) {
+          rc = launch_conv_igemm(cb.dgrad, BSMI_PREC_F32, cb.dtile, s, nullptr, 0);
+          if (rc) return rc;
+          if (cb.scatter) {
+            int cbase = 0;
+            for (int sl = 0; sl < p.nslots; ++sl) {
+              TDesc gt = ts->grad_of[st.slots[sl].ptr];
+              if (!gt.ptr) BSMI_FAIL(BSMI_ERR_STATE, "training plan: no gradient tensor for an input of %s", p.prefix.c_str());
+              const size_t total = (size_t)cb.dcat.D * cb.dcat.H * cb.dcat.W * p.cin[sl];
+              hipLaunchKernelGGL(scatter_add_kernel, dim3((unsigned)std::min<size_t>((total + 255) / 256, 16384)), dim3(256), 0, s,
+                                 (const float*)cb.dcat.ptr, cb.dcat.D, cb.dcat.H, cb.dcat.W, cb.dcat.Cpad, cbase, (float*)gt.ptr, gt.H, gt.W, gt.Cpad, 0,
+                                 st.so[sl][0], st.so[sl][1], st.so[sl][2], p.cin[sl]);
+              cbase += p.cin[sl];
+            }
+          }
+        }
+        break;
+      }
+      default: break;
+    }
+  }
+  BSMI_HIP(hipGetLastError());
+  if (loss_host) {
+    BSMI_HIP(hipMemcpyAsync(loss_host, ts->loss_dev, sizeof(float), hipMemcpyDeviceToHost, s));
+    BSMI_HIP(hipStreamSynchronize(s));
+  }
+  return BSMI_OK;
+}
+
+int bsmi_unet_train_adam_step(bsmi_unet* h, float lr, float beta1, float beta2, float eps, float grad_scale, void* stream) {
+  if (!h || !h->train) BSMI_FAIL(BSMI_ERR_STATE, "bsmi_unet_train_begin has not been called");
+  TrainState* ts = h->train;
+  BSMI_HIP(hipSetDevice(h->device));
+  hipStream_t s = (hipStream_t)stream;
+  ts->adam_t += 1;
+  const float bc1 = 1.f - powf(beta1, (float)ts->adam_t);
+  const float bc2 = 1.f - powf(beta2, (float)ts->adam_t);
+  hipLaunchKernelGGL(adam_kernel, dim3(1024), dim3(256), 0, s, ts->w, (const float*)ts->g, ts->m, ts->v, ts->nparams, lr, beta1, beta2, eps, bc1, sqrtf(bc2),
+                     grad_scale);
+  int rc = run_pack_jobs(ts, s);
+  if (rc) return rc;
+  for (HeadSite& hd : h->heads) {
+    const std::string pre = hd.prefix;
+    hipLaunchKernelGGL(pack_head_kernel, dim3((hd.cout * hd.cin + 255) / 256), dim3(256), 0, s, (const float*)ts->w,
+                       (long long)param_off(ts, pre + ".conv_pass.0.weight"), (long long)param_off(ts, pre + ".residual.0.weight"),
+                       (long long)param_off(ts, pre + ".conv_pass.0.bias"), (long long)param_off(ts, pre + ".residual.0.bias"), hd.cout, hd.cin, hd.hw, hd.hb);
+  }
+  BSMI_HIP(hipGetLastError());
+  return BSMI_OK;
+}
+
+int bsmi_unet_train_read_param(bsmi_unet* h, const char* key, int what, float* host_out) {
+  if (!h || !h->train || !key || !host_out) BSMI_FAIL(BSMI_ERR_STATE, "bsmi_unet_train_begin has not been called / null argument");
+  auto it = h->train->index.find(key);
+  if (it == h->train->index.end()) BSMI_FAIL(BSMI_ERR_MISSING, "no parameter \"%s\"", key);
+  const ParamRef& pr = h->train->params[it->second];
+  const float* src = what == 0 ? h->train->w : (what == 1 ? h->train->g : (what == 2 ? h->train->m : h->train->v));
+  BSMI_HIP(hipSetDevice(h->device));
+  BSMI_HIP(hipDeviceSynchronize());
+  BSMI_HIP(hipMemcpy(host_out, src + pr.off, pr.count * sizeof(float), hipMemcpyDeviceToHost));
+  return BSMI_OK;
+}
+
+int bsmi_unet_train_end(bsmi_unet* h) {
+  if (h && h->train) {
+    // the trained parameters become the handle's weights: host copies refreshed, the bf16 images re-packed on demand
+    BSMI_HIP(hipSetDevice(h->device));
+    BSMI_HIP(hipDeviceSynchronize());
+    for (const ParamRef& pr : h->train->params)
+      BSMI_HIP(hipMemcpy(h->weights[pr.key].data.data(), h->train->w + pr.off, pr.count * sizeof(float), hipMemcpyDeviceToHost));
+    for (auto* sites : {&h->l_conv, &h->r_conv})
+      for (PassSite& p : *sites)
+        for (int ci = 0; ci < p.nconv; ++ci) {
+          PackedConv& pc = p.packed[BSMI_PREC_BF16][ci];
+          if (pc.w) (void)hipFree(pc.w);
+          if (pc.bias) (void)hipFree(pc.bias);
+          pc = PackedConv();
+        }
+    h->finalized[BSMI_PREC_BF16] = false;
+  }
+  if (!h) BSMI_FAIL(BSMI_ERR_INVALID, "null handle");
+  BSMI_HIP(hipSetDevice(h->device));
+  BSMI_HIP(hipDeviceSynchronize());
+  free_train_state(h);
+  return BSMI_OK;
+}
+
+}  // extern "C"

@@ -16,8 +16,7 @@
 #include <memory>
 #include <vector>
 
-#include "conv_rh.h"
-#include "conv_igemm.h"
+#include "unet_internal.h"
 #include "unet_ops.h"
 
 namespace bsmi {
@@ -40,116 +39,15 @@ static inline uint16_t host_f32_to_bf16(float f) {
   return (uint16_t)(u >> 16);
 }
 
-struct HostWeight {
-  std::vector<int64_t> shape;
-  std::vector<float> data;
-  bool loaded = false;
-};
-
-// One 32-byte unit of K: 16 (bf16) / 8 (f32) consecutive channels of one kernel tap of one
-// source tensor.  kUnitsPerStep units of the same tensor slot form a K-step.
-struct PackEntry {
-  int slot;        // tensor slot of the launch
-  int dz, dy, dx;  // tap offset (voxels) relative to the slot's origin
-  int c0;          // first channel of the unit
-  int wsrc;        // 0 = this stage's conv weight, 1 = residual 1x1x1 weight
-  int tap;         // flat tap index into the weight's kernel dims
-  int cin_base;    // first input channel of this slot inside the weight's Cin dim
-  int creal;       // real channels of the slot
-  bool dummy;      // filler: delta 0, all-zero weights
-  int phase;       // index into PackedConv::phases
-};
-
-// A phase groups the units of one (slot, 32-channel chunk): kind 0 = all kernel taps, kind 1 = the
-// residual tap (bookkeeping of build_entries; conv_rh.hip splits kind 0 further by z-tap).
-struct PackPhase {
-  int slot, c0, kind, first_unit, nunits;
-};
-
-struct PackedConv {
-  bool ready = false;
-  std::vector<PackEntry> entries;
-  std::vector<PackPhase> phases;
-  void* w = nullptr;
-  float* bias = nullptr;
-  int Npad = 0;
-  TileCfg tile = TILE_256x32;
-};
-
-struct PassSite {
-  std::string prefix;
-  int nslots = 1;
-  int cin[2] = {0, 0};
-  int cout = 0;
-  int nconv = 0;
-  int k[BSMI_MAX_CONVS][3];
-  PackedConv packed[2][BSMI_MAX_CONVS];
-};
-
-struct HeadSite {
-  std::string prefix;
-  int cin = 0, cout = 0;
-  float* hw = nullptr;  // device [cout][2][cin]
-  float* hb = nullptr;  // device [cout][2]
-};
-
-struct TDesc {
-  void* ptr = nullptr;
-  int C = 0, Cpad = 0, D = 0, H = 0, W = 0;
-};
-
-struct PlanStep {
-  enum Type { INPUT, CONV, POOL, UP, HEAD } type;
-  ConvArgs conv;
-  RhArgs rh;
-  bool use_rh = false;
-  TileCfg tile;
-  TDesc in, out;
-  int f[3], o[3];
-  int head = 0;
-  double flops = 0;  // algorithmic FLOPs of this launch
-};
-
-struct Plan {
-  std::vector<float> last_ms;  // per-step durations of the last harvested forward
-  bool pending = false;        // events recorded but not yet harvested
-  std::vector<void*> allocs;
-  std::vector<PlanStep> steps;
-  int64_t out_shape[3] = {0, 0, 0};
-  double flops = 0;
-  size_t bytes = 0;
-  std::vector<hipEvent_t> events;  // 2 per step, created on demand (profiling)
-  bool profiled = false;           // last forward recorded events
-};
-
 }  // namespace bsmi
 
 using namespace bsmi;
 
-struct bsmi_unet {
-  bsmi_unet_config cfg;
-  int device = 0;
-  int nl = 0;
-  std::vector<PassSite> l_conv, r_conv;
-  std::vector<HeadSite> heads;
-  int crop_factor[BSMI_MAX_LEVELS][3];
-  std::map<std::string, HostWeight> weights;
-  bool finalized[2] = {false, false};
-  bool profiling = false;
-  Plan* last_plan = nullptr;
-  double prof_ms[5] = {0, 0, 0, 0, 0}, prof_flops[5] = {0, 0, 0, 0, 0};
-  int64_t prof_launches[5] = {0, 0, 0, 0, 0};
-  std::map<std::vector<int64_t>, std::unique_ptr<Plan>> plans;  // key: prec, D, H, W
-  float* sk_ws = nullptr;  // split-K tail partial tiles + work-queue counters (conv_igemm.h)
-  int sk_grid = 0;         // 0: not set up yet, -1: disabled
-  int sk_request = -1;     // bsmi_unet_set_persistent_grid: -1 = CU count of the device, 0 = off
-};
-
 namespace bsmi {
 
-static int esize(int prec) { return prec == BSMI_PREC_F32 ? 4 : 2; }
-static int bke(int prec) { return kStepRowBytes / esize(prec); }   // elements per K-step row
-static int sube(int prec) { return 32 / esize(prec); }   // elements per 32-byte sub-step
+int esize(int prec) { return prec == BSMI_PREC_F32 ? 4 : 2; }
+int bke(int prec) { return kStepRowBytes / esize(prec); }
+int sube(int prec) { return 32 / esize(prec); }
 
 static void expect_weight(bsmi_unet* h, const std::string& key, std::vector<int64_t> shape) {
   HostWeight hw;
@@ -176,8 +74,7 @@ static void register_pass(bsmi_unet* h, const PassSite& p) {
 // packs two taps per K-step), then, for the last stage, the cropped 1x1x1 residual in 32-channel
 // chunks.  Each (slot, 32-channel chunk) is also one PackPhase:
 // LONG = all kernel taps of the chunk, SHORT = its residual tap.
-static void build_entries(const PassSite& p, int ci, int prec, std::vector<PackEntry>& out,
-                          std::vector<PackPhase>* phases_out = nullptr) {
+void build_entries(const PassSite& p, int ci, int prec, std::vector<PackEntry>& out, std::vector<PackPhase>* phases_out) {
   const int SUB = sube(prec);
   const bool last = ci == p.nconv - 1;
   std::vector<PackPhase> phases;
@@ -533,6 +430,14 @@ struct Planner {
         a.Npad = pc.Npad;
         a.relu = 1;  // trunk activation is ReLU (model.py passes activation default "ReLU")
         st.flops = 2.0 * M * p.cout * kreal;
+        st.site = &p;
+        st.ci = ci;
+        st.nsl = nsl;
+        for (int sl = 0; sl < nsl; ++sl) {
+          st.slots[sl] = slots[sl];
+          for (int d = 0; d < 3; ++d) st.so[sl][d] = so[sl][d];
+        }
+        st.out = o;
         rc = plan_rh(p, ci, pc, slots, so, nsl, o, st);
         if (rc) return rc;
         if (getenv("BSMI_PLAN_DEBUG"))
@@ -676,6 +581,23 @@ static int harvest(bsmi_unet* h, Plan* plan) {
   return BSMI_OK;
 }
 
+int get_plan(bsmi_unet* h, int precision, const int64_t in_shape[3], Plan** out) {
+  const std::vector<int64_t> key = {precision, in_shape[0], in_shape[1], in_shape[2]};
+  auto it = h->plans.find(key);
+  if (it == h->plans.end()) {
+    std::unique_ptr<Plan> plan(new Plan);
+    Planner pl{h, precision, plan.get(), false};
+    const int rc = pl.run(in_shape);
+    if (rc) {
+      free_plan(plan.get());
+      return rc;
+    }
+    it = h->plans.emplace(key, std::move(plan)).first;
+  }
+  *out = it->second.get();
+  return BSMI_OK;
+}
+
 static int check_shape_arg(const int64_t s[3]) {
   for (int d = 0; d < 3; ++d)
     if (s[d] <= 0 || s[d] > 4096) BSMI_FAIL(BSMI_ERR_INVALID, "bad input shape (%lld,%lld,%lld)", (long long)s[0], (long long)s[1], (long long)s[2]);
@@ -807,6 +729,7 @@ int bsmi_unet_destroy(bsmi_unet* h) {
   };
   for (auto& p : h->l_conv) free_site(p);
   for (auto& p : h->r_conv) free_site(p);
+  free_train_state(h);
   if (h->sk_ws) (void)hipFree(h->sk_ws);
   for (auto& hd : h->heads) {
     if (hd.hw) (void)hipFree(hd.hw);
@@ -925,19 +848,10 @@ int bsmi_unet_forward(bsmi_unet* h, int precision, const void* raw_dev, int raw_
   if (rc) return rc;
   BSMI_HIP(hipSetDevice(h->device));
   hipStream_t s = (hipStream_t)stream;
-  const std::vector<int64_t> key = {precision, in_shape[0], in_shape[1], in_shape[2]};
-  auto it = h->plans.find(key);
-  if (it == h->plans.end()) {
-    std::unique_ptr<Plan> plan(new Plan);
-    Planner pl{h, precision, plan.get(), false};
-    rc = pl.run(in_shape);
-    if (rc) {
-      free_plan(plan.get());
-      return rc;
-    }
-    it = h->plans.emplace(key, std::move(plan)).first;
-  }
-  Plan& plan = *it->second;
+  Plan* plan_ptr = nullptr;
+  rc = get_plan(h, precision, in_shape, &plan_ptr);
+  if (rc) return rc;
+  Plan& plan = *plan_ptr;
   if (h->profiling) {
     rc = harvest(h, &plan);  // previous forward on this plan must be read before its events are reused
     if (rc) return rc;

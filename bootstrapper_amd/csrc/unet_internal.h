@@ -1,0 +1,138 @@
+// Internal structures of the U-Net engine shared by unet_api.hip (planner, forward) and train.hip (backward,
+// optimizer).  Not part of the C ABI.
+#pragma once
+#include <map>
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "conv_igemm.h"
+#include "conv_rh.h"
+
+namespace bsmi {
+
+struct HostWeight {
+  std::vector<int64_t> shape;
+  std::vector<float> data;
+  bool loaded = false;
+};
+
+// One 32-byte unit of K: 16 (bf16) / 8 (f32) consecutive channels of one kernel tap of one
+// source tensor.  kUnitsPerStep units of the same tensor slot form a K-step.
+struct PackEntry {
+  int slot;        // tensor slot of the launch
+  int dz, dy, dx;  // tap offset (voxels) relative to the slot's origin
+  int c0;          // first channel of the unit
+  int wsrc;        // 0 = this stage's conv weight, 1 = residual 1x1x1 weight
+  int tap;         // flat tap index into the weight's kernel dims
+  int cin_base;    // first input channel of this slot inside the weight's Cin dim
+  int creal;       // real channels of the slot
+  bool dummy;      // filler: delta 0, all-zero weights
+  int phase;       // index into PackedConv::phases
+};
+
+// A phase groups the units of one (slot, 32-channel chunk): kind 0 = all kernel taps, kind 1 = the
+// residual tap (bookkeeping of build_entries; conv_rh.hip splits kind 0 further by z-tap).
+struct PackPhase {
+  int slot, c0, kind, first_unit, nunits;
+};
+
+struct PackedConv {
+  bool ready = false;
+  std::vector<PackEntry> entries;
+  std::vector<PackPhase> phases;
+  void* w = nullptr;
+  float* bias = nullptr;
+  int Npad = 0;
+  TileCfg tile = TILE_256x32;
+};
+
+struct PassSite {
+  std::string prefix;
+  int nslots = 1;
+  int cin[2] = {0, 0};
+  int cout = 0;
+  int nconv = 0;
+  int k[BSMI_MAX_CONVS][3];
+  PackedConv packed[2][BSMI_MAX_CONVS];
+};
+
+struct HeadSite {
+  std::string prefix;
+  int cin = 0, cout = 0;
+  float* hw = nullptr;  // device [cout][2][cin]
+  float* hb = nullptr;  // device [cout][2]
+};
+
+struct TDesc {
+  void* ptr = nullptr;
+  int C = 0, Cpad = 0, D = 0, H = 0, W = 0;
+};
+
+struct PlanStep {
+  enum Type { INPUT, CONV, POOL, UP, HEAD } type;
+  ConvArgs conv;
+  RhArgs rh;
+  bool use_rh = false;
+  TileCfg tile;
+  TDesc in, out;
+  int f[3], o[3];
+  int head = 0;
+  double flops = 0;  // algorithmic FLOPs of this launch
+  // what the backward pass (train.hip) needs to know about a CONV step
+  struct PassSite* site = nullptr;
+  int ci = 0;                        // stage index inside the ConvPass
+  TDesc slots[kMaxConvTensors];      // source tensors of the launch
+  int so[kMaxConvTensors][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}};  // their origins (voxels)
+  int nsl = 0;
+};
+
+struct Plan {
+  std::vector<float> last_ms;  // per-step durations of the last harvested forward
+  bool pending = false;        // events recorded but not yet harvested
+  std::vector<void*> allocs;
+  std::vector<PlanStep> steps;
+  int64_t out_shape[3] = {0, 0, 0};
+  double flops = 0;
+  size_t bytes = 0;
+  std::vector<hipEvent_t> events;  // 2 per step, created on demand (profiling)
+  bool profiled = false;           // last forward recorded events
+};
+
+struct TrainState;
+
+int esize(int prec);
+int bke(int prec);   // elements per K-step row
+int sube(int prec);  // elements per 32-byte unit
+// unit list of stage `ci` of a ConvPass (see unet_api.hip)
+void build_entries(const PassSite& p, int ci, int prec, std::vector<PackEntry>& out, std::vector<PackPhase>* phases_out = nullptr);
+
+}  // namespace bsmi
+
+using namespace bsmi;
+
+struct bsmi_unet {
+  bsmi_unet_config cfg;
+  int device = 0;
+  int nl = 0;
+  std::vector<PassSite> l_conv, r_conv;
+  std::vector<HeadSite> heads;
+  int crop_factor[BSMI_MAX_LEVELS][3];
+  std::map<std::string, HostWeight> weights;
+  bool finalized[2] = {false, false};
+  bool profiling = false;
+  Plan* last_plan = nullptr;
+  double prof_ms[5] = {0, 0, 0, 0, 0}, prof_flops[5] = {0, 0, 0, 0, 0};
+  int64_t prof_launches[5] = {0, 0, 0, 0, 0};
+  std::map<std::vector<int64_t>, std::unique_ptr<Plan>> plans;  // key: prec, D, H, W
+  float* sk_ws = nullptr;  // split-K tail partial tiles + work-queue counters (conv_igemm.h)
+  int sk_grid = 0;         // 0: not set up yet, -1: disabled
+  int sk_request = -1;     // bsmi_unet_set_persistent_grid: -1 = CU count of the device, 0 = off
+  bsmi::TrainState* train = nullptr;  // train.hip
+};
+
+namespace bsmi {
+// the cached launch plan of (precision, input shape); built on first use
+int get_plan(bsmi_unet* h, int precision, const int64_t in_shape[3], Plan** out);
+void free_train_state(bsmi_unet* h);
+}  // namespace bsmi

@@ -97,6 +97,30 @@ int bsmi_unet_forward(bsmi_unet *h, int precision, const void *raw_dev, int raw_
                       const int64_t in_shape[3], float *const *out_f32_dev,
                       uint8_t *const *out_u8_dev, void *stream);
 
+/* ---- training (reference models/3d_affs/train.py:152-159, model.py:67-92; fp32 like the reference) ------------
+ * begin: after bsmi_unet_finalize(h, BSMI_PREC_F32); builds the backward plan for in_shape and moves the
+ *   parameters into a flat fp32 device buffer (sorted state_dict keys, each padded to 4 floats).
+ * forward_backward: raw_dev float32 [Cin][D][H][W] (already normalised, as the training pipeline delivers it);
+ *   targets_dev[i] / weights_dev[i]: float32 [head_dims[i]][d][h][w] per head, in Model.forward order; the loss is
+ *   the sum over heads of WeightedMSELoss; gradients of all parameters land in the flat gradient buffer
+ *   (zeroed first).  loss_host (optional) synchronises the stream.
+ * buffers: the flat parameter / gradient device buffers (the gradient buffer is what data-parallel training
+ *   all-reduces); param_info: offset and count of one state_dict key inside them.
+ * adam_step: torch.optim.Adam semantics (no weight decay); grad_scale multiplies the gradients first (1/world_size
+ *   after a summing all-reduce); the packed weight images of all launches are rewritten from the new parameters.
+ * read_param: what = 0 parameter, 1 gradient, 2 / 3 Adam moments -> host.  end: frees the training state; the trained
+ *   parameters stay the handle's weights (re-finalize BSMI_PREC_BF16 before predicting in bf16). */
+int bsmi_unet_train_begin(bsmi_unet *h, const int64_t in_shape[3]);
+int bsmi_unet_train_forward_backward(bsmi_unet *h, const float *raw_dev, const float *const *targets_dev,
+                                     const float *const *weights_dev, float *loss_host, void *stream);
+int bsmi_unet_train_num_params(bsmi_unet *h, uint64_t *count);
+int bsmi_unet_train_buffers(bsmi_unet *h, float **params_dev, float **grads_dev);
+int bsmi_unet_train_param_info(bsmi_unet *h, const char *key, uint64_t *offset, uint64_t *count);
+int bsmi_unet_train_adam_step(bsmi_unet *h, float lr, float beta1, float beta2, float eps, float grad_scale,
+                              void *stream);
+int bsmi_unet_train_read_param(bsmi_unet *h, const char *key, int what, float *host_out);
+int bsmi_unet_train_end(bsmi_unet *h);
+
 /* Number of CUs the stream bsmi_unet_forward is called on may use (a multiple of 8; -1 restores the
  * default = all CUs of the device, 0 disables the persistent launches).  The big-tile conv layers run
  * as that many persistent workgroups (conv_igemm.hip); set it when the stream carries a CU mask. */
