@@ -214,39 +214,66 @@ struct WgradArgs {
   int lines_per_block;
 };
 
+// KX = kx taps of one (kz, ky) tap row are accumulated by the same wave: one g value and KX pairs of x values per
+// voxel pair feed 2 * KX MFMAs (a 32 x 64 block of (n, c) per tap); 96 accumulator registers, so several waves share
+// a SIMD and hide each other's load latency.
+template <int KX>
 __global__ __launch_bounds__(64) void wgrad_kernel(const WgradArgs a) {
   const int lane = threadIdx.x, lr = lane & 31, lh = lane >> 5;
-  const int nblocks_c = (a.C + 31) / 32;
+  const int nblocks_c = (a.C + 63) / 64;
   const int nb = blockIdx.x / nblocks_c, cb = blockIdx.x - nb * nblocks_c;
-  const int tap = blockIdx.y;
-  const int tz = tap / (a.ky * a.kx), ty = (tap / a.kx) % a.ky, tx = tap % a.kx;
-  const int n = nb * 32 + lr, c = cb * 32 + lr;
-  const bool nok = n < a.N, cok = c < a.C;
-  const float* gp = a.g + (nok ? n : 0);
-  const float* xp = a.x + (cok ? c : 0) + tz * a.xsz + ty * a.xsy + tx * a.xsx;
-  f32x16_t acc;
+  const int trow = blockIdx.y;  // (tz, ty)
+  const int tz = trow / a.ky, ty = trow - tz * a.ky;
+  const int n0 = nb * 32 + lr, c0 = cb * 64 + lr;
+  const bool nok0 = n0 < a.N, cok0 = c0 < a.C, cok1 = c0 + 32 < a.C;
+  const float* gp = a.g + (nok0 ? n0 : 0);
+  const float* xp = a.x + (cok0 ? c0 : 0) + tz * a.xsz + ty * a.xsy;
+  f32x16_t acc[KX][2];
 #pragma unroll
-  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  for (int t = 0; t < KX; ++t)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[t][j][r] = 0.f;
   const int nlines = a.Do * a.Ho;
   const int l0 = blockIdx.z * a.lines_per_block, l1 = min(nlines, l0 + a.lines_per_block);
   for (int l = l0; l < l1; ++l) {
     const int z = l / a.Ho, y = l - z * a.Ho;
     const float* gl = gp + z * a.gsz + y * a.gsy;
     const float* xl = xp + z * a.xsz + y * a.xsy;
+#pragma unroll 2
     for (int x0 = 0; x0 < a.Wo; x0 += 2) {
       const int xx = x0 + lh;
       const bool ok = xx < a.Wo;
-      const float gv = (ok && nok) ? gl[xx * a.gsx] : 0.f;
-      const float xv = (ok && cok) ? xl[xx * a.xsx] : 0.f;
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(gv, xv, acc, 0, 0, 0);
+      const float g0 = (ok && nok0) ? gl[xx * a.gsx] : 0.f;
+      float x0v[KX], x1v[KX];
+#pragma unroll
+      for (int t = 0; t < KX; ++t) {
+        x0v[t] = (ok && cok0) ? xl[(xx + t) * a.xsx] : 0.f;
+        x1v[t] = (ok && cok1) ? xl[(xx + t) * a.xsx + 32] : 0.f;
+      }
+#pragma unroll
+      for (int t = 0; t < KX; ++t) {
+        acc[t][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(g0, x0v[t], acc[t][0], 0, 0, 0);
+        acc[t][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(g0, x1v[t], acc[t][1], 0, 0, 0);
+      }
     }
   }
   // acc[r]: row (n) = (r & 3) + 8 (r >> 2) + 4 lh, column (c) = lr
 #pragma unroll
-  for (int r = 0; r < 16; ++r) {
-    const int nn = nb * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-    if (nn < a.N && cok && acc[r] != 0.f)
-      atomicAdd(&a.dw[((size_t)nn * a.cin_total + a.cbase + c) * a.ntap + tap], acc[r]);
+  for (int t = 0; t < KX; ++t) {
+    const int tap = trow * KX + t;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int c = cb * 64 + j * 32 + lr;
+      if (c >= a.C) continue;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int nn = nb * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        if (nn < a.N && acc[t][j][r] != 0.f)
+          atomicAdd(&a.dw[((size_t)nn * a.cin_total + a.cbase + c) * a.ntap + tap], acc[t][j][r]);
+      }
+    }
   }
 }
 
@@ -691,6 +718,7 @@ int bsmi_unet_train_begin(bsmi_unet* h, const int64_t in_shape[3]) {
     for (int q = 0; q < n; ++q)
       for (int d = 0; d < 3; ++d) crop[d] += p.k[q][d] - 1;
     for (int d = 0; d < 3; ++d) cb.P[d] = st.ci == n - 1 ? std::max(p.k[st.ci][d] - 1, crop[d] / 2) : p.k[st.ci][d] - 1;
+    if (p.k[st.ci][2] > 3) BSMI_FAIL(BSMI_ERR_INVALID, "training: kernels wider than 3 along x are not supported");
     cb.gp = st.out;
     cb.gp.D += 2 * cb.P[0]; cb.gp.H += 2 * cb.P[1]; cb.gp.W += 2 * cb.P[2];
     const size_t bytes = (size_t)cb.gp.D * cb.gp.H * cb.gp.W * cb.gp.Cpad * sizeof(float);
@@ -841,11 +869,18 @@ int bsmi_unet_train_forward_backward(bsmi_unet* h, const float* raw_dev, const f
           a.kz = kk[0]; a.ky = kk[1]; a.kx = kk[2];
           a.dw = dw; a.cin_total = ct; a.cbase = cbase; a.ntap = kk[0] * kk[1] * kk[2];
           const int nlines = a.Do * a.Ho;
-          const int blocks_nc = ((a.N + 31) / 32) * ((a.C + 31) / 32);
-          int zsplit = std::max(1, std::min(nlines, 4096 / std::max(1, blocks_nc * a.ntap)));
+          const int blocks_nc = ((a.N + 31) / 32) * ((a.C + 63) / 64);
+          const int trows = a.kz * a.ky;
+          int zsplit = std::max(1, std::min(nlines, 8192 / std::max(1, blocks_nc * trows)));
           a.lines_per_block = (nlines + zsplit - 1) / zsplit;
           zsplit = (nlines + a.lines_per_block - 1) / a.lines_per_block;
-          hipLaunchKernelGGL(wgrad_kernel, dim3(blocks_nc, a.ntap, zsplit), dim3(64), 0, s, a);
+          const dim3 grid(blocks_nc, trows, zsplit);
+          switch (a.kx) {
+            case 1: hipLaunchKernelGGL(wgrad_kernel<1>, grid, dim3(64), 0, s, a); break;
+            case 2: hipLaunchKernelGGL(wgrad_kernel<2>, grid, dim3(64), 0, s, a); break;
+            case 3: hipLaunchKernelGGL(wgrad_kernel<3>, grid, dim3(64), 0, s, a); break;
+            default: return;  // checked in bsmi_unet_train_begin
+          }
         };
         float* dwm = ts->g + param_off(ts, base + ".weight");
         if (ci == 0) {

@@ -18,6 +18,51 @@ from . import _lib
 from ._lib import lib, check
 
 
+def sum_gradients(flat):
+    """Sum the flat gradient buffer over the ranks of the default process group, in place, and return the factor that
+    turns the sum into DDP's mean (1 / world_size; 1.0 without a process group).  `nccl` (= RCCL over xGMI) reduces
+    the device buffer directly; `gloo` (tests, CPU rehearsal) goes through a host copy."""
+    dist = torch.distributed
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return 1.0
+    if flat.is_cuda and dist.get_backend() != "nccl":
+        torch.cuda.current_stream(flat.device).synchronize()
+        host = flat.cpu()
+        dist.all_reduce(host, op=dist.ReduceOp.SUM)
+        flat.copy_(host)
+    else:
+        if flat.is_cuda:
+            torch.cuda.current_stream(flat.device).synchronize()  # the backward kernels run on this stream, RCCL on its own
+        dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+    return 1.0 / dist.get_world_size()
+
+
+def save_checkpoint(trainer, path, iteration):
+    """`model_checkpoint_<iteration>` in the layout the reference's predict worker loads
+    (models/3d_affs/predict.py:98-108: a dict with "state_dict" whose keys carry the Lightning "model." prefix)."""
+    sd = {"model." + k: torch.from_numpy(trainer.read(k).reshape(shape)) for k, shape in trainer.param_shapes().items()}
+    torch.save({"state_dict": sd, "global_step": int(iteration)}, path)
+
+
+def fit(trainer, batches, max_iterations, save_checkpoints_every=0, setup_dir=None, log_every=10, log=print):
+    """The training loop of training.py:96-137 without Lightning: `batches` is any iterable of reference-style batch
+    dicts ("raw", "gt_affs", "affs_weights"[, "gt_lsds", "lsds_weights"]) of CUDA float32 tensors."""
+    import os
+    it = 0
+    for batch in batches:
+        if it >= max_iterations:
+            break
+        loss = trainer.training_step(batch)
+        it += 1
+        if log and (it % log_every == 0 or it == 1):
+            log(f"step {it}: train_loss {loss:.6f}")
+        if save_checkpoints_every and setup_dir and it % save_checkpoints_every == 0:
+            rank = torch.distributed.get_rank() if torch.distributed.is_available() and torch.distributed.is_initialized() else 0
+            if rank == 0:
+                save_checkpoint(trainer, os.path.join(setup_dir, f"model_checkpoint_{it}.ckpt"), it)
+    return it
+
+
 class _DevBuf:
     """a raw device buffer as seen through __cuda_array_interface__ (zero-copy torch view)"""
 
@@ -42,6 +87,7 @@ class Trainer:
         self.grads = torch.as_tensor(_DevBuf(pg.value, n.value), device=dev)
         self.out_shape = model.output_shape(self.in_shape)
         self.last_loss = None
+        self._shapes = dict(model.param_shapes)
 
     def _stream(self):
         return C.c_void_p(torch.cuda.current_stream(torch.device("cuda", self.model.device)).cuda_stream)
@@ -70,10 +116,7 @@ class Trainer:
 
     def optimizer_step(self):
         """Average the gradients over the ranks (if torch.distributed is up) and apply Adam."""
-        scale = 1.0
-        if torch.distributed.is_available() and torch.distributed.is_initialized() and torch.distributed.get_world_size() > 1:
-            torch.distributed.all_reduce(self.grads, op=torch.distributed.ReduceOp.SUM)
-            scale = 1.0 / torch.distributed.get_world_size()
+        scale = sum_gradients(self.grads)
         check(lib.bsmi_unet_train_adam_step(self.model._h, self.lr, self.betas[0], self.betas[1], self.eps, scale, self._stream()))
 
     def training_step(self, batch):
@@ -91,6 +134,9 @@ class Trainer:
         out = np.empty(cnt.value, dtype=np.float32)
         check(lib.bsmi_unet_train_read_param(self.model._h, key.encode(), idx, out.ctypes.data_as(C.c_void_p)))
         return out
+
+    def param_shapes(self):
+        return dict(self._shapes)
 
     def close(self):
         if self.model is not None:

@@ -91,6 +91,7 @@ class Model:
         self.device = int(device)
         self.precision = PRECISIONS[precision]
         self._cfg, self.heads = make_config(net_config)
+        self.param_shapes = {}  # state_dict key -> shape, as loaded
         self._h = C.c_void_p()
         check(lib.bsmi_unet_create(C.byref(self._cfg), self.device, C.byref(self._h)))
         self._finalized = set()
@@ -110,6 +111,7 @@ class Model:
             a = np.ascontiguousarray(v, dtype=np.float32)
             shape = (C.c_int64 * a.ndim)(*a.shape)
             check(lib.bsmi_unet_load_weight(self._h, k.encode(), a.ctypes.data_as(C.c_void_p), shape, a.ndim))
+            self.param_shapes[k] = tuple(a.shape)
         self._finalized.clear()
         self._finalize(self.precision)
         return self

@@ -49,3 +49,31 @@ def test_two_rank_block_sharding():
     assert not set(m0) & set(m1) and len(set(m0) | set(m1)) == ngrid == 64
     assert not set(s0) & set(s1) and len(s0) + len(s1) == nblocks == 512
     assert g0 == g1 and t0 == t1 == 2.0
+
+
+def _grad_worker(rank, world, port, q):
+    import torch
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from bootstrapper_amd.training import sum_gradients
+    g = torch.arange(10, dtype=torch.float32) * (rank + 1)
+    scale = sum_gradients(g)
+    q.put((rank, g.tolist(), scale))
+    dist.destroy_process_group()
+
+
+def test_gradient_sum_two_ranks_gloo():
+    """the data-parallel reduction of the training step (bootstrapper_amd.training.sum_gradients), world size 2"""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    ps = [ctx.Process(target=_grad_worker, args=(r, 2, 29633, q)) for r in range(2)]
+    for p in ps:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in ps)
+    for p in ps:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, g, scale in res:
+        assert g == [3.0 * i for i in range(10)] and scale == 0.5

@@ -50,3 +50,30 @@ def test_training_step_vs_reference_goldens(golden_dir, tag):
             assert np.abs(got - ref).max() <= 1e-5 * max(1.0, np.abs(ref).max()) + meta["lr"] * 5e-2, (step, k)
     print("largest relative gradient error:", max(worst))
     tr.close()
+
+
+def test_data_parallel_two_ranks(tmp_path, golden_dir):
+    """Two ranks (processes) with different samples: the flat gradient buffer is summed over the ranks, Adam sees the
+    mean, and both ranks end with the same parameters = Adam(mean gradient) of the oracle's optimizer."""
+    import subprocess
+    import sys
+    from oracle import train_ref as T
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", "29611", os.path.join(root, "tests", "ddp_train_worker.py"), str(tmp_path)],
+                       env=env, capture_output=True, text=True, timeout=600, cwd=root)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    a, b = np.load(tmp_path / "rank0.npz"), np.load(tmp_path / "rank1.npz")
+    d = np.load(os.path.join(golden_dir, "train_affs_f4i2.npz"))
+    keys = [k[3:] for k in d.files if k.startswith("w0:")]
+    mean = {}
+    for k in keys:
+        assert np.abs(a["l:" + k] - b["l:" + k]).max() > 0 or "bias" in k       # the ranks really saw different samples
+        s = a["l:" + k] + b["l:" + k]
+        assert np.allclose(a["s:" + k], s, rtol=1e-6, atol=1e-9) and np.array_equal(a["s:" + k], b["s:" + k])
+        assert np.array_equal(a["p:" + k], b["p:" + k])
+        mean[k] = s / 2
+    ref = T.adam_step({k: d["w0:" + k].ravel() for k in keys}, mean, {}, lr=1e-3)
+    for k in keys:
+        assert np.abs(a["p:" + k] - ref[k]).max() <= 1e-6 + 1e-3 * 2e-3, k
