@@ -127,8 +127,74 @@ def cpu_baseline(model_flops_per_voxel, affs_u8_host):
     }
 
 
+def train_main(args):
+    """Secondary benchmark (`--mode train`): samples/s of the fp32 training step of the full 3d_affs net on the
+    reference's training block (32,196,196) -> (4,104,104), batch 1 per GPU, gradients averaged over the ranks."""
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: there is no CPU fallback for the HIP path")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    import torch.distributed as dist
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+    from bootstrapper_amd.unet import Model
+    from bootstrapper_amd.training import Trainer
+    from bootstrapper_amd.synth import synthetic_state_dict
+    shape = (32, 196, 196)
+    model = Model(NET_CONFIG, device=local_rank, precision="f32").load_state_dict(synthetic_state_dict(NET_CONFIG, 0))
+    tr = Trainer(model, shape)
+    g = torch.Generator(device=dev).manual_seed(rank)
+    out = (6,) + tuple(tr.out_shape)
+    batch = {"raw": torch.rand(shape, generator=g, device=dev) * 2 - 1,
+             "gt_affs": (torch.rand(out, generator=g, device=dev) > 0.5).float(),
+             "affs_weights": torch.rand(out, generator=g, device=dev)}
+
+    def barrier():
+        torch.cuda.synchronize(dev)
+        if world > 1:
+            dist.barrier()
+    for _ in range(args.warmup):
+        tr.training_step(batch)
+    barrier()
+    t0 = time.perf_counter()
+    loss = 0.0
+    for _ in range(args.steps):
+        loss = tr.training_step(batch)
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    fwd = model.flops(shape)
+    step_flops = 3.0 * fwd  # forward + input gradients + weight gradients
+    achieved = step_flops * args.steps / dt / 1e12
+    out_json = {"metric": "training samples/s, 3d_affs U-Net fp32, (32,196,196) blocks, batch 1 per GPU", "value": world * args.steps / dt,
+                "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
+                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+                "config": {"workload": "3d_affs U-Net (94.7M params) forward + WeightedMSELoss + backward + Adam, fp32, block (32,196,196) -> "
+                                       "(6,4,104,104), flat-gradient all-reduce over RCCL for N > 1", "last_loss": loss},
+                "roofline": {"bound": "mfma", "achieved": achieved, "peak": 157.3, "unit": "TFLOP/s", "frac": achieved / 157.3, "traffic": None,
+                             "kernel": "whole step: conv_igemm (forward, input gradients) + wgrad_kernel, f32 MFMA",
+                             "algorithmic_tflop_per_step": step_flops / 1e12}}
+    if rank == 0:
+        print(json.dumps(out_json), flush=True)
+    tr.close()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
+    ap.add_argument("--mode", default="predict", choices=["predict", "train"],
+                    help="predict = the headline predict + segment benchmark; train = training-step samples/s (secondary)")
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=32)
     ap.add_argument("--warmup", type=int, default=2)
@@ -141,6 +207,10 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--seg-stages", default="ws,agg", help="diagnostic: which segmentation stages the lanes run")
     args = ap.parse_args()
+    if args.mode == "train":
+        if args.steps == 32 and "--steps" not in sys.argv:
+            args.steps = 10
+        return train_main(args)
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
