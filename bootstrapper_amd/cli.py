@@ -1,4 +1,4 @@
-"""`bs`-compatible command line for the hot path: `predict` and `segment` with the reference's
+"""`bs`-compatible command line for the hot path: `train`, `predict` and `segment` with the reference's
 flags (/root/reference/bootstrapper/cli.py:51-92, predict.py:243-266, segment.py:166-241).
     python -m bootstrapper_amd.cli predict 02_pred.toml -s 01 -ng 8
     python -m bootstrapper_amd.cli segment 03_seg.toml -ws -p 'thresholds=[0.2,0.5]'
@@ -51,7 +51,23 @@ def segment(config_file, ws, mws, cc, **kwargs):
         run_segmentation(config_file, method, **kwargs)
 
 
+@cli.command()
+@click.argument("config_file", type=click.Path(exists=True, dir_okay=False))
+@click.option("--device", "-d", type=int, default=0, show_default=True)
+def train(config_file, device):
+    """Train the model of a setup directory as specified in config_file (fp32, one process per GPU; launch with
+    torch.distributed.run for data-parallel training)."""
+    import os
+    import torch
+    from .train import run_training
+    if "RANK" in os.environ and not torch.distributed.is_initialized():
+        torch.distributed.init_process_group("nccl")
+        device = int(os.environ.get("LOCAL_RANK", device))
+    run_training(config_file, device=device)
+
+
 # aliases of the reference CLI (cli.py:38-44)
+cli.add_command(train, "t")
 cli.add_command(predict, "p")
 cli.add_command(segment, "s")
 

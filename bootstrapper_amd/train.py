@@ -1,0 +1,192 @@
+"""`bs train` on the device: config checks, a minimal sample source and the training loop.
+
+Reference being mirrored (paths relative to /root/reference/bootstrapper):
+  train.py:13-120                 setup_train: sample path checks (same error texts), setup_dir / iteration settings
+  models/3d_affs/train.py:160-199 train(setup_dir, voxel_size, max_iterations, samples, save_checkpoints_every, ...)
+  training.py:96-137              fit(): seed 42, checkpoints `model_checkpoint_<step>`, resume from the latest one
+
+What is NOT restated: the gunpowder augmentation chain of models/3d_affs/train.py:88-117 (SimpleAugment,
+DeformAugment, ShiftAugment, noise / intensity / gamma / impulse / smooth / defect augmentations) and the snapshot
+callback -- third-party pipeline code outside the hot path.  `SampleSource` does the deterministic part only: random
+location with the >= 5 % labelled-voxel rejection, Normalize + IntensityScaleShift(2, -1), AddAffinities on the
+configured neighbourhood, BalanceLabels.  The arithmetic of the step itself is libbsmi (csrc/train.hip).
+"""
+import glob
+import json
+import os
+import re
+
+import numpy as np
+import torch
+
+try:
+    import tomllib as _toml
+except ImportError:  # python < 3.11
+    import tomli as _toml
+
+from .zarr_io import open_ds
+
+
+def setup_train(config_file):
+    """train.py:13-120: load the TOML, check the sample datasets, return the config."""
+    with open(config_file, "rb") as f:
+        config = _toml.load(f)
+    samples = config.get("samples", [])
+    if "samples" in config and not samples:
+        raise ValueError(f"No training samples provided in {config_file}")
+    for sample in samples:
+        raw, labels, mask = sample["raw"], sample["labels"], sample.get("mask")
+        if not os.path.exists(raw):
+            raise ValueError(f"Raw dataset path {raw} does not exist")
+        if ".zarray" not in os.listdir(raw):
+            raise ValueError(f"Raw dataset path {raw} does not contain a zarr array")
+        if not os.path.exists(labels):
+            raise ValueError(f"Labels dataset path {labels} does not exist")
+        if ".zarray" not in os.listdir(labels) and not glob.glob(os.path.join(labels, "**", ".zarray"), recursive=True):
+            raise ValueError(f"Labels dataset prefix {labels} does not contain any array")
+        if mask is not None and not os.path.exists(mask):
+            raise ValueError(f"Mask dataset path {mask} does not exist")
+    return config
+
+
+def affinities_from_labels(labels, neighborhood):
+    """gunpowder AddAffinities (seg_to_affgraph): aff[e][p] = labels[p] == labels[p + nhood[e]] and labels[p] > 0;
+    positions whose neighbour falls outside the block get affinity 0 and mask 0.  labels: int64 tensor (D, H, W)."""
+    D, H, W = labels.shape
+    affs = torch.zeros((len(neighborhood),) + tuple(labels.shape), dtype=torch.float32, device=labels.device)
+    mask = torch.zeros_like(affs)
+    for e, off in enumerate(neighborhood):
+        src, dst = [], []
+        for o, n in zip(off, (D, H, W)):
+            lo, hi = max(0, -o), min(n, n - o)
+            dst.append(slice(lo, hi))
+            src.append(slice(lo + o, hi + o))
+        a, b = labels[tuple(dst)], labels[tuple(src)]
+        affs[(e,) + tuple(dst)] = ((a == b) & (a > 0)).float()
+        mask[(e,) + tuple(dst)] = 1.0
+    return affs, mask
+
+
+def balance_labels(affs, mask, clip=(0.05, 0.95)):
+    """gunpowder BalanceLabels, two classes over the whole batch: w = mask / (2 * clipped class fraction)."""
+    total = mask.sum().clamp(min=1.0)
+    frac_pos = ((affs * mask).sum() / total).clamp(clip[0], clip[1])
+    w_pos, w_neg = 1.0 / (2.0 * frac_pos), 1.0 / (2.0 * (1.0 - frac_pos))
+    return mask * torch.where(affs > 0, w_pos, w_neg)
+
+
+class SampleSource:
+    """Infinite iterator of reference-style batches from (raw, labels[, mask]) Zarr volumes."""
+
+    def __init__(self, samples, input_shape, output_shape, neighborhood, device=0, seed=42, head="affs"):
+        self.samples = [(open_ds(s["raw"]), open_ds(s["labels"]), open_ds(s["mask"]) if s.get("mask") else None) for s in samples]
+        self.inp, self.out = tuple(input_shape), tuple(output_shape)
+        self.nhood = [list(map(int, o)) for o in neighborhood]
+        self.rng = np.random.default_rng(seed)
+        self.dev = torch.device("cuda", device)
+        if head != "affs":
+            raise NotImplementedError("only the affinity head has a ground-truth generator here (LSD targets need lsd.train [EXT])")
+
+    def __iter__(self):
+        return self
+
+    def __next__(self):
+        ctx = [(i - o) // 2 for i, o in zip(self.inp, self.out)]
+        for _ in range(1000):
+            raw_ds, lab_ds, mask_ds = self.samples[self.rng.integers(len(self.samples))]
+            shape = lab_ds.shape[-3:]
+            if any(s < o for s, o in zip(shape, self.out)):
+                raise ValueError("labels volume smaller than the network's output block")
+            off = [int(self.rng.integers(0, s - o + 1)) for s, o in zip(shape, self.out)]
+            sl = tuple(slice(a, a + o) for a, o in zip(off, self.out))
+            labels = lab_ds[sl].astype(np.int64)
+            unl = (mask_ds[sl] > 0) if mask_ds is not None else (labels > 0)
+            if unl.mean() < 0.05:  # gp.Reject(mask=unlabelled, min_masked=0.05)
+                continue
+            # raw with context; outside the volume: zeros (gp.Pad(raw, None))
+            raw = np.zeros(self.inp, dtype=np.uint8)
+            rshape = raw_ds.shape[-3:]
+            src, dst = [], []
+            for a, c, n, i in zip(off, ctx, rshape, self.inp):
+                lo, hi = max(a - c, 0), min(a - c + i, n)
+                src.append(slice(lo, hi))
+                dst.append(slice(lo - (a - c), hi - (a - c)))
+            raw[tuple(dst)] = raw_ds[tuple(src)]
+            x = torch.from_numpy(raw).to(self.dev).float() * (1.0 / 255.0) * 2.0 - 1.0
+            lab = torch.from_numpy(labels).to(self.dev)
+            affs, amask = affinities_from_labels(lab, self.nhood)
+            amask = amask * torch.from_numpy(unl.astype(np.float32)).to(self.dev)[None]
+            return {"raw": x, "gt_affs": affs, "affs_weights": balance_labels(affs, amask)}
+        raise RuntimeError("no training location with at least 5 % labelled voxels found")
+
+
+def default_init(net_config, seed=42):
+    """torch's default Conv3d initialisation (kaiming_uniform(a=sqrt(5)), bias uniform(+-1/sqrt(fan_in))) for every
+    parameter of the reference Model, keyed like its state_dict."""
+    from .unet import HEAD_OF_OUTPUT
+    g = torch.Generator().manual_seed(seed)
+    nf, inc = int(net_config["num_fmaps"]), int(net_config["fmap_inc_factor"])
+    dfs = net_config["downsample_factors"]
+    nl = len(dfs) + 1
+    ksd = net_config.get("kernel_size_down") or [[[3, 3, 3], [3, 3, 3]]] * nl
+    ksu = net_config.get("kernel_size_up") or [[[3, 3, 3], [3, 3, 3]]] * (nl - 1)
+    sd = {}
+
+    def conv(key, cout, cin, k):
+        fan_in = cin * int(np.prod(k))
+        bound = 1.0 / np.sqrt(fan_in)
+        sd[key + ".weight"] = ((torch.rand((cout, cin) + tuple(k), generator=g) * 2 - 1) * bound).numpy()
+        sd[key + ".bias"] = ((torch.rand(cout, generator=g) * 2 - 1) * bound).numpy()
+
+    def conv_pass(prefix, cin, cout, kernels):
+        c = cin
+        for i, k in enumerate(kernels):
+            conv(f"{prefix}.conv_pass.{2 * i}", cout, c, k)
+            c = cout
+        conv(f"{prefix}.residual.0", cout, cin, (1, 1, 1))
+
+    for lvl in range(nl):
+        conv_pass(f"unet.l_conv.{lvl}", int(net_config["in_channels"]) if lvl == 0 else nf * inc ** (lvl - 1), nf * inc ** lvl, ksd[lvl])
+    for lvl in range(nl - 1):
+        conv_pass(f"unet.r_conv.0.{lvl}", nf * inc ** lvl + nf * inc ** (lvl + 1), nf * inc ** lvl, ksu[lvl])
+    for name, val in net_config["outputs"].items():
+        conv_pass(HEAD_OF_OUTPUT[name], nf, int(val["dims"]), [(1, 1, 1)])
+    return sd
+
+
+def latest_checkpoint(setup_dir):
+    ckpts = glob.glob(os.path.join(setup_dir, "model_checkpoint_*.ckpt"))
+    if not ckpts:
+        return None, 0
+    step = lambda p: int(re.findall(r"(\d+)", os.path.basename(p))[-1])  # noqa: E731
+    best = max(ckpts, key=step)
+    return best, step(best)
+
+
+def run_training(config_file, device=0, batches=None, log=print):
+    """`bs train <config>`: returns the number of iterations run."""
+    from .unet import Model
+    from .training import Trainer, fit
+    config = setup_train(config_file)
+    setup_dir = config["setup_dir"]
+    with open(os.path.join(setup_dir, "net_config.json")) as f:
+        net_config = json.load(f)
+    max_iterations = int(config["max_iterations"])
+    model = Model(net_config, device=device, precision="f32")
+    ckpt, done = latest_checkpoint(setup_dir)
+    if ckpt:
+        model.load_checkpoint(ckpt)
+        log(f"resuming from {ckpt}")
+    else:
+        model.load_state_dict(default_init(net_config, seed=42))
+    trainer = Trainer(model, net_config["input_shape"])
+    if batches is None:
+        out3d = net_config["outputs"].get("3d_affs")
+        if out3d is None or len(net_config["outputs"]) != 1:
+            raise NotImplementedError("the built-in sample source feeds the 3d_affs model only")
+        log("note: the reference's gunpowder augmentations are not part of this engine; samples are random crops")
+        batches = SampleSource(config["samples"], net_config["input_shape"], net_config["output_shape"],
+                               out3d["neighborhood"][: int(out3d["dims"])], device=device)
+    n = fit(trainer, batches, max_iterations, int(config.get("save_checkpoints_every", 0)), setup_dir, log=log, start_iteration=done)
+    trainer.close()
+    return n

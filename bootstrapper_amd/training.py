@@ -44,17 +44,17 @@ def save_checkpoint(trainer, path, iteration):
     torch.save({"state_dict": sd, "global_step": int(iteration)}, path)
 
 
-def fit(trainer, batches, max_iterations, save_checkpoints_every=0, setup_dir=None, log_every=10, log=print):
+def fit(trainer, batches, max_iterations, save_checkpoints_every=0, setup_dir=None, log_every=10, log=print, start_iteration=0):
     """The training loop of training.py:96-137 without Lightning: `batches` is any iterable of reference-style batch
     dicts ("raw", "gt_affs", "affs_weights"[, "gt_lsds", "lsds_weights"]) of CUDA float32 tensors."""
     import os
-    it = 0
+    it = int(start_iteration)
     for batch in batches:
         if it >= max_iterations:
             break
         loss = trainer.training_step(batch)
         it += 1
-        if log and (it % log_every == 0 or it == 1):
+        if log and (it % log_every == 0 or it == start_iteration + 1):
             log(f"step {it}: train_loss {loss:.6f}")
         if save_checkpoints_every and setup_dir and it % save_checkpoints_every == 0:
             rank = torch.distributed.get_rank() if torch.distributed.is_available() and torch.distributed.is_initialized() else 0

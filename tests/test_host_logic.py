@@ -48,3 +48,44 @@ def test_merge_tree(cases):
         for g, ref in zip(got, c["scores"]):
             assert (ref is None and math.isnan(g)) or (ref is not None and g == ref)
     assert MergeTree([1, 2]).find_merge(1, 2) is None
+
+
+def test_train_host_helpers(tmp_path):
+    """setup_train's checks (train.py:13-120), AddAffinities / BalanceLabels restatements, default initialisation keys."""
+    import torch
+    from bootstrapper_amd import train as T
+    cfg = tmp_path / "t.toml"
+    cfg.write_text('setup_dir = "x"\nmax_iterations = 3\nsamples = []\n')
+    with pytest.raises(ValueError, match="No training samples provided"):
+        T.setup_train(str(cfg))
+    cfg.write_text(f'setup_dir = "x"\nmax_iterations = 3\n[[samples]]\nraw = "{tmp_path}/nope"\nlabels = "{tmp_path}/nope"\n')
+    with pytest.raises(ValueError, match="Raw dataset path .* does not exist"):
+        T.setup_train(str(cfg))
+
+    rng = np.random.default_rng(0)
+    labels = rng.integers(0, 4, size=(5, 9, 8))
+    nhood = [[-1, 0, 0], [0, -1, 0], [0, 0, -1], [-2, 0, 0], [0, -3, 0]]
+    affs, mask = T.affinities_from_labels(torch.from_numpy(labels), nhood)
+    for e, (dz, dy, dx) in enumerate(nhood):
+        for z, y, x in [(0, 0, 0), (2, 4, 3), (4, 8, 7), (1, 2, 0), (3, 0, 5)]:
+            zz, yy, xx = z + dz, y + dy, x + dx
+            inside = 0 <= zz < 5 and 0 <= yy < 9 and 0 <= xx < 8
+            want = float(inside and labels[z, y, x] == labels[zz, yy, xx] and labels[z, y, x] > 0)
+            assert float(affs[e, z, y, x]) == want and float(mask[e, z, y, x]) == float(inside)
+    w = T.balance_labels(affs, mask)
+    frac = float((affs * mask).sum() / mask.sum())
+    frac = min(max(frac, 0.05), 0.95)
+    assert np.isclose(float(w[affs > 0].max()), 1 / (2 * frac)) and float(w[mask == 0].abs().max()) == 0.0
+
+    from tests.test_lib_cpu import AFFS_NET_CONFIG
+    sd = T.default_init(AFFS_NET_CONFIG)
+    assert sd["unet.l_conv.3.conv_pass.2.weight"].shape == (1500, 1500, 3, 3, 3)
+    assert sd["unet.r_conv.0.2.conv_pass.0.weight"].shape == (300, 1800, 3, 3, 3) and sd["affs_head.residual.0.weight"].shape == (6, 12, 1, 1, 1)
+    assert abs(float(np.abs(sd["unet.l_conv.0.conv_pass.0.weight"]).max()) - 1 / np.sqrt(27)) < 0.01
+    from bootstrapper_amd.unet import Model
+    import ctypes as C
+    from bootstrapper_amd._lib import lib, check
+    m = Model(AFFS_NET_CONFIG)
+    for k, v in sd.items():      # every key and shape is one the engine expects (no device work: load only)
+        a = np.ascontiguousarray(v, dtype=np.float32)
+        check(lib.bsmi_unet_load_weight(m._h, k.encode(), a.ctypes.data_as(C.c_void_p), (C.c_int64 * a.ndim)(*a.shape), a.ndim))

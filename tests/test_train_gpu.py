@@ -77,3 +77,41 @@ def test_data_parallel_two_ranks(tmp_path, golden_dir):
     ref = T.adam_step({k: d["w0:" + k].ravel() for k in keys}, mean, {}, lr=1e-3)
     for k in keys:
         assert np.abs(a["p:" + k] - ref[k]).max() <= 1e-6 + 1e-3 * 2e-3, k
+
+
+def test_bs_train_driver(tmp_path):
+    """`bs train`: random crops from a labelled Zarr volume, three iterations, a checkpoint in the reference's layout
+    that the predict-side Model loads, and resuming from it."""
+    from bootstrapper_amd.train import run_training, latest_checkpoint
+    from bootstrapper_amd.unet import Model
+    from bootstrapper_amd.zarr_io import prepare_ds
+    rng = np.random.default_rng(4)
+    store = str(tmp_path / "vol.zarr")
+    raw = rng.integers(0, 256, size=(40, 130, 130), dtype=np.uint8)
+    labels = np.zeros((40, 130, 130), dtype=np.uint64)
+    for i, (z, y, x) in enumerate(rng.integers(0, 100, size=(40, 3))):
+        labels[z % 30:z % 30 + 10, y:y + 30, x:x + 30] = i + 1
+    for name, arr in (("raw", raw), ("labels", labels)):
+        ds = prepare_ds(f"{store}/{name}", arr.shape, offset=(0, 0, 0), voxel_size=(40, 4, 4), chunk_shape=(20, 64, 64), dtype=arr.dtype)
+        ds[:] = arr
+    setup = tmp_path / "setup_01"
+    setup.mkdir()
+    nc = {"in_channels": 1, "num_fmaps": 4, "fmap_inc_factor": 2, "downsample_factors": [[1, 2, 2]] * 3,
+          "kernel_size_down": [[[3, 3, 3], [3, 3, 3]]] * 4, "kernel_size_up": [[[3, 3, 3], [3, 3, 3]]] * 3,
+          "input_shape": [30, 108, 108], "output_shape": [2, 16, 16],
+          "outputs": {"3d_affs": {"dims": 3, "neighborhood": [[-1, 0, 0], [0, -1, 0], [0, 0, -1]], "grow_boundary": 1}}}
+    (setup / "net_config.json").write_text(json.dumps(nc))
+    cfg = tmp_path / "train.toml"
+    cfg.write_text(f'setup_dir = "{setup}"\nvoxel_size = [40, 4, 4]\nmax_iterations = 3\nsave_checkpoints_every = 3\nsave_snapshots_every = 1000\n'
+                   f'[[samples]]\nraw = "{store}/raw"\nlabels = "{store}/labels"\n')
+    logs = []
+    assert run_training(str(cfg), log=logs.append) == 3
+    ckpt, step = latest_checkpoint(str(setup))
+    assert step == 3 and os.path.basename(ckpt) == "model_checkpoint_3.ckpt"
+    assert any("train_loss" in l for l in logs)
+    m = Model(nc, precision="f32").load_checkpoint(ckpt)            # the predict worker's loader (predict.py:98-108)
+    y = m(torch.zeros(1, 1, 30, 108, 108, device="cuda"))
+    assert tuple(y.shape) == (1, 3, 2, 16, 16) and bool(torch.isfinite(y).all())
+    cfg.write_text(cfg.read_text().replace("max_iterations = 3", "max_iterations = 5").replace("save_checkpoints_every = 3", "save_checkpoints_every = 5"))
+    assert run_training(str(cfg), log=logs.append) == 5 and latest_checkpoint(str(setup))[1] == 5
+    assert any("resuming from" in l for l in logs)
