@@ -302,7 +302,7 @@ __device__ __forceinline__ void conv_igemm_body(const ConvArgs& a, char* smem, i
         }
       }
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#pragma unroll
+#pragma unroll 1  // rolled: unrolled, the f32 320-wide persistent kernel needs 13 registers too many and spills
       for (int k = 0; k < (NCH + 63) / 64; ++k) {
         const int c = lane + 64 * k;
         if (c >= NCH) break;

@@ -277,6 +277,137 @@ __global__ __launch_bounds__(64) void wgrad_kernel(const WgradArgs a) {
   }
 }
 
+// LDS-tiled form for the wide layers: a workgroup of 4 waves (2 x 2) owns a 128 x 128 block of (n, c) for the KX taps of
+// one (kz, ky) tap row.  32 voxels of g ([32][128] floats) and the 32 + KX - 1 voxels of x they meet are staged in LDS
+// once and shared by the four waves (a 3x smaller global read volume than the per-wave form, which is bound by it);
+// the next chunk is fetched into registers while the current one is multiplied.
+template <int KX>
+__global__ __launch_bounds__(256) void wgrad_tiled_kernel(const WgradArgs a) {
+  constexpr int MB = 32, TW = 128, XR = MB + KX - 1;
+  __shared__ float gs[MB][TW];
+  __shared__ float xs[XR][TW];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lr = lane & 31, lh = lane >> 5;
+  const int wn = wave >> 1, wc = wave & 1;
+  const int nblocks_c = (a.C + TW - 1) / TW;
+  const int nt = blockIdx.x / nblocks_c, ct = blockIdx.x - nt * nblocks_c;
+  const int trow = blockIdx.y;
+  const int tz = trow / a.ky, ty = trow - tz * a.ky;
+  const int nbase = nt * TW, cbase = ct * TW;
+  // which of this wave's 2 x 2 blocks hold real channels (uniform)
+  bool nuse[2], cuse[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    nuse[i] = nbase + wn * 64 + i * 32 < a.N;
+    cuse[i] = cbase + wc * 64 + i * 32 < a.C;
+  }
+  f32x16_t acc[KX][2][2];
+#pragma unroll
+  for (int t = 0; t < KX; ++t)
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][i][j][r] = 0.f;
+  // staging: thread -> (row, 4-float column group); g: MB rows x 32 groups = 1024 float4 = 4 per thread; x: XR rows
+  constexpr int GV = MB * (TW / 4) / 256, XV = (XR * (TW / 4) + 255) / 256;
+  float4 gr[GV], xr[XV];
+  const float* gp0 = a.g;
+  const float* xp0 = a.x + tz * a.xsz + ty * a.xsy;
+  const int nlines = a.Do * a.Ho;
+  const int l0 = blockIdx.z * a.lines_per_block, l1 = min(nlines, l0 + a.lines_per_block);
+  const int chunks_per_line = (a.Wo + MB - 1) / MB;
+  const int nchunks = (l1 - l0) * chunks_per_line;
+  auto fetch = [&](int ch) {
+    const int l = l0 + ch / chunks_per_line, x0 = (ch % chunks_per_line) * MB;
+    const int z = l / a.Ho, y = l - z * a.Ho;
+    const float* gl = gp0 + z * a.gsz + y * a.gsy;
+    const float* xl = xp0 + z * a.xsz + y * a.xsy;
+#pragma unroll
+    for (int v = 0; v < GV; ++v) {
+      const int idx = tid + v * 256, row = idx / (TW / 4), c4 = (idx % (TW / 4)) * 4;
+      const int xx = x0 + row, n = nbase + c4;
+      float4 val = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (xx < a.Wo && n < a.N) {  // channel counts are padded to 16, so a 4-group never straddles the tensor's row end
+        val = *(const float4*)(gl + (long long)xx * a.gsx + n);
+        if (n + 3 >= a.N) {
+          if (n + 1 >= a.N) val.y = 0.f;
+          if (n + 2 >= a.N) val.z = 0.f;
+          val.w = 0.f;
+        }
+      }
+      gr[v] = val;
+    }
+#pragma unroll
+    for (int v = 0; v < XV; ++v) {
+      const int idx = tid + v * 256, row = idx / (TW / 4), c4 = (idx % (TW / 4)) * 4;
+      const int xx = x0 + row, c = cbase + c4;
+      float4 val = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (row < XR && xx < a.Wo + KX - 1 && c < a.C) {
+        val = *(const float4*)(xl + (long long)xx * a.xsx + c);
+        if (c + 3 >= a.C) {
+          if (c + 1 >= a.C) val.y = 0.f;
+          if (c + 2 >= a.C) val.z = 0.f;
+          val.w = 0.f;
+        }
+      }
+      xr[v] = val;
+    }
+  };
+  if (nchunks > 0) fetch(0);
+  for (int ch = 0; ch < nchunks; ++ch) {
+    __syncthreads();  // the previous chunk has been multiplied
+#pragma unroll
+    for (int v = 0; v < GV; ++v) {
+      const int idx = tid + v * 256;
+      *(float4*)&gs[idx / (TW / 4)][(idx % (TW / 4)) * 4] = gr[v];
+    }
+#pragma unroll
+    for (int v = 0; v < XV; ++v) {
+      const int idx = tid + v * 256;
+      if (idx / (TW / 4) < XR) *(float4*)&xs[idx / (TW / 4)][(idx % (TW / 4)) * 4] = xr[v];
+    }
+    __syncthreads();
+    if (ch + 1 < nchunks) fetch(ch + 1);
+    const int x0 = (ch % chunks_per_line) * MB;
+    const int mvalid = min(MB, a.Wo - x0);  // rows beyond hold zeros in gs (fetch), so they add nothing
+#pragma unroll 4
+    for (int m = 0; m < MB; m += 2) {
+      if (m >= mvalid) break;
+      float g2[2], x2[KX][2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) g2[i] = gs[m + lh][wn * 64 + i * 32 + lr];
+#pragma unroll
+      for (int t = 0; t < KX; ++t)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) x2[t][j] = xs[m + lh + t][wc * 64 + j * 32 + lr];
+#pragma unroll
+      for (int t = 0; t < KX; ++t)
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j)
+            if (nuse[i] && cuse[j]) acc[t][i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(g2[i], x2[t][j], acc[t][i][j], 0, 0, 0);
+    }
+  }
+#pragma unroll
+  for (int t = 0; t < KX; ++t) {
+    const int tap = trow * KX + t;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int c = cbase + wc * 64 + j * 32 + lr;
+        if (!nuse[i] || c >= a.C) continue;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int nn = nbase + wn * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+          if (nn < a.N && acc[t][i][j][r] != 0.f) atomicAdd(&a.dw[((size_t)nn * a.cin_total + a.cbase + c) * a.ntap + tap], acc[t][i][j][r]);
+        }
+      }
+  }
+}
+
 // dst[region at (oz, oy, ox)][cdst + c] += src[..][csrc + c] for c < C (gradient of crop + concat)
 __global__ void scatter_add_kernel(const float* __restrict__ src, int D, int H, int W, int Cs, int csrc, float* __restrict__ dst, int Hd, int Wd,
                                    int Cd, int cdst, int oz, int oy, int ox, int C) {
@@ -869,12 +1000,22 @@ int bsmi_unet_train_forward_backward(bsmi_unet* h, const float* raw_dev, const f
           a.kz = kk[0]; a.ky = kk[1]; a.kx = kk[2];
           a.dw = dw; a.cin_total = ct; a.cbase = cbase; a.ntap = kk[0] * kk[1] * kk[2];
           const int nlines = a.Do * a.Ho;
-          const int blocks_nc = ((a.N + 31) / 32) * ((a.C + 63) / 64);
           const int trows = a.kz * a.ky;
-          int zsplit = std::max(1, std::min(nlines, 8192 / std::max(1, blocks_nc * trows)));
+          const bool tiled = a.N > 32 && a.C > 32;  // narrow layers: the per-wave form wastes fewer MFMAs on padding
+          const int blocks_nc = tiled ? ((a.N + 127) / 128) * ((a.C + 127) / 128) : ((a.N + 31) / 32) * ((a.C + 63) / 64);
+          int zsplit = std::max(1, std::min(nlines, (tiled ? 2048 : 8192) / std::max(1, blocks_nc * trows)));
           a.lines_per_block = (nlines + zsplit - 1) / zsplit;
           zsplit = (nlines + a.lines_per_block - 1) / a.lines_per_block;
           const dim3 grid(blocks_nc, trows, zsplit);
+          if (tiled) {
+            switch (a.kx) {
+              case 1: hipLaunchKernelGGL(wgrad_tiled_kernel<1>, grid, dim3(256), 0, s, a); break;
+              case 2: hipLaunchKernelGGL(wgrad_tiled_kernel<2>, grid, dim3(256), 0, s, a); break;
+              case 3: hipLaunchKernelGGL(wgrad_tiled_kernel<3>, grid, dim3(256), 0, s, a); break;
+              default: return;
+            }
+            return;
+          }
           switch (a.kx) {
             case 1: hipLaunchKernelGGL(wgrad_kernel<1>, grid, dim3(64), 0, s, a); break;
             case 2: hipLaunchKernelGGL(wgrad_kernel<2>, grid, dim3(64), 0, s, a); break;
@@ -910,7 +1051,7 @@ int bsmi_unet_train_forward_backward(bsmi_unet* h, const float* raw_dev, const f
         }
         // input gradient
         if (cb.need_dgrad) {
-          rc = launch_conv_igemm(cb.dgrad, BSMI_PREC_F32, cb.dtile, s, nullptr, 0);
+          rc = launch_conv_igemm(cb.dgrad, BSMI_PREC_F32, cb.dtile, s, h->sk_ws, h->sk_grid);
           if (rc) return rc;
           if (cb.scatter) {
             int cbase = 0;
