@@ -266,9 +266,6 @@ __device__ __forceinline__ void conv_igemm_body(const ConvArgs& a, char* smem, i
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     return;
   }
-#ifdef BSMI_ABLATE_NOSTORE  // timing experiment
-  if (a.relu != 12345) return;
-#endif
   // Epilogue: bias (+ReLU), convert, store channels-last.  A lane of the 32x32 accumulator holds
   // 16 rows of ONE channel, so storing from registers would write 2-byte pieces (64-byte runs per
   // row: partial cache lines, measured at ~170 GB/s).  Instead every wave transposes 16 rows of
@@ -541,9 +538,6 @@ __device__ __forceinline__ void conv_igemm_body16(const ConvArgs& a, char* smem,
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     return;
   }
-#ifdef BSMI_ABLATE_NOSTORE  // timing experiment
-  if (a.relu != 12345) return;
-#endif
   // Epilogue: bias (+ReLU), convert, store channels-last.  A lane of the 32x32 accumulator holds
   // 16 rows of ONE channel, so storing from registers would write 2-byte pieces (64-byte runs per
   // row: partial cache lines, measured at ~170 GB/s).  Instead every wave transposes 16 rows of
