@@ -115,3 +115,36 @@ def test_bs_train_driver(tmp_path):
     cfg.write_text(cfg.read_text().replace("max_iterations = 3", "max_iterations = 5").replace("save_checkpoints_every = 3", "save_checkpoints_every = 5"))
     assert run_training(str(cfg), log=logs.append) == 5 and latest_checkpoint(str(setup))[1] == 5
     assert any("resuming from" in l for l in logs)
+
+
+def test_full_net_training_step_vs_cpu_oracle():
+    """The full 3d_affs net (94.7 M parameters, 1500/1800-channel layers: multi-tile weight gradients, persistent
+    split-K input gradients) on the reference's training block, against the CPU oracle's autograd (about 20 s)."""
+    from oracle import train_ref as T
+    from oracle import unet_ref as R
+    from bootstrapper_amd.unet import Model
+    from bootstrapper_amd.training import Trainer
+    from bootstrapper_amd.synth import synthetic_state_dict
+    from tests.test_lib_cpu import AFFS_NET_CONFIG as NC
+    sd = synthetic_state_dict(NC, 0)
+    shape = (32, 196, 196)
+    m = Model(NC, precision="f32").load_state_dict(sd)
+    tr = Trainer(m, shape)
+    rng = np.random.default_rng(0)
+    x = (rng.random(shape, dtype=np.float32) * 2 - 1).astype(np.float32)
+    out = (6,) + tuple(tr.out_shape)
+    gt = (rng.random(out) > 0.5).astype(np.float32)
+    w = rng.random(out).astype(np.float32)
+    w[rng.random(out) < 0.2] = 0
+    loss = tr.forward_backward(torch.from_numpy(x).cuda(), [torch.from_numpy(gt).cuda()], [torch.from_numpy(w).cuda()])
+    torch.set_num_threads(min(16, os.cpu_count() or 1))
+    ref_loss, ref_grads, _ = T.loss_and_grads(R.default_cfg(12, 5), sd, x, [gt[None]], [w[None]], ["affs_head"])
+    assert abs(loss - ref_loss) < 1e-5 * max(1.0, abs(ref_loss)), (loss, ref_loss)
+    worst = (0.0, "")
+    for k, ref in ref_grads.items():
+        got = tr.read(k, "grad").reshape(ref.shape)
+        err = float(np.abs(got - ref).max() / max(1e-12, np.abs(ref).max()))
+        worst = max(worst, (err, k))
+        assert err < 2e-3, (k, err)
+    print("full net: loss", loss, "largest relative gradient error", worst)
+    tr.close()
