@@ -49,7 +49,7 @@ BF16_DENSE_PEAK_TFLOPS = 2500.0  # /opt/skills/guides/MI355X_MICROARCH.md, dense
 # HBM-side bytes per conv launch cannot be counted inside this process: they come from the committed
 # rocprofv3 PMC passes of the same kernels on the same block (tools/pmc_traffic.py; FETCH_SIZE and WRITE_SIZE
 # in separate passes, KiB -> bytes, FETCH_SIZE doubled for gfx950 wide reads as the guide prescribes).
-TRAFFIC_PROFILE = os.path.join(ROOT, "profiles", "r01_e_conv_traffic_pmc.json")
+TRAFFIC_PROFILE = os.path.join(ROOT, "profiles", "r01_f_conv_traffic_pmc.json")
 
 
 def pmc_traffic(precision):
