@@ -1152,6 +1152,49 @@ __global__ void cc26_write_kernel(const uint64_t* __restrict__ x, size_t n, Frag
   }
 }
 
+// thresholded-affinity connected components (reference post/cc.py:7-74): voxel p is linked with p + e_d when
+// affs[d][p] > cut; a voxel is labelled if it has a link of its own (even one that leaves the volume) or is the far end
+// of a neighbour's link.  Roots are the raster-first voxels of their components, so the cc26 ranking kernels give the
+// reference's numbering (depth-first fills started in raster order).
+__global__ void ccaff_init_kernel(size_t n, FragWs w, uint64_t* __restrict__ touched) {
+  for (size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x; p < n; p += (size_t)gridDim.x * blockDim.x) {
+    w.par[p] = (int32_t)p;
+    touched[p] = 0;
+  }
+}
+
+__global__ void ccaff_union_kernel(const uint8_t* __restrict__ affs, int D, int H, int W, int cut, FragWs w, uint64_t* __restrict__ touched) {
+  const size_t n = (size_t)D * H * W, hw = (size_t)H * W;
+  for (size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x; p < n; p += (size_t)gridDim.x * blockDim.x) {
+    const int x = (int)(p % W), y = (int)((p / W) % H), z = (int)(p / hw);
+    const bool ok[3] = {z + 1 < D, y + 1 < H, x + 1 < W};
+    const size_t st[3] = {hw, (size_t)W, 1};
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+      if ((int)affs[(size_t)d * n + p] <= cut) continue;
+      touched[p] = 1;
+      if (!ok[d]) continue;
+      const size_t q = p + st[d];
+      touched[q] = 1;
+      int a = (int)p, b = (int)q;
+      for (;;) {
+        a = cc_find(w.par, a);
+        b = cc_find(w.par, b);
+        if (a == b) break;
+        if (a < b) { const int t = a; a = b; b = t; }
+        const int old = atomicMin(&w.par[a], b);
+        if (old == a) break;
+        a = old;
+      }
+    }
+  }
+}
+
+__global__ void ccaff_finalize_kernel(size_t n, FragWs w, const uint64_t* __restrict__ touched) {
+  for (size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x; p < n; p += (size_t)gridDim.x * blockDim.x)
+    if (!touched[p]) w.par[p] = -1;
+}
+
 // per-label voxel count and coordinate sums (RAG node attributes, watershed_frags.py:230-246)
 __global__ void label_stats_kernel(const uint64_t* __restrict__ lab, int D, int H, int W, uint64_t id_offset, uint64_t num,
                                    unsigned long long* __restrict__ size, unsigned long long* __restrict__ sums) {
@@ -1520,6 +1563,41 @@ int bsmi_connected_components(const uint64_t* nodes, uint64_t n, const uint64_t*
     if (a < b) parent[b] = a; else parent[a] = b;
   }
   for (uint64_t i = 0; i < n; ++i) components[i] = nodes[find((uint32_t)i)];
+  return BSMI_OK;
+}
+
+int bsmi_cc_affs_u8(bsmi_seg* h, const uint8_t* affs_dev, const int64_t shape[3], int cut, int64_t min_size, uint64_t* frags_dev,
+                    uint64_t* seg_dev, uint64_t* num_labels_dev, void* stream) {
+  int rc = check_seg_shape(h, shape);
+  if (rc) return rc;
+  if (!affs_dev || !frags_dev || !num_labels_dev) BSMI_FAIL(BSMI_ERR_INVALID, "null argument");
+  if (cut < -1 || cut > 255) BSMI_FAIL(BSMI_ERR_INVALID, "cut must be in [-1, 255]");
+  BSMI_HIP(hipSetDevice(h->device));
+  hipStream_t s = (hipStream_t)stream;
+  const size_t n = (size_t)shape[0] * shape[1] * shape[2];
+  FragWs& f = h->frag;
+  const int bs = 256;
+  const int grid = (int)std::min<size_t>((n + bs - 1) / bs, 4096);
+  const uint32_t nblk = (uint32_t)((n + 1023) / 1024);
+  BSMI_HIP(hipMemsetAsync(f.flags, 0, 4 * sizeof(uint32_t), s));
+  hipLaunchKernelGGL(ccaff_init_kernel, dim3(grid), dim3(bs), 0, s, n, f, h->crop_tmp);
+  hipLaunchKernelGGL(ccaff_union_kernel, dim3(grid), dim3(bs), 0, s, affs_dev, (int)shape[0], (int)shape[1], (int)shape[2], cut, f, h->crop_tmp);
+  hipLaunchKernelGGL(ccaff_finalize_kernel, dim3(grid), dim3(bs), 0, s, n, f, (const uint64_t*)h->crop_tmp);
+  hipLaunchKernelGGL(cc26_count_kernel, dim3(nblk), dim3(1024), 0, s, n, f);
+  hipLaunchKernelGGL(cc26_scan_kernel, dim3(1), dim3(1024), 0, s, nblk, f, num_labels_dev);
+  hipLaunchKernelGGL(cc26_rank_kernel, dim3(nblk), dim3(1024), 0, s, n, f);
+  hipLaunchKernelGGL(cc26_write_kernel, dim3(grid), dim3(bs), 0, s, (const uint64_t*)h->crop_tmp, n, f, (uint64_t)0, frags_dev);
+  if (seg_dev) {
+    BSMI_HIP(hipMemcpyAsync(seg_dev, frags_dev, n * sizeof(uint64_t), hipMemcpyDeviceToDevice, s));
+    if (min_size > 0) {  // skimage remove_small_objects on the labels (post/connected_components.py:97-101)
+      BSMI_HIP(hipMemsetAsync(f.lsum, 0, (size_t)f.id_cap * sizeof(unsigned long long), s));
+      BSMI_HIP(hipMemsetAsync(f.lcnt, 0, (size_t)f.id_cap * sizeof(uint32_t), s));
+      hipLaunchKernelGGL(frag_stats_kernel, dim3(grid), dim3(bs), 0, s, affs_dev, (const uint64_t*)seg_dev, n, f);
+      hipLaunchKernelGGL(frag_decide_kernel, dim3(grid), dim3(bs), 0, s, affs_dev, (const uint64_t*)seg_dev, n, f, 0.0, (long long)min_size);
+      hipLaunchKernelGGL(frag_filter_kernel, dim3(grid), dim3(bs), 0, s, seg_dev, n, f);
+    }
+  }
+  BSMI_HIP(hipGetLastError());
   return BSMI_OK;
 }
 

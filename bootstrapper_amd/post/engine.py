@@ -117,6 +117,20 @@ class SegEngine:
             return edges[:ne], scores[:ne], merges[:nm], mscores[:nm]
         return edges[:ne], scores[:ne]
 
+    def cc_affs(self, affs_u8, threshold=0.5, remove_debris=0):
+        """Thresholded-affinity connected components (reference post/cc.py; post/connected_components.py:77-101).
+        -> (fragments int64, segmentation int64 (debris removed), count int64[1]); asynchronous."""
+        if affs_u8.dtype != torch.uint8 or not affs_u8.is_cuda or affs_u8.dim() != 4 or affs_u8.shape[0] != 3:
+            raise ValueError("affs must be a uint8 CUDA tensor of shape (3, D, H, W)")
+        a = affs_u8.contiguous()
+        shape = tuple(a.shape[1:])
+        frags = torch.empty(shape, dtype=torch.int64, device=a.device)
+        seg = torch.empty(shape, dtype=torch.int64, device=a.device)
+        num = torch.zeros(1, dtype=torch.int64, device=a.device)
+        check(lib.bsmi_cc_affs_u8(self._h, C.c_void_p(a.data_ptr()), _lib.i64x3(shape), threshold_to_cut(threshold), int(remove_debris),
+                                  C.c_void_p(frags.data_ptr()), C.c_void_p(seg.data_ptr()), C.c_void_p(num.data_ptr()), self._stream()))
+        return frags, seg, num
+
     def status(self):
         check(lib.bsmi_seg_status(self._h, self._stream()))
 
@@ -136,3 +150,12 @@ def lut_relabel(labels, keys, vals, out=None):
     check(lib.bsmi_lut_relabel(lab.device.index, C.c_void_p(lab.data_ptr()), lab.numel(), C.c_void_p(keys.data_ptr()),
                                C.c_void_p(vals.data_ptr()), keys.numel(), C.c_void_p(out.data_ptr()), stream))
     return out
+
+
+def threshold_to_cut(threshold):
+    """The uint8 cut equivalent to the reference's `affs.astype(float32) / 255.0 > threshold`
+    (post/connected_components.py:49-52,77): the largest v with not (float32(v) / 255 > float32(threshold)), -1 if none."""
+    import numpy as np
+    v = np.arange(256, dtype=np.float32) / np.float32(255.0)
+    below = np.nonzero(~(v > np.float32(threshold)))[0]
+    return int(below.max()) if below.size else -1

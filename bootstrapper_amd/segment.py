@@ -89,6 +89,9 @@ def run_segmentation(config_file, mode="ws", **kwargs):
     if mode == "ws":
         from .post.watershed import watershed_segmentation
         return watershed_segmentation(config)
-    if mode in ("mws", "cc"):
-        raise NotImplementedError(f"segmentation method {mode!r} is outside this engine's hot path (ws only)")
+    if mode == "cc":
+        from .post.connected_components import cc_segmentation
+        return cc_segmentation(config)
+    if mode == "mws":
+        raise NotImplementedError("segmentation method 'mws' (mutex watershed) is outside this engine's hot path")
     raise ValueError(f"Unknown segmentation mode: {mode}")

@@ -220,6 +220,14 @@ int bsmi_lut_relabel(int device, const uint64_t *in_dev, uint64_t n, const uint6
 int bsmi_connected_components(const uint64_t *nodes, uint64_t n, const uint64_t *edges,
                               const float *scores, uint64_t m, float threshold, uint64_t *components);
 
+/* Thresholded-affinity connected components (`bs segment --cc`; reference post/cc.py:7-74 called from
+ * post/connected_components.py:77-80, debris removal :97-101).  Voxel p is linked with its +z / +y / +x neighbour when
+ * affs[d][p] > cut (cut = the uint8 value equivalent to the reference's float threshold: the largest v with
+ * !(v / 255.0f > threshold)).  frags_dev: labels 1.. in raster order of each component's first voxel; seg_dev
+ * (optional): the same with components of fewer than min_size voxels removed; *num_labels_dev = component count. */
+int bsmi_cc_affs_u8(bsmi_seg *h, const uint8_t *affs_dev, const int64_t shape[3], int cut, int64_t min_size,
+                    uint64_t *frags_dev, uint64_t *seg_dev, uint64_t *num_labels_dev, void *stream);
+
 /* status of the last asynchronous seg call on this handle (reads a device flag;
  * synchronises `stream`): BSMI_OK or BSMI_ERR_OVERFLOW */
 int bsmi_seg_status(bsmi_seg *h, void *stream);

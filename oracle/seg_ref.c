@@ -741,3 +741,49 @@ void seg_connected_components(const uint64_t *nodes, int64_t n, const uint64_t *
   for (int64_t i = 0; i < n; i++) components[i] = nodes[uf_find(p, (int)i)];
   free(p);
 }
+
+/* ======================================================================================
+ * Thresholded-affinity connected components (reference post/cc.py:7-74, call site
+ * post/connected_components.py:77-80).  hard[d][p] = affs[d][p] > cut links voxel p with p + e_d;
+ * every voxel that has a link of its own, in raster order, starts a depth-first fill unless already
+ * visited; ids 1.. in that order.  Pinned by tests/golden/cc_cases.npz (tools/gen_goldens_cc.py runs the
+ * reference function).  The float comparison of the call site (u8 / 255 as float32 > threshold) is an
+ * integer cut for uint8 data: seg_cc_cut().
+ * ====================================================================================== */
+int seg_cc_cut(double threshold) {
+  /* largest u8 value v with !((float)v / 255.0f > (float)threshold); -1 if even 0 passes */
+  const float t = (float)threshold;
+  int cut = -1;
+  for (int v = 0; v < 256; v++) if (!(((float)v / 255.0f) > t)) cut = v;
+  return cut;
+}
+
+int64_t seg_cc_affs_u8(const uint8_t *affs, int D, int H, int W, int cut, uint32_t *seg) {
+  const int64_t hw = (int64_t)H * W, n = hw * D;
+  uint8_t *visited = (uint8_t *)calloc(n ? n : 1, 1);
+  int64_t *stack = (int64_t *)malloc(8 * (n ? n : 1));
+  memset(seg, 0, 4 * n);
+  uint32_t cur = 1;
+#define HARD(d_, p_) ((int)affs[(int64_t)(d_) * n + (p_)] > cut)
+  for (int64_t s = 0; s < n; s++) {
+    if (visited[s] || !(HARD(0, s) || HARD(1, s) || HARD(2, s))) continue;
+    int64_t top = 0;
+    stack[top++] = s;
+    visited[s] = 1;
+    while (top) {
+      const int64_t p = stack[--top];
+      seg[p] = cur;
+      const int z = (int)(p / hw), y = (int)((p / W) % H), x = (int)(p % W);
+      if (z + 1 < D && HARD(0, p) && !visited[p + hw]) { stack[top++] = p + hw; visited[p + hw] = 1; }
+      if (y + 1 < H && HARD(1, p) && !visited[p + W]) { stack[top++] = p + W; visited[p + W] = 1; }
+      if (x + 1 < W && HARD(2, p) && !visited[p + 1]) { stack[top++] = p + 1; visited[p + 1] = 1; }
+      if (z - 1 >= 0 && HARD(0, p - hw) && !visited[p - hw]) { stack[top++] = p - hw; visited[p - hw] = 1; }
+      if (y - 1 >= 0 && HARD(1, p - W) && !visited[p - W]) { stack[top++] = p - W; visited[p - W] = 1; }
+      if (x - 1 >= 0 && HARD(2, p - 1) && !visited[p - 1]) { stack[top++] = p - 1; visited[p - 1] = 1; }
+    }
+    cur++;
+  }
+#undef HARD
+  free(visited); free(stack);
+  return (int64_t)cur - 1;
+}

@@ -30,6 +30,10 @@ def _load():
     lib.seg_rag_merge_scores_u8.restype = C.c_int64
     lib.seg_connected_components.argtypes = [vp, C.c_int64, vp, vp, C.c_int64, C.c_float, vp]
     lib.seg_connected_components.restype = None
+    lib.seg_cc_cut.argtypes = [C.c_double]
+    lib.seg_cc_cut.restype = C.c_int
+    lib.seg_cc_affs_u8.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int, vp]
+    lib.seg_cc_affs_u8.restype = C.c_int64
     lib.seg_count_labels.argtypes = [vp, C.c_int64]
     lib.seg_count_labels.restype = C.c_int64
     return lib
@@ -119,3 +123,17 @@ def connected_components(nodes, edges, scores, threshold):
     _lib.seg_connected_components(nodes.ctypes.data, len(nodes), edges.ctypes.data, scores.ctypes.data, len(scores),
                                   float(threshold), out.ctypes.data)
     return out
+
+
+def cc_cut(threshold):
+    """u8 cut equivalent to `(u8 / 255 as float32) > threshold` (post/connected_components.py:49-52,77)."""
+    return int(_lib.seg_cc_cut(float(threshold)))
+
+
+def cc_affs_u8(affs_u8, threshold):
+    """post/cc.py:7-74 on uint8 affinities [3][D][H][W] -> (labels uint32, count)."""
+    a = np.ascontiguousarray(affs_u8[:3], dtype=np.uint8)
+    _, D, H, W = a.shape
+    seg = np.zeros((D, H, W), dtype=np.uint32)
+    n = _lib.seg_cc_affs_u8(a.ctypes.data, D, H, W, cc_cut(threshold), seg.ctypes.data)
+    return seg, int(n)

@@ -221,3 +221,30 @@ remove_debris = 12
     assert open_ds(written2[0]).attrs["bs_params"]["blockwise"] is False
     assert np.array_equal(open_ds(written2[0])[:], fr2)
     assert np.array_equal(open_ds(written2[2])[:], segs2[1])
+
+
+def test_cc_segmentation_driver(tmp_path):
+    """`bs segment --cc`: dataset names, attributes and contents of the thresholded-affinity connected components."""
+    from scipy.ndimage import gaussian_filter
+    from bootstrapper_amd.segment import run_segmentation
+    from bootstrapper_amd.zarr_io import open_ds, prepare_ds
+    from oracle import seg_ref as S
+    rng = np.random.default_rng(2)
+    a = gaussian_filter(rng.random((3, 10, 60, 50)), sigma=(0, 1, 2, 2))
+    affs = ((a - a.min()) / (a.max() - a.min()) * 255).astype(np.uint8)
+    store = str(tmp_path / "v.zarr")
+    ds = prepare_ds(store + "/affs", affs.shape, offset=(0, 0, 0), voxel_size=(40, 4, 4), chunk_shape=(3, 8, 32, 32), dtype=np.uint8,
+                    axis_names=["c^", "z", "y", "x"], units=["nm"] * 3)
+    ds[:] = affs
+    cfg = tmp_path / "seg.toml"
+    cfg.write_text(f'affs_dataset = "{store}/affs"\nfragments_dataset = "{store}/fragments"\nseg_dataset_prefix = "{store}/segmentations"\n'
+                   'blockwise = false\n[cc_params]\nthreshold = 0.55\nremove_debris = 20\n')
+    written = run_segmentation(str(cfg), "cc")
+    assert [os.path.relpath(w, store) for w in written] == ["fragments/t0.55", "segmentations/t0.55--rd20"]
+    ref, _ = S.cc_affs_u8(affs, 0.55)
+    f = open_ds(written[0])
+    assert f.attrs["bs_params"]["method"] == "cc" and np.array_equal(f[:], ref.astype(np.uint64))
+    counts = np.bincount(ref.ravel())
+    keep = counts >= 20
+    keep[0] = False
+    assert np.array_equal(open_ds(written[1])[:], np.where(keep[ref], ref, 0).astype(np.uint64))

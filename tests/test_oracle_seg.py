@@ -124,3 +124,18 @@ def test_rag_merge_scores_match_merge_tree_replay_and_cc():
             if ru != rv:
                 parent[max(ru, rv)] = min(ru, rv)
     assert [find(int(n)) for n in nodes] == comp.tolist()
+
+
+def test_cc_oracle_vs_reference_goldens(golden_dir):
+    """post/cc.py (run by tools/gen_goldens_cc.py) against the C restatement, including the float threshold -> u8 cut."""
+    d = np.load(os.path.join(golden_dir, "cc_cases.npz"))
+    names = sorted({k.split("/")[0] for k in d.files})
+    assert len(names) >= 6
+    for name in names:
+        affs, thr = d[name + "/affs"], float(d[name + "/thr"])
+        assert np.array_equal(affs > S.cc_cut(thr), d[name + "/hard"]), name
+        seg, n = S.cc_affs_u8(affs, thr)
+        assert np.array_equal(seg, d[name + "/seg"]) and n == int(d[name + "/seg"].max()), name
+    for thr in (0.0, 0.2, 0.35, 0.5, 1 / 3, 0.999, 1.0):
+        u = np.arange(256, dtype=np.uint8)
+        assert np.array_equal((u.astype(np.float32) / 255.0) > thr, u > S.cc_cut(thr)), thr

@@ -240,3 +240,31 @@ def test_lut_relabel():
     ref = np.vectorize(lambda v: lut.get(v, v))(lab)
     out = lut_relabel(torch.from_numpy(lab).cuda(), torch.from_numpy(keys), torch.from_numpy(vals))
     assert np.array_equal(out.cpu().numpy(), ref)
+
+
+def test_cc_affs_bit_exact_vs_reference_goldens_and_oracle(golden_dir):
+    """`bs segment --cc` labelling: goldens produced by the reference post/cc.py, then larger volumes against the oracle,
+    then debris removal."""
+    from bootstrapper_amd.post.engine import SegEngine
+    from oracle import seg_ref as S
+    d = np.load(os.path.join(golden_dir, "cc_cases.npz"))
+    for name in sorted({k.split("/")[0] for k in d.files}):
+        affs, thr = d[name + "/affs"], float(d[name + "/thr"])
+        eng = SegEngine(affs.shape[1:])
+        frags, seg, num = eng.cc_affs(torch.from_numpy(affs).cuda(), thr, 0)
+        eng.status()
+        assert np.array_equal(frags.cpu().numpy().astype(np.uint32), d[name + "/seg"]), name
+        assert torch.equal(frags, seg) and int(num.item()) == int(d[name + "/seg"].max())
+    rng = np.random.default_rng(8)
+    for shape, sigma, thr, debris in [((20, 96, 80), (1, 2, 2), 0.5, 40), ((7, 130, 70), (0, 1, 1), 0.62, 5), ((33, 40, 40), (1, 3, 3), 0.45, 0)]:
+        affs = _blobby(rng, shape, sigma)
+        ref, n = S.cc_affs_u8(affs, thr)
+        eng = SegEngine(shape)
+        frags, seg, num = eng.cc_affs(torch.from_numpy(affs).cuda(), thr, debris)
+        eng.status()
+        assert int(num.item()) == n and np.array_equal(frags.cpu().numpy().astype(np.uint32), ref)
+        counts = np.bincount(ref.ravel())
+        keep = counts >= debris
+        keep[0] = False
+        want = np.where(keep[ref], ref, 0)
+        assert np.array_equal(seg.cpu().numpy().astype(np.uint32), want)
