@@ -69,6 +69,7 @@ def _load():
         "bsmi_lut_relabel": (i32, [C.c_int, vp, C.c_uint64, vp, vp, C.c_uint64, vp, vp]),
         "bsmi_connected_components": (i32, [vp, C.c_uint64, vp, vp, C.c_uint64, C.c_float, vp]),
         "bsmi_cc_affs_u8": (i32, [p, vp, i64p, C.c_int, C.c_int64, vp, vp, vp, vp]),
+        "bsmi_label_table_u64": (i32, [p, vp, i64p, C.c_int64, vp, vp, vp, vp, C.c_uint64, vp, vp]),
         "bsmi_seg_status": (i32, [p, vp]),
         "bsmi_unet_train_begin": (i32, [p, i64p]),
         "bsmi_unet_train_forward_backward": (i32, [p, vp, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_float), vp]),

@@ -66,6 +66,10 @@ def train(config_file, device):
     run_training(config_file, device=device)
 
 
+from .refine import refine as _refine  # noqa: E402
+
+cli.add_command(_refine, "refine")
+
 # aliases of the reference CLI (cli.py:38-44)
 cli.add_command(train, "t")
 cli.add_command(predict, "p")

@@ -420,6 +420,9 @@ struct AggWs {
   uint32_t* cur;         // [node_cap] tree node of a cluster root
   uint32_t* ha; uint32_t* hb;  // [node_cap] merge history (ranks)
   int xcd_hint;          // XCD the sequential merge loop of this workspace should run on (see xcd_claim)
+  // label table (bs refine): per id-hash slot
+  unsigned long long* tcount;  // [icap]
+  int* tzmin; int* tzmax;      // [icap]
 };
 
 __global__ void agg_maxid_kernel(const uint64_t* __restrict__ frags, size_t n, AggWs w) {
@@ -1195,6 +1198,86 @@ __global__ void ccaff_finalize_kernel(size_t n, FragWs w, const uint64_t* __rest
     if (!touched[p]) w.par[p] = -1;
 }
 
+// label table of a block (reference refine.py:98-109 `_global_sizes`, :228-250 z extents): every distinct non-zero id
+// with its voxel count and the first / last z slice it occurs in.  Runs of equal ids along x are counted once.
+__global__ void ltab_clear_kernel(AggWs w) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < w.icap; i += (size_t)gridDim.x * blockDim.x) {
+    w.idkeys[i] = HEMPTY;
+    w.tcount[i] = 0;
+    w.tzmin[i] = 0x7fffffff;
+    w.tzmax[i] = -0x7fffffff;
+  }
+}
+
+__global__ void ltab_scan_kernel(const uint64_t* __restrict__ lab, int D, int H, int W, int z0, AggWs w) {
+  const size_t nrows = (size_t)D * H;
+  for (size_t row = (size_t)blockIdx.x * blockDim.x + threadIdx.x; row < nrows; row += (size_t)gridDim.x * blockDim.x) {
+    const int z = (int)(row / H);
+    const uint64_t* p = lab + row * W;
+    int x = 0;
+    while (x < W) {
+      const uint64_t f = p[x];
+      int len = 1;
+      while (x + len < W && p[x + len] == f) ++len;
+      x += len;
+      if (!f) continue;
+      if (f >= HTOMB) { atomicOr(&w.counters[3], 1u); continue; }
+      uint32_t s = (uint32_t)hmix(f) & (w.icap - 1);
+      bool ok = false;
+      for (uint32_t probe = 0; probe < w.icap; ++probe) {
+        const unsigned long long old = atomicCAS((unsigned long long*)&w.idkeys[s], HEMPTY, f);
+        if (old == HEMPTY) {
+          if (atomicAdd(&w.counters[0], 1u) >= w.node_cap) atomicOr(&w.counters[3], 2u);
+          ok = true;
+          break;
+        }
+        if (old == f) { ok = true; break; }
+        s = (s + 1) & (w.icap - 1);
+      }
+      if (!ok) { atomicOr(&w.counters[3], 2u); continue; }
+      atomicAdd(&w.tcount[s], (unsigned long long)len);
+      atomicMin(&w.tzmin[s], z0 + z);
+      atomicMax(&w.tzmax[s], z0 + z);
+    }
+  }
+}
+
+__global__ void ltab_compact_kernel(AggWs w) {
+  if (w.counters[3]) return;
+  for (uint32_t s = blockIdx.x * blockDim.x + threadIdx.x; s < w.icap; s += gridDim.x * blockDim.x) {
+    if (w.idkeys[s] == HEMPTY) continue;
+    const uint32_t i = atomicAdd(&w.counters[1], 1u);
+    if (i < w.node_cap) {
+      w.idu[i] = w.idkeys[s];
+      w.ha[i] = s;
+    }
+  }
+}
+
+__global__ void ltab_pad_kernel(AggWs w) {
+  const uint32_t nn = min(w.counters[0], w.node_cap);
+  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < w.node_cap; i += gridDim.x * blockDim.x)
+    if (i >= nn) { w.idu[i] = HEMPTY; w.ha[i] = 0; }
+}
+
+__global__ void ltab_gather_kernel(AggWs w, uint64_t* __restrict__ ids, uint64_t* __restrict__ counts, int32_t* __restrict__ zmin,
+                                   int32_t* __restrict__ zmax, uint64_t cap, uint64_t* __restrict__ n_out) {
+  if (w.counters[3]) return;
+  const uint32_t nn = w.counters[0];
+  if (nn > cap) {
+    if (blockIdx.x == 0 && threadIdx.x == 0) atomicOr(&w.counters[3], 32u);
+    return;
+  }
+  if (blockIdx.x == 0 && threadIdx.x == 0) *n_out = nn;
+  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < nn; i += gridDim.x * blockDim.x) {
+    const uint32_t s = w.hb[i];
+    ids[i] = w.ids[i];
+    counts[i] = w.tcount[s];
+    zmin[i] = w.tzmin[s];
+    zmax[i] = w.tzmax[s];
+  }
+}
+
 // per-label voxel count and coordinate sums (RAG node attributes, watershed_frags.py:230-246)
 __global__ void label_stats_kernel(const uint64_t* __restrict__ lab, int D, int H, int W, uint64_t id_offset, uint64_t num,
                                    unsigned long long* __restrict__ size, unsigned long long* __restrict__ sums) {
@@ -1312,6 +1395,7 @@ int bsmi_seg_create(int device, const int64_t max_shape[3], bsmi_seg** out) {
   A(g.skeys, (size_t)g.hcap); A(g.sslot, (size_t)g.hcap); A(g.iota, (size_t)g.hcap); A(g.qnext, (size_t)g.edge_cap);
   A(g.tnext, (size_t)g.node_cap * 2); A(g.tscore, (size_t)g.node_cap * 2); A(g.cur, (size_t)g.node_cap);
   A(g.ha, (size_t)g.node_cap); A(g.hb, (size_t)g.node_cap); A(h->rag_counts, 4);
+  A(g.tcount, (size_t)g.icap); A(g.tzmin, (size_t)g.icap); A(g.tzmax, (size_t)g.icap);
   if (!rc) {
     size_t b1 = 0, b2 = 0;
     if (hipcub::DeviceRadixSort::SortKeys(nullptr, b1, (const uint64_t*)nullptr, (uint64_t*)nullptr, (int)g.node_cap) != hipSuccess ||
@@ -1597,6 +1681,29 @@ int bsmi_cc_affs_u8(bsmi_seg* h, const uint8_t* affs_dev, const int64_t shape[3]
       hipLaunchKernelGGL(frag_filter_kernel, dim3(grid), dim3(bs), 0, s, seg_dev, n, f);
     }
   }
+  BSMI_HIP(hipGetLastError());
+  return BSMI_OK;
+}
+
+int bsmi_label_table_u64(bsmi_seg* h, const uint64_t* labels_dev, const int64_t shape[3], int64_t z0, uint64_t* ids_dev, uint64_t* counts_dev,
+                         int32_t* zmin_dev, int32_t* zmax_dev, uint64_t capacity, uint64_t* n_dev, void* stream) {
+  int rc = check_seg_shape(h, shape);
+  if (rc) return rc;
+  if (!labels_dev || !ids_dev || !counts_dev || !zmin_dev || !zmax_dev || !n_dev) BSMI_FAIL(BSMI_ERR_INVALID, "null argument");
+  BSMI_HIP(hipSetDevice(h->device));
+  hipStream_t s = (hipStream_t)stream;
+  AggWs& g = h->agg;
+  const int D = (int)shape[0], H = (int)shape[1], W = (int)shape[2];
+  BSMI_HIP(hipMemsetAsync(g.counters, 0, 8 * sizeof(uint32_t), s));
+  BSMI_HIP(hipMemsetAsync(n_dev, 0, sizeof(uint64_t), s));
+  hipLaunchKernelGGL(ltab_clear_kernel, dim3(512), dim3(256), 0, s, g);
+  const size_t nrows = (size_t)D * H;
+  hipLaunchKernelGGL(ltab_scan_kernel, dim3((unsigned)std::min<size_t>((nrows + 63) / 64, 8192)), dim3(64), 0, s, labels_dev, D, H, W, (int)z0, g);
+  hipLaunchKernelGGL(ltab_compact_kernel, dim3(512), dim3(256), 0, s, g);
+  hipLaunchKernelGGL(ltab_pad_kernel, dim3(256), dim3(256), 0, s, g);
+  size_t tb = h->sort_tmp_bytes;
+  BSMI_HIP(hipcub::DeviceRadixSort::SortPairs(h->sort_tmp, tb, (const uint64_t*)g.idu, g.ids, (const uint32_t*)g.ha, g.hb, (int)g.node_cap, 0, 64, s));
+  hipLaunchKernelGGL(ltab_gather_kernel, dim3(256), dim3(256), 0, s, g, ids_dev, counts_dev, zmin_dev, zmax_dev, capacity, n_dev);
   BSMI_HIP(hipGetLastError());
   return BSMI_OK;
 }

@@ -131,6 +131,26 @@ class SegEngine:
                                   C.c_void_p(frags.data_ptr()), C.c_void_p(seg.data_ptr()), C.c_void_p(num.data_ptr()), self._stream()))
         return frags, seg, num
 
+    def label_table(self, labels, z0=0):
+        """Distinct non-zero ids (ascending), voxel counts and first / last z slice of an int64 CUDA label block
+        (`bs refine` statistics, reference refine.py:98-109, 228-250).  Synchronises.  -> numpy (ids u64, counts, zmin, zmax)."""
+        if labels.dtype != torch.int64 or labels.dim() != 3 or not labels.is_cuda:
+            raise ValueError("labels must be an int64 CUDA tensor of shape (D, H, W)")
+        lab = labels.contiguous()
+        cap = max(1024, lab.numel() // 8 + 1024)
+        dev = lab.device
+        ids = torch.empty(cap, dtype=torch.int64, device=dev)
+        counts = torch.empty(cap, dtype=torch.int64, device=dev)
+        zmin = torch.empty(cap, dtype=torch.int32, device=dev)
+        zmax = torch.empty(cap, dtype=torch.int32, device=dev)
+        n = torch.zeros(1, dtype=torch.int64, device=dev)
+        check(lib.bsmi_label_table_u64(self._h, C.c_void_p(lab.data_ptr()), _lib.i64x3(lab.shape), int(z0), C.c_void_p(ids.data_ptr()),
+                                       C.c_void_p(counts.data_ptr()), C.c_void_p(zmin.data_ptr()), C.c_void_p(zmax.data_ptr()), cap,
+                                       C.c_void_p(n.data_ptr()), self._stream()))
+        self.status()
+        k = int(n.item())
+        return (ids[:k].cpu().numpy().view("uint64"), counts[:k].cpu().numpy(), zmin[:k].cpu().numpy(), zmax[:k].cpu().numpy())
+
     def status(self):
         check(lib.bsmi_seg_status(self._h, self._stream()))
 

@@ -228,6 +228,14 @@ int bsmi_connected_components(const uint64_t *nodes, uint64_t n, const uint64_t 
 int bsmi_cc_affs_u8(bsmi_seg *h, const uint8_t *affs_dev, const int64_t shape[3], int cut, int64_t min_size,
                     uint64_t *frags_dev, uint64_t *seg_dev, uint64_t *num_labels_dev, void *stream);
 
+/* Label table of a block (`bs refine` statistics: reference refine.py:98-109 `_global_sizes`, :228-250 z extents):
+ * the distinct non-zero ids of labels_dev in ascending order with their voxel counts and first / last z slice
+ * (z0 = global index of the block's first slice).  *n_dev = number of ids (<= capacity, else bsmi_seg_status
+ * reports an overflow).  The filters themselves mask / remap through bsmi_lut_relabel. */
+int bsmi_label_table_u64(bsmi_seg *h, const uint64_t *labels_dev, const int64_t shape[3], int64_t z0,
+                         uint64_t *ids_dev, uint64_t *counts_dev, int32_t *zmin_dev, int32_t *zmax_dev,
+                         uint64_t capacity, uint64_t *n_dev, void *stream);
+
 /* status of the last asynchronous seg call on this handle (reads a device flag;
  * synchronises `stream`): BSMI_OK or BSMI_ERR_OVERFLOW */
 int bsmi_seg_status(bsmi_seg *h, void *stream);

@@ -248,3 +248,52 @@ def test_cc_segmentation_driver(tmp_path):
     keep = counts >= 20
     keep[0] = False
     assert np.array_equal(open_ds(written[1])[:], np.where(keep[ref], ref, 0).astype(np.uint64))
+
+
+def test_refine_filters(tmp_path):
+    """`bs refine` size / outlier / z filters and remap against a numpy restatement of the reference's formulas
+    (refine.py:98-307; fastremap and daisy are absent, so the reference file itself cannot run here)."""
+    from bootstrapper_amd import refine as R
+    from bootstrapper_amd.zarr_io import open_ds, prepare_ds
+    rng = np.random.default_rng(6)
+    vol = np.zeros((24, 90, 70), dtype=np.uint64)
+    nid = 1
+    for _ in range(60):
+        z, y, x = rng.integers(0, 20), rng.integers(0, 80), rng.integers(0, 60)
+        dz, dy, dx = rng.integers(1, 8), rng.integers(2, 25), rng.integers(2, 25)
+        vol[z:z + dz, y:y + dy, x:x + dx] = nid * 1_000_003 + (1 << 40)      # sparse 64-bit ids
+        nid += 1
+    store = str(tmp_path / "s.zarr")
+    ds = prepare_ds(store + "/seg", vol.shape, offset=(0, 0, 0), voxel_size=(40, 4, 4), chunk_shape=(8, 32, 32), dtype=np.uint64,
+                    axis_names=["z", "y", "x"], units=["nm"] * 3, compressor="zlib")
+    ds[:] = vol
+    ids, sizes = np.unique(vol[vol > 0], return_counts=True)
+    zz = np.nonzero(vol)
+    zmin = {i: int(zz[0][vol[zz] == i].min()) for i in ids}
+    zmax = {i: int(zz[0][vol[zz] == i].max()) for i in ids}
+    tid, tsz, tzmin, tzmax = R.label_table(open_ds(store + "/seg"))
+    assert np.array_equal(tid, ids) and np.array_equal(tsz, sizes)
+    assert [zmin[i] for i in ids] == tzmin.tolist() and [zmax[i] for i in ids] == tzmax.tolist()
+
+    def masked(remove):
+        out = vol.copy()
+        out[np.isin(out, remove)] = 0
+        return out
+    out = R.size_filter(store + "/seg", min_size=300, max_size=4000)
+    assert out == store + "/seg_size_filtered"
+    o = open_ds(out)
+    assert o.chunks == (8, 32, 32) and o.voxel_size == (40, 4, 4)
+    assert np.array_equal(o[:], masked(ids[(sizes < 300) | (sizes > 4000)]))
+    stat = sizes[sizes >= 50]
+    lo, hi = stat.mean() - 1.0 * stat.std(), stat.mean() + 1.0 * stat.std()
+    out = R.outlier_filter(store + "/seg", num_std=1.0, min_size=50)
+    assert np.array_equal(open_ds(out)[:], masked(ids[(sizes < lo) | (sizes > hi)]))
+    out = R.z_filter(store + "/seg", min_z=3)
+    assert np.array_equal(open_ds(out)[:], masked(np.array([i for i in ids if zmax[i] - zmin[i] + 1 <= 3], dtype=np.uint64)))
+    a, b, c = int(ids[3]), int(ids[7]), int(ids[11])
+    out = R.remap(store + "/seg", remove_ids=f"{a}", merge_ids=(f"{b},{c}",))
+    want = vol.copy()
+    want[want == a] = 0
+    want[want == c] = b
+    assert out == store + "/seg_remapped" and np.array_equal(open_ds(out)[:], want)
+    assert R.size_filter(store + "/seg", min_size=10, dry_run=True) is None
