@@ -206,6 +206,7 @@ def main():
     ap.add_argument("--no-segment", action="store_true", help="predict only (diagnostic; not the headline metric)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--seg-stages", default="ws,agg", help="diagnostic: which segmentation stages the lanes run")
+    ap.add_argument("--seg-burst", type=int, default=0, help="launch the segmentation of this many blocks together (0: block by block)")
     args = ap.parse_args()
     if args.mode == "train":
         if args.steps == 32 and "--steps" not in sys.argv:
@@ -247,7 +248,7 @@ def main():
 
     pipe = BlockPipeline(model, OUT_BLOCK, CONTEXT, THRESHOLDS, n_seg_lanes=args.seg_lanes,
                          segment=not args.no_segment, device=local_rank, models=models, seg_cus=args.seg_cus,
-                         seg_stages=tuple(args.seg_stages.split(",")))
+                         seg_stages=tuple(args.seg_stages.split(",")), seg_burst=args.seg_burst)
 
     def barrier():
         torch.cuda.synchronize(dev)
@@ -292,7 +293,7 @@ def main():
                                "3d_affs U-Net (94.7M params, seeded random weights) + xy seeded watershed + mean-affinity "
                                "agglomeration at [0.2,0.35,0.5]",
                    "blocks_per_gpu": args.steps, "parallelism": f"blocks interleaved over {world} GPU(s), no collectives",
-                   "seg_lanes": args.seg_lanes, "pred_lanes": len(models), "seg_cus": pipe.seg_cus},
+                   "seg_lanes": args.seg_lanes, "pred_lanes": len(models), "seg_cus": pipe.seg_cus, "seg_burst": pipe.seg_burst},
         "roofline": {"bound": "mfma", "achieved": achieved, "peak": BF16_DENSE_PEAK_TFLOPS if args.precision == "bf16" else 157.3,
                      "unit": "TFLOP/s", "frac": achieved / (BF16_DENSE_PEAK_TFLOPS if args.precision == "bf16" else 157.3),
                      "traffic": traffic, "traffic_unit": "bytes per launch (memory side of L2, Infinity-Cache hits included)",

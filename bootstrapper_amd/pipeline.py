@@ -34,7 +34,7 @@ def cu_masked_stream(device, first_bit, n_bits, total_bits):
 
 class BlockPipeline:
     def __init__(self, model, out_block, context, thresholds=(0.2, 0.35, 0.5), min_seed_distance=10,
-                 n_seg_lanes=4, segment=True, device=0, keep_outputs=False, models=None, seg_cus=0, seg_stages=("ws", "agg")):
+                 n_seg_lanes=4, segment=True, device=0, keep_outputs=False, models=None, seg_cus=0, seg_stages=("ws", "agg"), seg_burst=0):
         # `models`: optional list of Model replicas (same weights), one per predict stream.  Two
         # predict streams let the last, partially filled round of workgroups of one block's
         # conv launch overlap with the other block's launches (each replica owns its activations).
@@ -49,6 +49,10 @@ class BlockPipeline:
         self.msd = int(min_seed_distance)
         self.segment = bool(segment)
         self.seg_stages = tuple(seg_stages)  # diagnostic: run only part of the segmentation half
+        # seg_burst = B > 0: the segmentation of B consecutive blocks is launched together, after the last of them has been
+        # predicted (needs n_seg_lanes >= B to run them side by side); 0: every block's segmentation follows its predict
+        self.seg_burst = int(seg_burst)
+        self._pending = []
         self.dev = torch.device("cuda", device)
         self.keep = keep_outputs
         # The U-Net's big layers run as persistent workgroups that want a whole CU each (all of its
@@ -99,6 +103,16 @@ class BlockPipeline:
                 if self.keep:
                     self.results.append((off, u8, None, None))
                 continue
+            self._pending.append((lane, off, raw, u8))
+            if len(self._pending) >= max(1, self.seg_burst):
+                self._launch_segmentation(ready)
+        if self._pending:
+            self._launch_segmentation(ready)
+
+    def _launch_segmentation(self, ready):
+        """Segmentation of the pending blocks, each on its lane, once `ready` (the last predict of the group) has fired."""
+        pending, self._pending = self._pending, []
+        for lane, off, raw, u8 in pending:
             with torch.cuda.stream(lane["stream"]):
                 lane["stream"].wait_event(ready)
                 affs = u8[0][:3]
