@@ -1278,6 +1278,209 @@ __global__ void ltab_gather_kernel(AggWs w, uint64_t* __restrict__ ids, uint64_t
   }
 }
 
+// ------------------------------------------------------------------------------------------
+// fragments_in_xy = False (reference post/ws.py:97-110): one 3-D domain.  Same steps as the per-slice path --
+// mask (a_z + a_y + a_x >= 383), exact squared EDT, separable reflect max filter, 6-connected maxima components in
+// raster order, literal replay of skimage's heap -- but the flood is ONE sequential queue over the whole volume (the
+// reference's own algorithm), so this mode is latency-bound on a single wave; the parallel steps are plain kernels.
+// ------------------------------------------------------------------------------------------
+constexpr int INF3 = 1 << 28;
+
+__global__ void ws3_mask_kernel(const uint8_t* __restrict__ affs, size_t n, uint8_t* __restrict__ mask, int* __restrict__ any_bg) {
+  int bg = 0;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    const int m = (int)affs[i] + (int)affs[n + i] + (int)affs[2 * n + i] >= 383;
+    mask[i] = (uint8_t)m;
+    bg |= !m;
+  }
+  if (bg) atomicOr(any_bg, 1);
+}
+
+// x pass: squared distance to the nearest background voxel of the same row (INF3 if none); one thread per row
+__global__ void ws3_edt_x_kernel(const uint8_t* __restrict__ mask, int rows, int W, int32_t* __restrict__ g) {
+  for (int r = blockIdx.x * blockDim.x + threadIdx.x; r < rows; r += gridDim.x * blockDim.x) {
+    const uint8_t* m = mask + (size_t)r * W;
+    int32_t* o = g + (size_t)r * W;
+    int last = -INF3;
+    for (int x = 0; x < W; ++x) {
+      if (!m[x]) last = x;
+      o[x] = last <= -INF3 ? INF3 : (x - last) * (x - last);
+    }
+    last = INF3;
+    for (int x = W - 1; x >= 0; --x) {
+      if (!m[x]) last = x;
+      if (last < INF3) {
+        const int d = (last - x) * (last - x);
+        if (d < o[x]) o[x] = d;
+      }
+    }
+  }
+}
+
+// out[p] = min over k along `axis` of in[p with coordinate k] + (coord - k)^2 (exact; brute force over the axis)
+__global__ void ws3_edt_axis_kernel(const int32_t* __restrict__ in, int D, int H, int W, int axis, int32_t* __restrict__ out) {
+  const size_t n = (size_t)D * H * W;
+  const size_t stride = axis == 0 ? (size_t)H * W : (size_t)W;
+  const int len = axis == 0 ? D : H;
+  for (size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x; p < n; p += (size_t)gridDim.x * blockDim.x) {
+    const int c = axis == 0 ? (int)(p / ((size_t)H * W)) : (int)((p / W) % H);
+    const size_t base = p - (size_t)c * stride;
+    int best = INF3;
+    for (int k = 0; k < len; ++k) {
+      const int v = in[base + (size_t)k * stride];
+      if (v >= INF3) continue;
+      const int d = v + (c - k) * (c - k);
+      best = d < best ? d : best;
+    }
+    out[p] = best;
+  }
+}
+
+// scipy's result when the volume has no background voxel at all: as if the only one sat at index (-1, 0, 0)
+__global__ void ws3_edt_nobg_kernel(int D, int H, int W, const int* __restrict__ any_bg, int32_t* __restrict__ d2) {
+  if (*any_bg) return;
+  const size_t n = (size_t)D * H * W;
+  for (size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x; p < n; p += (size_t)gridDim.x * blockDim.x) {
+    const int x = (int)(p % W), y = (int)((p / W) % H), z = (int)(p / ((size_t)H * W));
+    d2[p] = (z + 1) * (z + 1) + y * y + x * x;
+  }
+}
+
+// maximum over the window [c - size/2, c + size - 1 - size/2] along `axis`, border mode reflect (edge duplicated)
+__global__ void ws3_maxfilter_kernel(const int32_t* __restrict__ in, int D, int H, int W, int axis, int size, int32_t* __restrict__ out) {
+  const size_t n = (size_t)D * H * W;
+  const size_t stride = axis == 0 ? (size_t)H * W : (axis == 1 ? (size_t)W : 1);
+  const int len = axis == 0 ? D : (axis == 1 ? H : W);
+  const int left = size / 2, right = size - 1 - size / 2;
+  for (size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x; p < n; p += (size_t)gridDim.x * blockDim.x) {
+    const int c = axis == 0 ? (int)(p / ((size_t)H * W)) : (axis == 1 ? (int)((p / W) % H) : (int)(p % W));
+    const size_t base = p - (size_t)c * stride;
+    int m = INT32_MIN;
+    for (int k = c - left; k <= c + right; ++k) {
+      const int v = in[base + (size_t)reflect_dup(k, len) * stride];
+      m = v > m ? v : m;
+    }
+    out[p] = m;
+  }
+}
+
+// maxima flag (as the uint64 "value" array of the cc kernels) and union-find initialisation
+__global__ void ws3_maxima_kernel(const int32_t* __restrict__ d2, const int32_t* __restrict__ mf, size_t n, uint64_t* __restrict__ flag, FragWs w) {
+  for (size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x; p < n; p += (size_t)gridDim.x * blockDim.x) {
+    const bool mx = d2[p] == mf[p];
+    flag[p] = mx ? 1ull : 0ull;
+    w.par[p] = mx ? (int32_t)p : -1;
+  }
+}
+
+// 6-connected union of equal non-zero values with the three raster-preceding neighbours
+__global__ void cc6_union_kernel(const uint64_t* __restrict__ x, int D, int H, int W, FragWs w) {
+  const size_t n = (size_t)D * H * W, hw = (size_t)H * W;
+  for (size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x; p < n; p += (size_t)gridDim.x * blockDim.x) {
+    const uint64_t v = x[p];
+    if (!v) continue;
+    const int xx = (int)(p % W), y = (int)((p / W) % H), z = (int)(p / hw);
+    const bool ok[3] = {z > 0, y > 0, xx > 0};
+    const size_t st[3] = {hw, (size_t)W, 1};
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+      if (!ok[d] || x[p - st[d]] != v) continue;
+      int a = (int)p, b = (int)(p - st[d]);
+      for (;;) {
+        a = cc_find(w.par, a);
+        b = cc_find(w.par, b);
+        if (a == b) break;
+        if (a < b) { const int t = a; a = b; b = t; }
+        const int old = atomicMin(&w.par[a], b);
+        if (old == a) break;
+        a = old;
+      }
+    }
+  }
+}
+
+// markers: component rank of the maxima inside the mask, 0 elsewhere
+__global__ void ws3_markers_kernel(const uint64_t* __restrict__ flag, const uint8_t* __restrict__ mask, size_t n, FragWs w, int32_t* __restrict__ lab) {
+  for (size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x; p < n; p += (size_t)gridDim.x * blockDim.x)
+    lab[p] = (flag[p] && mask[p]) ? w.rank[cc_find(w.par, (int)p)] : 0;
+}
+
+// heap entry of the 3-D flood: [63:46] = MAXD2 - d2 (18 bit) | [45:23] = age (23 bit) | [22:0] = voxel index
+__device__ __forceinline__ bool flood3_smaller(uint64_t a, uint64_t b) { return (a >> 23) < (b >> 23); }
+
+__global__ __launch_bounds__(64) void ws3_flood_kernel(int D, int H, int W, WsScratch s, uint64_t* __restrict__ hg, uint64_t* __restrict__ frags) {
+  __shared__ uint64_t hl[8192];
+  constexpr int LH = 8192;
+  const size_t n = (size_t)D * H * W, hw = (size_t)H * W;
+  const int lane = threadIdx.x;
+  const uint8_t* mask = s.mask;
+  const int32_t* d2 = s.d2;
+  int32_t* lab = s.lab;
+  if (lane == 0) {
+    constexpr uint64_t MAXD2 = (1u << 18) - 1;
+    size_t items = 0;
+    auto hget = [&](size_t i) -> uint64_t { return i < LH ? hl[i] : hg[i - LH]; };
+    auto hset = [&](size_t i, uint64_t v) { if (i < LH) hl[i] = v; else hg[i - LH] = v; };
+    auto push = [&](uint64_t it) {
+      size_t c = items++;
+      while (c > 0) {
+        const size_t p = (c + 1) / 2 - 1;
+        const uint64_t pv = hget(p);
+        if (flood3_smaller(it, pv)) { hset(c, pv); c = p; } else break;
+      }
+      hset(c, it);
+    };
+    for (size_t i = 0; i < n; ++i)
+      if (lab[i] != 0) push(((MAXD2 - (uint64_t)d2[i]) << 46) | (uint64_t)i);
+    uint64_t age = 0;
+    while (items > 0) {
+      const uint64_t e = hget(0);
+      --items;
+      if (items > 0) {
+        const uint64_t last = hget(items);
+        size_t i = 0;
+        for (;;) {
+          const size_t c1 = 2 * i + 1, c2 = c1 + 1;
+          if (c1 >= items) break;
+          const uint64_t v1 = hget(c1);
+          size_t sm = i;
+          uint64_t smv = last;
+          if (flood3_smaller(v1, smv)) { sm = c1; smv = v1; }
+          if (c2 < items) {
+            const uint64_t v2 = hget(c2);
+            if (flood3_smaller(v2, smv)) { sm = c2; smv = v2; }
+          }
+          if (sm == i) break;
+          hset(i, smv);
+          i = sm;
+        }
+        hset(i, last);
+      }
+      const size_t idx = (size_t)(e & 0x7fffffu);
+      const int x = (int)(idx % W), y = (int)((idx / W) % H), z = (int)(idx / hw);
+      const int l = lab[idx];
+      const size_t nb[6] = {idx - hw, idx - W, idx - 1, idx + 1, idx + W, idx + hw};
+      const bool ok[6] = {z > 0, y > 0, x > 0, x < W - 1, y < H - 1, z < D - 1};
+#pragma unroll
+      for (int k = 0; k < 6; ++k) {
+        if (!ok[k]) continue;
+        const size_t q = nb[k];
+        if (!mask[q] || lab[q] != 0) continue;
+        ++age;
+        lab[q] = l;
+        push(((MAXD2 - (uint64_t)d2[q]) << 46) | (age << 23) | (uint64_t)q);
+      }
+    }
+  }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+  for (size_t i = lane; i < n; i += 64) {
+    const int l = lab[i];
+    frags[i] = l ? (uint64_t)l : 0ull;
+  }
+}
+
 // per-label voxel count and coordinate sums (RAG node attributes, watershed_frags.py:230-246)
 __global__ void label_stats_kernel(const uint64_t* __restrict__ lab, int D, int H, int W, uint64_t id_offset, uint64_t num,
                                    unsigned long long* __restrict__ size, unsigned long long* __restrict__ sums) {
@@ -1447,12 +1650,40 @@ int bsmi_ws_fragments_u8(bsmi_seg* h, const uint8_t* affs_dev, const int64_t sha
   int rc = check_seg_shape(h, shape);
   if (rc) return rc;
   if (!affs_dev || !frags_dev || !max_id_dev) BSMI_FAIL(BSMI_ERR_INVALID, "null argument");
-  if (!fragments_in_xy)
-    BSMI_FAIL(BSMI_ERR_INVALID, "fragments_in_xy=False (3-D flood) is not implemented on the device yet");
   if (min_seed_distance < 1 || min_seed_distance > 64) BSMI_FAIL(BSMI_ERR_INVALID, "min_seed_distance out of range");
   BSMI_HIP(hipSetDevice(h->device));
   hipStream_t s = (hipStream_t)stream;
   const int D = (int)shape[0], H = (int)shape[1], W = (int)shape[2];
+  if (!fragments_in_xy) {
+    const size_t n = (size_t)D * H * W;
+    if (n >= ((size_t)1 << 23) || (size_t)D * D + (size_t)H * H + (size_t)W * W + 2 * D + 1 >= ((size_t)1 << 18))
+      BSMI_FAIL(BSMI_ERR_INVALID, "3-D watershed: volumes of 2^23 voxels or more are not supported by the flood's queue entries");
+    WsScratch& w = h->ws;
+    FragWs& f = h->frag;
+    const int bs = 256;
+    const int grid = (int)std::min<size_t>((n + bs - 1) / bs, 4096);
+    int* any_bg = (int*)h->status_dev;
+    BSMI_HIP(hipMemsetAsync(any_bg, 0, sizeof(int), s));
+    hipLaunchKernelGGL(ws3_mask_kernel, dim3(grid), dim3(bs), 0, s, affs_dev, n, w.mask, any_bg);
+    hipLaunchKernelGGL(ws3_edt_x_kernel, dim3((D * H + 63) / 64), dim3(64), 0, s, (const uint8_t*)w.mask, D * H, W, w.g);
+    hipLaunchKernelGGL(ws3_edt_axis_kernel, dim3(grid), dim3(bs), 0, s, (const int32_t*)w.g, D, H, W, 1, w.mf);
+    hipLaunchKernelGGL(ws3_edt_axis_kernel, dim3(grid), dim3(bs), 0, s, (const int32_t*)w.mf, D, H, W, 0, w.d2);
+    hipLaunchKernelGGL(ws3_edt_nobg_kernel, dim3(grid), dim3(bs), 0, s, D, H, W, (const int*)any_bg, w.d2);
+    hipLaunchKernelGGL(ws3_maxfilter_kernel, dim3(grid), dim3(bs), 0, s, (const int32_t*)w.d2, D, H, W, 2, min_seed_distance, w.g);
+    hipLaunchKernelGGL(ws3_maxfilter_kernel, dim3(grid), dim3(bs), 0, s, (const int32_t*)w.g, D, H, W, 1, min_seed_distance, w.mf);
+    hipLaunchKernelGGL(ws3_maxfilter_kernel, dim3(grid), dim3(bs), 0, s, (const int32_t*)w.mf, D, H, W, 0, min_seed_distance, w.g);
+    f.par = w.par;
+    hipLaunchKernelGGL(ws3_maxima_kernel, dim3(grid), dim3(bs), 0, s, (const int32_t*)w.d2, (const int32_t*)w.g, n, h->crop_tmp, f);
+    hipLaunchKernelGGL(cc6_union_kernel, dim3(grid), dim3(bs), 0, s, (const uint64_t*)h->crop_tmp, D, H, W, f);
+    const uint32_t nblk = (uint32_t)((n + 1023) / 1024);
+    hipLaunchKernelGGL(cc26_count_kernel, dim3(nblk), dim3(1024), 0, s, n, f);
+    hipLaunchKernelGGL(cc26_scan_kernel, dim3(1), dim3(1024), 0, s, nblk, f, max_id_dev);
+    hipLaunchKernelGGL(cc26_rank_kernel, dim3(nblk), dim3(1024), 0, s, n, f);
+    hipLaunchKernelGGL(ws3_markers_kernel, dim3(grid), dim3(bs), 0, s, (const uint64_t*)h->crop_tmp, (const uint8_t*)w.mask, n, f, w.lab);
+    hipLaunchKernelGGL(ws3_flood_kernel, dim3(1), dim3(64), 0, s, D, H, W, w, h->flood_spill, frags_dev);
+    BSMI_HIP(hipGetLastError());
+    return BSMI_OK;
+  }
   {
     // squared distances must fit the uint16 intermediates of the LDS path: H^2 + W^2 < 65535
     const size_t lds = (((size_t)H * (W + 2) * 2 + 15) & ~(size_t)15) + (size_t)H * W * 4;

@@ -33,11 +33,28 @@ def test_fragments_bit_exact_vs_reference_goldens(golden_dir):
     assert n_checked >= 12
 
 
-def test_fragments_3d_mode_raises():
+def test_fragments_3d_mode_bit_exact(golden_dir):
+    """fragments_in_xy=False (post/ws.py:97-110): the reference golden and larger volumes against the oracle, including a
+    volume without any background voxel (scipy's EDT quirk) and one that is all background."""
     from bootstrapper_amd.post.ws import watershed_from_affinities
-    from bootstrapper_amd._lib import BsmiError
-    with pytest.raises(BsmiError):
-        watershed_from_affinities(torch.zeros(3, 4, 8, 8, dtype=torch.uint8, device="cuda"), fragments_in_xy=False)
+    from oracle import seg_ref as S
+    d = np.load(os.path.join(golden_dir, "ws_cases.npz"))
+    n3 = 0
+    for name in sorted({k.split("/")[0] for k in d.files}):
+        xy, msd, max_id = (int(v) for v in d[name + "/meta"])
+        if xy:
+            continue
+        frags, mx = watershed_from_affinities(torch.from_numpy(d[name + "/affs"]).cuda(), fragments_in_xy=False, min_seed_distance=msd)
+        assert mx == max_id and np.array_equal(frags.cpu().numpy().astype(np.uint64), d[name + "/frags"].astype(np.uint64)), name
+        n3 += 1
+    assert n3 >= 1
+    rng = np.random.default_rng(12)
+    cases = [(_blobby(rng, (20, 48, 40), (2, 3, 3)), 5), (_blobby(rng, (9, 33, 70), (1, 2, 2)), 3),
+             (np.full((3, 6, 20, 20), 255, np.uint8), 4), (np.zeros((3, 4, 10, 12), np.uint8), 4)]
+    for affs, msd in cases:
+        ref, ref_max = S.ws_fragments_u8(affs, False, msd)
+        frags, mx = watershed_from_affinities(torch.from_numpy(affs).cuda(), fragments_in_xy=False, min_seed_distance=msd)
+        assert mx == ref_max and np.array_equal(frags.cpu().numpy().astype(np.uint64), ref)
 
 
 @pytest.mark.parametrize("shape,sigma,msd", [((16, 128, 128), (1, 4, 4), 10), ((5, 160, 160), (1, 6, 6), 10),
