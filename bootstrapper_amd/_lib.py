@@ -30,6 +30,17 @@ class UNetConfig(C.Structure):
     ]
 
 
+class Codec(C.Structure):
+    """bsmi_codec of include/bsmi_io.h"""
+    _fields_ = [("id", C.c_int32), ("level", C.c_int32), ("cname", C.c_int32), ("shuffle", C.c_int32),
+                ("typesize", C.c_int32), ("blocksize", C.c_int32)]
+
+
+CODEC_RAW, CODEC_ZLIB, CODEC_GZIP, CODEC_ZSTD, CODEC_LZ4, CODEC_BLOSC = range(6)
+BLOSC_LZ4, BLOSC_ZLIB, BLOSC_ZSTD = 1, 3, 4
+CHUNK_MISSING = 1
+
+
 class BsmiError(RuntimeError):
     def __init__(self, code, msg):
         super().__init__(f"libbsmi error {code}: {msg}")
@@ -82,6 +93,14 @@ def _load():
         "bsmi_unet_set_persistent_grid": (i32, [p, C.c_int]),
         "bsmi_stream_create_cu_mask": (i32, [C.c_int, vp, C.c_int, C.POINTER(C.c_void_p)]),
         "bsmi_stream_destroy": (i32, [C.c_int, vp]),
+        # include/bsmi_io.h
+        "bsmi_codec_bound": (C.c_size_t, [C.POINTER(Codec), C.c_size_t]),
+        "bsmi_codec_decode": (i32, [C.POINTER(Codec), vp, C.c_size_t, vp, C.c_size_t, C.POINTER(C.c_size_t)]),
+        "bsmi_codec_encode": (i32, [C.POINTER(Codec), vp, C.c_size_t, vp, C.c_size_t, C.POINTER(C.c_size_t)]),
+        "bsmi_chunks_read": (i32, [C.POINTER(Codec), i32, C.POINTER(C.c_char_p), C.POINTER(vp), C.POINTER(C.c_size_t),
+                                   C.POINTER(C.c_size_t), C.POINTER(i32), i32]),
+        "bsmi_chunks_write": (i32, [C.POINTER(Codec), i32, C.POINTER(C.c_char_p), C.POINTER(vp), C.POINTER(C.c_size_t),
+                                    C.POINTER(i32), i32]),
     }
     for name, (res, args) in sigs.items():
         fn = getattr(lib, name)  # AttributeError if the symbol is missing: fail loudly

@@ -21,7 +21,7 @@ def _default_out(in_array, suffix):
 
 def _prepare_like(in_ds, out_array):
     return prepare_ds(out_array, shape=in_ds.shape, offset=in_ds.offset, voxel_size=in_ds.voxel_size, axis_names=in_ds.axis_names,
-                      units=in_ds.units, dtype=in_ds.dtype, chunk_shape=in_ds.chunks, compressor=in_ds.compressor)
+                      units=in_ds.units, dtype=in_ds.dtype, chunk_shape=in_ds.chunks, compressor=in_ds.meta.get("compressor"))
 
 
 def _tiles(in_ds, tile=1024):

@@ -3,17 +3,22 @@
 The reference reads and writes volumes through `funlib.persistence.open_ds / prepare_ds`
 (/root/reference/bootstrapper/predict.py:169-178, post/watershed.py:319-330) on top of zarr-python;
 neither package exists on the GPU box, so this module implements the on-disk format directly:
-`.zarray` / `.zattrs` JSON, C-order chunks named by `dimension_separator`, compressors
-null / zlib / gzip (Blosc and zstd need libraries that are not available here: a clear error is
-raised).  Attributes follow funlib.persistence: `offset`, `voxel_size` (alias `resolution`),
-`axis_names`, `units`; a leading channel axis is named "c^".
+`.zarray` / `.zattrs` JSON, C-order chunks named by `dimension_separator`, and the numcodecs
+compressors null / zlib / gzip / zstd / lz4 / blosc (lz4, lz4hc, zstd, zlib, blosclz frames; byte
+and bit shuffle) through libbsmi's chunk codecs (include/bsmi_io.h), which decode and encode the
+chunks of one request on a pool of host threads.  New arrays get zarr-python's default compressor
+(Blosc lz4, clevel 5, byte shuffle), as they do in the reference.  Attributes follow
+funlib.persistence: `offset`, `voxel_size` (alias `resolution`), `axis_names`, `units`; a leading
+channel axis is named "c^".
 """
-import gzip
 import json
 import os
-import zlib
 
 import numpy as np
+
+from . import codecs
+
+IO_THREADS = int(os.environ.get("BSMI_IO_THREADS", "8"))
 
 
 def split_store(path):
@@ -48,10 +53,8 @@ class ZarrArray:
         self.sep = self.meta.get("dimension_separator", ".")
         comp = self.meta.get("compressor")
         self.compressor = None if comp is None else comp.get("id")
-        if self.compressor not in (None, "zlib", "gzip"):
-            raise NotImplementedError(
-                f"zarr compressor {self.compressor!r} is not available in this build (supported: null, zlib, gzip)")
-        self.clevel = 1 if comp is None else int(comp.get("level", 1))
+        self.codec = codecs.from_config(comp, self.dtype.itemsize)
+        self.chunk_nbytes = int(np.prod(self.chunks)) * self.dtype.itemsize
         self.attrs = {}
         za = os.path.join(self.path, ".zattrs")
         if os.path.exists(za):
@@ -107,30 +110,22 @@ class ZarrArray:
     def _chunk_path(self, idx):
         return os.path.join(self.path, self.sep.join(str(i) for i in idx))
 
-    def _read_chunk(self, idx):
-        p = self._chunk_path(idx)
-        if not os.path.exists(p):
-            return np.full(self.chunks, self.fill_value, dtype=self.dtype)
-        with open(p, "rb") as f:
-            raw = f.read()
-        if self.compressor == "zlib":
-            raw = zlib.decompress(raw)
-        elif self.compressor == "gzip":
-            raw = gzip.decompress(raw)
-        return np.frombuffer(raw, dtype=self.dtype).reshape(self.chunks)
+    def _read_chunks(self, idxs):
+        """Chunks `idxs` (grid indices), read and decoded side by side; missing files are fill_value chunks."""
+        bufs = codecs.read_chunks(self.codec, [self._chunk_path(i) for i in idxs], self.chunk_nbytes, IO_THREADS)
+        out = []
+        for b in bufs:
+            if b is None:
+                out.append(np.full(self.chunks, self.fill_value, dtype=self.dtype))
+            else:
+                out.append(b.view(self.dtype).reshape(self.chunks))
+        return out
 
-    def _write_chunk(self, idx, data):
-        raw = np.ascontiguousarray(data, dtype=self.dtype).tobytes()
-        if self.compressor == "zlib":
-            raw = zlib.compress(raw, self.clevel)
-        elif self.compressor == "gzip":
-            raw = gzip.compress(raw, self.clevel)
-        p = self._chunk_path(idx)
-        os.makedirs(os.path.dirname(p), exist_ok=True)
-        tmp = p + f".tmp{os.getpid()}"
-        with open(tmp, "wb") as f:
-            f.write(raw)
-        os.replace(tmp, p)
+    def _write_chunks(self, idxs, arrays):
+        paths = [self._chunk_path(i) for i in idxs]
+        for d in {os.path.dirname(p) for p in paths}:
+            os.makedirs(d, exist_ok=True)
+        codecs.write_chunks(self.codec, paths, [np.ascontiguousarray(a, dtype=self.dtype) for a in arrays], IO_THREADS)
 
     def _norm(self, key):
         if not isinstance(key, tuple):
@@ -144,19 +139,27 @@ class ZarrArray:
             out.append((a, max(a, b)))
         return out
 
+    def _chunk_grid(self, box):
+        ranges = [range(a // c, (b - 1) // c + 1) if b > a else range(0) for (a, b), c in zip(box, self.chunks)]
+        return [tuple(r[i] for r, i in zip(ranges, idx)) for idx in np.ndindex(*[len(r) for r in ranges])]
+
+    def _overlap(self, box, cidx):
+        """(slices inside the chunk, slices inside the box, does the box cover the chunk's valid extent)"""
+        inner, outer, covers = [], [], True
+        for (a, b), c, ci, n in zip(box, self.chunks, cidx, self.shape):
+            lo, hi = max(a, ci * c), min(b, (ci + 1) * c)
+            inner.append(slice(lo - ci * c, hi - ci * c))
+            outer.append(slice(lo - a, hi - a))
+            covers &= lo == ci * c and hi == min((ci + 1) * c, n)
+        return tuple(inner), tuple(outer), covers
+
     def __getitem__(self, key):
         box = self._norm(key)
         out = np.empty([b - a for a, b in box], dtype=self.dtype)
-        ranges = [range(a // c, (b - 1) // c + 1) if b > a else range(0) for (a, b), c in zip(box, self.chunks)]
-        for idx in np.ndindex(*[len(r) for r in ranges]):
-            cidx = tuple(r[i] for r, i in zip(ranges, idx))
-            chunk = self._read_chunk(cidx)
-            src, dst = [], []
-            for (a, b), c, ci in zip(box, self.chunks, cidx):
-                lo, hi = max(a, ci * c), min(b, (ci + 1) * c)
-                src.append(slice(lo - ci * c, hi - ci * c))
-                dst.append(slice(lo - a, hi - a))
-            out[tuple(dst)] = chunk[tuple(src)]
+        grid = self._chunk_grid(box)
+        for cidx, chunk in zip(grid, self._read_chunks(grid)):
+            inner, outer, _ = self._overlap(box, cidx)
+            out[outer] = chunk[inner]
         return out
 
     def __setitem__(self, key, value):
@@ -164,22 +167,17 @@ class ZarrArray:
             raise PermissionError("array opened read-only")
         box = self._norm(key)
         value = np.broadcast_to(np.asarray(value, dtype=self.dtype), [b - a for a, b in box])
-        ranges = [range(a // c, (b - 1) // c + 1) if b > a else range(0) for (a, b), c in zip(box, self.chunks)]
-        for idx in np.ndindex(*[len(r) for r in ranges]):
-            cidx = tuple(r[i] for r, i in zip(ranges, idx))
-            src, dst, covers = [], [], True
-            for (a, b), c, ci, n in zip(box, self.chunks, cidx, self.shape):
-                lo, hi = max(a, ci * c), min(b, (ci + 1) * c)
-                dst.append(slice(lo - ci * c, hi - ci * c))
-                src.append(slice(lo - a, hi - a))
-                # the write covers this chunk along this axis if it spans the chunk's valid extent
-                covers &= lo == ci * c and hi == min((ci + 1) * c, n)
-            if covers:
-                chunk = np.full(self.chunks, self.fill_value, dtype=self.dtype)
-            else:
-                chunk = self._read_chunk(cidx).copy()
-            chunk[tuple(dst)] = value[tuple(src)]
-            self._write_chunk(cidx, chunk)
+        grid = self._chunk_grid(box)
+        overlaps = [self._overlap(box, cidx) for cidx in grid]
+        # chunks the write covers only partly are read back first (one threaded batch), the others start from fill_value
+        partial = [cidx for cidx, (_, _, covers) in zip(grid, overlaps) if not covers]
+        old = dict(zip(partial, self._read_chunks(partial)))
+        chunks = []
+        for cidx, (inner, outer, covers) in zip(grid, overlaps):
+            chunk = np.full(self.chunks, self.fill_value, dtype=self.dtype) if covers else old[cidx].copy()
+            chunk[inner] = value[outer]
+            chunks.append(chunk)
+        self._write_chunks(grid, chunks)
 
     # -- world-unit ROI access ------------------------------------------------------------------
     def roi_to_slices(self, roi_offset, roi_shape):
@@ -213,9 +211,25 @@ def _ensure_groups(container, dataset):
                 json.dump({"zarr_format": 2}, f)
 
 
+def _compressor_config(compressor):
+    if compressor is None:
+        return None
+    if isinstance(compressor, dict):
+        return dict(compressor)
+    if compressor in ("default", "blosc"):
+        return dict(codecs.DEFAULT_COMPRESSOR)
+    if compressor == "lz4":
+        return {"id": "lz4", "acceleration": 1}
+    if compressor in ("zstd", "zlib", "gzip"):
+        return {"id": compressor, "level": 1}
+    raise NotImplementedError(f"zarr compressor {compressor!r} is not supported")
+
+
 def prepare_ds(store, shape, offset=None, voxel_size=None, axis_names=None, units=None, chunk_shape=None,
-               dtype=np.uint8, compressor=None, mode="w"):
-    """Create (or overwrite) a dataset with funlib.persistence-style attributes and open it r+."""
+               dtype=np.uint8, compressor="default", mode="w"):
+    """Create (or overwrite) a dataset with funlib.persistence-style attributes and open it r+.
+    compressor: "default" (zarr-python's Blosc lz4 / clevel 5 / byte shuffle), None (raw chunks), a codec
+    name ("zstd", "zlib", "gzip", "lz4", "blosc") or a numcodecs config dict."""
     container, dataset = split_store(store)
     _ensure_groups(container, dataset)
     path = os.path.join(container, dataset)
@@ -233,7 +247,7 @@ def prepare_ds(store, shape, offset=None, voxel_size=None, axis_names=None, unit
         "zarr_format": 2, "shape": shape, "chunks": chunks,
         "dtype": dt.str if dt.itemsize > 1 else "|" + dt.str[1:], "fill_value": 0, "order": "C", "filters": None,
         "dimension_separator": ".",
-        "compressor": None if compressor is None else {"id": compressor, "level": 1},
+        "compressor": _compressor_config(compressor),
     }
     with open(os.path.join(path, ".zarray"), "w") as f:
         json.dump(meta, f, indent=1)

@@ -1,0 +1,75 @@
+/* bsmi_io.h -- C ABI of the volume I/O half of libbsmi.so: Zarr v2 chunk codecs and threaded
+ * chunk-file decode / encode (host only, no device work).
+ *
+ * Replaces what the reference gets from zarr-python + numcodecs underneath
+ * funlib.persistence.open_ds / prepare_ds (paths relative to /root/reference/bootstrapper:
+ * predict.py:169-178, post/watershed.py:319-330, post/blockwise/watershed_frags.py:61-98,
+ * data/volumes.py:14-19): the `compressor` entry of a `.zarray` selects one bsmi_codec.
+ * Same conventions as bsmi.h: 0 on success, negative on failure, message from
+ * bsmi_last_error() (per calling thread).
+ */
+#ifndef BSMI_IO_H
+#define BSMI_IO_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#include "bsmi.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* bsmi_codec.id: the numcodecs codec of `.zarray["compressor"]["id"]` */
+#define BSMI_CODEC_RAW 0   /* "compressor": null                                       */
+#define BSMI_CODEC_ZLIB 1  /* {"id": "zlib", "level": L}                               */
+#define BSMI_CODEC_GZIP 2  /* {"id": "gzip", "level": L}                               */
+#define BSMI_CODEC_ZSTD 3  /* {"id": "zstd", "level": L}: one zstd frame               */
+#define BSMI_CODEC_LZ4 4   /* {"id": "lz4", "acceleration": A}: u32 size + LZ4 block   */
+#define BSMI_CODEC_BLOSC 5 /* {"id": "blosc", "cname", "clevel", "shuffle", "blocksize"} */
+
+/* bsmi_codec.cname for BSMI_CODEC_BLOSC when encoding (decoding reads it from the frame and
+ * also takes lz4hc and blosclz frames) */
+#define BSMI_BLOSC_LZ4 1
+#define BSMI_BLOSC_ZLIB 3
+#define BSMI_BLOSC_ZSTD 4
+
+/* status of one chunk in bsmi_chunks_read: the file does not exist (zarr: fill_value chunk) */
+#define BSMI_CHUNK_MISSING 1
+
+typedef struct bsmi_codec {
+  int32_t id;        /* BSMI_CODEC_*                                                    */
+  int32_t level;     /* zlib / gzip / zstd level, blosc clevel (0..9)                    */
+  int32_t cname;     /* blosc: BSMI_BLOSC_*                                              */
+  int32_t shuffle;   /* blosc: 0 none, 1 byte shuffle, 2 bit shuffle (numcodecs' -1 "auto"
+                        is resolved by the caller: bit shuffle for 1-byte items)         */
+  int32_t typesize;  /* blosc: item size of the array's dtype                            */
+  int32_t blocksize; /* blosc: 0 = library default                                       */
+} bsmi_codec;
+
+/* Upper bound of the encoded size of n bytes (numcodecs Codec.encode allocates the same way). */
+size_t bsmi_codec_bound(const bsmi_codec *codec, size_t n);
+
+/* numcodecs Codec.decode(buf, out=dst): decode one chunk into dst (capacity cap bytes);
+ * *out_len = decoded bytes.  Fails if the chunk is corrupt or larger than cap.            */
+int bsmi_codec_decode(const bsmi_codec *codec, const void *src, size_t n, void *dst, size_t cap, size_t *out_len);
+
+/* numcodecs Codec.encode(buf): encode n bytes into dst (cap >= bsmi_codec_bound).          */
+int bsmi_codec_encode(const bsmi_codec *codec, const void *src, size_t n, void *dst, size_t cap, size_t *out_len);
+
+/* zarr.Array.__getitem__ over a set of chunks (zarr/core.py _chunk_getitems -> store read +
+ * Codec.decode per chunk): read and decode n chunk files on `threads` host threads.
+ * status[i] = BSMI_OK, BSMI_CHUNK_MISSING (no such file: the caller fills with fill_value) or a
+ * negative code; lens[i] = decoded bytes.  Returns the first failure, if any.               */
+int bsmi_chunks_read(const bsmi_codec *codec, int n, const char *const *paths, void *const *dsts, const size_t *caps,
+                     size_t *lens, int *status, int threads);
+
+/* zarr.Array.__setitem__ over whole chunks (_chunk_setitems -> Codec.encode + store write):
+ * encode and write n chunk files (write to a temporary name, then rename) on `threads` threads. */
+int bsmi_chunks_write(const bsmi_codec *codec, int n, const char *const *paths, const void *const *srcs,
+                      const size_t *sizes, int *status, int threads);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* BSMI_IO_H */

@@ -25,18 +25,46 @@ def test_zarr_roundtrip_and_attrs(tmp_path):
         b.roi_to_slices((81, 16, 16), (400, 64, 64))
     with pytest.raises(PermissionError):
         b[0:1] = 0
-    for comp in ("zlib", "gzip"):
-        q = str(tmp_path / "v.zarr" / comp)
+    for comp in ("zlib", "gzip", "zstd", "lz4", "blosc", "default", None,
+                 {"id": "blosc", "cname": "zstd", "clevel": 3, "shuffle": 2, "blocksize": 0}):
+        q = str(tmp_path / "v.zarr" / f"c{comp if not isinstance(comp, dict) else 'dict'}")
         c = prepare_ds(q, (3, 9, 9), chunk_shape=(3, 4, 4), dtype=np.uint64, compressor=comp)
         y = np.arange(243, dtype=np.uint64).reshape(3, 9, 9)
         c[:] = y
-        assert np.array_equal(open_ds(q)[:], y)
+        d = open_ds(q)
+        assert np.array_equal(d[:], y)
+        assert np.array_equal(d[1:3, 2:7, 3:9], y[1:3, 2:7, 3:9])
+    # new arrays carry zarr-python's default compressor, like the reference's prepare_ds
+    assert json.load(open(os.path.join(p, ".zarray")))["compressor"] == \
+        {"id": "blosc", "cname": "lz4", "clevel": 5, "shuffle": 1, "blocksize": 0}
     # unsupported codec is a clear error, not garbage
     meta = json.load(open(os.path.join(p, ".zarray")))
-    meta["compressor"] = {"id": "blosc", "cname": "lz4"}
+    meta["compressor"] = {"id": "bz2", "level": 1}
     json.dump(meta, open(os.path.join(p, ".zarray"), "w"))
     with pytest.raises(NotImplementedError):
         open_ds(p)
+
+
+def test_zarr_reads_chunks_written_by_c_blosc(tmp_path):
+    """An array whose chunk files are frames produced by c-blosc 1.21.0 (tests/golden/codec_cases.npz), as
+    zarr-python would have written them."""
+    from bootstrapper_amd.zarr_io import open_ds
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "codec_cases.npz"))
+    want = g["plain__raw_u8"].reshape(8, 40, 40)
+    for cname, shuffle in (("lz4", 1), ("zstd", 2), ("blosclz", 0), ("lz4hc", 1), ("zlib", 1)):
+        path = tmp_path / "ext.zarr" / f"{cname}{shuffle}"
+        os.makedirs(path)
+        json.dump({"zarr_format": 2, "shape": [16, 40, 40], "chunks": [8, 40, 40], "dtype": "|u1", "fill_value": 0, "order": "C",
+                   "filters": None, "compressor": {"id": "blosc", "cname": cname, "clevel": 5, "shuffle": shuffle, "blocksize": 0}},
+                  open(path / ".zarray", "w"))
+        json.dump({"resolution": [40, 4, 4], "offset": [0, 0, 0]}, open(path / ".zattrs", "w"))
+        with open(path / "1.0.0", "wb") as f:
+            f.write(g[f"blosc__raw_u8__{cname}__s{shuffle}__b0"].tobytes())
+        a = open_ds(str(path))
+        assert a.voxel_size == (40, 4, 4)
+        got = a[:]
+        assert np.array_equal(got[8:], want) and not got[:8].any()      # chunk 0.0.0 is missing: fill_value
+        assert np.array_equal(a[10:13, 5:30, 7:40], want[2:5, 5:30, 7:40])
 
 
 def test_block_geometry_and_names():

@@ -20,7 +20,10 @@ AFFS_NET_CONFIG = {
 
 def test_library_exports_every_declared_symbol():
     from bootstrapper_amd import _lib
-    hdr = open(os.path.join(ROOT, "include", "bsmi.h")).read()
+    import glob
+    headers = sorted(glob.glob(os.path.join(ROOT, "include", "*.h")))
+    assert len(headers) >= 2
+    hdr = "\n".join(open(h).read() for h in headers)
     declared = set(re.findall(r"\b(bsmi_[a-z0-9_]+)\s*\(", hdr))
     assert declared, "no declarations parsed"
     for name in declared:
