@@ -9,7 +9,7 @@ LIB_PATH = os.environ.get("BSMI_LIB") or os.path.join(_HERE, "libbsmi.so")
 
 MAX_LEVELS, MAX_CONVS, MAX_HEADS, NAME_LEN = 8, 4, 4, 32
 PREC_F32, PREC_BF16 = 0, 1
-RAW_U8, RAW_F32 = 0, 1
+RAW_U8, RAW_F32, RAW_U8_UNIT = 0, 1, 2
 ERR_INVALID, ERR_HIP, ERR_STATE, ERR_MISSING, ERR_OVERFLOW = -1, -2, -3, -4, -5
 
 
@@ -27,6 +27,7 @@ class UNetConfig(C.Structure):
         ("num_heads", C.c_int32),
         ("head_name", (C.c_char * NAME_LEN) * MAX_HEADS),
         ("head_dims", C.c_int32 * MAX_HEADS),
+        ("num_fmaps_out", C.c_int32),
     ]
 
 

@@ -615,7 +615,7 @@ int bsmi_unet_create(const bsmi_unet_config* cfg, int device, bsmi_unet** out) {
   if (!cfg || !out) BSMI_FAIL(BSMI_ERR_INVALID, "null argument");
   if (cfg->num_levels < 1 || cfg->num_levels > BSMI_MAX_LEVELS) BSMI_FAIL(BSMI_ERR_INVALID, "num_levels %d out of range", cfg->num_levels);
   if (cfg->num_heads < 1 || cfg->num_heads > BSMI_MAX_HEADS) BSMI_FAIL(BSMI_ERR_INVALID, "num_heads %d out of range", cfg->num_heads);
-  if (cfg->in_channels < 1 || cfg->num_fmaps < 1 || cfg->fmap_inc_factor < 1) BSMI_FAIL(BSMI_ERR_INVALID, "bad channel configuration");
+  if (cfg->in_channels < 1 || cfg->num_fmaps < 1 || cfg->fmap_inc_factor < 1 || cfg->num_fmaps_out < 0) BSMI_FAIL(BSMI_ERR_INVALID, "bad channel configuration");
   // no HIP call here: shape / flop arithmetic must work on a host without a GPU
   std::unique_ptr<bsmi_unet> h(new bsmi_unet);
   h->cfg = *cfg;
@@ -652,7 +652,7 @@ int bsmi_unet_create(const bsmi_unet_config* cfg, int device, bsmi_unet** out) {
     p.nslots = 2;
     p.cin[0] = fm(l);      // skip connection first (torch.cat([f_cropped, g_cropped]), unet.py:223)
     p.cin[1] = fm(l + 1);
-    p.cout = fm(l);
+    p.cout = (l == 0 && cfg->num_fmaps_out > 0) ? cfg->num_fmaps_out : fm(l);  // unet.py:426-427
     int rc = fill_k(p, cfg->n_convs_up[l], cfg->kernel_size_up[l]);
     if (rc) return rc;
     h->r_conv.push_back(p);
@@ -673,7 +673,7 @@ int bsmi_unet_create(const bsmi_unet_config* cfg, int device, bsmi_unet** out) {
   for (int i = 0; i < cfg->num_heads; ++i) {
     HeadSite hs;
     hs.prefix = std::string(cfg->head_name[i], strnlen(cfg->head_name[i], BSMI_NAME_LEN));
-    hs.cin = cfg->num_fmaps;
+    hs.cin = (cfg->num_fmaps_out > 0 && h->nl > 1) ? cfg->num_fmaps_out : cfg->num_fmaps;
     hs.cout = cfg->head_dims[i];
     if (hs.cout < 1 || hs.cout > 64) BSMI_FAIL(BSMI_ERR_INVALID, "head %s: dims %d unsupported", hs.prefix.c_str(), hs.cout);
     expect_weight(h.get(), hs.prefix + ".conv_pass.0.weight", {hs.cout, hs.cin, 1, 1, 1});
@@ -842,7 +842,7 @@ int bsmi_unet_forward(bsmi_unet* h, int precision, const void* raw_dev, int raw_
                       uint8_t* const* out_u8_dev, void* stream) {
   if (!h || !raw_dev || !in_shape) BSMI_FAIL(BSMI_ERR_INVALID, "null argument");
   if (precision != BSMI_PREC_F32 && precision != BSMI_PREC_BF16) BSMI_FAIL(BSMI_ERR_INVALID, "unknown precision %d", precision);
-  if (raw_dtype != BSMI_RAW_U8 && raw_dtype != BSMI_RAW_F32) BSMI_FAIL(BSMI_ERR_INVALID, "unknown raw dtype %d", raw_dtype);
+  if (raw_dtype != BSMI_RAW_U8 && raw_dtype != BSMI_RAW_F32 && raw_dtype != BSMI_RAW_U8_UNIT) BSMI_FAIL(BSMI_ERR_INVALID, "unknown raw dtype %d", raw_dtype);
   if (!h->finalized[precision]) BSMI_FAIL(BSMI_ERR_STATE, "bsmi_unet_finalize(precision=%d) has not been called", precision);
   int rc = check_shape_arg(in_shape);
   if (rc) return rc;

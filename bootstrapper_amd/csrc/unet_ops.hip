@@ -50,9 +50,10 @@ struct Vec<uint16_t> {
 
 // ---- input: raw [Cin][D][H][W] (u8 or f32) -> [D][H][W][Cpad] ---------------------
 // u8 path restates gp.Normalize + IntensityScaleShift(raw, 2, -1)
-// (reference models/3d_affs/predict.py:147-149): x = u8 * (1/255) * 2 - 1 in f32.
+// (reference models/3d_affs/predict.py:147-149): x = u8 * (1/255) * 2 - 1 in f32;
+// `unit`: gp.Normalize only (x = u8 * (1/255)), the inputs of the second-stage nets.
 template <typename T, typename RAW>
-__global__ void input_prep_kernel(const RAW* raw, T* out, int cin, int cpad, size_t nvox) {
+__global__ void input_prep_kernel(const RAW* raw, T* out, int cin, int cpad, size_t nvox, int unit) {
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   const size_t total = nvox * cpad;
   if (i >= total) return;
@@ -62,7 +63,7 @@ __global__ void input_prep_kernel(const RAW* raw, T* out, int cin, int cpad, siz
   if (c < cin) {
     if constexpr (sizeof(RAW) == 1) {
       x = (float)raw[(size_t)c * nvox + v] * (1.0f / 255.0f);
-      x = x * 2.0f + -1.0f;
+      if (!unit) x = x * 2.0f + -1.0f;
     } else {
       x = (float)raw[(size_t)c * nvox + v];
     }
@@ -75,16 +76,17 @@ int launch_input_prep(int precision, const void* raw, int raw_dtype, void* out, 
   const size_t total = nvox * cpad;
   const int bs = 256;
   const unsigned grid = (unsigned)ceil_div64((int64_t)total, bs);
+  const int unit = raw_dtype == BSMI_RAW_U8_UNIT;
   if (precision == BSMI_PREC_F32) {
-    if (raw_dtype == BSMI_RAW_U8)
-      hipLaunchKernelGGL((input_prep_kernel<float, uint8_t>), dim3(grid), dim3(bs), 0, s, (const uint8_t*)raw, (float*)out, cin, cpad, nvox);
+    if (raw_dtype != BSMI_RAW_F32)
+      hipLaunchKernelGGL((input_prep_kernel<float, uint8_t>), dim3(grid), dim3(bs), 0, s, (const uint8_t*)raw, (float*)out, cin, cpad, nvox, unit);
     else
-      hipLaunchKernelGGL((input_prep_kernel<float, float>), dim3(grid), dim3(bs), 0, s, (const float*)raw, (float*)out, cin, cpad, nvox);
+      hipLaunchKernelGGL((input_prep_kernel<float, float>), dim3(grid), dim3(bs), 0, s, (const float*)raw, (float*)out, cin, cpad, nvox, 0);
   } else {
-    if (raw_dtype == BSMI_RAW_U8)
-      hipLaunchKernelGGL((input_prep_kernel<uint16_t, uint8_t>), dim3(grid), dim3(bs), 0, s, (const uint8_t*)raw, (uint16_t*)out, cin, cpad, nvox);
+    if (raw_dtype != BSMI_RAW_F32)
+      hipLaunchKernelGGL((input_prep_kernel<uint16_t, uint8_t>), dim3(grid), dim3(bs), 0, s, (const uint8_t*)raw, (uint16_t*)out, cin, cpad, nvox, unit);
     else
-      hipLaunchKernelGGL((input_prep_kernel<uint16_t, float>), dim3(grid), dim3(bs), 0, s, (const float*)raw, (uint16_t*)out, cin, cpad, nvox);
+      hipLaunchKernelGGL((input_prep_kernel<uint16_t, float>), dim3(grid), dim3(bs), 0, s, (const float*)raw, (uint16_t*)out, cin, cpad, nvox, 0);
   }
   BSMI_HIP(hipGetLastError());
   return BSMI_OK;

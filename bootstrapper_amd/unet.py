@@ -19,7 +19,8 @@ from . import _lib
 from ._lib import lib, check
 
 # net_config["outputs"] key -> state-dict prefix of the head the reference Model builds
-HEAD_OF_OUTPUT = {"3d_affs": "affs_head", "3d_lsds": "lsds_head"}
+# (3-D: models/3d_mtlsd/model.py:54-59; 2-D: models/2d_mtlsd/model.py:56-61)
+HEAD_OF_OUTPUT = {"3d_affs": "affs_head", "3d_lsds": "lsds_head", "2d_affs": "aff_head", "2d_lsds": "lsd_head"}
 
 PRECISIONS = {"f32": _lib.PREC_F32, "fp32": _lib.PREC_F32, "float32": _lib.PREC_F32,
               "bf16": _lib.PREC_BF16, "bfloat16": _lib.PREC_BF16}
@@ -29,11 +30,33 @@ def _tuplify(x):
     return [[int(v) for v in ks] for ks in x]
 
 
+def _lift(k):
+    """2-D kernel / factor (h, w) -> the 3-D one with unit depth."""
+    k = [int(v) for v in k]
+    if len(k) == 2:
+        return [1] + k
+    if len(k) != 3:
+        raise ValueError("only 2-D and 3-D networks are supported by this engine")
+    return k
+
+
+def input_channels(net_config):
+    """models/2d_mtlsd/model.py:46 (in_channels * adj_slices), models/3d_affs_from_2d_mtlsd/model.py:15 (sum of the
+    input dims), models/3d_affs/model.py:13 (in_channels)."""
+    if "in_channels" in net_config:
+        return int(net_config["in_channels"]) * int(net_config.get("adj_slices", 1))
+    return sum(int(v["dims"]) for v in net_config["inputs"].values())
+
+
 def make_config(net_config):
-    """net_config.json dict -> _lib.UNetConfig (same keys Model() reads, model.py:10-25)."""
+    """net_config.json dict -> _lib.UNetConfig (same keys Model() reads, model.py:10-25).
+    The 2-D setups (models/2d_*: Conv2d, MaxPool2d, bilinear upsampling over (h, w)) are the same network
+    with unit-depth kernels and factors over a (1, h, w) volume; their state-dict tensors get the depth axis
+    in Model.load_state_dict."""
     cfg = _lib.UNetConfig()
-    cfg.in_channels = int(net_config["in_channels"])
+    cfg.in_channels = input_channels(net_config)
     cfg.num_fmaps = int(net_config["num_fmaps"])
+    cfg.num_fmaps_out = int(net_config.get("num_fmaps_out") or 0)
     cfg.fmap_inc_factor = int(net_config["fmap_inc_factor"])
     dfs = net_config["downsample_factors"]
     nl = len(dfs) + 1
@@ -41,28 +64,27 @@ def make_config(net_config):
         raise ValueError(f"at most {_lib.MAX_LEVELS} levels supported")
     cfg.num_levels = nl
     for i, f in enumerate(dfs):
-        if len(f) != 3:
-            raise ValueError("only 3-D networks are supported by this engine")
+        f = _lift(f)
         for d in range(3):
-            cfg.downsample_factors[i][d] = int(f[d])
-    ksd = net_config.get("kernel_size_down") or [[[3, 3, 3], [3, 3, 3]]] * nl
-    ksu = net_config.get("kernel_size_up") or [[[3, 3, 3], [3, 3, 3]]] * (nl - 1)
+            cfg.downsample_factors[i][d] = f[d]
+    nd = len(dfs[0]) if dfs else 3
+    k3 = [3] * nd
+    ksd = net_config.get("kernel_size_down") or [[k3, k3]] * nl
+    ksu = net_config.get("kernel_size_up") or [[k3, k3]] * (nl - 1)
     for dst_n, dst_k, src in ((cfg.n_convs_down, cfg.kernel_size_down, ksd),
                               (cfg.n_convs_up, cfg.kernel_size_up, ksu)):
         for i, ks in enumerate(src):
-            ks = _tuplify(ks)
             if len(ks) > _lib.MAX_CONVS:
                 raise ValueError(f"at most {_lib.MAX_CONVS} convolutions per pass supported")
             dst_n[i] = len(ks)
             for j, k in enumerate(ks):
-                if len(k) != 3:
-                    raise ValueError("only 3-D kernels are supported by this engine")
+                k = _lift(k)
                 for d in range(3):
                     dst_k[i][j][d] = k[d]
     heads = []
     for name, val in net_config["outputs"].items():
         if name not in HEAD_OF_OUTPUT:
-            raise ValueError(f"output {name!r} has no 3-D head in this engine")
+            raise ValueError(f"output {name!r} has no head in this engine")
         heads.append((HEAD_OF_OUTPUT[name], int(val["dims"])))
     if len(heads) > _lib.MAX_HEADS:
         raise ValueError("too many heads")
@@ -91,6 +113,11 @@ class Model:
         self.device = int(device)
         self.precision = PRECISIONS[precision]
         self._cfg, self.heads = make_config(net_config)
+        dfs = net_config["downsample_factors"]
+        self.two_d = bool(dfs) and len(dfs[0]) == 2
+        # networks fed with raw data normalise to [-1, 1], the second-stage ones (inputs = earlier predictions) to [0, 1]
+        self.raw_mode = _lib.RAW_U8 if "in_channels" in net_config else _lib.RAW_U8_UNIT
+        self.stack_infer = False  # models/2d_mtlsd/model.py:31,71-73: add the z axis to the 2-D outputs
         self.param_shapes = {}  # state_dict key -> shape, as loaded
         self._h = C.c_void_p()
         check(lib.bsmi_unet_create(C.byref(self._cfg), self.device, C.byref(self._h)))
@@ -109,9 +136,11 @@ class Model:
             if hasattr(v, "detach"):
                 v = v.detach().cpu().numpy()
             a = np.ascontiguousarray(v, dtype=np.float32)
+            self.param_shapes[k] = tuple(a.shape)
+            if self.two_d and a.ndim == 4:
+                a = a[:, :, None]  # Conv2d weight (O, I, kh, kw) -> (O, I, 1, kh, kw)
             shape = (C.c_int64 * a.ndim)(*a.shape)
             check(lib.bsmi_unet_load_weight(self._h, k.encode(), a.ctypes.data_as(C.c_void_p), shape, a.ndim))
-            self.param_shapes[k] = tuple(a.shape)
         self._finalized.clear()
         self._finalize(self.precision)
         return self
@@ -197,23 +226,38 @@ class Model:
                                     _lib.i64x3(in_shape), pf, pu, C.c_void_p(stream)))
         return f32, u8
 
-    def forward(self, input):
+    def forward(self, *inputs):
+        """3-D setups: (1, C, D, H, W).  Second-stage setups take their inputs one by one, in the order of
+        net_config["inputs"] (models/3d_affs_from_2d_mtlsd/model.py:62-64), and concatenate the channels.
+        2-D setups: (1, C, H, W), or (1, c, d, H, W) which is viewed as (1, c d, H, W) (models/2d_mtlsd/model.py:63-68)."""
+        if not all(t.is_cuda for t in inputs):
+            raise RuntimeError("bootstrapper_amd.Model runs on the GPU only; move the input to cuda")
+        input = inputs[0] if len(inputs) == 1 else torch.cat(inputs, dim=1)
+        if self.two_d:
+            if input.dim() == 5:
+                n, c, d, hh, ww = input.shape
+                input = input.reshape(n, c * d, hh, ww)
+            if input.dim() != 4 or input.shape[0] != 1:
+                raise ValueError("expected input of shape (1, C, H, W)")
+            input = input[:, :, None]
         if input.dim() != 5 or input.shape[0] != 1:
             raise ValueError("expected input of shape (1, C, D, H, W)")
         if input.shape[1] != self._cfg.in_channels:
             raise ValueError(f"expected {self._cfg.in_channels} input channels, got {input.shape[1]}")
-        if not input.is_cuda:
-            raise RuntimeError("bootstrapper_amd.Model runs on the GPU only; move the input to cuda")
         x = input.to(torch.float32).contiguous()
         f32, _ = self._run(x, _lib.RAW_F32, x.shape[2:], True, False)
         outs = [t[None] for t in f32]
+        if self.two_d and not self.stack_infer:
+            outs = [t[:, :, 0] for t in outs]
         return outs[0] if len(outs) == 1 else tuple(outs)
 
     __call__ = forward
 
     def predict_u8(self, raw_u8, want_f32=False):
         """raw_u8: uint8 CUDA tensor (D,H,W) or (Cin,D,H,W) -> list of uint8 (dims,d,h,w)
-        tensors in head order (and the float32 sigmoid outputs if want_f32)."""
+        tensors in head order (and the float32 sigmoid outputs if want_f32).  Normalisation as in the
+        setup's predict.py: u8/255*2-1 for raw data, u8/255 for the predictions a second-stage net reads.
+        A 2-D setup treats D as a stack of independent sections (its kernels have unit depth)."""
         if raw_u8.dtype != torch.uint8 or not raw_u8.is_cuda:
             raise ValueError("raw_u8 must be a uint8 CUDA tensor")
         x = raw_u8.contiguous()
@@ -221,7 +265,7 @@ class Model:
         cin = 1 if x.dim() == 3 else x.shape[0]
         if cin != self._cfg.in_channels:
             raise ValueError(f"expected {self._cfg.in_channels} input channels, got {cin}")
-        f32, u8 = self._run(x, _lib.RAW_U8, shape, want_f32, True)
+        f32, u8 = self._run(x, self.raw_mode, shape, want_f32, True)
         return (u8, f32) if want_f32 else u8
 
 

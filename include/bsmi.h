@@ -40,6 +40,8 @@ extern "C" {
 /* dtype of the raw input handed to bsmi_unet_forward */
 #define BSMI_RAW_U8 0     /* uint8 [Cin][D][H][W]; normalised on device as u8/255*2-1    */
 #define BSMI_RAW_F32 1    /* float [Cin][D][H][W]; already normalised                    */
+#define BSMI_RAW_U8_UNIT 2 /* uint8 [Cin][D][H][W]; normalised on device as u8/255: predictions
+                              fed to a second-stage net (models/3d_affs_from_2d_mtlsd/predict.py:163-164) */
 
 const char *bsmi_last_error(void);
 int bsmi_version(void);
@@ -65,6 +67,8 @@ typedef struct bsmi_unet_config {
   int32_t num_heads;
   char head_name[BSMI_MAX_HEADS][BSMI_NAME_LEN]; /* state-dict prefix, forward() return order */
   int32_t head_dims[BSMI_MAX_HEADS];
+  int32_t num_fmaps_out; /* channels of the last right-side ConvPass (unet.py:239,344,426); 0 = num_fmaps.
+                            Set by the second-stage nets (net_config.json of the models/3d_affs_from_... setups) */
 } bsmi_unet_config;
 
 typedef struct bsmi_unet bsmi_unet;

@@ -157,3 +157,45 @@ def default_cfg(num_fmaps=12, inc=5, in_channels=1):
                 downsample_factors=[[1, 2, 2]] * 3,
                 kernel_size_down=[[[3, 3, 3], [3, 3, 3]]] * 4,
                 kernel_size_up=[[[3, 3, 3], [3, 3, 3]]] * 3)
+
+
+# ---- the other setups of the model family ------------------------------------------------------
+# 2-D setups (models/2d_mtlsd/unet.py: Conv2d, MaxPool2d, mode="bilinear" at :400) are restated as the 3-D
+# operators above over a (1, h, w) volume: unit-depth kernels and factors, and trilinear interpolation with
+# scale 1 along z has weight 1 on the section itself, i.e. it is the bilinear one.  Second-stage setups
+# (models/3d_affs_from_2d_mtlsd/model.py:28-66) use num_fmaps_out for the last right-side ConvPass, which is
+# only visible in the tensor shapes of the state dict, and concatenate their inputs along the channels.
+
+FAMILY_HEADS = {"3d_affs": "affs_head", "3d_lsds": "lsds_head", "2d_affs": "aff_head", "2d_lsds": "lsd_head"}
+
+
+def lift_cfg(net_config):
+    """net_config.json dict of any setup -> cfg for unet_forward (3-D kernel sizes and factors)."""
+    def lift(k):
+        k = [int(v) for v in k]
+        return [1] + k if len(k) == 2 else k
+    dfs = [lift(f) for f in net_config["downsample_factors"]]
+    return dict(downsample_factors=dfs,
+                kernel_size_down=[[lift(k) for k in ks] for ks in net_config["kernel_size_down"]],
+                kernel_size_up=[[lift(k) for k in ks] for ks in net_config["kernel_size_up"]])
+
+
+def lift_sd(sd):
+    """Conv2d weights (O, I, kh, kw) -> (O, I, 1, kh, kw)."""
+    out = {}
+    for k, v in sd.items():
+        v = torch.from_numpy(v) if isinstance(v, np.ndarray) else v
+        out[k] = v[:, :, None] if v.dim() == 4 else v
+    return out
+
+
+def family_forward(net_config, sd, x):
+    """x: float32 (1, C, D, H, W) normalised input ((1, C, 1, H, W) for a 2-D setup).
+    Returns the head outputs (dims, d, h, w) in the order of net_config["outputs"]."""
+    heads = [FAMILY_HEADS[k] for k in net_config["outputs"]]
+    return model_forward(lift_cfg(net_config), lift_sd(sd), x, heads)
+
+
+def normalize_unit(u8):
+    """gp.Normalize alone (models/3d_affs_from_2d_mtlsd/predict.py:163-164)."""
+    return u8.astype(np.float32) * np.float32(1.0 / 255.0)

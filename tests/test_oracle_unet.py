@@ -59,3 +59,36 @@ def test_operators_match_reference(golden_dir):
 def test_downsample_rejects_indivisible():
     with pytest.raises(RuntimeError):
         R.downsample(torch.zeros(1, 1, 4, 7, 6), (1, 2, 2))
+
+
+FAMILY = ["2d_mtlsd_f4i2", "2d_lsd_f3i3", "2d_affs_f4i2", "3d_lsd_f4i2", "from_2d_mtlsd_f3i2", "from_3d_lsd_f4i2",
+          "from_2d_affs_f4i3"]
+
+
+def family_case(golden_dir, tag):
+    """(net_config, state dict, [u8 inputs], normalised float input (1,C,D,H,W), [reference outputs])"""
+    d, sd = _load(golden_dir, f"family_{tag}.npz")
+    nc = json.loads(bytes(d["net_config"]).decode())
+    ins = [d[k] for k in sorted(k for k in d.files if k.startswith("in") and k[2:].isdigit())]
+    if "in_channels" in nc:
+        x = R.normalize_raw(ins[0])
+        x = x[:, None] if "adj_slices" in nc else x[None]      # 2-D: (C, 1, H, W); 3-D raw: (1, D, H, W)
+    else:
+        x = np.concatenate([R.normalize_unit(a) for a in ins], axis=0)
+    outs = [d[k] for k in sorted(k for k in d.files if k.startswith("out"))]
+    return nc, sd, ins, x[None], outs
+
+
+@pytest.mark.parametrize("tag", FAMILY)
+def test_family_matches_reference(golden_dir, tag):
+    """2-D setups restated as unit-depth 3-D operators, second-stage setups with num_fmaps_out and several inputs."""
+    nc, sd, _, x, refs = family_case(golden_dir, tag)
+    outs = R.family_forward(nc, sd, torch.from_numpy(x))
+    assert len(outs) == len(refs)
+    for o, ref in zip(outs, refs):
+        o = o.numpy()
+        if ref.ndim == 3:          # 2-D setup: reference output (dims, h, w)
+            assert o.shape[1] == 1
+            o = o[:, 0]
+        assert o.shape == ref.shape
+        assert np.abs(o - ref).max() < TOL

@@ -142,3 +142,62 @@ def test_forward_before_weights_fails_loudly():
                "outputs": {"3d_affs": {"dims": 6}}})
     with pytest.raises(BsmiError):
         m(torch.zeros(1, 1, 20, 40, 40, device="cuda"))
+
+
+FAMILY = ["2d_mtlsd_f4i2", "2d_lsd_f3i3", "2d_affs_f4i2", "3d_lsd_f4i2", "from_2d_mtlsd_f3i2", "from_3d_lsd_f4i2",
+          "from_2d_affs_f4i3"]
+
+
+@pytest.mark.parametrize("tag", FAMILY)
+@pytest.mark.parametrize("prec,tol", [("f32", TOL_F32), ("bf16", TOL_BF16)])
+def test_model_family_matches_reference_goldens(golden_dir, tag, prec, tol):
+    """The other setups of the family: 2-D nets (Conv2d state dicts, (1,C,H,W) inputs), the LSD-only net and the
+    second-stage nets (several inputs, num_fmaps_out, (1,3,3) kernels), against outputs of the reference models."""
+    from bootstrapper_amd.unet import Model
+    from test_oracle_unet import family_case
+    nc, sd, ins, x, refs = family_case(golden_dir, tag)
+    m = Model(nc, precision=prec).load_state_dict(sd)
+    xt = torch.from_numpy(x).cuda()
+    if m.two_d:
+        y = m(xt[:, :, 0])                                   # (1, C, H, W), like the reference Model.forward
+    elif len(ins) > 1:
+        splits = np.cumsum([a.shape[0] for a in ins])[:-1]
+        y = m(*[torch.from_numpy(p).cuda() for p in np.split(x, splits, axis=1)])   # forward(input_lsds, input_affs)
+    else:
+        y = m(xt)
+    ys = y if isinstance(y, tuple) else (y,)
+    assert len(ys) == len(refs)
+    for i, (t, ref) in enumerate(zip(ys, refs)):
+        got = t[0].cpu().numpy()
+        assert got.shape == ref.shape
+        err = np.abs(got - ref).max()
+        print(f"{tag} {prec} head{i}: max abs err {err:.3e}")
+        assert err < tol
+    if prec == "f32":
+        # u8 in -> u8 out with the setup's own normalisation (raw: u8/255*2-1, predictions: u8/255)
+        raw = torch.from_numpy(np.concatenate(ins, axis=0) if len(ins) > 1 else ins[0]).cuda()
+        if m.two_d:
+            raw = raw[:, None]                                # (C, 1, H, W): one section
+        u8 = m.predict_u8(raw)
+        for t, ref in zip(u8, refs):
+            ref = ref if ref.ndim == 4 else ref[:, None]
+            want = (ref * np.float32(255)).astype(np.uint8)
+            diff = np.abs(t.cpu().numpy().astype(np.int32) - want.astype(np.int32))
+            assert diff.max() <= 1 and (diff == 0).mean() > 0.99
+
+
+def test_2d_setup_predicts_a_stack_of_sections(golden_dir):
+    """A 2-D setup's kernels have unit depth, so a (C, D, H, W) stack is D independent sections in one pass:
+    identical to running the sections one by one."""
+    from bootstrapper_amd.unet import Model
+    from test_oracle_unet import family_case
+    nc, sd, ins, _, _ = family_case(golden_dir, "2d_mtlsd_f4i2")
+    m = Model(nc, precision="f32").load_state_dict(sd)
+    rng = np.random.default_rng(0)
+    vol = torch.from_numpy(rng.integers(0, 256, (7,) + ins[0].shape[1:], dtype=np.uint8)).cuda()   # 7 sections
+    stack = torch.stack([vol[0:5], vol[1:6], vol[2:7]])                                               # (3, 5, H, W)
+    both = m.predict_u8(stack)
+    for z in range(5):
+        one = m.predict_u8(stack[:, z:z + 1])
+        for a, b in zip(both, one):
+            assert torch.equal(a[:, z:z + 1], b)
