@@ -787,6 +787,98 @@ static int make_dgrad(bsmi_unet* h, TrainState* ts, ConvBwd& cb, const ConvBwd* 
 
 using namespace bsmi;
 
+namespace bsmi {
+
+// ---- affinity training targets (GrowBoundary -> AddAffinities -> BalanceLabels) --------------------------
+constexpr int kMaxNeighborhood = 16;
+struct Neighborhood {
+  int n;
+  int off[kMaxNeighborhood][3];
+};
+
+// out[p] = labels[p] if every voxel within L1 distance `steps` of p (same section if only_xy) has p's label,
+// is unknown (unl == 0) or lies outside the block; else 0.  `steps` erosions with the 6- (4-) neighbour cross =
+// one erosion with that L1 ball.  An unknown voxel belongs to every label's mask (custom_grow_boundary.py:96-100):
+// it survives if the known voxels of its ball carry at most one label.
+__global__ void grow_boundary_kernel(const int64_t* __restrict__ labels, const uint8_t* __restrict__ unl, int64_t* __restrict__ out,
+                                     int D, int H, int W, int steps, int only_xy) {
+  const size_t nvox = (size_t)D * H * W;
+  for (size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x; p < nvox; p += (size_t)gridDim.x * blockDim.x) {
+    const int x = (int)(p % W), y = (int)((p / W) % H), z = (int)(p / ((size_t)W * H));
+    const int64_t mine = labels[p];
+    const bool known = !unl || unl[p];
+    int64_t want = known ? mine : -1;  // -1: any one label
+    bool keep = !(known && mine == 0);
+    const int rz = only_xy ? 0 : steps;
+    for (int dz = -rz; dz <= rz && keep; ++dz) {
+      const int zz = z + dz;
+      if (zz < 0 || zz >= D) continue;
+      const int ry = steps - abs(dz);
+      for (int dy = -ry; dy <= ry && keep; ++dy) {
+        const int yy = y + dy;
+        if (yy < 0 || yy >= H) continue;
+        const int rx = ry - abs(dy);
+        for (int dx = -rx; dx <= rx; ++dx) {
+          const int xx = x + dx;
+          if (xx < 0 || xx >= W) continue;
+          const size_t q = ((size_t)zz * H + yy) * W + xx;
+          if (unl && !unl[q]) continue;
+          const int64_t l = labels[q];
+          if (want == -1) want = l;
+          if (l != want || l == 0) { keep = false; break; }
+        }
+      }
+    }
+    out[p] = keep ? mine : 0;
+  }
+}
+
+__global__ void affinity_targets_kernel(const int64_t* __restrict__ labels, const uint8_t* __restrict__ unl, Neighborhood nb, int D, int H,
+                                        int W, float* __restrict__ affs, float* __restrict__ mask, unsigned long long* __restrict__ counts) {
+  const size_t nvox = (size_t)D * H * W;
+  unsigned long long n_mask = 0, n_pos = 0;
+  for (size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x; p < nvox; p += (size_t)gridDim.x * blockDim.x) {
+    const int x = (int)(p % W), y = (int)((p / W) % H), z = (int)(p / ((size_t)W * H));
+    const int64_t a = labels[p];
+    const bool known = !unl || unl[p];
+    for (int e = 0; e < nb.n; ++e) {
+      const int zz = z + nb.off[e][0], yy = y + nb.off[e][1], xx = x + nb.off[e][2];
+      const bool inside = zz >= 0 && zz < D && yy >= 0 && yy < H && xx >= 0 && xx < W;
+      float aff = 0.f, m = 0.f;
+      if (inside) {
+        const int64_t b = labels[((size_t)zz * H + yy) * W + xx];
+        aff = (a == b && a > 0) ? 1.f : 0.f;
+        m = known ? 1.f : 0.f;
+      }
+      affs[(size_t)e * nvox + p] = aff;
+      mask[(size_t)e * nvox + p] = m;
+      n_mask += m > 0.f;
+      n_pos += (m > 0.f && aff > 0.f);
+    }
+  }
+  // wave reduction, then one atomic pair per wave
+  for (int o = 32; o > 0; o >>= 1) {
+    n_mask += __shfl_down(n_mask, o);
+    n_pos += __shfl_down(n_pos, o);
+  }
+  if ((threadIdx.x & 63) == 0) {
+    atomicAdd(&counts[0], n_mask);
+    atomicAdd(&counts[1], n_pos);
+  }
+}
+
+__global__ void balance_kernel(const float* __restrict__ affs, float* __restrict__ weights, size_t total,
+                               const unsigned long long* __restrict__ counts, float clip_min, float clip_max) {
+  const float n_mask = fmaxf((float)counts[0], 1.f);
+  float frac = (float)counts[1] / n_mask;
+  frac = fminf(fmaxf(frac, clip_min), clip_max);
+  const float w_pos = 1.f / (2.f * frac), w_neg = 1.f / (2.f * (1.f - frac));
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x)
+    weights[i] = weights[i] * (affs[i] > 0.f ? w_pos : w_neg);
+}
+
+}  // namespace bsmi
+
 extern "C" {
 
 int bsmi_unet_train_begin(bsmi_unet* h, const int64_t in_shape[3]) {
@@ -1110,6 +1202,41 @@ int bsmi_unet_train_read_param(bsmi_unet* h, const char* key, int what, float* h
   BSMI_HIP(hipSetDevice(h->device));
   BSMI_HIP(hipDeviceSynchronize());
   BSMI_HIP(hipMemcpy(host_out, src + pr.off, pr.count * sizeof(float), hipMemcpyDeviceToHost));
+  return BSMI_OK;
+}
+
+int bsmi_train_affinity_targets(int device, int64_t* labels_dev, const uint8_t* unlabelled_dev, const int64_t shape[3],
+                                const int32_t* neighborhood, int n, int grow_steps, int only_xy, float clip_min, float clip_max,
+                                float* affs_dev, float* weights_dev, void* stream) {
+  if (!labels_dev || !shape || !neighborhood || !affs_dev || !weights_dev) BSMI_FAIL(BSMI_ERR_INVALID, "null argument");
+  if (n < 1 || n > kMaxNeighborhood) BSMI_FAIL(BSMI_ERR_INVALID, "neighborhood of %d offsets (1..%d supported)", n, kMaxNeighborhood);
+  if (grow_steps < 0 || grow_steps > 16) BSMI_FAIL(BSMI_ERR_INVALID, "grow_steps %d outside 0..16", grow_steps);
+  for (int d = 0; d < 3; ++d)
+    if (shape[d] < 1 || shape[d] > 4096) BSMI_FAIL(BSMI_ERR_INVALID, "bad shape");
+  BSMI_HIP(hipSetDevice(device));
+  hipStream_t s = (hipStream_t)stream;
+  const int D = (int)shape[0], H = (int)shape[1], W = (int)shape[2];
+  const size_t nvox = (size_t)D * H * W;
+  Neighborhood nb;
+  nb.n = n;
+  for (int e = 0; e < n; ++e)
+    for (int d = 0; d < 3; ++d) nb.off[e][d] = neighborhood[3 * e + d];
+  // scratch on the stream: the grown labels (the erosion reads its neighbours' old values) and two counters
+  int64_t* grown = nullptr;
+  unsigned long long* counts = nullptr;
+  BSMI_HIP(hipMallocAsync((void**)&grown, nvox * sizeof(int64_t) + 2 * sizeof(unsigned long long), s));
+  counts = (unsigned long long*)(grown + nvox);
+  BSMI_HIP(hipMemsetAsync(counts, 0, 2 * sizeof(unsigned long long), s));
+  const int bs = 256;
+  const unsigned grid = (unsigned)std::min<size_t>((nvox + bs - 1) / bs, 65535);
+  hipLaunchKernelGGL(grow_boundary_kernel, dim3(grid), dim3(bs), 0, s, labels_dev, unlabelled_dev, grown, D, H, W, grow_steps, only_xy);
+  BSMI_HIP(hipMemcpyAsync(labels_dev, grown, nvox * sizeof(int64_t), hipMemcpyDeviceToDevice, s));
+  hipLaunchKernelGGL(affinity_targets_kernel, dim3(grid), dim3(bs), 0, s, grown, unlabelled_dev, nb, D, H, W, affs_dev, weights_dev, counts);
+  const size_t total = nvox * (size_t)n;
+  hipLaunchKernelGGL(balance_kernel, dim3((unsigned)std::min<size_t>((total + bs - 1) / bs, 65535)), dim3(bs), 0, s, affs_dev, weights_dev, total,
+                     counts, clip_min, clip_max);
+  BSMI_HIP(hipGetLastError());
+  BSMI_HIP(hipFreeAsync(grown, s));
   return BSMI_OK;
 }
 

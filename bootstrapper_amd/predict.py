@@ -26,8 +26,9 @@ def block_rois(net_config, voxel_size):
     inc = net_config["shape_increase"]
     in_shape = [a + b for a, b in zip(inc, net_config["input_shape"])]
     out_shape = [a + b for a, b in zip(inc, net_config["output_shape"])]
-    if len(in_shape) != 3:
-        raise NotImplementedError("only 3-D networks are supported by this engine")
+    if len(in_shape) == 2:  # predict.py:118-124: z axis of the 2-D ("3ch") setups: adj_slices sections in, one out
+        in_shape = [int(net_config["adj_slices"]), *in_shape]
+        out_shape = [1, *out_shape]
     in_size = [s * v for s, v in zip(in_shape, voxel_size)]
     out_size = [s * v for s, v in zip(out_shape, voxel_size)]
     if any((a - b) % 2 for a, b in zip(in_size, out_size)):
@@ -91,11 +92,26 @@ def prepare_outputs(cfg, in_ds):
     return out
 
 
+SECTIONS_PER_LAUNCH = 16  # 2-D setups: sections predicted by one pass of the (unit-depth) network
+
+
+def launch_shapes(cfg):
+    """(input, output) block shape of one engine launch.  3-D setups: the reference's block.  2-D setups: the
+    reference predicts one section per block from adj_slices neighbours (models/2d_mtlsd/predict.py:84-91); every
+    kernel of such a net has unit depth, so SECTIONS_PER_LAUNCH output sections go through the network as one
+    (adj_slices, D, H, W) stack with identical results."""
+    in_shape, out_shape = list(cfg["input_shape"]), list(cfg["output_shape"])
+    if len(cfg["net_config"]["downsample_factors"][0]) == 2:
+        out_shape[0] = SECTIONS_PER_LAUNCH
+        in_shape[0] = SECTIONS_PER_LAUNCH + int(cfg["net_config"]["adj_slices"]) - 1
+    return in_shape, out_shape
+
+
 def enumerate_blocks(cfg):
     """Write-ROI origins (voxels, relative to the output ROI) covering it with fit='overhang'."""
     _, shape = cfg["output_roi"]
     nvox = [s // v for s, v in zip(shape, cfg["voxel_size"])]
-    ob = cfg["output_shape"]
+    ob = launch_shapes(cfg)[1] if "net_config" in cfg else cfg["output_shape"]
     return [(z, y, x) for z in range(0, nvox[0], ob[0]) for y in range(0, nvox[1], ob[1]) for x in range(0, nvox[2], ob[2])]
 
 
@@ -114,9 +130,18 @@ def predict_blocks(cfg, rank=0, world=1, device=None, precision="bf16"):
     roi_vox = [s // v for s, v in zip(roi_shape, vs)]
     # dataset-relative voxel origin of the output ROI
     org = [(o - d) // v for o, d, v in zip(roi_off, in_ds.offset, vs)]
-    vol = torch.from_numpy(in_ds[:] if len(in_ds.shape) == 3 else in_ds[:][0]).to(dev)  # whole raw volume in HBM
-    ctx = [c // v for c, v in zip(cfg["context"], vs)]
-    in_shape, out_shape = cfg["input_shape"], cfg["output_shape"]
+    # every input channel as a (D, H, W) volume resident in HBM, in the order of net_config["inputs"]
+    # (second-stage setups read several prediction datasets: models/3d_affs_from_2d_mtlsd/predict.py:80-81,139-142)
+    vols = []
+    for path in cfg["input_datasets"]:
+        a = open_ds(path)[:]
+        vols += [torch.from_numpy(a).to(dev)] if a.ndim == 3 else [torch.from_numpy(c).to(dev) for c in a]
+    two_d = model.two_d
+    adj = int(cfg["net_config"].get("adj_slices", 1))
+    if (len(vols) if not two_d else adj * len(vols)) != model._cfg.in_channels:
+        raise ValueError(f"the input datasets hold {len(vols)} channels, the network takes {model._cfg.in_channels}")
+    in_shape, out_shape = launch_shapes(cfg)
+    ctx = [(a - b) // 2 for a, b in zip(in_shape, out_shape)]
     blocks = enumerate_blocks(cfg)
     mine = blocks[rank::world]
     failed = 0
@@ -124,8 +149,10 @@ def predict_blocks(cfg, rank=0, world=1, device=None, precision="bf16"):
         for attempt in range(MAX_RETRIES + 1):
             try:
                 # reflect padding mirrors about the DATASET faces (gp.Pad on the array source)
-                raw = extract_block_reflect(vol, [org[d] + blk[d] - ctx[d] for d in range(3)], in_shape)
-                u8 = model.predict_u8(raw)
+                chans = [extract_block_reflect(v, [org[d] + blk[d] - ctx[d] for d in range(3)], in_shape) for v in vols]
+                if two_d:  # section z of the stack sees sections z .. z + adj - 1 of the read block as its channels
+                    chans = [c[i:i + out_shape[0]] for c in chans for i in range(adj)]
+                u8 = model.predict_u8(chans[0] if len(chans) == 1 else torch.stack(chans))
                 hi = [min(out_shape[d], roi_vox[d] - blk[d]) for d in range(3)]
                 for ds, t in zip(outs, u8):
                     data = t[:, :hi[0], :hi[1], :hi[2]].cpu().numpy()

@@ -8,9 +8,10 @@ Reference being mirrored (paths relative to /root/reference/bootstrapper):
 What is NOT restated: the gunpowder augmentation chain of models/3d_affs/train.py:88-117 (SimpleAugment,
 DeformAugment, ShiftAugment, noise / intensity / gamma / impulse / smooth / defect augmentations) and the snapshot
 callback -- third-party pipeline code outside the hot path.  `SampleSource` does the deterministic part only: random
-location with the >= 5 % labelled-voxel rejection, Normalize + IntensityScaleShift(2, -1), AddAffinities on the
-configured neighbourhood, BalanceLabels.  The arithmetic of the step itself is libbsmi (csrc/train.hip).
+location with the >= 5 % labelled-voxel rejection, Normalize + IntensityScaleShift(2, -1), then GrowBoundary,
+AddAffinities on the configured neighbourhood and BalanceLabels in one device call (`affinity_targets`).  The arithmetic of the step itself is libbsmi (csrc/train.hip).
 """
+import ctypes as C
 import glob
 import json
 import os
@@ -24,6 +25,7 @@ try:
 except ImportError:  # python < 3.11
     import tomli as _toml
 
+from . import _lib
 from .zarr_io import open_ds
 
 
@@ -49,41 +51,36 @@ def setup_train(config_file):
     return config
 
 
-def affinities_from_labels(labels, neighborhood):
-    """gunpowder AddAffinities (seg_to_affgraph): aff[e][p] = labels[p] == labels[p + nhood[e]] and labels[p] > 0;
-    positions whose neighbour falls outside the block get affinity 0 and mask 0.  labels: int64 tensor (D, H, W)."""
-    D, H, W = labels.shape
-    affs = torch.zeros((len(neighborhood),) + tuple(labels.shape), dtype=torch.float32, device=labels.device)
-    mask = torch.zeros_like(affs)
-    for e, off in enumerate(neighborhood):
-        src, dst = [], []
-        for o, n in zip(off, (D, H, W)):
-            lo, hi = max(0, -o), min(n, n - o)
-            dst.append(slice(lo, hi))
-            src.append(slice(lo + o, hi + o))
-        a, b = labels[tuple(dst)], labels[tuple(src)]
-        affs[(e,) + tuple(dst)] = ((a == b) & (a > 0)).float()
-        mask[(e,) + tuple(dst)] = 1.0
-    return affs, mask
-
-
-def balance_labels(affs, mask, clip=(0.05, 0.95)):
-    """gunpowder BalanceLabels, two classes over the whole batch: w = mask / (2 * clipped class fraction)."""
-    total = mask.sum().clamp(min=1.0)
-    frac_pos = ((affs * mask).sum() / total).clamp(clip[0], clip[1])
-    w_pos, w_neg = 1.0 / (2.0 * frac_pos), 1.0 / (2.0 * (1.0 - frac_pos))
-    return mask * torch.where(affs > 0, w_pos, w_neg)
+def affinity_targets(labels, unlabelled, neighborhood, grow_steps=0, only_xy=True, clip=(0.05, 0.95)):
+    """models/3d_affs/train.py:127-139 on the device (bsmi_train_affinity_targets): GrowBoundary(labels,
+    mask=unlabelled, steps, only_xy) -> AddAffinities(neighborhood) -> BalanceLabels.
+    labels: int64 CUDA (D, H, W), overwritten with the grown-boundary labels; unlabelled: uint8 CUDA (D, H, W) or None.
+    Returns (gt_affs, affs_weights), float32 (n, D, H, W)."""
+    if labels.dtype != torch.int64 or not labels.is_cuda or not labels.is_contiguous():
+        raise ValueError("labels must be a contiguous int64 CUDA tensor")
+    if unlabelled is not None and (unlabelled.dtype != torch.uint8 or unlabelled.shape != labels.shape or not unlabelled.is_contiguous()):
+        raise ValueError("unlabelled must be a contiguous uint8 tensor of the labels' shape")
+    n = len(neighborhood)
+    nb = (C.c_int32 * (3 * n))(*[int(v) for off in neighborhood for v in off])
+    affs = torch.empty((n,) + tuple(labels.shape), dtype=torch.float32, device=labels.device)
+    weights = torch.empty_like(affs)
+    _lib.check(_lib.lib.bsmi_train_affinity_targets(
+        labels.device.index, C.c_void_p(labels.data_ptr()), C.c_void_p(unlabelled.data_ptr()) if unlabelled is not None else None,
+        _lib.i64x3(labels.shape), nb, n, int(grow_steps), 1 if only_xy else 0, float(clip[0]), float(clip[1]),
+        C.c_void_p(affs.data_ptr()), C.c_void_p(weights.data_ptr()), C.c_void_p(torch.cuda.current_stream(labels.device).cuda_stream)))
+    return affs, weights
 
 
 class SampleSource:
     """Infinite iterator of reference-style batches from (raw, labels[, mask]) Zarr volumes."""
 
-    def __init__(self, samples, input_shape, output_shape, neighborhood, device=0, seed=42, head="affs"):
+    def __init__(self, samples, input_shape, output_shape, neighborhood, device=0, seed=42, head="affs", grow_boundary=0):
         self.samples = [(open_ds(s["raw"]), open_ds(s["labels"]), open_ds(s["mask"]) if s.get("mask") else None) for s in samples]
         self.inp, self.out = tuple(input_shape), tuple(output_shape)
         self.nhood = [list(map(int, o)) for o in neighborhood]
         self.rng = np.random.default_rng(seed)
         self.dev = torch.device("cuda", device)
+        self.grow = int(grow_boundary)
         if head != "affs":
             raise NotImplementedError("only the affinity head has a ground-truth generator here (LSD targets need lsd.train [EXT])")
 
@@ -114,9 +111,8 @@ class SampleSource:
             raw[tuple(dst)] = raw_ds[tuple(src)]
             x = torch.from_numpy(raw).to(self.dev).float() * (1.0 / 255.0) * 2.0 - 1.0
             lab = torch.from_numpy(labels).to(self.dev)
-            affs, amask = affinities_from_labels(lab, self.nhood)
-            amask = amask * torch.from_numpy(unl.astype(np.float32)).to(self.dev)[None]
-            return {"raw": x, "gt_affs": affs, "affs_weights": balance_labels(affs, amask)}
+            affs, weights = affinity_targets(lab, torch.from_numpy(unl.astype(np.uint8)).to(self.dev), self.nhood, self.grow, only_xy=True)
+            return {"raw": x, "gt_affs": affs, "affs_weights": weights}
         raise RuntimeError("no training location with at least 5 % labelled voxels found")
 
 
@@ -186,7 +182,8 @@ def run_training(config_file, device=0, batches=None, log=print):
             raise NotImplementedError("the built-in sample source feeds the 3d_affs model only")
         log("note: the reference's gunpowder augmentations are not part of this engine; samples are random crops")
         batches = SampleSource(config["samples"], net_config["input_shape"], net_config["output_shape"],
-                               out3d["neighborhood"][: int(out3d["dims"])], device=device)
+                               out3d["neighborhood"][: int(out3d["dims"])], device=device,
+                               grow_boundary=int(out3d.get("grow_boundary", 0)))
     n = fit(trainer, batches, max_iterations, int(config.get("save_checkpoints_every", 0)), setup_dir, log=log, start_iteration=done)
     trainer.close()
     return n

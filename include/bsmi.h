@@ -125,6 +125,24 @@ int bsmi_unet_train_adam_step(bsmi_unet *h, float lr, float beta1, float beta2, 
 int bsmi_unet_train_read_param(bsmi_unet *h, const char *key, int what, float *host_out);
 int bsmi_unet_train_end(bsmi_unet *h);
 
+/* Affinity training targets of one sample, on the device (reference models/3d_affs/train.py:127-139:
+ * gp.GrowBoundary(labels, mask=unlabelled, steps, only_xy) -> gp.AddAffinities(neighborhood) ->
+ * gp.BalanceLabels; the erosion as in gp/custom_grow_boundary.py:71-110 with a fixed step count).
+ *   labels_dev      int64 [D][H][W], 0 = background; overwritten with the grown-boundary labels
+ *   unlabelled_dev  uint8 [D][H][W] or NULL: 1 where the ground truth is known (CreateMask), 0 = unknown
+ *   neighborhood    n offsets (z, y, x), host pointer (net_config "neighborhood")
+ *   grow_steps      voxels of boundary to grow (net_config "grow_boundary"); a voxel keeps its label when every
+ *                   voxel within that L1 distance (in its section if only_xy) has the same label, is unknown, or
+ *                   lies outside the block (binary_erosion(iterations=steps, border_value=1))
+ *   affs_dev        float [n][D][H][W]: 1 where p and p + offset carry the same non-zero label
+ *   weights_dev     float [n][D][H][W]: affinity mask (both voxels inside the block, p known) scaled by
+ *                   1 / (2 f) for positives and 1 / (2 (1 - f)) for negatives, f = masked positive fraction
+ *                   clipped to [clip_min, clip_max] (BalanceLabels, slab = whole sample)                       */
+int bsmi_train_affinity_targets(int device, int64_t *labels_dev, const uint8_t *unlabelled_dev,
+                                const int64_t shape[3], const int32_t *neighborhood, int n, int grow_steps,
+                                int only_xy, float clip_min, float clip_max, float *affs_dev,
+                                float *weights_dev, void *stream);
+
 /* Number of CUs the stream bsmi_unet_forward is called on may use (a multiple of 8; -1 restores the
  * default = all CUs of the device, 0 disables the persistent launches).  The big-tile conv layers run
  * as that many persistent workgroups (conv_igemm.hip); set it when the stream carries a CU mask. */

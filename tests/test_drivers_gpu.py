@@ -297,3 +297,71 @@ def test_refine_filters(tmp_path):
     want[want == c] = b
     assert out == store + "/seg_remapped" and np.array_equal(open_ds(out)[:], want)
     assert R.size_filter(store + "/seg", min_size=10, dry_run=True) is None
+
+
+def test_bootstrap_chain_2d_mtlsd_then_second_stage(tmp_path, golden_dir):
+    """The chain of the CREMI example (2d_mtlsd -> 3d_affs_from_2d_mtlsd) through `run_prediction`: a 2-D setup
+    predicted as stacks of sections, then a second-stage setup reading both prediction datasets; each compared
+    with the oracle applied block by block to the same data."""
+    from bootstrapper_amd.predict import run_prediction
+    from bootstrapper_amd.zarr_io import open_ds, prepare_ds
+    from oracle import unet_ref as R
+    from test_oracle_unet import family_case
+    nc1, sd1, _, _, _ = family_case(golden_dir, "2d_mtlsd_f4i2")
+    nc2, sd2, _, _, _ = family_case(golden_dir, "from_2d_mtlsd_f3i2")
+    # block shapes for this small volume: 2-D net 108 -> 16 (+8), second stage (22,100,100) -> (2,8,8) (+2,+8,+8)
+    nc1.update(input_shape=[108, 108], output_shape=[16, 16], shape_increase=[8, 8])
+    nc2.update(input_shape=[22, 100, 100], output_shape=[2, 8, 8], shape_increase=[2, 8, 8])
+    store = str(tmp_path / "vol.zarr")
+    rng = np.random.default_rng(5)
+    raw = rng.integers(0, 256, size=(19, 40, 45), dtype=np.uint8)
+    ds = prepare_ds(store + "/raw", raw.shape, offset=(0, 0, 0), voxel_size=(40, 4, 4), chunk_shape=(8, 32, 32),
+                    dtype=np.uint8, axis_names=["z", "y", "x"], units=["nm"] * 3)
+    ds[:] = raw
+    toml = []
+    for i, (name, nc, sd) in enumerate((("2d_mtlsd", nc1, sd1), ("3d_affs_from_2d_mtlsd", nc2, sd2))):
+        setup = tmp_path / name
+        setup.mkdir()
+        (setup / "net_config.json").write_text(json.dumps(nc))
+        torch.save({"model_state_dict": {k: torch.from_numpy(v) for k, v in sd.items()}}, str(setup / "model_checkpoint_5.ckpt"))
+        ins = ([f"{store}/raw"] if i == 0 else [f"{store}/predictions/5/2d_lsds", f"{store}/predictions/5/2d_affs"])
+        toml.append(f'["0{i + 1}-{name}"]\nsetup_dir = "{setup}"\ninput_datasets = {json.dumps(ins)}\n'
+                    f'checkpoint = "{setup}/model_checkpoint_5"\noutput_datasets_prefix = "{store}/predictions"\n'
+                    f'chain_str = "{"" if i == 0 else "2d_mtlsd"}"\nnum_workers = 1\nnum_gpus = 1\n')
+    cfg = tmp_path / "pred.toml"
+    cfg.write_text("\n".join(toml))
+    run_prediction(str(cfg), "01", precision="f32")
+    lsds, affs = open_ds(store + "/predictions/5/2d_lsds"), open_ds(store + "/predictions/5/2d_affs")
+    assert lsds.shape == (6, 19, 40, 45) and lsds.chunks == (6, 1, 24, 24) and affs.dtype == np.uint8
+    got = [lsds[:], affs[:]]
+    # oracle, section by section like the reference worker: 3 adjacent sections (reflect padded) -> 1 section
+    full = np.pad(raw, [(1, 1), (46, 46 + 24), (46, 46 + 24)], mode="reflect")
+    ref = [np.zeros_like(g) for g in got]
+    for z in range(19):
+        for y in range(0, 40, 24):
+            for x in range(0, 45, 24):
+                blk = full[z:z + 3, y:y + 116, x:x + 116]
+                outs = R.family_forward(nc1, sd1, torch.from_numpy(R.normalize_raw(blk)[None, :, None]))
+                hy, hx = min(24, 40 - y), min(24, 45 - x)
+                for r, o in zip(ref, outs):
+                    r[:, z, y:y + hy, x:x + hx] = R.to_u8(o.numpy())[:, 0, :hy, :hx]
+    for g, r in zip(got, ref):
+        diff = np.abs(g.astype(np.int32) - r.astype(np.int32))
+        assert diff.max() <= 1 and (diff == 0).mean() > 0.99
+
+    run_prediction(str(cfg), "02", precision="f32")
+    out = open_ds(store + "/predictions/5--from--2d_mtlsd/3d_affs")
+    assert out.shape == (9, 19, 40, 45) and out.chunks == (9, 4, 16, 16)
+    got2 = out[:]
+    both = np.concatenate(got, axis=0)                                   # (12, D, H, W) u8, lsds then affs
+    full = np.pad(both, [(0, 0), (10, 10 + 4), (46, 46 + 16), (46, 46 + 16)], mode="reflect")
+    ref2 = np.zeros_like(got2)
+    for z in range(0, 19, 4):
+        for y in range(0, 40, 16):
+            for x in range(0, 45, 16):
+                blk = full[:, z:z + 24, y:y + 108, x:x + 108]
+                o = R.to_u8(R.family_forward(nc2, sd2, torch.from_numpy(R.normalize_unit(blk)[None]))[0].numpy())
+                hz, hy, hx = min(4, 19 - z), min(16, 40 - y), min(16, 45 - x)
+                ref2[:, z:z + hz, y:y + hy, x:x + hx] = o[:, :hz, :hy, :hx]
+    diff = np.abs(got2.astype(np.int32) - ref2.astype(np.int32))
+    assert diff.max() <= 1 and (diff == 0).mean() > 0.99

@@ -62,20 +62,26 @@ def test_train_host_helpers(tmp_path):
     with pytest.raises(ValueError, match="Raw dataset path .* does not exist"):
         T.setup_train(str(cfg))
 
+    from oracle import train_ref as TR
     rng = np.random.default_rng(0)
     labels = rng.integers(0, 4, size=(5, 9, 8))
     nhood = [[-1, 0, 0], [0, -1, 0], [0, 0, -1], [-2, 0, 0], [0, -3, 0]]
-    affs, mask = T.affinities_from_labels(torch.from_numpy(labels), nhood)
+    affs, mask = TR.affinities_from_labels(labels, nhood)
     for e, (dz, dy, dx) in enumerate(nhood):
         for z, y, x in [(0, 0, 0), (2, 4, 3), (4, 8, 7), (1, 2, 0), (3, 0, 5)]:
             zz, yy, xx = z + dz, y + dy, x + dx
             inside = 0 <= zz < 5 and 0 <= yy < 9 and 0 <= xx < 8
             want = float(inside and labels[z, y, x] == labels[zz, yy, xx] and labels[z, y, x] > 0)
             assert float(affs[e, z, y, x]) == want and float(mask[e, z, y, x]) == float(inside)
-    w = T.balance_labels(affs, mask)
+    w = TR.balance_labels(affs, mask)
     frac = float((affs * mask).sum() / mask.sum())
     frac = min(max(frac, 0.05), 0.95)
-    assert np.isclose(float(w[affs > 0].max()), 1 / (2 * frac)) and float(w[mask == 0].abs().max()) == 0.0
+    assert np.isclose(float(w[affs > 0].max()), 1 / (2 * frac)) and float(np.abs(w[mask == 0]).max()) == 0.0
+    # grow boundary: two touching labels lose one voxel each along their border, not along unknown (0) regions
+    lab = np.zeros((1, 6, 8), np.int64)
+    lab[0, 1:5, 1:4], lab[0, 1:5, 4:7] = 5, 9
+    g = TR.grow_boundary(lab, (lab > 0).astype(np.uint8), 1, only_xy=True)
+    assert (g[0, 1:5, 3:5] == 0).all() and (g[0, 1:5, 1:3] == 5).all() and (g[0, 1:5, 5:7] == 9).all()
 
     from tests.test_lib_cpu import AFFS_NET_CONFIG
     sd = T.default_init(AFFS_NET_CONFIG)

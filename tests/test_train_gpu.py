@@ -148,3 +148,67 @@ def test_full_net_training_step_vs_cpu_oracle():
         assert err < 2e-3, (k, err)
     print("full net: loss", loss, "largest relative gradient error", worst)
     tr.close()
+
+
+@pytest.mark.parametrize("tag", ["2d_mtlsd_f4i2", "from_2d_mtlsd_f3i2", "3d_lsd_f4i2"])
+def test_training_step_model_family_vs_oracle(golden_dir, tag):
+    """The training step on the other setups of the family (Conv2d state dicts, num_fmaps_out, (1,3,3) kernels,
+    12 input channels): loss and every gradient against the CPU oracle's autograd over the forward that
+    tests/test_oracle_unet.py pins to the reference models."""
+    from bootstrapper_amd.unet import Model
+    from bootstrapper_amd.training import Trainer
+    from oracle import train_ref as T
+    from oracle import unet_ref as R
+    from test_oracle_unet import family_case
+    nc, sd, _, x, refs = family_case(golden_dir, tag)
+    m = Model(nc, precision="f32").load_state_dict(sd)
+    tr = Trainer(m, x.shape[2:], lr=1e-3)
+    rng = np.random.default_rng(2)
+    shapes = [r.shape if r.ndim == 4 else (r.shape[0], 1) + r.shape[1:] for r in refs]
+    targets = [rng.random(s, dtype=np.float32) for s in shapes]
+    weights = [(rng.random(s, dtype=np.float32) * (rng.random(s) > 0.3)).astype(np.float32) for s in shapes]
+    loss = tr.forward_backward(torch.from_numpy(x[0]).cuda(), [torch.from_numpy(t).cuda() for t in targets],
+                               [torch.from_numpy(w).cuda() for w in weights])
+    heads = [R.FAMILY_HEADS[k] for k in nc["outputs"]]
+    lsd = {k: v.numpy() for k, v in R.lift_sd(sd).items()}
+    ref_loss, ref_grads, _ = T.loss_and_grads(R.lift_cfg(nc), lsd, x[0], [t[None] for t in targets], [w[None] for w in weights], heads)
+    assert abs(loss - ref_loss) < 1e-5 * max(1.0, abs(ref_loss))
+    worst = 0.0
+    for k, g in ref_grads.items():
+        got = tr.read(k, "grad")
+        err = np.abs(got - g.ravel()).max() / max(1e-6, np.abs(g).max())
+        worst = max(worst, err)
+        assert err < 1e-3, (k, err)
+    print(f"{tag}: loss {loss:.6f}, largest relative gradient error {worst:.2e}")
+    tr.optimizer_step()
+    assert tr.param_shapes()[next(iter(sd))] == tuple(sd[next(iter(sd))].shape)     # Conv2d shapes survive for checkpoints
+    tr.close()
+
+
+@pytest.mark.parametrize("steps,only_xy,with_mask", [(1, True, False), (2, True, True), (1, False, True), (0, True, False), (3, False, False)])
+def test_affinity_targets_vs_oracle(steps, only_xy, with_mask):
+    """GrowBoundary -> AddAffinities -> BalanceLabels in one device call, against the numpy / scipy restatement
+    (binary_erosion per label, as the reference's gp/custom_grow_boundary.py does)."""
+    from bootstrapper_amd.train import affinity_targets
+    from oracle import train_ref as TR
+    rng = np.random.default_rng(steps * 7 + only_xy + 2 * with_mask)
+    # blocky labels with background gaps: Voronoi cells of random seeds, some cells set to 0
+    D, H, W = 6, 40, 37
+    seeds = rng.integers(0, [D, H, W], size=(25, 3))
+    zz, yy, xx = np.meshgrid(np.arange(D), np.arange(H), np.arange(W), indexing="ij")
+    dist = ((zz[..., None] - seeds[:, 0]) * 4) ** 2 + (yy[..., None] - seeds[:, 1]) ** 2 + (xx[..., None] - seeds[:, 2]) ** 2
+    labels = (dist.argmin(-1) + 1).astype(np.int64) * 1000003
+    labels[np.isin(labels // 1000003, [3, 7, 11])] = 0
+    unl = (labels > 0).astype(np.uint8)
+    if with_mask:
+        unl[:, 5:12, 20:30] = 0          # an unknown region that still carries labels
+        unl[2:4, 25:, :6] = 0
+    nhood = [[-1, 0, 0], [0, -1, 0], [0, 0, -1], [-2, 0, 0], [0, -9, 0], [0, 0, -9]]
+    grown, affs, weights = TR.affinity_targets(labels, unl, nhood, steps, only_xy)
+    lab_t = torch.from_numpy(labels.copy()).cuda()
+    a, w = affinity_targets(lab_t, torch.from_numpy(unl).cuda(), nhood, steps, only_xy)
+    got_grown = lab_t.cpu().numpy()
+    assert np.array_equal(got_grown, grown)
+    assert np.array_equal(a.cpu().numpy(), affs)
+    assert np.allclose(w.cpu().numpy(), weights, rtol=1e-6, atol=0)
+    assert (grown != labels).any() == (steps > 0)
