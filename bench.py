@@ -298,7 +298,7 @@ def main():
                      "unit": "TFLOP/s", "frac": achieved / (BF16_DENSE_PEAK_TFLOPS if args.precision == "bf16" else 157.3),
                      "traffic": traffic, "traffic_unit": "bytes per launch (memory side of L2, Infinity-Cache hits included)",
                      "traffic_source": traffic_src,
-                     "kernel": "bsmi::conv_igemm_kernel / conv_igemm_sk_kernel (all implicit-GEMM launches of the U-Net)",
+                     "kernel": "bsmi::conv_igemm_kernel / conv_igemm_sk_kernel / first_pass_kernel (all convolution launches of the U-Net)",
                      "launches": int(conv_launches), "avg_launch_ms": conv_ms / max(conv_launches, 1),
                      "algorithmic_tflop_per_block": flops_block / 1e12,
                      "other_unet_ms_per_block": sum(totals[k][0] for k in ("input", "pool", "upsample", "head")) / max(args.steps, 1)},

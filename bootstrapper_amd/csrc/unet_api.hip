@@ -572,13 +572,26 @@ static int harvest(bsmi_unet* h, Plan* plan) {
     float t = 0.f;
     BSMI_HIP(hipEventElapsedTime(&t, plan->events[2 * i], plan->events[2 * i + 1]));
     plan->last_ms[i] = t;
-    const int ty = (int)plan->steps[i].type;
+    // with the fused first pass, steps 0 and 1 launch nothing: their work is done (and timed) in step 2
+    const int ty = (plan->fused_first && i < 2) ? (int)PlanStep::CONV : (int)plan->steps[i].type;
     h->prof_ms[ty] += t;
     h->prof_flops[ty] += plan->steps[i].flops;
-    h->prof_launches[ty] += 1;
+    h->prof_launches[ty] += (plan->fused_first && i < 2) ? 0 : 1;
   }
   plan->pending = false;
   return BSMI_OK;
+}
+
+// The first ConvPass can run as one launch (first_pass.hip): one raw channel, two 3x3x3 convs, at most 16 feature maps.
+static bool first_pass_eligible(const bsmi_unet* h) {
+  if (h->cfg.in_channels != 1 || h->l_conv.empty()) return false;
+  const PassSite& p = h->l_conv[0];
+  if (p.nconv != 2 || p.cout > 16) return false;
+  for (int c = 0; c < 2; ++c)
+    for (int d = 0; d < 3; ++d)
+      if (p.k[c][d] != 3) return false;
+  const char* e = getenv("BSMI_FUSED_FIRST");
+  return !(e && e[0] == '0');
 }
 
 int get_plan(bsmi_unet* h, int precision, const int64_t in_shape[3], Plan** out) {
@@ -592,6 +605,10 @@ int get_plan(bsmi_unet* h, int precision, const int64_t in_shape[3], Plan** out)
       free_plan(plan.get());
       return rc;
     }
+    const std::vector<PlanStep>& ps = plan->steps;
+    plan->fused_first = precision == BSMI_PREC_BF16 && first_pass_eligible(h) && h->first_pass.ready && ps.size() > 3 &&
+                        ps[0].type == PlanStep::INPUT && ps[1].type == PlanStep::CONV && ps[2].type == PlanStep::CONV &&
+                        ps[1].site == &h->l_conv[0] && ps[2].site == &h->l_conv[0] && ps[2].out.Cpad == 16;
     it = h->plans.emplace(key, std::move(plan)).first;
   }
   *out = it->second.get();
@@ -730,6 +747,7 @@ int bsmi_unet_destroy(bsmi_unet* h) {
   for (auto& p : h->l_conv) free_site(p);
   for (auto& p : h->r_conv) free_site(p);
   free_train_state(h);
+  free_first_pass(h->first_pass);
   if (h->sk_ws) (void)hipFree(h->sk_ws);
   for (auto& hd : h->heads) {
     if (hd.hw) (void)hipFree(hd.hw);
@@ -801,6 +819,14 @@ int bsmi_unet_finalize(bsmi_unet* h, int precision) {
     if (!hd.hb) BSMI_HIP(hipMalloc((void**)&hd.hb, hb.size() * sizeof(float)));
     BSMI_HIP(hipMemcpy(hd.hw, hw.data(), hw.size() * sizeof(float), hipMemcpyHostToDevice));
     BSMI_HIP(hipMemcpy(hd.hb, hb.data(), hb.size() * sizeof(float), hipMemcpyHostToDevice));
+  }
+  if (precision == BSMI_PREC_BF16 && first_pass_eligible(h)) {
+    const std::string pre = h->l_conv[0].prefix;
+    int rc = pack_first_pass(h->first_pass, h->l_conv[0].cout, h->weights[pre + ".conv_pass.0.weight"].data.data(),
+                             h->weights[pre + ".conv_pass.0.bias"].data.data(), h->weights[pre + ".conv_pass.2.weight"].data.data(),
+                             h->weights[pre + ".conv_pass.2.bias"].data.data(), h->weights[pre + ".residual.0.weight"].data.data(),
+                             h->weights[pre + ".residual.0.bias"].data.data());
+    if (rc) return rc;
   }
   // plans hold pointers to packed weights: drop those of this precision
   h->last_plan = nullptr;
@@ -880,6 +906,21 @@ int bsmi_unet_forward(bsmi_unet* h, int precision, const void* raw_dev, int raw_
   size_t step_idx = 0;
   for (const PlanStep& st : plan.steps) {
     if (h->profiling) BSMI_HIP(hipEventRecord(plan.events[2 * step_idx], s));
+    if (plan.fused_first && step_idx < 3) {
+      // l_conv.0 as one launch in place of its second conv; the input-preparation and first-conv steps fall away
+      if (step_idx == 2) {
+        FirstPassArgs fa;
+        fa.raw = raw_dev; fa.raw_dtype = raw_dtype;
+        fa.D = plan.steps[0].out.D; fa.H = plan.steps[0].out.H; fa.W = plan.steps[0].out.W;
+        fa.out = (uint16_t*)st.out.ptr;
+        fa.w1a = h->first_pass.w1a; fa.w2a = h->first_pass.w2a; fa.vec = h->first_pass.vec;
+        rc = launch_first_pass(fa, h->sk_grid > 0 ? h->sk_grid : 256, s);
+        if (rc) return rc;
+      }
+      if (h->profiling) BSMI_HIP(hipEventRecord(plan.events[2 * step_idx + 1], s));
+      ++step_idx;
+      continue;
+    }
     switch (st.type) {
       case PlanStep::INPUT:
         rc = launch_input_prep(precision, raw_dev, raw_dtype, st.out.ptr, st.out.C, st.out.Cpad,

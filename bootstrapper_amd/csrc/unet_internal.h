@@ -8,6 +8,7 @@
 
 #include "conv_igemm.h"
 #include "conv_rh.h"
+#include "first_pass.h"
 
 namespace bsmi {
 
@@ -97,6 +98,7 @@ struct Plan {
   size_t bytes = 0;
   std::vector<hipEvent_t> events;  // 2 per step, created on demand (profiling)
   bool profiled = false;           // last forward recorded events
+  bool fused_first = false;        // steps 0..2 (INPUT, CONV, CONV of l_conv.0) run as one first_pass launch
 };
 
 struct TrainState;
@@ -129,6 +131,7 @@ struct bsmi_unet {
   int sk_grid = 0;         // 0: not set up yet, -1: disabled
   int sk_request = -1;     // bsmi_unet_set_persistent_grid: -1 = CU count of the device, 0 = off
   bsmi::TrainState* train = nullptr;  // train.hip
+  bsmi::FirstPassWeights first_pass;  // first_pass.hip: weights of the fused first ConvPass (bf16 mode)
 };
 
 namespace bsmi {

@@ -54,35 +54,42 @@ struct Vec<uint16_t> {
 // `unit`: gp.Normalize only (x = u8 * (1/255)), the inputs of the second-stage nets.
 template <typename T, typename RAW>
 __global__ void input_prep_kernel(const RAW* raw, T* out, int cin, int cpad, size_t nvox, int unit) {
+  // one 16-byte channel vector per thread
+  constexpr int N = Vec<T>::N;
+  const int cv = cpad / N;
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  const size_t total = nvox * cpad;
-  if (i >= total) return;
-  const int c = (int)(i % cpad);
-  const size_t v = i / cpad;
-  float x = 0.f;
-  if (c < cin) {
-    if constexpr (sizeof(RAW) == 1) {
-      x = (float)raw[(size_t)c * nvox + v] * (1.0f / 255.0f);
-      if (!unit) x = x * 2.0f + -1.0f;
-    } else {
-      x = (float)raw[(size_t)c * nvox + v];
+  if (i >= nvox * cv) return;
+  const int c0 = (int)(i % cv) * N;
+  const size_t v = i / cv;
+  float f[N];
+#pragma unroll
+  for (int k = 0; k < N; ++k) {
+    float x = 0.f;
+    if (c0 + k < cin) {
+      if constexpr (sizeof(RAW) == 1) {
+        x = (float)raw[(size_t)(c0 + k) * nvox + v] * (1.0f / 255.0f);
+        if (!unit) x = x * 2.0f + -1.0f;
+      } else {
+        x = (float)raw[(size_t)(c0 + k) * nvox + v];
+      }
     }
+    f[k] = x;
   }
-  if constexpr (sizeof(T) == 4) out[i] = x; else out[i] = f32_to_bf16(x);
+  *(u32x4_t*)(out + i * N) = Vec<T>::pack(f);
 }
 
 int launch_input_prep(int precision, const void* raw, int raw_dtype, void* out, int cin, int cpad,
                       size_t nvox, hipStream_t s) {
-  const size_t total = nvox * cpad;
   const int bs = 256;
-  const unsigned grid = (unsigned)ceil_div64((int64_t)total, bs);
   const int unit = raw_dtype == BSMI_RAW_U8_UNIT;
   if (precision == BSMI_PREC_F32) {
+    const unsigned grid = (unsigned)ceil_div64((int64_t)(nvox * (cpad / 4)), bs);
     if (raw_dtype != BSMI_RAW_F32)
       hipLaunchKernelGGL((input_prep_kernel<float, uint8_t>), dim3(grid), dim3(bs), 0, s, (const uint8_t*)raw, (float*)out, cin, cpad, nvox, unit);
     else
       hipLaunchKernelGGL((input_prep_kernel<float, float>), dim3(grid), dim3(bs), 0, s, (const float*)raw, (float*)out, cin, cpad, nvox, 0);
   } else {
+    const unsigned grid = (unsigned)ceil_div64((int64_t)(nvox * (cpad / 8)), bs);
     if (raw_dtype != BSMI_RAW_F32)
       hipLaunchKernelGGL((input_prep_kernel<uint16_t, uint8_t>), dim3(grid), dim3(bs), 0, s, (const uint8_t*)raw, (uint16_t*)out, cin, cpad, nvox, unit);
     else
@@ -155,64 +162,65 @@ __device__ __forceinline__ void lin_src(int dst, int f, int n, int& i0, int& i1,
   w0 = 1.f - w1;
 }
 
+// One workgroup per output row (z, y): the row's y / z source lines and weights are uniform, a thread walks the
+// row's (x, channel vector) pairs; streaming stores (the consumer conv reads the tensor once, much later).
 template <typename T>
 __global__ void upsample_crop_kernel(const T* in, T* out, int D, int H, int W, int C, int Do, int Ho,
                                      int Wo, int fz, int fy, int fx, int oz, int oy, int ox) {
   constexpr int N = Vec<T>::N;
   const int cv = C / N;
-  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  const size_t total = (size_t)Do * Ho * Wo * cv;
-  if (i >= total) return;
-  const int c = (int)(i % cv);
-  size_t v = i / cv;
-  const int x = (int)(v % Wo); v /= Wo;
-  const int y = (int)(v % Ho);
-  const int z = (int)(v / Ho);
-  int z0, z1, y0, y1, x0, x1;
-  float wz0, wz1, wy0, wy1, wx0, wx1;
+  const int y = blockIdx.x % Ho, z = blockIdx.x / Ho;
+  int z0, z1, y0, y1;
+  float wz0, wz1, wy0, wy1;
   lin_src(z + oz, fz, D, z0, z1, wz0, wz1);
   lin_src(y + oy, fy, H, y0, y1, wy0, wy1);
-  lin_src(x + ox, fx, W, x0, x1, wx0, wx1);
-  auto ld = [&](int zz, int yy, int xx, float* f) {
-    Vec<T>::unpack(*(const u32x4_t*)(in + ((size_t)(zz * H + yy) * W + xx) * C + c * N), f);
-  };
-  float a[N], b[N], r[N], acc[N];
-  auto plane = [&](int zz, float* o) {
-    float p[N], q[N];
-    ld(zz, y0, x0, a); ld(zz, y0, x1, b);
+  const T* r00 = in + ((size_t)z0 * H + y0) * W * C;
+  const T* r01 = in + ((size_t)z0 * H + y1) * W * C;
+  const T* r10 = in + ((size_t)z1 * H + y0) * W * C;
+  const T* r11 = in + ((size_t)z1 * H + y1) * W * C;
+  T* orow = out + ((size_t)z * Ho + y) * Wo * C;
+  const int n = Wo * cv;
+  for (int i = threadIdx.x; i < n; i += blockDim.x) {
+    const int x = i / cv, c = (i - x * cv) * N;
+    int x0, x1;
+    float wx0, wx1;
+    lin_src(x + ox, fx, W, x0, x1, wx0, wx1);
+    auto line = [&](const T* row, float* o) {
+      float a[N], b[N];
+      Vec<T>::unpack(*(const u32x4_t*)(row + (size_t)x0 * C + c), a);
+      Vec<T>::unpack(*(const u32x4_t*)(row + (size_t)x1 * C + c), b);
 #pragma unroll
-    for (int k = 0; k < N; ++k) p[k] = wx0 * a[k] + wx1 * b[k];
-    ld(zz, y1, x0, a); ld(zz, y1, x1, b);
+      for (int k = 0; k < N; ++k) o[k] = wx0 * a[k] + wx1 * b[k];
+    };
+    float p[N], q[N], r[N], acc[N];
+    line(r00, p); line(r01, q);
 #pragma unroll
-    for (int k = 0; k < N; ++k) q[k] = wx0 * a[k] + wx1 * b[k];
+    for (int k = 0; k < N; ++k) r[k] = wy0 * p[k] + wy1 * q[k];
+    if (z1 != z0) {
+      float r1[N];
+      line(r10, p); line(r11, q);
 #pragma unroll
-    for (int k = 0; k < N; ++k) o[k] = wy0 * p[k] + wy1 * q[k];
-  };
-  plane(z0, r);
-  if (z1 != z0) {
-    float r1[N];
-    plane(z1, r1);
+      for (int k = 0; k < N; ++k) r1[k] = wy0 * p[k] + wy1 * q[k];
 #pragma unroll
-    for (int k = 0; k < N; ++k) acc[k] = wz0 * r[k] + wz1 * r1[k];
-  } else {
+      for (int k = 0; k < N; ++k) acc[k] = wz0 * r[k] + wz1 * r1[k];
+    } else {
 #pragma unroll
-    for (int k = 0; k < N; ++k) acc[k] = wz0 * r[k] + wz1 * r[k];
+      for (int k = 0; k < N; ++k) acc[k] = wz0 * r[k] + wz1 * r[k];
+    }
+    __builtin_nontemporal_store(Vec<T>::pack(acc), (u32x4_t*)(orow + (size_t)i * N));
   }
-  *(u32x4_t*)(out + i * N) = Vec<T>::pack(acc);
 }
 
 int launch_upsample_crop(int precision, const void* in, void* out, int D, int H, int W, int C, int Do,
                          int Ho, int Wo, int fz, int fy, int fx, int oz, int oy, int ox, hipStream_t s) {
   const int bs = 256;
-  if (precision == BSMI_PREC_F32) {
-    const size_t total = (size_t)Do * Ho * Wo * (C / 4);
-    hipLaunchKernelGGL(upsample_crop_kernel<float>, dim3((unsigned)ceil_div64(total, bs)), dim3(bs), 0, s,
+  const unsigned grid = (unsigned)(Do * Ho);
+  if (precision == BSMI_PREC_F32)
+    hipLaunchKernelGGL(upsample_crop_kernel<float>, dim3(grid), dim3(bs), 0, s,
                        (const float*)in, (float*)out, D, H, W, C, Do, Ho, Wo, fz, fy, fx, oz, oy, ox);
-  } else {
-    const size_t total = (size_t)Do * Ho * Wo * (C / 8);
-    hipLaunchKernelGGL(upsample_crop_kernel<uint16_t>, dim3((unsigned)ceil_div64(total, bs)), dim3(bs), 0, s,
+  else
+    hipLaunchKernelGGL(upsample_crop_kernel<uint16_t>, dim3(grid), dim3(bs), 0, s,
                        (const uint16_t*)in, (uint16_t*)out, D, H, W, C, Do, Ho, Wo, fz, fy, fx, oz, oy, ox);
-  }
   BSMI_HIP(hipGetLastError());
   return BSMI_OK;
 }
