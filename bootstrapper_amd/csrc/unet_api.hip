@@ -334,6 +334,114 @@ struct Planner {
     return BSMI_OK;
   }
 
+  // Box-halo launch of one ConvPass stage (conv_box.hip): bf16, 3x3x3, at most 16 output channels.
+  // BSMI_USE_BOX: 0 = never, unset / 1 = wherever it applies.
+  int plan_box(const PassSite& p, int ci, const TDesc* slots, const int (*so)[3], int nsl, const TDesc& o, PlanStep& st) {
+    st.use_box = false;
+    static const bool enabled = [] { const char* e = getenv("BSMI_USE_BOX"); return !(e && e[0] == '0'); }();
+    const int* k = p.k[ci];
+    if (!enabled || prec != BSMI_PREC_BF16 || k[0] != 3 || k[1] != 3 || k[2] != 3 || !box_supported(p.cout)) return BSMI_OK;
+    const bool last = ci == p.nconv - 1;
+    const int NB = 1;  // one block of 16 output channels
+    const HostWeight& wm = h->weights[p.prefix + ".conv_pass." + std::to_string(2 * ci) + ".weight"];
+    const HostWeight& bm = h->weights[p.prefix + ".conv_pass." + std::to_string(2 * ci) + ".bias"];
+    const HostWeight& wr = h->weights[p.prefix + ".residual.0.weight"];
+    const HostWeight& br = h->weights[p.prefix + ".residual.0.bias"];
+    const int64_t cin_m = wm.shape[1], cin_r = wr.shape[1];
+    int crop[3] = {0, 0, 0};
+    for (int i = 0; i < p.nconv; ++i)
+      for (int d = 0; d < 3; ++d) crop[d] += p.k[i][d] - 1;
+
+    struct Src { int slot, cin_base, creal; };
+    std::vector<Src> full, center;
+    if (ci == 0) {
+      int base = 0;
+      for (int s = 0; s < p.nslots; ++s) { full.push_back({s, base, p.cin[s]}); base += p.cin[s]; }
+    } else {
+      full.push_back({0, 0, p.cout});
+    }
+    if (last) {
+      const int first_slot = ci == 0 ? 0 : 1;
+      int base = 0;
+      for (int s = 0; s < p.nslots; ++s) { center.push_back({first_slot + s, base, p.cin[s]}); base += p.cin[s]; }
+    }
+    std::vector<BoxChunk> chunks;
+    std::vector<uint32_t> wimg;
+    auto chunk_of = [&](const TDesc& t, const int* org, int c0) {
+      BoxChunk ck;
+      ck.sx = t.Cpad * 2; ck.sy = t.W * ck.sx; ck.sz = t.H * ck.sy;
+      ck.base = (uint64_t)(uintptr_t)t.ptr + (uint64_t)org[0] * ck.sz + (uint64_t)org[1] * ck.sy + (uint64_t)org[2] * ck.sx + (uint64_t)c0 * 2;
+      ck.D = t.D - org[0]; ck.H = t.H - org[1]; ck.W = t.W - org[2];
+      return ck;
+    };
+    auto put = [&](size_t lane_base, int j, float v) { wimg[lane_base + j / 2] |= (uint32_t)host_f32_to_bf16(v) << (16 * (j & 1)); };
+    // FULL chunks: 16 channels x 27 taps, 14 K-steps of (2 taps x 16 channels)
+    for (const Src& sr : full) {
+      const TDesc& t = slots[sr.slot];
+      for (int c0 = 0; c0 < t.Cpad; c0 += 16) {
+        chunks.push_back(chunk_of(t, so[sr.slot], c0));
+        const size_t w0 = wimg.size();
+        wimg.resize(w0 + (size_t)14 * NB * 64 * 4, 0u);
+        for (int s = 0; s < 14; ++s)
+          for (int b = 0; b < NB; ++b)
+            for (int l = 0; l < 64; ++l) {
+              const int m = b * 16 + (l & 15), q = l >> 4, tap = 2 * s + (q >> 1);
+              if (m >= p.cout || tap >= 27) continue;
+              for (int j = 0; j < 8; ++j) {
+                const int c = c0 + (q & 1) * 8 + j;
+                if (c >= sr.creal) break;
+                put(w0 + (((size_t)s * NB + b) * 64 + l) * 4, j, wm.data[((size_t)m * cin_m + (sr.cin_base + c)) * 27 + tap]);
+              }
+            }
+      }
+    }
+    const int n_full = (int)chunks.size();
+    // CENTER chunks: 32 channels of the box's own voxels in the residual source (cropped by half the pass's crop)
+    for (const Src& sr : center) {
+      const TDesc& t = slots[sr.slot];
+      const int org[3] = {so[sr.slot][0] + crop[0] / 2, so[sr.slot][1] + crop[1] / 2, so[sr.slot][2] + crop[2] / 2};
+      for (int c0 = 0; c0 < t.Cpad; c0 += 32) {
+        chunks.push_back(chunk_of(t, org, c0));
+        const size_t w0 = wimg.size();
+        wimg.resize(w0 + (size_t)NB * 64 * 4, 0u);
+        for (int b = 0; b < NB; ++b)
+          for (int l = 0; l < 64; ++l) {
+            const int m = b * 16 + (l & 15), q = l >> 4;
+            if (m >= p.cout) continue;
+            for (int j = 0; j < 8; ++j) {
+              const int c = c0 + q * 8 + j;
+              if (c >= sr.creal) break;
+              put(w0 + ((size_t)b * 64 + l) * 4, j, wr.data[(size_t)m * cin_r + (sr.cin_base + c)]);
+            }
+          }
+      }
+    }
+    std::vector<float> bias((size_t)16 * NB, 0.f);
+    for (int m = 0; m < p.cout; ++m) bias[m] = bm.data[m] + (last ? br.data[m] : 0.f);
+    BoxChunk* dchunks = nullptr;
+    uint32_t* dw = nullptr;
+    float* dbias = nullptr;
+    BSMI_HIP(hipMalloc((void**)&dchunks, chunks.size() * sizeof(BoxChunk)));
+    plan->allocs.push_back(dchunks);
+    BSMI_HIP(hipMalloc((void**)&dw, wimg.size() * 4));
+    plan->allocs.push_back(dw);
+    BSMI_HIP(hipMalloc((void**)&dbias, bias.size() * 4));
+    plan->allocs.push_back(dbias);
+    BSMI_HIP(hipMemcpy(dchunks, chunks.data(), chunks.size() * sizeof(BoxChunk), hipMemcpyHostToDevice));
+    BSMI_HIP(hipMemcpy(dw, wimg.data(), wimg.size() * 4, hipMemcpyHostToDevice));
+    BSMI_HIP(hipMemcpy(dbias, bias.data(), bias.size() * 4, hipMemcpyHostToDevice));
+    st.box.chunks = dchunks;
+    st.box.n_full = n_full;
+    st.box.n_center = (int)chunks.size() - n_full;
+    st.box.w = dw;
+    st.box.bias = dbias;
+    st.box.out = (uint16_t*)o.ptr;
+    st.box.Do = o.D; st.box.Ho = o.H; st.box.Wo = o.W; st.box.Co = o.Cpad;
+    st.use_box = true;
+    (void)nsl;
+    return BSMI_OK;
+  }
+
   // One ConvPass (reference unet.py:63-76).  in[s] with per-slot origin org[s]; `sp` is the
   // logical input extent (the extent of the concatenated, cropped input).
   int pass(PassSite& p, const TDesc* in, const int (*org)[3], const int sp_in[3], TDesc& out) {
@@ -440,9 +548,11 @@ struct Planner {
         st.out = o;
         rc = plan_rh(p, ci, pc, slots, so, nsl, o, st);
         if (rc) return rc;
+        rc = plan_box(p, ci, slots, so, nsl, o, st);
+        if (rc) return rc;
         if (getenv("BSMI_PLAN_DEBUG"))
           fprintf(stderr, "[bsmi plan] %s conv %d: out (%d,%d,%d)x%d tile BN=%d K-steps %d %s\n", p.prefix.c_str(), ci, o.D, o.H, o.W,
-                  p.cout, tile_bn(st.tile), a.nsteps, st.use_rh ? "raster-halo" : "gather");
+                  p.cout, tile_bn(st.tile), a.nsteps, st.use_box ? "box-halo" : st.use_rh ? "raster-halo" : "gather");
         plan->steps.push_back(st);
       }
       cur = o;
@@ -927,8 +1037,9 @@ int bsmi_unet_forward(bsmi_unet* h, int precision, const void* raw_dev, int raw_
                                (size_t)st.out.D * st.out.H * st.out.W, s);
         break;
       case PlanStep::CONV:
-        rc = st.use_rh ? launch_conv_rh(st.rh, precision, st.tile, s, h->sk_ws, h->sk_grid)
-                       : launch_conv_igemm(st.conv, precision, st.tile, s, h->sk_ws, h->sk_grid);
+        rc = st.use_box ? launch_conv_box(st.box, s)
+             : st.use_rh ? launch_conv_rh(st.rh, precision, st.tile, s, h->sk_ws, h->sk_grid)
+                         : launch_conv_igemm(st.conv, precision, st.tile, s, h->sk_ws, h->sk_grid);
         break;
       case PlanStep::POOL:
         rc = launch_maxpool(precision, st.in.ptr, st.out.ptr, st.in.D, st.in.H, st.in.W, st.in.Cpad,

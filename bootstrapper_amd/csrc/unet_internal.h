@@ -8,6 +8,7 @@
 
 #include "conv_igemm.h"
 #include "conv_rh.h"
+#include "conv_box.h"
 #include "first_pass.h"
 
 namespace bsmi {
@@ -75,6 +76,8 @@ struct PlanStep {
   ConvArgs conv;
   RhArgs rh;
   bool use_rh = false;
+  BoxArgs box;           // conv_box.hip launch of this step (use_box)
+  bool use_box = false;
   TileCfg tile;
   TDesc in, out;
   int f[3], o[3];
