@@ -162,58 +162,130 @@ __device__ __forceinline__ void lin_src(int dst, int f, int n, int& i0, int& i1,
   w0 = 1.f - w1;
 }
 
-// One workgroup per output row (z, y): the row's y / z source lines and weights are uniform, a thread walks the
-// row's (x, channel vector) pairs; streaming stores (the consumer conv reads the tensor once, much later).
+// General factors: one workgroup per output row (z, y), a thread walks the row's (x, channel vector) pairs.
+template <typename T>
+__global__ void upsample_crop_kernel(const T* in, T* out, int D, int H, int W, int C, int Do, int Ho,
+                                     int Wo, int fz, int fy, int fx, int oz, int oy, int ox);
+
+// One output voxel (z, y, x), one channel vector, the general way.
+template <typename T>
+__device__ __forceinline__ void upsample_one(const T* in, T* out, int D, int H, int W, int C, int Ho, int Wo, int fz, int fy, int fx,
+                                             int oz, int oy, int ox, int z, int y, int x, int c) {
+  constexpr int N = Vec<T>::N;
+  int z0, z1, y0, y1, x0, x1;
+  float wz0, wz1, wy0, wy1, wx0, wx1;
+  lin_src(z + oz, fz, D, z0, z1, wz0, wz1);
+  lin_src(y + oy, fy, H, y0, y1, wy0, wy1);
+  lin_src(x + ox, fx, W, x0, x1, wx0, wx1);
+  auto plane = [&](int zz, float* o) {
+    float a[N], b[N], p[N], q[N];
+    Vec<T>::unpack(*(const u32x4_t*)(in + (((size_t)zz * H + y0) * W + x0) * C + c), a);
+    Vec<T>::unpack(*(const u32x4_t*)(in + (((size_t)zz * H + y0) * W + x1) * C + c), b);
+#pragma unroll
+    for (int k = 0; k < N; ++k) p[k] = wx0 * a[k] + wx1 * b[k];
+    Vec<T>::unpack(*(const u32x4_t*)(in + (((size_t)zz * H + y1) * W + x0) * C + c), a);
+    Vec<T>::unpack(*(const u32x4_t*)(in + (((size_t)zz * H + y1) * W + x1) * C + c), b);
+#pragma unroll
+    for (int k = 0; k < N; ++k) q[k] = wx0 * a[k] + wx1 * b[k];
+#pragma unroll
+    for (int k = 0; k < N; ++k) o[k] = wy0 * p[k] + wy1 * q[k];
+  };
+  float r[N], acc[N];
+  plane(z0, r);
+  if (z1 != z0) {
+    float r1[N];
+    plane(z1, r1);
+#pragma unroll
+    for (int k = 0; k < N; ++k) acc[k] = wz0 * r[k] + wz1 * r1[k];
+  } else {
+#pragma unroll
+    for (int k = 0; k < N; ++k) acc[k] = wz0 * r[k] + wz1 * r[k];
+  }
+  __builtin_nontemporal_store(Vec<T>::pack(acc), (u32x4_t*)(out + (((size_t)z * Ho + y) * Wo + x) * C + c));
+}
+
 template <typename T>
 __global__ void upsample_crop_kernel(const T* in, T* out, int D, int H, int W, int C, int Do, int Ho,
                                      int Wo, int fz, int fy, int fx, int oz, int oy, int ox) {
   constexpr int N = Vec<T>::N;
   const int cv = C / N;
   const int y = blockIdx.x % Ho, z = blockIdx.x / Ho;
-  int z0, z1, y0, y1;
-  float wz0, wz1, wy0, wy1;
-  lin_src(z + oz, fz, D, z0, z1, wz0, wz1);
-  lin_src(y + oy, fy, H, y0, y1, wy0, wy1);
-  const T* r00 = in + ((size_t)z0 * H + y0) * W * C;
-  const T* r01 = in + ((size_t)z0 * H + y1) * W * C;
-  const T* r10 = in + ((size_t)z1 * H + y0) * W * C;
-  const T* r11 = in + ((size_t)z1 * H + y1) * W * C;
-  T* orow = out + ((size_t)z * Ho + y) * Wo * C;
-  const int n = Wo * cv;
-  for (int i = threadIdx.x; i < n; i += blockDim.x) {
+  for (int i = threadIdx.x; i < Wo * cv; i += blockDim.x) {
     const int x = i / cv, c = (i - x * cv) * N;
-    int x0, x1;
-    float wx0, wx1;
-    lin_src(x + ox, fx, W, x0, x1, wx0, wx1);
-    auto line = [&](const T* row, float* o) {
-      float a[N], b[N];
-      Vec<T>::unpack(*(const u32x4_t*)(row + (size_t)x0 * C + c), a);
-      Vec<T>::unpack(*(const u32x4_t*)(row + (size_t)x1 * C + c), b);
+    upsample_one<T>(in, out, D, H, W, C, Ho, Wo, fz, fy, fx, oz, oy, ox, z, y, x, c);
+  }
+}
+
+// Factor (1, 2, 2), the factor of every shipped setup: the outputs at global (pre-crop) coordinates (2p - 1, 2p)
+// along y and along x all interpolate the same two source lines / columns (p - 1, p) with weights (3/4, 1/4) and
+// (1/4, 3/4), so a thread that owns such a 2 x 2 patch loads 4 source vectors for 4 outputs instead of 16.  The
+// arithmetic is that of upsample_one, operation for operation; patches that touch the border, where the source
+// index is clamped, take the general path.
+template <typename T>
+__global__ void upsample2x_kernel(const T* in, T* out, int D, int H, int W, int C, int Do, int Ho, int Wo, int oz, int oy, int ox,
+                                  int py0, int npy, int px0, int npx) {
+  constexpr int N = Vec<T>::N;
+  const int cv = C / N;
+  const int py = py0 + blockIdx.x % npy, z = blockIdx.x / npy;
+  const int ya = 2 * py - 1 - oy;  // output rows ya, ya + 1
+  const bool row_in = ya >= 0 && ya + 1 < Ho && py - 1 >= 0 && py <= H - 1;
+  const int n = npx * cv;
+  for (int i = threadIdx.x; i < n; i += blockDim.x) {
+    const int pxi = i / cv, c = (i - pxi * cv) * N;
+    const int px = px0 + pxi;
+    const int xa = 2 * px - 1 - ox;
+    if (row_in && xa >= 0 && xa + 1 < Wo && px - 1 >= 0 && px <= W - 1) {
+      float s00[N], s01[N], s10[N], s11[N];
+      const T* base = in + (((size_t)(z + oz) * H + (py - 1)) * W + (px - 1)) * C + c;
+      Vec<T>::unpack(*(const u32x4_t*)(base), s00);
+      Vec<T>::unpack(*(const u32x4_t*)(base + C), s01);
+      Vec<T>::unpack(*(const u32x4_t*)(base + (size_t)W * C), s10);
+      Vec<T>::unpack(*(const u32x4_t*)(base + (size_t)W * C + C), s11);
 #pragma unroll
-      for (int k = 0; k < N; ++k) o[k] = wx0 * a[k] + wx1 * b[k];
-    };
-    float p[N], q[N], r[N], acc[N];
-    line(r00, p); line(r01, q);
+      for (int r = 0; r < 2; ++r) {
+        const float wy1 = r ? 0.75f : 0.25f, wy0 = 1.f - wy1;
 #pragma unroll
-    for (int k = 0; k < N; ++k) r[k] = wy0 * p[k] + wy1 * q[k];
-    if (z1 != z0) {
-      float r1[N];
-      line(r10, p); line(r11, q);
+        for (int q = 0; q < 2; ++q) {
+          const float wx1 = q ? 0.75f : 0.25f, wx0 = 1.f - wx1;
+          float acc[N];
 #pragma unroll
-      for (int k = 0; k < N; ++k) r1[k] = wy0 * p[k] + wy1 * q[k];
-#pragma unroll
-      for (int k = 0; k < N; ++k) acc[k] = wz0 * r[k] + wz1 * r1[k];
+          for (int k = 0; k < N; ++k) {
+            const float p = wx0 * s00[k] + wx1 * s01[k];
+            const float qq = wx0 * s10[k] + wx1 * s11[k];
+            const float v = wy0 * p + wy1 * qq;
+            acc[k] = 1.f * v + 0.f * v;  // the z weights (1, 0) of upsample_one
+          }
+          __builtin_nontemporal_store(Vec<T>::pack(acc), (u32x4_t*)(out + (((size_t)z * Ho + ya + r) * Wo + xa + q) * C + c));
+        }
+      }
     } else {
 #pragma unroll
-      for (int k = 0; k < N; ++k) acc[k] = wz0 * r[k] + wz1 * r[k];
+      for (int r = 0; r < 2; ++r)
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+          const int y = ya + r, x = xa + q;
+          if (y >= 0 && y < Ho && x >= 0 && x < Wo) upsample_one<T>(in, out, D, H, W, C, Ho, Wo, 1, 2, 2, oz, oy, ox, z, y, x, c);
+        }
     }
-    __builtin_nontemporal_store(Vec<T>::pack(acc), (u32x4_t*)(orow + (size_t)i * N));
   }
 }
 
 int launch_upsample_crop(int precision, const void* in, void* out, int D, int H, int W, int C, int Do,
                          int Ho, int Wo, int fz, int fy, int fx, int oz, int oy, int ox, hipStream_t s) {
   const int bs = 256;
+  if (fz == 1 && fy == 2 && fx == 2) {
+    const int py0 = (oy + 1) / 2, npy = (oy + Ho) / 2 - py0 + 1;
+    const int px0 = (ox + 1) / 2, npx = (ox + Wo) / 2 - px0 + 1;
+    const unsigned grid = (unsigned)(Do * npy);
+    if (precision == BSMI_PREC_F32)
+      hipLaunchKernelGGL(upsample2x_kernel<float>, dim3(grid), dim3(bs), 0, s, (const float*)in, (float*)out, D, H, W, C, Do, Ho, Wo, oz, oy, ox,
+                         py0, npy, px0, npx);
+    else
+      hipLaunchKernelGGL(upsample2x_kernel<uint16_t>, dim3(grid), dim3(bs), 0, s, (const uint16_t*)in, (uint16_t*)out, D, H, W, C, Do, Ho, Wo,
+                         oz, oy, ox, py0, npy, px0, npx);
+    BSMI_HIP(hipGetLastError());
+    return BSMI_OK;
+  }
   const unsigned grid = (unsigned)(Do * Ho);
   if (precision == BSMI_PREC_F32)
     hipLaunchKernelGGL(upsample_crop_kernel<float>, dim3(grid), dim3(bs), 0, s,
