@@ -8,7 +8,7 @@ and of the worker models/3d_affs/predict.py:59-162 (u8 -> [-1,1], reflect paddin
 dataset, one model(input) per block, x255 -> uint8 store clipped to the dataset ROI).
 The daisy TCP scheduler is replaced by a static interleave of the block list over the GPUs
 (blocks are independent: read_write_conflict=False, predict.py:37); on each GPU the blocks
-stream through `Model.predict_u8` on a HIP stream while the host thread decodes / encodes chunks.
+stream through `Model.predict_u8` while a write-behind pool copies, encodes and writes the finished blocks.
 """
 import json
 import os
@@ -144,6 +144,29 @@ def predict_blocks(cfg, rank=0, world=1, device=None, precision="bf16"):
     ctx = [(a - b) // 2 for a, b in zip(in_shape, out_shape)]
     blocks = enumerate_blocks(cfg)
     mine = blocks[rank::world]
+    # Write-behind: the device -> host copy of a block's outputs runs on its own stream and the chunk encoding + file
+    # writes (native threads, no GIL: zarr_io / codecs) on a small pool, while the next blocks are predicted.
+    import concurrent.futures as cf
+    copy_stream = torch.cuda.Stream(dev)
+    pool = cf.ThreadPoolExecutor(max_workers=2, thread_name_prefix="bsmi-write")
+    pending = []
+
+    def write_block(blk, hi, u8, ready):
+        with torch.cuda.stream(copy_stream):
+            copy_stream.wait_event(ready)
+            host = [t[:, :hi[0], :hi[1], :hi[2]].to("cpu", non_blocking=True) for t in u8]
+            done = torch.cuda.Event()
+            done.record(copy_stream)
+        done.synchronize()
+        for attempt in range(MAX_RETRIES + 1):
+            try:
+                for ds, t in zip(outs, host):
+                    ds[(slice(None),) + tuple(slice(blk[d], blk[d] + hi[d]) for d in range(3))] = t.numpy()
+                return True
+            except Exception:  # noqa: BLE001
+                if attempt == MAX_RETRIES:
+                    return False
+
     failed = 0
     for blk in mine:
         for attempt in range(MAX_RETRIES + 1):
@@ -153,14 +176,19 @@ def predict_blocks(cfg, rank=0, world=1, device=None, precision="bf16"):
                 if two_d:  # section z of the stack sees sections z .. z + adj - 1 of the read block as its channels
                     chans = [c[i:i + out_shape[0]] for c in chans for i in range(adj)]
                 u8 = model.predict_u8(chans[0] if len(chans) == 1 else torch.stack(chans))
+                ready = torch.cuda.Event()
+                ready.record(torch.cuda.current_stream(dev))
                 hi = [min(out_shape[d], roi_vox[d] - blk[d]) for d in range(3)]
-                for ds, t in zip(outs, u8):
-                    data = t[:, :hi[0], :hi[1], :hi[2]].cpu().numpy()
-                    ds[(slice(None),) + tuple(slice(blk[d], blk[d] + hi[d]) for d in range(3))] = data
+                pending.append(pool.submit(write_block, blk, hi, u8, ready))
                 break
             except Exception:  # noqa: BLE001 - a block is retried like a daisy block (max_retries=5)
                 if attempt == MAX_RETRIES:
                     failed += 1
+        while len(pending) > 4:  # bound the blocks in flight (their outputs stay alive until written)
+            failed += 0 if pending.pop(0).result() else 1
+    for f in pending:
+        failed += 0 if f.result() else 1
+    pool.shutdown()
     return len(mine), failed
 
 
