@@ -3,6 +3,11 @@ library is missing or a symbol is absent, importing this module raises."""
 import ctypes as C
 import os
 
+# PyTorch first: it brings its own copy of the HIP runtime (same soname as /opt/rocm's), and the process must bind
+# ONE of them.  Loading libbsmi.so before torch starts a second runtime, whose calls then fail with
+# "no ROCm-capable device is detected" while torch's work.
+import torch  # noqa: F401,E402
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # BSMI_LIB: developer knob to A/B another build of the same library (never a fallback)
 LIB_PATH = os.environ.get("BSMI_LIB") or os.path.join(_HERE, "libbsmi.so")
