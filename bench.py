@@ -214,6 +214,8 @@ def main():
     ap.add_argument("--seg-lanes", type=int, default=8)
     ap.add_argument("--pred-lanes", type=int, default=1, help="U-Net replicas / predict streams per GPU")
     ap.add_argument("--seg-cus", type=int, default=0, help="CUs reserved for the segmentation lanes (0: shared CUs)")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="process-group backend for N > 1: nccl (= RCCL, the real thing) or gloo (rehearsal on a box with fewer GPUs)")
     ap.add_argument("--no-segment", action="store_true", help="predict only (diagnostic; not the headline metric)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--seg-stages", default="ws,agg", help="diagnostic: which segmentation stages the lanes run")
@@ -231,12 +233,17 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: there is no CPU fallback for the HIP path")
+    if args.backend == "gloo":  # rehearsal on a box with fewer GPUs than ranks: the ranks share the GPUs there are
+        local_rank %= torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group("gloo")
 
     from bootstrapper_amd.unet import Model
     from bootstrapper_amd.synth import synthetic_state_dict, synthetic_volume
@@ -287,7 +294,7 @@ def main():
         totals = t if totals is None else {k: tuple(a + b for a, b in zip(totals[k], t[k])) for k in t}
 
     if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        t = torch.tensor([dt], dtype=torch.float64, device=dev if args.backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
