@@ -122,9 +122,6 @@ __device__ __forceinline__ void conv_igemm_body(const ConvArgs& a, char* smem, i
   // that the whole K-loop body is one scheduling region; h past the end re-loads the last K-step
   // into a slot nobody reads any more.
   auto issue = [&](int h, const Desc& ds) {
-#ifdef BSMI_ABLATE_NOLOAD  // timing experiment: multiply whatever is in LDS
-    if (h > 3) return;
-#endif
     const bool t1 = ds.t == 1, t2 = ds.t == 2;
     const uint64_t tbase = t1 ? base1 : (t2 ? base2 : base0);
     const uint32_t lofs = (uint32_t)(unit1 ? ds.d1 : ds.d0) + hoff;
@@ -167,13 +164,6 @@ __device__ __forceinline__ void conv_igemm_body(const ConvArgs& a, char* smem, i
     for (int j = 0; j < FN; ++j) pb[j] = *(const u32x4_t*)(st + brow[j] + ((c ^ bkey[j]) << 4));
   };
   auto mma = [&](const u32x4_t* pa, const u32x4_t* pb) {
-#ifdef BSMI_ABLATE_NOMMA  // timing experiment: keep the fragment reads alive, skip the MFMAs
-#pragma unroll
-    for (int i = 0; i < FM; ++i) asm volatile("" ::"v"(pa[i]));
-#pragma unroll
-    for (int j = 0; j < FN; ++j) asm volatile("" ::"v"(pb[j]));
-    return;
-#endif
 #pragma unroll
     for (int i = 0; i < FM; ++i)
 #pragma unroll
@@ -407,9 +397,6 @@ __device__ __forceinline__ void conv_igemm_body16(const ConvArgs& a, char* smem,
   // that the whole K-loop body is one scheduling region; h past the end re-loads the last K-step
   // into a slot nobody reads any more.
   auto issue = [&](int h, const Desc& ds) {
-#ifdef BSMI_ABLATE_NOLOAD  // timing experiment: multiply whatever is in LDS
-    if (h > 3) return;
-#endif
     const bool t1 = ds.t == 1, t2 = ds.t == 2;
     const uint64_t tbase = t1 ? base1 : (t2 ? base2 : base0);
     const uint32_t lofs = (uint32_t)(unit1 ? ds.d1 : ds.d0) + hoff;
