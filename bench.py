@@ -49,7 +49,7 @@ BF16_DENSE_PEAK_TFLOPS = 2500.0  # /opt/skills/guides/MI355X_MICROARCH.md, dense
 # HBM-side bytes per conv launch cannot be counted inside this process: they come from the committed
 # rocprofv3 PMC passes of the same kernels on the same block (tools/pmc_traffic.py; FETCH_SIZE and WRITE_SIZE
 # in separate passes, KiB -> bytes, FETCH_SIZE doubled for gfx950 wide reads as the guide prescribes).
-TRAFFIC_PROFILE = os.path.join(ROOT, "profiles", "r01_f_conv_traffic_pmc.json")
+TRAFFIC_PROFILE = os.path.join(ROOT, "profiles", "r01_g_conv_traffic_pmc.json")
 
 
 def pmc_traffic(precision):
@@ -60,6 +60,24 @@ def pmc_traffic(precision):
             return float(json.load(f)["traffic_bytes_per_conv_launch"]), os.path.relpath(TRAFFIC_PROFILE, ROOT)
     except (OSError, KeyError, ValueError):
         return None, None
+
+
+SQ_PROFILE = os.path.join(ROOT, "profiles", "r01_g_conv_sq_pmc.json")
+
+
+def pmc_mfma_busy(precision):
+    """MFMA-busy fraction of the persistent implicit-GEMM launches (the dominant kernels), from the committed PMC
+    passes (tools/run_pmc_passes.sh + tools/pmc_sq.py): SIMD cycles with the matrix pipe busy / SIMD cycles."""
+    if precision != "bf16":
+        return None
+    try:
+        with open(SQ_PROFILE) as f:
+            ks = json.load(f)["kernels"]
+        rows = [r for k, r in ks.items() if "conv_igemm_sk_kernel" in k]
+        tot = sum(r["chip_cycles_per_launch"] * r["launches"] for r in rows)
+        return sum(r["mfma_busy"] * r["chip_cycles_per_launch"] * r["launches"] for r in rows) / tot
+    except (OSError, KeyError, ValueError, ZeroDivisionError):
+        return None
 
 
 def host_cores():
@@ -316,6 +334,7 @@ def main():
                      "unit": "TFLOP/s", "frac": achieved / (BF16_DENSE_PEAK_TFLOPS if args.precision == "bf16" else 157.3),
                      "traffic": traffic, "traffic_unit": "bytes per launch (memory side of L2, Infinity-Cache hits included)",
                      "traffic_source": traffic_src,
+                     "mfma_busy": pmc_mfma_busy(args.precision), "mfma_busy_source": os.path.relpath(SQ_PROFILE, ROOT),
                      "kernel": "bsmi::conv_igemm_kernel / conv_igemm_sk_kernel / first_pass_kernel (all convolution launches of the U-Net)",
                      "launches": int(conv_launches), "avg_launch_ms": conv_ms / max(conv_launches, 1),
                      "algorithmic_tflop_per_block": flops_block / 1e12,

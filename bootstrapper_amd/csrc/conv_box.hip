@@ -30,10 +30,13 @@ namespace box {
 constexpr int TZ = 4, TY = 8, TX = 16;
 constexpr int HZ = TZ + 2, HY = TY + 2, HX = TX + 2;
 constexpr int NH = HZ * HY * HX;  // 1080 voxels of a halo tile
+// voxels between the two 8-channel halves of the image: a multiple of 16, so that a ds_read_b128 lane group -- 8 lanes
+// of one half and 8 of the other, 16 voxels apart in total -- covers 16 different 16-byte slots (all 64 banks)
+constexpr int NHP = (NH + 15) / 16 * 16;
 constexpr int NV = TZ * TY * TX;  // 512 voxels of the box = 32 groups of 16 x-consecutive voxels, g = (z = g / 8, y = g % 8)
 constexpr int NG = NV / 16 / 4;   // groups per wave
 constexpr int kThreads = 256;
-constexpr int kFullInstr = (2 * NH + kThreads - 1) / kThreads;  // 16-byte pieces of a halo tile / threads
+constexpr int kFullInstr = (2 * NHP + kThreads - 1) / kThreads;  // 16-byte pieces of a halo image / threads
 constexpr int kCenterInstr = 4 * NV / kThreads;
 constexpr int kBuf = kFullInstr * kThreads * 16;                 // bytes of one staging buffer (>= 4 NV 16)
 __device__ __forceinline__ constexpr int tap_bytes(int k) {  // tap k as a byte offset inside one half of the halo image
@@ -66,8 +69,10 @@ __global__ __launch_bounds__(box::kThreads, 2) void conv_box_kernel(BoxArgs a, i
 #pragma unroll
     for (int k = 0; k < kFullInstr; ++k) {
       int i = k * kThreads + tid;
-      i = i < 2 * NH ? i : 2 * NH - 1;
-      const int hf = i >= NH, v = i - hf * NH;
+      i = i < 2 * NHP ? i : 2 * NHP - 1;
+      const int hf = i >= NHP;
+      int v = i - hf * NHP;
+      v = v < NH ? v : NH - 1;  // the pad between the halves is filled with a copy of the last voxel
       const int hz = v / (HY * HX), r = v - hz * (HY * HX), hy = r / HX, hx = r - hy * HX;
       const int cz = min(Z0 + hz, ck.D - 1), cy = min(Y0 + hy, ck.H - 1), cx = min(X0 + hx, ck.W - 1);
       const size_t off = (size_t)cz * ck.sz + (size_t)cy * ck.sy + (size_t)cx * ck.sx + hf * 16;
@@ -108,7 +113,7 @@ __global__ __launch_bounds__(box::kThreads, 2) void conv_box_kernel(BoxArgs a, i
       stage_center(nf, buf ^ 1);
       load_center_w(0, anext);
     }
-    const uint32_t rd = (uint32_t)(buf * kBuf + half * (NH * 16) + n * 16);
+    const uint32_t rd = (uint32_t)(buf * kBuf + half * (NHP * 16) + n * 16);
 #pragma unroll
     for (int s = 0; s < 14; ++s) {
       const uint32_t ts = rd + (hi ? tap_bytes(2 * s + 1) : tap_bytes(2 * s));
