@@ -236,7 +236,7 @@ def main():
                     help="process-group backend for N > 1: nccl (= RCCL, the real thing) or gloo (rehearsal on a box with fewer GPUs)")
     ap.add_argument("--no-segment", action="store_true", help="predict only (diagnostic; not the headline metric)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--seg-stages", default="ws,agg", help="diagnostic: which segmentation stages the lanes run")
+    ap.add_argument("--seg-stages", default="ws,agg", help="diagnostic: which segmentation stages the lanes run (ws, agg, or none: lane events only)")
     ap.add_argument("--seg-burst", type=int, default=0, help="launch the segmentation of this many blocks together (0: block by block)")
     args = ap.parse_args()
     if args.mode == "train":

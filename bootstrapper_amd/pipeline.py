@@ -116,13 +116,16 @@ class BlockPipeline:
             with torch.cuda.stream(lane["stream"]):
                 lane["stream"].wait_event(ready)
                 affs = u8[0][:3]
-                if "ws" in self.seg_stages or lane.get("frags") is None:
+                if self.seg_stages == ("none",):  # diagnostic: the lane structure (events, streams) without any segmentation kernel
+                    frags = segs = affs
+                elif "ws" in self.seg_stages or lane.get("frags") is None:
                     frags, max_id = lane["engine"].ws_fragments(affs, True, self.msd)
                     lane["frags"] = frags
                 else:
                     frags = lane["frags"]  # diagnostic mode: agglomerate the lane's first fragments again
-                segs = (lane["engine"].agglomerate_mean(affs, frags, self.thresholds) if "agg" in self.seg_stages
-                        else frags[None])
+                if self.seg_stages != ("none",):
+                    segs = (lane["engine"].agglomerate_mean(affs, frags, self.thresholds) if "agg" in self.seg_stages
+                            else frags[None])
                 for t in (raw, affs, frags, segs) + tuple(u8):
                     t.record_stream(lane["stream"])
                 done = torch.cuda.Event()
