@@ -62,6 +62,7 @@ __device__ __forceinline__ void conv_igemm_body(const ConvArgs& a, char* smem, i
 
 #ifdef BSMI_STAMP
   const unsigned long long st_begin = wall_clock64();
+  const unsigned long long cy_begin = clock64();
 #endif
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -238,6 +239,7 @@ __device__ __forceinline__ void conv_igemm_body(const ConvArgs& a, char* smem, i
   }
 #ifdef BSMI_STAMP
   const unsigned long long st0 = wall_clock64();
+  const unsigned long long cy0 = clock64();
 #endif
   // drain the run-ahead loads; after the barrier nobody reads or writes the LDS ring any more
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
@@ -314,6 +316,7 @@ __device__ __forceinline__ void conv_igemm_body(const ConvArgs& a, char* smem, i
     atomicAdd(&g_stamp[2], st3 - st2);
     atomicAdd(&g_stamp[3], 1ull);
     atomicAdd(&g_stamp[4], st0 - st_begin);
+    atomicAdd(&g_stamp[5], cy0 - cy_begin);  // shader cycles of the K loop: with [4] the clock it ran at
   }
 #endif
 }
@@ -337,6 +340,7 @@ __device__ __forceinline__ void conv_igemm_body16(const ConvArgs& a, char* smem,
 
 #ifdef BSMI_STAMP
   const unsigned long long st_begin = wall_clock64();
+  const unsigned long long cy_begin = clock64();
 #endif
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -507,6 +511,7 @@ __device__ __forceinline__ void conv_igemm_body16(const ConvArgs& a, char* smem,
 #undef MMA1
 #ifdef BSMI_STAMP
   const unsigned long long st0 = wall_clock64();
+  const unsigned long long cy0 = clock64();
 #endif
   // drain the run-ahead loads; after the barrier nobody reads or writes the LDS ring any more
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
@@ -579,6 +584,7 @@ __device__ __forceinline__ void conv_igemm_body16(const ConvArgs& a, char* smem,
     atomicAdd(&g_stamp[2], st3 - st2);
     atomicAdd(&g_stamp[3], 1ull);
     atomicAdd(&g_stamp[4], st0 - st_begin);
+    atomicAdd(&g_stamp[5], cy0 - cy_begin);  // shader cycles of the K loop: with [4] the clock it ran at
   }
 #endif
 }
@@ -658,8 +664,11 @@ __global__ __launch_bounds__(64 * WM * WN, 1) void conv_igemm_sk_kernel(const Co
   __shared__ int sh_item;
   const int ntiles = ((a.M + BM - 1) / BM) * (a.Npad / BN);
   const int S = a.nsteps;
+  // the XCD this workgroup really runs on (blockIdx % 8 is only the usual placement: a CU-masked queue deals differently)
+  unsigned xcc;
+  asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
   for (int k = 0; k < 8; ++k) {
-    const int xcd = (blockIdx.x + k) & 7;
+    const int xcd = ((int)(xcc & 7) + k) & 7;
     const SkGeom g = sk_geom(ntiles, xcd, gridDim.x);
     const int nfull = g.rounds * g.per, nitems = nfull + g.rem * g.P;
     for (;;) {

@@ -1,33 +1,45 @@
-"""Timing of the segmentation stages on one full-size block (dev tool)."""
-import sys, time
-import numpy as np, torch
-sys.path.insert(0, ".")
-from bootstrapper_amd.unet import Model
+"""Dev tool: standalone latency of one block's segmentation (fragments, agglomeration) on an idle GPU, on affinities
+the U-Net predicts from the benchmark's synthetic volume; 1 lane, then 8 lanes side by side."""
+import sys, os, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from bench import NET_CONFIG, OUT_BLOCK, CONTEXT, THRESHOLDS
+from bootstrapper_amd.unet import Model, extract_block_reflect
 from bootstrapper_amd.synth import synthetic_state_dict, synthetic_volume
 from bootstrapper_amd.post.engine import SegEngine
-from tests.test_lib_cpu import AFFS_NET_CONFIG as NC
-shape = (156, 220, 220)
-m = Model(NC, precision="bf16").load_state_dict(synthetic_state_dict(NC, 0))
-raw = synthetic_volume(shape, 0)
-u8 = m.predict_u8(raw)[0]
-affs = u8[:3].contiguous()
-print("affs mean", affs.float().mean().item(), "mask frac", ((affs[1].int() + affs[2].int()) >= 256).float().mean().item())
-eng = SegEngine((128, 128, 128))
-for it in range(3):
-    torch.cuda.synchronize(); t0 = time.time()
-    frags, mx = eng.ws_fragments(affs, True, 10)
-    torch.cuda.synchronize(); t1 = time.time()
-    segs = eng.agglomerate_mean(affs, frags, [0.2, 0.35, 0.5])
-    eng.status(); t2 = time.time()
-    print(f"iter {it}: fragments {1e3*(t1-t0):.1f} ms, agglomerate {1e3*(t2-t1):.1f} ms, max_id {int(mx)}, "
-          f"nfrag {len(torch.unique(frags))-1}, nseg {[len(torch.unique(s))-1 for s in segs]}")
-# synthetic affinity volume (blobby) for comparison
-a2 = torch.stack([synthetic_volume((128, 128, 128), 10 + c, corr=(2, 12, 12)) for c in range(3)])
-for it in range(2):
-    torch.cuda.synchronize(); t0 = time.time()
-    frags, mx = eng.ws_fragments(a2, True, 10)
-    torch.cuda.synchronize(); t1 = time.time()
-    segs = eng.agglomerate_mean(a2, frags, [0.2, 0.35, 0.5])
-    eng.status(); t2 = time.time()
-    print(f"synthetic affs iter {it}: fragments {1e3*(t1-t0):.1f} ms, agglomerate {1e3*(t2-t1):.1f} ms, max_id {int(mx)}, "
-          f"nfrag {len(torch.unique(frags))-1}, nseg {[len(torch.unique(s))-1 for s in segs]}")
+
+dev = torch.device("cuda", 0)
+m = Model(NET_CONFIG, precision="bf16").load_state_dict(synthetic_state_dict(NET_CONFIG, 0))
+vol = synthetic_volume((512,) * 3, seed=0, device=dev)
+in_block = tuple(o + 2 * c for o, c in zip(OUT_BLOCK, CONTEXT))
+affs = []
+for i in range(8):
+    raw = extract_block_reflect(vol, [128 * (i % 4) - CONTEXT[0], 128 * (i // 4) - CONTEXT[1], -CONTEXT[2]], in_block)
+    affs.append(m.predict_u8(raw)[0][:3].contiguous())
+torch.cuda.synchronize()
+engines = [SegEngine(OUT_BLOCK, 0) for _ in range(8)]
+streams = [torch.cuda.Stream(dev) for _ in range(8)]
+
+
+def run(n):
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    marks = []
+    for i in range(n):
+        with torch.cuda.stream(streams[i]):
+            e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True); e2 = torch.cuda.Event(enable_timing=True)
+            e0.record()
+            frags, _ = engines[i].ws_fragments(affs[i], True, 10)
+            e1.record()
+            engines[i].agglomerate_mean(affs[i], frags, THRESHOLDS)
+            e2.record()
+            marks.append((e0, e1, e2))
+    torch.cuda.synchronize()
+    wall = (time.perf_counter() - t0) * 1e3
+    ws = [a.elapsed_time(b) for a, b, _ in marks]
+    ag = [b.elapsed_time(c) for _, b, c in marks]
+    print(f"{n} lane(s): wall {wall:.1f} ms; fragments {min(ws):.1f}..{max(ws):.1f} ms, agglomeration {min(ag):.1f}..{max(ag):.1f} ms")
+
+
+for n in (1, 1, 8, 8):
+    run(n)
