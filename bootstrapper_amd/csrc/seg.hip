@@ -283,6 +283,12 @@ __global__ void ws_offsets_kernel(int D, WsScratch s, uint64_t* max_id) {
   }
 }
 
+// lane 0's 64-bit value to the whole wave
+__device__ __forceinline__ uint64_t bcast0(uint64_t v) {
+  const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)v), hi = __builtin_amdgcn_readfirstlane((uint32_t)(v >> 32));
+  return ((uint64_t)hi << 32) | lo;
+}
+
 // heap entry: [63:40] = MAXD2 - d2 (24 bit) | [39:20] = age (20 bit) | [19:0] = voxel index.
 // Ordering ignores the index bits (skimage compares (value, age) only).
 __device__ __forceinline__ bool flood_smaller(uint64_t a, uint64_t b) { return (a >> 20) < (b >> 20); }
@@ -299,11 +305,28 @@ __global__ __launch_bounds__(64 * FLOOD_WAVES) void ws_flood_kernel(int D, int H
   const int32_t* d2 = s.d2 + (size_t)z * n;
   int32_t* lab = s.lab + (size_t)z * n;
   uint64_t* hg = heap_spill + (size_t)z * spill_stride;  // entries >= FLOOD_LDS_HEAP live here
-  if (lane == 0) {
+  // The queue order is inherently sequential, so the whole wave walks the same loop in lockstep (every lane holds the
+  // same `items`, `age` and heap values; lane 0 alone owns the heap).  What the other lanes buy: the four neighbours
+  // of a popped voxel are fetched side by side -- lane k reads mask, label and distance of neighbour k in one round of
+  // loads -- where a single lane would chain up to twelve dependent global loads per voxel.  Label stores are issued by
+  // all four fetching lanes (same address, same value), so that each lane's later loads follow its own stores in program
+  // order.
+  {
     constexpr uint64_t MAXD2 = (1u << 24) - 1;
     int items = 0;
-    auto hget = [&](int i) -> uint64_t { return i < FLOOD_LDS_HEAP ? hl[i] : hg[i - FLOOD_LDS_HEAP]; };
-    auto hset = [&](int i, uint64_t v) { if (i < FLOOD_LDS_HEAP) hl[i] = v; else hg[i - FLOOD_LDS_HEAP] = v; };
+    // the heap is written by lane 0 alone; its HBM spill is also read by lane 0 alone (and broadcast), so that those loads
+    // follow that lane's stores in its own program order; LDS operations of a wave execute in order anyway
+    auto hget = [&](int i) -> uint64_t {
+      if (i < FLOOD_LDS_HEAP) return hl[i];
+      uint64_t v = 0;
+      if (lane == 0) v = hg[i - FLOOD_LDS_HEAP];
+      return bcast0(v);
+    };
+    auto hset = [&](int i, uint64_t v) {
+      if (lane == 0) {
+        if (i < FLOOD_LDS_HEAP) hl[i] = v; else hg[i - FLOOD_LDS_HEAP] = v;
+      }
+    };
     auto push = [&](uint64_t it) {
       int c = items++;
       while (c > 0) {
@@ -314,12 +337,37 @@ __global__ __launch_bounds__(64 * FLOOD_WAVES) void ws_flood_kernel(int D, int H
       hset(c, it);
     };
     // seeds in raster order, age 0
-    for (int i = 0; i < n; ++i)
-      if (lab[i] != 0) push(((MAXD2 - (uint64_t)d2[i]) << 40) | (uint64_t)i);
+    for (int i0 = 0; i0 < n; i0 += 64) {
+      const int i = i0 + lane;
+      const int li = i < n ? lab[i] : 0;
+      unsigned long long seeds = __ballot(li != 0);
+      while (seeds) {
+        const int k = __ffsll(seeds) - 1;
+        seeds &= seeds - 1;
+        const int j = i0 + k;
+        push(((MAXD2 - (uint64_t)d2[j]) << 40) | (uint64_t)j);
+      }
+    }
     uint32_t age = 0;
+    const int k4 = lane & 3;
+    const int dq = k4 == 0 ? -W : (k4 == 1 ? -1 : (k4 == 2 ? 1 : W));
     while (items > 0) {
       const uint64_t e = hget(0);
       --items;
+      // the popped voxel's label and its neighbours' state are requested first: their latency hides behind the sift
+      const int idx = (int)(e & 0xfffffu);
+      const int y = idx / W, x = idx - y * W;
+      // neighbour order [-W, -1, +1, +W]: lane k < 4 looks at neighbour k; the other lanes stay out of global memory
+      const bool okk = k4 == 0 ? y > 0 : (k4 == 1 ? x > 0 : (k4 == 2 ? x < W - 1 : y < H - 1));
+      const int qk = okk ? idx + dq : idx;
+      int lme = 0, mk = 0, lk = 0, dk = 0;
+      if (lane < 4) {
+        lme = lab[idx];
+        mk = mask[qk];
+        lk = lab[qk];
+        dk = d2[qk];
+      }
+      const int l = __builtin_amdgcn_readfirstlane(lme);
       if (items > 0) {
         // sift the last element down from the root (skimage heappop order)
         const uint64_t last = hget(items);
@@ -341,24 +389,19 @@ __global__ __launch_bounds__(64 * FLOOD_WAVES) void ws_flood_kernel(int D, int H
         }
         hset(i, last);
       }
-      const int idx = (int)(e & 0xfffffu);
-      const int y = idx / W, x = idx - y * W;
-      const int l = lab[idx];
-      // neighbour order [-W, -1, +1, +W]
-      const int nb[4] = {idx - W, idx - 1, idx + 1, idx + W};
-      const bool ok[4] = {y > 0, x > 0, x < W - 1, y < H - 1};
+      const int cand = (okk && mk && lk == 0) ? 1 : 0;
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
-        if (!ok[k]) continue;
-        const int q = nb[k];
-        if (!mask[q] || lab[q] != 0) continue;
+        if (!__shfl(cand, k)) continue;  // wave uniform
+        const int q = __shfl(qk, k);
+        const uint64_t dd = (uint64_t)(uint32_t)__shfl(dk, k);
         ++age;
-        lab[q] = l;
-        push(((MAXD2 - (uint64_t)d2[q]) << 40) | ((uint64_t)age << 20) | (uint64_t)q);
+        if (lane < 4) lab[q] = l;
+        push(((MAXD2 - dd) << 40) | ((uint64_t)age << 20) | (uint64_t)q);
       }
     }
   }
-  // lane 0's label writes become visible to the other lanes of its wave in program order
+  // the label writes become visible to the whole wave before the copy-out
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
   __builtin_amdgcn_wave_barrier();
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
@@ -1416,11 +1459,20 @@ __global__ __launch_bounds__(64) void ws3_flood_kernel(int D, int H, int W, WsSc
   const uint8_t* mask = s.mask;
   const int32_t* d2 = s.d2;
   int32_t* lab = s.lab;
-  if (lane == 0) {
+  // As in ws_flood_kernel the wave walks the one sequential loop in lockstep: lane 0 writes the LDS part of the heap, every
+  // lane its HBM part (same address, same value: each lane's later loads then follow its own stores), lanes k < 6 fetch
+  // neighbour k of the popped voxel in one round of loads issued before the sift-down, and write the labels.
+  {
     constexpr uint64_t MAXD2 = (1u << 18) - 1;
     size_t items = 0;
     auto hget = [&](size_t i) -> uint64_t { return i < LH ? hl[i] : hg[i - LH]; };
-    auto hset = [&](size_t i, uint64_t v) { if (i < LH) hl[i] = v; else hg[i - LH] = v; };
+    auto hset = [&](size_t i, uint64_t v) {
+      if (i < LH) {
+        if (lane == 0) hl[i] = v;
+      } else {
+        hg[i - LH] = v;
+      }
+    };
     auto push = [&](uint64_t it) {
       size_t c = items++;
       while (c > 0) {
@@ -1430,12 +1482,36 @@ __global__ __launch_bounds__(64) void ws3_flood_kernel(int D, int H, int W, WsSc
       }
       hset(c, it);
     };
-    for (size_t i = 0; i < n; ++i)
-      if (lab[i] != 0) push(((MAXD2 - (uint64_t)d2[i]) << 46) | (uint64_t)i);
+    for (size_t i0 = 0; i0 < n; i0 += 64) {
+      const size_t i = i0 + lane;
+      const int li = i < n ? lab[i] : 0;
+      unsigned long long seeds = __ballot(li != 0);
+      while (seeds) {
+        const int k = __ffsll(seeds) - 1;
+        seeds &= seeds - 1;
+        const size_t j = i0 + k;
+        push(((MAXD2 - (uint64_t)d2[j]) << 46) | (uint64_t)j);
+      }
+    }
     uint64_t age = 0;
+    const int k8 = lane & 7;
+    const long long dq = k8 == 0 ? -(long long)hw : (k8 == 1 ? -(long long)W : (k8 == 2 ? -1 : (k8 == 3 ? 1 : (k8 == 4 ? (long long)W : (long long)hw))));
     while (items > 0) {
       const uint64_t e = hget(0);
       --items;
+      const size_t idx = (size_t)(e & 0x7fffffu);
+      const int x = (int)(idx % W), y = (int)((idx / W) % H), z = (int)(idx / hw);
+      // neighbour order [-HW, -W, -1, +1, +W, +HW]
+      const bool okk = k8 == 0 ? z > 0 : (k8 == 1 ? y > 0 : (k8 == 2 ? x > 0 : (k8 == 3 ? x < W - 1 : (k8 == 4 ? y < H - 1 : z < D - 1))));
+      const size_t qk = okk ? (size_t)((long long)idx + dq) : idx;
+      int lme = 0, mk = 0, lk = 0, dk = 0;
+      if (lane < 6) {
+        lme = lab[idx];
+        mk = mask[qk];
+        lk = lab[qk];
+        dk = d2[qk];
+      }
+      const int l = __builtin_amdgcn_readfirstlane(lme);
       if (items > 0) {
         const uint64_t last = hget(items);
         size_t i = 0;
@@ -1456,19 +1532,16 @@ __global__ __launch_bounds__(64) void ws3_flood_kernel(int D, int H, int W, WsSc
         }
         hset(i, last);
       }
-      const size_t idx = (size_t)(e & 0x7fffffu);
-      const int x = (int)(idx % W), y = (int)((idx / W) % H), z = (int)(idx / hw);
-      const int l = lab[idx];
-      const size_t nb[6] = {idx - hw, idx - W, idx - 1, idx + 1, idx + W, idx + hw};
-      const bool ok[6] = {z > 0, y > 0, x > 0, x < W - 1, y < H - 1, z < D - 1};
+      const int cand = (lane < 6 && okk && mk && lk == 0) ? 1 : 0;
+      const int qlo = (int)qk;
 #pragma unroll
       for (int k = 0; k < 6; ++k) {
-        if (!ok[k]) continue;
-        const size_t q = nb[k];
-        if (!mask[q] || lab[q] != 0) continue;
+        if (!__shfl(cand, k)) continue;  // wave uniform
+        const size_t q = (size_t)(uint32_t)__shfl(qlo, k);
+        const uint64_t dd = (uint64_t)(uint32_t)__shfl(dk, k);
         ++age;
-        lab[q] = l;
-        push(((MAXD2 - (uint64_t)d2[q]) << 46) | (age << 23) | (uint64_t)q);
+        if (lane < 6) lab[q] = l;
+        push(((MAXD2 - dd) << 46) | (age << 23) | (uint64_t)q);
       }
     }
   }
