@@ -716,29 +716,50 @@ __global__ __launch_bounds__(64) void agg_merge_kernel(AggWs w, const float* __r
         }
         const uint32_t eu = w.eu[e], evv = w.ev[e];
         const uint32_t a = eu < evv ? eu : evv, b = eu < evv ? evv : eu;
+        // Every access below is a dependent trip to L2 (~0.3 us), so the loads that do not depend on each other are
+        // issued together: all fields of f at once, the first probes of both hash lookups at once, the sums at once.
         uint32_t f = w.head[b];
         while (f != NOEDGE && !fail) {
-          const uint32_t fu = w.eu[f], fv = w.ev[f];
+          const uint32_t fu = w.eu[f], fv = w.ev[f], fnu = w.enextu[f], fnv = w.enextv[f];
+          const uint8_t ffl = w.eflags[f];
           const bool b_in_u = fu == b;
-          const uint32_t nxt = b_in_u ? w.enextu[f] : w.enextv[f];
-          if (f != e && !(w.eflags[f] & 1)) {
+          const uint32_t nxt = b_in_u ? fnu : fnv;
+          if (f != e && !(ffl & 1)) {
             const uint32_t nb = b_in_u ? fv : fu;
-            const uint64_t gkey = norm_key(a, nb);
-            const int64_t fs = hfind(norm_key(fu, fv));
+            const uint64_t fkey = norm_key(fu, fv), gkey = norm_key(a, nb);
+            uint32_t sf = (uint32_t)hmix(fkey) & (w.hcap - 1), sg = (uint32_t)hmix(gkey) & (w.hcap - 1);
+            uint64_t kf = w.hkeys[sf], kg = w.hkeys[sg];  // both first probes in flight together
+            int64_t fs = -1, gs = -1;
+            for (uint32_t probe = 0; probe < w.hcap; ++probe) {
+              if (kf == fkey) { fs = (int64_t)sf; break; }
+              if (kf == HEMPTY) break;
+              sf = (sf + 1) & (w.hcap - 1);
+              kf = w.hkeys[sf];
+            }
             if (fs >= 0) w.hkeys[fs] = HTOMB;
-            const int64_t gs = hfind(gkey);
+            // (gkey != fkey: a tombstone at fs and the key it replaces both mean "keep probing" to the lookup of gkey)
+            for (uint32_t probe = 0; probe < w.hcap; ++probe) {
+              if (kg == gkey) { gs = (int64_t)sg; break; }
+              if (kg == HEMPTY) break;
+              sg = (sg + 1) & (w.hcap - 1);
+              kg = sg == (uint32_t)fs ? HTOMB : w.hkeys[sg];
+            }
             if (gs >= 0) {
               const uint32_t g = w.hvals[gs];
-              w.esum[g] += w.esum[f];
-              w.ecnt[g] += w.ecnt[f];
-              w.eflags[g] |= 2;
-              w.eflags[f] |= 1;
+              const unsigned long long sum_f = w.esum[f], sum_g = w.esum[g];
+              const uint32_t cnt_f = w.ecnt[f], cnt_g = w.ecnt[g];
+              const uint8_t gfl = w.eflags[g];
+              w.esum[g] = sum_g + sum_f;
+              w.ecnt[g] = cnt_g + cnt_f;
+              w.eflags[g] = gfl | 2;
+              w.eflags[f] = ffl | 1;
             } else {
               // f becomes {a, nb}: b is replaced IN ITS SLOT so that nb's list keeps following
               // the link that belongs to nb's slot; f joins a's list through b's old slot
-              if (b_in_u) { w.eu[f] = a; w.enextu[f] = w.head[a]; } else { w.ev[f] = a; w.enextv[f] = w.head[a]; }
+              const uint32_t ha = w.head[a];
+              if (b_in_u) { w.eu[f] = a; w.enextu[f] = ha; } else { w.ev[f] = a; w.enextv[f] = ha; }
               w.head[a] = f;
-              w.eflags[f] |= 2;
+              w.eflags[f] = ffl | 2;
               hput(gkey, f);
             }
           }
