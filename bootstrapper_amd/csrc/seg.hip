@@ -618,7 +618,12 @@ __device__ __forceinline__ bool xcd_claim(uint32_t* claim, int target) {
 }
 
 // One wave per volume; lane 0 replays the sequential merge loop of oracle/seg_ref.c.
-__global__ __launch_bounds__(64) void agg_merge_kernel(AggWs w, const float* __restrict__ thresholds, int nthr) {
+struct AggThresholds {  // by value: no host-to-device copy per call
+  float v[16];
+};
+
+__global__ __launch_bounds__(64) void agg_merge_kernel(AggWs w, const AggThresholds thr_arg, int nthr) {
+  const float* thresholds = thr_arg.v;
   __shared__ uint64_t hl[AGG_LDS_HEAP];
   __shared__ int sh_dummy;
   if (!xcd_claim(&w.counters[5], w.xcd_hint)) return;
@@ -1815,7 +1820,9 @@ int bsmi_agglomerate_mean_u8(bsmi_seg* h, const uint8_t* affs_dev, const uint64_
   const int D = (int)shape[0], H = (int)shape[1], W = (int)shape[2];
   const size_t n = (size_t)D * H * W;
   AggWs& g = h->agg;
-  BSMI_HIP(hipMemcpyAsync(h->thr_dev, thresholds_host, sizeof(float) * n_thresholds, hipMemcpyHostToDevice, s));
+  AggThresholds thr;
+  static_assert(kMaxThresholds <= 16, "AggThresholds holds 16 values");
+  for (int i = 0; i < 16; ++i) thr.v[i] = i < n_thresholds ? thresholds_host[i] : 0.f;
   BSMI_HIP(hipMemsetAsync(g.counters, 0, 8 * sizeof(uint32_t), s));
   BSMI_HIP(hipMemsetAsync(g.maxid, 0, sizeof(uint64_t), s));
   // The scans run as FEW, FAT workgroups (kScanGrid x 1024 threads, grid-stride loops): a lane shares the GPU with
@@ -1829,7 +1836,7 @@ int bsmi_agglomerate_mean_u8(bsmi_seg* h, const uint8_t* affs_dev, const uint64_
   hipLaunchKernelGGL(agg_rank_kernel, dim3(1), dim3(1024), 0, s, g);
   hipLaunchKernelGGL(agg_edges_kernel<false>, dim3(grid), dim3(bs), 0, s, affs_dev, frags_dev, D, H, W, g);
   hipLaunchKernelGGL(agg_compact_kernel, dim3(grid), dim3(bs), 0, s, g);
-  hipLaunchKernelGGL(agg_merge_kernel, dim3(8), dim3(64), 0, s, g, (const float*)h->thr_dev, n_thresholds);
+  hipLaunchKernelGGL(agg_merge_kernel, dim3(8), dim3(64), 0, s, g, thr, n_thresholds);
   hipLaunchKernelGGL(agg_relabel_kernel, dim3(grid), dim3(bs), 0, s, frags_dev, n, n_thresholds, g, segs_dev);
   BSMI_HIP(hipGetLastError());
   return BSMI_OK;
