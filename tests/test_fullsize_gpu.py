@@ -128,6 +128,7 @@ def test_full_block_blockwise_stages_bit_exact(full_block):
     ("persistent split-K tail, 256x256 tiles", {"BSMI_SK_GRID": "8", "BSMI_TILE_EFF": "0.01,0.01,0.01,1,0.01"}),
     ("persistent split-K tail, 256x320 tiles", {"BSMI_SK_GRID": "16", "BSMI_TILE_EFF": "0.01,0.01,0.01,0.01,1"}),
     ("4-wave kernels", {"BSMI_WAVES8": "0"}),
+    ("implicit GEMM for the first pass and the small-Cout layers (no first_pass / conv_box)", {"BSMI_FUSED_FIRST": "0", "BSMI_USE_BOX": "0"}),
 ])
 def test_conv_kernel_variants_in_subprocess(variant, env):
     """The conv kernel variants that the golden nets do not reach by themselves (they are chosen by layer
