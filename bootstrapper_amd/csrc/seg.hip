@@ -592,6 +592,29 @@ __global__ void agg_compact_kernel(AggWs w) {
   }
 }
 
+// Ties of the merge queue are broken by the edge's initial key (oracle/seg_ref.c).  The mean affinities of uint8 sums tie
+// often, and looking the two keys up costs the single-lane loop two trips to L2 per comparison: 3.3 us per pop.  So the
+// edges are ranked by their key once, here (one workgroup, keys in LDS, rank = number of smaller keys), and the queue
+// entries carry the rank: a comparison is then one 64-bit compare.  Graphs of more than kRankMax edges keep the look-up.
+// erank = w.qnext, eofrank = w.iota (arrays the mean-agglomeration path does not use otherwise); counters[7] = ranks valid.
+constexpr uint32_t kRankMax = 16384;
+__global__ __launch_bounds__(1024) void agg_edge_rank_kernel(AggWs w) {
+  extern __shared__ uint64_t rank_keys[];
+  if (w.counters[3]) return;
+  const uint32_t ne = w.counters[1];
+  if (ne > kRankMax || ne > w.edge_cap) return;
+  for (uint32_t e = threadIdx.x; e < ne; e += blockDim.x) rank_keys[e] = w.ekey0[e];
+  __syncthreads();
+  for (uint32_t e = threadIdx.x; e < ne; e += blockDim.x) {
+    const uint64_t k = rank_keys[e];
+    uint32_t r = 0;
+    for (uint32_t j = 0; j < ne; ++j) r += rank_keys[j] < k ? 1u : 0u;
+    w.qnext[e] = r;
+    w.iota[r] = e;
+  }
+  if (threadIdx.x == 0) w.counters[7] = 1;
+}
+
 __device__ __forceinline__ float agg_score(unsigned long long sum, uint32_t cnt) {
   return 1.0f - (float)((double)sum / (255.0 * (double)cnt));
 }
@@ -622,26 +645,36 @@ struct AggThresholds {  // by value: no host-to-device copy per call
   float v[16];
 };
 
-__global__ __launch_bounds__(64) void agg_merge_kernel(AggWs w, const AggThresholds thr_arg, int nthr) {
+// SPILL = false: the queue never holds more entries than there are edges, so with ne <= AGG_LDS_HEAP every access is a plain
+// LDS access.  (With the HBM overflow in the same expression the compiler selects between the two addresses and emits
+// FLAT loads, which cost the single-lane sift-down 0.25 us per level: 3 us per pop.)
+template <bool SPILL>
+__device__ __forceinline__ void agg_merge_body(const AggWs& w, const AggThresholds& thr_arg, int nthr, uint64_t* hl, int* sh_dummy_p,
+                                               uint32_t nn, uint32_t ne) {
   const float* thresholds = thr_arg.v;
-  __shared__ uint64_t hl[AGG_LDS_HEAP];
-  __shared__ int sh_dummy;
-  if (!xcd_claim(&w.counters[5], w.xcd_hint)) return;
-  if (w.counters[3]) return;
-  const uint32_t nn = w.counters[0];
-  const uint32_t ne = min(w.counters[1], w.edge_cap);
+  int& sh_dummy = *sh_dummy_p;
   const int lane = threadIdx.x;
   int items = 0;  // meaningful on lane 0 only
   const float tmax = thresholds[nthr - 1];
   // entry: [63:32] float bits of the score (scores are >= 0: bit pattern order == value order),
   //        [31:0] edge index; ties on the score are broken by the edge's initial key.
-  auto hget = [&](int i) -> uint64_t { return i < AGG_LDS_HEAP ? hl[i] : w.heap_spill[i - AGG_LDS_HEAP]; };
-  auto hset = [&](int i, uint64_t v) { if (i < AGG_LDS_HEAP) hl[i] = v; else w.heap_spill[i - AGG_LDS_HEAP] = v; };
+  auto hget = [&](int i) -> uint64_t {
+    if constexpr (SPILL) return i < AGG_LDS_HEAP ? hl[i] : w.heap_spill[i - AGG_LDS_HEAP];
+    else return hl[i];
+  };
+  auto hset = [&](int i, uint64_t v) {
+    if constexpr (SPILL) { if (i < AGG_LDS_HEAP) hl[i] = v; else w.heap_spill[i - AGG_LDS_HEAP] = v; }
+    else hl[i] = v;
+  };
+  // low word of an entry: the edge's rank by initial key if the edges were ranked (agg_edge_rank_kernel), else the edge
+  const bool ranked = w.counters[7] != 0;
   auto less = [&](uint64_t a, uint64_t b) -> bool {
+    if (ranked) return a < b;
     const uint32_t sa = (uint32_t)(a >> 32), sb = (uint32_t)(b >> 32);
     if (sa != sb) return sa < sb;
     return w.ekey0[(uint32_t)a] < w.ekey0[(uint32_t)b];
   };
+  auto entry = [&](float sc, uint32_t e) -> uint64_t { return ((uint64_t)__float_as_uint(sc) << 32) | (ranked ? w.qnext[e] : e); };
   auto sift_down = [&](int i, uint64_t val) {
     for (;;) {
       const int c1 = 2 * i + 1, c2 = c1 + 1;
@@ -698,7 +731,7 @@ __global__ __launch_bounds__(64) void agg_merge_kernel(AggWs w, const AggThresho
     // initial queue: only edges below the largest threshold can ever be popped
     for (uint32_t e = 0; e < ne; ++e) {
       const float sc = agg_score(w.esum[e], w.ecnt[e]);
-      if (sc < tmax) hset(items++, ((uint64_t)__float_as_uint(sc) << 32) | e);
+      if (sc < tmax) hset(items++, entry(sc, e));
     }
     for (int i = items / 2 - 1; i >= 0; --i) sift_down(i, hget(i));  // Floyd heapify
   }
@@ -710,13 +743,13 @@ __global__ __launch_bounds__(64) void agg_merge_kernel(AggWs w, const AggThresho
         if (!(__uint_as_float((uint32_t)(top >> 32)) < thr)) break;
         --items;
         if (items > 0) sift_down(0, hget(items));
-        const uint32_t e = (uint32_t)top;
+        const uint32_t e = ranked ? w.iota[(uint32_t)top] : (uint32_t)top;
         const uint8_t fl = w.eflags[e];
         if (fl & 1) continue;
         if (fl & 2) {
           w.eflags[e] = fl & ~2;
           const float sc = agg_score(w.esum[e], w.ecnt[e]);
-          if (sc < tmax) push(((uint64_t)__float_as_uint(sc) << 32) | e);
+          if (sc < tmax) push(entry(sc, e));
           continue;
         }
         const uint32_t eu = w.eu[e], evv = w.ev[e];
@@ -794,6 +827,17 @@ __global__ __launch_bounds__(64) void agg_merge_kernel(AggWs w, const AggThresho
     }
     __syncthreads();
   }
+}
+
+__global__ __launch_bounds__(64) void agg_merge_kernel(AggWs w, const AggThresholds thr_arg, int nthr) {
+  __shared__ uint64_t hl[AGG_LDS_HEAP];
+  __shared__ int sh_dummy;
+  if (!xcd_claim(&w.counters[5], w.xcd_hint)) return;
+  if (w.counters[3]) return;
+  const uint32_t nn = w.counters[0];
+  const uint32_t ne = min(w.counters[1], w.edge_cap);
+  if (ne <= (uint32_t)AGG_LDS_HEAP) agg_merge_body<false>(w, thr_arg, nthr, hl, &sh_dummy, nn, ne);
+  else agg_merge_body<true>(w, thr_arg, nthr, hl, &sh_dummy, nn, ne);
 }
 
 __global__ void agg_relabel_kernel(const uint64_t* __restrict__ frags, size_t n, int nthr, AggWs w,
@@ -1836,6 +1880,12 @@ int bsmi_agglomerate_mean_u8(bsmi_seg* h, const uint8_t* affs_dev, const uint64_
   hipLaunchKernelGGL(agg_rank_kernel, dim3(1), dim3(1024), 0, s, g);
   hipLaunchKernelGGL(agg_edges_kernel<false>, dim3(grid), dim3(bs), 0, s, affs_dev, frags_dev, D, H, W, g);
   hipLaunchKernelGGL(agg_compact_kernel, dim3(grid), dim3(bs), 0, s, g);
+  {
+    static const bool attr_set = [] {
+      return hipFuncSetAttribute((const void*)agg_edge_rank_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(kRankMax * sizeof(uint64_t))) == hipSuccess;
+    }();
+    if (attr_set) hipLaunchKernelGGL(agg_edge_rank_kernel, dim3(1), dim3(1024), kRankMax * sizeof(uint64_t), s, g);
+  }
   hipLaunchKernelGGL(agg_merge_kernel, dim3(8), dim3(64), 0, s, g, thr, n_thresholds);
   hipLaunchKernelGGL(agg_relabel_kernel, dim3(grid), dim3(bs), 0, s, frags_dev, n, n_thresholds, g, segs_dev);
   BSMI_HIP(hipGetLastError());
