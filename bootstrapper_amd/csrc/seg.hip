@@ -596,8 +596,8 @@ __global__ void agg_compact_kernel(AggWs w) {
 // often, and looking the two keys up costs the single-lane loop two trips to L2 per comparison: 3.3 us per pop.  So the
 // edges are ranked by their key once, here (one workgroup, keys in LDS, rank = number of smaller keys), and the queue
 // entries carry the rank: a comparison is then one 64-bit compare.  Graphs of more than kRankMax edges keep the look-up.
-// erank = w.qnext, eofrank = w.iota (arrays the mean-agglomeration path does not use otherwise); counters[7] = ranks valid.
-constexpr uint32_t kRankMax = 16384;
+// erank = w.qnext (an array the mean-agglomeration path does not use otherwise); counters[7] = ranks valid.
+constexpr uint32_t kRankMax = AGG_LDS_HEAP;  // ranked <=> the merge loop's FAST form (queue, flags and ranks fit the LDS)
 __global__ __launch_bounds__(1024) void agg_edge_rank_kernel(AggWs w) {
   extern __shared__ uint64_t rank_keys[];
   if (w.counters[3]) return;
@@ -610,7 +610,6 @@ __global__ __launch_bounds__(1024) void agg_edge_rank_kernel(AggWs w) {
     uint32_t r = 0;
     for (uint32_t j = 0; j < ne; ++j) r += rank_keys[j] < k ? 1u : 0u;
     w.qnext[e] = r;
-    w.iota[r] = e;
   }
   if (threadIdx.x == 0) w.counters[7] = 1;
 }
@@ -645,36 +644,55 @@ struct AggThresholds {  // by value: no host-to-device copy per call
   float v[16];
 };
 
-// SPILL = false: the queue never holds more entries than there are edges, so with ne <= AGG_LDS_HEAP every access is a plain
-// LDS access.  (With the HBM overflow in the same expression the compiler selects between the two addresses and emits
-// FLAT loads, which cost the single-lane sift-down 0.25 us per level: 3 us per pop.)
-template <bool SPILL>
-__device__ __forceinline__ void agg_merge_body(const AggWs& w, const AggThresholds& thr_arg, int nthr, uint64_t* hl, int* sh_dummy_p,
-                                               uint32_t nn, uint32_t ne) {
+// FAST: the graph fits -- ne <= AGG_LDS_HEAP edges, ranked by agg_edge_rank_kernel.  The queue never holds more entries than
+// there are edges, so every queue access is a plain LDS access (with the HBM overflow in the same expression the compiler
+// selects between the two addresses and emits FLAT loads: 0.25 us per sift level, 3 us per pop); an entry carries
+// rank << 16 | edge below the score, so a pop needs no look-up; and the edge flags live in LDS.
+template <bool FAST>
+__device__ __forceinline__ void agg_merge_body(const AggWs& w, const AggThresholds& thr_arg, int nthr, uint64_t* hl, uint8_t* fl_lds,
+                                               int* sh_dummy_p, uint32_t nn, uint32_t ne) {
   const float* thresholds = thr_arg.v;
   int& sh_dummy = *sh_dummy_p;
+  if constexpr (FAST) {
+    for (uint32_t i = threadIdx.x; i < ne; i += 64) fl_lds[i] = 0;  // agg_compact_kernel left every flag at 0
+    __syncthreads();
+  }
+  auto fget = [&](uint32_t e) -> uint8_t {
+    if constexpr (FAST) return fl_lds[e];
+    else return w.eflags[e];
+  };
+  auto fset = [&](uint32_t e, uint8_t v) {
+    if constexpr (FAST) fl_lds[e] = v;
+    else w.eflags[e] = v;
+  };
   const int lane = threadIdx.x;
   int items = 0;  // meaningful on lane 0 only
   const float tmax = thresholds[nthr - 1];
   // entry: [63:32] float bits of the score (scores are >= 0: bit pattern order == value order),
   //        [31:0] edge index; ties on the score are broken by the edge's initial key.
   auto hget = [&](int i) -> uint64_t {
-    if constexpr (SPILL) return i < AGG_LDS_HEAP ? hl[i] : w.heap_spill[i - AGG_LDS_HEAP];
-    else return hl[i];
+    if constexpr (FAST) return hl[i];
+    else return i < AGG_LDS_HEAP ? hl[i] : w.heap_spill[i - AGG_LDS_HEAP];
   };
   auto hset = [&](int i, uint64_t v) {
-    if constexpr (SPILL) { if (i < AGG_LDS_HEAP) hl[i] = v; else w.heap_spill[i - AGG_LDS_HEAP] = v; }
-    else hl[i] = v;
+    if constexpr (FAST) hl[i] = v;
+    else { if (i < AGG_LDS_HEAP) hl[i] = v; else w.heap_spill[i - AGG_LDS_HEAP] = v; }
   };
-  // low word of an entry: the edge's rank by initial key if the edges were ranked (agg_edge_rank_kernel), else the edge
-  const bool ranked = w.counters[7] != 0;
+  // low word of an entry: FAST: rank by initial key << 16 | edge; else the edge, and ties look the keys up
   auto less = [&](uint64_t a, uint64_t b) -> bool {
-    if (ranked) return a < b;
+    if constexpr (FAST) return a < b;
     const uint32_t sa = (uint32_t)(a >> 32), sb = (uint32_t)(b >> 32);
     if (sa != sb) return sa < sb;
     return w.ekey0[(uint32_t)a] < w.ekey0[(uint32_t)b];
   };
-  auto entry = [&](float sc, uint32_t e) -> uint64_t { return ((uint64_t)__float_as_uint(sc) << 32) | (ranked ? w.qnext[e] : e); };
+  auto entry = [&](float sc, uint32_t e) -> uint64_t {
+    if constexpr (FAST) return ((uint64_t)__float_as_uint(sc) << 32) | ((uint64_t)w.qnext[e] << 16) | e;
+    else return ((uint64_t)__float_as_uint(sc) << 32) | e;
+  };
+  auto edge_of = [&](uint64_t top) -> uint32_t {
+    if constexpr (FAST) return (uint32_t)top & 0xffffu;
+    else return (uint32_t)top;
+  };
   auto sift_down = [&](int i, uint64_t val) {
     for (;;) {
       const int c1 = 2 * i + 1, c2 = c1 + 1;
@@ -743,11 +761,11 @@ __device__ __forceinline__ void agg_merge_body(const AggWs& w, const AggThreshol
         if (!(__uint_as_float((uint32_t)(top >> 32)) < thr)) break;
         --items;
         if (items > 0) sift_down(0, hget(items));
-        const uint32_t e = ranked ? w.iota[(uint32_t)top] : (uint32_t)top;
-        const uint8_t fl = w.eflags[e];
+        const uint32_t e = edge_of(top);
+        const uint8_t fl = fget(e);
         if (fl & 1) continue;
         if (fl & 2) {
-          w.eflags[e] = fl & ~2;
+          fset(e, fl & ~2);
           const float sc = agg_score(w.esum[e], w.ecnt[e]);
           if (sc < tmax) push(entry(sc, e));
           continue;
@@ -759,7 +777,7 @@ __device__ __forceinline__ void agg_merge_body(const AggWs& w, const AggThreshol
         uint32_t f = w.head[b];
         while (f != NOEDGE && !fail) {
           const uint32_t fu = w.eu[f], fv = w.ev[f], fnu = w.enextu[f], fnv = w.enextv[f];
-          const uint8_t ffl = w.eflags[f];
+          const uint8_t ffl = fget(f);
           const bool b_in_u = fu == b;
           const uint32_t nxt = b_in_u ? fnu : fnv;
           if (f != e && !(ffl & 1)) {
@@ -786,18 +804,18 @@ __device__ __forceinline__ void agg_merge_body(const AggWs& w, const AggThreshol
               const uint32_t g = w.hvals[gs];
               const unsigned long long sum_f = w.esum[f], sum_g = w.esum[g];
               const uint32_t cnt_f = w.ecnt[f], cnt_g = w.ecnt[g];
-              const uint8_t gfl = w.eflags[g];
+              const uint8_t gfl = fget(g);
               w.esum[g] = sum_g + sum_f;
               w.ecnt[g] = cnt_g + cnt_f;
-              w.eflags[g] = gfl | 2;
-              w.eflags[f] = ffl | 1;
+              fset(g, gfl | 2);
+              fset(f, ffl | 1);
             } else {
               // f becomes {a, nb}: b is replaced IN ITS SLOT so that nb's list keeps following
               // the link that belongs to nb's slot; f joins a's list through b's old slot
               const uint32_t ha = w.head[a];
               if (b_in_u) { w.eu[f] = a; w.enextu[f] = ha; } else { w.ev[f] = a; w.enextv[f] = ha; }
               w.head[a] = f;
-              w.eflags[f] = ffl | 2;
+              fset(f, ffl | 2);
               hput(gkey, f);
             }
           }
@@ -808,7 +826,7 @@ __device__ __forceinline__ void agg_merge_body(const AggWs& w, const AggThreshol
           const int64_t es = hfind(norm_key(eu, evv));
           if (es >= 0) w.hkeys[es] = HTOMB;
         }
-        w.eflags[e] |= 1;
+        fset(e, fget(e) | 1);
         w.parent[b] = a;
       }
       sh_dummy = items;
@@ -831,13 +849,15 @@ __device__ __forceinline__ void agg_merge_body(const AggWs& w, const AggThreshol
 
 __global__ __launch_bounds__(64) void agg_merge_kernel(AggWs w, const AggThresholds thr_arg, int nthr) {
   __shared__ uint64_t hl[AGG_LDS_HEAP];
+  __shared__ uint8_t fl_lds[AGG_LDS_HEAP];
   __shared__ int sh_dummy;
+  static_assert(AGG_LDS_HEAP <= 65536, "FAST entries hold 16-bit ranks and edges");
   if (!xcd_claim(&w.counters[5], w.xcd_hint)) return;
   if (w.counters[3]) return;
   const uint32_t nn = w.counters[0];
   const uint32_t ne = min(w.counters[1], w.edge_cap);
-  if (ne <= (uint32_t)AGG_LDS_HEAP) agg_merge_body<false>(w, thr_arg, nthr, hl, &sh_dummy, nn, ne);
-  else agg_merge_body<true>(w, thr_arg, nthr, hl, &sh_dummy, nn, ne);
+  if (ne <= (uint32_t)AGG_LDS_HEAP && w.counters[7] != 0) agg_merge_body<true>(w, thr_arg, nthr, hl, fl_lds, &sh_dummy, nn, ne);
+  else agg_merge_body<false>(w, thr_arg, nthr, hl, fl_lds, &sh_dummy, nn, ne);
 }
 
 __global__ void agg_relabel_kernel(const uint64_t* __restrict__ frags, size_t n, int nthr, AggWs w,
@@ -1884,7 +1904,9 @@ int bsmi_agglomerate_mean_u8(bsmi_seg* h, const uint8_t* affs_dev, const uint64_
     static const bool attr_set = [] {
       return hipFuncSetAttribute((const void*)agg_edge_rank_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(kRankMax * sizeof(uint64_t))) == hipSuccess;
     }();
-    if (attr_set) hipLaunchKernelGGL(agg_edge_rank_kernel, dim3(1), dim3(1024), kRankMax * sizeof(uint64_t), s, g);
+    // BSMI_AGG_FAST=0 (tests): leave the edges unranked, i.e. take the general form of the merge loop
+    static const bool fast = [] { const char* e = getenv("BSMI_AGG_FAST"); return !(e && e[0] == '0'); }();
+    if (attr_set && fast) hipLaunchKernelGGL(agg_edge_rank_kernel, dim3(1), dim3(1024), kRankMax * sizeof(uint64_t), s, g);
   }
   hipLaunchKernelGGL(agg_merge_kernel, dim3(8), dim3(64), 0, s, g, thr, n_thresholds);
   hipLaunchKernelGGL(agg_relabel_kernel, dim3(grid), dim3(bs), 0, s, frags_dev, n, n_thresholds, g, segs_dev);

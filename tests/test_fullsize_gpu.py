@@ -137,3 +137,14 @@ def test_conv_kernel_variants_in_subprocess(variant, env):
     r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(ROOT, "tests", "test_unet_gpu.py"), "-x", "-q"],
                        env=dict(os.environ, **env), capture_output=True, text=True, timeout=600, cwd=ROOT)
     assert r.returncode == 0, f"{variant}:\n" + r.stdout[-3000:] + r.stderr[-2000:]
+
+
+def test_merge_loop_general_form_in_subprocess():
+    """The merge loop has a FAST form for graphs that fit the LDS (every test graph does) and a general one (queue overflow
+    in HBM, tie look-ups, flags in HBM): run the segmentation parity module with the FAST form switched off."""
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(ROOT, "tests", "test_seg_gpu.py"), "-x", "-q"],
+                       env=dict(os.environ, BSMI_AGG_FAST="0"), capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(ROOT, "tests", "test_fullsize_gpu.py"), "-x", "-q", "-k", "seg or blockwise"],
+                       env=dict(os.environ, BSMI_AGG_FAST="0"), capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert r.returncode in (0, 5), r.stdout[-3000:] + r.stderr[-2000:]
