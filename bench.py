@@ -229,7 +229,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--precision", default="bf16", choices=["bf16", "f32"])
     ap.add_argument("--volume", type=int, default=1024, help="edge of the synthetic cubic volume")
-    ap.add_argument("--seg-lanes", type=int, default=18)
+    ap.add_argument("--seg-lanes", type=int, default=16)
     ap.add_argument("--pred-lanes", type=int, default=1, help="U-Net replicas / predict streams per GPU")
     ap.add_argument("--seg-cus", type=int, default=0, help="CUs reserved for the segmentation lanes (0: shared CUs)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
@@ -237,10 +237,10 @@ def main():
     ap.add_argument("--no-segment", action="store_true", help="predict only (diagnostic; not the headline metric)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--seg-stages", default="ws,agg", help="diagnostic: which segmentation stages the lanes run (ws, agg, or none: lane events only)")
-    ap.add_argument("--seg-burst", type=int, default=9,
-                    help="launch the segmentation of this many blocks together, on as many lanes, once the last of them is predicted\n"
-                         "(0: block by block).  The lanes then share the chip with the predict stream about half of the time\n"
-                         "instead of always: 9 blocks x 18 lanes measured best (more than 20 lanes run out of hardware queues)")
+    ap.add_argument("--seg-burst", type=int, default=16,
+                    help="launch the segmentation of this many blocks together, one per lane, once the last of them is predicted\n"
+                         "(0: block by block).  The lanes then share the chip with the predict stream a fifth of the time\n"
+                         "instead of always (more than 20 lanes run out of hardware queues)")
     args = ap.parse_args()
     if args.mode == "train":
         if "--steps" not in sys.argv:

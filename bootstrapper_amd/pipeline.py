@@ -92,9 +92,13 @@ class BlockPipeline:
             lane = self.lanes[i % len(self.lanes)] if self.segment else None
             pstream = self.pred_streams[i % len(self.models)]
             with torch.cuda.stream(pstream):
-                if lane is not None and lane["done"] is not None:
-                    # bound the run-ahead: a lane takes a new block only after its previous one
-                    pstream.wait_event(lane["done"])
+                if lane is not None:
+                    # bound the run-ahead: a lane's block is predicted only after the lane has finished its block before
+                    # last (bursts: the burst before last -- the last one is still being segmented while this one is
+                    # predicted) resp. its last block (block by block)
+                    gate = lane.get("done_before") if self.seg_burst else lane["done"]
+                    if gate is not None:
+                        pstream.wait_event(gate)
                 raw = extract_block_reflect(volume_u8, [o - c for o, c in zip(off, self.context)], self.in_block)
                 u8 = self.models[i % len(self.models)].predict_u8(raw)
                 ready = torch.cuda.Event()
@@ -130,6 +134,7 @@ class BlockPipeline:
                     t.record_stream(lane["stream"])
                 done = torch.cuda.Event()
                 done.record(lane["stream"])
+                lane["done_before"] = lane["done"]
                 lane["done"] = done
             if self.keep:
                 self.results.append((off, u8, frags, segs))
