@@ -801,7 +801,17 @@ static int launch_one(const ConvArgs& a, hipStream_t stream, float* sk_ws, int s
   if (sk_ws && sk_ok && sk_grid >= 8 && big_tile && ntiles % sk_grid != 0 && rounds <= 16 && (size_t)BM * BN <= kStreamKTileElems) {
     int* counters = (int*)(sk_ws + (size_t)sk_grid * kStreamKTileElems);
     hipLaunchKernelGGL(kern_sk, dim3(sk_grid), dim3(64 * WM * WN), smem, stream, a, sk_ws, counters);
-    hipLaunchKernelGGL((conv_fixup_kernel<T, BM, BN, WM, WN, MS>), dim3(sk_grid / 8, 8, (BM / WM / MS) * (BN / WN / MS)),
+    // fix-up grid: only as many tail tiles per XCD as the fullest XCD has (sk_geom's arithmetic); a (32, 8, fragments) grid
+    // dispatched thousands of workgroups that left at once, 75-99 us per launch
+    int max_rem = 0;
+    {
+      const int q = ntiles >> 3, r = ntiles & 7, per = sk_grid >> 3;
+      for (int x = 0; x < 8; ++x) {
+        const int count = q + (x < r ? 1 : 0);
+        max_rem = std::max(max_rem, count - count / per * per);
+      }
+    }
+    hipLaunchKernelGGL((conv_fixup_kernel<T, BM, BN, WM, WN, MS>), dim3(std::max(max_rem, 1), 8, (BM / WM / MS) * (BN / WN / MS)),
                        dim3(64 * WM * WN), 0, stream, a, (const float*)sk_ws, sk_grid, counters);
   } else {
     hipLaunchKernelGGL(kern, dim3(ntiles), dim3(64 * WM * WN), smem, stream, a);
