@@ -6,7 +6,7 @@ from collections import defaultdict
 
 rows = list(csv.DictReader(open(sys.argv[1])))
 print("columns:", list(rows[0].keys()))
-UNET = ("conv_igemm", "conv_rh", "conv_box", "conv_fixup", "first_pass", "maxpool", "upsample_crop", "head_kernel", "input_prep", "extract_block")
+UNET = ("conv_igemm", "conv_rh", "conv_box", "conv_fixup", "first_pass", "maxpool", "upsample", "head_kernel", "input_prep", "extract_block")
 ev = []
 for r in rows:
     name = r["Kernel_Name"]
