@@ -13,7 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("BSMI_LIB") or os.path.join(_HERE, "libbsmi.so")
 
 MAX_LEVELS, MAX_CONVS, MAX_HEADS, NAME_LEN = 8, 4, 4, 32
-PREC_F32, PREC_BF16 = 0, 1
+PREC_F32, PREC_BF16, PREC_BF16X3 = 0, 1, 2
 RAW_U8, RAW_F32, RAW_U8_UNIT = 0, 1, 2
 ERR_INVALID, ERR_HIP, ERR_STATE, ERR_MISSING, ERR_OVERFLOW = -1, -2, -3, -4, -5
 
@@ -71,6 +71,7 @@ def _load():
         "bsmi_unet_output_shape": (i32, [p, i64p, i64p]),
         "bsmi_unet_flops": (i32, [p, i64p, C.POINTER(C.c_double)]),
         "bsmi_unet_forward": (i32, [p, i32, vp, i32, i64p, C.POINTER(vp), C.POINTER(vp), vp]),
+        "bsmi_unet_debug_activation": (i32, [p, i32, i32, i64p, vp, C.c_uint64]),
         "bsmi_unet_profile_enable": (i32, [p, i32]),
         "bsmi_unet_profile_read": (i32, [p, i32, C.POINTER(i32), C.POINTER(C.c_int32), C.POINTER(C.c_double),
                                          C.POINTER(C.c_double)]),

@@ -45,6 +45,30 @@ struct Elem<bf16_elem> {
   }
 };
 
+// Element of a split-bf16 tensor (BSMI_PREC_BF16X3): the kernels multiply bf16 planes exactly as in the bf16 mode --
+// the host lists every logical K-step three times (hi x hi, lo x hi, hi x lo: unet_api.hip) -- and the epilogue
+// writes the f32 result as a (hi, lo) pair of planes: hi = bf16(v), lo = bf16(v - hi).
+struct bf16s_elem {
+  uint16_t v;
+};
+template <>
+struct Elem<bf16s_elem> {
+  static __device__ __forceinline__ f32x16_t mfma(u32x4_t a, u32x4_t b, f32x16_t acc) { return Elem<bf16_elem>::mfma(a, b, acc); }
+  static __device__ __forceinline__ void store(bf16s_elem* p, float v) {
+    __bf16 h = (__bf16)v;
+    p->v = __builtin_bit_cast(uint16_t, h);
+  }
+};
+template <typename T>
+struct IsSplit { static constexpr bool value = false; };
+template <>
+struct IsSplit<bf16s_elem> { static constexpr bool value = true; };
+// the lo plane's value: what the bf16 rounding of v (the hi plane) left over
+__device__ __forceinline__ float split_lo(float v) {
+  const __bf16 h = (__bf16)v;
+  return v - (float)h;
+}
+
 // 16-byte store of finished output rows.  Streaming (nt): the 0.1-0.2 GB a layer writes should not
 // compete for L2 with the panels the K-loops of the other workgroups are re-reading; measured
 // on the 128^3 block, the two largest layers 5.39 -> 5.15 ms and 4.82 -> 4.63 ms, sc1 and sc0 sc1 the
@@ -52,13 +76,16 @@ struct Elem<bf16_elem> {
 #ifndef BSMI_STORE_POLICY
 #define BSMI_STORE_POLICY 2
 #endif
+// The inline-asm forms end in s_nop 1: the compiler does not see an asm statement as a VMEM store, so it does not keep
+// the two wait states gfx950 needs between a store of more than 64 bits and a VALU write of its data registers
+// (observed: the address arithmetic of the next store landed in the upper half of the previous store's data).
 __device__ __forceinline__ void store_stream16(void* p, u32x4_t v) {
 #if BSMI_STORE_POLICY == 1
-  asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(p), "v"(v) : "memory");
+  asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(p), "v"(v) : "memory");
 #elif BSMI_STORE_POLICY == 2
-  asm volatile("global_store_dwordx4 %0, %1, off nt" ::"v"(p), "v"(v) : "memory");
+  __builtin_nontemporal_store(v, (u32x4_t*)p);  // global_store_dwordx4 ... nt
 #elif BSMI_STORE_POLICY == 3
-  asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(p), "v"(v) : "memory");
+  asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1\n\ts_nop 1" ::"v"(p), "v"(v) : "memory");
 #else
   *(u32x4_t*)p = v;
 #endif

@@ -44,6 +44,7 @@ struct ConvArgs {
   const void* w;      // device, packed [nsteps][Npad][64 bytes] (+ kWeightRowSlack rows)
   const float* bias;  // device [Npad]
   void* out;          // device [Do][Ho][Wo][Co]
+  int64_t out_lo;     // BSMI_PREC_BF16X3: byte offset of the output's lo plane behind `out` (the hi plane)
   int Do, Ho, Wo, Co;
   int M;     // Do*Ho*Wo
   int Npad;  // multiple of the tile's BN

@@ -268,8 +268,12 @@ __device__ __forceinline__ void conv_igemm_body(const ConvArgs& a, char* smem, i
   constexpr int CPR = WTN * ESZ / 16;         // 16-byte chunks per row
   constexpr int NCH = 16 * CPR;               // chunks per 16-row strip
   static_assert(NW * 16 * PITCH <= NSLOT * SLOT, "epilogue strips fit in the ring");
+  constexpr bool SPLIT = IsSplit<T>::value;  // (hi, lo) output planes: the lo values go through a second set of strips
+  constexpr int LO_STRIPS = NW * 16 * PITCH;
+  static_assert(!SPLIT || 2 * LO_STRIPS <= NSLOT * SLOT, "both strip sets fit in the ring");
   char* strip = smem + wave * (16 * PITCH);
   T* out = (T*)a.out;
+  T* out_lo = (T*)((char*)a.out + a.out_lo);
   float bv[FN];
 #pragma unroll
   for (int j = 0; j < FN; ++j) {
@@ -288,6 +292,7 @@ __device__ __forceinline__ void conv_igemm_body(const ConvArgs& a, char* smem, i
           float v = acc[i][j][hf * 8 + rr] + bv[j];
           if (a.relu) v = v > 0.f ? v : 0.f;
           Elem<T>::store((T*)(strip + row * PITCH) + j * 32 + lr, v);
+          if constexpr (SPLIT) Elem<T>::store((T*)(strip + LO_STRIPS + row * PITCH) + j * 32 + lr, split_lo(v));
         }
       }
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -299,7 +304,10 @@ __device__ __forceinline__ void conv_igemm_body(const ConvArgs& a, char* smem, i
         const u32x4_t v = *(const u32x4_t*)(strip + row * PITCH + cc * 16);
         const int m = m0 + wm * WTM + i * 32 + hf * 16 + row;
         const int n = n0 + wn * WTN + cc * (16 / ESZ);
-        if (m < a.M && n < a.Co) store_stream16(out + (size_t)m * a.Co + n, v);
+        if (m < a.M && n < a.Co) {
+          store_stream16(out + (size_t)m * a.Co + n, v);
+          if constexpr (SPLIT) store_stream16(out_lo + (size_t)m * a.Co + n, *(const u32x4_t*)(strip + LO_STRIPS + row * PITCH + cc * 16));
+        }
       }
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     }
@@ -321,14 +329,13 @@ __device__ __forceinline__ void conv_igemm_body(const ConvArgs& a, char* smem, i
 #endif
 }
 
-template <int BM, int BN, int WM, int WN, int B_INSTR, bool LATE>
+template <typename T, int BM, int BN, int WM, int WN, int B_INSTR, bool LATE>
 __device__ __forceinline__ void conv_igemm_body16(const ConvArgs& a, char* smem, int tile, int s0, int s1, float* part) {
   constexpr int NW = WM * WN;
   static_assert(NW == 4 || NW == 8, "one or two waves per SIMD");
   constexpr int ROWB = kStepRowBytes;
   constexpr int NSLOT = 4;
   constexpr int WTM = BM / WM, WTN = BN / WN;
-  using T = bf16_elem;
   constexpr int FM = WTM / 16, FN = WTN / 16;  // 16 x 16 accumulator fragments
   constexpr int NH0 = FN / 2, NH1 = FN - NH0;   // the two MFMA groups of a K-step split the B fragments
   constexpr int A_INSTR = BM / 16 / NW;  // LDS-DMA instructions per wave per K-step
@@ -540,8 +547,12 @@ __device__ __forceinline__ void conv_igemm_body16(const ConvArgs& a, char* smem,
   constexpr int CPR = WTN * ESZ / 16;         // 16-byte chunks per row
   constexpr int NCH = 16 * CPR;               // chunks per 16-row strip
   static_assert(NW * 16 * PITCH <= NSLOT * SLOT, "epilogue strips fit in the ring");
+  constexpr bool SPLIT = IsSplit<T>::value;  // (hi, lo) output planes: the lo values go through a second set of strips
+  constexpr int LO_STRIPS = NW * 16 * PITCH;
+  static_assert(!SPLIT || 2 * LO_STRIPS <= NSLOT * SLOT, "both strip sets fit in the ring");
   char* strip = smem + wave * (16 * PITCH);
   T* out = (T*)a.out;
+  T* out_lo = (T*)((char*)a.out + a.out_lo);
   float bv[FN];
 #pragma unroll
   for (int j = 0; j < FN; ++j) {
@@ -557,6 +568,7 @@ __device__ __forceinline__ void conv_igemm_body16(const ConvArgs& a, char* smem,
         float v = acc[i][j][r] + bv[j];
         if (a.relu) v = v > 0.f ? v : 0.f;
         Elem<T>::store((T*)(strip + (4 * lq + r) * PITCH) + j * 16 + lr, v);
+        if constexpr (SPLIT) Elem<T>::store((T*)(strip + LO_STRIPS + (4 * lq + r) * PITCH) + j * 16 + lr, split_lo(v));
       }
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -568,7 +580,10 @@ __device__ __forceinline__ void conv_igemm_body16(const ConvArgs& a, char* smem,
       const u32x4_t v = *(const u32x4_t*)(strip + row * PITCH + cc * 16);
       const int m = m0 + wm * WTM + i * 16 + row;
       const int n = n0 + wn * WTN + cc * (16 / ESZ);
-      if (m < a.M && n < a.Co) store_stream16(out + (size_t)m * a.Co + n, v);
+      if (m < a.M && n < a.Co) {
+        store_stream16(out + (size_t)m * a.Co + n, v);
+        if constexpr (SPLIT) store_stream16(out_lo + (size_t)m * a.Co + n, *(const u32x4_t*)(strip + LO_STRIPS + row * PITCH + cc * 16));
+      }
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   }
@@ -594,7 +609,7 @@ __device__ __forceinline__ void conv_igemm_body16(const ConvArgs& a, char* smem,
 // DVFS give-back item 7)
 template <typename T, int BM, int BN, int WM, int WN, int MS, int BI, bool LATE>
 __device__ __forceinline__ void conv_igemm_body_ms(const ConvArgs& a, char* smem, int tile, int s0, int s1, float* part) {
-  if constexpr (MS == 16) conv_igemm_body16<BM, BN, WM, WN, BI, LATE>(a, smem, tile, s0, s1, part);
+  if constexpr (MS == 16) conv_igemm_body16<T, BM, BN, WM, WN, BI, LATE>(a, smem, tile, s0, s1, part);
   else conv_igemm_body<T, BM, BN, WM, WN, BI, LATE>(a, smem, tile, s0, s1, part);
 }
 
@@ -734,6 +749,7 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_fixup_kernel(const ConvArgs
       float v = x[r] + bv;
       if (a.relu) v = v > 0.f ? v : 0.f;
       Elem<T>::store(out + (size_t)m * a.Co + n, v);
+      if constexpr (IsSplit<T>::value) Elem<T>::store((T*)((char*)a.out + a.out_lo) + (size_t)m * a.Co + n, split_lo(v));
     }
   }
 }
@@ -839,7 +855,7 @@ static int launch_cfg(const ConvArgs& a, TileCfg cfg, hipStream_t stream, float*
     case TILE_256x320: return launch_one<T, 256, 320, 4, 2>(a, stream, sk_ws, sk_grid);
     case TILE_256x256:
       if (two_waves_per_simd()) {
-        if constexpr (std::is_same<T, bf16_elem>::value)
+        if constexpr (!std::is_same<T, float>::value)
           if (mfma_16x16()) return launch_one<T, 256, 256, 4, 2, 16>(a, stream, sk_ws, sk_grid);
         return launch_one<T, 256, 256, 4, 2>(a, stream, sk_ws, sk_grid);
       }
@@ -853,6 +869,7 @@ int launch_conv_igemm(const ConvArgs& a, int precision, TileCfg cfg, hipStream_t
     BSMI_FAIL(BSMI_ERR_INVALID, "conv launch: bad geometry M=%d nsteps=%d Npad=%d", a.M, a.nsteps, a.Npad);
   if (precision == BSMI_PREC_F32) return launch_cfg<float>(a, cfg, stream, sk_ws, sk_grid);
   if (precision == BSMI_PREC_BF16) return launch_cfg<bf16_elem>(a, cfg, stream, sk_ws, sk_grid);
+  if (precision == BSMI_PREC_BF16X3) return launch_cfg<bf16s_elem>(a, cfg, stream, sk_ws, sk_grid);
   BSMI_FAIL(BSMI_ERR_INVALID, "unknown precision %d", precision);
 }
 

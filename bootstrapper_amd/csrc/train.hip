@@ -1249,13 +1249,15 @@ int bsmi_unet_train_end(bsmi_unet* h) {
       BSMI_HIP(hipMemcpy(h->weights[pr.key].data.data(), h->train->w + pr.off, pr.count * sizeof(float), hipMemcpyDeviceToHost));
     for (auto* sites : {&h->l_conv, &h->r_conv})
       for (PassSite& p : *sites)
-        for (int ci = 0; ci < p.nconv; ++ci) {
-          PackedConv& pc = p.packed[BSMI_PREC_BF16][ci];
-          if (pc.w) (void)hipFree(pc.w);
-          if (pc.bias) (void)hipFree(pc.bias);
-          pc = PackedConv();
-        }
+        for (int ci = 0; ci < p.nconv; ++ci)
+          for (int prec : {BSMI_PREC_BF16, BSMI_PREC_BF16X3}) {
+            PackedConv& pc = p.packed[prec][ci];
+            if (pc.w) (void)hipFree(pc.w);
+            if (pc.bias) (void)hipFree(pc.bias);
+            pc = PackedConv();
+          }
     h->finalized[BSMI_PREC_BF16] = false;
+    h->finalized[BSMI_PREC_BF16X3] = false;
   }
   if (!h) BSMI_FAIL(BSMI_ERR_INVALID, "null handle");
   BSMI_HIP(hipSetDevice(h->device));

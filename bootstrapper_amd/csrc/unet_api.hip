@@ -46,6 +46,13 @@ using namespace bsmi;
 namespace bsmi {
 
 int esize(int prec) { return prec == BSMI_PREC_F32 ? 4 : 2; }
+int ksplit(int prec) { return prec == BSMI_PREC_BF16X3 ? 3 : 1; }
+static inline float host_bf16_to_f32(uint16_t b) {
+  const uint32_t u = (uint32_t)b << 16;
+  float f;
+  memcpy(&f, &u, 4);
+  return f;
+}
 int bke(int prec) { return kStepRowBytes / esize(prec); }
 int sube(int prec) { return 32 / esize(prec); }
 
@@ -166,7 +173,10 @@ static int pack_conv(bsmi_unet* h, PassSite& p, int ci, int prec) {
   const int64_t cin_m = wm.shape[1], ntap_m = wm.shape[2] * wm.shape[3] * wm.shape[4];
   const int64_t cin_r = wr.shape[1];
   const int SUB = sube(prec);
-  const size_t nsteps = pc.entries.size() / kUnitsPerStep;
+  // Split mode: logical K-step s becomes the kernel's K-steps 3s (hi activations x hi weights), 3s + 1 (lo
+  // activations x hi weights) and 3s + 2 (hi activations x lo weights); the weight image carries a row block for each
+  const int KS = ksplit(prec);
+  const size_t nsteps = pc.entries.size() / kUnitsPerStep * KS;
   const size_t nelem = (nsteps * (size_t)pc.Npad + kWeightRowSlack) * BKE;  // slack rows: padded tile loads
   std::vector<float> bias(pc.Npad, 0.f);
   for (int n = 0; n < p.cout; ++n) bias[n] = bm.data[n] + (last ? br.data[n] : 0.f);
@@ -183,9 +193,20 @@ static int pack_conv(bsmi_unet* h, PassSite& p, int ci, int prec) {
         float v;
         if (e.wsrc == 0) v = wm.data[((size_t)n * cin_m + (e.cin_base + c)) * ntap_m + e.tap];
         else v = wr.data[(size_t)n * cin_r + (e.cin_base + c)];
-        const size_t idx = (s * pc.Npad + n) * BKE + j * SUB + kk;
-        if (prec == BSMI_PREC_F32) ((float*)packed.data())[idx] = v;
-        else ((uint16_t*)packed.data())[idx] = host_f32_to_bf16(v);
+        const size_t idx = (s * KS * pc.Npad + n) * BKE + j * SUB + kk;
+        if (prec == BSMI_PREC_F32) {
+          ((float*)packed.data())[idx] = v;
+        } else if (prec == BSMI_PREC_BF16) {
+          ((uint16_t*)packed.data())[idx] = host_f32_to_bf16(v);
+        } else {
+          const uint16_t hi = host_f32_to_bf16(v);
+          const uint16_t lo = host_f32_to_bf16(v - host_bf16_to_f32(hi));
+          uint16_t* w16 = (uint16_t*)packed.data();
+          const size_t blk = (size_t)pc.Npad * BKE;
+          w16[idx] = hi;
+          w16[idx + blk] = hi;
+          w16[idx + 2 * blk] = lo;
+        }
       }
     }
   }
@@ -205,7 +226,10 @@ struct Planner {
 
   int alloc(TDesc& t) {
     t.Cpad = round_up(t.C, kChanPad);
-    const size_t bytes = (size_t)t.D * t.H * t.W * t.Cpad * esize(prec);
+    const size_t plane = (size_t)t.D * t.H * t.W * t.Cpad * esize(prec);
+    const bool split = prec == BSMI_PREC_BF16X3;
+    t.lo_off = split ? plane : 0;  // (hi, lo) planes back to back: the lo plane is reached through the K-step byte offsets
+    const size_t bytes = split ? 2 * plane : plane;
     plan->bytes += bytes;
     if (bytes >= ((size_t)1 << 31))
       BSMI_FAIL(BSMI_ERR_INVALID, "activation tensor of %zu bytes exceeds the 31-bit byte offsets of the conv kernel", bytes);
@@ -231,7 +255,7 @@ struct Planner {
     const bool enabled = mode == 1 || (mode == 2 && tile_bn(st.tile) <= 64 && pc.entries.size() / kUnitsPerStep >= 200);
     const int* k = p.k[ci];
     const int Hin = o.H + k[1] - 1, Win = o.W + k[2] - 1;
-    if (!enabled || !two_waves_per_simd() || !rh_supported(st.tile, Win, k[1], k[2])) return BSMI_OK;
+    if (!enabled || prec == BSMI_PREC_BF16X3 || !two_waves_per_simd() || !rh_supported(st.tile, Win, k[1], k[2])) return BSMI_OK;
     const int64_t es = esize(prec);
     const int SUB = sube(prec);
     const size_t nsteps = pc.entries.size() / kUnitsPerStep;
@@ -500,7 +524,8 @@ struct Planner {
         st.tile = pc.tile;
         ConvArgs& a = st.conv;
         memset(&a, 0, sizeof a);
-        std::vector<KStep> ks(pc.entries.size() / kUnitsPerStep);
+        const int KS = ksplit(prec);
+        std::vector<KStep> ks(pc.entries.size() / kUnitsPerStep * KS);
         const int64_t es = esize(prec);
         for (int sl = 0; sl < kMaxConvTensors; ++sl) {
           const TDesc& t = slots[sl < nsl ? sl : 0];
@@ -509,7 +534,7 @@ struct Planner {
           a.t[sl].sy = (int32_t)((int64_t)t.W * t.Cpad * es);
           a.t[sl].sx = (int32_t)((int64_t)t.Cpad * es);
         }
-        for (size_t s = 0; s < ks.size(); ++s) {
+        for (size_t s = 0; s < ks.size() / KS; ++s) {
           const int slot = pc.entries[kUnitsPerStep * s].slot;
           const TDesc& t = slots[slot];
           KStep k;
@@ -522,7 +547,14 @@ struct Planner {
                                  (e.dx + so[slot][2])) * t.Cpad + e.c0;
             k.delta[j] = (int32_t)(off * es);
           }
-          ks[s] = k;
+          ks[s * KS] = k;
+          if (KS == 3) {
+            KStep lo = k;  // the same taps of the lo plane (a padding unit stays at offset 0: it meets zero weights)
+            for (int j = 0; j < kUnitsPerStep; ++j)
+              if (!pc.entries[kUnitsPerStep * s + j].dummy) lo.delta[j] = (int32_t)(k.delta[j] + (int64_t)t.lo_off);
+            ks[s * KS + 1] = lo;
+            ks[s * KS + 2] = k;
+          }
         }
         KStep* dks = nullptr;
         BSMI_HIP(hipMalloc((void**)&dks, ks.size() * sizeof(KStep)));
@@ -533,6 +565,7 @@ struct Planner {
         a.w = pc.w;
         a.bias = pc.bias;
         a.out = o.ptr;
+        a.out_lo = (int64_t)o.lo_off;
         a.Do = o.D; a.Ho = o.H; a.Wo = o.W; a.Co = o.Cpad;
         a.M = o.D * o.H * o.W;
         a.Npad = pc.Npad;
@@ -709,6 +742,7 @@ int get_plan(bsmi_unet* h, int precision, const int64_t in_shape[3], Plan** out)
   auto it = h->plans.find(key);
   if (it == h->plans.end()) {
     std::unique_ptr<Plan> plan(new Plan);
+    plan->prec = precision;
     Planner pl{h, precision, plan.get(), false};
     const int rc = pl.run(in_shape);
     if (rc) {
@@ -848,7 +882,7 @@ int bsmi_unet_destroy(bsmi_unet* h) {
   (void)hipSetDevice(h->device);
   for (auto& kv : h->plans) free_plan(kv.second.get());
   auto free_site = [](PassSite& p) {
-    for (int pr = 0; pr < 2; ++pr)
+    for (int pr = 0; pr < BSMI_NUM_PREC; ++pr)
       for (int c = 0; c < BSMI_MAX_CONVS; ++c) {
         if (p.packed[pr][c].w) (void)hipFree(p.packed[pr][c].w);
         if (p.packed[pr][c].bias) (void)hipFree(p.packed[pr][c].bias);
@@ -886,13 +920,13 @@ int bsmi_unet_load_weight(bsmi_unet* h, const char* key, const float* data, cons
   w.data.assign(data, data + n);
   w.loaded = true;
   // weights changed: packed copies are stale
-  for (int pr = 0; pr < 2; ++pr) h->finalized[pr] = false;
+  for (int pr = 0; pr < BSMI_NUM_PREC; ++pr) h->finalized[pr] = false;
   return BSMI_OK;
 }
 
 int bsmi_unet_finalize(bsmi_unet* h, int precision) {
   if (!h) BSMI_FAIL(BSMI_ERR_INVALID, "null handle");
-  if (precision != BSMI_PREC_F32 && precision != BSMI_PREC_BF16) BSMI_FAIL(BSMI_ERR_INVALID, "unknown precision %d", precision);
+  if (precision < 0 || precision >= BSMI_NUM_PREC) BSMI_FAIL(BSMI_ERR_INVALID, "unknown precision %d", precision);
   std::string missing;
   for (auto& kv : h->weights)
     if (!kv.second.loaded) missing += (missing.empty() ? "\"" : ", \"") + kv.first + "\"";
@@ -977,7 +1011,7 @@ int bsmi_unet_forward(bsmi_unet* h, int precision, const void* raw_dev, int raw_
                       const int64_t in_shape[3], float* const* out_f32_dev,
                       uint8_t* const* out_u8_dev, void* stream) {
   if (!h || !raw_dev || !in_shape) BSMI_FAIL(BSMI_ERR_INVALID, "null argument");
-  if (precision != BSMI_PREC_F32 && precision != BSMI_PREC_BF16) BSMI_FAIL(BSMI_ERR_INVALID, "unknown precision %d", precision);
+  if (precision < 0 || precision >= BSMI_NUM_PREC) BSMI_FAIL(BSMI_ERR_INVALID, "unknown precision %d", precision);
   if (raw_dtype != BSMI_RAW_U8 && raw_dtype != BSMI_RAW_F32 && raw_dtype != BSMI_RAW_U8_UNIT) BSMI_FAIL(BSMI_ERR_INVALID, "unknown raw dtype %d", raw_dtype);
   if (!h->finalized[precision]) BSMI_FAIL(BSMI_ERR_STATE, "bsmi_unet_finalize(precision=%d) has not been called", precision);
   int rc = check_shape_arg(in_shape);
@@ -1033,7 +1067,7 @@ int bsmi_unet_forward(bsmi_unet* h, int precision, const void* raw_dev, int raw_
     }
     switch (st.type) {
       case PlanStep::INPUT:
-        rc = launch_input_prep(precision, raw_dev, raw_dtype, st.out.ptr, st.out.C, st.out.Cpad,
+        rc = launch_input_prep(precision, raw_dev, raw_dtype, st.out.ptr, st.out.lo_off, st.out.C, st.out.Cpad,
                                (size_t)st.out.D * st.out.H * st.out.W, s);
         break;
       case PlanStep::CONV:
@@ -1042,11 +1076,11 @@ int bsmi_unet_forward(bsmi_unet* h, int precision, const void* raw_dev, int raw_
                          : launch_conv_igemm(st.conv, precision, st.tile, s, h->sk_ws, h->sk_grid);
         break;
       case PlanStep::POOL:
-        rc = launch_maxpool(precision, st.in.ptr, st.out.ptr, st.in.D, st.in.H, st.in.W, st.in.Cpad,
+        rc = launch_maxpool(precision, st.in.ptr, st.in.lo_off, st.out.ptr, st.out.lo_off, st.in.D, st.in.H, st.in.W, st.in.Cpad,
                             st.f[0], st.f[1], st.f[2], s);
         break;
       case PlanStep::UP:
-        rc = launch_upsample_crop(precision, st.in.ptr, st.out.ptr, st.in.D, st.in.H, st.in.W, st.in.Cpad,
+        rc = launch_upsample_crop(precision, st.in.ptr, st.in.lo_off, st.out.ptr, st.out.lo_off, st.in.D, st.in.H, st.in.W, st.in.Cpad,
                                   st.out.D, st.out.H, st.out.W, st.f[0], st.f[1], st.f[2], st.o[0], st.o[1], st.o[2], s);
         break;
       case PlanStep::HEAD: {
@@ -1054,7 +1088,7 @@ int bsmi_unet_forward(bsmi_unet* h, int precision, const void* raw_dev, int raw_
         float* of = out_f32_dev ? out_f32_dev[st.head] : nullptr;
         uint8_t* ou = out_u8_dev ? out_u8_dev[st.head] : nullptr;
         if (of || ou)
-          rc = launch_head(precision, st.in.ptr, st.in.Cpad, hd.cin, hd.cout, hd.hw, hd.hb, of, ou,
+          rc = launch_head(precision, st.in.ptr, st.in.lo_off, st.in.Cpad, hd.cin, hd.cout, hd.hw, hd.hb, of, ou,
                            (size_t)st.in.D * st.in.H * st.in.W, s);
         break;
       }
@@ -1063,6 +1097,40 @@ int bsmi_unet_forward(bsmi_unet* h, int precision, const void* raw_dev, int raw_
     if (h->profiling) BSMI_HIP(hipEventRecord(plan.events[2 * step_idx + 1], s));
     ++step_idx;
   }
+  return BSMI_OK;
+}
+
+int bsmi_unet_debug_activation(bsmi_unet* h, int step, int what, int64_t shape_out[4], float* host_out, uint64_t capacity) {
+  if (!h || !shape_out) BSMI_FAIL(BSMI_ERR_INVALID, "null argument");
+  Plan* plan = h->last_plan;
+  if (!plan) BSMI_FAIL(BSMI_ERR_STATE, "no forward has run");
+  if (step < 0 || step >= (int)plan->steps.size()) BSMI_FAIL(BSMI_ERR_INVALID, "step %d out of range (%zu steps)", step, plan->steps.size());
+  const PlanStep& st = plan->steps[step];
+  if (st.type == PlanStep::HEAD) BSMI_FAIL(BSMI_ERR_INVALID, "head steps write into the caller's buffers");
+  const TDesc& t = st.out;
+  shape_out[0] = t.D; shape_out[1] = t.H; shape_out[2] = t.W; shape_out[3] = t.C;
+  if (!host_out) return BSMI_OK;
+  const size_t nvox = (size_t)t.D * t.H * t.W;
+  if (capacity < nvox * t.C) BSMI_FAIL(BSMI_ERR_INVALID, "buffer of %llu floats too small", (unsigned long long)capacity);
+  BSMI_HIP(hipSetDevice(h->device));
+  BSMI_HIP(hipDeviceSynchronize());
+  const int es = esize(plan->prec);
+  const size_t plane = nvox * t.Cpad * es;
+  std::vector<uint8_t> raw(plane + t.lo_off);
+  BSMI_HIP(hipMemcpy(raw.data(), t.ptr, raw.size(), hipMemcpyDeviceToHost));
+  for (size_t v = 0; v < nvox; ++v)
+    for (int c = 0; c < t.C; ++c) {
+      const size_t i = v * t.Cpad + c;
+      float x;
+      if (plan->prec == BSMI_PREC_F32) {
+        x = ((const float*)raw.data())[i];
+      } else {
+        const float hi = host_bf16_to_f32(((const uint16_t*)raw.data())[i]);
+        const float lo = t.lo_off ? host_bf16_to_f32(((const uint16_t*)(raw.data() + t.lo_off))[i]) : 0.f;
+        x = what == 1 ? hi : (what == 2 ? lo : hi + lo);
+      }
+      host_out[v * t.C + c] = x;
+    }
   return BSMI_OK;
 }
 

@@ -56,7 +56,7 @@ struct PassSite {
   int cout = 0;
   int nconv = 0;
   int k[BSMI_MAX_CONVS][3];
-  PackedConv packed[2][BSMI_MAX_CONVS];
+  PackedConv packed[BSMI_NUM_PREC][BSMI_MAX_CONVS];
 };
 
 struct HeadSite {
@@ -69,6 +69,7 @@ struct HeadSite {
 struct TDesc {
   void* ptr = nullptr;
   int C = 0, Cpad = 0, D = 0, H = 0, W = 0;
+  size_t lo_off = 0;  // BSMI_PREC_BF16X3: byte offset of the lo plane behind the hi plane (0 otherwise)
 };
 
 struct PlanStep {
@@ -102,11 +103,13 @@ struct Plan {
   std::vector<hipEvent_t> events;  // 2 per step, created on demand (profiling)
   bool profiled = false;           // last forward recorded events
   bool fused_first = false;        // steps 0..2 (INPUT, CONV, CONV of l_conv.0) run as one first_pass launch
+  int prec = 0;                    // precision the plan was built for
 };
 
 struct TrainState;
 
-int esize(int prec);
+int esize(int prec);  // bytes of one stored element (per plane in the split mode)
+int ksplit(int prec); // K-steps the kernel walks per logical K-step (3 in the split-bf16 mode)
 int bke(int prec);   // elements per K-step row
 int sube(int prec);  // elements per 32-byte unit
 // unit list of stage `ci` of a ConvPass (see unet_api.hip)
@@ -124,7 +127,7 @@ struct bsmi_unet {
   std::vector<HeadSite> heads;
   int crop_factor[BSMI_MAX_LEVELS][3];
   std::map<std::string, HostWeight> weights;
-  bool finalized[2] = {false, false};
+  bool finalized[BSMI_NUM_PREC] = {false, false, false};
   bool profiling = false;
   Plan* last_plan = nullptr;
   double prof_ms[5] = {0, 0, 0, 0, 0}, prof_flops[5] = {0, 0, 0, 0, 0};

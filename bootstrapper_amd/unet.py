@@ -23,7 +23,9 @@ from ._lib import lib, check
 HEAD_OF_OUTPUT = {"3d_affs": "affs_head", "3d_lsds": "lsds_head", "2d_affs": "aff_head", "2d_lsds": "lsd_head"}
 
 PRECISIONS = {"f32": _lib.PREC_F32, "fp32": _lib.PREC_F32, "float32": _lib.PREC_F32,
-              "bf16": _lib.PREC_BF16, "bfloat16": _lib.PREC_BF16}
+              "bf16": _lib.PREC_BF16, "bfloat16": _lib.PREC_BF16,
+              # split bf16 (hi + lo operands, three MFMAs per product): the parity-grade fast mode
+              "bf16x3": _lib.PREC_BF16X3}
 
 
 def _tuplify(x):
@@ -209,6 +211,15 @@ class Model:
         check(lib.bsmi_unet_profile_totals(self._h, ms, fl, cnt, 1 if reset else 0))
         names = ["input", "conv", "pool", "upsample", "head"]
         return {names[i]: (ms[i], fl[i], cnt[i]) for i in range(5)}
+
+    def debug_activation(self, step, what=0):
+        """Development aid: output tensor of launch `step` of the last forward as a float32 (D, H, W, C) array
+        (what: 0 value, 1 / 2 the hi / lo plane of the split mode)."""
+        shape = (C.c_int64 * 4)()
+        check(lib.bsmi_unet_debug_activation(self._h, int(step), int(what), shape, None, 0))
+        out = np.empty(tuple(shape), dtype=np.float32)
+        check(lib.bsmi_unet_debug_activation(self._h, int(step), int(what), shape, out.ctypes.data_as(C.c_void_p), out.size))
+        return out
 
     # -- forward -----------------------------------------------------------------------
     def _run(self, raw, raw_dtype, in_shape, want_f32, want_u8):

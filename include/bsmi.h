@@ -36,6 +36,10 @@ extern "C" {
 /* arithmetic type of the U-Net contraction */
 #define BSMI_PREC_F32 0   /* f32 MFMA (exact f32 products, f32 accumulate): parity mode */
 #define BSMI_PREC_BF16 1  /* bf16 MFMA operands, f32 accumulate: throughput mode        */
+#define BSMI_PREC_BF16X3 2 /* split bf16: every f32 operand x = hi + lo (two bf16), products hi*hi + lo*hi + hi*lo
+                              on the bf16 MFMA, f32 accumulate; activations stored as (hi, lo) planes.  Within the
+                              1e-4 parity gate of the fp32 reference at 3 MFMAs per product                        */
+#define BSMI_NUM_PREC 3
 
 /* dtype of the raw input handed to bsmi_unet_forward */
 #define BSMI_RAW_U8 0     /* uint8 [Cin][D][H][W]; normalised on device as u8/255*2-1    */
@@ -165,6 +169,13 @@ int bsmi_unet_profile_read(bsmi_unet *h, int max_n, int *n, int32_t *types, doub
 /* totals over every profiled forward since the last reset, indexed by launch type */
 int bsmi_unet_profile_totals(bsmi_unet *h, double ms_by_type[5], double flops_by_type[5],
                              int64_t launches_by_type[5], int reset);
+
+/* Development aid: the output tensor of launch `step` of the last forward (launch order as in
+ * bsmi_unet_profile_read), as float32 channels-last [D][H][W][C] on the host, whatever the precision mode stores
+ * (f32, bf16, or the hi + lo planes of the split mode).  shape_out = {D, H, W, C}; host_out may be NULL to query
+ * the shape.  what: 0 = the value, 1 / 2 = only the hi / lo plane of the split mode.  Synchronises the device. */
+int bsmi_unet_debug_activation(bsmi_unet *h, int step, int what, int64_t shape_out[4], float *host_out,
+                               uint64_t capacity);
 
 /* Reflect-padded block extraction (gp.Pad(raw, None, mode="reflect") +
  * ArraySource ROI read, models/3d_affs/predict.py:145-148): copies the window

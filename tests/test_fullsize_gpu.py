@@ -26,23 +26,29 @@ def full_block():
     u8_b, f_b = m.predict_u8(raw, want_f32=True)
     m.set_precision("f32")
     u8_f, f_f = m.predict_u8(raw, want_f32=True)
+    m.set_precision("bf16x3")
+    u8_s, f_s = m.predict_u8(raw, want_f32=True)
+    u8_t, f_t = m.predict_u8(raw, want_f32=True)
     torch.cuda.synchronize()
-    return dict(bf16=(u8_a[0], f_a[0]), bf16_again=(u8_b[0], f_b[0]), f32=(u8_f[0], f_f[0]))
+    return dict(bf16=(u8_a[0], f_a[0]), bf16_again=(u8_b[0], f_b[0]), f32=(u8_f[0], f_f[0]),
+                bf16x3=(u8_s[0], f_s[0]), bf16x3_again=(u8_t[0], f_t[0]))
 
 
 def test_full_block_shapes_and_determinism(full_block):
     u8, f = full_block["bf16"]
     assert tuple(u8.shape) == (6, 128, 128, 128) and u8.dtype == torch.uint8
     assert torch.equal(u8, full_block["bf16_again"][0]) and torch.equal(f, full_block["bf16_again"][1])
+    assert torch.equal(full_block["bf16x3"][1], full_block["bf16x3_again"][1])
     # the synthetic weights give structured affinities (needed for a meaningful segmentation stage)
     assert 20 < float(u8.float().std()) < 90
 
 
 def test_full_block_vs_cpu_oracle(full_block):
     """The whole 3d_affs network on one BASELINE-size block against the CPU restatement (oracle/unet_ref.py, about
-    15 s on the box's cores): exact-f32 MFMA mode within the 1e-4 parity gate -- this is the test that sees the
-    persistent split-K launches, the 8-wave kernels and K up to 48 600 at their real sizes -- and the bf16
-    throughput mode within 1e-2 (measured 4.3e-3) of the same reference."""
+    15 s on the box's cores): exact-f32 MFMA mode and the split-bf16 mode (bf16x3, the benchmarked one) within the
+    1e-4 parity gate of the north star -- this is the test that sees the persistent split-K launches, the 8-wave
+    kernels and K up to 48 600 at their real sizes -- and the bf16 throughput mode within 6e-3 (measured 4.3e-3) of
+    the same reference."""
     from oracle import unet_ref as R
     from bootstrapper_amd.synth import synthetic_state_dict, synthetic_volume
     from tests.test_lib_cpu import AFFS_NET_CONFIG as NC
@@ -51,9 +57,15 @@ def test_full_block_vs_cpu_oracle(full_block):
     ref = torch.from_numpy(R.predict_block(R.default_cfg(12, 5), synthetic_state_dict(NC, 0), raw, ["affs_head"])[0])
     d32 = (full_block["f32"][1].cpu() - ref).abs()
     d16 = (full_block["bf16"][1].cpu() - ref).abs()
-    print("f32 vs oracle: max", float(d32.max()), "mean", float(d32.mean()), "| bf16 vs oracle: max", float(d16.max()), "mean", float(d16.mean()))
+    dx3 = (full_block["bf16x3"][1].cpu() - ref).abs()
+    print("f32 vs oracle: max", float(d32.max()), "mean", float(d32.mean()), "| bf16x3 vs oracle: max", float(dx3.max()), "mean",
+          float(dx3.mean()), "| bf16 vs oracle: max", float(d16.max()), "mean", float(d16.mean()))
     assert float(d32.max()) < 1e-4
-    assert float(d16.max()) < 1e-2 and float(d16.mean()) < 2e-3
+    assert float(dx3.max()) < 1e-4
+    assert float(d16.max()) < 6e-3 and float(d16.mean()) < 1e-3
+    # u8 outputs of the split mode: a 1e-5 float difference can flip the truncation at an integer boundary
+    dus = (full_block["bf16x3"][0].int() - full_block["f32"][0].int()).abs()
+    assert int(dus.max()) <= 1 and float((dus == 0).float().mean()) > 0.995
     du = (full_block["bf16"][0].int() - full_block["f32"][0].int()).abs()
     assert int(du.max()) <= 3 and float((du <= 1).float().mean()) > 0.95
 
