@@ -433,7 +433,8 @@ struct AggWs {
   uint32_t id_cap;
   uint64_t* ids;         // [node_cap] rank -> id
   uint32_t node_cap;
-  uint32_t* counters;    // [0]=nn, [1]=ne, [2]=heap_n, [3]=overflow flags
+  uint32_t* counters;    // [0]=nn, [1]=ne, [2]=heap_n, [3]=overflow flags of the call in flight (zeroed by every call)
+  uint32_t* sticky;      // [1] overflow flags of every call since the last bsmi_seg_status (the last kernel of a call ORs [3] in)
   // hash table over edges
   uint64_t* hkeys;       // [hcap]
   uint32_t* hvals;       // [hcap] -> edge index
@@ -462,6 +463,9 @@ struct AggWs {
   float* tscore;         // [2 * node_cap]
   uint32_t* cur;         // [node_cap] tree node of a cluster root
   uint32_t* ha; uint32_t* hb;  // [node_cap] merge history (ranks)
+  float* escore;         // [edge_cap] stored score: the score at the edge's last (re)scoring = its place in the queue
+  uint32_t* etime;       // [edge_cap] RAG path: merge clock at the edge's last scoring
+  uint32_t* ntime;       // [node_cap] RAG path: merge clock when the node last survived a merge (edges scored before are stale)
   int xcd_hint;          // XCD the sequential merge loop of this workspace should run on (see xcd_claim)
   // label table (bs refine): per id-hash slot
   unsigned long long* tcount;  // [icap]
@@ -639,7 +643,12 @@ __device__ __forceinline__ bool xcd_claim(uint32_t* claim, int target) {
   return sh_run != 0;
 }
 
-// One wave per volume; lane 0 replays the sequential merge loop of oracle/seg_ref.c.
+// One wave per volume; lane 0 replays the sequential merge loop of oracle/seg_ref.c (waterz mergeUntil / mergeRegions:
+// on a shared neighbour the dearer of the two parallel edges, by STORED score, is merged into the cheaper one, which
+// keeps its place in the queue).  mergeRegions also marks every edge incident to the survivor stale; with this queue --
+// a total order on (stored score, initial key) -- rescoring an edge whose sums did not change puts it back exactly
+// where it was, so that marking cannot be observed and is not replayed here (the bin queue of rag_merge_kernel, where
+// a re-insertion moves the edge to the back of its bin, does replay it).
 struct AggThresholds {  // by value: no host-to-device copy per call
   float v[16];
 };
@@ -749,6 +758,7 @@ __device__ __forceinline__ void agg_merge_body(const AggWs& w, const AggThreshol
     // initial queue: only edges below the largest threshold can ever be popped
     for (uint32_t e = 0; e < ne; ++e) {
       const float sc = agg_score(w.esum[e], w.ecnt[e]);
+      w.escore[e] = sc;
       if (sc < tmax) hset(items++, entry(sc, e));
     }
     for (int i = items / 2 - 1; i >= 0; --i) sift_down(i, hget(i));  // Floyd heapify
@@ -767,6 +777,7 @@ __device__ __forceinline__ void agg_merge_body(const AggWs& w, const AggThreshol
         if (fl & 2) {
           fset(e, fl & ~2);
           const float sc = agg_score(w.esum[e], w.ecnt[e]);
+          w.escore[e] = sc;
           if (sc < tmax) push(entry(sc, e));
           continue;
         }
@@ -800,23 +811,34 @@ __device__ __forceinline__ void agg_merge_body(const AggWs& w, const AggThreshol
               sg = (sg + 1) & (w.hcap - 1);
               kg = sg == (uint32_t)fs ? HTOMB : w.hkeys[sg];
             }
+            bool move_f = true;  // f becomes {a, nb}
             if (gs >= 0) {
               const uint32_t g = w.hvals[gs];
               const unsigned long long sum_f = w.esum[f], sum_g = w.esum[g];
               const uint32_t cnt_f = w.ecnt[f], cnt_g = w.ecnt[g];
+              const float st_f = w.escore[f], st_g = w.escore[g];
               const uint8_t gfl = fget(g);
-              w.esum[g] = sum_g + sum_f;
-              w.ecnt[g] = cnt_g + cnt_f;
-              fset(g, gfl | 2);
-              fset(f, ffl | 1);
-            } else {
-              // f becomes {a, nb}: b is replaced IN ITS SLOT so that nb's list keeps following
-              // the link that belongs to nb's slot; f joins a's list through b's old slot
+              if (st_f > st_g) {  // the a-side edge is the cheaper one: it takes f's sums and keeps its place
+                w.esum[g] = sum_g + sum_f;
+                w.ecnt[g] = cnt_g + cnt_f;
+                fset(g, gfl | 2);
+                fset(f, ffl | 1);
+                move_f = false;
+              } else {            // f is the cheaper one (or ties): it takes g's sums and g's slot in the edge table
+                w.esum[f] = sum_f + sum_g;
+                w.ecnt[f] = cnt_f + cnt_g;
+                fset(g, gfl | 1);
+                w.hvals[gs] = f;
+              }
+            }
+            if (move_f) {
+              // b is replaced IN ITS SLOT so that nb's list keeps following the link that belongs to nb's slot;
+              // f joins a's list through b's old slot
               const uint32_t ha = w.head[a];
               if (b_in_u) { w.eu[f] = a; w.enextu[f] = ha; } else { w.ev[f] = a; w.enextv[f] = ha; }
               w.head[a] = f;
               fset(f, ffl | 2);
-              hput(gkey, f);
+              if (gs < 0) hput(gkey, f);
             }
           }
           f = nxt;
@@ -860,8 +882,18 @@ __global__ __launch_bounds__(64) void agg_merge_kernel(AggWs w, const AggThresho
   else agg_merge_body<false>(w, thr_arg, nthr, hl, fl_lds, &sh_dummy, nn, ne);
 }
 
+// Last kernel of a call: an overflow of this call outlives the next call's reset of counters[3] (a pipeline that checks
+// bsmi_seg_status once per lane after many blocks must still see it).
+__device__ __forceinline__ void keep_overflow(const AggWs& w) {
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    const uint32_t f = w.counters[3];
+    if (f) atomicOr(w.sticky, f);
+  }
+}
+
 __global__ void agg_relabel_kernel(const uint64_t* __restrict__ frags, size_t n, int nthr, AggWs w,
                                    uint64_t* __restrict__ segs) {
+  keep_overflow(w);
   if (w.counters[3]) return;
   for (size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x; p < n; p += (size_t)gridDim.x * blockDim.x) {
     const uint64_t f = frags[p];
@@ -919,6 +951,7 @@ __global__ void rag_rank_kernel(AggWs w) {
     w.parent[r] = r;
     w.cur[r] = r;
     w.tnext[r] = NOEDGE;
+    w.ntime[r] = 0;
   }
 }
 
@@ -974,7 +1007,9 @@ __device__ __forceinline__ uint64_t agg_norm_key(uint32_t x, uint32_t y) {
   return x < y ? (((uint64_t)x << 32) | y) : (((uint64_t)y << 32) | x);
 }
 
-// contract live edge e: b = larger endpoint is absorbed by a (same rewiring as agg_merge_kernel)
+// contract live edge e: b = larger endpoint is absorbed by a (same rewiring as agg_merge_kernel).  Staleness in this path
+// is a clock comparison (rag_merge_kernel), so nothing is flagged here: every edge that ends up incident to a is stale
+// because a's clock moves.
 __device__ __forceinline__ bool agg_contract(const AggWs& w, uint32_t e, uint32_t& a_out, uint32_t& b_out) {
   const uint32_t eu = w.eu[e], evv = w.ev[e];
   const uint32_t a = eu < evv ? eu : evv, b = eu < evv ? evv : eu;
@@ -989,17 +1024,25 @@ __device__ __forceinline__ bool agg_contract(const AggWs& w, uint32_t e, uint32_
       const int64_t fs = agg_hfind(w, agg_norm_key(fu, fv));
       if (fs >= 0) w.hkeys[fs] = HTOMB;
       const int64_t gs = agg_hfind(w, gkey);
+      bool move_f = true;
       if (gs >= 0) {
         const uint32_t g = w.hvals[gs];
-        w.esum[g] += w.esum[f];
-        w.ecnt[g] += w.ecnt[f];
-        w.eflags[g] |= 2;
-        w.eflags[f] |= 1;
-      } else {
+        if (w.escore[f] > w.escore[g]) {
+          w.esum[g] += w.esum[f];
+          w.ecnt[g] += w.ecnt[f];
+          w.eflags[f] |= 1;
+          move_f = false;
+        } else {
+          w.esum[f] += w.esum[g];
+          w.ecnt[f] += w.ecnt[g];
+          w.eflags[g] |= 1;
+          w.hvals[gs] = f;
+        }
+      }
+      if (move_f) {
         if (b_in_u) { w.eu[f] = a; w.enextu[f] = w.head[a]; } else { w.ev[f] = a; w.enextv[f] = w.head[a]; }
         w.head[a] = f;
-        w.eflags[f] |= 2;
-        if (!agg_hput(w, gkey, f)) return false;
+        if (gs < 0 && !agg_hput(w, gkey, f)) return false;
       }
     }
     f = nxt;
@@ -1037,24 +1080,32 @@ __global__ __launch_bounds__(64) void rag_merge_kernel(AggWs w, float threshold,
   };
   for (uint32_t e = 0; e < ne; ++e) {
     const float sc = agg_score(w.esum[e], w.ecnt[e]);
+    w.escore[e] = sc;
+    w.etime[e] = 0;
     if (sc < threshold) push(e, sc);
   }
-  uint32_t nm = 0;
+  // mergeRegions marks every edge incident to the survivor stale -- its own, the moved and the merged ones alike.
+  // That is a clock: a merge stamps its survivor (ntime), scoring stamps the edge (etime), and an edge is stale when
+  // one of its endpoints was stamped after it.
+  uint32_t nm = 0, clock = 0;
   for (;;) {
     while (minbin < nbins && bhead[minbin] == NOEDGE) ++minbin;
     if (minbin >= nbins) break;
     const uint32_t e = bhead[minbin];
     bhead[minbin] = w.qnext[e];
-    const uint8_t fl = w.eflags[e];
-    if (fl & 1) continue;
-    const float sc = agg_score(w.esum[e], w.ecnt[e]);
-    if (fl & 2) {
-      w.eflags[e] = fl & ~2;
+    if (w.eflags[e] & 1) continue;
+    const uint32_t tu = w.ntime[w.eu[e]], tv = w.ntime[w.ev[e]];
+    if (w.etime[e] < (tu > tv ? tu : tv)) {
+      const float sc = agg_score(w.esum[e], w.ecnt[e]);
+      w.escore[e] = sc;
+      w.etime[e] = clock;
       if (sc < threshold) push(e, sc);
       continue;
     }
+    const float sc = w.escore[e];
     uint32_t a, b;
     if (!agg_contract(w, e, a, b)) { atomicOr(&w.counters[3], 16u); break; }
+    w.ntime[a] = ++clock;
     const uint32_t t = nn + nm;
     w.tnext[w.cur[a]] = t;
     w.tnext[w.cur[b]] = t;
@@ -1072,12 +1123,13 @@ __global__ __launch_bounds__(64) void rag_merge_kernel(AggWs w, float threshold,
 // are numbered in creation order, so the smaller index is always the one to climb)
 __global__ void rag_scores_kernel(AggWs w, uint64_t* __restrict__ edges, float* __restrict__ scores, uint64_t cap,
                                   uint64_t* __restrict__ merges, float* __restrict__ mscores, uint64_t* __restrict__ counts) {
+  keep_overflow(w);
   if (w.counters[3]) return;
   const uint32_t nn = w.counters[0];
   const uint32_t ne = min(w.counters[1], w.edge_cap);
   const uint32_t nm = w.counters[4];
   if (ne > cap) {
-    if (blockIdx.x == 0 && threadIdx.x == 0) atomicOr(&w.counters[3], 32u);
+    if (blockIdx.x == 0 && threadIdx.x == 0) { atomicOr(&w.counters[3], 32u); atomicOr(w.sticky, 32u); }
     return;
   }
   if (blockIdx.x == 0 && threadIdx.x == 0) { counts[0] = ne; counts[1] = nm; counts[2] = nn; }
@@ -1395,10 +1447,11 @@ __global__ void ltab_pad_kernel(AggWs w) {
 
 __global__ void ltab_gather_kernel(AggWs w, uint64_t* __restrict__ ids, uint64_t* __restrict__ counts, int32_t* __restrict__ zmin,
                                    int32_t* __restrict__ zmax, uint64_t cap, uint64_t* __restrict__ n_out) {
+  keep_overflow(w);
   if (w.counters[3]) return;
   const uint32_t nn = w.counters[0];
   if (nn > cap) {
-    if (blockIdx.x == 0 && threadIdx.x == 0) atomicOr(&w.counters[3], 32u);
+    if (blockIdx.x == 0 && threadIdx.x == 0) { atomicOr(&w.counters[3], 32u); atomicOr(w.sticky, 32u); }
     return;
   }
   if (blockIdx.x == 0 && threadIdx.x == 0) *n_out = nn;
@@ -1750,6 +1803,8 @@ int bsmi_seg_create(int device, const int64_t max_shape[3], bsmi_seg** out) {
   A(g.enextv, (size_t)g.edge_cap); A(g.eflags, (size_t)g.edge_cap);
   A(g.head, (size_t)g.node_cap); A(g.parent, (size_t)g.node_cap);
   A(g.roots, (size_t)g.node_cap * kMaxThresholds); A(g.heap_spill, (size_t)g.edge_cap); A(g.maxid, 1);
+  A(g.sticky, 1);
+  A(g.escore, (size_t)g.edge_cap); A(g.etime, (size_t)g.edge_cap); A(g.ntime, (size_t)g.node_cap);
   A(h->thr_dev, kMaxThresholds); A(h->status_dev, 4);
   FragWs& f = h->frag;
   f.id_cap = (uint32_t)std::min<size_t>(nv + 2, (size_t)1 << 27);
@@ -1783,6 +1838,7 @@ int bsmi_seg_create(int device, const int64_t max_shape[3], bsmi_seg** out) {
     return rc;
   }
   BSMI_HIP(hipMemset(g.counters, 0, 8 * sizeof(uint32_t)));
+  BSMI_HIP(hipMemset(g.sticky, 0, sizeof(uint32_t)));
   BSMI_HIP(hipMemset(h->frag.flags, 0, 4 * sizeof(uint32_t)));
   *out = h;
   return BSMI_OK;
@@ -2115,14 +2171,18 @@ int bsmi_label_table_u64(bsmi_seg* h, const uint64_t* labels_dev, const int64_t 
 int bsmi_seg_status(bsmi_seg* h, void* stream) {
   if (!h) BSMI_FAIL(BSMI_ERR_INVALID, "null handle");
   BSMI_HIP(hipSetDevice(h->device));
-  uint32_t c[8];
+  uint32_t c[8], sticky = 0;
   BSMI_HIP(hipMemcpyAsync(c, h->agg.counters, sizeof c, hipMemcpyDeviceToHost, (hipStream_t)stream));
+  BSMI_HIP(hipMemcpyAsync(&sticky, h->agg.sticky, sizeof sticky, hipMemcpyDeviceToHost, (hipStream_t)stream));
   BSMI_HIP(hipStreamSynchronize((hipStream_t)stream));
   uint32_t ff[4];
   BSMI_HIP(hipMemcpy(ff, h->frag.flags, sizeof ff, hipMemcpyDeviceToHost));
   if (ff[0]) BSMI_FAIL(BSMI_ERR_OVERFLOW, "fragment id exceeds the post-processing table (ids must stay below %u)", h->frag.id_cap);
-  if (c[3])
-    BSMI_FAIL(BSMI_ERR_OVERFLOW, "agglomeration workspace overflow (flags 0x%x: 1 id range, 2 nodes, 4 hash, 8 edges, 16 hash churn, 32 edge buffer too small)", c[3]);
+  // counters[3]: the last call; sticky: every call on this handle since the previous status check (cleared here)
+  const uint32_t flags = c[3] | sticky;
+  if (sticky) BSMI_HIP(hipMemsetAsync(h->agg.sticky, 0, sizeof(uint32_t), (hipStream_t)stream));
+  if (flags)
+    BSMI_FAIL(BSMI_ERR_OVERFLOW, "agglomeration workspace overflow (flags 0x%x: 1 id range, 2 nodes, 4 hash, 8 edges, 16 hash churn, 32 edge buffer too small)", flags);
   return BSMI_OK;
 }
 

@@ -269,8 +269,9 @@ int bsmi_label_table_u64(bsmi_seg *h, const uint64_t *labels_dev, const int64_t 
                          uint64_t *ids_dev, uint64_t *counts_dev, int32_t *zmin_dev, int32_t *zmax_dev,
                          uint64_t capacity, uint64_t *n_dev, void *stream);
 
-/* status of the last asynchronous seg call on this handle (reads a device flag;
- * synchronises `stream`): BSMI_OK or BSMI_ERR_OVERFLOW */
+/* status of the asynchronous seg calls on this handle since the previous bsmi_seg_status (an overflow of any of
+ * them is remembered on the device until it is read here; synchronises `stream`): BSMI_OK or BSMI_ERR_OVERFLOW.
+ * After an overflow the outputs of that call are undefined. */
 int bsmi_seg_status(bsmi_seg *h, void *stream);
 
 #ifdef __cplusplus

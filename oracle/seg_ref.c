@@ -280,23 +280,33 @@ int seg_ws_fragments_u8(const uint8_t *affs, int D, int H, int W, int fragments_
 }
 
 /* ---- mean-affinity hierarchical agglomeration (waterz restatement; parity unpinned) ---- */
-/* Specification (also the contract of the HIP kernels):
+/* waterz (ZettaAI/waterz, unpinned git dependency of the reference, not in /root/reference) cannot be read or run
+ * here.  This restates its published algorithm -- IterativeRegionMerging::mergeUntil / mergeRegions with the
+ * MeanAffinity provider and OneMinus -- as far as it is specified; what it leaves to its containers is fixed below
+ * and listed in DESIGN.md section 2.  It is also the contract of the HIP kernels.
  *  nodes   = distinct non-zero fragment ids.
  *  edges   = unordered pairs {u < v} of nodes that are 6-adjacent somewhere; each adjacent
  *            voxel pair (p, p - e_d), d in {z,y,x}, contributes affinity affs[d][p]
  *            (channel d at the higher-index voxel) to (sum, count) of its edge.
  *  score   = 1.0f - (float)((double)sum / (255.0 * count))          (OneMinus<MeanAffinity>)
- *  queue   = min-queue over the total order (score, key0) where key0 = (u0 << 32 | v0) packs
- *            the edge's INITIAL endpoints as ranks in the sorted node list.  Every edge sits
- *            in the queue exactly once with the score it had when it was (re)inserted.
- *  for each threshold t (ascending), continuing from the previous state:
- *    while queue not empty and top.score < t:
- *      pop e; if e deleted: continue
- *      if e stale: stale = false; reinsert with fresh score; continue
- *      merge: a = min(u,v), b = max(u,v) of e's current endpoints; b is absorbed by a
+ *  stored  = the score an edge had when it was last (re)scored: its position in the queue.
+ *  queue   = min-queue over the total order (stored score, key0) where key0 = (u0 << 32 | v0) packs
+ *            the edge's INITIAL endpoints as ranks in the sorted node list (seg_agglomerate_mean_u8), or
+ *            discretize_queue = N FIFO bins, bin = (int)(stored * (N - 1)) (seg_rag_merge_scores_u8).
+ *  mergeUntil(t), for each threshold t (ascending), continuing from the previous state:
+ *    while queue not empty:
+ *      e = top; if stored(e) >= t: break            (the STORED score of the popped edge decides)
+ *      pop; if e deleted: continue
+ *      if e stale: stale = false; rescore (stored = fresh score), reinsert; continue
+ *      mergeRegions(e): a = min(u,v), b = max(u,v) of e's current endpoints; b is absorbed by a
+ *        every live edge incident to a becomes stale
  *        for every live edge f != e incident to b with other endpoint n:
- *          if a live edge g = {a, n} exists: g.sum += f.sum; g.count += f.count; delete f; g stale
- *          else: f becomes {a, n}; f stale
+ *          if no live edge {a, n} exists: f becomes {a, n}; f stale                 (exclusive neighbour)
+ *          else g = {a, n}:                                                          (shared neighbour)
+ *            if stored(f) > stored(g): g.sum += f.sum; g.count += f.count; delete f; g stale
+ *            else:                     f.sum += g.sum; f.count += g.count; delete g; f becomes {a, n}; f stale
+ *            (the dearer edge is merged into the cheaper one, which keeps its place in the queue: a stale
+ *             edge therefore never waits behind a score larger than its true one)
  *        delete e; parent[b] = a
  *    seg_t[p] = id of root(frag[p])   (0 stays 0)
  */
@@ -307,6 +317,7 @@ typedef struct {
   uint64_t sum;
   uint32_t cnt;
   uint8_t deleted, stale;
+  float stored;       /* score at the last (re)scoring */
 } edge_t;
 
 static __thread edge_t *g_edges; /* per-thread: the cpu_baseline leg runs one volume per core */
@@ -330,6 +341,57 @@ static void hm_put(hmap *m, uint64_t k, uint32_t v) { uint64_t i = hmix(k) & (m-
 static void hm_del(hmap *m, uint64_t k) { int64_t i = hm_find(m, k); if (i >= 0) m->keys[i] = HTOMB; }
 
 static int cmp_u64(const void *a, const void *b) { uint64_t x = *(const uint64_t *)a, y = *(const uint64_t *)b; return x < y ? -1 : x > y; }
+
+/* per-node growable lists of edge ids (entries of deleted or moved-away edges stay and are skipped) */
+typedef struct { uint32_t **adj; uint32_t *adjn, *adjc; } adj_t;
+static void adj_push(adj_t *A, uint32_t node, uint32_t e) {
+  if (A->adjn[node] == A->adjc[node]) {
+    A->adjc[node] = A->adjc[node] ? 2 * A->adjc[node] : 4;
+    A->adj[node] = (uint32_t *)realloc(A->adj[node], 4 * A->adjc[node]);
+  }
+  A->adj[node][A->adjn[node]++] = e;
+}
+
+/* IterativeRegionMerging::mergeRegions restated (see the specification above).  em: live edges by current key. */
+static void merge_regions(edge_t *E, uint32_t ei, hmap *em, adj_t *A, uint32_t *a_out, uint32_t *b_out) {
+  edge_t *e = &E[ei];
+  const uint32_t a = e->u < e->v ? e->u : e->v, b = e->u < e->v ? e->v : e->u;
+  for (uint32_t k = 0; k < A->adjn[a]; k++) {
+    edge_t *g = &E[A->adj[a][k]];
+    if (!g->deleted && (g->u == a || g->v == a)) g->stale = 1;
+  }
+  for (uint32_t k = 0; k < A->adjn[b]; k++) {
+    const uint32_t fi = A->adj[b][k];
+    edge_t *f = &E[fi];
+    if (fi == ei || f->deleted) continue;
+    if (f->u != b && f->v != b) continue; /* moved away earlier (cannot happen: b only dies once) */
+    const uint32_t nb = f->u == b ? f->v : f->u;
+    const uint32_t gu = a < nb ? a : nb, gv = a < nb ? nb : a;
+    const uint64_t gkey = ((uint64_t)gu << 32) | gv;
+    const uint64_t fkey = ((uint64_t)(f->u) << 32) | f->v;
+    const int64_t s = hm_find(em, gkey);
+    hm_del(em, fkey);
+    if (s >= 0 && f->stored > E[em->vals[s]].stored) {
+      edge_t *g = &E[em->vals[s]];
+      g->sum += f->sum; g->cnt += f->cnt; g->stale = 1;
+      f->deleted = 1;
+      continue;
+    }
+    if (s >= 0) {
+      edge_t *g = &E[em->vals[s]];
+      f->sum += g->sum; f->cnt += g->cnt;
+      g->deleted = 1;
+      hm_del(em, gkey);
+    }
+    f->u = gu; f->v = gv; f->stale = 1;
+    hm_put(em, gkey, fi);
+    adj_push(A, a, fi);
+  }
+  hm_del(em, ((uint64_t)e->u << 32) | e->v);
+  e->deleted = 1;
+  *a_out = a;
+  *b_out = b;
+}
 
 int seg_agglomerate_mean_u8(const uint8_t *affs, const uint64_t *frags, int D, int H, int W,
                             const float *thresholds, int nthr, uint64_t *segs) {
@@ -378,7 +440,7 @@ int seg_agglomerate_mean_u8(const uint8_t *affs, const uint64_t *frags, int D, i
               hm_free(&em); em = nm;
             }
             e = (uint32_t)ne++;
-            E[e].u = u; E[e].v = v; E[e].key0 = key; E[e].sum = 0; E[e].cnt = 0; E[e].deleted = 0; E[e].stale = 0;
+            E[e].u = u; E[e].v = v; E[e].key0 = key; E[e].sum = 0; E[e].cnt = 0; E[e].deleted = 0; E[e].stale = 0; E[e].stored = 0.f;
             hm_put(&em, key, e); em_n++;
           } else e = em.vals[s];
           E[e].sum += affs[(int64_t)d * n + p];
@@ -386,16 +448,18 @@ int seg_agglomerate_mean_u8(const uint8_t *affs, const uint64_t *frags, int D, i
         }
       }
   g_edges = E;
-  /* adjacency: per-node growable lists of edge ids */
-  uint32_t **adj = (uint32_t **)calloc(nn ? nn : 1, sizeof(uint32_t *));
-  uint32_t *adjn = (uint32_t *)calloc(nn ? nn : 1, 4), *adjc = (uint32_t *)calloc(nn ? nn : 1, 4);
-#define ADJ_PUSH(node, e_) do { if (adjn[node] == adjc[node]) { adjc[node] = adjc[node] ? 2 * adjc[node] : 4; adj[node] = (uint32_t *)realloc(adj[node], 4 * adjc[node]); } adj[node][adjn[node]++] = (e_); } while (0)
-  for (int64_t e = 0; e < ne; e++) { ADJ_PUSH(E[e].u, (uint32_t)e); ADJ_PUSH(E[e].v, (uint32_t)e); }
-  /* queue: binary heap (any correct priority queue gives the same result: the order is total) */
-  qitem *heap = (qitem *)malloc(sizeof(qitem) * (ne + 1));
+  adj_t A;
+  A.adj = (uint32_t **)calloc(nn ? nn : 1, sizeof(uint32_t *));
+  A.adjn = (uint32_t *)calloc(nn ? nn : 1, 4);
+  A.adjc = (uint32_t *)calloc(nn ? nn : 1, 4);
+  for (int64_t e = 0; e < ne; e++) { adj_push(&A, E[e].u, (uint32_t)e); adj_push(&A, E[e].v, (uint32_t)e); }
+  /* queue: binary heap (any correct priority queue gives the same result: the order is total).  An edge is rescored
+   * at most once per pop, so the heap never holds more than ne + (number of pushes in flight) entries: grown on demand. */
+  int64_t hcap = ne + 1;
+  qitem *heap = (qitem *)malloc(sizeof(qitem) * hcap);
   int64_t hn = 0;
-#define QPUSH(it) do { int64_t c_ = hn++; heap[c_] = (it); while (c_ > 0) { int64_t p_ = (c_ - 1) / 2; if (q_less(&heap[c_], &heap[p_])) { qitem t_ = heap[c_]; heap[c_] = heap[p_]; heap[p_] = t_; c_ = p_; } else break; } } while (0)
-  for (int64_t e = 0; e < ne; e++) { qitem it = {edge_score(&E[e]), (uint32_t)e}; QPUSH(it); }
+#define QPUSH(it) do { if (hn == hcap) { hcap *= 2; heap = (qitem *)realloc(heap, sizeof(qitem) * hcap); } int64_t c_ = hn++; heap[c_] = (it); while (c_ > 0) { int64_t p_ = (c_ - 1) / 2; if (q_less(&heap[c_], &heap[p_])) { qitem t_ = heap[c_]; heap[c_] = heap[p_]; heap[p_] = t_; c_ = p_; } else break; } } while (0)
+  for (int64_t e = 0; e < ne; e++) { E[e].stored = edge_score(&E[e]); qitem it = {E[e].stored, (uint32_t)e}; QPUSH(it); }
   uint32_t *parent = (uint32_t *)malloc(4 * (nn ? nn : 1));
   for (int64_t i = 0; i < nn; i++) parent[i] = (uint32_t)i;
 
@@ -414,32 +478,9 @@ int seg_agglomerate_mean_u8(const uint8_t *affs, const uint64_t *frags, int D, i
       }
       edge_t *e = &E[top.e];
       if (e->deleted) continue;
-      if (e->stale) { e->stale = 0; qitem it = {edge_score(e), top.e}; QPUSH(it); continue; }
-      const uint32_t a = e->u < e->v ? e->u : e->v, b = e->u < e->v ? e->v : e->u;
-      for (uint32_t k = 0; k < adjn[b]; k++) {
-        const uint32_t fi = adj[b][k];
-        edge_t *f = &E[fi];
-        if (fi == top.e || f->deleted) continue;
-        if (f->u != b && f->v != b) continue; /* moved away earlier (cannot happen: b only dies once) */
-        const uint32_t nb = f->u == b ? f->v : f->u;
-        const uint32_t gu = a < nb ? a : nb, gv = a < nb ? nb : a;
-        const uint64_t gkey = ((uint64_t)gu << 32) | gv;
-        const uint64_t fkey = ((uint64_t)(f->u) << 32) | f->v;
-        int64_t s = hm_find(&em, gkey);
-        if (s >= 0) {
-          edge_t *g = &E[em.vals[s]];
-          g->sum += f->sum; g->cnt += f->cnt; g->stale = 1;
-          f->deleted = 1;
-          hm_del(&em, fkey);
-        } else {
-          hm_del(&em, fkey);
-          f->u = gu; f->v = gv; f->stale = 1;
-          hm_put(&em, gkey, fi);
-          ADJ_PUSH(a, fi);
-        }
-      }
-      hm_del(&em, ((uint64_t)e->u << 32) | e->v);
-      e->deleted = 1;
+      if (e->stale) { e->stale = 0; e->stored = edge_score(e); qitem it = {e->stored, top.e}; QPUSH(it); continue; }
+      uint32_t a, b;
+      merge_regions(E, top.e, &em, &A, &a, &b);
       parent[b] = a;
     }
     uint64_t *seg = segs + (int64_t)t * n;
@@ -450,8 +491,8 @@ int seg_agglomerate_mean_u8(const uint8_t *affs, const uint64_t *frags, int D, i
       seg[i] = ids[r];
     }
   }
-  for (int64_t i = 0; i < nn; i++) free(adj[i]);
-  free(adj); free(adjn); free(adjc); free(heap); free(parent); free(E); hm_free(&em); free(rank); free(ids);
+  for (int64_t i = 0; i < nn; i++) free(A.adj[i]);
+  free(A.adj); free(A.adjn); free(A.adjc); free(heap); free(parent); free(E); hm_free(&em); free(rank); free(ids);
   return 0;
 }
 
@@ -639,9 +680,11 @@ int64_t seg_rag_merge_scores_u8(const uint8_t *affs, const uint64_t *frags, int 
     }
   }
   free(P);
-  uint32_t **adj = (uint32_t **)calloc(nn ? nn : 1, sizeof(uint32_t *));
-  uint32_t *adjn = (uint32_t *)calloc(nn ? nn : 1, 4), *adjc = (uint32_t *)calloc(nn ? nn : 1, 4);
-  for (int64_t e = 0; e < ne; e++) { ADJ_PUSH(E[e].u, (uint32_t)e); ADJ_PUSH(E[e].v, (uint32_t)e); }
+  adj_t A;
+  A.adj = (uint32_t **)calloc(nn ? nn : 1, sizeof(uint32_t *));
+  A.adjn = (uint32_t *)calloc(nn ? nn : 1, 4);
+  A.adjc = (uint32_t *)calloc(nn ? nn : 1, 4);
+  for (int64_t e = 0; e < ne; e++) { adj_push(&A, E[e].u, (uint32_t)e); adj_push(&A, E[e].v, (uint32_t)e); }
   /* bin queue: FIFO lists threaded through qnext (an edge is queued at most once) */
   uint32_t *qnext = (uint32_t *)malloc(4 * (ne ? ne : 1));
   uint32_t *bhead = (uint32_t *)malloc(4 * nbins), *btail = (uint32_t *)malloc(4 * nbins);
@@ -650,7 +693,9 @@ int64_t seg_rag_merge_scores_u8(const uint8_t *affs, const uint64_t *frags, int 
 #define BPUSH(e_, sc_) do { int b_ = (int)((sc_) * (float)(nbins - 1)); if (b_ < 0) b_ = 0; if (b_ > nbins - 1) b_ = nbins - 1; \
     qnext[e_] = 0xffffffffu; if (bhead[b_] == 0xffffffffu) bhead[b_] = (e_); else qnext[btail[b_]] = (e_); btail[b_] = (e_); \
     if (b_ < minbin) minbin = b_; } while (0)
-  for (int64_t e = 0; e < ne; e++) { const float sc = edge_score(&E[e]); if (sc < threshold) BPUSH((uint32_t)e, sc); }
+  /* an edge whose stored score is not below the threshold can never be popped before the loop ends: it is left out
+   * of the queue (upstream queues it and stops at it), its stored score still takes part in the comparisons */
+  for (int64_t e = 0; e < ne; e++) { E[e].stored = edge_score(&E[e]); if (E[e].stored < threshold) BPUSH((uint32_t)e, E[e].stored); }
   /* merge tree: leaves 0..nn-1, merge i creates node nn+i */
   uint32_t *tnext = (uint32_t *)malloc(4 * (2 * nn + 1)), *cur = (uint32_t *)malloc(4 * (nn ? nn : 1));
   float *tscore = (float *)calloc(2 * nn + 1, 4);
@@ -664,33 +709,10 @@ int64_t seg_rag_merge_scores_u8(const uint8_t *affs, const uint64_t *frags, int 
     bhead[minbin] = qnext[ei];
     edge_t *e = &E[ei];
     if (e->deleted) continue;
-    if (e->stale) { e->stale = 0; const float sc = edge_score(e); if (sc < threshold) BPUSH(ei, sc); continue; }
-    const float sc = edge_score(e);
-    const uint32_t a = e->u < e->v ? e->u : e->v, b = e->u < e->v ? e->v : e->u;
-    for (uint32_t k = 0; k < adjn[b]; k++) {
-      const uint32_t fi = adj[b][k];
-      edge_t *f = &E[fi];
-      if (fi == ei || f->deleted) continue;
-      if (f->u != b && f->v != b) continue;
-      const uint32_t nb = f->u == b ? f->v : f->u;
-      const uint32_t gu = a < nb ? a : nb, gv = a < nb ? nb : a;
-      const uint64_t gkey = ((uint64_t)gu << 32) | gv;
-      const uint64_t fkey = ((uint64_t)(f->u) << 32) | f->v;
-      int64_t s = hm_find(&em, gkey);
-      if (s >= 0) {
-        edge_t *g = &E[em.vals[s]];
-        g->sum += f->sum; g->cnt += f->cnt; g->stale = 1;
-        f->deleted = 1;
-        hm_del(&em, fkey);
-      } else {
-        hm_del(&em, fkey);
-        f->u = gu; f->v = gv; f->stale = 1;
-        hm_put(&em, gkey, fi);
-        ADJ_PUSH(a, fi);
-      }
-    }
-    hm_del(&em, ((uint64_t)e->u << 32) | e->v);
-    e->deleted = 1;
+    if (e->stale) { e->stale = 0; e->stored = edge_score(e); if (e->stored < threshold) BPUSH(ei, e->stored); continue; }
+    const float sc = e->stored;
+    uint32_t a, b;
+    merge_regions(E, ei, &em, &A, &a, &b);
     const uint32_t t = (uint32_t)(nn + nm);
     tnext[cur[a]] = t; tnext[cur[b]] = t; cur[a] = t; tscore[t] = sc;
     if (merges_out) { merges_out[2 * nm] = ids[a]; merges_out[2 * nm + 1] = ids[b]; }
@@ -709,8 +731,8 @@ int64_t seg_rag_merge_scores_u8(const uint8_t *affs, const uint64_t *frags, int 
     }
     scores_out[e] = s;
   }
-  for (int64_t i = 0; i < nn; i++) free(adj[i]);
-  free(adj); free(adjn); free(adjc); free(qnext); free(bhead); free(btail); free(tnext); free(cur); free(tscore);
+  for (int64_t i = 0; i < nn; i++) free(A.adj[i]);
+  free(A.adj); free(A.adjn); free(A.adjc); free(qnext); free(bhead); free(btail); free(tnext); free(cur); free(tscore);
   free(E); hm_free(&em); free(rank); free(ids);
   return ne;
 }

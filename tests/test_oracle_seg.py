@@ -139,3 +139,72 @@ def test_cc_oracle_vs_reference_goldens(golden_dir):
     for thr in (0.0, 0.2, 0.35, 0.5, 1 / 3, 0.999, 1.0):
         u = np.arange(256, dtype=np.uint8)
         assert np.array_equal((u.astype(np.float32) / 255.0) > thr, u > S.cc_cut(thr)), thr
+
+
+def _three_node_case():
+    """Fragments 1 | 2 over 3 3 on a 1 x 2 x 2 grid: edges {1,2} (x-affinity at voxel (0,0,1)), {1,3} and {2,3}
+    (y-affinities at (0,1,0) and (0,1,1))."""
+    frags = np.array([[[1, 2], [3, 3]]], dtype=np.uint64)
+    affs = np.zeros((3, 1, 2, 2), dtype=np.uint8)
+    affs[2, 0, 0, 1] = 230   # {1,2}: score 0.098
+    affs[1, 0, 1, 0] = 26    # {1,3}: score 0.898
+    affs[1, 0, 1, 1] = 204   # {2,3}: score 0.200
+    return affs, frags
+
+
+def test_shared_neighbour_keeps_the_cheaper_edge():
+    """waterz mergeRegions merges the dearer of two parallel edges into the cheaper one, which keeps its queue
+    position.  After 1 <- 2 the edges {1,3} (0.898) and {2,3} (0.2) are one edge of true score 0.549: it must be
+    met at 0.2, rescored and merged below the threshold 0.6.  (Keeping the a-side edge at 0.898 would end the loop
+    with fragment 3 unmerged: the rule this restatement had before.)"""
+    affs, frags = _three_node_case()
+    segs = S.agglomerate_mean_u8(affs, frags, [0.5, 0.6])
+    assert np.array_equal(segs[0], np.array([[[1, 1], [3, 3]]], dtype=np.uint64))
+    assert np.array_equal(segs[1], np.ones((1, 2, 2), dtype=np.uint64))
+    edges, scores, merges, mscores = S.rag_merge_scores_u8(affs, frags, 0.6, 256)
+    assert merges.tolist() == [[1, 2], [1, 3]]
+    np.testing.assert_allclose(mscores, [1 - 230 / 255, 1 - 230 / 510], rtol=1e-6)
+
+
+def test_merge_order_follows_the_cheaper_edge():
+    """Four fragments in a row of columns 1 2 3 4 over a second row 1 1 3 4 ... : the merged edge {1,3} (true score
+    0.45) must be handled before {3,4} (0.5), after which {3,4} and {1,4} are parallel and too dear to merge; with the
+    merged edge waiting at the dearer score 0.8, 3 <- 4 would happen first and everything would end up in one segment."""
+    frags = np.array([[[1, 2, 2], [3, 3, 4], [1, 1, 4]]], dtype=np.uint64)
+    affs = np.zeros((3, 1, 3, 3), dtype=np.uint8)
+    affs[2, 0, 0, 1] = 240            # {1,2} x: 0.059
+    affs[1, 0, 1, 0] = 51             # {1,3} y at (1,0): 0.8
+    affs[1, 0, 1, 1] = 230            # {2,3} y at (1,1): 0.098
+    affs[1, 0, 1, 2] = 0              # {2,4} y at (1,2): 1.0
+    affs[2, 0, 1, 2] = 128            # {3,4} x at (1,2): 0.498
+    affs[1, 0, 2, 0] = 51             # {1,3} y at (2,0)
+    affs[1, 0, 2, 1] = 230            # {1,3} y at (2,1)
+    affs[2, 0, 2, 2] = 0              # {1,4} x at (2,2): 1.0
+    from tests.agglo_model import agglomerate
+    want = agglomerate(affs, frags, [0.55])[0]
+    got = S.agglomerate_mean_u8(affs, frags, [0.55])[0]
+    assert np.array_equal(got, want)
+    assert len(np.unique(got)) == 2 and got[0, 1, 2] == 4      # 4 stays on its own
+
+
+def test_oracle_equals_literal_python_model():
+    """The C restatement against the dictionary-based model of the same specification (tests/agglo_model.py) on small
+    random volumes with many ties: exact queue (segmentations at three thresholds) and bin queue (merge history)."""
+    from tests.agglo_model import agglomerate, merge_history
+    rng = np.random.default_rng(17)
+    for case in range(12):
+        shape = (int(rng.integers(1, 4)), int(rng.integers(4, 9)), int(rng.integers(4, 9)))
+        nfr = int(rng.integers(4, 14))
+        frags = rng.integers(0 if case % 3 == 0 else 1, nfr, size=shape).astype(np.uint64)
+        levels = np.array([0, 40, 80, 128, 200, 255]) if case % 2 else np.arange(256)
+        affs = rng.choice(levels, size=(3,) + shape).astype(np.uint8)
+        thr = [0.3, 0.55, 0.8]
+        got = S.agglomerate_mean_u8(affs, frags, thr)
+        want = agglomerate(affs, frags, thr)
+        for g, w in zip(got, want):
+            assert np.array_equal(g, w), case
+        for nbins in (256, 8):
+            hist = merge_history(affs, frags, 0.7, nbins)
+            _, _, merges, mscores = S.rag_merge_scores_u8(affs, frags, 0.7, nbins)
+            assert [(a, b) for a, b, _ in hist] == [tuple(m) for m in merges.tolist()], (case, nbins)
+            np.testing.assert_array_equal(np.array([s for _, _, s in hist], dtype=np.float32), mscores)

@@ -285,3 +285,75 @@ def test_cc_affs_bit_exact_vs_reference_goldens_and_oracle(golden_dir):
         keep[0] = False
         want = np.where(keep[ref], ref, 0)
         assert np.array_equal(seg.cpu().numpy().astype(np.uint32), want)
+
+
+def test_merge_rule_hand_built_graphs():
+    """The two hand-built graphs of tests/test_oracle_seg.py on which waterz's shared-neighbour rule (the dearer edge is
+    merged into the cheaper one, which keeps its place in the queue) and the rule this engine had before give different
+    segmentations; both queues, both forms of the merge loop are covered by the variant run of this file."""
+    from bootstrapper_amd.post.engine import SegEngine
+    from oracle import seg_ref as S
+    from tests.test_oracle_seg import _three_node_case
+    eng = SegEngine((2, 8, 8))
+    affs, frags = _three_node_case()
+    segs = eng.agglomerate_mean(torch.from_numpy(affs).cuda(), torch.from_numpy(frags.astype(np.int64)).cuda(), [0.5, 0.6])
+    eng.status()
+    assert segs[0].cpu().numpy().tolist() == [[[1, 1], [3, 3]]]
+    assert segs[1].cpu().numpy().tolist() == [[[1, 1], [1, 1]]]
+    e, s, m, ms = eng.rag_merge_scores(torch.from_numpy(affs).cuda(), torch.from_numpy(frags.view(np.int64)).cuda(), 0.6, 256,
+                                       return_merges=True)
+    assert m.cpu().numpy().tolist() == [[1, 2], [1, 3]]
+    frags = np.array([[[1, 2, 2], [3, 3, 4], [1, 1, 4]]], dtype=np.uint64)
+    affs = np.zeros((3, 1, 3, 3), dtype=np.uint8)
+    affs[2, 0, 0, 1] = 240; affs[1, 0, 1, 0] = 51; affs[1, 0, 1, 1] = 230; affs[2, 0, 1, 2] = 128
+    affs[1, 0, 2, 0] = 51; affs[1, 0, 2, 1] = 230
+    ref = S.agglomerate_mean_u8(affs, frags, [0.55])[0]
+    segs = eng.agglomerate_mean(torch.from_numpy(affs).cuda(), torch.from_numpy(frags.astype(np.int64)).cuda(), [0.55])
+    eng.status()
+    assert np.array_equal(segs[0].cpu().numpy().astype(np.uint64), ref)
+    assert ref[0, 1, 2] == 4 and len(np.unique(ref)) == 2
+
+
+def test_tie_rich_agglomeration_bit_exact_vs_oracle():
+    """Few affinity levels: many equal scores and many shared neighbours with equal stored scores (the branch where the
+    b-side edge survives)."""
+    from bootstrapper_amd.post.engine import SegEngine
+    from oracle import seg_ref as S
+    rng = np.random.default_rng(23)
+    shape = (6, 40, 40)
+    eng = SegEngine(shape)
+    for case in range(4):
+        affs = rng.choice(np.array([0, 64, 128, 191, 255], dtype=np.uint8), size=(3,) + shape)
+        frags = np.kron(rng.integers(0 if case % 2 else 1, 60, size=(3, 10, 10)), np.ones((2, 4, 4), dtype=np.int64)).astype(np.uint64)
+        thr = [0.3, 0.5, 0.7]
+        ref = S.agglomerate_mean_u8(affs, frags, thr)
+        segs = eng.agglomerate_mean(torch.from_numpy(affs).cuda(), torch.from_numpy(frags.astype(np.int64)).cuda(), thr)
+        eng.status()
+        for t in range(3):
+            assert np.array_equal(segs[t].cpu().numpy().astype(np.uint64), ref[t]), (case, t)
+        for bins in (256, 16):
+            e_ref, s_ref, m_ref, ms_ref = S.rag_merge_scores_u8(affs, frags, 0.8, bins)
+            e, s, m, ms = eng.rag_merge_scores(torch.from_numpy(affs).cuda(), torch.from_numpy(frags.view(np.int64)).cuda(), 0.8, bins,
+                                               return_merges=True)
+            assert np.array_equal(e.cpu().numpy().view(np.uint64), e_ref)
+            assert np.array_equal(m.cpu().numpy().view(np.uint64), m_ref), (case, bins)
+            np.testing.assert_array_equal(ms.cpu().numpy(), ms_ref)
+            np.testing.assert_array_equal(s.cpu().numpy(), s_ref)
+
+
+def test_overflow_of_an_earlier_call_is_remembered():
+    """An overflow is reported by the next status() even when later calls on the same handle went well (the per-call flag
+    word is reset by every call; the pipeline checks once per lane after many blocks)."""
+    from bootstrapper_amd.post.engine import SegEngine
+    from bootstrapper_amd._lib import BsmiError
+    shape = (2, 8, 8)
+    eng = SegEngine(shape)
+    affs = torch.full((3,) + shape, 200, dtype=torch.uint8, device="cuda")
+    bad = torch.full(shape, 10_000, dtype=torch.int64, device="cuda")     # id beyond the direct-address table of this workspace
+    good = torch.ones(shape, dtype=torch.int64, device="cuda")
+    eng.agglomerate_mean(affs, bad, [0.5])
+    eng.agglomerate_mean(affs, good, [0.5])
+    with pytest.raises(BsmiError):
+        eng.status()
+    eng.agglomerate_mean(affs, good, [0.5])
+    eng.status()                                                          # cleared by the failed check
