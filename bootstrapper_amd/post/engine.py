@@ -54,7 +54,7 @@ class SegEngine:
         return segs
 
     def postprocess_fragments(self, affs_u8, frags, filter_value=0.0, min_size=0, crop_offset=(0, 0, 0),
-                              crop_shape=None, id_offset=0):
+                              crop_shape=None, id_offset=0, out=None, num=None):
         """Blockwise fragment clean-up (reference post/blockwise/watershed_frags.py:181-224): filter
         by mean affinity, drop debris, crop to the write ROI, relabel 26-connected components in
         raster order and add `id_offset`.  `frags` is filtered in place.  -> (labels int64
@@ -66,23 +66,33 @@ class SegEngine:
         a = affs_u8.contiguous()
         shape = tuple(frags.shape)
         crop_shape = tuple(shape) if crop_shape is None else tuple(int(c) for c in crop_shape)
-        out = torch.empty(crop_shape, dtype=torch.int64, device=a.device)
-        num = torch.zeros(1, dtype=torch.int64, device=a.device)
+        # out / num: caller-owned destinations (a pipeline that keeps every block's results without a host round trip)
+        if out is None:
+            out = torch.empty(crop_shape, dtype=torch.int64, device=a.device)
+        elif out.dtype != torch.int64 or tuple(out.shape) != crop_shape or not out.is_contiguous():
+            raise ValueError("out must be a contiguous int64 tensor of the crop shape")
+        if num is None:
+            num = torch.zeros(1, dtype=torch.int64, device=a.device)
         check(lib.bsmi_frag_postprocess_u8(self._h, C.c_void_p(a.data_ptr()), C.c_void_p(frags.data_ptr()),
                                            _lib.i64x3(shape), float(filter_value), int(min_size),
                                            _lib.i64x3(crop_offset), _lib.i64x3(crop_shape), int(id_offset),
                                            C.c_void_p(out.data_ptr()), C.c_void_p(num.data_ptr()), self._stream()))
         return out, num
 
-    def label_stats(self, labels, id_offset, num):
+    def label_stats(self, labels, id_offset, num, size=None, sums=None):
         """Voxel count and z/y/x index sums of labels id_offset+1..id_offset+num (RAG node
         attributes, watershed_frags.py:230-246) -> (size int64[num], sums int64[num][3])."""
         if labels.dtype != torch.int64 or labels.dim() != 3 or not labels.is_cuda:
             raise ValueError("labels must be an int64 CUDA tensor of shape (D, H, W)")
         lab = labels.contiguous()
         num = int(num)
-        size = torch.empty(max(num, 1), dtype=torch.int64, device=lab.device)
-        sums = torch.empty((max(num, 1), 3), dtype=torch.int64, device=lab.device)
+        # size / sums: caller-owned destinations of at least `num` entries (`num` may then be an upper bound)
+        if size is None:
+            size = torch.empty(max(num, 1), dtype=torch.int64, device=lab.device)
+        if sums is None:
+            sums = torch.empty((max(num, 1), 3), dtype=torch.int64, device=lab.device)
+        if size.numel() < num or sums.numel() < 3 * num or not size.is_contiguous() or not sums.is_contiguous():
+            raise ValueError("size / sums too small")
         check(lib.bsmi_label_stats(self._h, C.c_void_p(lab.data_ptr()), _lib.i64x3(lab.shape), int(id_offset), num,
                                    C.c_void_p(size.data_ptr()), C.c_void_p(sums.data_ptr()), self._stream()))
         return size[:num], sums[:num]
@@ -116,6 +126,23 @@ class SegEngine:
         if return_merges:
             return edges[:ne], scores[:ne], merges[:nm], mscores[:nm]
         return edges[:ne], scores[:ne]
+
+    def rag_merge_scores_async(self, affs_u8, frags, threshold, discretize_queue, edges, scores, counts, merges=None,
+                               merge_scores=None):
+        """rag_merge_scores into caller-owned CUDA buffers, asynchronous on the current stream: edges int64 [cap][2],
+        scores float32 [cap], counts int64 [>= 3] (edges, merges, nodes); status() reports a too small buffer."""
+        if affs_u8.dtype != torch.uint8 or not affs_u8.is_cuda or affs_u8.dim() != 4 or affs_u8.shape[0] != 3 or not affs_u8.is_contiguous():
+            raise ValueError("affs must be a contiguous uint8 CUDA tensor of shape (3, D, H, W)")
+        if frags.dtype != torch.int64 or tuple(frags.shape) != tuple(affs_u8.shape[1:]) or not frags.is_contiguous():
+            raise ValueError("fragments must be a contiguous int64 tensor of shape (D, H, W)")
+        if not (edges.is_contiguous() and scores.is_contiguous() and counts.is_contiguous()) or edges.shape[0] != scores.shape[0]:
+            raise ValueError("edges / scores / counts must be contiguous and of one capacity")
+        check(lib.bsmi_rag_merge_scores_u8(self._h, C.c_void_p(affs_u8.data_ptr()), C.c_void_p(frags.data_ptr()),
+                                           _lib.i64x3(frags.shape), float(threshold), int(discretize_queue),
+                                           C.c_void_p(edges.data_ptr()), C.c_void_p(scores.data_ptr()), int(edges.shape[0]),
+                                           C.c_void_p(merges.data_ptr()) if merges is not None else None,
+                                           C.c_void_p(merge_scores.data_ptr()) if merge_scores is not None else None,
+                                           C.c_void_p(counts.data_ptr()), self._stream()))
 
     def cc_affs(self, affs_u8, threshold=0.5, remove_debris=0):
         """Thresholded-affinity connected components (reference post/cc.py; post/connected_components.py:77-101).

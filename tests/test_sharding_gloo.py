@@ -77,3 +77,64 @@ def test_gradient_sum_two_ranks_gloo():
         assert p.exitcode == 0
     for rank, g, scale in res:
         assert g == [3.0 * i for i in range(10)] and scale == 0.5
+
+
+def _volume_worker(rank, world, port, q):
+    import numpy as np
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from bootstrapper_amd.volume import exchange_faces, gather_and_stitch, slab_layers
+    # face exchange: a (C, Z + 2c, Y, X) slab with context c = 2; the margins must receive the neighbours' outer layers
+    c, Z = 2, 6
+    vol = torch.arange(3 * world * Z * 4 * 5, dtype=torch.int64).reshape(3, world * Z, 4, 5)
+    slab = torch.zeros(3, Z + 2 * c, 4, 5, dtype=torch.int64)
+    slab[:, c:c + Z] = vol[:, rank * Z:(rank + 1) * Z]
+    exchange_faces(slab[:, c:2 * c], slab[:, Z:Z + c], slab[:, 0:c], slab[:, Z + c:Z + 2 * c], rank, world)
+    want = torch.zeros_like(slab)
+    lo, hi = max(rank * Z - c, 0), min((rank + 1) * Z + c, world * Z)
+    want[:, lo - (rank * Z - c):hi - (rank * Z - c)] = vol[:, lo:hi]
+    faces_ok = bool(torch.equal(slab, want))
+    # stitching: a chain of fragments cut over the ranks; the components must come out as if one rank had it all
+    rng = np.random.default_rng(5)
+    n = 40
+    nodes = np.arange(1, n + 1, dtype=np.uint64) * 3
+    edges = np.stack([nodes[:-1], nodes[1:]], axis=1)
+    extra = rng.integers(0, n, size=(30, 2))
+    extra = np.sort(extra[extra[:, 0] != extra[:, 1]], axis=1)
+    edges = np.concatenate([edges, nodes[extra]])
+    scores = rng.random(len(edges)).astype(np.float32)
+    scores[::7] = np.nan                                  # unscored edges are dropped (post/watershed.py:163-171)
+    starts, counts = slab_layers(n, world)
+    mine = slice(starts[rank], starts[rank] + counts[rank])
+    own = (edges[:, 0] >= nodes[mine][0]) & (edges[:, 0] <= nodes[mine][-1])      # an edge travels with its smaller fragment
+    got_nodes, got = gather_and_stitch(nodes[mine], edges[own], scores[own], [0.3, 0.6], rank, world)
+    one_nodes, one = gather_and_stitch(nodes, edges, scores, [0.3, 0.6])
+    q.put((rank, faces_ok, bool(np.array_equal(got_nodes, one_nodes)), [bool(np.array_equal(a, b)) for a, b in zip(got, one)],
+           [int(len(np.unique(a))) for a in one]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_slab_exchange_and_stitch_gloo(world):
+    """The communication of bootstrapper_amd.volume on CPU tensors: slab faces to the z-neighbours, edges to rank 0, LUT back."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29700 + os.getpid() % 200 + world
+    ps = [ctx.Process(target=_volume_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in ps:
+        p.start()
+    res = sorted(q.get(timeout=180) for _ in ps)
+    for p in ps:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, faces_ok, nodes_ok, comps_ok, ncomp in res:
+        assert faces_ok and nodes_ok and all(comps_ok), (rank, faces_ok, nodes_ok, comps_ok)
+        assert 1 < ncomp[1] < ncomp[0] < 40
+
+
+def test_slab_layers():
+    from bootstrapper_amd.volume import slab_layers
+    assert slab_layers(8, 1) == ([0], [8])
+    assert slab_layers(8, 3) == ([0, 3, 6], [3, 3, 2])
+    assert slab_layers(2, 4) == ([0, 1, 2, 2], [1, 1, 0, 0])

@@ -1,0 +1,104 @@
+"""bootstrapper_amd.volume: a slab of blocks taken through fragments -> RAG scoring -> global components -> relabel on
+the device, bit-equal to the blockwise pipeline composed from the CPU oracle (tests/blockwise_ref.py), alone and split
+over two ranks; and the whole predict + segment pipeline on a small network.  Needs an MI355X."""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def blobby_affs(shape, seed, empty_corner=True):
+    from scipy.ndimage import gaussian_filter
+    rng = np.random.default_rng(seed)
+    a = gaussian_filter(rng.random((3,) + tuple(shape)), sigma=(0, 1, 3, 3))
+    affs = ((a - a.min()) / (a.max() - a.min()) * 255).astype(np.uint8)
+    if empty_corner:
+        affs[:, :, :40, :50] = 0                    # read boxes without any affinity: blocks that produce nothing
+    return affs
+
+
+@pytest.mark.parametrize("shape,block,ctx,lanes", [((20, 150, 130), (8, 64, 64), (1, 8, 8), 5), ((24, 96, 96), (8, 32, 32), (2, 4, 4), 16)])
+def test_slab_segmenter_equals_cpu_blockwise(shape, block, ctx, lanes):
+    from bootstrapper_amd.volume import SlabSegmenter
+    from tests.blockwise_ref import cpu_blockwise
+    affs = blobby_affs(shape, 21)
+    thr = [0.3, 0.45]
+    frags_ref, nodes, E, Sc, segs_ref = cpu_blockwise(affs, block, ctx, 4, 0.35, 12, thr)
+    layers = -(-shape[0] // block[0])
+    seg = SlabSegmenter(shape, block, ctx, layers, 0, thr, True, 4, 0.35, 12, 256, n_lanes=lanes)
+    seg.interior(seg.affs).copy_(torch.from_numpy(affs).cuda())
+    segs = seg.run()
+    assert np.array_equal(seg.interior(seg.frags).cpu().numpy().view(np.uint64), frags_ref)
+    assert np.array_equal(seg.nodes, nodes)
+    # the same edges with the same scores, whatever the order the blocks delivered them in
+    order = np.lexsort((seg.rag_edges[:, 1], seg.rag_edges[:, 0]))
+    order_ref = np.lexsort((E[:, 1], E[:, 0]))
+    assert np.array_equal(seg.rag_edges[order], E[order_ref])
+    np.testing.assert_array_equal(seg.rag_scores[order], Sc[order_ref])
+    for t in range(len(thr)):
+        assert np.array_equal(segs[t].cpu().numpy().view(np.uint64), segs_ref[t])
+    assert len(np.unique(segs_ref[1])) < len(nodes)
+    # RAG node attributes (watershed_frags.py:230-246)
+    ids, pos, size = seg.node_table()
+    assert np.array_equal(ids, nodes)
+    k = len(ids) // 3
+    m = frags_ref == ids[k]
+    assert size[k] == int(m.sum()) and np.allclose(pos[k], np.argwhere(m).mean(axis=0))
+
+
+def test_two_ranks_equal_one_rank(tmp_path):
+    """Two ranks (gloo, both on cuda:0), each with half of the block layers: face exchange of affinities and fragments,
+    edges gathered on rank 0, LUT broadcast -- the fragments and segmentations of the two slabs put together are
+    bit-equal to the one-rank run and to the CPU composition."""
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", "29621", os.path.join(ROOT, "tests", "volume_worker.py"), str(tmp_path)],
+                       env=env, capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    verdict = json.loads((tmp_path / "verdict.json").read_text())
+    assert verdict == {"frags_equal": True, "segs_equal": True, "cpu_equal": True, "luts_equal": True}, verdict
+
+
+def test_volume_pipeline_small_net(golden_dir):
+    """Predict + segment through VolumePipeline on a small golden network: the affinities of the slab are the blocks the
+    model predicts one by one, and the segmentation is the CPU composition applied to them."""
+    from bootstrapper_amd.unet import Model, extract_block_reflect
+    from bootstrapper_amd.volume import VolumePipeline
+    from tests.blockwise_ref import cpu_blockwise
+    d = np.load(os.path.join(golden_dir, "unet_affs_f4i2.npz"))
+    sd = {k[2:]: d[k] for k in d.files if k.startswith("w:")}
+    nc = {"in_channels": 1, "num_fmaps": 4, "fmap_inc_factor": 2, "downsample_factors": [[1, 2, 2]] * 3,
+          "kernel_size_down": [[[3, 3, 3], [3, 3, 3]]] * 4, "kernel_size_up": [[[3, 3, 3], [3, 3, 3]]] * 3,
+          "outputs": {"3d_affs": {"dims": 6}}}
+    m = Model(nc, precision="f32").load_state_dict(sd)
+    out_block, ctx = (6, 32, 32), (14, 46, 46)
+    assert m.output_shape(tuple(o + 2 * c for o, c in zip(out_block, ctx))) == out_block
+    rng = np.random.default_rng(9)
+    from scipy.ndimage import gaussian_filter
+    raw = gaussian_filter(rng.random((40, 120, 120)), sigma=(1, 3, 3))
+    raw = torch.from_numpy(((raw - raw.min()) / (raw.max() - raw.min()) * 255).astype(np.uint8)).cuda()
+    pipe = VolumePipeline(m, out_block, ctx, (3, 2, 2), seg_context=(1, 4, 4), thresholds=[0.3, 0.5], min_seed_distance=3,
+                          n_lanes=4, job_origin=(4, 8, 8))
+    segs = pipe.run(raw)
+    affs = pipe.seg.interior(pipe.seg.affs).cpu().numpy()
+    k = 0
+    for z in range(3):
+        for y in range(2):
+            for x in range(2):
+                off = [4 + 6 * z - 14, 8 + 32 * y - 46, 8 + 32 * x - 46]
+                blk = m.predict_u8(extract_block_reflect(raw, off, (34, 124, 124)))[0][:3].cpu().numpy()
+                assert np.array_equal(affs[:, 6 * z:6 * z + 6, 32 * y:32 * y + 32, 32 * x:32 * x + 32], blk), (z, y, x)
+                k += 1
+    frags_ref, nodes, _, _, segs_ref = cpu_blockwise(affs, out_block, (1, 4, 4), 3, 0.0, 0, [0.3, 0.5])
+    assert np.array_equal(pipe.seg.interior(pipe.seg.frags).cpu().numpy().view(np.uint64), frags_ref)
+    for t in range(2):
+        assert np.array_equal(segs[t].cpu().numpy().view(np.uint64), segs_ref[t])
+    assert len(nodes) > 20
