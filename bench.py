@@ -3,19 +3,25 @@
 processed in 128^3 output blocks (BASELINE.json metric), one process per GPU.
 
 A "step" is one 128^3 output block taken through the whole hot path with its input already
-resident in HBM: reflect-padded (156,220,220) read -> 3-D U-Net (bf16 MFMA) -> uint8
-affinities -> seeded-watershed fragments -> mean-affinity agglomeration at thresholds
-[0.2, 0.35, 0.5].  Blocks are independent: with N ranks every rank takes its own K blocks
-(weak scaling, no data-path collective); the only collectives are the timing barrier and
-the max-over-ranks reduction.
+resident in HBM.  The timed region takes a box of `--steps` blocks per GPU (the ranks' boxes
+stacked along z) through bootstrapper_amd.volume.VolumePipeline:
+  reflect-padded (156,220,220) read -> 3-D U-Net -> uint8 affinities                    (predict)
+  per block, on the 160^3 read box (context 16): seeded-watershed fragments, crop,
+  26-connected relabel with global ids, node statistics; RAG edge scoring              (segment)
+  global thresholded connected components at [0.2, 0.35, 0.5] -> LUT -> relabel        (stitch)
+so what is timed ends in ONE consistent segmentation of the box per threshold.  Default
+precision: split bf16 (bf16x3), the mode that meets the 1e-4 parity gate of the fp32 reference.
+Exchange steps (N > 1): context margins of affinities / fragments between z-neighbours, scored
+edges to rank 0, LUT broadcast; everything else is rank-local (weak scaling).
 
-  python bench.py --gpus 1 --steps 256 --warmup 2
+  python bench.py --gpus 1 --steps 64 --warmup 2
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
       --master-port P bench.py --gpus N --steps K --warmup W
 
 Prints ONE JSON line (rank 0) with the driver's contract fields plus `roofline` (implicit-GEMM
-conv kernels, HIP-event timed inside the timed region) and `cpu_baseline` (the repo's CPU
-restatement timed on this node's host cores; N=1 only).
+conv kernels, HIP-event timed inside the timed region), `predict_only` / `segment_only` (the two
+halves of the timed region), `cpu_baseline` (the repo's CPU restatement timed on this node's host
+cores; N=1 only) and `modes` (speed and max error of every precision mode on the same blocks).
 """
 import argparse
 import json
@@ -44,8 +50,15 @@ NET_CONFIG = {  # reference models/3d_affs/net_config.json
 }
 OUT_BLOCK = (128, 128, 128)
 CONTEXT = (14, 46, 46)          # (input - output) / 2 of the 3-D nets (reference predict.py:127-131)
+SEG_CONTEXT = (16, 16, 16)      # block_size / 8 (reference post/watershed.py:79-83)
 THRESHOLDS = [0.2, 0.35, 0.5]   # reference segment.py:17
 BF16_DENSE_PEAK_TFLOPS = 2500.0  # /opt/skills/guides/MI355X_MICROARCH.md, dense bf16 MFMA
+# what the conv kernels are priced against, per precision mode.  The split mode spends three bf16 MFMAs per product of the
+# algorithmic count, so its ceiling is a third of the dense bf16 peak.
+MFMA_PEAK_TFLOPS = {"bf16": BF16_DENSE_PEAK_TFLOPS, "bf16x3": BF16_DENSE_PEAK_TFLOPS / 3.0, "f32": 157.3}
+MFMA_PEAK_NOTE = {"bf16": "dense bf16 MFMA peak", "f32": "dense f32 MFMA peak",
+                  "bf16x3": "dense bf16 MFMA peak / 3: each f32-accurate product is hi*hi + lo*hi + hi*lo on the bf16 MFMA"}
+HBM_PEAK_BYTES = 8.0e12
 # HBM-side bytes per conv launch cannot be counted inside this process: they come from the committed
 # rocprofv3 PMC passes of the same kernels on the same block (tools/pmc_traffic.py; FETCH_SIZE and WRITE_SIZE
 # in separate passes, KiB -> bytes, FETCH_SIZE doubled for gfx950 wide reads as the guide prescribes).
@@ -93,65 +106,56 @@ def host_cores():
     return max(1, min(n, int(os.environ.get("BSMI_BENCH_CORES", "16"))))
 
 
-def cpu_baseline(model_flops_per_voxel, affs_u8_host):
-    """CPU restatement (oracle/) timed on this node's host cores on a bounded sample.
+def job_blocks_for(steps):
+    """(layers, blocks in y, blocks in x) with layers * y * x == steps, as cubic as the factors allow, layers smallest
+    (ranks stack their slabs along z)."""
+    best = (1, 1, steps)
+    for a in range(1, int(round(steps ** (1 / 3))) + 2):
+        if steps % a:
+            continue
+        r = steps // a
+        for b in range(a, int(r ** 0.5) + 1):
+            if r % b == 0 and (r // b) - a < best[2] - best[0]:
+                best = (a, b, r // b)
+    return best
 
-    predict: torch-CPU fp32 network on one (32,196,196)->(4,104,104) block (1.53 TFLOP, the
-    reference's training block shape), all cores; converted to 128^3-block voxels/s through the
-    measured FLOP/s (the small block has a worse halo ratio than the benchmark's).
-    segment: C restatement of ws.py fragments + specified mean-affinity agglomeration on
-    (32,128,128) slabs of the affinities the GPU predicted, one slab per core concurrently."""
-    from concurrent.futures import ThreadPoolExecutor
+
+def cpu_baseline(raw_blocks, affs_u8_host, seg_blocks):
+    """CPU restatement (oracle/) timed on this node's host cores on a bounded sample of the same workload.
+
+    predict: the torch-CPU fp32 network (oracle/unet_ref.py) on real (156,220,220) -> 128^3 blocks of the job, all cores.
+    segment: the blockwise pipeline composed from the C restatement (oracle/blockwise_ref.py: fragments with context 16,
+    clean-up, RAG scoring, connected components, relabel) on `seg_blocks` 128^3 blocks of the affinities the GPU
+    predicted, blocks of a stage side by side on all cores."""
     from oracle import unet_ref as R
-    from oracle import seg_ref as S
+    from oracle.blockwise_ref import cpu_blockwise
     from bootstrapper_amd.synth import synthetic_state_dict
     cores = host_cores()
     torch.set_num_threads(cores)
     sd = synthetic_state_dict(NET_CONFIG, 0)
     cfg = R.default_cfg(12, 5)
-    rng = np.random.default_rng(0)
-    raw = rng.integers(0, 256, size=(32, 196, 196), dtype=np.uint8)
-    # flops of the sample block, same accounting as the device planner (algorithmic)
-    from bootstrapper_amd.unet import Model
-    m = Model(NET_CONFIG)
-    sample_flops = m.flops(raw.shape)
-    R.predict_block(cfg, sd, raw, ["affs_head"])  # thread pool and allocator warm-up
-    n_pred = 8
+    nvox = int(np.prod(OUT_BLOCK))
+    R.predict_block(cfg, sd, np.ascontiguousarray(raw_blocks[0][:40, :116, :116]), ["affs_head"])  # thread pool and allocator warm-up
+    outs = []
     t0 = time.perf_counter()
-    for _ in range(n_pred):
-        R.predict_block(cfg, sd, raw, ["affs_head"])
+    for raw in raw_blocks:
+        outs.append(R.predict_block(cfg, sd, raw, ["affs_head"])[0])
     t_pred = time.perf_counter() - t0
-    cpu_flops = n_pred * sample_flops / t_pred
-    pred_vox_s = cpu_flops / model_flops_per_voxel
-
-    slabs = [np.ascontiguousarray(affs_u8_host[:, z:z + 32]) for z in range(0, 128, 32)]
-    work = [slabs[i % len(slabs)] for i in range(cores)]
-
-    a_slab_vox = slabs[0][0].size
-    seg_budget = 6.0  # seconds of wall time: every core keeps segmenting slabs until then
-
-    def seg_worker(a):
-        n, t_end = 0, time.perf_counter() + seg_budget
-        while time.perf_counter() < t_end:
-            frags, _ = S.ws_fragments_u8(a, True, 10)
-            S.agglomerate_mean_u8(a, frags, THRESHOLDS)
-            n += a[0].size
-        return n
+    pred_vox_s = len(raw_blocks) * nvox / t_pred
 
     t0 = time.perf_counter()
-    with ThreadPoolExecutor(max_workers=cores) as ex:
-        nvox = sum(ex.map(seg_worker, work))
+    _, nodes, E, _, segs = cpu_blockwise(affs_u8_host, OUT_BLOCK, SEG_CONTEXT, 10, 0.0, 0, THRESHOLDS, 256, workers=cores)
     t_seg = time.perf_counter() - t0
-    seg_vox_s = nvox / t_seg
+    seg_vox_s = affs_u8_host[0].size / t_seg
     both = 1.0 / (1.0 / pred_vox_s + 1.0 / seg_vox_s)
     return {
         "value": both / 1e6, "unit": "Mvoxels/s", "cores": cores, "kind": "port",
-        "sample": (f"predict: torch-CPU fp32 restatement, {n_pred} blocks (32,196,196)->(4,104,104), {t_pred:.1f} s, "
-                   f"{cpu_flops / 1e9:.0f} GFLOP/s -> {pred_vox_s / 1e3:.2f} kvox/s at 128^3 blocks; "
-                   f"segment: C restatement on (32,128,128) slabs of GPU-predicted affinities, {cores} cores side by side, "
-                   f"{nvox / a_slab_vox:.0f} slabs in {t_seg:.1f} s -> {seg_vox_s / 1e6:.2f} Mvox/s"),
+        "sample": (f"predict: torch-CPU fp32 restatement, {len(raw_blocks)} blocks (156,220,220)->128^3 of the job in {t_pred:.1f} s "
+                   f"-> {pred_vox_s / 1e3:.2f} kvox/s; segment: blockwise pipeline of the C restatement (fragments with context 16, "
+                   f"RAG scoring, connected components, relabel) on {seg_blocks} blocks of GPU-predicted affinities, {cores} cores, "
+                   f"{len(nodes)} fragments, {len(E)} edges, {t_seg:.1f} s -> {seg_vox_s / 1e6:.2f} Mvox/s"),
         "predict_kvox_s": pred_vox_s / 1e3, "segment_Mvox_s": seg_vox_s / 1e6,
-    }
+    }, outs
 
 
 def train_main(args):
@@ -223,24 +227,20 @@ def main():
     ap.add_argument("--mode", default="predict", choices=["predict", "train"],
                     help="predict = the headline predict + segment benchmark; train = training-step samples/s (secondary)")
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=256,
-                    help="blocks per GPU in the timed region (the 1024^3 volume is 512 blocks; the segmentation of the last\n"
-                         "blocks drains after the last predict, ~0.1 s once per run, so short runs under-report)")
-    ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--precision", default="bf16", choices=["bf16", "f32"])
+    ap.add_argument("--steps", type=int, default=64,
+                    help="128^3 blocks per GPU in the timed region: a box of blocks of the 1024^3 volume, the ranks' boxes stacked along z")
+    ap.add_argument("--warmup", type=int, default=2, help="blocks taken through the whole pipeline before the timed region")
+    ap.add_argument("--precision", default="bf16x3", choices=["bf16x3", "bf16", "f32"],
+                    help="bf16x3 (default): split bf16, within the 1e-4 parity gate; bf16: throughput mode (4e-3); f32: exact f32 MFMA")
     ap.add_argument("--volume", type=int, default=1024, help="edge of the synthetic cubic volume")
-    ap.add_argument("--seg-lanes", type=int, default=16)
-    ap.add_argument("--pred-lanes", type=int, default=1, help="U-Net replicas / predict streams per GPU")
-    ap.add_argument("--seg-cus", type=int, default=0, help="CUs reserved for the segmentation lanes (0: shared CUs)")
+    ap.add_argument("--seg-lanes", type=int, default=16, help="blocks of a segmentation stage in flight side by side")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="process-group backend for N > 1: nccl (= RCCL, the real thing) or gloo (rehearsal on a box with fewer GPUs)")
     ap.add_argument("--no-segment", action="store_true", help="predict only (diagnostic; not the headline metric)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--seg-stages", default="ws,agg", help="diagnostic: which segmentation stages the lanes run (ws, agg, or none: lane events only)")
-    ap.add_argument("--seg-burst", type=int, default=16,
-                    help="launch the segmentation of this many blocks together, one per lane, once the last of them is predicted\n"
-                         "(0: block by block).  The lanes then share the chip with the predict stream a fifth of the time\n"
-                         "instead of always (more than 20 lanes run out of hardware queues)")
+    ap.add_argument("--no-modes", action="store_true", help="skip the per-precision predict lines (speed and error of f32 / bf16x3 / bf16)")
+    ap.add_argument("--cpu-predict-blocks", type=int, default=2)
+    ap.add_argument("--cpu-segment-blocks", type=int, default=16)
     args = ap.parse_args()
     if args.mode == "train":
         if "--steps" not in sys.argv:
@@ -258,36 +258,27 @@ def main():
         local_rank %= torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    import torch.distributed as dist
     if world > 1:
-        import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if args.backend == "nccl":
             dist.init_process_group("nccl", device_id=dev)
         else:
             dist.init_process_group("gloo")
 
-    from bootstrapper_amd.unet import Model
+    from bootstrapper_amd.unet import Model, extract_block_reflect
     from bootstrapper_amd.synth import synthetic_state_dict, synthetic_volume
-    from bootstrapper_amd.pipeline import BlockPipeline, block_grid
+    from bootstrapper_amd.volume import VolumePipeline
 
     sd = synthetic_state_dict(NET_CONFIG, 0)
-    models = [Model(NET_CONFIG, device=local_rank, precision=args.precision).load_state_dict(sd)
-              for _ in range(max(1, args.pred_lanes))]
-    model = models[0]
+    model = Model(NET_CONFIG, device=local_rank, precision=args.precision).load_state_dict(sd)
     in_block = tuple(o + 2 * c for o, c in zip(OUT_BLOCK, CONTEXT))
     flops_block = model.flops(in_block)
     nvox_block = int(np.prod(OUT_BLOCK))
 
     vol_shape = (args.volume,) * 3
-    vol = synthetic_volume(vol_shape, seed=0, device=dev)  # every rank holds the same volume in HBM
-    grid = block_grid(vol_shape, OUT_BLOCK)
-    # interleaved block -> rank map (reference predict.py:46-49: worker_id % num_gpus)
-    n_warm = max(args.warmup, max(1, args.pred_lanes))
-    mine = [grid[(rank + i * world) % len(grid)] for i in range(n_warm + args.steps)]
-
-    pipe = BlockPipeline(model, OUT_BLOCK, CONTEXT, THRESHOLDS, n_seg_lanes=args.seg_lanes,
-                         segment=not args.no_segment, device=local_rank, models=models, seg_cus=args.seg_cus,
-                         seg_stages=tuple(args.seg_stages.split(",")), seg_burst=args.seg_burst)
+    vol = synthetic_volume(vol_shape, seed=0, device=dev)  # the input store: every rank reads its blocks (+ halo) from it
+    job = job_blocks_for(args.steps)
 
     def barrier():
         torch.cuda.synchronize(dev)
@@ -295,61 +286,94 @@ def main():
             dist.barrier()
         torch.cuda.synchronize(dev)
 
-    # warmup (also allocates every workspace and the profiling events)
-    for m in models:
-        m.profile(True)
-    pipe.run(vol, mine[:n_warm])
-    pipe.finish()
-    for m in models:
-        m.profile_totals(reset=True)
+    # warm-up: `warmup` blocks through every stage (kernel images, workspaces of the block shapes, process-group channels)
+    warm = VolumePipeline(model, OUT_BLOCK, CONTEXT, (1, 1, max(1, args.warmup)), SEG_CONTEXT, THRESHOLDS, n_lanes=args.seg_lanes,
+                          device=local_rank, rank=rank, world=world, segment=not args.no_segment)
+    warm.run(vol)
+    del warm
+    pipe = VolumePipeline(model, OUT_BLOCK, CONTEXT, job, SEG_CONTEXT, THRESHOLDS, n_lanes=args.seg_lanes, device=local_rank,
+                          rank=rank, world=world, segment=not args.no_segment)
+    model.profile(True)
+    model.profile_totals(reset=True)
     barrier()
     t0 = time.perf_counter()
-    pipe.run(vol, mine[n_warm:])
-    pipe.finish()
+    segs = pipe.run(vol)
     barrier()
     dt = time.perf_counter() - t0
-    totals = None
-    for m in models:
-        t = m.profile_totals(reset=True)
-        m.profile(False)
-        totals = t if totals is None else {k: tuple(a + b for a, b in zip(totals[k], t[k])) for k in t}
+    totals = model.profile_totals(reset=True)
+    model.profile(False)
+    t_pred, t_seg = pipe.t_predict, pipe.t_segment
 
     if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev if args.backend == "nccl" else "cpu")
+        t = torch.tensor([dt, t_pred, t_seg], dtype=torch.float64, device=dev if args.backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+        dt, t_pred, t_seg = (float(v) for v in t.tolist())
 
     conv_ms, conv_flops, conv_launches = totals["conv"]
+    peak = MFMA_PEAK_TFLOPS[args.precision]
     traffic, traffic_src = pmc_traffic(args.precision)
     achieved = conv_flops / (conv_ms * 1e-3) / 1e12 if conv_ms > 0 else 0.0
-    value = world * args.steps * nvox_block / dt / 1e6
+    nvox = world * args.steps * nvox_block
+    value = nvox / dt / 1e6
     out = {
         "metric": "Mvoxels/s predict+segment, 1024^3 vol in 128^3 blocks" if not args.no_segment else "Mvoxels/s predict only (diagnostic)",
         "value": value, "unit": "Mvoxels/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": args.precision, "data": "synthetic",
-        "config": {"workload": f"synthetic {args.volume}^3 uint8 volume, 128^3 output blocks (156,220,220 reads, reflect padded), "
-                               "3d_affs U-Net (94.7M params, seeded random weights) + xy seeded watershed + mean-affinity "
-                               "agglomeration at [0.2,0.35,0.5]",
-                   "blocks_per_gpu": args.steps, "parallelism": f"blocks interleaved over {world} GPU(s), no collectives",
-                   "seg_lanes": args.seg_lanes, "pred_lanes": len(models), "seg_cus": pipe.seg_cus, "seg_burst": pipe.seg_burst},
-        "roofline": {"bound": "mfma", "achieved": achieved, "peak": BF16_DENSE_PEAK_TFLOPS if args.precision == "bf16" else 157.3,
-                     "unit": "TFLOP/s", "frac": achieved / (BF16_DENSE_PEAK_TFLOPS if args.precision == "bf16" else 157.3),
+        "config": {"workload": f"box of {job[0] * world}x{job[1]}x{job[2]} 128^3 output blocks of a synthetic {args.volume}^3 uint8 volume "
+                               "(156,220,220 reads, reflect padded): 3d_affs U-Net (94.7M params, seeded random weights) -> uint8 affinities -> "
+                               "per block: xy seeded watershed on the 160^3 read box (context 16), crop, 26-connected relabel, node statistics, "
+                               "RAG edge scoring (mean affinity, 256-bin queue) -> global connected components at [0.2,0.35,0.5] -> LUT -> "
+                               "relabel: one consistent segmentation per threshold",
+                   "blocks_per_gpu": args.steps, "job_blocks_per_gpu": list(job),
+                   "parallelism": f"slabs of block layers over {world} GPU(s); face exchange of affinities and fragments, edges to rank 0, LUT broadcast",
+                   "seg_lanes": args.seg_lanes},
+        "predict_only": {"Mvoxels_per_s": nvox / t_pred / 1e6, "seconds": t_pred, "mfma_frac": flops_block * world * args.steps / t_pred / 1e12 / peak},
+        "roofline": {"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
+                     "peak_note": MFMA_PEAK_NOTE[args.precision],
                      "traffic": traffic, "traffic_unit": "bytes per launch (memory side of L2, Infinity-Cache hits included)",
                      "traffic_source": traffic_src,
-                     "mfma_busy": pmc_mfma_busy(args.precision), "mfma_busy_source": os.path.relpath(SQ_PROFILE, ROOT),
-                     "kernel": "bsmi::conv_igemm_kernel / conv_igemm_sk_kernel / first_pass_kernel (all convolution launches of the U-Net)",
+                     "kernel": "bsmi::conv_igemm_kernel / conv_igemm_sk_kernel (all convolution launches of the U-Net)",
                      "launches": int(conv_launches), "avg_launch_ms": conv_ms / max(conv_launches, 1),
                      "algorithmic_tflop_per_block": flops_block / 1e12,
                      "other_unet_ms_per_block": sum(totals[k][0] for k in ("input", "pool", "upsample", "head")) / max(args.steps, 1)},
     }
+    if not args.no_segment:
+        seg_vox_s = nvox / t_seg
+        out["segment_only"] = {"Mvoxels_per_s": seg_vox_s / 1e6, "seconds": t_seg, "bytes_per_voxel": 38,
+                               "hbm_frac": 38.0 * seg_vox_s / world / HBM_PEAK_BYTES,
+                               "fragments": int(len(pipe.seg.nodes)), "segments": [int(len(np.unique(c))) for c in pipe.seg.luts]}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        # affinities of one block for the CPU segment sample
-        raw = torch.empty(0)
-        from bootstrapper_amd.unet import extract_block_reflect
-        raw = extract_block_reflect(vol, [o - c for o, c in zip(mine[0], CONTEXT)], in_block)
-        affs = model.predict_u8(raw)[0][:3].cpu().numpy()
-        out["cpu_baseline"] = cpu_baseline(flops_block / nvox_block, affs)
+        nb = max(1, min(args.cpu_predict_blocks, args.steps))
+        raws = [extract_block_reflect(vol, [o + lo - c for o, lo, c in zip(pipe.origin, b, CONTEXT)], in_block)
+                for b, _ in pipe.seg.boxes[:nb]]
+        sj = job_blocks_for(max(1, min(args.cpu_segment_blocks, args.steps)))
+        sj = tuple(min(a, b) for a, b in zip(sj, job))
+        affs = pipe.seg.interior(pipe.seg.affs)[:, :sj[0] * 128, :sj[1] * 128, :sj[2] * 128].contiguous().cpu().numpy()
+        out["cpu_baseline"], cpu_outs = cpu_baseline([r.cpu().numpy() for r in raws], affs, sj[0] * sj[1] * sj[2])
+        if not args.no_segment:
+            out["segment_only"]["gpu_over_cpu"] = out["segment_only"]["Mvoxels_per_s"] / out["cpu_baseline"]["segment_Mvox_s"]
+        out["predict_only"]["gpu_over_cpu"] = out["predict_only"]["Mvoxels_per_s"] * 1e3 / out["cpu_baseline"]["predict_kvox_s"]
+        if not args.no_modes:
+            # speed / accuracy of every precision mode on the same blocks, errors against the CPU fp32 restatement
+            modes = {}
+            for prec in ("f32", "bf16x3", "bf16"):
+                model.set_precision(prec)
+                err = 0.0
+                for raw, ref in zip(raws, cpu_outs):
+                    _, f32 = model.predict_u8(raw, want_f32=True)
+                    err = max(err, float((f32[0].cpu() - torch.from_numpy(ref)).abs().max()))
+                torch.cuda.synchronize(dev)
+                t1 = time.perf_counter()
+                reps = 4
+                for i in range(reps):
+                    model.predict_u8(raws[i % len(raws)])
+                torch.cuda.synchronize(dev)
+                ms = (time.perf_counter() - t1) / reps * 1e3
+                modes[prec] = {"ms_per_block": ms, "Mvoxels_per_s": nvox_block / ms / 1e3, "tflops": flops_block / ms / 1e9,
+                               "max_abs_err_vs_cpu_fp32": err, "within_1e-4": err < 1e-4}
+            model.set_precision(args.precision)
+            out["modes"] = modes
     if rank == 0:
         print(json.dumps(out), flush=True)
     if world > 1:

@@ -95,7 +95,7 @@ min_seed_distance = 4
         run_segmentation(str(seg_cfg), "ws", blockwise=True, param=())
 
 
-from tests.blockwise_ref import pad_read as _pad_read, cpu_blockwise as _cpu_blockwise  # noqa: E402
+from oracle.blockwise_ref import pad_read as _pad_read, cpu_blockwise as _cpu_blockwise  # noqa: E402
 
 
 def test_blockwise_segmentation_driver(tmp_path):

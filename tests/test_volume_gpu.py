@@ -1,5 +1,5 @@
 """bootstrapper_amd.volume: a slab of blocks taken through fragments -> RAG scoring -> global components -> relabel on
-the device, bit-equal to the blockwise pipeline composed from the CPU oracle (tests/blockwise_ref.py), alone and split
+the device, bit-equal to the blockwise pipeline composed from the CPU oracle (oracle/blockwise_ref.py), alone and split
 over two ranks; and the whole predict + segment pipeline on a small network.  Needs an MI355X."""
 import json
 import os
@@ -28,7 +28,7 @@ def blobby_affs(shape, seed, empty_corner=True):
 @pytest.mark.parametrize("shape,block,ctx,lanes", [((20, 150, 130), (8, 64, 64), (1, 8, 8), 5), ((24, 96, 96), (8, 32, 32), (2, 4, 4), 16)])
 def test_slab_segmenter_equals_cpu_blockwise(shape, block, ctx, lanes):
     from bootstrapper_amd.volume import SlabSegmenter
-    from tests.blockwise_ref import cpu_blockwise
+    from oracle.blockwise_ref import cpu_blockwise
     affs = blobby_affs(shape, 21)
     thr = [0.3, 0.45]
     frags_ref, nodes, E, Sc, segs_ref = cpu_blockwise(affs, block, ctx, 4, 0.35, 12, thr)
@@ -72,7 +72,7 @@ def test_volume_pipeline_small_net(golden_dir):
     model predicts one by one, and the segmentation is the CPU composition applied to them."""
     from bootstrapper_amd.unet import Model, extract_block_reflect
     from bootstrapper_amd.volume import VolumePipeline
-    from tests.blockwise_ref import cpu_blockwise
+    from oracle.blockwise_ref import cpu_blockwise
     d = np.load(os.path.join(golden_dir, "unet_affs_f4i2.npz"))
     sd = {k[2:]: d[k] for k in d.files if k.startswith("w:")}
     nc = {"in_channels": 1, "num_fmaps": 4, "fmap_inc_factor": 2, "downsample_factors": [[1, 2, 2]] * 3,

@@ -30,7 +30,7 @@ def main():
     parts = [None] * world if rank == 0 else None
     dist.gather_object(mine, parts, dst=0)
     if rank == 0:
-        from tests.blockwise_ref import cpu_blockwise
+        from oracle.blockwise_ref import cpu_blockwise
         frags2 = np.concatenate([p[0] for p in parts], axis=0)
         segs2 = np.concatenate([p[1] for p in parts], axis=1)
         one = SlabSegmenter(shape, block, ctx, layers, 0, thr, True, 4, 0.35, 12, 256, n_lanes=4)
