@@ -106,18 +106,23 @@ def host_cores():
     return max(1, min(n, int(os.environ.get("BSMI_BENCH_CORES", "16"))))
 
 
-def job_blocks_for(steps):
-    """(layers, blocks in y, blocks in x) with layers * y * x == steps, as cubic as the factors allow, layers smallest
-    (ranks stack their slabs along z)."""
-    best = (1, 1, steps)
-    for a in range(1, int(round(steps ** (1 / 3))) + 2):
-        if steps % a:
+def job_blocks_for(steps, max_edge=8):
+    """(layers, blocks in y, blocks in x) with layers * y * x == steps: the box of blocks a rank takes.  A block can be
+    segmented once the next layer of blocks is predicted, so the cross-section y * x is kept as small as the factors allow
+    while the box still fits the volume (`max_edge` blocks per axis: 1024 / 128); the ranks stack their boxes along z."""
+    best = None
+    for gx in range(1, steps + 1):
+        if steps % gx:
             continue
-        r = steps // a
-        for b in range(a, int(r ** 0.5) + 1):
-            if r % b == 0 and (r // b) - a < best[2] - best[0]:
-                best = (a, b, r // b)
-    return best
+        for gy in range(gx, steps // gx + 1):
+            if (steps // gx) % gy:
+                continue
+            gz = steps // gx // gy
+            fits = gz <= max_edge and gy <= max_edge
+            key = (not fits, gy * gx, gy - gx)
+            if best is None or key < best[0]:
+                best = (key, (gz, gy, gx))
+    return best[1]
 
 
 def cpu_baseline(raw_blocks, affs_u8_host, seg_blocks):
@@ -236,6 +241,8 @@ def main():
     ap.add_argument("--seg-lanes", type=int, default=16, help="blocks of a segmentation stage in flight side by side")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="process-group backend for N > 1: nccl (= RCCL, the real thing) or gloo (rehearsal on a box with fewer GPUs)")
+    ap.add_argument("--overlap", action="store_true",
+                    help="start a block's segmentation as soon as the blocks it reads are predicted (default: stage by stage; measured equal)")
     ap.add_argument("--no-segment", action="store_true", help="predict only (diagnostic; not the headline metric)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-modes", action="store_true", help="skip the per-precision predict lines (speed and error of f32 / bf16x3 / bf16)")
@@ -287,12 +294,12 @@ def main():
         torch.cuda.synchronize(dev)
 
     # warm-up: `warmup` blocks through every stage (kernel images, workspaces of the block shapes, process-group channels)
-    warm = VolumePipeline(model, OUT_BLOCK, CONTEXT, (1, 1, max(1, args.warmup)), SEG_CONTEXT, THRESHOLDS, n_lanes=args.seg_lanes,
+    warm = VolumePipeline(model, OUT_BLOCK, CONTEXT, (max(1, args.warmup), 1, 1), SEG_CONTEXT, THRESHOLDS, n_lanes=args.seg_lanes,
                           device=local_rank, rank=rank, world=world, segment=not args.no_segment)
     warm.run(vol)
     del warm
     pipe = VolumePipeline(model, OUT_BLOCK, CONTEXT, job, SEG_CONTEXT, THRESHOLDS, n_lanes=args.seg_lanes, device=local_rank,
-                          rank=rank, world=world, segment=not args.no_segment)
+                          rank=rank, world=world, segment=not args.no_segment, overlap=args.overlap)
     model.profile(True)
     model.profile_totals(reset=True)
     barrier()
@@ -302,7 +309,19 @@ def main():
     dt = time.perf_counter() - t0
     totals = model.profile_totals(reset=True)
     model.profile(False)
-    t_pred, t_seg = pipe.t_predict, pipe.t_segment
+    t_pred, t_seg = pipe.t_predict, 0.0
+    if not args.no_segment:
+        # the segmentation half on its own (outside the timed region: there it overlaps the predict stream): the same
+        # slab of affinities again, from fragments to the relabelled volumes; must reproduce the timed run's result
+        first = segs.clone()
+        barrier()
+        t1 = time.perf_counter()
+        again = pipe.seg.run()
+        barrier()
+        t_seg = time.perf_counter() - t1
+        if not torch.equal(first, again):
+            raise SystemExit("the segmentation-only pass does not reproduce the segmentation of the timed run")
+        del first, again
 
     if world > 1:
         t = torch.tensor([dt, t_pred, t_seg], dtype=torch.float64, device=dev if args.backend == "nccl" else "cpu")
@@ -327,8 +346,9 @@ def main():
                                "relabel: one consistent segmentation per threshold",
                    "blocks_per_gpu": args.steps, "job_blocks_per_gpu": list(job),
                    "parallelism": f"slabs of block layers over {world} GPU(s); face exchange of affinities and fragments, edges to rank 0, LUT broadcast",
-                   "seg_lanes": args.seg_lanes},
-        "predict_only": {"Mvoxels_per_s": nvox / t_pred / 1e6, "seconds": t_pred, "mfma_frac": flops_block * world * args.steps / t_pred / 1e12 / peak},
+                   "seg_lanes": args.seg_lanes, "overlap": bool(args.overlap)},
+        "predict_only": {"Mvoxels_per_s": nvox / t_pred / 1e6, "seconds": t_pred, "mfma_frac": flops_block * args.steps / t_pred / 1e12 / peak,
+                         "note": "start of the timed region to the last predicted block" + ("; the segmentation lanes already run meanwhile" if args.overlap else "")},
         "roofline": {"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
                      "peak_note": MFMA_PEAK_NOTE[args.precision],
                      "traffic": traffic, "traffic_unit": "bytes per launch (memory side of L2, Infinity-Cache hits included)",
@@ -340,7 +360,8 @@ def main():
     }
     if not args.no_segment:
         seg_vox_s = nvox / t_seg
-        out["segment_only"] = {"Mvoxels_per_s": seg_vox_s / 1e6, "seconds": t_seg, "bytes_per_voxel": 38,
+        out["segment_only"] = {"note": "separate pass over the same affinities after the timed region (fragments -> relabelled volumes)",
+                               "Mvoxels_per_s": seg_vox_s / 1e6, "seconds": t_seg, "bytes_per_voxel": 38,
                                "hbm_frac": 38.0 * seg_vox_s / world / HBM_PEAK_BYTES,
                                "fragments": int(len(pipe.seg.nodes)), "segments": [int(len(np.unique(c))) for c in pipe.seg.luts]}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

@@ -701,26 +701,34 @@ struct Planner {
 static void free_plan(Plan* p) {
   for (void* a : p->allocs) (void)hipFree(a);
   p->allocs.clear();
-  for (hipEvent_t e : p->events) (void)hipEventDestroy(e);
+  for (auto* sets : {&p->inflight, &p->spare})
+    for (auto& set : *sets)
+      for (hipEvent_t e : set) (void)hipEventDestroy(e);
+  p->inflight.clear();
+  p->spare.clear();
   p->events.clear();
 }
 
-// Wait for the events of the last profiled forward of `plan` and fold them into the totals.
+// Wait for the events of the profiled forwards of `plan` that have not been read yet and fold them into the totals.
 static int harvest(bsmi_unet* h, Plan* plan) {
-  if (!plan || !plan->pending) return BSMI_OK;
+  if (!plan || plan->inflight.empty()) return BSMI_OK;
   const size_t n = plan->steps.size();
-  plan->last_ms.assign(n, 0.f);
-  BSMI_HIP(hipEventSynchronize(plan->events[2 * n - 1]));
-  for (size_t i = 0; i < n; ++i) {
-    float t = 0.f;
-    BSMI_HIP(hipEventElapsedTime(&t, plan->events[2 * i], plan->events[2 * i + 1]));
-    plan->last_ms[i] = t;
-    // with the fused first pass, steps 0 and 1 launch nothing: their work is done (and timed) in step 2
-    const int ty = (plan->fused_first && i < 2) ? (int)PlanStep::CONV : (int)plan->steps[i].type;
-    h->prof_ms[ty] += t;
-    h->prof_flops[ty] += plan->steps[i].flops;
-    h->prof_launches[ty] += (plan->fused_first && i < 2) ? 0 : 1;
+  for (auto& set : plan->inflight) {
+    plan->last_ms.assign(n, 0.f);
+    BSMI_HIP(hipEventSynchronize(set[2 * n - 1]));
+    for (size_t i = 0; i < n; ++i) {
+      float t = 0.f;
+      BSMI_HIP(hipEventElapsedTime(&t, set[2 * i], set[2 * i + 1]));
+      plan->last_ms[i] = t;
+      // with the fused first pass, steps 0 and 1 launch nothing: their work is done (and timed) in step 2
+      const int ty = (plan->fused_first && i < 2) ? (int)PlanStep::CONV : (int)plan->steps[i].type;
+      h->prof_ms[ty] += t;
+      h->prof_flops[ty] += plan->steps[i].flops;
+      h->prof_launches[ty] += (plan->fused_first && i < 2) ? 0 : 1;
+    }
+    plan->spare.push_back(std::move(set));
   }
+  plan->inflight.clear();
   plan->pending = false;
   return BSMI_OK;
 }
@@ -1022,17 +1030,24 @@ int bsmi_unet_forward(bsmi_unet* h, int precision, const void* raw_dev, int raw_
   rc = get_plan(h, precision, in_shape, &plan_ptr);
   if (rc) return rc;
   Plan& plan = *plan_ptr;
-  if (h->profiling) {
-    rc = harvest(h, &plan);  // previous forward on this plan must be read before its events are reused
-    if (rc) return rc;
-  }
   h->last_plan = &plan;
   plan.profiled = h->profiling;
   plan.pending = h->profiling;
-  if (h->profiling && plan.events.size() != 2 * plan.steps.size()) {
-    for (hipEvent_t e : plan.events) (void)hipEventDestroy(e);
-    plan.events.assign(2 * plan.steps.size(), nullptr);
-    for (auto& e : plan.events) BSMI_HIP(hipEventCreate(&e));
+  if (h->profiling) {
+    // a fresh set of events for this forward: recording must not wait for an earlier forward to finish (the caller may
+    // have many blocks in flight); bsmi_unet_profile_read / _totals read the sets
+    const size_t n_ev = 2 * plan.steps.size();
+    if (plan.inflight.size() >= 4096) {  // nobody reads: do not grow without bound
+      rc = harvest(h, &plan);
+      if (rc) return rc;
+    }
+    if (!plan.spare.empty() && plan.spare.back().size() == n_ev) {
+      plan.events = std::move(plan.spare.back());
+      plan.spare.pop_back();
+    } else {
+      plan.events.assign(n_ev, nullptr);
+      for (auto& e : plan.events) BSMI_HIP(hipEventCreate(&e));
+    }
   }
   if (!h->sk_grid) {
     const char* e = getenv("BSMI_STREAMK");
@@ -1097,6 +1112,7 @@ int bsmi_unet_forward(bsmi_unet* h, int precision, const void* raw_dev, int raw_
     if (h->profiling) BSMI_HIP(hipEventRecord(plan.events[2 * step_idx + 1], s));
     ++step_idx;
   }
+  if (h->profiling) plan.inflight.push_back(std::move(plan.events));
   return BSMI_OK;
 }
 

@@ -100,7 +100,11 @@ struct Plan {
   int64_t out_shape[3] = {0, 0, 0};
   double flops = 0;
   size_t bytes = 0;
-  std::vector<hipEvent_t> events;  // 2 per step, created on demand (profiling)
+  // Profiling: a set of 2 events per step for every profiled forward that has not been read yet (`inflight`, oldest
+  // first), so that recording never waits for an earlier forward; read sets go back to `spare`.  `events` is the set of
+  // the forward being recorded.
+  std::vector<hipEvent_t> events;
+  std::vector<std::vector<hipEvent_t>> inflight, spare;
   bool profiled = false;           // last forward recorded events
   bool fused_first = false;        // steps 0..2 (INPUT, CONV, CONV of l_conv.0) run as one first_pass launch
   int prec = 0;                    // precision the plan was built for

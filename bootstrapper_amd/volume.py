@@ -120,7 +120,7 @@ class SlabSegmenter:
         self.rank, self.world, self.group = int(rank), int(world), group
         self.dev = torch.device("cuda", int(device))
         self.boxes = shrink_blocks(self.shape, self.block)
-        counts = [-(-s // b) for s, b in zip(self.shape, self.block)]
+        counts = self.counts = [-(-s // b) for s, b in zip(self.shape, self.block)]
         # global z-major block ids (`block.block_id` of the reference's tasks; daisy numbers differently)
         self.block_ids = [((int(layer0) + iz) * counts[1] + iy) * counts[2] + ix
                           for iz in range(counts[0]) for iy in range(counts[1]) for ix in range(counts[2])]
@@ -137,7 +137,8 @@ class SlabSegmenter:
         self.sums = torch.zeros((K, self.label_cap, 3), dtype=torch.int64, device=self.dev)
         self.edges = torch.empty((K, self.edge_cap, 2), dtype=torch.int64, device=self.dev)
         self.scores = torch.empty((K, self.edge_cap), dtype=torch.float32, device=self.dev)
-        self.counts = torch.zeros((K, 4), dtype=torch.int64, device=self.dev)
+        self.counts_dev = torch.zeros((K, 4), dtype=torch.int64, device=self.dev)
+        self.frag_done = [None] * K
         read = tuple(min(b, s) + 2 * c for b, s, c in zip(self.block, self.shape, self.ctx))
         self.lanes = []
         for _ in range(max(1, min(int(n_lanes), K))):
@@ -170,72 +171,141 @@ class SlabSegmenter:
 
     # -- exchange ------------------------------------------------------------------------
     def _exchange(self, t):
-        """context margins of `t` ([..., Zp, Yp, Xp]) at the slab's z faces <- the neighbours' outermost layers"""
+        """context margins of `t` ([..., Zp, Yp, Xp]) at the slab's z faces <- the neighbours' outermost layers.  The
+        caller has made sure those layers are complete; -> an event on the current stream that fires when the margins are."""
         c, Z = self.ctx[0], self.shape[0]
-        if self.world == 1 or c == 0:
-            return
-        torch.cuda.synchronize(self.dev)
-        exchange_faces(t[..., c:2 * c, :, :], t[..., Z:Z + c, :, :], t[..., 0:c, :, :], t[..., Z + c:Z + 2 * c, :, :],
-                       self.rank, self.world, self.group)
+        if self.world > 1 and c > 0:
+            exchange_faces(t[..., c:2 * c, :, :], t[..., Z:Z + c, :, :], t[..., 0:c, :, :], t[..., Z + c:Z + 2 * c, :, :],
+                           self.rank, self.world, self.group)
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream(self.dev))
+        return ev
 
     # -- stages --------------------------------------------------------------------------
-    def _after(self, event):
-        for lane in self.lanes:
-            if event is not None:
-                lane["stream"].wait_event(event)
-
     def _sync(self):
         for lane in self.lanes:
             lane["stream"].synchronize()
             lane["engine"].status()
 
-    def fragments(self, after=None):
-        """post/blockwise/watershed_frags.py:196-246 for every block of the slab (asynchronous on the lanes; ends
-        synchronised).  An all-zero read box yields no fragment, as the early return of the reference does."""
-        self._exchange(self.affs)
-        self._after(after)
-        for k, (b, e) in enumerate(self.boxes):
-            lane = self.lanes[k % len(self.lanes)]
-            wshape = tuple(hi - lo for lo, hi in zip(b, e))
-            rshape = tuple(w + 2 * c for w, c in zip(wshape, self.ctx))
-            with torch.cuda.stream(lane["stream"]):
-                a = self._buf(lane["a"], rshape, (3,))
-                a.copy_(self.affs[(slice(None),) + self._read_slices(k)])
-                eng = lane["engine"]
-                fr, _ = eng.ws_fragments(a, self.fragments_in_xy, self.msd)
-                lab = self._buf(lane["lab"], wshape)
-                eng.postprocess_fragments(a, fr, self.filter_fragments, self.remove_debris, self.ctx, wshape,
-                                          self.block_ids[k] * self.nvb, out=lab, num=self.nums[k:k + 1])
-                self.frags[tuple(slice(c + lo, c + hi) for c, lo, hi in zip(self.ctx, b, e))].copy_(lab)
-                eng.label_stats(lab, self.block_ids[k] * self.nvb, self.label_cap, size=self.sizes[k], sums=self.sums[k])
+    def _neighbours(self, k):
+        """blocks whose write box touches the read box of block k (k itself included)"""
+        cy, cx = self.counts[1], self.counts[2]
+        iz, r = divmod(k, cy * cx)
+        iy, ix = divmod(r, cx)
+        out = []
+        for dz in (-1, 0, 1):
+            for dy in (-1, 0, 1):
+                for dx in (-1, 0, 1):
+                    z, y, x = iz + dz, iy + dy, ix + dx
+                    if 0 <= z < self.counts[0] and 0 <= y < cy and 0 <= x < cx:
+                        out.append((z * cy + y) * cx + x)
+        return out
+
+    def _on_face(self, k):
+        """does block k read context that belongs to another rank's slab?"""
+        iz = k // (self.counts[1] * self.counts[2])
+        return self.ctx[0] > 0 and ((self.rank > 0 and iz == 0) or (self.rank < self.world - 1 and iz == self.counts[0] - 1))
+
+    def _launch_fragments(self, k, wait=()):
+        """post/blockwise/watershed_frags.py:196-246 for block k, asynchronous on its lane.  An all-zero read box yields
+        no fragment, as the early return of the reference does."""
+        b, e = self.boxes[k]
+        lane = self.lanes[k % len(self.lanes)]
+        wshape = tuple(hi - lo for lo, hi in zip(b, e))
+        rshape = tuple(w + 2 * c for w, c in zip(wshape, self.ctx))
+        with torch.cuda.stream(lane["stream"]):
+            for ev in wait:
+                lane["stream"].wait_event(ev)
+            a = self._buf(lane["a"], rshape, (3,))
+            a.copy_(self.affs[(slice(None),) + self._read_slices(k)])
+            eng = lane["engine"]
+            fr, _ = eng.ws_fragments(a, self.fragments_in_xy, self.msd)
+            lab = self._buf(lane["lab"], wshape)
+            eng.postprocess_fragments(a, fr, self.filter_fragments, self.remove_debris, self.ctx, wshape,
+                                      self.block_ids[k] * self.nvb, out=lab, num=self.nums[k:k + 1])
+            self.frags[tuple(slice(c + lo, c + hi) for c, lo, hi in zip(self.ctx, b, e))].copy_(lab)
+            eng.label_stats(lab, self.block_ids[k] * self.nvb, self.label_cap, size=self.sizes[k], sums=self.sums[k])
+            self.frag_done[k] = torch.cuda.Event()
+            self.frag_done[k].record(lane["stream"])
+
+    def _launch_scores(self, k, wait=()):
+        """post/blockwise/waterz_agglom.py:106-170 for block k, asynchronous on its lane"""
+        b, e = self.boxes[k]
+        lane = self.lanes[k % len(self.lanes)]
+        rshape = tuple(hi - lo + 2 * c for lo, hi, c in zip(b, e, self.ctx))
+        with torch.cuda.stream(lane["stream"]):
+            for ev in wait:
+                lane["stream"].wait_event(ev)
+            a = self._buf(lane["a"], rshape, (3,))
+            a.copy_(self.affs[(slice(None),) + self._read_slices(k)])
+            f = self._buf(lane["f"], rshape)
+            f.copy_(self.frags[self._read_slices(k)])
+            lane["engine"].rag_merge_scores_async(a, f, 1.0, self.bins, self.edges[k], self.scores[k], self.counts_dev[k])
+
+    def _collect(self):
+        """end of the two block stages: one synchronisation, overflow checks, the edges every block owns (the block that
+        created the smaller-id fragment, see post/blockwise.py) to the host"""
         self._sync()
         nums = self.nums.cpu().numpy()
         if nums.max(initial=0) > self.label_cap or nums.max(initial=0) >= self.nvb:
             raise _lib.BsmiError(_lib.ERR_OVERFLOW, f"a block produced {int(nums.max())} fragments (label_cap {self.label_cap})")
         self.block_nums = nums
-        return nums
-
-    def score_edges(self):
-        """post/blockwise/waterz_agglom.py:106-170 for every block; keeps the edges each block owns (the block that
-        created the smaller-id fragment, see post/blockwise.py).  Ends synchronised; -> number of edges kept."""
-        self._exchange(self.frags)
-        for k, (b, e) in enumerate(self.boxes):
-            lane = self.lanes[k % len(self.lanes)]
-            rshape = tuple(hi - lo + 2 * c for lo, hi, c in zip(b, e, self.ctx))
-            with torch.cuda.stream(lane["stream"]):
-                a = self._buf(lane["a"], rshape, (3,))
-                a.copy_(self.affs[(slice(None),) + self._read_slices(k)])
-                f = self._buf(lane["f"], rshape)
-                f.copy_(self.frags[self._read_slices(k)])
-                lane["engine"].rag_merge_scores_async(a, f, 1.0, self.bins, self.edges[k], self.scores[k], self.counts[k])
-        self._sync()
-        ne = self.counts[:, 0]
+        ne = self.counts_dev[:, 0]
         take = torch.arange(self.edge_cap, device=self.dev)[None, :] < ne[:, None]
         bid = torch.tensor(self.block_ids, dtype=torch.int64, device=self.dev)[:, None].expand(-1, self.edge_cap)
         own = take & (torch.div(self.edges[:, :, 0] - 1, self.nvb, rounding_mode="floor") == bid)
         self.rag_edges = self.edges[own].cpu().numpy().view(np.uint64)
         self.rag_scores = self.scores[own].cpu().numpy()
         return len(self.rag_scores)
+
+    def run_blocks(self, ready=None, overlap=False):
+        """Both block stages of the slab.  ready[k]: an event that fires when the affinities of blocks 0..k are in the
+        slab (None: they all are).  overlap = False: stage by stage, once every block is predicted.  overlap = True: a
+        block's fragments start as soon as the blocks its read box touches are predicted, its edge scoring as soon as
+        their fragments are there, so the lanes work while the predict stream still runs (measured on the benchmark:
+        the predict stream then loses about as much as the lanes gain -- its persistent conv workgroups want whole CUs --
+        so this is not the default).  The blocks at a slab face shared with another rank wait for the exchange of that face."""
+        K = len(self.boxes)
+        last = [max(self._neighbours(k)) for k in range(K)]
+        face = [k for k in range(K) if self._on_face(k)]
+        inner = [k for k in range(K) if not self._on_face(k)]
+        inner_set = set(inner)
+        if ready is None:  # whatever filled the slab did so on the current stream
+            here = torch.cuda.Event()
+            here.record(torch.cuda.current_stream(self.dev))
+            ready = [here] * K
+        # Launch order = dependency order: a lane is an in-order stream, so a block's edge scoring is queued as soon as the
+        # fragments of every block it reads have been queued, not behind fragments that wait for later predictions.
+        nb = [self._neighbours(k) for k in range(K)]
+        queued, scored = set(), set()
+
+        def score_what_can_be(candidates, extra=()):
+            for j in candidates:
+                if j not in scored and all(i in queued for i in nb[j]):
+                    self._launch_scores(j, list(extra) + [self.frag_done[i] for i in nb[j]])
+                    scored.add(j)
+        for k in inner:
+            self._launch_fragments(k, (ready[last[k] if overlap else K - 1],))
+            queued.add(k)
+            if overlap:
+                score_what_can_be([j for j in nb[k] if j in inner_set])
+        if face:
+            ready[K - 1].synchronize()
+            got = self._exchange(self.affs)
+            for k in face:
+                self._launch_fragments(k, (got,))
+                queued.add(k)
+                if overlap:
+                    score_what_can_be([j for j in nb[k] if j in inner_set])
+        score_what_can_be(inner)
+        if face:
+            for k in range(K):     # the outermost layers feed the neighbours' context
+                iz = k // (self.counts[1] * self.counts[2])
+                if iz == 0 or iz == self.counts[0] - 1:
+                    self.frag_done[k].synchronize()
+            got = self._exchange(self.frags)
+            score_what_can_be(face, (got,))
+        return self._collect()
 
     def node_table(self):
         """RAG nodes of the slab's blocks {id, position (voxels of the slab), size} (watershed_frags.py:230-246)."""
@@ -269,9 +339,8 @@ class SlabSegmenter:
         torch.cuda.synchronize(self.dev)
         return self.segs
 
-    def run(self, after=None):
-        self.fragments(after)
-        self.score_edges()
+    def run(self, ready=None, overlap=False):
+        self.run_blocks(ready, overlap)
         return self.stitch()
 
 
@@ -280,7 +349,7 @@ class VolumePipeline:
 
     def __init__(self, model, out_block, net_context, job_blocks, seg_context=(16, 16, 16), thresholds=(0.2, 0.35, 0.5),
                  min_seed_distance=10, filter_fragments=0.0, remove_debris=0, n_lanes=16, device=0, rank=0, world=1,
-                 group=None, job_origin=(0, 0, 0), segment=True):
+                 group=None, job_origin=(0, 0, 0), segment=True, overlap=False):
         """job_blocks: (layers per rank, blocks in y, blocks in x): the job is `world` such slabs stacked along z,
         its first voxel at `job_origin` of the raw volume."""
         self.model = model
@@ -299,33 +368,33 @@ class VolumePipeline:
                                  self.job_blocks[0] * self.rank, thresholds, True, min_seed_distance, filter_fragments,
                                  remove_debris, 256, n_lanes if segment else 1, device, rank, world, group)
         self.segment = bool(segment)
-        self.t_predict = self.t_segment = 0.0
+        self.overlap = bool(overlap)
+        self.t_predict = 0.0
 
     def predict(self, volume_u8):
         """models/3d_affs/predict.py:128-162 for every block of the slab: reflect-padded read, U-Net, uint8 affinities
-        into the slab (first three channels: what the segmentation reads, post/watershed.py:70)."""
+        into the slab (first three channels: what the segmentation reads, post/watershed.py:70).  Asynchronous on the
+        predict stream; -> one event per block."""
         from .unet import extract_block_reflect
+        ready = []
         with torch.cuda.stream(self.pred_stream):
+            self._t0 = torch.cuda.Event(enable_timing=True)
+            self._t0.record(self.pred_stream)
             for k, (b, _) in enumerate(self.seg.boxes):
                 off = [o + lo - c for o, lo, c in zip(self.origin, b, self.net_context)]
                 raw = extract_block_reflect(volume_u8, off, self.in_block)
                 u8 = self.model.predict_u8(raw)
                 self.seg.write_view(k).copy_(u8[0][:3])
-            done = torch.cuda.Event()
-            done.record(self.pred_stream)
-        return done
+                ev = torch.cuda.Event(enable_timing=(k + 1 == len(self.seg.boxes)))
+                ev.record(self.pred_stream)
+                ready.append(ev)
+        return ready
 
     def run(self, volume_u8):
-        import time
-        t0 = time.perf_counter()
-        done = self.predict(volume_u8)
-        if not self.segment:
-            self.pred_stream.synchronize()
-            self.t_predict = time.perf_counter() - t0
-            return None
-        done.synchronize()
-        t1 = time.perf_counter()
-        segs = self.seg.run()
-        t2 = time.perf_counter()
-        self.t_predict, self.t_segment = t1 - t0, t2 - t1
+        """-> segs int64 [thresholds][Z][Y][X] of this rank's slab (None without segmentation).  t_predict: seconds until
+        the last block was predicted (the lanes already segment meanwhile)."""
+        ready = self.predict(volume_u8)
+        segs = self.seg.run(ready, self.overlap) if self.segment else None
+        ready[-1].synchronize()
+        self.t_predict = self._t0.elapsed_time(ready[-1]) * 1e-3
         return segs

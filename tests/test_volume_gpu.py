@@ -25,8 +25,10 @@ def blobby_affs(shape, seed, empty_corner=True):
     return affs
 
 
-@pytest.mark.parametrize("shape,block,ctx,lanes", [((20, 150, 130), (8, 64, 64), (1, 8, 8), 5), ((24, 96, 96), (8, 32, 32), (2, 4, 4), 16)])
-def test_slab_segmenter_equals_cpu_blockwise(shape, block, ctx, lanes):
+@pytest.mark.parametrize("shape,block,ctx,lanes,overlap", [((20, 150, 130), (8, 64, 64), (1, 8, 8), 5, False),
+                                                          ((24, 96, 96), (8, 32, 32), (2, 4, 4), 16, False),
+                                                          ((24, 96, 96), (8, 32, 32), (2, 4, 4), 3, True)])
+def test_slab_segmenter_equals_cpu_blockwise(shape, block, ctx, lanes, overlap):
     from bootstrapper_amd.volume import SlabSegmenter
     from oracle.blockwise_ref import cpu_blockwise
     affs = blobby_affs(shape, 21)
@@ -35,7 +37,7 @@ def test_slab_segmenter_equals_cpu_blockwise(shape, block, ctx, lanes):
     layers = -(-shape[0] // block[0])
     seg = SlabSegmenter(shape, block, ctx, layers, 0, thr, True, 4, 0.35, 12, 256, n_lanes=lanes)
     seg.interior(seg.affs).copy_(torch.from_numpy(affs).cuda())
-    segs = seg.run()
+    segs = seg.run(overlap=overlap)
     assert np.array_equal(seg.interior(seg.frags).cpu().numpy().view(np.uint64), frags_ref)
     assert np.array_equal(seg.nodes, nodes)
     # the same edges with the same scores, whatever the order the blocks delivered them in
@@ -86,7 +88,7 @@ def test_volume_pipeline_small_net(golden_dir):
     raw = gaussian_filter(rng.random((40, 120, 120)), sigma=(1, 3, 3))
     raw = torch.from_numpy(((raw - raw.min()) / (raw.max() - raw.min()) * 255).astype(np.uint8)).cuda()
     pipe = VolumePipeline(m, out_block, ctx, (3, 2, 2), seg_context=(1, 4, 4), thresholds=[0.3, 0.5], min_seed_distance=3,
-                          n_lanes=4, job_origin=(4, 8, 8))
+                          n_lanes=4, job_origin=(4, 8, 8), overlap=True)
     segs = pipe.run(raw)
     affs = pipe.seg.interior(pipe.seg.affs).cpu().numpy()
     k = 0
