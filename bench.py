@@ -52,6 +52,7 @@ OUT_BLOCK = (128, 128, 128)
 CONTEXT = (14, 46, 46)          # (input - output) / 2 of the 3-D nets (reference predict.py:127-131)
 SEG_CONTEXT = (16, 16, 16)      # block_size / 8 (reference post/watershed.py:79-83)
 THRESHOLDS = [0.2, 0.35, 0.5]   # reference segment.py:17
+FILTER_FRAGMENTS, REMOVE_DEBRIS = 0.1, 64   # reference segment.py:16 (`bs segment --ws` defaults)
 BF16_DENSE_PEAK_TFLOPS = 2500.0  # /opt/skills/guides/MI355X_MICROARCH.md, dense bf16 MFMA
 # what the conv kernels are priced against, per precision mode.  The split mode spends three bf16 MFMAs per product of the
 # algorithmic count, so its ceiling is a third of the dense bf16 peak.
@@ -149,7 +150,8 @@ def cpu_baseline(raw_blocks, affs_u8_host, seg_blocks):
     pred_vox_s = len(raw_blocks) * nvox / t_pred
 
     t0 = time.perf_counter()
-    _, nodes, E, _, segs = cpu_blockwise(affs_u8_host, OUT_BLOCK, SEG_CONTEXT, 10, 0.0, 0, THRESHOLDS, 256, workers=cores)
+    _, nodes, E, _, segs = cpu_blockwise(affs_u8_host, OUT_BLOCK, SEG_CONTEXT, 10, FILTER_FRAGMENTS, REMOVE_DEBRIS, THRESHOLDS, 256,
+                                         workers=cores)
     t_seg = time.perf_counter() - t0
     seg_vox_s = affs_u8_host[0].size / t_seg
     both = 1.0 / (1.0 / pred_vox_s + 1.0 / seg_vox_s)
@@ -294,12 +296,13 @@ def main():
         torch.cuda.synchronize(dev)
 
     # warm-up: `warmup` blocks through every stage (kernel images, workspaces of the block shapes, process-group channels)
+    seg_kw = dict(min_seed_distance=10, filter_fragments=FILTER_FRAGMENTS, remove_debris=REMOVE_DEBRIS)
     warm = VolumePipeline(model, OUT_BLOCK, CONTEXT, (max(1, args.warmup), 1, 1), SEG_CONTEXT, THRESHOLDS, n_lanes=args.seg_lanes,
-                          device=local_rank, rank=rank, world=world, segment=not args.no_segment)
+                          device=local_rank, rank=rank, world=world, segment=not args.no_segment, **seg_kw)
     warm.run(vol)
     del warm
     pipe = VolumePipeline(model, OUT_BLOCK, CONTEXT, job, SEG_CONTEXT, THRESHOLDS, n_lanes=args.seg_lanes, device=local_rank,
-                          rank=rank, world=world, segment=not args.no_segment, overlap=args.overlap)
+                          rank=rank, world=world, segment=not args.no_segment, overlap=args.overlap, **seg_kw)
     model.profile(True)
     model.profile_totals(reset=True)
     barrier()
@@ -341,7 +344,7 @@ def main():
         "vs_baseline": None, "dtype": args.precision, "data": "synthetic",
         "config": {"workload": f"box of {job[0] * world}x{job[1]}x{job[2]} 128^3 output blocks of a synthetic {args.volume}^3 uint8 volume "
                                "(156,220,220 reads, reflect padded): 3d_affs U-Net (94.7M params, seeded random weights) -> uint8 affinities -> "
-                               "per block: xy seeded watershed on the 160^3 read box (context 16), crop, 26-connected relabel, node statistics, "
+                               "per block: xy seeded watershed on the 160^3 read box (context 16), fragment filter 0.1 / debris 64, crop, 26-connected relabel, node statistics, "
                                "RAG edge scoring (mean affinity, 256-bin queue) -> global connected components at [0.2,0.35,0.5] -> LUT -> "
                                "relabel: one consistent segmentation per threshold",
                    "blocks_per_gpu": args.steps, "job_blocks_per_gpu": list(job),

@@ -20,7 +20,8 @@ def cli():
 @click.option("--roi-shape", "-rs", type=str, help="Shape of ROI in world units (space separated integers)")
 @click.option("--num-workers", "-nw", type=int, help="Number of workers")
 @click.option("--num-gpus", "-ng", type=int, help="Number of GPUs to use")
-@click.option("--precision", type=click.Choice(["bf16", "f32"]), default="bf16", show_default=True)
+@click.option("--precision", type=click.Choice(["bf16x3", "f32", "bf16"]), default="bf16x3", show_default=True,
+              help="bf16x3: split bf16, within 1e-4 of the fp32 reference; f32: exact f32 MFMA; bf16: throughput mode (4e-3)")
 def predict(config_file, setup_id, precision, **kwargs):
     """Run prediction for a setup or all setups in a prediction config file."""
     from .predict import run_prediction

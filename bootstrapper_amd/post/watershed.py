@@ -84,11 +84,31 @@ def connected_components(nodes, edges, scores, threshold):
     return out
 
 
-def waterz_pipeline(config, device=0):
-    """post/watershed.py:8-203.  Returns the list of datasets written (fragments first)."""
+def _fill_affinities(seg, affs, origin, z0, mask=None):
+    """The slab's affinities WITH their context margins straight from the dataset (`to_ndarray(read_roi, fill_value=0)`,
+    watershed_frags.py:196-201: zeros beyond the array, real data beyond the ROI), first three channels, masked."""
     import torch
-    from .blockwise import RagStore, WatershedFrags, WaterzAgglom
-    from .engine import lut_relabel
+    from .blockwise import read_with_fill
+    begin = tuple(o + lo - c for o, lo, c in zip(origin, (z0, 0, 0), seg.ctx))
+    end = tuple(b + s + 2 * c for b, s, c in zip(begin, seg.shape, seg.ctx))
+    a = read_with_fill(affs, begin, end, lead=(affs.shape[0],))[:3]
+    if a.shape[0] == 2:  # 2-channel affinities get an all-zero z channel (post/watershed.py:305-308)
+        a = np.concatenate([np.zeros_like(a[:1]), a])
+    t = torch.from_numpy(np.ascontiguousarray(a)).to(seg.dev)
+    if mask is not None:
+        m = read_with_fill(mask, begin, end)
+        t = t * torch.from_numpy((m > 0).astype(np.uint8)).to(seg.dev)
+    seg.affs.copy_(t)
+
+
+def waterz_pipeline(config, device=None, rank=0, world=1, group=None):
+    """post/watershed.py:8-203 for one worker of `world` (one slab of block layers each, bootstrapper_amd.volume):
+    blockwise fragments with context, per-block RAG edge scoring, global thresholded connected components, LUT, relabel.
+    Returns the list of datasets written (fragments first)."""
+    import torch
+    from ..blockwise import check_task_states, TaskState
+    from ..volume import SlabSegmenter, slab_layers
+    from .blockwise import RagStore
     from .naming import dump_lut_params
 
     affs = open_ds(config["affs_dataset"])
@@ -96,6 +116,8 @@ def waterz_pipeline(config, device=0):
         raise NotImplementedError("the device path takes uint8 affinities (what `bs predict` stores)")
     thresholds = config.get("thresholds", [0.2, 0.35, 0.5])
     merge_function = config.get("merge_function", "mean")
+    if merge_function != "mean":
+        raise NotImplementedError(f"merge_function {merge_function!r}: only 'mean' is implemented (the one the reference enables)")
     blockwise = config.get("blockwise", False)
     frag_params = {
         "fragments_in_xy": config.get("fragments_in_xy", True),
@@ -108,6 +130,10 @@ def waterz_pipeline(config, device=0):
         "filter_fragments": config.get("filter_fragments", 0.0),
         "remove_debris": config.get("remove_debris", 0),
     }
+    if frag_params["seed_eps"] is not None or frag_params["epsilon_agglomerate"] or any(
+            [frag_params["sigma"], frag_params["noise_eps"], frag_params["bias"]]):
+        raise NotImplementedError("seed_eps / epsilon_agglomerate / sigma / noise_eps / bias are not implemented on the device "
+                                  "(the reference defaults leave them off)")
     voxel_size = affs.voxel_size
     if config.get("roi_offset") is not None:
         roi = (list(config["roi_offset"]), list(config["roi_shape"]))
@@ -121,58 +147,117 @@ def waterz_pipeline(config, device=0):
         ctx = tuple(config["context"]) if config.get("context") else tuple(max(1, b // 8) for b in block_size)
     else:
         block_size, ctx = total_shape, (0, 0, 0)
-    block_size = tuple(min(int(b), t) for b, t in zip(block_size, total_shape))
+    block_size = tuple(int(b) for b in block_size)   # not clipped to the ROI: ids are block id * voxels of a whole block
 
+    device = rank % max(1, torch.cuda.device_count()) if device is None else device
+    layers = -(-total_shape[0] // block_size[0])
+    starts, counts = slab_layers(layers, world)
+    z0 = starts[rank] * block_size[0]
+    z1 = min(total_shape[0], (starts[rank] + counts[rank]) * block_size[0])
+    if z1 <= z0:
+        raise ValueError(f"{world} workers for {layers} layer(s) of blocks: use at most {layers}")
     mask = open_ds(config["mask_dataset"]) if config.get("mask_dataset") else None
-    rag = RagStore()
-    frags_vol = np.zeros(total_shape, dtype=np.uint64)
+    seg = SlabSegmenter((z1 - z0,) + total_shape[1:], block_size, ctx, layers, starts[rank], thresholds, frag_params["fragments_in_xy"],
+                        frag_params["min_seed_distance"], frag_params["filter_fragments"], frag_params["remove_debris"], 256,
+                        n_lanes=int(config.get("lanes", 8)), device=device, rank=rank, world=world, group=group, exchange_affs=False)
+    _fill_affinities(seg, affs, origin, z0, mask)
 
-    # fragments via seeded watershed (post/watershed.py:118-139)
-    frags_task = WatershedFrags(block_size, ctx, total_shape, device=device, origin=origin, **frag_params)
-    for b in range(len(frags_task.blocks)):
-        frags_task.watershed_in_block(b, affs, frags_vol, rag, offset=roi[0], voxel_size=voxel_size, mask=mask)
+    # fragments + edge scores of this worker's blocks (post/watershed.py:118-153), accounted like daisy tasks
+    states = seg.run_blocks_accounted()
+    if world > 1:
+        import torch.distributed as dist
+        mine = {k: v.as_tuple() for k, v in states.items()}
+        parts = [None] * world
+        dist.all_gather_object(parts, mine, group=group)
+        states = {k: TaskState(k) for k in mine}
+        for p in parts:
+            for k, t in p.items():
+                states[k].merge(TaskState.from_tuple(k, t))
+    check_task_states(states)
+
     frags_name = os.path.join(config["fragments_dataset"], build_name(frag_params))
     common = dict(offset=roi[0], voxel_size=voxel_size, axis_names=affs.axis_names[1:], units=affs.units, dtype=np.uint64,
-                  chunk_shape=block_size)
-    out = prepare_ds(frags_name, shape=total_shape, **common)
-    out[:] = frags_vol
-    dump_params(frags_name, {"method": "ws", "blockwise": blockwise, **frag_params})
-    del frags_task
+                  chunk_shape=tuple(min(b, t) for b, t in zip(block_size, total_shape)))
 
-    # score RAG edges (post/watershed.py:141-153)
-    agglom = WaterzAgglom(block_size, ctx, total_shape, merge_function=merge_function, device=device, origin=origin)
-    for b in range(len(agglom.blocks)):
-        agglom.agglomerate_in_block(b, affs, frags_vol, rag)
-    del agglom
+    def barrier():
+        if world > 1:
+            import torch.distributed as dist
+            dist.barrier(group=group)
+    if rank == 0:
+        prepare_ds(frags_name, shape=total_shape, **common)
+        dump_params(frags_name, {"method": "ws", "blockwise": blockwise, **frag_params})
+    barrier()
+    open_ds(frags_name, "r+")[z0:z1] = seg.interior(seg.frags).cpu().numpy().view(np.uint64)
+
+    # RAG to the database (rank 0 gathers nodes and all edges, scored or not: post/watershed.py:100-117 db config)
+    ids, pos, size = seg.node_table()
+    pos = np.asarray(roi[0], np.float64) + (pos + np.array([z0, 0, 0], np.float64)) * np.asarray(voxel_size, np.float64)
+    mine = (ids, pos, size, seg.rag_edges, seg.rag_scores)
+    if world > 1:
+        import torch.distributed as dist
+        parts = [None] * world if rank == 0 else None
+        dist.gather_object(mine, parts, dst=0, group=group)
+    else:
+        parts = [mine]
     db = config.get("db") or {}
-    if "db_file" in db:
+    if rank == 0 and "db_file" in db:
+        rag = RagStore()
+        for p in parts:
+            rag.add_nodes(p[0], p[1], p[2])
+            rag.add_edges(p[3], p[4])
         rag.to_sqlite(db["db_file"])
 
     # global segmentation: thresholded connected components -> LUT -> relabel (post/watershed.py:155-203)
     written = [frags_name]
-    nodes, _, _ = rag.nodes()
-    if nodes.size == 0:
+    segs = seg.stitch()
+    if seg.nodes.size == 0:
         return written
-    edges, scores = rag.scored_edges()
     lut_dir = config["lut_dir"]
-    os.makedirs(lut_dir, exist_ok=True)
-    dev = torch.device("cuda", device)
-    frags_dev = torch.from_numpy(frags_vol.view(np.int64)).to(dev)
-    for threshold in thresholds:
-        components = nodes.copy() if edges.shape[0] == 0 else connected_components(nodes, edges, scores, threshold)
+    for t, threshold in enumerate(thresholds):
         params = {"merge_function": merge_function, "threshold": threshold, **frag_params}
         name = build_name(params)
         recorded = {"method": "ws", "blockwise": blockwise, **params}
-        lut_path = os.path.join(lut_dir, name)
-        np.savez_compressed(lut_path + ".npz", fragment_segment_lut=np.array([nodes, components]))
-        dump_lut_params(lut_path, recorded)
-        seg = lut_relabel(frags_dev, torch.from_numpy(nodes.view(np.int64)), torch.from_numpy(components.view(np.int64)))
         seg_name = os.path.join(config["seg_dataset_prefix"], name)
-        out = prepare_ds(seg_name, shape=total_shape, **common)
-        out[:] = seg.cpu().numpy().view(np.uint64)
-        dump_params(seg_name, recorded)
+        if rank == 0:
+            os.makedirs(lut_dir, exist_ok=True)
+            lut_path = os.path.join(lut_dir, name)
+            np.savez_compressed(lut_path + ".npz", fragment_segment_lut=np.array([seg.nodes, seg.luts[t]]))
+            dump_lut_params(lut_path, recorded)
+            prepare_ds(seg_name, shape=total_shape, **common)
+            dump_params(seg_name, recorded)
+        barrier()
+        open_ds(seg_name, "r+")[z0:z1] = segs[t].cpu().numpy().view(np.uint64)
         written.append(seg_name)
+    barrier()
     return written
+
+
+def _waterz_worker(rank, world, config, port, results):
+    import torch
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    # workers that share a GPU (more workers than cards) cannot form an RCCL group: gloo, device tensors staged through the host
+    backend = "nccl" if world <= torch.cuda.device_count() else "gloo"
+    if backend == "nccl":
+        torch.cuda.set_device(rank)
+    dist.init_process_group(backend, rank=rank, world_size=world)
+    try:
+        results[rank] = waterz_pipeline(config, rank=rank, world=world)
+    finally:
+        dist.destroy_process_group()
+
+
+def run_waterz_pipeline(config):
+    """One worker per `num_workers` (post/watershed.py:56: only when blockwise), each on GPU rank % (number of GPUs)."""
+    world = int(config.get("num_workers", 1) or 1) if config.get("blockwise", False) else 1
+    if world <= 1:
+        return waterz_pipeline(config)
+    import torch.multiprocessing as mp
+    port = 29800 + os.getpid() % 1000
+    with mp.Manager() as mgr:
+        results = mgr.dict()
+        mp.spawn(_waterz_worker, args=(world, dict(config), port, results), nprocs=world, join=True)
+        return list(results[0])
 
 
 def watershed_segmentation(config):
@@ -180,5 +265,5 @@ def watershed_segmentation(config):
     if config.get("blockwise", False):
         if config.get("block_shape") == "roi":
             config["blockwise"] = False
-        return waterz_pipeline(config)
+        return run_waterz_pipeline(config)
     return simple_watershed(config)

@@ -18,7 +18,7 @@ import numpy as np
 from .segment import load_toml
 from .zarr_io import open_ds, prepare_ds
 
-MAX_RETRIES = 5  # reference predict.py:38
+from .blockwise import MAX_RETRIES  # reference predict.py:38
 
 
 def block_rois(net_config, voxel_size):
@@ -115,11 +115,21 @@ def enumerate_blocks(cfg):
     return [(z, y, x) for z in range(0, nvox[0], ob[0]) for y in range(0, nvox[1], ob[1]) for x in range(0, nvox[2], ob[2])]
 
 
-def predict_blocks(cfg, rank=0, world=1, device=None, precision="bf16"):
-    """Worker body (one per GPU): blocks rank, rank+world, ... of the block list."""
+def rank_blocks(blocks, rank, world):
+    """This worker's share of the z-major block list: a contiguous run (the reference's daisy server hands blocks out
+    one by one, predict.py:46-49; a contiguous run lets a worker read only the slab of the input it needs)."""
+    q, r = divmod(len(blocks), world)
+    start = rank * q + min(rank, r)
+    return blocks[start:start + q + (1 if rank < r else 0)]
+
+
+def predict_blocks(cfg, rank=0, world=1, device=None, precision="bf16x3"):
+    """Worker body (one per GPU) -> TaskState of its blocks.  precision: bf16x3 (default; within 1e-4 of the reference's
+    fp32 forward), f32, or bf16 (throughput mode, 4e-3)."""
     import torch
+    from .blockwise import run_blocks
     from .unet import Model, extract_block_reflect
-    device = rank if device is None else device
+    device = rank % max(1, torch.cuda.device_count()) if device is None else device
     torch.cuda.set_device(device)
     dev = torch.device("cuda", device)
     model = Model(cfg["net_config"], device=device, precision=precision).load_checkpoint(cfg["checkpoint"])
@@ -130,27 +140,57 @@ def predict_blocks(cfg, rank=0, world=1, device=None, precision="bf16"):
     roi_vox = [s // v for s, v in zip(roi_shape, vs)]
     # dataset-relative voxel origin of the output ROI
     org = [(o - d) // v for o, d, v in zip(roi_off, in_ds.offset, vs)]
-    # every input channel as a (D, H, W) volume resident in HBM, in the order of net_config["inputs"]
-    # (second-stage setups read several prediction datasets: models/3d_affs_from_2d_mtlsd/predict.py:80-81,139-142)
+    in_shape, out_shape = launch_shapes(cfg)
+    ctx = [(a - b) // 2 for a, b in zip(in_shape, out_shape)]
+    mine = rank_blocks(enumerate_blocks(cfg), rank, world)
+    if not mine:
+        from .blockwise import TaskState
+        return TaskState("PredictBlockwiseTask", 0)
+    # The slab of the input this worker's blocks read (with context), clipped to the dataset: z only -- y and x stay
+    # whole, so the reflect padding about the dataset faces (gp.Pad on the array source) is the padding about the faces
+    # of what is resident.  Every input channel becomes a (D, H, W) volume in HBM, in the order of net_config["inputs"]
+    # (second-stage setups read several prediction datasets: models/3d_affs_from_2d_mtlsd/predict.py:80-81,139-142).
+    nz = in_ds.shape[-3]
+    z_need = (org[0] + min(b[0] for b in mine) - ctx[0], org[0] + max(b[0] for b in mine) + out_shape[0] + ctx[0])
+    lo, hi = z_need
+    if hi > nz:  # reads beyond the last section mirror back to section 2 (nz - 1) - i
+        lo = min(lo, 2 * (nz - 1) - (hi - 1))
+    if z_need[0] < 0:  # reads before the first section mirror to section -i
+        hi = max(hi, 1 - z_need[0])
+    whole = nz <= 2 * (in_shape[0] + 1)  # a dataset this thin may be mirrored more than once: keep all of it
+    z_lo, z_hi = (0, nz) if whole else (max(0, lo), min(nz, hi))
     vols = []
     for path in cfg["input_datasets"]:
-        a = open_ds(path)[:]
+        ds = open_ds(path)
+        a = ds[(slice(None),) * (len(ds.shape) - 3) + (slice(z_lo, z_hi),)]
         vols += [torch.from_numpy(a).to(dev)] if a.ndim == 3 else [torch.from_numpy(c).to(dev) for c in a]
     two_d = model.two_d
     adj = int(cfg["net_config"].get("adj_slices", 1))
     if (len(vols) if not two_d else adj * len(vols)) != model._cfg.in_channels:
         raise ValueError(f"the input datasets hold {len(vols)} channels, the network takes {model._cfg.in_channels}")
-    in_shape, out_shape = launch_shapes(cfg)
-    ctx = [(a - b) // 2 for a, b in zip(in_shape, out_shape)]
-    blocks = enumerate_blocks(cfg)
-    mine = blocks[rank::world]
+
+    def read_block(v, blk):
+        """block read with the z axis re-based on the resident slab; a mirror image beyond a dataset face is taken from
+        the full-depth side of the slab (the slab reaches the face whenever a read does)"""
+        off = [org[d] + blk[d] - ctx[d] for d in range(3)]
+        if z_lo == 0 and z_hi == nz:
+            return extract_block_reflect(v, off, in_shape)
+        lo, hi = off[0], off[0] + in_shape[0]
+        if lo >= z_lo and hi <= z_hi:
+            return extract_block_reflect(v, [off[0] - z_lo, off[1], off[2]], in_shape)
+        # the read crosses a dataset face: mirror indices by hand (rare: first / last layer of blocks)
+        idx = torch.arange(lo, hi, device=v.device)
+        period = 2 * (nz - 1)
+        idx = idx % period
+        idx = torch.where(idx >= nz, period - idx, idx) - z_lo
+        plane = extract_block_reflect(v, [0, off[1], off[2]], [v.shape[0], in_shape[1], in_shape[2]])
+        return plane.index_select(0, idx)
+
     # Write-behind: the device -> host copy of a block's outputs runs on its own stream and the chunk encoding + file
     # writes (native threads, no GIL: zarr_io / codecs) on a small pool, while the next blocks are predicted.
     import concurrent.futures as cf
     copy_stream = torch.cuda.Stream(dev)
     pool = cf.ThreadPoolExecutor(max_workers=2, thread_name_prefix="bsmi-write")
-    pending = []
-
     def write_block(blk, hi, u8, ready):
         with torch.cuda.stream(copy_stream):
             copy_stream.wait_event(ready)
@@ -158,45 +198,52 @@ def predict_blocks(cfg, rank=0, world=1, device=None, precision="bf16"):
             done = torch.cuda.Event()
             done.record(copy_stream)
         done.synchronize()
-        for attempt in range(MAX_RETRIES + 1):
-            try:
-                for ds, t in zip(outs, host):
-                    ds[(slice(None),) + tuple(slice(blk[d], blk[d] + hi[d]) for d in range(3))] = t.numpy()
-                return True
-            except Exception:  # noqa: BLE001
-                if attempt == MAX_RETRIES:
-                    return False
+        for ds, t in zip(outs, host):
+            ds[(slice(None),) + tuple(slice(blk[d], blk[d] + hi[d]) for d in range(3))] = t.numpy()
 
-    failed = 0
-    for blk in mine:
-        for attempt in range(MAX_RETRIES + 1):
+    inflight, redo = [], []
+
+    def predict_and_submit(blk):
+        chans = [read_block(v, blk) for v in vols]
+        if two_d:  # section z of the stack sees sections z .. z + adj - 1 of the read block as its channels
+            chans = [c[i:i + out_shape[0]] for c in chans for i in range(adj)]
+        u8 = model.predict_u8(chans[0] if len(chans) == 1 else torch.stack(chans))
+        ready = torch.cuda.Event()
+        ready.record(torch.cuda.current_stream(dev))
+        hi = [min(out_shape[d], roi_vox[d] - blk[d]) for d in range(3)]
+        return pool.submit(write_block, blk, hi, u8, ready)
+
+    def settle(limit):
+        """await the oldest writes: bounds the blocks in flight (their outputs stay alive until written)"""
+        while len(inflight) > limit:
+            blk, fut = inflight.pop(0)
             try:
-                # reflect padding mirrors about the DATASET faces (gp.Pad on the array source)
-                chans = [extract_block_reflect(v, [org[d] + blk[d] - ctx[d] for d in range(3)], in_shape) for v in vols]
-                if two_d:  # section z of the stack sees sections z .. z + adj - 1 of the read block as its channels
-                    chans = [c[i:i + out_shape[0]] for c in chans for i in range(adj)]
-                u8 = model.predict_u8(chans[0] if len(chans) == 1 else torch.stack(chans))
-                ready = torch.cuda.Event()
-                ready.record(torch.cuda.current_stream(dev))
-                hi = [min(out_shape[d], roi_vox[d] - blk[d]) for d in range(3)]
-                pending.append(pool.submit(write_block, blk, hi, u8, ready))
-                break
-            except Exception:  # noqa: BLE001 - a block is retried like a daisy block (max_retries=5)
-                if attempt == MAX_RETRIES:
-                    failed += 1
-        while len(pending) > 4:  # bound the blocks in flight (their outputs stay alive until written)
-            failed += 0 if pending.pop(0).result() else 1
-    for f in pending:
-        failed += 0 if f.result() else 1
-    pool.shutdown()
-    return len(mine), failed
+                fut.result()
+            except Exception:  # noqa: BLE001 - the block is predicted and written again below
+                redo.append(blk)
+
+    def process(blk):
+        inflight.append((blk, predict_and_submit(blk)))
+        settle(4)
+    try:
+        state = run_blocks("PredictBlockwiseTask", mine, process, MAX_RETRIES)
+        settle(0)
+        if redo:  # a write failed after its block had been counted: the whole block again, awaited, with the retries left
+            again = run_blocks("PredictBlockwiseTask", redo, lambda blk: predict_and_submit(blk).result(), MAX_RETRIES - 1)
+            state.completed_count += again.completed_count - len(redo)
+            state.failed_count += again.failed_count
+            state.failed_blocks += again.failed_blocks
+    finally:
+        pool.shutdown()
+    return state
 
 
 def _worker(rank, world, cfg, precision, results):
-    results[rank] = predict_blocks(cfg, rank, world, precision=precision)
+    results[rank] = predict_blocks(cfg, rank, world, precision=precision).as_tuple()
 
 
-def run_prediction(config_file, setup_ids=None, precision="bf16", **kwargs):
+def run_prediction(config_file, setup_ids=None, precision="bf16x3", **kwargs):
+    from .blockwise import TaskState, check_task_states
     all_ids = list(load_toml(config_file).keys())
     valid = {**{s.split("-")[0]: s for s in all_ids}, **{s.split("-")[-1]: s for s in all_ids}, **{s: s for s in all_ids}}
     setups = sorted(setup_ids.strip().split()) if setup_ids else all_ids
@@ -207,14 +254,58 @@ def run_prediction(config_file, setup_ids=None, precision="bf16", **kwargs):
         prepare_outputs(cfg, open_ds(cfg["input_datasets"][0]))
         world = max(1, int(cfg["num_gpus"]))
         if world == 1:
-            total, failed = predict_blocks(cfg, 0, 1, precision=precision)
+            state = predict_blocks(cfg, 0, 1, precision=precision)
         else:
+            # one worker process per GPU (predict.py:46-49; on a box with fewer GPUs the workers share them); a worker
+            # that dies takes the run down with it, like the reference's CalledProcessError
             import torch.multiprocessing as mp
             with mp.Manager() as mgr:
                 results = mgr.dict()
                 mp.spawn(_worker, args=(world, cfg, precision, results), nprocs=world, join=True)
-                total = sum(r[0] for r in results.values())
-                failed = sum(r[1] for r in results.values())
-        if failed:
-            # reference blockwise.py:12-22 check_task_states
-            raise RuntimeError(f"task PredictBlockwiseTask: {failed} failed, 0 orphaned of {total} blocks")
+                state = TaskState("PredictBlockwiseTask")
+                for r in range(world):
+                    state.merge(TaskState.from_tuple("PredictBlockwiseTask", results[r]))
+        check_task_states({"PredictBlockwiseTask": state})  # reference blockwise.py:12-22
+
+
+def worker_main(argv=None):
+    """The per-setup worker script contract of the reference (models/3d_affs/predict.py:19-58):
+        predict.py -c CKPT -i IN_ZARR... -o OUT_ZARR... [-ro "z y x" -rs "z y x"] [-n W] [-d]
+    run from (or with --setup-dir pointing at) the setup directory that holds net_config.json.  Output datasets are
+    created by the caller (predict.py:169-178); this worker only writes inside the ROI.  -n / -d are accepted for
+    compatibility: blocks go through the device one after the other either way."""
+    import argparse
+    ap = argparse.ArgumentParser(prog="predict.py")
+    ap.add_argument("--checkpoint", "-c", required=True)
+    ap.add_argument("--input_datasets", "-i", required=True, action="append")
+    ap.add_argument("--output_datasets", "-o", required=True, action="append")
+    ap.add_argument("--roi_offset", "-ro", type=str)
+    ap.add_argument("--roi_shape", "-rs", type=str)
+    ap.add_argument("--num_workers", "-n", type=int, default=1)
+    ap.add_argument("--daisy", "-d", action="store_true")
+    ap.add_argument("--setup-dir", default=os.getcwd())
+    ap.add_argument("--precision", default="bf16x3", choices=["bf16x3", "f32", "bf16"])
+    a = ap.parse_args(argv)
+    with open(os.path.join(a.setup_dir, "net_config.json")) as f:
+        net_config = json.load(f)
+    if not os.path.exists(a.checkpoint) and not os.path.exists(a.checkpoint + ".ckpt"):
+        raise FileNotFoundError(f"Neither {a.checkpoint} nor {a.checkpoint}.ckpt were found.")
+    if len(a.output_datasets) != len(net_config["outputs"]):
+        raise ValueError(f"{len(a.output_datasets)} output datasets for {len(net_config['outputs'])} network outputs")
+    in_ds = open_ds(a.input_datasets[0])
+    vs = in_ds.voxel_size
+    if a.roi_offset is not None:
+        roi = ([int(x) for x in a.roi_offset.split()], [int(x) for x in a.roi_shape.split()])
+    else:
+        roi = (list(in_ds.roi[0]), list(in_ds.roi[1]))
+    cfg = dict(setup_dir=a.setup_dir, checkpoint=a.checkpoint, net_config=net_config, input_datasets=a.input_datasets,
+               output_datasets=a.output_datasets, output_roi=roi, voxel_size=list(vs), **block_rois(net_config, vs))
+    from .blockwise import check_task_states
+    rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
+    state = predict_blocks(cfg, rank, world, precision=a.precision)
+    check_task_states({"PredictBlockwiseTask": state})
+    return 0
+
+
+if __name__ == "__main__":
+    raise SystemExit(worker_main())

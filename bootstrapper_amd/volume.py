@@ -109,7 +109,7 @@ class SlabSegmenter:
 
     def __init__(self, slab_shape, block, context, total_layers, layer0, thresholds=(0.2, 0.35, 0.5),
                  fragments_in_xy=True, min_seed_distance=10, filter_fragments=0.0, remove_debris=0, discretize_queue=256,
-                 n_lanes=8, device=0, rank=0, world=1, group=None, edge_cap=1 << 17, label_cap=1 << 16):
+                 n_lanes=8, device=0, rank=0, world=1, group=None, edge_cap=1 << 17, label_cap=1 << 16, exchange_affs=True):
         self.shape = tuple(int(s) for s in slab_shape)
         self.block = tuple(int(b) for b in block)
         self.ctx = tuple(int(c) for c in context)
@@ -118,6 +118,9 @@ class SlabSegmenter:
         self.filter_fragments, self.remove_debris = float(filter_fragments), int(remove_debris)
         self.bins = int(discretize_queue)
         self.rank, self.world, self.group = int(rank), int(world), group
+        # False: the caller fills the context margins of the affinities itself (a driver reads them from the dataset,
+        # where also the data beyond the ROI is real); the fragments' margins are always exchanged
+        self.exchange_affs = bool(exchange_affs)
         self.dev = torch.device("cuda", int(device))
         self.boxes = shrink_blocks(self.shape, self.block)
         counts = self.counts = [-(-s // b) for s, b in zip(self.shape, self.block)]
@@ -131,7 +134,9 @@ class SlabSegmenter:
         self.frags = torch.zeros(padded, dtype=torch.int64, device=self.dev)
         self.segs = None
         K = len(self.boxes)
-        self.edge_cap, self.label_cap = int(edge_cap), int(label_cap)
+        read_vox = int(np.prod([min(b, s) + 2 * c for b, s, c in zip(self.block, self.shape, self.ctx)]))
+        self.edge_cap = max(64, min(int(edge_cap), 3 * read_vox))
+        self.label_cap = max(64, min(int(label_cap), self.nvb))
         self.nums = torch.zeros(K, dtype=torch.int64, device=self.dev)
         self.sizes = torch.zeros((K, self.label_cap), dtype=torch.int64, device=self.dev)
         self.sums = torch.zeros((K, self.label_cap, 3), dtype=torch.int64, device=self.dev)
@@ -174,7 +179,7 @@ class SlabSegmenter:
         """context margins of `t` ([..., Zp, Yp, Xp]) at the slab's z faces <- the neighbours' outermost layers.  The
         caller has made sure those layers are complete; -> an event on the current stream that fires when the margins are."""
         c, Z = self.ctx[0], self.shape[0]
-        if self.world > 1 and c > 0:
+        if self.world > 1 and c > 0 and (t is not self.affs or self.exchange_affs):
             exchange_faces(t[..., c:2 * c, :, :], t[..., Z:Z + c, :, :], t[..., 0:c, :, :], t[..., Z + c:Z + 2 * c, :, :],
                            self.rank, self.world, self.group)
         ev = torch.cuda.Event()
@@ -306,6 +311,58 @@ class SlabSegmenter:
             got = self._exchange(self.frags)
             score_what_can_be(face, (got,))
         return self._collect()
+
+    def run_blocks_accounted(self, max_retries=None):
+        """run_blocks with the reference's task accounting (blockwise.py:12-22, daisy retries): the stages first run
+        as usual, all blocks in flight on the lanes; only if that fails somewhere are they run again block by block, each
+        block awaited, retried and counted on its own -- a block of the scoring task that reads a failed fragments block
+        is orphaned.  With several ranks they agree on which way to go (the face exchanges are collective).
+        -> {task id: TaskState} of this rank's blocks."""
+        import torch.distributed as dist
+        from .blockwise import MAX_RETRIES, TaskState, run_blocks
+        max_retries = MAX_RETRIES if max_retries is None else max_retries
+        K = len(self.boxes)
+        failed = 0
+        try:
+            self.run_blocks()
+        except Exception as exc:  # noqa: BLE001
+            from .blockwise import is_fatal
+            if is_fatal(exc):
+                raise
+            failed = 1
+        if self.world > 1:
+            flag = torch.tensor([failed], dtype=torch.int32, device=self.dev if dist.get_backend(self.group) == "nccl" else "cpu")
+            dist.all_reduce(flag, op=dist.ReduceOp.MAX, group=self.group)
+            failed = int(flag.item())
+        names = ("WatershedFrags", "WaterzAgglom")
+        if not failed:
+            states = {}
+            for n in names:
+                states[n] = TaskState(n, K)
+                states[n].completed_count = K
+            return states
+
+        def one(launch):
+            def run(k):
+                launch(k)
+                lane = self.lanes[k % len(self.lanes)]
+                lane["stream"].synchronize()
+                lane["engine"].status()
+            return run
+        here = self._exchange(self.affs)
+        here.synchronize()
+        st_f = run_blocks(names[0], list(range(K)), one(self._launch_fragments), max_retries)
+        for k in st_f.failed_blocks:  # a failed block contributes no fragments
+            b, e = self.boxes[k]
+            self.frags[tuple(slice(c + lo, c + hi) for c, lo, hi in zip(self.ctx, b, e))].zero_()
+            self.nums[k] = 0
+        torch.cuda.synchronize(self.dev)
+        self._exchange(self.frags).synchronize()
+        self.counts_dev.zero_()
+        st_s = run_blocks(names[1], list(range(K)), one(self._launch_scores), max_retries, upstream_failed=st_f.failed_blocks,
+                          depends_on=self._neighbours)
+        self._collect()
+        return {names[0]: st_f, names[1]: st_s}
 
     def node_table(self):
         """RAG nodes of the slab's blocks {id, position (voxels of the slab), size} (watershed_frags.py:230-246)."""

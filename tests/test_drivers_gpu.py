@@ -158,6 +158,18 @@ remove_debris = 12
     assert n_edges == len(E) and n_null == int(np.isnan(Sc).sum())
     con.close()
 
+    # two workers (two slabs of block layers, fragment margins exchanged, edges gathered on rank 0): the same datasets
+    cfg3 = tmp_path / "seg3.toml"
+    cfg3.write_text(cfg.read_text().replace("blockwise = true", "blockwise = true\nnum_workers = 2")
+                    .replace("fragments\"", "fragments_w2\"").replace("segmentations\"", "segmentations_w2\"").replace("rag.db", "rag_w2.db"))
+    written3 = run_segmentation(str(cfg3), "ws")
+    for a, b in zip(written, written3):
+        assert np.array_equal(open_ds(a)[:], open_ds(b)[:]), (a, b)
+    con = sqlite3.connect(str(tmp_path / "rag_w2.db"))
+    assert con.execute("SELECT COUNT(*) FROM edges").fetchone()[0] == len(E)
+    assert [r[0] for r in con.execute("SELECT id FROM nodes ORDER BY id").fetchall()] == nodes.tolist()
+    con.close()
+
     # block_shape = "roi": one block, no context (post/watershed.py:357-363), same machinery
     cfg2 = tmp_path / "seg2.toml"
     cfg2.write_text(cfg.read_text().replace("blockwise = true", 'blockwise = true\nblock_shape = "roi"')
@@ -311,3 +323,125 @@ def test_bootstrap_chain_2d_mtlsd_then_second_stage(tmp_path, golden_dir):
                 ref2[:, z:z + hz, y:y + hy, x:x + hx] = o[:, :hz, :hy, :hx]
     diff = np.abs(got2.astype(np.int32) - ref2.astype(np.int32))
     assert diff.max() <= 1 and (diff == 0).mean() > 0.99
+
+
+def test_predict_two_workers_failure_injection_and_worker_script(tmp_path, golden_dir, monkeypatch):
+    """`run_prediction` with num_gpus = 2 (two worker processes; on a one-GPU box they share the card), each reading only
+    the slab of the input its blocks need: bit-equal to the one-worker run.  Then the failure path: a block that raises
+    twice is retried and the output is unchanged; a block that always raises ends in the reference's RuntimeError
+    (blockwise.py:12-22).  Then the per-setup worker script contract (models/3d_affs/predict.py:19-58)."""
+    import subprocess
+    import sys
+    from bootstrapper_amd import predict as P
+    from bootstrapper_amd.unet import Model
+    from bootstrapper_amd.zarr_io import open_ds
+    nc, sd, raw, store, cfg = _setup(tmp_path, golden_dir)
+    P.run_prediction(cfg, "01", precision="f32")
+    one = open_ds(store + "/predictions/1000/3d_affs")[:]
+    assert one.std() > 5
+    cfg2 = str(tmp_path / "pred2.toml")
+    open(cfg2, "w").write(open(cfg).read().replace("num_gpus = 1", "num_gpus = 2").replace("/predictions", "/predictions2"))
+    P.run_prediction(cfg2, "01", precision="f32")
+    assert np.array_equal(open_ds(store + "/predictions2/1000/3d_affs")[:], one)
+
+    # failure injection (one worker, in process)
+    real = Model.predict_u8
+    calls = {"n": 0}
+
+    def flaky(self, raw_u8, want_f32=False):
+        calls["n"] += 1
+        if calls["n"] in (3, 4):                                   # the third block fails twice, then goes through
+            raise RuntimeError("injected")
+        return real(self, raw_u8, want_f32)
+    monkeypatch.setattr(Model, "predict_u8", flaky)
+    cfg3 = str(tmp_path / "pred3.toml")
+    open(cfg3, "w").write(open(cfg).read().replace("/predictions", "/predictions3"))
+    P.run_prediction(cfg3, "01", precision="f32")
+    assert np.array_equal(open_ds(store + "/predictions3/1000/3d_affs")[:], one)
+    n_blocks = len(P.enumerate_blocks(P.get_pred_config(cfg3, "01-3d_affs")))
+    assert calls["n"] == n_blocks + 2
+
+    state = {"k": 0}
+
+    def broken(self, raw_u8, want_f32=False):
+        state["k"] += 1
+        if 2 < state["k"] <= 2 + 6:                                 # all six attempts of the third block
+            raise RuntimeError("injected")
+        return real(self, raw_u8, want_f32)
+    monkeypatch.setattr(Model, "predict_u8", broken)
+    with pytest.raises(RuntimeError, match=rf"task PredictBlockwiseTask: 1 failed, 0 orphaned of {n_blocks} blocks"):
+        P.run_prediction(cfg3, "01", precision="f32")
+    monkeypatch.setattr(Model, "predict_u8", real)
+
+    # the worker script: argv of the reference, datasets prepared by the caller, ROI given in world units
+    pc = P.get_pred_config(cfg, "01-3d_affs")
+    pc["output_datasets"] = [store + "/by_worker/3d_affs"]
+    P.prepare_outputs(pc, open_ds(store + "/raw"))
+    setup_dir = pc["setup_dir"]
+    r = subprocess.run([sys.executable, "-m", "bootstrapper_amd.predict", "-c", pc["checkpoint"], "-i", store + "/raw", "-o",
+                        store + "/by_worker/3d_affs", "-ro", "80 8 8", "-rs", f"{23 * 40} {50 * 4} {61 * 4}", "-n", "1",
+                        "--setup-dir", setup_dir, "--precision", "f32"],
+                       capture_output=True, text=True, timeout=600, cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert np.array_equal(open_ds(store + "/by_worker/3d_affs")[:], one)
+
+
+def test_cremi_shaped_volume_full_net_then_blockwise_segment_and_filter(tmp_path):
+    """BASELINE configs 2 and 5 in one chain, on a CREMI-shaped synthetic volume (125 x 1250 x 1250 voxels of (40,4,4) nm,
+    examples/cremi/README.md:19-24): `run_prediction` with the full 3d_affs network in 128^3 blocks over a sub-ROI
+    (a single layer of blocks that overhangs the 125 sections, and overhangs the ROI in y and x: writes are clipped),
+    three blocks against the CPU oracle in the split-bf16 mode, then `bs segment --ws` blockwise on the predicted
+    affinities and `bs refine` size filter on the result."""
+    from bootstrapper_amd.predict import run_prediction
+    from bootstrapper_amd.segment import run_segmentation
+    from bootstrapper_amd import refine as RF
+    from bootstrapper_amd.synth import synthetic_state_dict, synthetic_volume
+    from bootstrapper_amd.zarr_io import open_ds, prepare_ds
+    from oracle import unet_ref as R
+    from oracle.blockwise_ref import cpu_blockwise
+    from tests.test_lib_cpu import AFFS_NET_CONFIG as NC
+    nc = dict(NC, input_shape=[32, 196, 196], output_shape=[4, 104, 104], shape_increase=[124, 24, 24],
+              inputs={"raw": {"dims": 1}}, outputs={"3d_affs": {"dtype": "uint8", "dims": 6}})
+    setup = tmp_path / "setup_03"
+    setup.mkdir()
+    (setup / "net_config.json").write_text(json.dumps(nc))
+    sd = synthetic_state_dict(NC, 0)
+    torch.save({"state_dict": {"model." + k: torch.from_numpy(v) for k, v in sd.items()}}, str(setup / "model_checkpoint_3000.ckpt"))
+    raw = synthetic_volume((125, 1250, 1250), 0).cpu().numpy()
+    store = str(tmp_path / "cremi.zarr")
+    ds = prepare_ds(store + "/raw", raw.shape, offset=(0, 0, 0), voxel_size=(40, 4, 4), chunk_shape=(25, 250, 250), dtype=np.uint8,
+                    axis_names=["z", "y", "x"], units=["nm"] * 3)
+    ds[:] = raw
+    cfg = tmp_path / "pred.toml"
+    oy, ox, ny, nx = 300, 500, 300, 290                      # ROI in voxels: 3 x 3 blocks, the last ones overhang it
+    cfg.write_text(f'["03-3d_affs"]\nsetup_dir = "{setup}"\ninput_datasets = ["{store}/raw"]\ncheckpoint = "{setup}/model_checkpoint_3000"\n'
+                   f'output_datasets_prefix = "{store}/predictions"\nchain_str = ""\nnum_workers = 1\nnum_gpus = 1\n'
+                   f'roi_offset = [0, {oy * 4}, {ox * 4}]\nroi_shape = [{125 * 40}, {ny * 4}, {nx * 4}]\n')
+    run_prediction(str(cfg), "03")                          # default precision: bf16x3
+    out = open_ds(store + "/predictions/3000/3d_affs")
+    assert out.shape == (6, 125, ny, nx) and out.chunks == (6, 125, 128, 128) and out.offset == (0, oy * 4, ox * 4)
+    got = out[:]
+    full = np.pad(raw, [(14, 14 + 128), (46, 46 + 128), (46, 46 + 128)], mode="reflect")
+    torch.set_num_threads(min(16, os.cpu_count() or 1))
+    for (y, x) in ((0, 0), (128, 256), (256, 128)):          # a corner block, two blocks that overhang the ROI
+        blk = full[0:156, oy + y:oy + y + 220, ox + x:ox + x + 220]
+        ref = R.to_u8(R.predict_block(R.default_cfg(12, 5), sd, blk, ["affs_head"])[0])
+        hy, hx = min(128, ny - y), min(128, nx - x)
+        diff = np.abs(got[:, :, y:y + hy, x:x + hx].astype(np.int32) - ref[:, :125, :hy, :hx].astype(np.int32))
+        assert diff.max() <= 1 and (diff == 0).mean() > 0.995, (y, x, diff.max())
+    # blockwise segmentation of the predicted affinities (block = chunk = 128^3 clipped to 125 sections, context 16)
+    seg_cfg = tmp_path / "seg.toml"
+    seg_cfg.write_text(f'affs_dataset = "{store}/predictions/3000/3d_affs"\nfragments_dataset = "{store}/fragments"\n'
+                       f'seg_dataset_prefix = "{store}/segmentations"\nblockwise = true\n[db]\ndb_file = "{tmp_path}/rag.db"\n'
+                       f'[ws_params]\nthresholds = [0.35]\n')
+    written = run_segmentation(str(seg_cfg), "ws")
+    frags_ref, nodes, _, _, segs_ref = cpu_blockwise(got[:3], (125, 128, 128), (15, 16, 16), 10, 0.1, 64, [0.35], workers=8)  # segment.py:16 defaults
+    assert np.array_equal(open_ds(written[0])[:], frags_ref)
+    seg = open_ds(written[1])[:]
+    assert np.array_equal(seg, segs_ref[0]) and len(np.unique(seg)) < len(nodes)
+    # bs refine size filter on the segmentation dataset
+    ids, counts = np.unique(seg[seg > 0], return_counts=True)
+    out_ds = RF.size_filter(written[1], min_size=500, max_size=10 ** 9)
+    want = seg.copy()
+    want[np.isin(want, ids[counts < 500])] = 0
+    assert np.array_equal(open_ds(out_ds)[:], want) and (want > 0).any()

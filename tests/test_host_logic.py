@@ -95,3 +95,37 @@ def test_train_host_helpers(tmp_path):
     for k, v in sd.items():      # every key and shape is one the engine expects (no device work: load only)
         a = np.ascontiguousarray(v, dtype=np.float32)
         check(lib.bsmi_unet_load_weight(m._h, k.encode(), a.ctypes.data_as(C.c_void_p), (C.c_int64 * a.ndim)(*a.shape), a.ndim))
+
+
+def test_block_task_retries_and_failure_accounting():
+    """bootstrapper_amd.blockwise against the contract of the reference's blockwise.py:12-22 and daisy's max_retries=5
+    (predict.py:38): a block that raises twice and then succeeds completes; one that always raises is counted failed after
+    six attempts; downstream blocks that read a failed block are orphaned; any of these ends in the reference's RuntimeError."""
+    import pytest
+    from bootstrapper_amd.blockwise import run_blocks, check_task_states, FatalBlockError, TaskState
+    calls = {}
+
+    def flaky(blk):
+        calls[blk] = calls.get(blk, 0) + 1
+        if blk == 3 and calls[blk] <= 2:
+            raise ValueError("transient")
+        if blk == 5:
+            raise IOError("always")
+    st = run_blocks("PredictBlockwiseTask", list(range(8)), flaky)
+    assert calls[3] == 3 and calls[5] == 6 and all(calls[b] == 1 for b in (0, 1, 2, 4, 6, 7))
+    assert st.as_tuple() == (8, 7, 1, 0, [5])
+    with pytest.raises(RuntimeError, match=r"task PredictBlockwiseTask: 1 failed, 0 orphaned of 8 blocks"):
+        check_task_states({"PredictBlockwiseTask": st})
+    # downstream task: blocks 4, 5, 6 read the failed block 5
+    ran = []
+    st2 = run_blocks("agglom", list(range(8)), ran.append, upstream_failed=st.failed_blocks, depends_on=lambda b: (b - 1, b, b + 1))
+    assert ran == [0, 1, 2, 3, 7] and st2.as_tuple() == (8, 5, 0, 3, [])
+    merged = TaskState("agglom").merge(st2).merge(TaskState.from_tuple("agglom", (4, 4, 0, 0, [])))
+    with pytest.raises(RuntimeError, match=r"task agglom: 0 failed, 3 orphaned of 12 blocks"):
+        check_task_states({"agglom": merged})
+    check_task_states({"ok": run_blocks("ok", [1, 2], lambda b: None)})
+
+    def fatal(blk):
+        raise FatalBlockError("device lost")
+    with pytest.raises(FatalBlockError):
+        run_blocks("t", [0, 1], fatal)

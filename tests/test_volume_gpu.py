@@ -104,3 +104,28 @@ def test_volume_pipeline_small_net(golden_dir):
     for t in range(2):
         assert np.array_equal(segs[t].cpu().numpy().view(np.uint64), segs_ref[t])
     assert len(nodes) > 20
+
+
+def test_block_task_mirrors_equal_cpu_blockwise():
+    """The per-block methods that mirror the reference's volara tasks (post/blockwise.py: WatershedFrags.watershed_in_block,
+    WaterzAgglom.agglomerate_in_block) walked block by block over host arrays: same fragments, nodes and edges."""
+    from bootstrapper_amd.post.blockwise import RagStore, WatershedFrags, WaterzAgglom
+    from oracle.blockwise_ref import cpu_blockwise
+    shape, block, ctx = (20, 150, 130), (8, 64, 64), (1, 8, 8)
+    affs = blobby_affs(shape, 21)
+    frags_ref, nodes, E, Sc, _ = cpu_blockwise(affs, block, ctx, 4, 0.35, 12, [0.3])
+    rag = RagStore()
+    frags = np.zeros(shape, dtype=np.uint64)
+    task = WatershedFrags(block, ctx, shape, min_seed_distance=4, filter_fragments=0.35, remove_debris=12)
+    for b in range(len(task.blocks)):
+        task.watershed_in_block(b, affs, frags, rag)
+    assert np.array_equal(frags, frags_ref)
+    agg = WaterzAgglom(block, ctx, shape)
+    for b in range(len(agg.blocks)):
+        agg.agglomerate_in_block(b, affs, frags, rag)
+    ids, _, size = rag.nodes()
+    assert np.array_equal(ids, nodes) and size.sum() == int((frags_ref > 0).sum())
+    e, s = rag.all_edges()
+    o, o_ref = np.lexsort((e[:, 1], e[:, 0])), np.lexsort((E[:, 1], E[:, 0]))
+    assert np.array_equal(e[o], E[o_ref])
+    np.testing.assert_array_equal(s[o], Sc[o_ref])
