@@ -46,6 +46,7 @@ struct WsScratch {
   int32_t* lab;     // local seed labels (1..n), later flood labels
   int32_t* nseeds;  // [D]
   uint64_t* offs;   // [D] exclusive scan of nseeds
+  int32_t* seedlab; // optional (return_seeds): the seed labels before masking (ws.py:20-23), slice-local numbering
 };
 
 // LDS = true: the row distances / filter intermediates (uint16) and the squared distances
@@ -270,7 +271,13 @@ __global__ __launch_bounds__(WS_T) void ws_seeds_kernel(const uint8_t* __restric
   // markers = label * mask (seeds outside the mask vanish inside skimage)
   for (int i = tid; i < n; i += WS_T) {
     int l = 0;
-    if (par[i] >= 0 && mask[i]) l = g[find(i)];
+    if (par[i] >= 0) {
+      const int sl = g[find(i)];
+      if (s.seedlab) s.seedlab[(size_t)z * n + i] = sl;
+      if (mask[i]) l = sl;
+    } else if (s.seedlab) {
+      s.seedlab[(size_t)z * n + i] = 0;
+    }
     lab[i] = l;
   }
 }
@@ -1154,6 +1161,18 @@ __global__ void rag_scores_kernel(AggWs w, uint64_t* __restrict__ edges, float* 
     }
 }
 
+// affinity sum and voxel-pair count of every INITIAL edge of the last RAG call, in edge order (the merge loop changes
+// esum / ecnt; the hash table rows the edges were compacted from still hold the initial values)
+__global__ void rag_edge_stats_kernel(AggWs w, uint64_t* __restrict__ sums, uint64_t* __restrict__ counts, uint64_t cap) {
+  if (w.counters[3]) return;
+  const uint32_t ne = min(w.counters[1], w.edge_cap);
+  for (uint32_t e = blockIdx.x * blockDim.x + threadIdx.x; e < ne && e < cap; e += gridDim.x * blockDim.x) {
+    const uint32_t slot = w.sslot[e];
+    sums[e] = w.hsum[slot];
+    counts[e] = w.hcnt[slot];
+  }
+}
+
 // segmentation lookup: out[p] = vals[k] where keys[k] == in[p] (keys ascending), 0 stays 0, an id
 // that is not a key maps to itself.  volara Relabel + LUT (post/watershed.py:187-202).
 __global__ void lut_relabel_kernel(const uint64_t* __restrict__ in, size_t n, const uint64_t* __restrict__ keys,
@@ -1586,9 +1605,22 @@ __global__ void cc6_union_kernel(const uint64_t* __restrict__ x, int D, int H, i
 }
 
 // markers: component rank of the maxima inside the mask, 0 elsewhere
-__global__ void ws3_markers_kernel(const uint64_t* __restrict__ flag, const uint8_t* __restrict__ mask, size_t n, FragWs w, int32_t* __restrict__ lab) {
-  for (size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x; p < n; p += (size_t)gridDim.x * blockDim.x)
-    lab[p] = (flag[p] && mask[p]) ? w.rank[cc_find(w.par, (int)p)] : 0;
+__global__ void ws3_markers_kernel(const uint64_t* __restrict__ flag, const uint8_t* __restrict__ mask, size_t n, FragWs w, int32_t* __restrict__ lab,
+                                   uint64_t* __restrict__ seeds) {
+  for (size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x; p < n; p += (size_t)gridDim.x * blockDim.x) {
+    const int l = flag[p] ? (int)w.rank[cc_find(w.par, (int)p)] : 0;
+    lab[p] = mask[p] ? l : 0;
+    if (seeds) seeds[p] = (uint64_t)l;
+  }
+}
+
+// return_seeds of the xy mode: slice-local seed labels + the slice's id offset (ws.py:24, 82-90)
+__global__ void ws_seeds_out_kernel(int D, size_t n, WsScratch s, uint64_t* __restrict__ seeds) {
+  const size_t total = (size_t)D * n;
+  for (size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x; p < total; p += (size_t)gridDim.x * blockDim.x) {
+    const int l = s.seedlab[p];
+    seeds[p] = l ? (uint64_t)l + s.offs[p / n] : 0ull;
+  }
 }
 
 // heap entry of the 3-D flood: [63:46] = MAXD2 - d2 (18 bit) | [45:23] = age (23 bit) | [22:0] = voxel index
@@ -1747,6 +1779,7 @@ struct bsmi_seg {
   uint64_t* crop_tmp = nullptr;  // [max_vox] cropped fragments before relabelling
   void* sort_tmp = nullptr;      // hipcub radix-sort scratch
   size_t sort_tmp_bytes = 0;
+  int32_t* seedlab = nullptr;      // [max_vox] unmasked seed labels (bsmi_ws_fragments_seeds_u8), allocated on first use
   uint64_t* rag_counts = nullptr;  // [4] ne, nm, nn of the last RAG call
   float* thr_dev = nullptr;
   int* status_dev = nullptr;
@@ -1787,6 +1820,7 @@ int bsmi_seg_create(int device, const int64_t max_shape[3], bsmi_seg** out) {
 #define A(ptr, cnt) if (!rc) rc = dalloc(h, &(ptr), (cnt))
   A(h->ws.mask, nv); A(h->ws.g, nv); A(h->ws.d2, nv); A(h->ws.mf, nv); A(h->ws.par, nv); A(h->ws.lab, nv);
   A(h->ws.nseeds, (size_t)max_shape[0]); A(h->ws.offs, (size_t)max_shape[0]);
+  h->ws.seedlab = nullptr;
   h->flood_spill_stride = ns;
   A(h->flood_spill, nv);
   AggWs& g = h->agg;
@@ -1866,6 +1900,11 @@ static int check_seg_shape(bsmi_seg* h, const int64_t shape[3]) {
 
 int bsmi_ws_fragments_u8(bsmi_seg* h, const uint8_t* affs_dev, const int64_t shape[3], int fragments_in_xy,
                          int min_seed_distance, uint64_t* frags_dev, uint64_t* max_id_dev, void* stream) {
+  return bsmi_ws_fragments_seeds_u8(h, affs_dev, shape, fragments_in_xy, min_seed_distance, frags_dev, max_id_dev, nullptr, stream);
+}
+
+int bsmi_ws_fragments_seeds_u8(bsmi_seg* h, const uint8_t* affs_dev, const int64_t shape[3], int fragments_in_xy,
+                               int min_seed_distance, uint64_t* frags_dev, uint64_t* max_id_dev, uint64_t* seeds_dev, void* stream) {
   int rc = check_seg_shape(h, shape);
   if (rc) return rc;
   if (!affs_dev || !frags_dev || !max_id_dev) BSMI_FAIL(BSMI_ERR_INVALID, "null argument");
@@ -1898,10 +1937,21 @@ int bsmi_ws_fragments_u8(bsmi_seg* h, const uint8_t* affs_dev, const int64_t sha
     hipLaunchKernelGGL(cc26_count_kernel, dim3(nblk), dim3(1024), 0, s, n, f);
     hipLaunchKernelGGL(cc26_scan_kernel, dim3(1), dim3(1024), 0, s, nblk, f, max_id_dev);
     hipLaunchKernelGGL(cc26_rank_kernel, dim3(nblk), dim3(1024), 0, s, n, f);
-    hipLaunchKernelGGL(ws3_markers_kernel, dim3(grid), dim3(bs), 0, s, (const uint64_t*)h->crop_tmp, (const uint8_t*)w.mask, n, f, w.lab);
+    hipLaunchKernelGGL(ws3_markers_kernel, dim3(grid), dim3(bs), 0, s, (const uint64_t*)h->crop_tmp, (const uint8_t*)w.mask, n, f, w.lab, seeds_dev);
     hipLaunchKernelGGL(ws3_flood_kernel, dim3(1), dim3(64), 0, s, D, H, W, w, h->flood_spill, frags_dev);
     BSMI_HIP(hipGetLastError());
     return BSMI_OK;
+  }
+  WsScratch wsx = h->ws;
+  wsx.seedlab = nullptr;
+  if (seeds_dev) {
+    if (!h->seedlab) {  // allocated on first use
+      void* q = nullptr;
+      BSMI_HIP(hipMalloc(&q, h->max_vox * sizeof(int32_t)));
+      h->allocs.push_back(q);
+      h->seedlab = (int32_t*)q;
+    }
+    wsx.seedlab = h->seedlab;
   }
   {
     // squared distances must fit the uint16 intermediates of the LDS path: H^2 + W^2 < 65535
@@ -1913,12 +1963,15 @@ int bsmi_ws_fragments_u8(bsmi_seg* h, const uint8_t* affs_dev, const int64_t sha
         BSMI_HIP(hipFuncSetAttribute((const void*)ws_seeds_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 158 * 1024));
         attr_set = true;
       }
-      hipLaunchKernelGGL(ws_seeds_kernel<true>, dim3(D), dim3(WS_T), lds, s, affs_dev, D, H, W, min_seed_distance, h->ws);
+      hipLaunchKernelGGL(ws_seeds_kernel<true>, dim3(D), dim3(WS_T), lds, s, affs_dev, D, H, W, min_seed_distance, wsx);
     } else {
-      hipLaunchKernelGGL(ws_seeds_kernel<false>, dim3(D), dim3(WS_T), 0, s, affs_dev, D, H, W, min_seed_distance, h->ws);
+      hipLaunchKernelGGL(ws_seeds_kernel<false>, dim3(D), dim3(WS_T), 0, s, affs_dev, D, H, W, min_seed_distance, wsx);
     }
   }
   hipLaunchKernelGGL(ws_offsets_kernel, dim3(1), dim3(64), 0, s, D, h->ws, max_id_dev);
+  if (seeds_dev)
+    hipLaunchKernelGGL(ws_seeds_out_kernel, dim3((unsigned)std::min<size_t>(((size_t)D * H * W + 255) / 256, 4096)), dim3(256), 0, s, D,
+                       (size_t)H * W, wsx, seeds_dev);
   hipLaunchKernelGGL(ws_flood_kernel, dim3((D + FLOOD_WAVES - 1) / FLOOD_WAVES), dim3(64 * FLOOD_WAVES), 0, s, D, H, W, h->ws, h->flood_spill, h->flood_spill_stride,
                      frags_dev, h->status_dev);
   BSMI_HIP(hipGetLastError());
@@ -2067,6 +2120,14 @@ int bsmi_rag_merge_scores_u8(bsmi_seg* h, const uint8_t* affs_dev, const uint64_
   hipLaunchKernelGGL(rag_merge_kernel, dim3(8), dim3(64), 0, s, g, threshold, discretize_queue);
   hipLaunchKernelGGL(rag_scores_kernel, dim3(1024), dim3(bs), 0, s, g, edges_dev, scores_dev, edge_capacity, merges_dev,
                      merge_scores_dev, counts_dev);
+  BSMI_HIP(hipGetLastError());
+  return BSMI_OK;
+}
+
+int bsmi_rag_edge_stats(bsmi_seg* h, uint64_t* sums_dev, uint64_t* counts_dev, uint64_t capacity, void* stream) {
+  if (!h || !sums_dev || !counts_dev) BSMI_FAIL(BSMI_ERR_INVALID, "null argument");
+  BSMI_HIP(hipSetDevice(h->device));
+  hipLaunchKernelGGL(rag_edge_stats_kernel, dim3(256), dim3(256), 0, (hipStream_t)stream, h->agg, sums_dev, counts_dev, capacity);
   BSMI_HIP(hipGetLastError());
   return BSMI_OK;
 }

@@ -23,19 +23,21 @@ class SegEngine:
     def _stream(self):
         return C.c_void_p(torch.cuda.current_stream(torch.device("cuda", self.device)).cuda_stream)
 
-    def ws_fragments(self, affs_u8, fragments_in_xy=True, min_seed_distance=10):
+    def ws_fragments(self, affs_u8, fragments_in_xy=True, min_seed_distance=10, return_seeds=False):
         """affs_u8: uint8 CUDA tensor [3][D][H][W] -> (fragments int64 [D][H][W] holding the
-        uint64 ids, max_id tensor int64[1]); asynchronous on the current stream."""
+        uint64 ids, max_id tensor int64[1][, seeds int64 [D][H][W]]); asynchronous on the current stream."""
         if affs_u8.dtype != torch.uint8 or not affs_u8.is_cuda or affs_u8.dim() != 4 or affs_u8.shape[0] != 3:
             raise ValueError("affs must be a uint8 CUDA tensor of shape (3, D, H, W)")
         a = affs_u8.contiguous()
         shape = a.shape[1:]
         frags = torch.empty(tuple(shape), dtype=torch.int64, device=a.device)
         max_id = torch.zeros(1, dtype=torch.int64, device=a.device)
-        check(lib.bsmi_ws_fragments_u8(self._h, C.c_void_p(a.data_ptr()), _lib.i64x3(shape),
-                                       1 if fragments_in_xy else 0, int(min_seed_distance),
-                                       C.c_void_p(frags.data_ptr()), C.c_void_p(max_id.data_ptr()), self._stream()))
-        return frags, max_id
+        seeds = torch.empty(tuple(shape), dtype=torch.int64, device=a.device) if return_seeds else None
+        check(lib.bsmi_ws_fragments_seeds_u8(self._h, C.c_void_p(a.data_ptr()), _lib.i64x3(shape),
+                                             1 if fragments_in_xy else 0, int(min_seed_distance),
+                                             C.c_void_p(frags.data_ptr()), C.c_void_p(max_id.data_ptr()),
+                                             C.c_void_p(seeds.data_ptr()) if return_seeds else None, self._stream()))
+        return (frags, max_id, seeds) if return_seeds else (frags, max_id)
 
     def agglomerate_mean(self, affs_u8, frags, thresholds):
         """-> int64 CUDA tensor [len(thresholds)][D][H][W]; asynchronous on the current stream
@@ -126,6 +128,15 @@ class SegEngine:
         if return_merges:
             return edges[:ne], scores[:ne], merges[:nm], mscores[:nm]
         return edges[:ne], scores[:ne]
+
+    def rag_edge_stats(self, n_edges):
+        """(affinity sums, voxel-pair counts) int64 [n_edges] of the initial edges of the last rag_merge_scores call."""
+        dev = torch.device("cuda", self.device)
+        sums = torch.zeros(max(1, n_edges), dtype=torch.int64, device=dev)
+        counts = torch.zeros(max(1, n_edges), dtype=torch.int64, device=dev)
+        check(lib.bsmi_rag_edge_stats(self._h, C.c_void_p(sums.data_ptr()), C.c_void_p(counts.data_ptr()), int(n_edges), self._stream()))
+        self.status()
+        return sums[:n_edges].cpu().numpy(), counts[:n_edges].cpu().numpy()
 
     def rag_merge_scores_async(self, affs_u8, frags, threshold, discretize_queue, edges, scores, counts, merges=None,
                                merge_scores=None):

@@ -60,7 +60,7 @@ def simple_watershed(config, device=0):
     dump_params(frags_name, {"method": "ws", "blockwise": False, **frag_params})
 
     written = [frags_name]
-    for threshold, seg in zip(thresholds, agglomerate(a, thresholds, fragments=frags)):
+    for threshold, seg in zip(thresholds, agglomerate(a, thresholds, fragments=frags.clone())):   # a copy, as post/watershed.py:336
         params = {"merge_function": merge_function, "threshold": threshold, **frag_params}
         seg_name = os.path.join(config["seg_dataset_prefix"], build_name(params))
         out = prepare_ds(seg_name, shape=seg.shape, **common)

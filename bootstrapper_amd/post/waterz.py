@@ -1,32 +1,103 @@
-"""Mirror of the `waterz.agglomerate` call the reference makes
-(/root/reference/bootstrapper/post/watershed.py:333-338), on the device.
-
-Only the scoring function the reference enables is implemented
+"""Mirror of the `waterz.agglomerate` calls the reference makes, on the device:
+  /root/reference/bootstrapper/post/watershed.py:333-338        thresholds, fragments, scoring function (exact queue)
+  /root/reference/bootstrapper/post/blockwise/waterz_agglom.py:131-160   thresholds [0, 1.0], discretize_queue=256,
+                                                                 return_merge_history, return_region_graph
+  /root/reference/bootstrapper/post/blockwise/watershed_frags.py:165-176 epsilon agglomeration (one threshold, drained)
+A generator, one item per threshold (ascending): the segmentation, or (segmentation, merge_history, region_graph) as
+requested -- merge_history = [{a, b, c, score}] of the merges since the previous threshold (c = a: the surviving id),
+region_graph = [{u, v, score}] of the current graph.  Like waterz, `fragments` is updated IN PLACE and the same array
+comes back at every step.  Only the scoring function the reference enables is implemented
 (post/blockwise/waterz_agglom.py:25 "mean"); anything else raises.
 """
+import numpy as np
 import torch
 
-from .ws import _engine
+from .engine import lut_relabel
+from .ws import _engine, as_u8_affinities
 
 MEAN = "OneMinus<MeanAffinity<RegionGraphType, ScoreValue>>"
 
 
+def _score(sums, counts):
+    """OneMinus<MeanAffinity> of (sum in uint8 units, count), as oracle/seg_ref.c edge_score"""
+    return (np.float32(1.0) - (sums.astype(np.float64) / (255.0 * counts.astype(np.float64))).astype(np.float32)).astype(np.float32)
+
+
 def agglomerate(affs, thresholds, fragments=None, scoring_function=MEAN, discretize_queue=0,
                 return_merge_history=False, return_region_graph=False, engine=None):
-    """Generator: one int64 CUDA segmentation (uint64 ids) per threshold, ascending."""
     if scoring_function != MEAN:
         raise NotImplementedError(f"scoring function {scoring_function!r} is not implemented")
-    if discretize_queue:
-        raise NotImplementedError("discretize_queue != 0 is not implemented yet")
-    if return_merge_history or return_region_graph:
-        raise NotImplementedError("merge history / region graph output is not implemented yet")
     if fragments is None:
         raise NotImplementedError("waterz's own fragment extraction is not used by the reference path")
-    if affs.dtype != torch.uint8:
-        raise TypeError("the device path takes uint8 affinities")
-    a = affs[:3]
+    thresholds = [float(t) for t in thresholds]
+    if any(b < a for a, b in zip(thresholds, thresholds[1:])):
+        raise ValueError("thresholds must be ascending")
+    a = as_u8_affinities(affs, None)[:3]
+    host_out = isinstance(fragments, np.ndarray)
+    frag = torch.from_numpy(fragments.view(np.int64)).to(a.device) if host_out else fragments
+    if frag.dtype != torch.int64 or tuple(frag.shape) != tuple(a.shape[1:]):
+        raise ValueError("fragments must hold 64-bit ids of shape (D, H, W)")
     eng = engine or _engine(a.shape[1:], a.device.index or 0)
-    segs = eng.agglomerate_mean(a, fragments, list(thresholds))
-    eng.status()
-    for i in range(len(thresholds)):
-        yield segs[i]
+
+    def publish(seg):
+        if host_out:
+            fragments[...] = seg.cpu().numpy().view(fragments.dtype)
+            return fragments
+        fragments.copy_(seg)
+        return fragments
+
+    if not (discretize_queue or return_merge_history or return_region_graph):
+        segs = eng.agglomerate_mean(a, frag.contiguous(), thresholds)
+        eng.status()
+        for i in range(len(thresholds)):
+            yield publish(segs[i])
+        return
+    if not discretize_queue:
+        raise NotImplementedError("merge history / region graph are produced by the discretized queue (the reference passes "
+                                  "discretize_queue=256); the exact queue only yields segmentations")
+
+    frag0 = frag.contiguous().clone()          # every threshold is agglomerated from the fragments (see below)
+    done = 0
+    for t in thresholds:
+        # mergeUntil(t) stops BEFORE it pops anything, so running from scratch up to t gives exactly the merges a
+        # continued run would have made by then: history since the previous threshold = the new tail
+        if t > 0:
+            edges, scores, merges, mscores = eng.rag_merge_scores(a, frag0, t, int(discretize_queue), return_merges=True)
+        else:
+            edges, scores = eng.rag_merge_scores(a, frag0, 1e-30, int(discretize_queue))
+            merges = torch.zeros((0, 2), dtype=torch.int64, device=a.device)
+            mscores = torch.zeros(0, dtype=torch.float32, device=a.device)
+        e = edges.cpu().numpy().view(np.uint64)
+        m = merges.cpu().numpy().view(np.uint64)
+        ms = mscores.cpu().numpy()
+        # survivors: every absorbed id points at its survivor; chase to the root
+        parent = {int(b): int(s) for s, b in m}
+
+        def root(x):
+            while x in parent:
+                x = parent[x]
+            return x
+        if len(m):
+            keys = np.unique(m[:, 1])
+            vals = np.array([root(int(k)) for k in keys], dtype=np.uint64)
+            seg = lut_relabel(frag0, torch.from_numpy(keys.view(np.int64)), torch.from_numpy(vals.view(np.int64)))
+        else:
+            seg = frag0.clone()
+        item = [publish(seg)]
+        if return_merge_history:
+            item.append([{"a": int(s), "b": int(b), "c": int(s), "score": float(sc)} for (s, b), sc in zip(m[done:], ms[done:])])
+        done = len(m)
+        if return_region_graph:
+            sums, counts = eng.rag_edge_stats(len(e))
+            acc = {}
+            for (u, v), su, c in zip(e.tolist(), sums.tolist(), counts.tolist()):
+                ru, rv = root(u), root(v)
+                if ru == rv:
+                    continue
+                k = (min(ru, rv), max(ru, rv))
+                p = acc.get(k)
+                acc[k] = (su, c) if p is None else (p[0] + su, p[1] + c)
+            ks = sorted(acc)
+            sc = _score(np.array([acc[k][0] for k in ks], np.uint64), np.array([acc[k][1] for k in ks], np.uint64)) if ks else []
+            item.append([{"u": k[0], "v": k[1], "score": float(s)} for k, s in zip(ks, sc)])
+        yield item[0] if len(item) == 1 else tuple(item)

@@ -199,6 +199,12 @@ int bsmi_ws_fragments_u8(bsmi_seg *h, const uint8_t *affs_dev, const int64_t sha
                          int fragments_in_xy, int min_seed_distance, uint64_t *frags_dev,
                          uint64_t *max_id_dev, void *stream);
 
+/* The same with `return_seeds` (ws.py:42,105-110): seeds_dev (uint64 [D][H][W], may be NULL) receives the labelled
+ * maxima before they meet the mask, with the same id offsets as the fragments they grow into. */
+int bsmi_ws_fragments_seeds_u8(bsmi_seg *h, const uint8_t *affs_dev, const int64_t shape[3],
+                               int fragments_in_xy, int min_seed_distance, uint64_t *frags_dev,
+                               uint64_t *max_id_dev, uint64_t *seeds_dev, void *stream);
+
 /* Mean-affinity hierarchical agglomeration (reference call site
  * post/watershed.py:333-338 waterz.agglomerate(affs, thresholds, fragments,
  * "OneMinus<MeanAffinity<RegionGraphType, ScoreValue>>"); algorithm restated in
@@ -240,6 +246,11 @@ int bsmi_rag_merge_scores_u8(bsmi_seg *h, const uint8_t *affs_dev, const uint64_
                              uint64_t *edges_dev, float *scores_dev, uint64_t edge_capacity,
                              uint64_t *merges_dev, float *merge_scores_dev, uint64_t *counts_dev,
                              void *stream);
+
+/* Affinity sum (uint8 units) and voxel-pair count of every initial RAG edge of the last bsmi_rag_merge_scores_u8 call
+ * on this handle, in the order of its edges_dev: what waterz's region graph {u, v, score} is computed from
+ * (score = 1 - sum / (255 count)); also lets a caller contract the graph along the merge history. */
+int bsmi_rag_edge_stats(bsmi_seg *h, uint64_t *sums_dev, uint64_t *counts_dev, uint64_t capacity, void *stream);
 
 /* LUT relabel (volara Relabel + LUT, post/watershed.py:187-202): out[p] = vals[k] where keys[k] == in[p]
  * (keys ascending); 0 stays 0; ids without a key are copied.  in_dev == out_dev is allowed. */

@@ -126,20 +126,65 @@ def test_agglomeration_edge_cases():
 
 
 def test_mirror_api_generator():
+    """post/ws.py and waterz.agglomerate as the reference's call sites use them: float affinities that are exactly
+    u8 / 255 (post/watershed.py:259-262), return_seeds, fragments updated in place, and the blockwise call with
+    thresholds [0, 1.0], discretize_queue=256, merge history and region graph (waterz_agglom.py:131-170)."""
     from bootstrapper_amd.post.ws import watershed_from_affinities
     from bootstrapper_amd.post.waterz import agglomerate
+    from bootstrapper_amd.post.merge_tree import MergeTree
+    from bootstrapper_amd.post.engine import SegEngine
     from oracle import seg_ref as S
     rng = np.random.default_rng(9)
     affs = _blobby(rng, (6, 48, 48), (1, 3, 3))
     a = torch.from_numpy(affs).cuda()
     frags, n = watershed_from_affinities(a, fragments_in_xy=True, min_seed_distance=10)
-    ref_frags, ref_n = S.ws_fragments_u8(affs, True, 10)
+    ref_frags, ref_n, ref_seeds = S.ws_fragments_u8(affs, True, 10, return_seeds=True)
     assert n == ref_n
+    # what the reference's drivers hand over: float32 u8 / 255, max_affinity_value left at 1.0; seeds on request
+    af = affs.astype(np.float32) / np.float32(255.0)
+    f2, n2, seeds = watershed_from_affinities(af, fragments_in_xy=True, return_seeds=True, min_seed_distance=10)
+    assert n2 == ref_n and torch.equal(f2, frags)
+    assert np.array_equal(seeds.cpu().numpy().view(np.uint64), ref_seeds)
+    f3, n3, seeds3 = watershed_from_affinities(torch.from_numpy(af).cuda().double(), fragments_in_xy=False, return_seeds=True, min_seed_distance=5)
+    r3, rn3, rs3 = S.ws_fragments_u8(affs, False, 5, return_seeds=True)
+    assert n3 == rn3 and np.array_equal(f3.cpu().numpy().view(np.uint64), r3) and np.array_equal(seeds3.cpu().numpy().view(np.uint64), rs3)
+    with pytest.raises(ValueError, match="exactly uint8 / 255"):
+        watershed_from_affinities(af + np.float32(1e-3), fragments_in_xy=True)
     ref = S.agglomerate_mean_u8(affs, ref_frags, [0.2, 0.5])
-    for seg, r in zip(agglomerate(a, [0.2, 0.5], fragments=frags), ref):
-        assert np.array_equal(seg.cpu().numpy().astype(np.uint64), r)
+    work = frags.clone()
+    for seg, r in zip(agglomerate(af, [0.2, 0.5], fragments=work), ref):
+        assert seg is work and np.array_equal(seg.cpu().numpy().astype(np.uint64), r)      # in place, the same array every time
     with pytest.raises(NotImplementedError):
         next(agglomerate(a, [0.2], fragments=frags, scoring_function="OneMinus<HistogramQuantileAffinity<RegionGraphType, 50, ScoreValue, 256, false>>"))
+    # the blockwise call (numpy fragments, modified in place like waterz does)
+    e_ref, s_ref, m_ref, ms_ref = S.rag_merge_scores_u8(affs, ref_frags, 1.0, 256)
+    fr_np = ref_frags.copy()
+    gen = agglomerate(a, thresholds=[0, 1.0], fragments=fr_np, discretize_queue=256, return_merge_history=True, return_region_graph=True)
+    seg0, hist0, rag0 = next(gen)
+    assert seg0 is fr_np and hist0 == [] and np.array_equal(seg0, ref_frags)
+    assert [(g["u"], g["v"]) for g in rag0] == [tuple(x) for x in e_ref.tolist()]
+    seg1, hist1, rag1 = next(gen)
+    for _ in gen:
+        pass
+    assert [(h["a"], h["b"]) for h in hist1] == [tuple(x) for x in m_ref.tolist()] and all(h["c"] == h["a"] for h in hist1)
+    np.testing.assert_array_equal(np.array([h["score"] for h in hist1], np.float32), ms_ref)
+    nodes = np.unique(ref_frags)
+    mt = MergeTree(nodes[nodes > 0])
+    for h in hist1:
+        mt.merge(h["a"], h["b"], h["c"], h["score"])
+    got = mt.find_merges(e_ref[:, 0], e_ref[:, 1])
+    assert np.array_equal(np.isnan(got), np.isnan(s_ref)) and np.array_equal(got[~np.isnan(got)].astype(np.float32), s_ref[~np.isnan(s_ref)])
+    # the segmentation at 1.0 is the partition the history implies, and the remaining region graph only links distinct segments
+    assert len(np.unique(seg1)) == len(np.unique(ref_frags)) - len(hist1)
+    assert all(g["u"] < g["v"] and g["score"] >= 0 for g in rag1)
+    ids1 = set(np.unique(seg1).tolist())
+    assert all(g["u"] in ids1 and g["v"] in ids1 for g in rag1)
+    # initial region-graph scores are the mean-affinity scores of the initial edges
+    eng = SegEngine((6, 48, 48))
+    eng.rag_merge_scores(a, torch.from_numpy(ref_frags.view(np.int64)).cuda(), 1e-30, 256)
+    sums, counts = eng.rag_edge_stats(len(e_ref))
+    np.testing.assert_array_equal(np.array([g["score"] for g in rag0], np.float32),
+                                  (np.float32(1.0) - (sums / (255.0 * counts)).astype(np.float32)).astype(np.float32))
 
 
 @pytest.mark.parametrize("shape,crop,filt,min_size", [
