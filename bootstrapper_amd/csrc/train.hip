@@ -529,6 +529,13 @@ struct TrainState {
   size_t nparams = 0;
   float *w = nullptr, *g = nullptr, *m = nullptr, *v = nullptr;
   int adam_t = 0;
+  // Gradient groups: the parameters of one ConvPass / head are one contiguous range of the flat buffers (their keys share
+  // a prefix and the buffers follow the sorted keys); a group's gradients are final once the backward pass has left its
+  // first stage.  group_order: groups in the order the backward pass finishes them; an event per group is recorded on
+  // the backward stream so that a data-parallel caller can start reducing a group while the pass goes on.
+  struct GradGroup { std::string prefix; size_t off = 0, count = 0; hipEvent_t ev = nullptr; };
+  std::vector<GradGroup> groups;       // completion order
+  std::map<std::string, int> group_of; // prefix -> index into groups
   std::map<void*, TDesc> grad_of;
   std::vector<std::pair<void*, size_t>> zero_list;  // gradient tensors cleared at the start of every backward pass
   std::vector<void*> allocs;
@@ -551,6 +558,8 @@ static int talloc(TrainState* ts, void** p, size_t bytes, bool zero) {
 
 void free_train_state(bsmi_unet* h) {
   if (!h->train) return;
+  for (auto& g : h->train->groups)
+    if (g.ev) (void)hipEventDestroy(g.ev);
   for (void* p : h->train->allocs) (void)hipFree(p);
   delete h->train;
   h->train = nullptr;
@@ -976,6 +985,35 @@ int bsmi_unet_train_begin(bsmi_unet* h, const int64_t in_shape[3]) {
       if ((rc = grad_tensor(ts.get(), st.in, &t))) return rc;
     }
   }
+  // gradient groups in completion order = the order in which the backward pass (plan steps in reverse) leaves them
+  auto add_group = [&](const std::string& prefix) -> int {
+    if (ts->group_of.count(prefix)) return BSMI_OK;
+    TrainState::GradGroup g;
+    g.prefix = prefix;
+    size_t lo = (size_t)-1, hi = 0;
+    for (const ParamRef& pr : ts->params)
+      if (pr.key.compare(0, prefix.size() + 1, prefix + ".") == 0) {
+        lo = std::min(lo, pr.off);
+        hi = std::max(hi, pr.off + (pr.count + 3) / 4 * 4);
+      }
+    if (lo == (size_t)-1) BSMI_FAIL(BSMI_ERR_STATE, "training plan: no parameters under %s", prefix.c_str());
+    g.off = lo;
+    g.count = hi - lo;
+    BSMI_HIP(hipEventCreateWithFlags(&g.ev, hipEventDisableTiming));
+    ts->group_of[prefix] = (int)ts->groups.size();
+    ts->groups.push_back(g);
+    return BSMI_OK;
+  };
+  for (size_t i = plan.steps.size(); i-- > 0;) {
+    const PlanStep& st = plan.steps[i];
+    if (st.type == PlanStep::HEAD) { if ((rc = add_group(h->heads[st.head].prefix))) return rc; }
+    else if (st.type == PlanStep::CONV && st.ci == 0) { if ((rc = add_group(st.site->prefix))) return rc; }
+  }
+  {
+    size_t covered = 0;
+    for (auto& g : ts->groups) covered += g.count;
+    if (covered != ts->nparams) BSMI_FAIL(BSMI_ERR_STATE, "training plan: gradient groups cover %zu of %zu parameters", covered, ts->nparams);
+  }
   h->train = ts.release();
   return run_pack_jobs(h->train, nullptr) || hipDeviceSynchronize() != hipSuccess ? BSMI_ERR_HIP : BSMI_OK;
 }
@@ -1042,6 +1080,7 @@ int bsmi_unet_train_forward_backward(bsmi_unet* h, const float* raw_dev, const f
         hipLaunchKernelGGL(head_bwd_kernel, dim3((unsigned)((nv + 255) / 256)), dim3(256), (hd.cout * hd.cin + hd.cout) * sizeof(float), s,
                            (const float*)st.in.ptr, st.in.Cpad, (const float*)ts->head_out[st.head], (const float*)ts->head_dp[st.head], nv, hd.cin,
                            hd.cout, (const float*)hd.hw, (float*)dz.ptr, gwc, gwr, gbc, gbr);
+        BSMI_HIP(hipEventRecord(ts->groups[ts->group_of[hd.prefix]].ev, s));
         break;
       }
       case PlanStep::UP: {
@@ -1158,6 +1197,7 @@ int bsmi_unet_train_forward_backward(bsmi_unet* h, const float* raw_dev, const f
             }
           }
         }
+        if (ci == 0) BSMI_HIP(hipEventRecord(ts->groups[ts->group_of[p.prefix]].ev, s));  // the pass's gradients are final
         break;
       }
       default: break;
@@ -1168,6 +1208,51 @@ int bsmi_unet_train_forward_backward(bsmi_unet* h, const float* raw_dev, const f
     BSMI_HIP(hipMemcpyAsync(loss_host, ts->loss_dev, sizeof(float), hipMemcpyDeviceToHost, s));
     BSMI_HIP(hipStreamSynchronize(s));
   }
+  return BSMI_OK;
+}
+
+int bsmi_unet_train_last_loss(bsmi_unet* h, float* loss_host, void* stream) {
+  if (!h || !h->train || !loss_host) BSMI_FAIL(BSMI_ERR_STATE, "bsmi_unet_train_begin has not been called / null argument");
+  BSMI_HIP(hipSetDevice(h->device));
+  BSMI_HIP(hipMemcpyAsync(loss_host, h->train->loss_dev, sizeof(float), hipMemcpyDeviceToHost, (hipStream_t)stream));
+  BSMI_HIP(hipStreamSynchronize((hipStream_t)stream));
+  return BSMI_OK;
+}
+
+int bsmi_unet_train_grad_groups(bsmi_unet* h, int max_n, int* n, uint64_t* offsets, uint64_t* counts) {
+  if (!h || !h->train || !n) BSMI_FAIL(BSMI_ERR_STATE, "bsmi_unet_train_begin has not been called / null argument");
+  *n = (int)h->train->groups.size();
+  for (int i = 0; i < *n && i < max_n; ++i) {
+    if (offsets) offsets[i] = h->train->groups[i].off;
+    if (counts) counts[i] = h->train->groups[i].count;
+  }
+  return BSMI_OK;
+}
+
+int bsmi_unet_train_wait_grad_group(bsmi_unet* h, int group, void* stream) {
+  if (!h || !h->train) BSMI_FAIL(BSMI_ERR_STATE, "bsmi_unet_train_begin has not been called");
+  if (group < 0 || group >= (int)h->train->groups.size()) BSMI_FAIL(BSMI_ERR_INVALID, "gradient group %d out of range", group);
+  BSMI_HIP(hipSetDevice(h->device));
+  BSMI_HIP(hipStreamWaitEvent((hipStream_t)stream, h->train->groups[group].ev, 0));
+  return BSMI_OK;
+}
+
+int bsmi_unet_train_write_param(bsmi_unet* h, const char* key, int what, const float* host_in) {
+  if (!h || !h->train || !key || !host_in) BSMI_FAIL(BSMI_ERR_STATE, "bsmi_unet_train_begin has not been called / null argument");
+  if (what != 2 && what != 3) BSMI_FAIL(BSMI_ERR_INVALID, "only the Adam moments (2, 3) can be written; parameters go through bsmi_unet_load_weight");
+  auto it = h->train->index.find(key);
+  if (it == h->train->index.end()) BSMI_FAIL(BSMI_ERR_MISSING, "no parameter \"%s\"", key);
+  const ParamRef& pr = h->train->params[it->second];
+  BSMI_HIP(hipSetDevice(h->device));
+  BSMI_HIP(hipDeviceSynchronize());
+  BSMI_HIP(hipMemcpy((what == 2 ? h->train->m : h->train->v) + pr.off, host_in, pr.count * sizeof(float), hipMemcpyHostToDevice));
+  return BSMI_OK;
+}
+
+int bsmi_unet_train_step_count(bsmi_unet* h, int set_to, int* value) {
+  if (!h || !h->train) BSMI_FAIL(BSMI_ERR_STATE, "bsmi_unet_train_begin has not been called");
+  if (set_to >= 0) h->train->adam_t = set_to;
+  if (value) *value = h->train->adam_t;
   return BSMI_OK;
 }
 

@@ -116,6 +116,17 @@ class SampleSource:
         raise RuntimeError("no training location with at least 5 % labelled voxels found")
 
 
+def make_sample_source(config, net_config, device=0, rank=0):
+    """The built-in sample stream of `bs train` for this rank: seed 42 + rank, so that data-parallel ranks see different
+    samples (with one seed for all, the averaged gradient would be the single-rank gradient computed N times)."""
+    out3d = net_config["outputs"].get("3d_affs")
+    if out3d is None or len(net_config["outputs"]) != 1:
+        raise NotImplementedError("the built-in sample source feeds the 3d_affs model only")
+    return SampleSource(config["samples"], net_config["input_shape"], net_config["output_shape"],
+                        out3d["neighborhood"][: int(out3d["dims"])], device=device, seed=42 + int(rank),
+                        grow_boundary=int(out3d.get("grow_boundary", 0)))
+
+
 def default_init(net_config, seed=42):
     """torch's default Conv3d initialisation (kaiming_uniform(a=sqrt(5)), bias uniform(+-1/sqrt(fan_in))) for every
     parameter of the reference Model, keyed like its state_dict."""
@@ -160,9 +171,13 @@ def latest_checkpoint(setup_dir):
 
 
 def run_training(config_file, device=0, batches=None, log=print):
-    """`bs train <config>`: returns the number of iterations run."""
+    """`bs train <config>`: returns the number of iterations run.  Under torch.distributed every rank draws its own
+    samples (seed 42 + rank: Lightning's seed_everything(42, workers=True) gives each rank's loader workers their own
+    stream, training.py:128) and the gradients are averaged over the ranks."""
     from .unet import Model
-    from .training import Trainer, fit
+    from .training import Trainer, fit, load_optimizer_state
+    dist = torch.distributed
+    rank = dist.get_rank() if dist.is_available() and dist.is_initialized() else 0
     config = setup_train(config_file)
     setup_dir = config["setup_dir"]
     with open(os.path.join(setup_dir, "net_config.json")) as f:
@@ -176,14 +191,11 @@ def run_training(config_file, device=0, batches=None, log=print):
     else:
         model.load_state_dict(default_init(net_config, seed=42))
     trainer = Trainer(model, net_config["input_shape"])
+    if ckpt and load_optimizer_state(trainer, ckpt):
+        log(f"optimizer state restored (step {trainer.step_count()})")
     if batches is None:
-        out3d = net_config["outputs"].get("3d_affs")
-        if out3d is None or len(net_config["outputs"]) != 1:
-            raise NotImplementedError("the built-in sample source feeds the 3d_affs model only")
         log("note: the reference's gunpowder augmentations are not part of this engine; samples are random crops")
-        batches = SampleSource(config["samples"], net_config["input_shape"], net_config["output_shape"],
-                               out3d["neighborhood"][: int(out3d["dims"])], device=device,
-                               grow_boundary=int(out3d.get("grow_boundary", 0)))
+        batches = make_sample_source(config, net_config, device, rank)
     n = fit(trainer, batches, max_iterations, int(config.get("save_checkpoints_every", 0)), setup_dir, log=log, start_iteration=done)
     trainer.close()
     return n

@@ -37,11 +37,80 @@ def sum_gradients(flat):
     return 1.0 / dist.get_world_size()
 
 
+REDUCE_CHUNK = 8 << 20  # floats per all-reduce call (32 MB): the 243 MB weight of l_conv.3 goes out in eight pieces
+
+
+def reduce_gradient_groups(trainer):
+    """Data-parallel gradient reduction overlapped with the backward pass: the gradients of a ConvPass / head are summed
+    over the ranks as soon as the backward pass has left that pass (bsmi_unet_train_wait_grad_group), group after group
+    on a side stream, in pieces of REDUCE_CHUNK floats, while the earlier layers are still being differentiated.
+    Returns the factor that turns the sums into DDP's mean; the caller's stream then waits for every piece.
+    `nccl` (= RCCL over xGMI) reduces device memory in place; `gloo` (tests) stages each piece through the host."""
+    dist = torch.distributed
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return 1.0
+    dev = trainer.grads.device
+    comm = trainer.comm_stream
+    nccl = dist.get_backend() == "nccl"
+    works = []
+    with torch.cuda.stream(comm):
+        for g, (off, cnt) in enumerate(trainer.grad_groups):
+            check(lib.bsmi_unet_train_wait_grad_group(trainer.model._h, g, C.c_void_p(comm.cuda_stream)))
+            for a in range(off, off + cnt, REDUCE_CHUNK):
+                piece = trainer.grads[a:min(a + REDUCE_CHUNK, off + cnt)]
+                if nccl:
+                    works.append(dist.all_reduce(piece, op=dist.ReduceOp.SUM, async_op=True))
+                else:
+                    comm.synchronize()
+                    host = piece.cpu()
+                    dist.all_reduce(host, op=dist.ReduceOp.SUM)
+                    piece.copy_(host)
+        done = torch.cuda.Event()
+        done.record(comm)
+    for w in works:
+        w.wait()  # the current (backward) stream waits for the reduction
+    torch.cuda.current_stream(dev).wait_event(done)
+    return 1.0 / dist.get_world_size()
+
+
 def save_checkpoint(trainer, path, iteration):
     """`model_checkpoint_<iteration>` in the layout the reference's predict worker loads
-    (models/3d_affs/predict.py:98-108: a dict with "state_dict" whose keys carry the Lightning "model." prefix)."""
-    sd = {"model." + k: torch.from_numpy(trainer.read(k).reshape(shape)) for k, shape in trainer.param_shapes().items()}
-    torch.save({"state_dict": sd, "global_step": int(iteration)}, path)
+    (models/3d_affs/predict.py:98-108: a dict with "state_dict" whose keys carry the Lightning "model." prefix), plus
+    the optimizer state in torch.optim.Adam's state_dict layout as Lightning stores it ("optimizer_states": parameters
+    numbered in state_dict order), so that a resumed run continues with its moments and step count."""
+    shapes = trainer.param_shapes()
+    sd = {"model." + k: torch.from_numpy(trainer.read(k).reshape(shape)) for k, shape in shapes.items()}
+    step = trainer.step_count()
+    state = {i: {"step": torch.tensor(float(step)), "exp_avg": torch.from_numpy(trainer.read(k, "exp_avg").reshape(shape)),
+                 "exp_avg_sq": torch.from_numpy(trainer.read(k, "exp_avg_sq").reshape(shape))}
+             for i, (k, shape) in enumerate(shapes.items())}
+    group = {"lr": trainer.lr, "betas": trainer.betas, "eps": trainer.eps, "weight_decay": 0, "amsgrad": False,
+             "params": list(range(len(shapes)))}
+    torch.save({"state_dict": sd, "global_step": int(iteration), "optimizer_states": [{"state": state, "param_groups": [group]}]}, path)
+
+
+def load_optimizer_state(trainer, checkpoint):
+    """Restore Adam's moments and step count from a checkpoint written by save_checkpoint (or by Lightning for the
+    reference model: same parameter order).  -> True if the checkpoint carried an optimizer state."""
+    try:
+        ck = torch.load(checkpoint, map_location="cpu", weights_only=True)
+    except Exception:  # noqa: BLE001 - an older torch or a checkpoint with non-tensor payloads
+        ck = torch.load(checkpoint, map_location="cpu", weights_only=False)
+    states = ck.get("optimizer_states") if isinstance(ck, dict) else None
+    if not states:
+        return False
+    state = states[0]["state"]
+    keys = list(trainer.param_shapes())
+    step = 0
+    for i, k in enumerate(keys):
+        st = state.get(i)
+        if st is None:
+            raise ValueError(f"optimizer state of the checkpoint has no entry for parameter {i} ({k})")
+        trainer.write(k, "exp_avg", st["exp_avg"].numpy())
+        trainer.write(k, "exp_avg_sq", st["exp_avg_sq"].numpy())
+        step = int(float(st["step"]))
+    trainer.step_count(step)
+    return True
 
 
 def fit(trainer, batches, max_iterations, save_checkpoints_every=0, setup_dir=None, log_every=10, log=print, start_iteration=0):
@@ -88,13 +157,20 @@ class Trainer:
         self.out_shape = model.output_shape(self.in_shape)
         self.last_loss = None
         self._shapes = dict(model.param_shapes)
+        ng = C.c_int()
+        check(lib.bsmi_unet_train_grad_groups(model._h, 0, C.byref(ng), None, None))
+        offs, cnts = (C.c_uint64 * ng.value)(), (C.c_uint64 * ng.value)()
+        check(lib.bsmi_unet_train_grad_groups(model._h, ng.value, C.byref(ng), offs, cnts))
+        self.grad_groups = [(int(o), int(c)) for o, c in zip(offs, cnts)]   # in the order the backward pass finishes them
+        self.comm_stream = torch.cuda.Stream(dev)
 
     def _stream(self):
         return C.c_void_p(torch.cuda.current_stream(torch.device("cuda", self.model.device)).cuda_stream)
 
-    def forward_backward(self, raw, targets, weights):
+    def forward_backward(self, raw, targets, weights, wait=True):
         """raw: float32 CUDA (Cin, D, H, W) or (D, H, W); targets / weights: per head float32 CUDA (C, d, h, w).
-        Returns the loss (python float; synchronises).  Gradients are in self.grads."""
+        Returns the loss (python float; synchronises) -- or, with wait=False, None: the step is only queued and the
+        loss is read later (last_loss()).  Gradients are in self.grads."""
         nh = len(self.model.heads)
         if len(targets) != nh or len(weights) != nh:
             raise ValueError(f"the model has {nh} head(s)")
@@ -109,23 +185,36 @@ class Trainer:
                 raise ValueError(f"{name}: target and weights must be float32 of shape {want}")
         tp = (C.c_void_p * nh)(*[t.data_ptr() for t in ts])
         wp = (C.c_void_p * nh)(*[w.data_ptr() for w in ws])
+        self._keep = (raw, ts, ws)  # alive until the queued kernels have read them
+        if not wait:
+            check(lib.bsmi_unet_train_forward_backward(self.model._h, C.c_void_p(raw.data_ptr()), tp, wp, None, self._stream()))
+            return None
         loss = C.c_float()
         check(lib.bsmi_unet_train_forward_backward(self.model._h, C.c_void_p(raw.data_ptr()), tp, wp, C.byref(loss), self._stream()))
         self.last_loss = float(loss.value)
         return self.last_loss
 
-    def optimizer_step(self):
-        """Average the gradients over the ranks (if torch.distributed is up) and apply Adam."""
-        scale = sum_gradients(self.grads)
+    def read_last_loss(self):
+        loss = C.c_float()
+        check(lib.bsmi_unet_train_last_loss(self.model._h, C.byref(loss), self._stream()))
+        self.last_loss = float(loss.value)
+        return self.last_loss
+
+    def optimizer_step(self, overlapped=True):
+        """Average the gradients over the ranks (if torch.distributed is up) and apply Adam.  overlapped: reduce group by
+        group behind the backward pass (reduce_gradient_groups); else one all-reduce of the whole buffer once it is done."""
+        scale = reduce_gradient_groups(self) if overlapped else sum_gradients(self.grads)
         check(lib.bsmi_unet_train_adam_step(self.model._h, self.lr, self.betas[0], self.betas[1], self.eps, scale, self._stream()))
 
     def training_step(self, batch):
-        """batch: dict like the reference's ("raw", then per head "gt_<x>", "<x>_weights" in head order)."""
+        """batch: dict like the reference's ("raw", then per head "gt_<x>", "<x>_weights" in head order).  The forward /
+        backward pass is queued without waiting, the gradient reduction follows it group by group, then Adam; the loss is
+        read last (one synchronisation per step)."""
         heads = [h for h, _ in self.model.heads]
         key = {"affs_head": ("gt_affs", "affs_weights"), "lsds_head": ("gt_lsds", "lsds_weights")}
-        loss = self.forward_backward(batch["raw"], [batch[key[h][0]] for h in heads], [batch[key[h][1]] for h in heads])
+        self.forward_backward(batch["raw"], [batch[key[h][0]] for h in heads], [batch[key[h][1]] for h in heads], wait=False)
         self.optimizer_step()
-        return loss
+        return self.read_last_loss()
 
     def read(self, key, what="param"):
         idx = {"param": 0, "grad": 1, "exp_avg": 2, "exp_avg_sq": 3}[what]
@@ -134,6 +223,21 @@ class Trainer:
         out = np.empty(cnt.value, dtype=np.float32)
         check(lib.bsmi_unet_train_read_param(self.model._h, key.encode(), idx, out.ctypes.data_as(C.c_void_p)))
         return out
+
+    def write(self, key, what, values):
+        """restore an Adam moment ("exp_avg" / "exp_avg_sq") of one parameter"""
+        idx = {"exp_avg": 2, "exp_avg_sq": 3}[what]
+        a = np.ascontiguousarray(values, dtype=np.float32).ravel()
+        off, cnt = C.c_uint64(), C.c_uint64()
+        check(lib.bsmi_unet_train_param_info(self.model._h, key.encode(), C.byref(off), C.byref(cnt)))
+        if a.size != cnt.value:
+            raise ValueError(f"{key}: {a.size} values for {cnt.value} parameters")
+        check(lib.bsmi_unet_train_write_param(self.model._h, key.encode(), idx, a.ctypes.data_as(C.c_void_p)))
+
+    def step_count(self, set_to=None):
+        v = C.c_int()
+        check(lib.bsmi_unet_train_step_count(self.model._h, -1 if set_to is None else int(set_to), C.byref(v)))
+        return v.value
 
     def param_shapes(self):
         return dict(self._shapes)

@@ -153,7 +153,10 @@ class Model:
         path = checkpoint if os.path.exists(checkpoint) else f"{checkpoint}.ckpt"
         if not os.path.exists(path):
             raise FileNotFoundError(f"Neither {checkpoint} nor {checkpoint}.ckpt were found.")
-        sd = torch.load(path, map_location="cpu", weights_only=False)
+        try:  # tensors only: a checkpoint is data, not code
+            sd = torch.load(path, map_location="cpu", weights_only=True)
+        except Exception:  # noqa: BLE001 - Lightning checkpoints may carry pickled hyper-parameter objects
+            sd = torch.load(path, map_location="cpu", weights_only=False)
         sd = sd.get("state_dict", sd.get("model_state_dict", sd))
         sd = {k.removeprefix("model."): v for k, v in sd.items()}
         return self.load_state_dict(sd)

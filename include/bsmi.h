@@ -127,6 +127,19 @@ int bsmi_unet_train_param_info(bsmi_unet *h, const char *key, uint64_t *offset, 
 int bsmi_unet_train_adam_step(bsmi_unet *h, float lr, float beta1, float beta2, float eps, float grad_scale,
                               void *stream);
 int bsmi_unet_train_read_param(bsmi_unet *h, const char *key, int what, float *host_out);
+/* last_loss: the loss of the last forward_backward (synchronises `stream`), for callers that passed loss_host = NULL to
+ *   keep the step asynchronous.
+ * grad_groups: the flat buffers cut into the ranges whose gradients become final together (one per ConvPass / head), in
+ *   the order the backward pass finishes them; wait_grad_group makes `stream` wait until the last forward_backward has
+ *   finished group g -- a data-parallel caller reduces group after group on a side stream while the backward pass
+ *   still runs (the implicit DDP of training.py:125-133 overlaps bucket all-reduces the same way).
+ * write_param (what = 2 / 3) and step_count restore the Adam moments and step of a checkpoint (Lightning resumes them,
+ *   training.py:131-137 ckpt_path); step_count(set_to < 0) only reads. */
+int bsmi_unet_train_last_loss(bsmi_unet *h, float *loss_host, void *stream);
+int bsmi_unet_train_grad_groups(bsmi_unet *h, int max_n, int *n, uint64_t *offsets, uint64_t *counts);
+int bsmi_unet_train_wait_grad_group(bsmi_unet *h, int group, void *stream);
+int bsmi_unet_train_write_param(bsmi_unet *h, const char *key, int what, const float *host_in);
+int bsmi_unet_train_step_count(bsmi_unet *h, int set_to, int *value);
 int bsmi_unet_train_end(bsmi_unet *h);
 
 /* Affinity training targets of one sample, on the device (reference models/3d_affs/train.py:127-139:

@@ -117,6 +117,76 @@ def test_bs_train_driver(tmp_path):
     assert any("resuming from" in l for l in logs)
 
 
+def test_resume_restores_optimizer_state_and_steps_repeat(golden_dir):
+    """Two steps, a checkpoint (weights + Adam moments + step count in the Lightning layout), a fresh trainer resumed from it,
+    two more steps: the parameters equal four uninterrupted steps.  The weight gradients are accumulated with f32 atomics,
+    so two runs of the same step agree to rounding, not bit for bit: the check states that tolerance."""
+    from bootstrapper_amd.unet import Model
+    from bootstrapper_amd.training import Trainer, save_checkpoint, load_optimizer_state
+    d = np.load(os.path.join(golden_dir, "train_affs_f4i2.npz"))
+    meta = json.loads(bytes(d["config"]).decode())
+    sd = {k[3:]: d[k] for k in d.files if k.startswith("w0:")}
+    nc = {"in_channels": 1, "num_fmaps": meta["num_fmaps"], "fmap_inc_factor": meta["fmap_inc_factor"],
+          "downsample_factors": [[1, 2, 2]] * 3, "kernel_size_down": [[[3, 3, 3], [3, 3, 3]]] * 4,
+          "kernel_size_up": [[[3, 3, 3], [3, 3, 3]]] * 3, "outputs": {"3d_affs": {"dims": 6}}}
+    batch = {"raw": torch.from_numpy(d["x"]).cuda(), "gt_affs": torch.from_numpy(d["gt0"][0]).cuda(),
+             "affs_weights": torch.from_numpy(d["w0"][0]).cuda()}
+
+    def run(n_steps, model=None, resume=None):
+        m = model or Model(nc, precision="f32").load_state_dict(sd)
+        tr = Trainer(m, meta["in_shape"], lr=1e-3)
+        if resume:
+            assert load_optimizer_state(tr, resume)
+        losses = [tr.training_step(batch) for _ in range(n_steps)]
+        return m, tr, losses
+
+    _, tr4, losses4 = run(4)
+    p4 = {k: tr4.read(k) for k in sd}
+    assert tr4.step_count() == 4 and losses4[3] < losses4[0]
+    tr4.close()
+    _, tr4b, _ = run(4)
+    d_rr = max(np.abs(tr4b.read(k) - p4[k]).max() for k in sd)   # run-to-run: atomics reorder the weight-gradient sums
+    tr4b.close()
+    m2, tr2, _ = run(2)
+    import tempfile
+    with tempfile.TemporaryDirectory() as td:
+        path = os.path.join(td, "model_checkpoint_2.ckpt")
+        save_checkpoint(tr2, path, 2)
+        tr2.close()
+        ck = torch.load(path, map_location="cpu", weights_only=True)
+        assert ck["global_step"] == 2 and set(ck["optimizer_states"][0]["state"][0]) == {"step", "exp_avg", "exp_avg_sq"}
+        assert len(ck["optimizer_states"][0]["param_groups"][0]["params"]) == len(sd)
+        m3 = Model(nc, precision="f32").load_checkpoint(path)
+        _, tr3, _ = run(2, model=m3, resume=path)
+        assert tr3.step_count() == 4
+        d_resume = max(np.abs(tr3.read(k) - p4[k]).max() for k in sd)
+        # without the optimizer state the first resumed steps are bias-corrected sign steps: visibly different
+        m4 = Model(nc, precision="f32").load_checkpoint(path)
+        _, tr5, _ = run(2, model=m4)
+        d_nostate = max(np.abs(tr5.read(k) - p4[k]).max() for k in sd)
+        tr3.close(); tr5.close()
+        print(f"run-to-run {d_rr:.3e}, resumed {d_resume:.3e}, resumed without optimizer state {d_nostate:.3e}")
+        assert d_rr < 1e-4 and d_resume < 1e-4 and d_nostate > 10 * max(d_rr, d_resume, 1e-5)
+
+
+def test_ranks_draw_different_samples(tmp_path):
+    """`bs train` seeds its sample stream with 42 + rank: two data-parallel ranks must not train on the same crops."""
+    from bootstrapper_amd.train import make_sample_source
+    from bootstrapper_amd.zarr_io import prepare_ds
+    rng = np.random.default_rng(4)
+    store = str(tmp_path / "vol.zarr")
+    raw = rng.integers(0, 256, size=(40, 130, 130), dtype=np.uint8)
+    labels = rng.integers(1, 9, size=(40, 130, 130)).astype(np.uint64)
+    for name, arr in (("raw", raw), ("labels", labels)):
+        ds = prepare_ds(f"{store}/{name}", arr.shape, offset=(0, 0, 0), voxel_size=(40, 4, 4), chunk_shape=(20, 64, 64), dtype=arr.dtype)
+        ds[:] = arr
+    nc = {"input_shape": [30, 108, 108], "output_shape": [2, 16, 16],
+          "outputs": {"3d_affs": {"dims": 3, "neighborhood": [[-1, 0, 0], [0, -1, 0], [0, 0, -1]], "grow_boundary": 0}}}
+    cfg = {"samples": [{"raw": f"{store}/raw", "labels": f"{store}/labels"}]}
+    a, b, a2 = (next(make_sample_source(cfg, nc, 0, r)) for r in (0, 1, 0))
+    assert torch.equal(a["raw"], a2["raw"]) and not torch.equal(a["raw"], b["raw"])
+
+
 def test_full_net_training_step_vs_cpu_oracle():
     """The full 3d_affs net (94.7 M parameters, 1500/1800-channel layers: multi-tile weight gradients, persistent
     split-K input gradients) on the reference's training block, against the CPU oracle's autograd (about 20 s)."""
