@@ -81,6 +81,7 @@ def _load():
         "bsmi_seg_destroy": (i32, [p]),
         "bsmi_ws_fragments_u8": (i32, [p, vp, i64p, i32, i32, vp, vp, vp]),
         "bsmi_ws_fragments_seeds_u8": (i32, [p, vp, i64p, i32, i32, vp, vp, vp, vp]),
+        "bsmi_rag_agglomerate_u8": (i32, [p, vp, vp, i64p, C.c_float, C.c_int, vp]),
         "bsmi_rag_edge_stats": (i32, [p, vp, vp, C.c_uint64, vp]),
         "bsmi_agglomerate_mean_u8": (i32, [p, vp, vp, i64p, C.POINTER(C.c_float), i32, vp, vp]),
         "bsmi_frag_postprocess_u8": (i32, [p, vp, vp, i64p, C.c_double, C.c_int64, i64p, i64p, C.c_uint64, vp, vp, vp]),

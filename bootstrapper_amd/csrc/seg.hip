@@ -1161,6 +1161,24 @@ __global__ void rag_scores_kernel(AggWs w, uint64_t* __restrict__ edges, float* 
     }
 }
 
+// fragments -> ids of their merged clusters after rag_merge_kernel, in place (a cluster is named by its smallest id: the
+// survivor of every merge is the smaller rank, and ranks ascend with the ids)
+__global__ void rag_relabel_kernel(uint64_t* __restrict__ frags, size_t n, AggWs w) {
+  keep_overflow(w);
+  if (w.counters[3]) return;
+  for (size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x; p < n; p += (size_t)gridDim.x * blockDim.x) {
+    const uint64_t f = frags[p];
+    if (!f) continue;
+    uint32_t r = agg_rank<true>(w, f);
+    for (;;) {
+      const uint32_t q = w.parent[r];
+      if (q == r) break;
+      r = q;
+    }
+    frags[p] = w.ids[r];
+  }
+}
+
 // affinity sum and voxel-pair count of every INITIAL edge of the last RAG call, in edge order (the merge loop changes
 // esum / ecnt; the hash table rows the edges were compacted from still hold the initial values)
 __global__ void rag_edge_stats_kernel(AggWs w, uint64_t* __restrict__ sums, uint64_t* __restrict__ counts, uint64_t cap) {
@@ -2083,23 +2101,15 @@ int bsmi_label_stats(bsmi_seg* h, const uint64_t* labels_dev, const int64_t shap
   return BSMI_OK;
 }
 
-int bsmi_rag_merge_scores_u8(bsmi_seg* h, const uint8_t* affs_dev, const uint64_t* frags_dev, const int64_t shape[3],
-                             float threshold, int discretize_queue, uint64_t* edges_dev, float* scores_dev,
-                             uint64_t edge_capacity, uint64_t* merges_dev, float* merge_scores_dev, uint64_t* counts_dev,
-                             void* stream) {
-  int rc = check_seg_shape(h, shape);
-  if (rc) return rc;
-  if (!affs_dev || !frags_dev || !edges_dev || !scores_dev || !counts_dev) BSMI_FAIL(BSMI_ERR_INVALID, "null argument");
-  if (discretize_queue < 1 || discretize_queue > kMaxQueueBins)
-    BSMI_FAIL(BSMI_ERR_INVALID, "discretize_queue must be in [1, %d] (the exact-order queue is bsmi_agglomerate_mean_u8)", kMaxQueueBins);
-  if (!(threshold > 0.f)) BSMI_FAIL(BSMI_ERR_INVALID, "threshold must be positive");
+// ids -> ranks, region graph, bin-queue merge loop up to `threshold` (the common front of the two RAG entry points)
+static int rag_build_and_merge(bsmi_seg* h, const uint8_t* affs_dev, const uint64_t* frags_dev, const int64_t shape[3], float threshold,
+                               int discretize_queue, uint64_t* counts_dev, hipStream_t s) {
   BSMI_HIP(hipSetDevice(h->device));
-  hipStream_t s = (hipStream_t)stream;
   const size_t n = (size_t)shape[0] * shape[1] * shape[2];
   const int D = (int)shape[0], H = (int)shape[1], W = (int)shape[2];
   AggWs& g = h->agg;
   BSMI_HIP(hipMemsetAsync(g.counters, 0, 8 * sizeof(uint32_t), s));
-  BSMI_HIP(hipMemsetAsync(counts_dev, 0, 3 * sizeof(uint64_t), s));
+  if (counts_dev) BSMI_HIP(hipMemsetAsync(counts_dev, 0, 3 * sizeof(uint64_t), s));
   BSMI_HIP(hipMemsetAsync(g.idkeys, 0xff, (size_t)g.icap * sizeof(uint64_t), s));
   BSMI_HIP(hipMemsetAsync(g.hkeys, 0xff, (size_t)g.hcap * sizeof(uint64_t), s));
   BSMI_HIP(hipMemsetAsync(g.hsum, 0, (size_t)g.hcap * sizeof(unsigned long long), s));
@@ -2118,8 +2128,41 @@ int bsmi_rag_merge_scores_u8(bsmi_seg* h, const uint8_t* affs_dev, const uint64_
                                               (int)g.hcap, 0, 64, s));
   hipLaunchKernelGGL(rag_compact_kernel, dim3(std::min<uint32_t>(g.hcap / bs, 2048u)), dim3(bs), 0, s, g);
   hipLaunchKernelGGL(rag_merge_kernel, dim3(8), dim3(64), 0, s, g, threshold, discretize_queue);
-  hipLaunchKernelGGL(rag_scores_kernel, dim3(1024), dim3(bs), 0, s, g, edges_dev, scores_dev, edge_capacity, merges_dev,
+  return BSMI_OK;
+}
+
+int bsmi_rag_merge_scores_u8(bsmi_seg* h, const uint8_t* affs_dev, const uint64_t* frags_dev, const int64_t shape[3],
+                             float threshold, int discretize_queue, uint64_t* edges_dev, float* scores_dev,
+                             uint64_t edge_capacity, uint64_t* merges_dev, float* merge_scores_dev, uint64_t* counts_dev,
+                             void* stream) {
+  int rc = check_seg_shape(h, shape);
+  if (rc) return rc;
+  if (!affs_dev || !frags_dev || !edges_dev || !scores_dev || !counts_dev) BSMI_FAIL(BSMI_ERR_INVALID, "null argument");
+  if (discretize_queue < 1 || discretize_queue > kMaxQueueBins)
+    BSMI_FAIL(BSMI_ERR_INVALID, "discretize_queue must be in [1, %d] (the exact-order queue is bsmi_agglomerate_mean_u8)", kMaxQueueBins);
+  if (!(threshold > 0.f)) BSMI_FAIL(BSMI_ERR_INVALID, "threshold must be positive");
+  hipStream_t s = (hipStream_t)stream;
+  rc = rag_build_and_merge(h, affs_dev, frags_dev, shape, threshold, discretize_queue, counts_dev, s);
+  if (rc) return rc;
+  const int bs = 256;
+  hipLaunchKernelGGL(rag_scores_kernel, dim3(1024), dim3(bs), 0, s, h->agg, edges_dev, scores_dev, edge_capacity, merges_dev,
                      merge_scores_dev, counts_dev);
+  BSMI_HIP(hipGetLastError());
+  return BSMI_OK;
+}
+
+int bsmi_rag_agglomerate_u8(bsmi_seg* h, const uint8_t* affs_dev, uint64_t* frags_dev, const int64_t shape[3], float threshold,
+                            int discretize_queue, void* stream) {
+  int rc = check_seg_shape(h, shape);
+  if (rc) return rc;
+  if (!affs_dev || !frags_dev) BSMI_FAIL(BSMI_ERR_INVALID, "null argument");
+  if (discretize_queue < 1 || discretize_queue > kMaxQueueBins) BSMI_FAIL(BSMI_ERR_INVALID, "discretize_queue must be in [1, %d]", kMaxQueueBins);
+  if (!(threshold > 0.f)) BSMI_FAIL(BSMI_ERR_INVALID, "threshold must be positive");
+  hipStream_t s = (hipStream_t)stream;
+  rc = rag_build_and_merge(h, affs_dev, frags_dev, shape, threshold, discretize_queue, nullptr, s);
+  if (rc) return rc;
+  const size_t n = (size_t)shape[0] * shape[1] * shape[2];
+  hipLaunchKernelGGL(rag_relabel_kernel, dim3((unsigned)std::min<size_t>((n + 255) / 256, 4096)), dim3(256), 0, s, frags_dev, n, h->agg);
   BSMI_HIP(hipGetLastError());
   return BSMI_OK;
 }

@@ -140,9 +140,10 @@ class WatershedFrags(_BlockTask):
                  epsilon_agglomerate=0.0, sigma=None, noise_eps=None, bias=None, filter_fragments=0.0,
                  remove_debris=0, device=0, origin=(0, 0, 0)):
         super().__init__(block_size, context, total_shape, device, origin)
-        if seed_eps is not None or epsilon_agglomerate or any([sigma, noise_eps, bias]):
-            raise NotImplementedError("seed_eps / epsilon_agglomerate / sigma / noise_eps / bias are not implemented "
-                                      "on the device (the reference defaults leave them off)")
+        if seed_eps is not None:
+            raise NotImplementedError("seed_eps is not implemented on the device (the reference default leaves it off)")
+        self.epsilon_agglomerate = float(epsilon_agglomerate or 0.0)
+        self.shift = dict(sigma=sigma, noise_eps=noise_eps, bias=bias)
         self.fragments_in_xy = bool(fragments_in_xy)
         self.min_seed_distance = int(min_seed_distance)
         self.filter_fragments = float(filter_fragments)
@@ -164,7 +165,14 @@ class WatershedFrags(_BlockTask):
             m = self.read_array(mask, rbegin, rend)
             a_dev = a_dev * torch.from_numpy((m > 0).astype(np.uint8)).to(dev)
         eng = self.engine
-        frags, _ = eng.ws_fragments(a_dev, self.fragments_in_xy, self.min_seed_distance)
+        src = a_dev
+        if any(v is not None for v in self.shift.values()):  # compute_fragments, watershed_frags.py:116-145
+            from .shifts import boundary_mask_affinities
+            src = boundary_mask_affinities(a_dev, self.fragments_in_xy, dtype=torch.float64,
+                                           generator=torch.Generator(device=dev).manual_seed(block_index), **self.shift)
+        frags, _ = eng.ws_fragments(src, self.fragments_in_xy, self.min_seed_distance)
+        if self.epsilon_agglomerate > 0:                     # epsilon_agglomerate_fragments, :158-177
+            eng.rag_agglomerate(a_dev.contiguous(), frags, self.epsilon_agglomerate, 256)
         crop_off = tuple(w - r for w, r in zip(wbox[0], rbegin))
         crop_shape = tuple(e - b for b, e in zip(*wbox))
         id_offset = block_index * self.num_voxels_in_block

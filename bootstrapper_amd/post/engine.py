@@ -129,6 +129,16 @@ class SegEngine:
             return edges[:ne], scores[:ne], merges[:nm], mscores[:nm]
         return edges[:ne], scores[:ne]
 
+    def rag_agglomerate(self, affs_u8, frags, threshold, discretize_queue=256):
+        """Epsilon agglomeration of `frags` IN PLACE (reference watershed_frags.py:158-177); asynchronous."""
+        if affs_u8.dtype != torch.uint8 or not affs_u8.is_cuda or affs_u8.dim() != 4 or affs_u8.shape[0] != 3 or not affs_u8.is_contiguous():
+            raise ValueError("affs must be a contiguous uint8 CUDA tensor of shape (3, D, H, W)")
+        if frags.dtype != torch.int64 or tuple(frags.shape) != tuple(affs_u8.shape[1:]) or not frags.is_contiguous():
+            raise ValueError("fragments must be a contiguous int64 tensor of shape (D, H, W)")
+        check(lib.bsmi_rag_agglomerate_u8(self._h, C.c_void_p(affs_u8.data_ptr()), C.c_void_p(frags.data_ptr()), _lib.i64x3(frags.shape),
+                                          float(threshold), int(discretize_queue), self._stream()))
+        return frags
+
     def rag_edge_stats(self, n_edges):
         """(affinity sums, voxel-pair counts) int64 [n_edges] of the initial edges of the last rag_merge_scores call."""
         dev = torch.device("cuda", self.device)

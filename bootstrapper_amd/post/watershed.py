@@ -29,8 +29,6 @@ def simple_watershed(config, device=0):
     sigma, noise_eps, bias = config.get("sigma"), config.get("noise_eps"), config.get("bias")
     if merge_function != "mean":
         raise NotImplementedError(f"merge_function {merge_function!r}: only 'mean' is implemented (the one the reference enables)")
-    if any([sigma, noise_eps, bias]):
-        raise NotImplementedError("affinity shifts (sigma / noise_eps / bias) are not implemented on the device")
     if affs.dtype != np.uint8:
         raise NotImplementedError("the device path takes uint8 affinities (what `bs predict` stores)")
 
@@ -51,7 +49,12 @@ def simple_watershed(config, device=0):
 
     frag_params = {"fragments_in_xy": fragments_in_xy, "min_seed_distance": min_seed_distance,
                    "sigma": sigma, "noise_eps": noise_eps, "bias": bias}
-    frags, _ = watershed_from_affinities(a, fragments_in_xy=fragments_in_xy, min_seed_distance=min_seed_distance)
+    if any([sigma, noise_eps, bias]):   # post/watershed.py:285-303: the watershed sees the shifted affinities
+        from .shifts import boundary_mask_affinities
+        src = boundary_mask_affinities(a, fragments_in_xy, sigma, noise_eps, bias, dtype=torch.float32)
+    else:
+        src = a
+    frags, _ = watershed_from_affinities(src, fragments_in_xy=fragments_in_xy, min_seed_distance=min_seed_distance)
     frags_name = os.path.join(config["fragments_dataset"], build_name(frag_params))
     common = dict(offset=roi[0], voxel_size=affs.voxel_size, axis_names=affs.axis_names[1:], units=affs.units,
                   dtype=np.uint64)
@@ -130,10 +133,8 @@ def waterz_pipeline(config, device=None, rank=0, world=1, group=None):
         "filter_fragments": config.get("filter_fragments", 0.0),
         "remove_debris": config.get("remove_debris", 0),
     }
-    if frag_params["seed_eps"] is not None or frag_params["epsilon_agglomerate"] or any(
-            [frag_params["sigma"], frag_params["noise_eps"], frag_params["bias"]]):
-        raise NotImplementedError("seed_eps / epsilon_agglomerate / sigma / noise_eps / bias are not implemented on the device "
-                                  "(the reference defaults leave them off)")
+    if frag_params["seed_eps"] is not None:
+        raise NotImplementedError("seed_eps is not implemented on the device (the reference default leaves it off)")
     voxel_size = affs.voxel_size
     if config.get("roi_offset") is not None:
         roi = (list(config["roi_offset"]), list(config["roi_shape"]))
@@ -159,7 +160,9 @@ def waterz_pipeline(config, device=None, rank=0, world=1, group=None):
     mask = open_ds(config["mask_dataset"]) if config.get("mask_dataset") else None
     seg = SlabSegmenter((z1 - z0,) + total_shape[1:], block_size, ctx, layers, starts[rank], thresholds, frag_params["fragments_in_xy"],
                         frag_params["min_seed_distance"], frag_params["filter_fragments"], frag_params["remove_debris"], 256,
-                        n_lanes=int(config.get("lanes", 8)), device=device, rank=rank, world=world, group=group, exchange_affs=False)
+                        n_lanes=int(config.get("lanes", 8)), device=device, rank=rank, world=world, group=group, exchange_affs=False,
+                        epsilon_agglomerate=frag_params["epsilon_agglomerate"], sigma=frag_params["sigma"],
+                        noise_eps=frag_params["noise_eps"], bias=frag_params["bias"])
     _fill_affinities(seg, affs, origin, z0, mask)
 
     # fragments + edge scores of this worker's blocks (post/watershed.py:118-153), accounted like daisy tasks

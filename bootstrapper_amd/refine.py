@@ -1,10 +1,10 @@
 """`bs refine` statistics filters and id remap on the device.
 
-Behavioural mirror of /root/reference/bootstrapper/refine.py: `size_filter` (:176-213), `outlier_filter` (:131-168),
-`z_filter` (:221-257), `remap` (:272-307) with the same options, statistics formulas, default output names
-(`_default_out`, :24-31) and dataset metadata (`_prepare_like`, :34-45).  The label scans (`_global_sizes`, z extents)
-and the masking / remapping run in libbsmi (`bsmi_label_table_u64`, `bsmi_lut_relabel`), tile by tile; the decisions
-on the per-object table are a few numpy lines, as in the reference.  `morph` (fastmorph [EXT]) is not part of this engine.
+Same commands, options, statistics and default output names as /root/reference/bootstrapper/refine.py (`size_filter`
+:176-213, `outlier_filter` :131-168, `z_filter` :221-257, `remap` :272-307; `morph` needs fastmorph [EXT] and is not part
+of this engine).  Structure: the label volume is scanned once on the device into an `ObjectTable` (ids, voxel counts,
+first / last section: `bsmi_label_table_u64` tile by tile), a filter is a rule that turns the table into a rejection
+mask (`FILTERS`), and `run_filter` writes the volume with the rejected ids zeroed through `bsmi_lut_relabel`.
 """
 import click
 import numpy as np
@@ -12,16 +12,21 @@ import numpy as np
 from .zarr_io import open_ds, prepare_ds
 
 
-def _default_out(in_array, suffix):
-    head, sep, tail = in_array.partition(".zarr/")
-    if not sep or ".zarr/" in tail:
-        raise click.ClickException(f"cannot derive an out_array from {in_array!r}; pass --out_array")
-    return f"{head}.zarr/{tail}_{suffix}"
+def derived_dataset(in_array, suffix):
+    """`<store>.zarr/<dataset>` -> `<store>.zarr/<dataset>_<suffix>`, the reference's default output name; an input that
+    does not sit directly inside exactly one .zarr container has no such default."""
+    marker = ".zarr/"
+    at = in_array.find(marker)
+    if at < 0 or marker in in_array[at + len(marker):]:
+        raise click.ClickException(f"no default output name for {in_array!r}: give --out_array")
+    return f"{in_array}_{suffix}"
 
 
-def _prepare_like(in_ds, out_array):
-    return prepare_ds(out_array, shape=in_ds.shape, offset=in_ds.offset, voxel_size=in_ds.voxel_size, axis_names=in_ds.axis_names,
-                      units=in_ds.units, dtype=in_ds.dtype, chunk_shape=in_ds.chunks, compressor=in_ds.meta.get("compressor"))
+def _empty_copy(in_ds, out_array):
+    """an output dataset with the input's geometry, metadata, chunking and compressor"""
+    keep = dict(shape=in_ds.shape, dtype=in_ds.dtype, chunk_shape=in_ds.chunks, offset=in_ds.offset, voxel_size=in_ds.voxel_size,
+                axis_names=in_ds.axis_names, units=in_ds.units, compressor=in_ds.meta.get("compressor"))
+    return prepare_ds(out_array, **keep)
 
 
 def _tiles(in_ds, tile=1024):
@@ -70,7 +75,7 @@ def _apply_mapping(in_ds, out_array, keys, vals, device=0):
     """out = in with keys[k] -> vals[k] (ids not listed stay), tile by tile through bsmi_lut_relabel."""
     from .post.engine import lut_relabel
     d = _Device(in_ds, device)
-    out_ds = _prepare_like(in_ds, out_array)
+    out_ds = _empty_copy(in_ds, out_array)
     order = np.argsort(keys, kind="stable")
     k = d.torch.from_numpy(np.asarray(keys, np.uint64)[order].view(np.int64)).to(d.dev)
     v = d.torch.from_numpy(np.asarray(vals, np.uint64)[order].view(np.int64)).to(d.dev)
@@ -80,79 +85,115 @@ def _apply_mapping(in_ds, out_array, keys, vals, device=0):
     return out_ds
 
 
-def _finish_filter(in_ds, in_array, out_array, remove_ids, dry_run, suffix, device=0):
+class ObjectTable:
+    """Per-object statistics of a label volume, gathered on the device: ids ascending, voxel counts, first / last section."""
+
+    def __init__(self, in_array, device=0):
+        self.path = in_array
+        self.ds = open_ds(in_array)
+        self.ids, self.sizes, self.zmin, self.zmax = label_table(self.ds, device)
+        if self.ids.size == 0:
+            raise click.ClickException(f"{in_array} holds no labelled voxels")
+
+    @property
+    def z_extent(self):
+        return self.zmax - self.zmin + 1
+
+
+def _by_size(t, min_size=0, max_size=None, **_):
+    """objects below min_size (when set) or above max_size (when set)"""
+    drop = np.zeros(t.ids.size, dtype=bool)
+    if min_size > 0:
+        drop |= t.sizes < min_size
+    if max_size:
+        drop |= t.sizes > max_size
+    yield f"{t.ids.size} objects, {int(t.sizes.min())} to {int(t.sizes.max())} voxels (median {int(np.median(t.sizes))})"
+    yield f"keeping sizes in [{min_size}, {max_size}]: {int(drop.sum())} objects go"
+    return drop
+
+
+def _by_outlier(t, num_std=3.0, min_size=0, **_):
+    """objects whose size is further than num_std standard deviations from the mean; both moments are taken over the
+    objects of at least min_size voxels (population standard deviation), the cut applies to all"""
+    basis = t.sizes[t.sizes >= min_size]
+    if basis.size == 0:
+        raise click.ClickException(f"no object reaches min_size = {min_size}: no statistics to cut by")
+    centre, spread = float(basis.mean()), float(basis.std())
+    low, high = centre - num_std * spread, centre + num_std * spread
+    drop = (t.sizes < low) | (t.sizes > high)
+    q = np.percentile(basis, [50, 90, 99, 99.9])
+    yield f"{t.ids.size} objects, {basis.size} of them >= {min_size} voxels; quantiles 50/90/99/99.9 %: " + " / ".join(f"{v:.0f}" for v in q)
+    yield f"mean {centre:.1f}, std {spread:.1f}: sizes outside [{low:.1f}, {high:.1f}] go ({int(drop.sum())} objects)"
+    return drop
+
+
+def _by_z_extent(t, min_z=1, **_):
+    """objects that span min_z sections or fewer"""
+    drop = t.z_extent <= min_z
+    yield f"{t.ids.size} objects; {int(drop.sum())} span {min_z} section(s) or fewer and go"
+    return drop
+
+
+# filter name -> (rule, suffix of the default output dataset)
+FILTERS = {"size": (_by_size, "size_filtered"), "outlier": (_by_outlier, "outlier_filtered"), "z": (_by_z_extent, "z_filtered")}
+
+
+def run_filter(kind, in_array, out_array=None, dry_run=False, device=0, **options):
+    """Evaluate one rule on the object table and write the volume with the rejected objects set to 0 (refine.py:131-257).
+    -> the dataset written, None on a dry run."""
+    rule, suffix = FILTERS[kind]
+    table = ObjectTable(in_array, device)
+    steps = rule(table, **options)
+    try:
+        while True:
+            print(next(steps))
+    except StopIteration as done:
+        drop = done.value
     if dry_run:
-        print("dry run; nothing written")
+        print("dry run: no dataset written")
         return None
-    out_array = out_array or _default_out(in_array, suffix)
-    print(f"Writing to {out_array}")
-    _apply_mapping(in_ds, out_array, remove_ids, np.zeros(len(remove_ids), np.uint64), device)
-    return out_array
+    target = out_array or derived_dataset(in_array, suffix)
+    print(f"-> {target}")
+    gone = table.ids[drop]
+    _apply_mapping(table.ds, target, gone, np.zeros(gone.size, np.uint64), device)
+    return target
 
 
 def size_filter(in_array, out_array=None, min_size=0, max_size=None, dry_run=False, device=0):
-    in_ds = open_ds(in_array)
-    uniq, sizes, _, _ = label_table(in_ds, device)
-    if uniq.size == 0:
-        raise click.ClickException("no foreground objects in volume")
-    remove = np.zeros(uniq.size, dtype=bool)
-    if min_size > 0:
-        remove |= sizes < min_size
-    if max_size:
-        remove |= sizes > max_size
-    remove_ids = uniq[remove]
-    print(f"{uniq.size} objects; sizes min={int(sizes.min())} max={int(sizes.max())} median={int(np.median(sizes))}")
-    print(f"range [{min_size}, {max_size}] -> removing {remove_ids.size} objects")
-    return _finish_filter(in_ds, in_array, out_array, remove_ids, dry_run, "size_filtered", device)
+    return run_filter("size", in_array, out_array, dry_run, device, min_size=min_size, max_size=max_size)
 
 
 def outlier_filter(in_array, out_array=None, num_std=3.0, min_size=0, dry_run=False, device=0):
-    in_ds = open_ds(in_array)
-    uniq, sizes, _, _ = label_table(in_ds, device)
-    if uniq.size == 0:
-        raise click.ClickException("no foreground objects in volume")
-    stat_sizes = sizes[sizes >= min_size]
-    if stat_sizes.size == 0:
-        raise click.ClickException(f"no objects with size >= min_size ({min_size})")
-    mean, std = float(stat_sizes.mean()), float(stat_sizes.std())
-    lo, hi = mean - num_std * std, mean + num_std * std
-    remove_ids = uniq[(sizes < lo) | (sizes > hi)]
-    p50, p90, p99, p999 = np.percentile(stat_sizes, [50, 90, 99, 99.9])
-    print(f"{uniq.size} objects; {stat_sizes.size} with size >= {min_size}")
-    print(f"size p50={p50:.0f} p90={p90:.0f} p99={p99:.0f} p99.9={p999:.0f} min={int(sizes.min())} max={int(sizes.max())}")
-    print(f"mean={mean:.1f} std={std:.1f} | cut lo={lo:.1f} hi={hi:.1f} -> removing {remove_ids.size} objects")
-    return _finish_filter(in_ds, in_array, out_array, remove_ids, dry_run, "outlier_filtered", device)
+    return run_filter("outlier", in_array, out_array, dry_run, device, num_std=num_std, min_size=min_size)
 
 
 def z_filter(in_array, out_array=None, min_z=1, dry_run=False, device=0):
-    in_ds = open_ds(in_array)
-    ids, _, zmin, zmax = label_table(in_ds, device)
-    spans = zmax - zmin + 1
-    remove_ids = ids[spans <= min_z]
-    print(f"{ids.size} objects; removing {remove_ids.size} with z-extent <= {min_z}")
-    return _finish_filter(in_ds, in_array, out_array, remove_ids, dry_run, "z_filtered", device)
+    return run_filter("z", in_array, out_array, dry_run, device, min_z=min_z)
+
+
+def _id_list(text):
+    return [int(tok) for tok in text.replace(" ", "").split(",") if tok]
 
 
 def remap(in_array, out_array=None, remove_ids=None, merge_ids=(), device=0):
-    remove = {int(x) for x in remove_ids.replace(" ", "").split(",")} if remove_ids else set()
-    merge = {}
+    """ids of --remove_ids become 0; every id of a --merge_ids group becomes the group's first id (refine.py:272-307)"""
+    table = {}
     for group in merge_ids:
-        ids = [int(x) for x in group.replace(" ", "").split(",")]
-        for mid in ids:
-            merge[mid] = ids[0]
-    conflict = remove & set(merge)
-    if conflict:
-        raise click.ClickException(f"ids given to both --remove_ids and --merge_ids: {sorted(conflict)}")
-    mapping = {**{i: 0 for i in remove}, **merge}
-    if not mapping:
-        raise click.ClickException("nothing to do: pass --remove_ids and/or --merge_ids")
-    print(f"remapping {len(mapping)} ids: {mapping}")
-    in_ds = open_ds(in_array)
-    out_array = out_array or _default_out(in_array, "remapped")
-    print(f"Writing to {out_array}")
-    keys = np.array(sorted(mapping), dtype=np.uint64)
-    _apply_mapping(in_ds, out_array, keys, np.array([mapping[int(k)] for k in keys], dtype=np.uint64), device)
-    return out_array
+        members = _id_list(group)
+        table.update({m: members[0] for m in members})
+    zeroed = _id_list(remove_ids) if remove_ids else []
+    both = sorted(set(zeroed) & set(table))
+    if both:
+        raise click.ClickException(f"{both}: an id cannot be removed and merged at once")
+    table.update({z: 0 for z in zeroed})
+    if not table:
+        raise click.ClickException("give --remove_ids and / or --merge_ids")
+    print(f"{len(table)} ids change: {table}")
+    target = out_array or derived_dataset(in_array, "remapped")
+    print(f"-> {target}")
+    src = np.fromiter(sorted(table), dtype=np.uint64, count=len(table))
+    _apply_mapping(open_ds(in_array), target, src, np.array([table[int(k)] for k in src], dtype=np.uint64), device)
+    return target
 
 
 @click.group()

@@ -109,7 +109,8 @@ class SlabSegmenter:
 
     def __init__(self, slab_shape, block, context, total_layers, layer0, thresholds=(0.2, 0.35, 0.5),
                  fragments_in_xy=True, min_seed_distance=10, filter_fragments=0.0, remove_debris=0, discretize_queue=256,
-                 n_lanes=8, device=0, rank=0, world=1, group=None, edge_cap=1 << 17, label_cap=1 << 16, exchange_affs=True):
+                 n_lanes=8, device=0, rank=0, world=1, group=None, edge_cap=1 << 17, label_cap=1 << 16, exchange_affs=True,
+                 epsilon_agglomerate=0.0, sigma=None, noise_eps=None, bias=None, noise_seed=0):
         self.shape = tuple(int(s) for s in slab_shape)
         self.block = tuple(int(b) for b in block)
         self.ctx = tuple(int(c) for c in context)
@@ -117,6 +118,9 @@ class SlabSegmenter:
         self.fragments_in_xy, self.msd = bool(fragments_in_xy), int(min_seed_distance)
         self.filter_fragments, self.remove_debris = float(filter_fragments), int(remove_debris)
         self.bins = int(discretize_queue)
+        self.epsilon = float(epsilon_agglomerate or 0.0)
+        self.shift = dict(sigma=sigma, noise_eps=noise_eps, bias=bias)
+        self.noise_seed = int(noise_seed)
         self.rank, self.world, self.group = int(rank), int(world), group
         # False: the caller fills the context margins of the affinities itself (a driver reads them from the dataset,
         # where also the data beyond the ROI is real); the fragments' margins are always exchanged
@@ -224,7 +228,16 @@ class SlabSegmenter:
             a = self._buf(lane["a"], rshape, (3,))
             a.copy_(self.affs[(slice(None),) + self._read_slices(k)])
             eng = lane["engine"]
-            fr, _ = eng.ws_fragments(a, self.fragments_in_xy, self.msd)
+            if any(v is not None for v in self.shift.values()):
+                # watershed_frags.py:116-145: the watershed sees the shifted affinities, everything after it the plain ones
+                from .post.shifts import boundary_mask_affinities
+                gen = torch.Generator(device=self.dev).manual_seed(self.noise_seed + self.block_ids[k])
+                src = boundary_mask_affinities(a, self.fragments_in_xy, dtype=torch.float64, generator=gen, **self.shift)
+            else:
+                src = a
+            fr, _ = eng.ws_fragments(src, self.fragments_in_xy, self.msd)
+            if self.epsilon > 0:
+                eng.rag_agglomerate(a, fr, self.epsilon, 256)   # watershed_frags.py:182-183
             lab = self._buf(lane["lab"], wshape)
             eng.postprocess_fragments(a, fr, self.filter_fragments, self.remove_debris, self.ctx, wshape,
                                       self.block_ids[k] * self.nvb, out=lab, num=self.nums[k:k + 1])

@@ -260,6 +260,13 @@ int bsmi_rag_merge_scores_u8(bsmi_seg *h, const uint8_t *affs_dev, const uint64_
                              uint64_t *merges_dev, float *merge_scores_dev, uint64_t *counts_dev,
                              void *stream);
 
+/* Epsilon agglomeration of a block's fragments IN PLACE (reference post/blockwise/watershed_frags.py:158-177:
+ * waterz.agglomerate(thresholds=[epsilon], fragments, "OneMinus<MeanAffinity>", discretize_queue=256), result written
+ * back into the fragments): every fragment takes the id of its cluster, the smallest id among the fragments merged
+ * into it.  Same region graph and merge loop as bsmi_rag_merge_scores_u8. */
+int bsmi_rag_agglomerate_u8(bsmi_seg *h, const uint8_t *affs_dev, uint64_t *frags_dev, const int64_t shape[3],
+                            float threshold, int discretize_queue, void *stream);
+
 /* Affinity sum (uint8 units) and voxel-pair count of every initial RAG edge of the last bsmi_rag_merge_scores_u8 call
  * on this handle, in the order of its edges_dev: what waterz's region graph {u, v, score} is computed from
  * (score = 1 - sum / (255 count)); also lets a caller contract the graph along the merge history. */

@@ -24,7 +24,37 @@ def _boxes(total, block):
             for z in grid[0] for y in grid[1] for x in grid[2]]
 
 
-def cpu_blockwise(affs, block, ctx, msd, ff, rd, thresholds, bins=256, workers=1):
+def shifted_mask_affinities(a, fragments_in_xy=True, sigma=None, bias=None, dtype=np.float64):
+    """watershed_frags.py:116-131 / post/watershed.py:285-303 with scipy, then ws.py's threshold (ws.py:64-77,100): the mask
+    of the shifted affinities as 0 / 255 pseudo-affinities (post/ws.py reads nothing else from them)."""
+    from scipy.ndimage import gaussian_filter
+    x = a[:3].astype(dtype) / dtype(255.0)
+    shift = np.zeros_like(x)
+    if sigma is not None:
+        shift += gaussian_filter(x, sigma=(0, *sigma)) - x
+    if bias is not None:
+        b = list(bias) if isinstance(bias, (list, tuple)) else [bias] * x.shape[0]
+        shift += np.array([b]).reshape((-1, 1, 1, 1)).astype(dtype)
+    x = x + shift
+    mask = (0.5 * (x[-1] + x[-2]) > 0.5) if fragments_in_xy else (np.mean(x, axis=0) > 0.5)
+    return np.repeat((mask.astype(np.uint8) * 255)[None], 3, axis=0)
+
+
+def epsilon_agglomerate(a, frags, epsilon, bins=256):
+    """watershed_frags.py:158-177: waterz.agglomerate(thresholds=[epsilon], discretize_queue=256) written back into the fragments"""
+    from oracle import seg_ref as S
+    _, _, merges, _ = S.rag_merge_scores_u8(a, frags, epsilon, bins)
+    parent = {int(b): int(s) for s, b in merges}
+    out = frags.copy()
+    for b in parent:
+        r = b
+        while r in parent:
+            r = parent[r]
+        out[frags == np.uint64(b)] = np.uint64(r)
+    return out
+
+
+def cpu_blockwise(affs, block, ctx, msd, ff, rd, thresholds, bins=256, workers=1, epsilon=0.0, sigma=None, bias=None):
     """-> (fragments u64, nodes, edges, scores, [segmentation per threshold]).  workers > 1: the blocks of a stage run on
     a thread pool (the C calls release the GIL), as the reference's stages run on daisy workers."""
     from concurrent.futures import ThreadPoolExecutor
@@ -40,7 +70,10 @@ def cpu_blockwise(affs, block, ctx, msd, ff, rd, thresholds, bins=256, workers=1
         a = pad_read(affs, rb, re, lead=True)
         if a.max() == 0:
             return
-        fr, _ = S.ws_fragments_u8(a, True, msd)
+        src = a if sigma is None and bias is None else shifted_mask_affinities(a, True, sigma, bias)
+        fr, _ = S.ws_fragments_u8(src, True, msd)
+        if epsilon > 0:
+            fr = epsilon_agglomerate(a, fr, epsilon)
         fr = S.filter_fragments_u8(a, fr, ff, rd)
         crop = np.ascontiguousarray(fr[tuple(slice(ctx[d], ctx[d] + e[d] - b[d]) for d in range(3))])
         lab, n = S.label26(crop)

@@ -129,3 +129,30 @@ def test_block_task_mirrors_equal_cpu_blockwise():
     o, o_ref = np.lexsort((e[:, 1], e[:, 0])), np.lexsort((E[:, 1], E[:, 0]))
     assert np.array_equal(e[o], E[o_ref])
     np.testing.assert_array_equal(s[o], Sc[o_ref])
+
+
+def test_epsilon_agglomeration_and_affinity_shifts():
+    """The optional steps of the blockwise fragments task (watershed_frags.py:116-131 shifts, :158-177 epsilon
+    agglomeration) through SlabSegmenter against the CPU composition (scipy's Gaussian; the noise shift is random in the
+    reference and left out).  The Gaussian runs in float64 on both sides; a voxel whose shifted mean lands within rounding
+    of the 0.5 cut could differ, so the mask itself is compared first."""
+    from bootstrapper_amd.volume import SlabSegmenter
+    from bootstrapper_amd.post.shifts import boundary_mask_affinities
+    from oracle.blockwise_ref import cpu_blockwise, shifted_mask_affinities
+    shape, block, ctx = (12, 96, 80), (6, 48, 40), (1, 6, 5)
+    affs = blobby_affs(shape, 41, empty_corner=False)
+    sigma, bias = (0.5, 1.5, 1.5), [-0.05, 0.02, 0.03]
+    for xy in (True, False):
+        m_dev = boundary_mask_affinities(torch.from_numpy(affs).cuda(), xy, sigma=sigma, bias=bias, dtype=torch.float64).cpu().numpy()
+        m_ref = shifted_mask_affinities(affs, xy, sigma, bias)
+        assert np.array_equal(m_dev, m_ref), xy
+        assert 0.2 < (m_ref[0] > 0).mean() < 0.8
+    thr = [0.4]
+    frags_ref, nodes, E, Sc, segs_ref = cpu_blockwise(affs, block, ctx, 4, 0.2, 8, thr, epsilon=0.15, sigma=sigma, bias=bias)
+    plain, _, _, _, _ = cpu_blockwise(affs, block, ctx, 4, 0.2, 8, thr)
+    assert len(nodes) < len(np.unique(plain)) - 1                   # the epsilon merges reduce the fragments
+    seg = SlabSegmenter(shape, block, ctx, 2, 0, thr, True, 4, 0.2, 8, 256, n_lanes=4, epsilon_agglomerate=0.15, sigma=sigma, bias=bias)
+    seg.interior(seg.affs).copy_(torch.from_numpy(affs).cuda())
+    segs = seg.run()
+    assert np.array_equal(seg.interior(seg.frags).cpu().numpy().view(np.uint64), frags_ref)
+    assert np.array_equal(segs[0].cpu().numpy().view(np.uint64), segs_ref[0])
