@@ -107,6 +107,7 @@ def _load():
         "bsmi_unet_train_end": (i32, [p]),
         "bsmi_train_affinity_targets": (i32, [C.c_int, vp, vp, i64p, C.POINTER(C.c_int32), C.c_int, C.c_int, C.c_int, C.c_float,
                                               C.c_float, vp, vp, vp]),
+        "bsmi_train_lsd_targets": (i32, [C.c_int, vp, vp, i64p, i64p, i64p, C.POINTER(C.c_float), C.POINTER(C.c_float), C.c_int, vp, vp, vp]),
         "bsmi_unet_set_persistent_grid": (i32, [p, C.c_int]),
         "bsmi_stream_create_cu_mask": (i32, [C.c_int, vp, C.c_int, C.POINTER(C.c_void_p)]),
         "bsmi_stream_destroy": (i32, [C.c_int, vp]),

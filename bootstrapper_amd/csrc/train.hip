@@ -1325,6 +1325,142 @@ int bsmi_train_affinity_targets(int device, int64_t* labels_dev, const uint8_t* 
   return BSMI_OK;
 }
 
+// ---- local shape descriptors (3-D, 10 channels) -------------------------------------------------------------
+// lsd.train.LsdExtractor.get_descriptors as AddLocalShapeDescriptor calls it (reference models/3d_mtlsd/train.py:134-141;
+// the lsd package is not in /root/reference: restated from its published algorithm, see oracle/lsd_ref.py).  For a voxel p
+// of object l the statistics are those of l inside a Gaussian window around p's cell of the `df`-times sub-sampled grid:
+//   count = sum_t w(t - s) [label(t) == l],  mean = sum w c(t) / count,  cov = sum w c c^T / count - mean mean^T
+// with s = p / df (integer), t over the sub-sampled grid, c = world coordinates of the sub-grid points and w the product
+// of normalised 1-D Gaussians truncated at 3 sigma (scipy.ndimage.gaussian_filter(mode="constant", truncate=3.0)).
+// Channels: mean - c(s) (z, y, x) / sigma * 0.5 + 0.5 | variances / sigma^2 | Pearson zy, zx, yx * 0.5 + 0.5 | count;
+// clipped to [0, 1]; background voxels are all zero.  Coordinates are taken relative to s (the differences are what
+// enters; the library's absolute float32 coordinates only add rounding).
+struct LsdArgs {
+  const int64_t* labels;  // [D][H][W] with the context the window needs
+  int D, H, W;
+  int oz, oy, ox, d, h, w;  // output ROI inside the label array
+  int df;                   // sub-sampling factor
+  int rz, ry, rx;           // window radii on the sub-sampled grid
+  float step[3];            // world distance between sub-grid points
+  float sigma[3];           // world units
+  const float* wz; const float* wy; const float* wx;  // normalised 1-D weights [2r + 1]
+};
+
+__global__ void lsd_targets_kernel(LsdArgs a, const uint8_t* __restrict__ unl, float* __restrict__ lsds, float* __restrict__ weights) {
+  const size_t nout = (size_t)a.d * a.h * a.w;
+  const int SD = a.D / a.df, SH = a.H / a.df, SW = a.W / a.df;  // sub-sampled extent (labels[::df])
+  for (size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x; p < nout; p += (size_t)gridDim.x * blockDim.x) {
+    const int x = (int)(p % a.w), y = (int)((p / a.w) % a.h), z = (int)(p / ((size_t)a.w * a.h));
+    const int Z = z + a.oz, Y = y + a.oy, X = x + a.ox;
+    const size_t q0 = ((size_t)Z * a.H + Y) * a.W + X;
+    const int64_t l = a.labels[q0];
+    float out[10] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if (l != 0) {
+      const int sz = Z / a.df, sy = Y / a.df, sx = X / a.df;
+      double n = 0, m[3] = {0, 0, 0}, c[6] = {0, 0, 0, 0, 0, 0};
+      for (int dz = -a.rz; dz <= a.rz; ++dz) {
+        const int tz = sz + dz;
+        if (tz < 0 || tz >= SD) continue;
+        const float gz = a.wz[dz + a.rz];
+        for (int dy = -a.ry; dy <= a.ry; ++dy) {
+          const int ty = sy + dy;
+          if (ty < 0 || ty >= SH) continue;
+          const float gzy = gz * a.wy[dy + a.ry];
+          const int64_t* row = a.labels + ((size_t)(tz * a.df) * a.H + (size_t)ty * a.df) * a.W;
+          for (int dx = -a.rx; dx <= a.rx; ++dx) {
+            const int tx = sx + dx;
+            if (tx < 0 || tx >= SW) continue;
+            if (row[(size_t)tx * a.df] != l) continue;
+            const double wgt = (double)(gzy * a.wx[dx + a.rx]);
+            const double cz = dz * (double)a.step[0], cy = dy * (double)a.step[1], cx = dx * (double)a.step[2];
+            n += wgt;
+            m[0] += wgt * cz; m[1] += wgt * cy; m[2] += wgt * cx;
+            c[0] += wgt * cz * cz; c[1] += wgt * cy * cy; c[2] += wgt * cx * cx;
+            c[3] += wgt * cz * cy; c[4] += wgt * cz * cx; c[5] += wgt * cy * cx;
+          }
+        }
+      }
+      const double cnt = n == 0 ? 1.0 : n;
+      double mean[3], var[3], pe[3];
+      for (int i = 0; i < 3; ++i) mean[i] = m[i] / cnt;
+      for (int i = 0; i < 3; ++i) var[i] = c[i] / cnt - mean[i] * mean[i];
+      pe[0] = c[3] / cnt - mean[0] * mean[1];
+      pe[1] = c[4] / cnt - mean[0] * mean[2];
+      pe[2] = c[5] / cnt - mean[1] * mean[2];
+      for (int i = 0; i < 3; ++i) var[i] = var[i] < 1e-3 ? 1e-3 : var[i];
+      pe[0] /= sqrt(var[0] * var[1]);
+      pe[1] /= sqrt(var[0] * var[2]);
+      pe[2] /= sqrt(var[1] * var[2]);
+      for (int i = 0; i < 3; ++i) {
+        out[i] = (float)(mean[i] / a.sigma[i] * 0.5 + 0.5);
+        out[3 + i] = (float)(var[i] / ((double)a.sigma[i] * a.sigma[i]));
+        out[6 + i] = (float)(pe[i] * 0.5 + 0.5);
+      }
+      out[9] = (float)n;
+      for (int i = 0; i < 10; ++i) out[i] = out[i] < 0.f ? 0.f : (out[i] > 1.f ? 1.f : out[i]);
+    }
+    // lsds_mask: labelled voxels, times the known-voxel mask (AddLocalShapeDescriptor.process)
+    const float wv = (l != 0 && (!unl || unl[q0])) ? 1.f : 0.f;
+    for (int i = 0; i < 10; ++i) {
+      lsds[(size_t)i * nout + p] = out[i];
+      if (weights) weights[(size_t)i * nout + p] = wv;
+    }
+  }
+}
+
+extern "C" int bsmi_train_lsd_targets(int device, const int64_t* labels_dev, const uint8_t* unlabelled_dev, const int64_t shape[3],
+                                      const int64_t roi_offset[3], const int64_t roi_shape[3], const float sigma[3],
+                                      const float voxel_size[3], int downsample, float* lsds_dev, float* weights_dev, void* stream) {
+  if (!labels_dev || !shape || !roi_offset || !roi_shape || !sigma || !voxel_size || !lsds_dev) BSMI_FAIL(BSMI_ERR_INVALID, "null argument");
+  if (downsample < 1 || downsample > 8) BSMI_FAIL(BSMI_ERR_INVALID, "downsample %d outside 1..8", downsample);
+  LsdArgs a;
+  a.labels = labels_dev;
+  a.D = (int)shape[0]; a.H = (int)shape[1]; a.W = (int)shape[2];
+  a.oz = (int)roi_offset[0]; a.oy = (int)roi_offset[1]; a.ox = (int)roi_offset[2];
+  a.d = (int)roi_shape[0]; a.h = (int)roi_shape[1]; a.w = (int)roi_shape[2];
+  a.df = downsample;
+  for (int i = 0; i < 3; ++i) {
+    if (shape[i] < 1 || shape[i] > 4096 || roi_shape[i] < 1 || roi_offset[i] < 0 || roi_offset[i] + roi_shape[i] > shape[i])
+      BSMI_FAIL(BSMI_ERR_INVALID, "bad shape / ROI");
+    if (shape[i] % downsample || roi_offset[i] % downsample || roi_shape[i] % downsample)
+      BSMI_FAIL(BSMI_ERR_INVALID, "shape and ROI must be multiples of the downsample factor %d (as the lsd package requires)", downsample);
+    if (!(sigma[i] > 0.f) || !(voxel_size[i] > 0.f)) BSMI_FAIL(BSMI_ERR_INVALID, "sigma and voxel_size must be positive");
+    a.sigma[i] = sigma[i];
+    a.step[i] = voxel_size[i] * downsample;
+  }
+  BSMI_HIP(hipSetDevice(device));
+  hipStream_t s = (hipStream_t)stream;
+  // normalised 1-D weights as scipy's gaussian_filter1d builds them (sigma in sub-grid voxels, truncate = 3.0)
+  int r[3];
+  std::vector<float> w[3];
+  for (int i = 0; i < 3; ++i) {
+    const double sv = (double)sigma[i] / ((double)voxel_size[i] * downsample);
+    r[i] = (int)(3.0 * sv + 0.5);
+    if (r[i] > 512) BSMI_FAIL(BSMI_ERR_INVALID, "LSD window radius %d too large", r[i]);
+    std::vector<double> g(2 * r[i] + 1);
+    double sum = 0;
+    for (int k = -r[i]; k <= r[i]; ++k) sum += g[k + r[i]] = exp(-0.5 * (double)k * k / (sv * sv));
+    w[i].resize(g.size());
+    for (size_t k = 0; k < g.size(); ++k) w[i][k] = (float)(g[k] / sum);
+  }
+  a.rz = r[0]; a.ry = r[1]; a.rx = r[2];
+  float* wdev = nullptr;
+  const size_t nw = w[0].size() + w[1].size() + w[2].size();
+  BSMI_HIP(hipMallocAsync((void**)&wdev, nw * sizeof(float), s));
+  std::vector<float> all;
+  for (int i = 0; i < 3; ++i) all.insert(all.end(), w[i].begin(), w[i].end());
+  // the host vector must outlive the asynchronous copy: copy synchronously (a few hundred bytes)
+  BSMI_HIP(hipStreamSynchronize(s));
+  BSMI_HIP(hipMemcpy(wdev, all.data(), nw * sizeof(float), hipMemcpyHostToDevice));
+  a.wz = wdev; a.wy = wdev + w[0].size(); a.wx = wdev + w[0].size() + w[1].size();
+  const size_t nout = (size_t)a.d * a.h * a.w;
+  hipLaunchKernelGGL(lsd_targets_kernel, dim3((unsigned)std::min<size_t>((nout + 127) / 128, 65535)), dim3(128), 0, s, a, unlabelled_dev, lsds_dev,
+                     weights_dev);
+  BSMI_HIP(hipGetLastError());
+  BSMI_HIP(hipFreeAsync(wdev, s));
+  return BSMI_OK;
+}
+
 int bsmi_unet_train_end(bsmi_unet* h) {
   if (h && h->train) {
     // the trained parameters become the handle's weights: host copies refreshed, the bf16 images re-packed on demand

@@ -71,18 +71,43 @@ def affinity_targets(labels, unlabelled, neighborhood, grow_steps=0, only_xy=Tru
     return affs, weights
 
 
+def lsd_targets(labels, roi_offset, roi_shape, sigma, voxel_size, downsample=1, unlabelled=None):
+    """3-D local shape descriptors of one sample on the device (reference models/3d_mtlsd/train.py:134-141).
+    labels: int64 CUDA (D, H, W) holding the crop with the window context; -> (gt_lsds, lsds_weights) float32 (10, d, h, w)."""
+    if labels.dtype != torch.int64 or not labels.is_cuda or labels.dim() != 3 or not labels.is_contiguous():
+        raise ValueError("labels must be a contiguous int64 CUDA tensor")
+    if unlabelled is not None and (unlabelled.dtype != torch.uint8 or unlabelled.shape != labels.shape or not unlabelled.is_contiguous()):
+        raise ValueError("unlabelled must be a contiguous uint8 tensor of the labels' shape")
+    sig = [float(sigma)] * 3 if isinstance(sigma, (int, float)) else [float(v) for v in sigma]
+    out = torch.empty((10,) + tuple(int(v) for v in roi_shape), dtype=torch.float32, device=labels.device)
+    weights = torch.empty_like(out)
+    _lib.check(_lib.lib.bsmi_train_lsd_targets(
+        labels.device.index, C.c_void_p(labels.data_ptr()), C.c_void_p(unlabelled.data_ptr()) if unlabelled is not None else None,
+        _lib.i64x3(labels.shape), _lib.i64x3(roi_offset), _lib.i64x3(roi_shape), (C.c_float * 3)(*sig),
+        (C.c_float * 3)(*[float(v) for v in voxel_size]), int(downsample), C.c_void_p(out.data_ptr()), C.c_void_p(weights.data_ptr()),
+        C.c_void_p(torch.cuda.current_stream(labels.device).cuda_stream)))
+    return out, weights
+
+
 class SampleSource:
     """Infinite iterator of reference-style batches from (raw, labels[, mask]) Zarr volumes."""
 
-    def __init__(self, samples, input_shape, output_shape, neighborhood, device=0, seed=42, head="affs", grow_boundary=0):
+    def __init__(self, samples, input_shape, output_shape, neighborhood, device=0, seed=42, head="affs", grow_boundary=0,
+                 lsd_sigma=None, lsd_downsample=1, voxel_size=(1, 1, 1)):
         self.samples = [(open_ds(s["raw"]), open_ds(s["labels"]), open_ds(s["mask"]) if s.get("mask") else None) for s in samples]
         self.inp, self.out = tuple(input_shape), tuple(output_shape)
         self.nhood = [list(map(int, o)) for o in neighborhood]
         self.rng = np.random.default_rng(seed)
         self.dev = torch.device("cuda", device)
         self.grow = int(grow_boundary)
-        if head != "affs":
-            raise NotImplementedError("only the affinity head has a ground-truth generator here (LSD targets need lsd.train [EXT])")
+        # head: "affs" (3d_affs), "lsds" (3d_lsd) or "mtlsd" (3d_mtlsd: both, models/3d_mtlsd/train.py:134-153)
+        if head not in ("affs", "lsds", "mtlsd"):
+            raise ValueError(f"unknown head {head!r}")
+        self.head = head
+        self.lsd_sigma, self.lsd_df = lsd_sigma, int(lsd_downsample)
+        self.voxel_size = tuple(float(v) for v in voxel_size)
+        if head != "affs" and lsd_sigma is None:
+            raise ValueError("the LSD head needs net_config outputs.3d_lsds.sigma")
 
     def __iter__(self):
         return self
@@ -111,20 +136,47 @@ class SampleSource:
             raw[tuple(dst)] = raw_ds[tuple(src)]
             x = torch.from_numpy(raw).to(self.dev).float() * (1.0 / 255.0) * 2.0 - 1.0
             lab = torch.from_numpy(labels).to(self.dev)
-            affs, weights = affinity_targets(lab, torch.from_numpy(unl.astype(np.uint8)).to(self.dev), self.nhood, self.grow, only_xy=True)
-            return {"raw": x, "gt_affs": affs, "affs_weights": weights}
+            unl_dev = torch.from_numpy(unl.astype(np.uint8)).to(self.dev)
+            batch = {"raw": x}
+            if self.head != "affs":
+                # descriptors see the labels 3 sigma beyond the output block (AddLocalShapeDescriptor grows its request by
+                # that context; beyond the volume the padded labels are 0), snapped to the sub-sampling grid
+                df = self.lsd_df
+                sig = [float(self.lsd_sigma)] * 3 if isinstance(self.lsd_sigma, (int, float)) else list(self.lsd_sigma)
+                cv = [int(-(-3.0 * s // v)) for s, v in zip(sig, self.voxel_size)]
+                cv = [-(-c // df) * df for c in cv]
+                big = np.zeros([o + 2 * c for o, c in zip(self.out, cv)], dtype=np.int64)
+                bun = np.zeros(big.shape, dtype=np.uint8)
+                src, dst = [], []
+                for a, c, n, o in zip(off, cv, shape, self.out):
+                    lo, hi = max(a - c, 0), min(a + o + c, n)
+                    src.append(slice(lo, hi))
+                    dst.append(slice(lo - (a - c), hi - (a - c)))
+                big[tuple(dst)] = lab_ds[tuple(src)].astype(np.int64)
+                bun[tuple(dst)] = (mask_ds[tuple(src)] > 0) if mask_ds is not None else (big[tuple(dst)] > 0)
+                lsds, lw = lsd_targets(torch.from_numpy(big).to(self.dev), cv, self.out, sig, self.voxel_size, df,
+                                       torch.from_numpy(bun).to(self.dev))
+                batch.update(gt_lsds=lsds, lsds_weights=lw)
+            if self.head != "lsds":
+                affs, weights = affinity_targets(lab, unl_dev, self.nhood, self.grow, only_xy=True)
+                batch.update(gt_affs=affs, affs_weights=weights)
+            return batch
         raise RuntimeError("no training location with at least 5 % labelled voxels found")
 
 
 def make_sample_source(config, net_config, device=0, rank=0):
     """The built-in sample stream of `bs train` for this rank: seed 42 + rank, so that data-parallel ranks see different
     samples (with one seed for all, the averaged gradient would be the single-rank gradient computed N times)."""
-    out3d = net_config["outputs"].get("3d_affs")
-    if out3d is None or len(net_config["outputs"]) != 1:
-        raise NotImplementedError("the built-in sample source feeds the 3d_affs model only")
-    return SampleSource(config["samples"], net_config["input_shape"], net_config["output_shape"],
-                        out3d["neighborhood"][: int(out3d["dims"])], device=device, seed=42 + int(rank),
-                        grow_boundary=int(out3d.get("grow_boundary", 0)))
+    outs = net_config["outputs"]
+    out3d, lsd3d = outs.get("3d_affs"), outs.get("3d_lsds")
+    if set(outs) - {"3d_affs", "3d_lsds"} or not outs:
+        raise NotImplementedError(f"the built-in sample source feeds the 3-D setups (3d_affs, 3d_lsd, 3d_mtlsd), not {sorted(outs)}")
+    head = "mtlsd" if out3d and lsd3d else ("affs" if out3d else "lsds")
+    nhood = out3d["neighborhood"][: int(out3d["dims"])] if out3d else [[-1, 0, 0], [0, -1, 0], [0, 0, -1]]
+    return SampleSource(config["samples"], net_config["input_shape"], net_config["output_shape"], nhood, device=device,
+                        seed=42 + int(rank), head=head, grow_boundary=int(out3d.get("grow_boundary", 0)) if out3d else 0,
+                        lsd_sigma=lsd3d.get("sigma") if lsd3d else None, lsd_downsample=int(lsd3d.get("downsample", 1)) if lsd3d else 1,
+                        voxel_size=config.get("voxel_size", (1, 1, 1)))
 
 
 def default_init(net_config, seed=42):

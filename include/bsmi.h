@@ -160,6 +160,19 @@ int bsmi_train_affinity_targets(int device, int64_t *labels_dev, const uint8_t *
                                 int only_xy, float clip_min, float clip_max, float *affs_dev,
                                 float *weights_dev, void *stream);
 
+/* Local-shape-descriptor training targets of one sample, on the device (reference models/3d_mtlsd/train.py:134-141:
+ * AddLocalShapeDescriptor(labels, gt_lsds, unlabelled, lsds_mask, sigma, downsample) of the lsd package [EXT]; restated
+ * in oracle/lsd_ref.py).  3-D descriptors, 10 channels: mean offset (z, y, x), variances, Pearson coefficients
+ * (zy, zx, yx), size -- each in [0, 1].
+ *   labels_dev   int64 [D][H][W]: the label crop grown by the window context (3 sigma; zeros where the volume ends)
+ *   unlabelled_dev  uint8 [D][H][W] or NULL: 1 where the ground truth is known
+ *   roi_offset / roi_shape  the output block inside that array (all multiples of `downsample`, like the lsd package asks)
+ *   sigma, voxel_size  world units (net_config "sigma" is one number: the same for the three axes)
+ *   lsds_dev     float [10][d][h][w];  weights_dev  float [10][d][h][w] or NULL: 1 on labelled, known voxels        */
+int bsmi_train_lsd_targets(int device, const int64_t *labels_dev, const uint8_t *unlabelled_dev, const int64_t shape[3],
+                           const int64_t roi_offset[3], const int64_t roi_shape[3], const float sigma[3],
+                           const float voxel_size[3], int downsample, float *lsds_dev, float *weights_dev, void *stream);
+
 /* Number of CUs the stream bsmi_unet_forward is called on may use (a multiple of 8; -1 restores the
  * default = all CUs of the device, 0 disables the persistent launches).  The big-tile conv layers run
  * as that many persistent workgroups (conv_igemm.hip); set it when the stream carries a CU mask. */

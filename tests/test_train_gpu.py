@@ -282,3 +282,64 @@ def test_affinity_targets_vs_oracle(steps, only_xy, with_mask):
     assert np.array_equal(a.cpu().numpy(), affs)
     assert np.allclose(w.cpu().numpy(), weights, rtol=1e-6, atol=0)
     assert (grown != labels).any() == (steps > 0)
+
+
+@pytest.mark.parametrize("df,sigma,vs", [(1, (6.0, 6.0, 6.0), (3.0, 2.0, 2.0)), (2, (80.0, 80.0, 80.0), (40.0, 4.0, 4.0)), (2, (10.0, 12.0, 9.0), (2.0, 2.0, 3.0))])
+def test_lsd_targets_vs_numpy_restatement(df, sigma, vs):
+    """bsmi_train_lsd_targets against the numpy / scipy restatement of lsd's LsdExtractor (oracle/lsd_ref.py; the lsd
+    package itself is absent: parity unpinned).  Floating point: the kernel sums the window directly in float64 with
+    float32 weights, scipy filters axis by axis -- agreement to 1e-4 of the [0, 1] range."""
+    from bootstrapper_amd.train import lsd_targets
+    from oracle.lsd_ref import lsd_targets as ref_lsd
+    from scipy.ndimage import gaussian_filter
+    rng = np.random.default_rng(7)
+    shape = (16, 72, 64)
+    blobs = gaussian_filter(rng.random(shape), (1, 4, 4))
+    labels = (np.digitize(blobs, np.quantile(blobs, [0.2, 0.4, 0.6, 0.8])) + 1).astype(np.int64)
+    labels[blobs < np.quantile(blobs, 0.1)] = 0                       # background
+    labels[:, :, 40:] += 7                                            # more objects, a straight boundary
+    unl = (rng.random(shape) > 0.1).astype(np.uint8)
+    off, roi = (4, 16, 12), (8, 40, 36)
+    lsds, w = lsd_targets(torch.from_numpy(labels).cuda(), off, roi, sigma, vs, df, torch.from_numpy(unl).cuda())
+    ref, wref = ref_lsd(labels, off, roi, sigma, vs, df, unl)
+    got = lsds.cpu().numpy()
+    assert got.shape == (10,) + roi and np.array_equal(w.cpu().numpy(), wref)
+    err = np.abs(got - ref).max(axis=(1, 2, 3))
+    print("max abs error per channel", err)
+    assert err.max() < 1e-4
+    fg = labels[tuple(slice(o, o + s) for o, s in zip(off, roi))] != 0
+    assert np.all(got[:, ~fg] == 0) and got[9][fg].min() > 0 and 0.2 < got[0][fg].mean() < 0.8
+    assert got[3:6][:, fg].std() > 0.01                               # the variances vary over the objects
+
+
+def test_bs_train_mtlsd_driver(tmp_path):
+    """`bs train` for the two-headed 3d_mtlsd setup (BASELINE config 3 in small): LSD and affinity targets built on the
+    device from a labelled Zarr volume, the sum of both losses trained for three iterations."""
+    from bootstrapper_amd.train import run_training, latest_checkpoint, make_sample_source
+    from bootstrapper_amd.zarr_io import prepare_ds
+    rng = np.random.default_rng(4)
+    store = str(tmp_path / "vol.zarr")
+    raw = rng.integers(0, 256, size=(40, 130, 130), dtype=np.uint8)
+    labels = np.zeros((40, 130, 130), dtype=np.uint64)
+    for i, (z, y, x) in enumerate(rng.integers(0, 100, size=(40, 3))):
+        labels[z % 30:z % 30 + 10, y:y + 30, x:x + 30] = i + 1
+    for name, arr in (("raw", raw), ("labels", labels)):
+        ds = prepare_ds(f"{store}/{name}", arr.shape, offset=(0, 0, 0), voxel_size=(40, 4, 4), chunk_shape=(20, 64, 64), dtype=arr.dtype)
+        ds[:] = arr
+    setup = tmp_path / "setup_02"
+    setup.mkdir()
+    nc = {"in_channels": 1, "num_fmaps": 4, "fmap_inc_factor": 2, "downsample_factors": [[1, 2, 2]] * 3,
+          "kernel_size_down": [[[3, 3, 3], [3, 3, 3]]] * 4, "kernel_size_up": [[[3, 3, 3], [3, 3, 3]]] * 3,
+          "input_shape": [30, 108, 108], "output_shape": [2, 16, 16],
+          "outputs": {"3d_lsds": {"dims": 10, "sigma": 80, "downsample": 2},
+                      "3d_affs": {"dims": 3, "neighborhood": [[-1, 0, 0], [0, -1, 0], [0, 0, -1]], "grow_boundary": 1}}}
+    (setup / "net_config.json").write_text(json.dumps(nc))
+    cfg = tmp_path / "train.toml"
+    cfg.write_text(f'setup_dir = "{setup}"\nvoxel_size = [40, 4, 4]\nmax_iterations = 3\nsave_checkpoints_every = 3\nsave_snapshots_every = 1000\n'
+                   f'[[samples]]\nraw = "{store}/raw"\nlabels = "{store}/labels"\n')
+    b = next(make_sample_source({"samples": [{"raw": f"{store}/raw", "labels": f"{store}/labels"}], "voxel_size": [40, 4, 4]}, nc))
+    assert tuple(b["gt_lsds"].shape) == (10, 2, 16, 16) and tuple(b["gt_affs"].shape) == (3, 2, 16, 16)
+    assert float(b["gt_lsds"].max()) <= 1.0 and float(b["lsds_weights"].sum()) > 0
+    logs = []
+    assert run_training(str(cfg), log=logs.append) == 3
+    assert latest_checkpoint(str(setup))[1] == 3 and any("train_loss" in l for l in logs)
