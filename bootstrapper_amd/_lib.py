@@ -100,6 +100,7 @@ def _load():
         "bsmi_unet_train_adam_step": (i32, [p, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, vp]),
         "bsmi_unet_train_read_param": (i32, [p, C.c_char_p, C.c_int, vp]),
         "bsmi_unet_train_last_loss": (i32, [p, C.POINTER(C.c_float), vp]),
+        "bsmi_unet_train_prediction": (i32, [p, i32, C.POINTER(C.c_void_p), C.POINTER(C.c_uint64)]),
         "bsmi_unet_train_grad_groups": (i32, [p, i32, C.POINTER(i32), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
         "bsmi_unet_train_wait_grad_group": (i32, [p, i32, vp]),
         "bsmi_unet_train_write_param": (i32, [p, C.c_char_p, C.c_int, vp]),

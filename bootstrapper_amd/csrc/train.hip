@@ -1219,6 +1219,14 @@ int bsmi_unet_train_last_loss(bsmi_unet* h, float* loss_host, void* stream) {
   return BSMI_OK;
 }
 
+int bsmi_unet_train_prediction(bsmi_unet* h, int head, float** out_dev, uint64_t* count) {
+  if (!h || !h->train || !out_dev) BSMI_FAIL(BSMI_ERR_STATE, "bsmi_unet_train_begin has not been called / null argument");
+  if (head < 0 || head >= (int)h->train->head_out.size()) BSMI_FAIL(BSMI_ERR_INVALID, "head %d out of range", head);
+  *out_dev = h->train->head_out[head];
+  if (count) *count = (uint64_t)h->train->out_vox * h->heads[head].cout;
+  return BSMI_OK;
+}
+
 int bsmi_unet_train_grad_groups(bsmi_unet* h, int max_n, int* n, uint64_t* offsets, uint64_t* counts) {
   if (!h || !h->train || !n) BSMI_FAIL(BSMI_ERR_STATE, "bsmi_unet_train_begin has not been called / null argument");
   *n = (int)h->train->groups.size();

@@ -248,6 +248,7 @@ def run_training(config_file, device=0, batches=None, log=print):
     if batches is None:
         log("note: the reference's gunpowder augmentations are not part of this engine; samples are random crops")
         batches = make_sample_source(config, net_config, device, rank)
-    n = fit(trainer, batches, max_iterations, int(config.get("save_checkpoints_every", 0)), setup_dir, log=log, start_iteration=done)
+    n = fit(trainer, batches, max_iterations, int(config.get("save_checkpoints_every", 0)), setup_dir, log=log, start_iteration=done,
+            save_snapshots_every=int(config.get("save_snapshots_every", 0)), voxel_size=config.get("voxel_size"))
     trainer.close()
     return n

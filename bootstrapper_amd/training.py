@@ -113,11 +113,43 @@ def load_optimizer_state(trainer, checkpoint):
     return True
 
 
-def fit(trainer, batches, max_iterations, save_checkpoints_every=0, setup_dir=None, log_every=10, log=print, start_iteration=0):
+def save_snapshot(setup_dir, voxel_size, step, rank, data):
+    """SnapshotCallback._save_snapshot (training.py:69-93): `<setup_dir>/snapshots/batch_<step>_rank_<rank>.zarr` with one
+    dataset per entry of the batch and of the predictions; floats in [-1, 1] go back to uint8 [0, 255], everything else
+    as it is; output-sized arrays are centred inside the input-sized ones (`offset`, in world units)."""
+    import os
+    from .zarr_io import prepare_ds
+    path = os.path.join(setup_dir, "snapshots", f"batch_{step}_rank_{rank}.zarr")
+    n = len(voxel_size)
+    arrays = {k: (v.detach().cpu().numpy() if hasattr(v, "detach") else np.asarray(v)) for k, v in data.items()}
+    largest = [max(a.shape[-n:][d] for a in arrays.values()) for d in range(n)]
+    for key, a in arrays.items():
+        if not np.issubdtype(a.dtype, np.integer):
+            lo, hi = a.min(), a.max()
+            if -1 <= lo < 0 and hi <= 1:
+                a = ((a * 0.5 + 0.5) * 255).astype(np.uint8)
+        offset = [(big - s) // 2 * int(v) for big, s, v in zip(largest, a.shape[-n:], voxel_size)]
+        ds = prepare_ds(f"{path}/{key}", a.shape, offset=offset, voxel_size=[int(v) for v in voxel_size], dtype=a.dtype)
+        ds[(slice(None),) * a.ndim] = a
+    return path
+
+
+def fit(trainer, batches, max_iterations, save_checkpoints_every=0, setup_dir=None, log_every=10, log=print, start_iteration=0,
+        save_snapshots_every=0, voxel_size=None):
     """The training loop of training.py:96-137 without Lightning: `batches` is any iterable of reference-style batch
-    dicts ("raw", "gt_affs", "affs_weights"[, "gt_lsds", "lsds_weights"]) of CUDA float32 tensors."""
+    dicts ("raw", "gt_affs", "affs_weights"[, "gt_lsds", "lsds_weights"]) of CUDA float32 tensors.  Every `log_every`
+    steps the loss also goes to `<setup_dir>/log/train_loss.csv` (the reference logs the same scalar to TensorBoard,
+    whose writer is not in this image); snapshots as SnapshotCallback writes them (step 1 and every
+    `save_snapshots_every` steps)."""
     import os
     it = int(start_iteration)
+    rank = torch.distributed.get_rank() if torch.distributed.is_available() and torch.distributed.is_initialized() else 0
+    scalars = None
+    if setup_dir and rank == 0:
+        os.makedirs(os.path.join(setup_dir, "log"), exist_ok=True)
+        scalars = open(os.path.join(setup_dir, "log", "train_loss.csv"), "a")
+        if scalars.tell() == 0:
+            scalars.write("step,train_loss\n")
     for batch in batches:
         if it >= max_iterations:
             break
@@ -125,10 +157,19 @@ def fit(trainer, batches, max_iterations, save_checkpoints_every=0, setup_dir=No
         it += 1
         if log and (it % log_every == 0 or it == start_iteration + 1):
             log(f"step {it}: train_loss {loss:.6f}")
+        if scalars and it % log_every == 0:
+            scalars.write(f"{it},{loss:.8g}\n")
+            scalars.flush()
+        if save_snapshots_every and setup_dir and voxel_size is not None and (it == 1 or it % save_snapshots_every == 0):
+            data = dict(batch)
+            data.update(trainer.predictions())
+            save_snapshot(setup_dir, voxel_size, it, rank, data)
         if save_checkpoints_every and setup_dir and it % save_checkpoints_every == 0:
             rank = torch.distributed.get_rank() if torch.distributed.is_available() and torch.distributed.is_initialized() else 0
             if rank == 0:
                 save_checkpoint(trainer, os.path.join(setup_dir, f"model_checkpoint_{it}.ckpt"), it)
+    if scalars:
+        scalars.close()
     return it
 
 
@@ -215,6 +256,17 @@ class Trainer:
         self.forward_backward(batch["raw"], [batch[key[h][0]] for h in heads], [batch[key[h][1]] for h in heads], wait=False)
         self.optimizer_step()
         return self.read_last_loss()
+
+    def predictions(self):
+        """{"pred_<x>": float32 CUDA (dims, d, h, w)} of the last step, named like the reference's training_step outputs"""
+        name = {"affs_head": "pred_affs", "lsds_head": "pred_lsds"}
+        dev = torch.device("cuda", self.model.device)
+        out = {}
+        for i, (head, dims) in enumerate(self.model.heads):
+            ptr, cnt = C.c_void_p(), C.c_uint64()
+            check(lib.bsmi_unet_train_prediction(self.model._h, i, C.byref(ptr), C.byref(cnt)))
+            out[name.get(head, "pred_" + head)] = torch.as_tensor(_DevBuf(ptr.value, cnt.value), device=dev).view((dims,) + tuple(self.out_shape)).clone()
+        return out
 
     def read(self, key, what="param"):
         idx = {"param": 0, "grad": 1, "exp_avg": 2, "exp_avg_sq": 3}[what]

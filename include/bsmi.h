@@ -136,6 +136,9 @@ int bsmi_unet_train_read_param(bsmi_unet *h, const char *key, int what, float *h
  * write_param (what = 2 / 3) and step_count restore the Adam moments and step of a checkpoint (Lightning resumes them,
  *   training.py:131-137 ckpt_path); step_count(set_to < 0) only reads. */
 int bsmi_unet_train_last_loss(bsmi_unet *h, float *loss_host, void *stream);
+/* the sigmoid outputs of head `head` from the last forward_backward, float [dims][d][h][w] on the device (what the
+ * reference's training_step returns as pred_<head> for the snapshot callback, models/3d_mtlsd/train.py:183-187) */
+int bsmi_unet_train_prediction(bsmi_unet *h, int head, float **out_dev, uint64_t *count);
 int bsmi_unet_train_grad_groups(bsmi_unet *h, int max_n, int *n, uint64_t *offsets, uint64_t *counts);
 int bsmi_unet_train_wait_grad_group(bsmi_unet *h, int group, void *stream);
 int bsmi_unet_train_write_param(bsmi_unet *h, const char *key, int what, const float *host_in);

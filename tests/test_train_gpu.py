@@ -341,5 +341,15 @@ def test_bs_train_mtlsd_driver(tmp_path):
     assert tuple(b["gt_lsds"].shape) == (10, 2, 16, 16) and tuple(b["gt_affs"].shape) == (3, 2, 16, 16)
     assert float(b["gt_lsds"].max()) <= 1.0 and float(b["lsds_weights"].sum()) > 0
     logs = []
+    cfg.write_text(cfg.read_text().replace("save_snapshots_every = 1000", "save_snapshots_every = 2"))
     assert run_training(str(cfg), log=logs.append) == 3
     assert latest_checkpoint(str(setup))[1] == 3 and any("train_loss" in l for l in logs)
+    # snapshots at step 1 and every 2 steps (training.py:46-93): batch + predictions, [-1, 1] floats as uint8, centred offsets
+    from bootstrapper_amd.zarr_io import open_ds
+    for step in (1, 2):
+        snap = str(setup / "snapshots" / f"batch_{step}_rank_0.zarr")
+        raw_s, lsds_s, pa = open_ds(snap + "/raw"), open_ds(snap + "/gt_lsds"), open_ds(snap + "/pred_affs")
+        assert raw_s.dtype == np.uint8 and raw_s.shape == (30, 108, 108) and raw_s.offset == (0, 0, 0) and raw_s.voxel_size == (40, 4, 4)
+        assert lsds_s.shape == (10, 2, 16, 16) and lsds_s.offset == (14 * 40, 46 * 4, 46 * 4) and pa.shape == (3, 2, 16, 16)
+        assert pa.dtype == np.float32 and 0 < float(pa[:].mean()) < 1
+    assert not (setup / "snapshots" / "batch_3_rank_0.zarr").exists()
