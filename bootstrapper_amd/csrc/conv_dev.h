@@ -59,8 +59,28 @@ struct Elem<bf16s_elem> {
     p->v = __builtin_bit_cast(uint16_t, h);
   }
 };
+// The same tensors and results, but the kernel itself walks LOGICAL K-steps: it stages the hi and lo planes of both
+// operands once per K-step and multiplies hi x hi, lo x hi and hi x lo from them (conv_x3_body): two thirds of the
+// LDS-DMA traffic of the K-step-list form for the same MFMAs.
+struct bf16f_elem {
+  uint16_t v;
+};
+template <>
+struct Elem<bf16f_elem> {
+  static __device__ __forceinline__ f32x16_t mfma(u32x4_t a, u32x4_t b, f32x16_t acc) { return Elem<bf16_elem>::mfma(a, b, acc); }
+  static __device__ __forceinline__ void store(bf16f_elem* p, float v) {
+    __bf16 h = (__bf16)v;
+    p->v = __builtin_bit_cast(uint16_t, h);
+  }
+};
+template <typename T>
+struct IsFused { static constexpr bool value = false; };
+template <>
+struct IsFused<bf16f_elem> { static constexpr bool value = true; };
 template <typename T>
 struct IsSplit { static constexpr bool value = false; };
+template <>
+struct IsSplit<bf16f_elem> { static constexpr bool value = true; };
 template <>
 struct IsSplit<bf16s_elem> { static constexpr bool value = true; };
 // the lo plane's value: what the bf16 rounding of v (the hi plane) left over

@@ -28,7 +28,7 @@ static_assert(sizeof(KStep) == 16, "KStep layout");
 struct ConvSrc {
   uint64_t base;       // device pointer of the channels-last source tensor
   int32_t sz, sy, sx;  // byte strides of one step in z, y, x
-  int32_t pad;
+  int32_t lo;          // fused split-bf16 launches: byte offset of the tensor's lo plane behind its hi plane
 };
 
 constexpr int kUnitsPerStep = 2;
@@ -42,6 +42,7 @@ struct ConvArgs {
   const KStep* steps;  // device
   int nsteps;
   const void* w;      // device, packed [nsteps][Npad][64 bytes] (+ kWeightRowSlack rows)
+  const void* w_lo;   // fused split-bf16 launches: the lo image of the weights, same layout (w is the hi image)
   const float* bias;  // device [Npad]
   void* out;          // device [Do][Ho][Wo][Co]
   int64_t out_lo;     // BSMI_PREC_BF16X3: byte offset of the output's lo plane behind `out` (the hi plane)

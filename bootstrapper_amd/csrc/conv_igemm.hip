@@ -604,12 +604,333 @@ __device__ __forceinline__ void conv_igemm_body16(const ConvArgs& a, char* smem,
 #endif
 }
 
+// ---- fused split-bf16 body (BSMI_PREC_BF16X3) --------------------------------------------------------------------
+// One LOGICAL K-step = the hi and lo planes of the activation rows (A lo, A hi) and of the weight rows (B hi, B lo),
+// each staged ONCE by LDS-DMA, and six MFMA groups out of them:
+//     g0  A lo x B hi[first half]      g2  A hi x B hi[first half]      g4  A hi x B lo[first half]
+//     g1  A lo x B hi[second half]     g3  A hi x B hi[second half]     g5  A hi x B lo[second half]
+// i.e. hi*hi + lo*hi + hi*lo with f32 accumulation, as the K-step-list form does with three K-steps, but with two
+// thirds of its LDS-DMA bytes, fragment reads and barriers per MFMA (the kernels sit at ~10.5 TB/s of LDS-DMA fill on
+// every tile shape: that traffic, not the MFMA pipe, is what bounds them).
+// LDS: [A lo][A hi][B hi][B lo], two entries each (K-step parity).  Entries are released as early as they die:
+// barrier X (after g1) frees A lo / A hi / B hi of this K-step for the loads of K-step h + 2 ("batch 1"), barrier Y
+// (after g4) frees B lo ("batch 2").  One A register set: the A lo fragments are replaced by A hi ones row block by
+// row block while g1 runs (and A hi by the next K-step's A lo during g5); the two B register halves alternate.
+// Early waves (all waves of a 4-wave kernel, waves 0-3 of an 8-wave one) stage batch 1 in g2 / g3 and batch 2 in g5,
+// LATE waves batch 1 in g5 / g0 and batch 2 in g2, so the two waves of a SIMD do not sit in LDS-DMA issue together.
+template <int BM, int BN, int WM, int WN, int MS, int B_INSTR, bool LATE>
+__device__ __forceinline__ void conv_x3_body(const ConvArgs& a, char* smem, int tile, int s0, int s1, float* part) {
+  using T = bf16f_elem;
+  constexpr int NW = WM * WN;
+  static_assert(NW == 4 || NW == 8, "one or two waves per SIMD");
+  static_assert(!LATE || NW == 8, "late waves exist in 8-wave kernels only");
+  constexpr int ROWB = kStepRowBytes;
+  constexpr int WTM = BM / WM, WTN = BN / WN;
+  constexpr int FM = WTM / MS, FN = WTN / MS;
+  constexpr int NH0 = FN / 2, NH1 = FN - NH0;
+  static_assert(MS == 16 || MS == 32, "MFMA shape");
+  static_assert(WTM % MS == 0 && WTN % MS == 0 && NH0 >= 1, "wave tile: whole fragments, two B halves");
+  constexpr int SUB = MS == 16 ? 1 : 2;  // 16-byte reads per fragment: 32x32x16 walks the 64-byte K-step in two halves
+  constexpr int A_INSTR = BM / 16 / NW;
+  constexpr int EA = BM * ROWB, EB = BN * ROWB;
+  constexpr int OFF_AL = 0, OFF_AH = 2 * EA, OFF_BH = 4 * EA, OFF_BL = 4 * EA + 2 * EB;
+  constexpr int G1 = 2 * A_INSTR + B_INSTR, G2 = B_INSTR;  // LDS-DMA instructions of batch 1 / batch 2 per wave
+  constexpr int P1 = (G1 + 1) / 2;                         // batch 1 goes out in two parts
+  // outstanding loads allowed at the barriers (see the schedule above): what was issued after the batch that must have landed
+  constexpr int NX = LATE ? G1 : G1 + G2;
+  constexpr int NY = LATE ? G2 : G1 + G2;
+  static_assert(G1 + G2 <= 63, "vmcnt range");
+  static_assert(BM % (16 * NW) == 0, "tile/wave mismatch");
+  typedef typename std::conditional<MS == 16, f32x4_t, f32x16_t>::type acc_t;
+
+  // every field of the launch arguments this body needs, as locals (the lambdas below capture these, not `a`)
+  const cint_ptr_t steps = (cint_ptr_t)a.steps;
+  const int nsteps = a.nsteps;
+  const gptr_t w_hi = (gptr_t)a.w, w_lo = (gptr_t)a.w_lo;
+  const float* const bias = a.bias;
+  char* const out_base = (char*)a.out;
+  const int64_t out_lo_off = a.out_lo;
+  const int aM = a.M, aNpad = a.Npad, aCo = a.Co, aWo = a.Wo, aHo = a.Ho, relu = a.relu;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave / WN, wn = wave % WN;
+  const int ntn = aNpad / BN;
+  const int nloc = s1 - s0;
+  const int tile_m = tile / ntn, tile_n = tile - tile_m * ntn;
+  const int m0 = tile_m * BM, n0 = tile_n * BN;
+
+  // staging geometry: as conv_igemm_body (lane l lands at row l >> 2, 16-byte slot l & 3 of its KiB and fetches the
+  // source chunk (l & 3) ^ key(row)); the key function belongs to the MFMA shape's fragment reads
+  const int lrow = lane >> 2, lchunk = lane & 3;
+  const int skey = MS == 16 ? swz16((lane >> 4) & 3) : ((lane >> 4) & 3);
+  const int g = lchunk ^ skey;
+  const bool unit1 = (g >> 1) != 0;
+  const uint32_t hoff = (uint32_t)((g & 1) << 4);
+  static_assert(kMaxConvTensors == 3, "three source slots");
+  uint32_t ro0[A_INSTR], ro1[A_INSTR], ro2[A_INSTR];
+#pragma unroll
+  for (int i = 0; i < A_INSTR; ++i) {
+    const int row = (i * NW + wave) * 16 + lrow;
+    int m = m0 + row;
+    m = m < aM ? m : aM - 1;
+    const int x = m % aWo;
+    const int zy = m / aWo;
+    const int y = zy % aHo, z = zy / aHo;
+    ro0[i] = (uint32_t)(z * a.t[0].sz + y * a.t[0].sy + x * a.t[0].sx);
+    ro1[i] = (uint32_t)(z * a.t[1].sz + y * a.t[1].sy + x * a.t[1].sx);
+    ro2[i] = (uint32_t)(z * a.t[2].sz + y * a.t[2].sy + x * a.t[2].sx);
+  }
+  const uint64_t base0 = a.t[0].base, base1 = a.t[1].base, base2 = a.t[2].base;
+  const uint32_t lo0 = (uint32_t)a.t[0].lo, lo1 = (uint32_t)a.t[1].lo, lo2 = (uint32_t)a.t[2].lo;
+  const uint32_t offb = (uint32_t)((n0 + wave * 16 + lrow) * ROWB + ((lchunk ^ skey) << 4));
+  const size_t wstep = (size_t)aNpad * ROWB;
+
+  acc_t acc[FM][FN];
+#pragma unroll
+  for (int i = 0; i < FM; ++i)
+#pragma unroll
+    for (int j = 0; j < FN; ++j)
+#pragma unroll
+      for (int r = 0; r < (MS == 16 ? 4 : 16); ++r) acc[i][j][r] = 0.f;
+
+  struct Desc { int t, d0, d1; };
+  auto fetch = [&](int h) __attribute__((always_inline)) -> Desc {
+    const int ha = s0 + h;
+    const cint_ptr_t d = steps + (ha < nsteps ? ha : nsteps - 1) * 4;
+    return Desc{d[0], d[1], d[2]};
+  };
+  // Batch 1 of K-step h_, instructions [K0_, K1_): k < A_INSTR: A lo, k < 2 A_INSTR: A hi, else B hi.  Macros, not lambdas:
+  // a closure that selects among the three row-offset arrays keeps them (and everything else it captures) in scratch.
+#define ISSUE1(h_, ds_, K0_, K1_)                                                                                         \
+  do {                                                                                                                     \
+    const bool t1_ = (ds_).t == 1, t2_ = (ds_).t == 2;                                                                     \
+    const gptr_t abase_ = (gptr_t)(t1_ ? base1 : (t2_ ? base2 : base0));                                                   \
+    const uint32_t tlo_ = t1_ ? lo1 : (t2_ ? lo2 : lo0);                                                                   \
+    const uint32_t lofs_ = (uint32_t)(unit1 ? (ds_).d1 : (ds_).d0) + hoff;                                                 \
+    const int p_ = (h_) & 1;                                                                                               \
+    const size_t wi_ = (size_t)(s0 + (h_) < nsteps ? s0 + (h_) : nsteps - 1) * wstep;                                      \
+    _Pragma("unroll") for (int k_ = (K0_); k_ < (K1_); ++k_) {                                                             \
+      if (k_ < 2 * A_INSTR) {                                                                                              \
+        const int i_ = k_ < A_INSTR ? k_ : k_ - A_INSTR;                                                                   \
+        const uint32_t r0_ = ro0[i_], r1_ = ro1[i_], r2_ = ro2[i_];                                                        \
+        const uint32_t src_ = (t1_ ? r1_ : (t2_ ? r2_ : r0_)) + lofs_ + (k_ < A_INSTR ? tlo_ : 0u);                        \
+        const lptr_t dst_ = (lptr_t)(smem + (k_ < A_INSTR ? OFF_AL : OFF_AH) + p_ * EA) + (i_ * NW + wave) * 1024;         \
+        __builtin_amdgcn_global_load_lds(abase_ + (size_t)src_, dst_, 16, 0, 0);                                           \
+      } else {                                                                                                             \
+        const int i_ = k_ - 2 * A_INSTR;                                                                                   \
+        __builtin_amdgcn_global_load_lds(w_hi + wi_ + (size_t)i_ * NW * 16 * ROWB + offb,                                  \
+                                         (lptr_t)(smem + OFF_BH + p_ * EB) + (i_ * NW + wave) * 1024, 16, 0, 0);           \
+      }                                                                                                                    \
+    }                                                                                                                      \
+  } while (0)
+  // batch 2: B lo of K-step h_
+#define ISSUE2(h_)                                                                                                         \
+  do {                                                                                                                     \
+    const int p_ = (h_) & 1;                                                                                               \
+    const size_t wi_ = (size_t)(s0 + (h_) < nsteps ? s0 + (h_) : nsteps - 1) * wstep;                                      \
+    _Pragma("unroll") for (int i_ = 0; i_ < B_INSTR; ++i_)                                                                 \
+      __builtin_amdgcn_global_load_lds(w_lo + wi_ + (size_t)i_ * NW * 16 * ROWB + offb,                                    \
+                                       (lptr_t)(smem + OFF_BL + p_ * EB) + (i_ * NW + wave) * 1024, 16, 0, 0);             \
+  } while (0)
+
+  // fragment addresses of this lane (loop invariant).  The swizzle key of a row is (row >> 2) & 3 and every fragment row
+  // block starts at a multiple of 16 rows, so the key -- and with it the chunk -- is the same for all blocks: one base
+  // offset per operand, the block's i * MS rows go into the instruction's immediate offset.
+  const int lr = MS == 16 ? (lane & 15) : (lane & 31);
+  const int lq = MS == 16 ? (lane >> 4) : (lane >> 5);
+  static_assert(WTM % 16 == 0 && WTN % 16 == 0 && MS % 16 == 0, "row blocks keep the swizzle key");
+  uint32_t aoff0[SUB], boff0[SUB];
+#pragma unroll
+  for (int sb = 0; sb < SUB; ++sb) {
+    const int key = MS == 16 ? swz16((lr >> 2) & 3) : ((lr >> 2) & 3);
+    const int chunk = MS == 16 ? (lq ^ key) : ((2 * sb + lq) ^ key);
+    aoff0[sb] = (uint32_t)((wm * WTM + lr) * ROWB + (chunk << 4));
+    boff0[sb] = (uint32_t)((wn * WTN + lr) * ROWB + (chunk << 4));
+  }
+  u32x4_t RA[FM][SUB], RB0[NH0][SUB], RB1[NH1][SUB];  // indexed by compile-time constants only
+  auto rdA = [&](u32x4_t* dst, const char* entry, int i) __attribute__((always_inline)) {
+#pragma unroll
+    for (int sb = 0; sb < SUB; ++sb) dst[sb] = *(const u32x4_t*)(entry + aoff0[sb] + i * (MS * ROWB));
+  };
+  auto rdB = [&](u32x4_t* dst, const char* entry, int j) __attribute__((always_inline)) {
+#pragma unroll
+    for (int sb = 0; sb < SUB; ++sb) dst[sb] = *(const u32x4_t*)(entry + boff0[sb] + j * (MS * ROWB));
+  };
+  auto fma = [&](acc_t& c, const u32x4_t* x, const u32x4_t* y) __attribute__((always_inline)) {
+    if constexpr (MS == 16) {
+      c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, x[0]), __builtin_bit_cast(bf16x8_t, y[0]), c, 0, 0, 0);
+    } else {
+#pragma unroll
+      for (int sb = 0; sb < SUB; ++sb)
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, x[sb]), __builtin_bit_cast(bf16x8_t, y[sb]), c, 0, 0, 0);
+    }
+  };
+
+  // prologue: K-steps 0 and 1 (late waves: K-step 1 up to the first part of batch 1, the rest goes out in the loop)
+  {
+    const Desc d0 = fetch(0), d1 = fetch(1);
+    ISSUE1(0, d0, 0, G1);
+    ISSUE2(0);
+    ISSUE1(1, d1, 0, P1);
+    if constexpr (!LATE) {
+      ISSUE1(1, d1, P1, G1);
+      ISSUE2(1);
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(G1 + G2) : "memory");
+    } else {
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(P1) : "memory");
+    }
+  }
+  __builtin_amdgcn_s_barrier();
+#pragma unroll
+  for (int i = 0; i < FM; ++i) rdA(RA[i], smem + OFF_AL, i);
+#pragma unroll
+  for (int j = 0; j < NH0; ++j) rdB(RB0[j], smem + OFF_BH, j);
+  Desc dl = fetch(1);  // late waves: descriptor of the batch 1 whose second part is still to go out
+
+  for (int h = 0; h < nloc; ++h) {
+    const int p = h & 1, q = p ^ 1;
+    const char* eAH = smem + OFF_AH + p * EA;
+    const char* eBH = smem + OFF_BH + p * EB;
+    const char* eBL = smem + OFF_BL + p * EB;
+    // g0: A lo x B hi, first half; the second half of B hi arrives in RB1
+    if constexpr (LATE) { ISSUE1(h + 1, dl, P1, G1); }
+#pragma unroll
+    for (int j = 0; j < NH1; ++j) rdB(RB1[j], eBH, NH0 + j);
+#pragma unroll
+    for (int i = 0; i < FM; ++i)
+#pragma unroll
+      for (int j = 0; j < NH0; ++j) fma(acc[i][j], RA[i], RB0[j]);
+    __builtin_amdgcn_sched_barrier(0);  // keep the groups apart: reads hoisted across them cost registers the 8-wave kernels do not have
+    // g1: A lo x B hi, second half, row block by row block; each A lo block gives way to its A hi block
+#pragma unroll
+    for (int i = 0; i < FM; ++i) {
+#pragma unroll
+      for (int j = 0; j < NH1; ++j) fma(acc[i][NH0 + j], RA[i], RB1[j]);
+      rdA(RA[i], eAH, i);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    // X: A lo / A hi / B hi of this K-step are read; batch 2 of this K-step (B lo) has landed everywhere
+    asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(NX) : "memory");
+    __builtin_amdgcn_s_barrier();
+    const Desc dn = fetch(h + 2);
+    __builtin_amdgcn_sched_barrier(0);
+    // g2: A hi x B hi, first half
+    if constexpr (!LATE) { ISSUE1(h + 2, dn, 0, P1); }
+    else ISSUE2(h + 1);
+#pragma unroll
+    for (int i = 0; i < FM; ++i)
+#pragma unroll
+      for (int j = 0; j < NH0; ++j) fma(acc[i][j], RA[i], RB0[j]);
+    __builtin_amdgcn_sched_barrier(0);
+    // g3: A hi x B hi, second half; the first half of B lo arrives in RB0
+    if constexpr (!LATE) { ISSUE1(h + 2, dn, P1, G1); }
+#pragma unroll
+    for (int j = 0; j < NH0; ++j) rdB(RB0[j], eBL, j);
+#pragma unroll
+    for (int i = 0; i < FM; ++i)
+#pragma unroll
+      for (int j = 0; j < NH1; ++j) fma(acc[i][NH0 + j], RA[i], RB1[j]);
+    __builtin_amdgcn_sched_barrier(0);
+    // g4: A hi x B lo, first half; the second half of B lo arrives in RB1
+#pragma unroll
+    for (int j = 0; j < NH1; ++j) rdB(RB1[j], eBL, NH0 + j);
+#pragma unroll
+    for (int i = 0; i < FM; ++i)
+#pragma unroll
+      for (int j = 0; j < NH0; ++j) fma(acc[i][j], RA[i], RB0[j]);
+    __builtin_amdgcn_sched_barrier(0);
+    // Y: B lo of this K-step is read; batch 1 of K-step h + 1 has landed everywhere
+    asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(NY) : "memory");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    // g5: A hi x B lo, second half; A lo and the first half of B hi of the next K-step arrive
+    if constexpr (!LATE) ISSUE2(h + 2);
+    else { dl = dn; ISSUE1(h + 2, dl, 0, P1); }
+#pragma unroll
+    for (int j = 0; j < NH0; ++j) rdB(RB0[j], smem + OFF_BH + q * EB, j);
+#pragma unroll
+    for (int i = 0; i < FM; ++i) {
+#pragma unroll
+      for (int j = 0; j < NH1; ++j) fma(acc[i][NH0 + j], RA[i], RB1[j]);
+      rdA(RA[i], smem + OFF_AL + q * EA, i);
+    }
+  }
+  // drain the run-ahead loads; after the barrier nobody reads or writes the staging area any more
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+
+  if (part) {
+    constexpr int NR = MS == 16 ? 4 : 16;
+#pragma unroll
+    for (int i = 0; i < FM; ++i)
+#pragma unroll
+      for (int j = 0; j < FN; ++j) *(acc_t*)(part + ((size_t)(i * FN + j) * (64 * NW) + tid) * NR) = acc[i][j];
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    return;
+  }
+  // epilogue: bias (+ReLU), (hi, lo) planes through per-wave LDS strips, 16-byte streaming stores (as the other bodies)
+  constexpr int ESZ = 2;
+  constexpr int PITCH = WTN * ESZ + 16;
+  constexpr int CPR = WTN * ESZ / 16;
+  constexpr int NCH = 16 * CPR;
+  constexpr int LO_STRIPS = NW * 16 * PITCH;
+  static_assert(2 * LO_STRIPS <= 4 * (EA + EB), "both strip sets fit in the staging area");
+  char* strip = smem + wave * (16 * PITCH);
+  T* out = (T*)out_base;
+  T* out_lo = (T*)(out_base + out_lo_off);
+  float bv[FN];
+#pragma unroll
+  for (int j = 0; j < FN; ++j) {
+    const int n = n0 + wn * WTN + j * MS + lr;
+    bv[j] = n < aNpad ? bias[n] : 0.f;
+  }
+  constexpr int NSTRIP = MS / 16;  // 16-row strips per fragment row block
+#pragma unroll
+  for (int i = 0; i < FM; ++i) {
+#pragma unroll
+    for (int hf = 0; hf < NSTRIP; ++hf) {
+#pragma unroll
+      for (int j = 0; j < FN; ++j) {
+#pragma unroll
+        for (int rr = 0; rr < (MS == 16 ? 4 : 8); ++rr) {
+          // 16x16: register r holds row 4 (lane >> 4) + r; 32x32: register hf * 8 + rr holds row (rr & 3) + 8 (rr >> 2) + 4 (lane >> 5) of half hf
+          const int row = MS == 16 ? 4 * lq + rr : (rr & 3) + 8 * (rr >> 2) + 4 * lq;
+          float v = acc[i][j][MS == 16 ? rr : hf * 8 + rr] + bv[j];
+          if (relu) v = v > 0.f ? v : 0.f;
+          Elem<T>::store((T*)(strip + row * PITCH) + j * MS + lr, v);
+          Elem<T>::store((T*)(strip + LO_STRIPS + row * PITCH) + j * MS + lr, split_lo(v));
+        }
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+      for (int k = 0; k < (NCH + 63) / 64; ++k) {
+        const int c = lane + 64 * k;
+        if (c >= NCH) break;
+        const int row = c / CPR, cc = c - row * CPR;
+        const u32x4_t v = *(const u32x4_t*)(strip + row * PITCH + cc * 16);
+        const int m = m0 + wm * WTM + i * MS + hf * 16 + row;
+        const int n = n0 + wn * WTN + cc * (16 / ESZ);
+        if (m < aM && n < aCo) {
+          store_stream16(out + (size_t)m * aCo + n, v);
+          store_stream16(out_lo + (size_t)m * aCo + n, *(const u32x4_t*)(strip + LO_STRIPS + row * PITCH + cc * 16));
+        }
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // a persistent workgroup stages its next tile after this
+}
+#undef ISSUE1
+#undef ISSUE2
+
 // wave -> (weight-piece count, early/late) instantiation of the body; MS = MFMA shape (32: 32x32x16 /
 // 32x32x2, 16: v_mfma_f32_16x16x32_bf16, which holds a ~12 % higher clock on real data: MI355X_MICROARCH.md,
 // DVFS give-back item 7)
 template <typename T, int BM, int BN, int WM, int WN, int MS, int BI, bool LATE>
 __device__ __forceinline__ void conv_igemm_body_ms(const ConvArgs& a, char* smem, int tile, int s0, int s1, float* part) {
-  if constexpr (MS == 16) conv_igemm_body16<T, BM, BN, WM, WN, BI, LATE>(a, smem, tile, s0, s1, part);
+  if constexpr (IsFused<T>::value) conv_x3_body<BM, BN, WM, WN, MS, BI, LATE>(a, smem, tile, s0, s1, part);
+  else if constexpr (MS == 16) conv_igemm_body16<T, BM, BN, WM, WN, BI, LATE>(a, smem, tile, s0, s1, part);
   else conv_igemm_body<T, BM, BN, WM, WN, BI, LATE>(a, smem, tile, s0, s1, part);
 }
 
@@ -692,16 +1013,18 @@ __global__ __launch_bounds__(64 * WM * WN, 1) void conv_igemm_sk_kernel(const Co
       __syncthreads();
       const int it = __builtin_amdgcn_readfirstlane(sh_item);
       if (it >= nitems) break;
-      if (it < nfull) {
-        conv_igemm_dispatch<T, BM, BN, WM, WN, MS>(a, smem, g.base + it, 0, S, nullptr);
-      } else {
+      // one call site for full tiles and tail parts (the body is large: two inlined copies cost the fused kernels their registers)
+      int tile_i = g.base + it, sa = 0, sb = S;
+      float* dst = nullptr;
+      if (it >= nfull) {
         const int r = it - nfull;
         const int rt = r / g.P, part = r - rt * g.P;
-        const int sa = (int)((long long)(S / 2) * part / g.P) * 2;  // K ranges in whole pairs of K-steps (16x16x32 body)
-        const int sb = part + 1 == g.P ? S : (int)((long long)(S / 2) * (part + 1) / g.P) * 2;
-        float* dst = g.P == 1 ? nullptr : ws + ((size_t)xcd * g.per + r) * (BM * BN);
-        if (sb > sa) conv_igemm_dispatch<T, BM, BN, WM, WN, MS>(a, smem, g.base + nfull + rt, sa, sb, dst);
+        sa = (int)((long long)(S / 2) * part / g.P) * 2;  // K ranges in whole pairs of K-steps (16x16x32 body)
+        sb = part + 1 == g.P ? S : (int)((long long)(S / 2) * (part + 1) / g.P) * 2;
+        dst = g.P == 1 ? nullptr : ws + ((size_t)xcd * g.per + r) * (BM * BN);
+        tile_i = g.base + nfull + rt;
       }
+      if (sb > sa) conv_igemm_dispatch<T, BM, BN, WM, WN, MS>(a, smem, tile_i, sa, sb, dst);
     }
   }
 }
@@ -848,6 +1171,17 @@ bool two_waves_per_simd() {
 
 template <typename T>
 static int launch_cfg(const ConvArgs& a, TileCfg cfg, hipStream_t stream, float* sk_ws, int sk_grid) {
+  if constexpr (IsFused<T>::value) {
+    // conv_x3_body: 16x16x32 where the wave tile allows (it needs two halves of B fragments), 32x32x16 for the wide wave tiles
+    switch (cfg) {
+      case TILE_256x32: return launch_one<T, 256, 32, 4, 1, 16>(a, stream, sk_ws, sk_grid);
+      case TILE_256x64: return launch_one<T, 256, 64, 4, 1, 32>(a, stream, sk_ws, sk_grid);
+      case TILE_256x160: return launch_one<T, 256, 160, 4, 1, 32>(a, stream, sk_ws, sk_grid);
+      case TILE_256x320: return launch_one<T, 256, 320, 4, 2, 32>(a, stream, sk_ws, sk_grid);
+      case TILE_256x256: return launch_one<T, 256, 256, 4, 2, 16>(a, stream, sk_ws, sk_grid);
+      default: BSMI_FAIL(BSMI_ERR_INVALID, "unknown tile config %d", (int)cfg);
+    }
+  } else {
   switch (cfg) {
     case TILE_256x32: return launch_one<T, 256, 32, 4, 1>(a, stream, sk_ws, sk_grid);
     case TILE_256x64: return launch_one<T, 256, 64, 4, 1>(a, stream, sk_ws, sk_grid);
@@ -862,6 +1196,7 @@ static int launch_cfg(const ConvArgs& a, TileCfg cfg, hipStream_t stream, float*
       return launch_one<T, 256, 256, 2, 2>(a, stream, sk_ws, sk_grid);
     default: BSMI_FAIL(BSMI_ERR_INVALID, "unknown tile config %d", (int)cfg);
   }
+  }
 }
 
 int launch_conv_igemm(const ConvArgs& a, int precision, TileCfg cfg, hipStream_t stream, float* sk_ws, int sk_grid) {
@@ -869,7 +1204,13 @@ int launch_conv_igemm(const ConvArgs& a, int precision, TileCfg cfg, hipStream_t
     BSMI_FAIL(BSMI_ERR_INVALID, "conv launch: bad geometry M=%d nsteps=%d Npad=%d", a.M, a.nsteps, a.Npad);
   if (precision == BSMI_PREC_F32) return launch_cfg<float>(a, cfg, stream, sk_ws, sk_grid);
   if (precision == BSMI_PREC_BF16) return launch_cfg<bf16_elem>(a, cfg, stream, sk_ws, sk_grid);
-  if (precision == BSMI_PREC_BF16X3) return launch_cfg<bf16s_elem>(a, cfg, stream, sk_ws, sk_grid);
+  if (precision == BSMI_PREC_BF16X3) {
+    if (a.w_lo) {  // logical K-steps, hi and lo weight images: the fused form
+      if (!two_waves_per_simd()) BSMI_FAIL(BSMI_ERR_STATE, "the fused split-bf16 kernels are 8-wave kernels (BSMI_WAVES8=0 is set)");
+      return launch_cfg<bf16f_elem>(a, cfg, stream, sk_ws, sk_grid);
+    }
+    return launch_cfg<bf16s_elem>(a, cfg, stream, sk_ws, sk_grid);  // every K-step listed three times
+  }
   BSMI_FAIL(BSMI_ERR_INVALID, "unknown precision %d", precision);
 }
 

@@ -46,7 +46,19 @@ using namespace bsmi;
 namespace bsmi {
 
 int esize(int prec) { return prec == BSMI_PREC_F32 ? 4 : 2; }
-int ksplit(int prec) { return prec == BSMI_PREC_BF16X3 ? 3 : 1; }
+// Which form of the split mode a layer takes: the fused kernel (conv_x3_body) or three listed K-steps through the bf16
+// kernels.  The persistent form of the fused 256 x 320 kernel does not fit the 256 registers of an 8-wave kernel (13
+// spilled: counted vmcnt waits forbid that), and without the split-K tail those layers lose more than the fusion gains,
+// so 320-wide layers keep the listed form.  BSMI_X3_FUSED (dev / tests): 0 = listed form everywhere, 2 = fused everywhere.
+static int x3_fused_mode() {
+  static const int m = [] { const char* e = getenv("BSMI_X3_FUSED"); return e ? atoi(e) : 1; }();
+  return m;
+}
+bool x3_fused_for(TileCfg tile) {
+  if (!two_waves_per_simd()) return false;  // BSMI_WAVES8=0 (tests): the fused wide kernels exist as 8-wave kernels only
+  return x3_fused_mode() == 2 || (x3_fused_mode() == 1 && tile != TILE_256x320);
+}
+int ksplit(int prec) { return prec == BSMI_PREC_BF16X3 ? 3 : 1; }  // listed form; PackedConv::ks holds the layer's own value
 static inline float host_bf16_to_f32(uint16_t b) {
   const uint32_t u = (uint32_t)b << 16;
   float f;
@@ -175,13 +187,15 @@ static int pack_conv(bsmi_unet* h, PassSite& p, int ci, int prec) {
   const int SUB = sube(prec);
   // Split mode: logical K-step s becomes the kernel's K-steps 3s (hi activations x hi weights), 3s + 1 (lo
   // activations x hi weights) and 3s + 2 (hi activations x lo weights); the weight image carries a row block for each
-  const int KS = ksplit(prec);
+  const bool fused = prec == BSMI_PREC_BF16X3 && x3_fused_for(pc.tile);
+  const int KS = pc.ks = fused ? 1 : ksplit(prec);
   const size_t nsteps = pc.entries.size() / kUnitsPerStep * KS;
   const size_t nelem = (nsteps * (size_t)pc.Npad + kWeightRowSlack) * BKE;  // slack rows: padded tile loads
   std::vector<float> bias(pc.Npad, 0.f);
   for (int n = 0; n < p.cout; ++n) bias[n] = bm.data[n] + (last ? br.data[n] : 0.f);
 
-  std::vector<uint8_t> packed(nelem * esize(prec), 0);
+  pc.lo_image_bytes = fused ? nelem * esize(prec) : 0;
+  std::vector<uint8_t> packed(nelem * esize(prec) * (fused ? 2 : 1), 0);
   for (size_t u = 0; u < pc.entries.size(); ++u) {
     const PackEntry& e = pc.entries[u];
     if (e.dummy) continue;
@@ -202,10 +216,15 @@ static int pack_conv(bsmi_unet* h, PassSite& p, int ci, int prec) {
           const uint16_t hi = host_f32_to_bf16(v);
           const uint16_t lo = host_f32_to_bf16(v - host_bf16_to_f32(hi));
           uint16_t* w16 = (uint16_t*)packed.data();
-          const size_t blk = (size_t)pc.Npad * BKE;
-          w16[idx] = hi;
-          w16[idx + blk] = hi;
-          w16[idx + 2 * blk] = lo;
+          if (fused) {  // hi image, then the lo image of the same layout
+            w16[idx] = hi;
+            w16[idx + nelem] = lo;
+          } else {
+            const size_t blk = (size_t)pc.Npad * BKE;
+            w16[idx] = hi;
+            w16[idx + blk] = hi;
+            w16[idx + 2 * blk] = lo;
+          }
         }
       }
     }
@@ -524,7 +543,7 @@ struct Planner {
         st.tile = pc.tile;
         ConvArgs& a = st.conv;
         memset(&a, 0, sizeof a);
-        const int KS = ksplit(prec);
+        const int KS = pc.ks;
         std::vector<KStep> ks(pc.entries.size() / kUnitsPerStep * KS);
         const int64_t es = esize(prec);
         for (int sl = 0; sl < kMaxConvTensors; ++sl) {
@@ -533,6 +552,7 @@ struct Planner {
           a.t[sl].sz = (int32_t)((int64_t)t.H * t.W * t.Cpad * es);
           a.t[sl].sy = (int32_t)((int64_t)t.W * t.Cpad * es);
           a.t[sl].sx = (int32_t)((int64_t)t.Cpad * es);
+          a.t[sl].lo = (int32_t)t.lo_off;
         }
         for (size_t s = 0; s < ks.size() / KS; ++s) {
           const int slot = pc.entries[kUnitsPerStep * s].slot;
@@ -563,6 +583,7 @@ struct Planner {
         a.steps = dks;
         a.nsteps = (int)ks.size();
         a.w = pc.w;
+        a.w_lo = pc.lo_image_bytes ? (const char*)pc.w + pc.lo_image_bytes : nullptr;
         a.bias = pc.bias;
         a.out = o.ptr;
         a.out_lo = (int64_t)o.lo_off;

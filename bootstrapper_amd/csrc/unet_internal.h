@@ -44,6 +44,8 @@ struct PackedConv {
   std::vector<PackEntry> entries;
   std::vector<PackPhase> phases;
   void* w = nullptr;
+  int ks = 1;                 // kernel K-steps per logical K-step (3: the split mode as listed K-steps)
+  size_t lo_image_bytes = 0;  // fused split-bf16: the lo image follows the hi image at this byte offset (0: no lo image)
   float* bias = nullptr;
   int Npad = 0;
   TileCfg tile = TILE_256x32;

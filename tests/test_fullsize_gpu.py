@@ -140,6 +140,9 @@ def test_full_block_blockwise_stages_bit_exact(full_block):
     ("persistent split-K tail, 256x256 tiles", {"BSMI_SK_GRID": "8", "BSMI_TILE_EFF": "0.01,0.01,0.01,1,0.01"}),
     ("persistent split-K tail, 256x320 tiles", {"BSMI_SK_GRID": "16", "BSMI_TILE_EFF": "0.01,0.01,0.01,0.01,1"}),
     ("4-wave kernels", {"BSMI_WAVES8": "0"}),
+    ("split-bf16 as listed K-steps everywhere", {"BSMI_X3_FUSED": "0"}),
+    ("fused split-bf16 kernel on 256x320 tiles too", {"BSMI_X3_FUSED": "2", "BSMI_SK_GRID": "16", "BSMI_TILE_EFF": "0.01,0.01,0.01,0.01,1"}),
+    ("fused split-bf16 kernel on 256x160 tiles", {"BSMI_TILE_EFF": "0.01,0.01,1,0.01,0.01"}),
     ("implicit GEMM for the first pass and the small-Cout layers (no first_pass / conv_box)", {"BSMI_FUSED_FIRST": "0", "BSMI_USE_BOX": "0"}),
 ])
 def test_conv_kernel_variants_in_subprocess(variant, env):
@@ -160,3 +163,35 @@ def test_merge_loop_general_form_in_subprocess():
     r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(ROOT, "tests", "test_fullsize_gpu.py"), "-x", "-q", "-k", "seg or blockwise"],
                        env=dict(os.environ, BSMI_AGG_FAST="0"), capture_output=True, text=True, timeout=600, cwd=ROOT)
     assert r.returncode in (0, 5), r.stdout[-3000:] + r.stderr[-2000:]
+
+
+def test_cremi_single_block_96_predict_and_segment():
+    """BASELINE config 1: one 96^3 output block of the full 3d_affs network ((124,188,188) in), predict + waterz-style
+    segment, against the CPU plumbing case: affinities of the split-bf16 mode within 1e-4 of the torch-CPU oracle, and
+    fragments + agglomeration on them bit-exact against the C restatement."""
+    from bootstrapper_amd.unet import Model
+    from bootstrapper_amd.post.engine import SegEngine
+    from bootstrapper_amd.synth import synthetic_state_dict, synthetic_volume
+    from oracle import unet_ref as R
+    from oracle import seg_ref as S
+    from tests.test_lib_cpu import AFFS_NET_CONFIG as NC
+    sd = synthetic_state_dict(NC, 0)
+    raw = synthetic_volume((124, 188, 188), 3)
+    m = Model(NC, precision="bf16x3").load_state_dict(sd)
+    assert m.output_shape((124, 188, 188)) == (96, 96, 96)
+    u8, f32 = m.predict_u8(raw, want_f32=True)
+    torch.set_num_threads(min(16, os.cpu_count() or 1))
+    ref = R.predict_block(R.default_cfg(12, 5), sd, raw.cpu().numpy(), ["affs_head"])[0]
+    err = float((f32[0].cpu() - torch.from_numpy(ref)).abs().max())
+    print("96^3 block, bf16x3 vs CPU oracle: max abs err", err)
+    assert err < 1e-4
+    affs = u8[0][:3].contiguous()
+    eng = SegEngine((96, 96, 96))
+    frags, mx = eng.ws_fragments(affs, True, 10)
+    segs = eng.agglomerate_mean(affs, frags, [0.2, 0.35, 0.5])
+    eng.status()
+    a = affs.cpu().numpy()
+    ref_frags, ref_max = S.ws_fragments_u8(a, True, 10)
+    assert int(mx.item()) == ref_max and np.array_equal(frags.cpu().numpy().astype(np.uint64), ref_frags)
+    for t, r in enumerate(S.agglomerate_mean_u8(a, ref_frags, [0.2, 0.35, 0.5])):
+        assert np.array_equal(segs[t].cpu().numpy().astype(np.uint64), r)
