@@ -248,6 +248,8 @@ def main():
     ap.add_argument("--no-segment", action="store_true", help="predict only (diagnostic; not the headline metric)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-modes", action="store_true", help="skip the per-precision predict lines (speed and error of f32 / bf16x3 / bf16)")
+    ap.add_argument("--profile-every", type=int, default=1,
+                    help="per-launch HIP-event timing (the roofline figures) on every Nth block of the timed region")
     ap.add_argument("--cpu-predict-blocks", type=int, default=2)
     ap.add_argument("--cpu-segment-blocks", type=int, default=16)
     args = ap.parse_args()
@@ -303,7 +305,7 @@ def main():
     del warm
     pipe = VolumePipeline(model, OUT_BLOCK, CONTEXT, job, SEG_CONTEXT, THRESHOLDS, n_lanes=args.seg_lanes, device=local_rank,
                           rank=rank, world=world, segment=not args.no_segment, overlap=args.overlap, **seg_kw)
-    model.profile(True)
+    model.profile(max(1, args.profile_every))
     model.profile_totals(reset=True)
     barrier()
     t0 = time.perf_counter()

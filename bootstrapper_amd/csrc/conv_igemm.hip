@@ -651,7 +651,11 @@ __device__ __forceinline__ void conv_x3_body(const ConvArgs& a, char* smem, int 
   char* const out_base = (char*)a.out;
   const int64_t out_lo_off = a.out_lo;
   const int aM = a.M, aNpad = a.Npad, aCo = a.Co, aWo = a.Wo, aHo = a.Ho, relu = a.relu;
-  const int tid = threadIdx.x;
+  // opaque per call: the lane geometry below is recomputed per tile rather than hoisted out of a persistent
+  // kernel's tile loop, where it would stay live across the whole body (the 256x320 form has no registers for that)
+  int tid_ = threadIdx.x;
+  asm volatile("" : "+v"(tid_));
+  const int tid = tid_;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave / WN, wn = wave % WN;

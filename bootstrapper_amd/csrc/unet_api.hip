@@ -47,16 +47,15 @@ namespace bsmi {
 
 int esize(int prec) { return prec == BSMI_PREC_F32 ? 4 : 2; }
 // Which form of the split mode a layer takes: the fused kernel (conv_x3_body) or three listed K-steps through the bf16
-// kernels.  The persistent form of the fused 256 x 320 kernel does not fit the 256 registers of an 8-wave kernel (13
-// spilled: counted vmcnt waits forbid that), and without the split-K tail those layers lose more than the fusion gains,
-// so 320-wide layers keep the listed form.  BSMI_X3_FUSED (dev / tests): 0 = listed form everywhere, 2 = fused everywhere.
+// kernels.  BSMI_X3_FUSED (dev / tests): 0 = listed form everywhere, 1 (default) / 2 = fused wherever the 8-wave kernels
+// run, 3 = fused except on 256 x 320 tiles (the two forms side by side in one forward).
 static int x3_fused_mode() {
   static const int m = [] { const char* e = getenv("BSMI_X3_FUSED"); return e ? atoi(e) : 1; }();
   return m;
 }
 bool x3_fused_for(TileCfg tile) {
   if (!two_waves_per_simd()) return false;  // BSMI_WAVES8=0 (tests): the fused wide kernels exist as 8-wave kernels only
-  return x3_fused_mode() == 2 || (x3_fused_mode() == 1 && tile != TILE_256x320);
+  return x3_fused_mode() == 1 || x3_fused_mode() == 2 || (x3_fused_mode() == 3 && tile != TILE_256x320);
 }
 int ksplit(int prec) { return prec == BSMI_PREC_BF16X3 ? 3 : 1; }  // listed form; PackedConv::ks holds the layer's own value
 static inline float host_bf16_to_f32(uint16_t b) {
@@ -1052,9 +1051,11 @@ int bsmi_unet_forward(bsmi_unet* h, int precision, const void* raw_dev, int raw_
   if (rc) return rc;
   Plan& plan = *plan_ptr;
   h->last_plan = &plan;
-  plan.profiled = h->profiling;
-  plan.pending = h->profiling;
-  if (h->profiling) {
+  // profile_period N > 0: every Nth forward records its per-step events (N = 1: every forward)
+  const bool prof = h->profile_period > 0 && (h->profile_count++ % h->profile_period) == 0;
+  if (prof || h->profile_period == 0) plan.profiled = prof;
+  if (prof) plan.pending = true;
+  if (prof) {
     // a fresh set of events for this forward: recording must not wait for an earlier forward to finish (the caller may
     // have many blocks in flight); bsmi_unet_profile_read / _totals read the sets
     const size_t n_ev = 2 * plan.steps.size();
@@ -1085,7 +1086,7 @@ int bsmi_unet_forward(bsmi_unet* h, int precision, const void* raw_dev, int raw_
   }
   size_t step_idx = 0;
   for (const PlanStep& st : plan.steps) {
-    if (h->profiling) BSMI_HIP(hipEventRecord(plan.events[2 * step_idx], s));
+    if (prof) BSMI_HIP(hipEventRecord(plan.events[2 * step_idx], s));
     if (plan.fused_first && step_idx < 3) {
       // l_conv.0 as one launch in place of its second conv; the input-preparation and first-conv steps fall away
       if (step_idx == 2) {
@@ -1097,7 +1098,7 @@ int bsmi_unet_forward(bsmi_unet* h, int precision, const void* raw_dev, int raw_
         rc = launch_first_pass(fa, h->sk_grid > 0 ? h->sk_grid : 256, s);
         if (rc) return rc;
       }
-      if (h->profiling) BSMI_HIP(hipEventRecord(plan.events[2 * step_idx + 1], s));
+      if (prof) BSMI_HIP(hipEventRecord(plan.events[2 * step_idx + 1], s));
       ++step_idx;
       continue;
     }
@@ -1130,10 +1131,10 @@ int bsmi_unet_forward(bsmi_unet* h, int precision, const void* raw_dev, int raw_
       }
     }
     if (rc) return rc;
-    if (h->profiling) BSMI_HIP(hipEventRecord(plan.events[2 * step_idx + 1], s));
+    if (prof) BSMI_HIP(hipEventRecord(plan.events[2 * step_idx + 1], s));
     ++step_idx;
   }
-  if (h->profiling) plan.inflight.push_back(std::move(plan.events));
+  if (prof) plan.inflight.push_back(std::move(plan.events));
   return BSMI_OK;
 }
 
@@ -1173,7 +1174,8 @@ int bsmi_unet_debug_activation(bsmi_unet* h, int step, int what, int64_t shape_o
 
 int bsmi_unet_profile_enable(bsmi_unet* h, int on) {
   if (!h) BSMI_FAIL(BSMI_ERR_INVALID, "null handle");
-  h->profiling = on != 0;
+  h->profile_period = on > 0 ? on : 0;
+  h->profile_count = 0;
   return BSMI_OK;
 }
 

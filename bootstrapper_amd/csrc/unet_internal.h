@@ -134,7 +134,8 @@ struct bsmi_unet {
   int crop_factor[BSMI_MAX_LEVELS][3];
   std::map<std::string, HostWeight> weights;
   bool finalized[BSMI_NUM_PREC] = {false, false, false};
-  bool profiling = false;
+  int profile_period = 0;       // 0 off, N: every Nth forward is timed step by step
+  uint64_t profile_count = 0;
   Plan* last_plan = nullptr;
   double prof_ms[5] = {0, 0, 0, 0, 0}, prof_flops[5] = {0, 0, 0, 0, 0};
   int64_t prof_launches[5] = {0, 0, 0, 0, 0};

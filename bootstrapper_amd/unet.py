@@ -192,7 +192,8 @@ class Model:
 
     # -- profiling ---------------------------------------------------------------------
     def profile(self, on=True):
-        check(lib.bsmi_unet_profile_enable(self._h, 1 if on else 0))
+        """Time every launch of every `on`-th forward with HIP events (True = every forward)."""
+        check(lib.bsmi_unet_profile_enable(self._h, int(on)))
         return self
 
     def read_profile(self):

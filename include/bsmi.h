@@ -188,9 +188,9 @@ int bsmi_stream_create_cu_mask(int device, const uint32_t *cu_mask, int n_words,
 int bsmi_stream_destroy(int device, void *stream);
 
 /* Per-launch timing of the forward pass with HIP events recorded on the caller's stream
- * (bench.py's roofline leg).  After enabling, every bsmi_unet_forward brackets each launch
- * with events; bsmi_unet_profile_read synchronises on them and returns, for the last
- * forward, the launch type (0 input, 1 implicit-GEMM conv, 2 max-pool, 3 upsample+crop,
+ * (bench.py's roofline leg).  on = N > 0: every Nth bsmi_unet_forward (N = 1: every one)
+ * brackets each launch with events; on = 0 switches the timing off.
+ * bsmi_unet_profile_read synchronises on them and returns, for the last timed forward, the launch type (0 input, 1 implicit-GEMM conv, 2 max-pool, 3 upsample+crop,
  * 4 head), its duration in ms and its algorithmic FLOPs. */
 int bsmi_unet_profile_enable(bsmi_unet *h, int on);
 int bsmi_unet_profile_read(bsmi_unet *h, int max_n, int *n, int32_t *types, double *ms,

@@ -141,7 +141,8 @@ def test_full_block_blockwise_stages_bit_exact(full_block):
     ("persistent split-K tail, 256x320 tiles", {"BSMI_SK_GRID": "16", "BSMI_TILE_EFF": "0.01,0.01,0.01,0.01,1"}),
     ("4-wave kernels", {"BSMI_WAVES8": "0"}),
     ("split-bf16 as listed K-steps everywhere", {"BSMI_X3_FUSED": "0"}),
-    ("fused split-bf16 kernel on 256x320 tiles too", {"BSMI_X3_FUSED": "2", "BSMI_SK_GRID": "16", "BSMI_TILE_EFF": "0.01,0.01,0.01,0.01,1"}),
+    ("fused split-bf16 kernel on 256x320 tiles, split-K tails forced", {"BSMI_X3_FUSED": "2", "BSMI_SK_GRID": "16", "BSMI_TILE_EFF": "0.01,0.01,0.01,0.01,1"}),
+    ("fused and listed split-bf16 layers in one forward", {"BSMI_X3_FUSED": "3"}),
     ("fused split-bf16 kernel on 256x160 tiles", {"BSMI_TILE_EFF": "0.01,0.01,1,0.01,0.01"}),
     ("implicit GEMM for the first pass and the small-Cout layers (no first_pass / conv_box)", {"BSMI_FUSED_FIRST": "0", "BSMI_USE_BOX": "0"}),
 ])
