@@ -83,7 +83,17 @@ template <>
 struct IsSplit<bf16f_elem> { static constexpr bool value = true; };
 template <>
 struct IsSplit<bf16s_elem> { static constexpr bool value = true; };
-// the lo plane's value: what the bf16 rounding of v (the hi plane) left over
+// Activation layout of the split mode: every 16-byte vector of 8 hi values is followed by the 16-byte vector of their 8
+// lo values, so the 32 channels of a K-step are ONE 128-byte line per voxel row (hi and lo in separate planes cost a
+// half-used line each per K-step: the LDS-DMA gather missed the vector L1 on every row and pulled twice the bytes
+// out of L2).  Element index of channel n in the row that starts at element `row` (= voxel * Cpad) of a plain tensor:
+template <typename T>
+__device__ __forceinline__ size_t act_index(size_t row, int n) {
+  if constexpr (IsSplit<T>::value) return 2 * row + (size_t)(((n >> 3) << 4) + (n & 7));
+  else return row + (size_t)n;
+}
+constexpr int kSplitLoElems = 8;  // the lo vector follows its hi vector
+// the lo value: what the bf16 rounding of v (the hi value) left over
 __device__ __forceinline__ float split_lo(float v) {
   const __bf16 h = (__bf16)v;
   return v - (float)h;

@@ -28,7 +28,7 @@ static_assert(sizeof(KStep) == 16, "KStep layout");
 struct ConvSrc {
   uint64_t base;       // device pointer of the channels-last source tensor
   int32_t sz, sy, sx;  // byte strides of one step in z, y, x
-  int32_t lo;          // fused split-bf16 launches: byte offset of the tensor's lo plane behind its hi plane
+  int32_t pad;
 };
 
 constexpr int kUnitsPerStep = 2;
@@ -45,7 +45,7 @@ struct ConvArgs {
   const void* w_lo;   // fused split-bf16 launches: the lo image of the weights, same layout (w is the hi image)
   const float* bias;  // device [Npad]
   void* out;          // device [Do][Ho][Wo][Co]
-  int64_t out_lo;     // BSMI_PREC_BF16X3: byte offset of the output's lo plane behind `out` (the hi plane)
+  int64_t pad;        // (BSMI_PREC_BF16X3 tensors carry (hi, lo) vectors interleaved: conv_dev.h act_index)
   int Do, Ho, Wo, Co;
   int M;     // Do*Ho*Wo
   int Npad;  // multiple of the tile's BN

@@ -83,7 +83,7 @@ __device__ __forceinline__ void conv_igemm_body(const ConvArgs& a, char* smem, i
   const int skey = (lane >> 4) & 3;
   const int g = lchunk ^ skey;             // source chunk that lands in LDS slot lchunk
   const bool unit1 = (g >> 1) != 0;        // which of the K-step's 2 units this lane fetches
-  const uint32_t hoff = (uint32_t)((g & 1) << 4);
+  const uint32_t hoff = (uint32_t)((g & 1) << (IsSplit<T>::value ? 5 : 4));  // split tensors: (hi, lo) vectors interleaved
   // byte offset of row(i)'s output voxel inside each source tensor (three named arrays: a
   // runtime-indexed array would live in scratch and its reload would drain vmcnt every K-step)
   static_assert(kMaxConvTensors == 3, "three source slots");
@@ -273,7 +273,6 @@ __device__ __forceinline__ void conv_igemm_body(const ConvArgs& a, char* smem, i
   static_assert(!SPLIT || 2 * LO_STRIPS <= NSLOT * SLOT, "both strip sets fit in the ring");
   char* strip = smem + wave * (16 * PITCH);
   T* out = (T*)a.out;
-  T* out_lo = (T*)((char*)a.out + a.out_lo);
   float bv[FN];
 #pragma unroll
   for (int j = 0; j < FN; ++j) {
@@ -305,8 +304,9 @@ __device__ __forceinline__ void conv_igemm_body(const ConvArgs& a, char* smem, i
         const int m = m0 + wm * WTM + i * 32 + hf * 16 + row;
         const int n = n0 + wn * WTN + cc * (16 / ESZ);
         if (m < a.M && n < a.Co) {
-          store_stream16(out + (size_t)m * a.Co + n, v);
-          if constexpr (SPLIT) store_stream16(out_lo + (size_t)m * a.Co + n, *(const u32x4_t*)(strip + LO_STRIPS + row * PITCH + cc * 16));
+          T* dst = out + act_index<T>((size_t)m * a.Co, n);
+          store_stream16(dst, v);
+          if constexpr (SPLIT) store_stream16(dst + kSplitLoElems, *(const u32x4_t*)(strip + LO_STRIPS + row * PITCH + cc * 16));
         }
       }
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -368,7 +368,7 @@ __device__ __forceinline__ void conv_igemm_body16(const ConvArgs& a, char* smem,
   const int skey = swz16((lane >> 4) & 3);
   const int g = lchunk ^ skey;             // source chunk that lands in LDS slot lchunk
   const bool unit1 = (g >> 1) != 0;        // which of the K-step's 2 units this lane fetches
-  const uint32_t hoff = (uint32_t)((g & 1) << 4);
+  const uint32_t hoff = (uint32_t)((g & 1) << (IsSplit<T>::value ? 5 : 4));
   // byte offset of row(i)'s output voxel inside each source tensor (three named arrays: a
   // runtime-indexed array would live in scratch and its reload would drain vmcnt every K-step)
   static_assert(kMaxConvTensors == 3, "three source slots");
@@ -552,7 +552,6 @@ __device__ __forceinline__ void conv_igemm_body16(const ConvArgs& a, char* smem,
   static_assert(!SPLIT || 2 * LO_STRIPS <= NSLOT * SLOT, "both strip sets fit in the ring");
   char* strip = smem + wave * (16 * PITCH);
   T* out = (T*)a.out;
-  T* out_lo = (T*)((char*)a.out + a.out_lo);
   float bv[FN];
 #pragma unroll
   for (int j = 0; j < FN; ++j) {
@@ -581,8 +580,9 @@ __device__ __forceinline__ void conv_igemm_body16(const ConvArgs& a, char* smem,
       const int m = m0 + wm * WTM + i * 16 + row;
       const int n = n0 + wn * WTN + cc * (16 / ESZ);
       if (m < a.M && n < a.Co) {
-        store_stream16(out + (size_t)m * a.Co + n, v);
-        if constexpr (SPLIT) store_stream16(out_lo + (size_t)m * a.Co + n, *(const u32x4_t*)(strip + LO_STRIPS + row * PITCH + cc * 16));
+        T* dst = out + act_index<T>((size_t)m * a.Co, n);
+        store_stream16(dst, v);
+        if constexpr (SPLIT) store_stream16(dst + kSplitLoElems, *(const u32x4_t*)(strip + LO_STRIPS + row * PITCH + cc * 16));
       }
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -649,7 +649,6 @@ __device__ __forceinline__ void conv_x3_body(const ConvArgs& a, char* smem, int 
   const gptr_t w_hi = (gptr_t)a.w, w_lo = (gptr_t)a.w_lo;
   const float* const bias = a.bias;
   char* const out_base = (char*)a.out;
-  const int64_t out_lo_off = a.out_lo;
   const int aM = a.M, aNpad = a.Npad, aCo = a.Co, aWo = a.Wo, aHo = a.Ho, relu = a.relu;
   // opaque per call: the lane geometry below is recomputed per tile rather than hoisted out of a persistent
   // kernel's tile loop, where it would stay live across the whole body (the 256x320 form has no registers for that)
@@ -670,7 +669,7 @@ __device__ __forceinline__ void conv_x3_body(const ConvArgs& a, char* smem, int 
   const int skey = MS == 16 ? swz16((lane >> 4) & 3) : ((lane >> 4) & 3);
   const int g = lchunk ^ skey;
   const bool unit1 = (g >> 1) != 0;
-  const uint32_t hoff = (uint32_t)((g & 1) << 4);
+  const uint32_t hoff = (uint32_t)((g & 1) << 5);  // 8-channel vectors are 32 bytes apart: (hi, lo) interleaved
   static_assert(kMaxConvTensors == 3, "three source slots");
   uint32_t ro0[A_INSTR], ro1[A_INSTR], ro2[A_INSTR];
 #pragma unroll
@@ -686,7 +685,6 @@ __device__ __forceinline__ void conv_x3_body(const ConvArgs& a, char* smem, int 
     ro2[i] = (uint32_t)(z * a.t[2].sz + y * a.t[2].sy + x * a.t[2].sx);
   }
   const uint64_t base0 = a.t[0].base, base1 = a.t[1].base, base2 = a.t[2].base;
-  const uint32_t lo0 = (uint32_t)a.t[0].lo, lo1 = (uint32_t)a.t[1].lo, lo2 = (uint32_t)a.t[2].lo;
   const uint32_t offb = (uint32_t)((n0 + wave * 16 + lrow) * ROWB + ((lchunk ^ skey) << 4));
   const size_t wstep = (size_t)aNpad * ROWB;
 
@@ -704,22 +702,23 @@ __device__ __forceinline__ void conv_x3_body(const ConvArgs& a, char* smem, int 
     const cint_ptr_t d = steps + (ha < nsteps ? ha : nsteps - 1) * 4;
     return Desc{d[0], d[1], d[2]};
   };
-  // Batch 1 of K-step h_, instructions [K0_, K1_): k < A_INSTR: A lo, k < 2 A_INSTR: A hi, else B hi.  Macros, not lambdas:
+  // Batch 1 of K-step h_, instructions [K0_, K1_): k < 2 A_INSTR: the A rows (lo and hi vectors of a row block back to
+  // back: the second finds the 128-byte lines of the first in the vector L1), else B hi.  Macros, not lambdas:
   // a closure that selects among the three row-offset arrays keeps them (and everything else it captures) in scratch.
 #define ISSUE1(h_, ds_, K0_, K1_)                                                                                         \
   do {                                                                                                                     \
     const bool t1_ = (ds_).t == 1, t2_ = (ds_).t == 2;                                                                     \
     const gptr_t abase_ = (gptr_t)(t1_ ? base1 : (t2_ ? base2 : base0));                                                   \
-    const uint32_t tlo_ = t1_ ? lo1 : (t2_ ? lo2 : lo0);                                                                   \
     const uint32_t lofs_ = (uint32_t)(unit1 ? (ds_).d1 : (ds_).d0) + hoff;                                                 \
     const int p_ = (h_) & 1;                                                                                               \
     const size_t wi_ = (size_t)(s0 + (h_) < nsteps ? s0 + (h_) : nsteps - 1) * wstep;                                      \
     _Pragma("unroll") for (int k_ = (K0_); k_ < (K1_); ++k_) {                                                             \
       if (k_ < 2 * A_INSTR) {                                                                                              \
-        const int i_ = k_ < A_INSTR ? k_ : k_ - A_INSTR;                                                                   \
+        const int i_ = k_ >> 1;                                                                                            \
+        const bool lo_ = (k_ & 1) == 0;                                                                                    \
         const uint32_t r0_ = ro0[i_], r1_ = ro1[i_], r2_ = ro2[i_];                                                        \
-        const uint32_t src_ = (t1_ ? r1_ : (t2_ ? r2_ : r0_)) + lofs_ + (k_ < A_INSTR ? tlo_ : 0u);                        \
-        const lptr_t dst_ = (lptr_t)(smem + (k_ < A_INSTR ? OFF_AL : OFF_AH) + p_ * EA) + (i_ * NW + wave) * 1024;         \
+        const uint32_t src_ = (t1_ ? r1_ : (t2_ ? r2_ : r0_)) + lofs_ + (lo_ ? 16u : 0u);                                  \
+        const lptr_t dst_ = (lptr_t)(smem + (lo_ ? OFF_AL : OFF_AH) + p_ * EA) + (i_ * NW + wave) * 1024;                  \
         __builtin_amdgcn_global_load_lds(abase_ + (size_t)src_, dst_, 16, 0, 0);                                           \
       } else {                                                                                                             \
         const int i_ = k_ - 2 * A_INSTR;                                                                                   \
@@ -882,7 +881,6 @@ __device__ __forceinline__ void conv_x3_body(const ConvArgs& a, char* smem, int 
   static_assert(2 * LO_STRIPS <= 4 * (EA + EB), "both strip sets fit in the staging area");
   char* strip = smem + wave * (16 * PITCH);
   T* out = (T*)out_base;
-  T* out_lo = (T*)(out_base + out_lo_off);
   float bv[FN];
 #pragma unroll
   for (int j = 0; j < FN; ++j) {
@@ -916,8 +914,9 @@ __device__ __forceinline__ void conv_x3_body(const ConvArgs& a, char* smem, int 
         const int m = m0 + wm * WTM + i * MS + hf * 16 + row;
         const int n = n0 + wn * WTN + cc * (16 / ESZ);
         if (m < aM && n < aCo) {
-          store_stream16(out + (size_t)m * aCo + n, v);
-          store_stream16(out_lo + (size_t)m * aCo + n, *(const u32x4_t*)(strip + LO_STRIPS + row * PITCH + cc * 16));
+          T* dst = out + act_index<T>((size_t)m * aCo, n);
+          store_stream16(dst, v);
+          store_stream16(dst + kSplitLoElems, *(const u32x4_t*)(strip + LO_STRIPS + row * PITCH + cc * 16));
         }
       }
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -1075,8 +1074,9 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_fixup_kernel(const ConvArgs
     if (m < a.M) {
       float v = x[r] + bv;
       if (a.relu) v = v > 0.f ? v : 0.f;
-      Elem<T>::store(out + (size_t)m * a.Co + n, v);
-      if constexpr (IsSplit<T>::value) Elem<T>::store((T*)((char*)a.out + a.out_lo) + (size_t)m * a.Co + n, split_lo(v));
+      T* dst = out + act_index<T>((size_t)m * a.Co, n);
+      Elem<T>::store(dst, v);
+      if constexpr (IsSplit<T>::value) Elem<T>::store(dst + kSplitLoElems, split_lo(v));
     }
   }
 }

@@ -246,7 +246,8 @@ struct Planner {
     t.Cpad = round_up(t.C, kChanPad);
     const size_t plane = (size_t)t.D * t.H * t.W * t.Cpad * esize(prec);
     const bool split = prec == BSMI_PREC_BF16X3;
-    t.lo_off = split ? plane : 0;  // (hi, lo) planes back to back: the lo plane is reached through the K-step byte offsets
+    // split mode: each 16-byte vector of 8 hi values is followed by the 16 bytes of their lo values (conv_dev.h act_index)
+    t.lo_off = split ? 16 : 0;
     const size_t bytes = split ? 2 * plane : plane;
     plan->bytes += bytes;
     if (bytes >= ((size_t)1 << 31))
@@ -544,14 +545,13 @@ struct Planner {
         memset(&a, 0, sizeof a);
         const int KS = pc.ks;
         std::vector<KStep> ks(pc.entries.size() / kUnitsPerStep * KS);
-        const int64_t es = esize(prec);
+        const int64_t es = esize(prec) * (prec == BSMI_PREC_BF16X3 ? 2 : 1);  // bytes per channel of a row: (hi, lo) interleaved
         for (int sl = 0; sl < kMaxConvTensors; ++sl) {
           const TDesc& t = slots[sl < nsl ? sl : 0];
           a.t[sl].base = (uint64_t)(uintptr_t)t.ptr;
           a.t[sl].sz = (int32_t)((int64_t)t.H * t.W * t.Cpad * es);
           a.t[sl].sy = (int32_t)((int64_t)t.W * t.Cpad * es);
           a.t[sl].sx = (int32_t)((int64_t)t.Cpad * es);
-          a.t[sl].lo = (int32_t)t.lo_off;
         }
         for (size_t s = 0; s < ks.size() / KS; ++s) {
           const int slot = pc.entries[kUnitsPerStep * s].slot;
@@ -585,7 +585,6 @@ struct Planner {
         a.w_lo = pc.lo_image_bytes ? (const char*)pc.w + pc.lo_image_bytes : nullptr;
         a.bias = pc.bias;
         a.out = o.ptr;
-        a.out_lo = (int64_t)o.lo_off;
         a.Do = o.D; a.Ho = o.H; a.Wo = o.W; a.Co = o.Cpad;
         a.M = o.D * o.H * o.W;
         a.Npad = pc.Npad;
@@ -778,7 +777,8 @@ int get_plan(bsmi_unet* h, int precision, const int64_t in_shape[3], Plan** out)
       return rc;
     }
     const std::vector<PlanStep>& ps = plan->steps;
-    plan->fused_first = precision == BSMI_PREC_BF16 && first_pass_eligible(h) && h->first_pass.ready && ps.size() > 3 &&
+    const bool fp_ready = precision == BSMI_PREC_BF16 ? h->first_pass.ready : precision == BSMI_PREC_BF16X3 && h->first_pass_x3.ready;
+    plan->fused_first = fp_ready && first_pass_eligible(h) && ps.size() > 3 &&
                         ps[0].type == PlanStep::INPUT && ps[1].type == PlanStep::CONV && ps[2].type == PlanStep::CONV &&
                         ps[1].site == &h->l_conv[0] && ps[2].site == &h->l_conv[0] && ps[2].out.Cpad == 16;
     it = h->plans.emplace(key, std::move(plan)).first;
@@ -920,6 +920,7 @@ int bsmi_unet_destroy(bsmi_unet* h) {
   for (auto& p : h->r_conv) free_site(p);
   free_train_state(h);
   free_first_pass(h->first_pass);
+  free_first_pass(h->first_pass_x3);
   if (h->sk_ws) (void)hipFree(h->sk_ws);
   for (auto& hd : h->heads) {
     if (hd.hw) (void)hipFree(hd.hw);
@@ -992,12 +993,13 @@ int bsmi_unet_finalize(bsmi_unet* h, int precision) {
     BSMI_HIP(hipMemcpy(hd.hw, hw.data(), hw.size() * sizeof(float), hipMemcpyHostToDevice));
     BSMI_HIP(hipMemcpy(hd.hb, hb.data(), hb.size() * sizeof(float), hipMemcpyHostToDevice));
   }
-  if (precision == BSMI_PREC_BF16 && first_pass_eligible(h)) {
+  if ((precision == BSMI_PREC_BF16 || precision == BSMI_PREC_BF16X3) && first_pass_eligible(h)) {
     const std::string pre = h->l_conv[0].prefix;
-    int rc = pack_first_pass(h->first_pass, h->l_conv[0].cout, h->weights[pre + ".conv_pass.0.weight"].data.data(),
+    const bool split = precision == BSMI_PREC_BF16X3;
+    int rc = pack_first_pass(split ? h->first_pass_x3 : h->first_pass, h->l_conv[0].cout, h->weights[pre + ".conv_pass.0.weight"].data.data(),
                              h->weights[pre + ".conv_pass.0.bias"].data.data(), h->weights[pre + ".conv_pass.2.weight"].data.data(),
                              h->weights[pre + ".conv_pass.2.bias"].data.data(), h->weights[pre + ".residual.0.weight"].data.data(),
-                             h->weights[pre + ".residual.0.bias"].data.data());
+                             h->weights[pre + ".residual.0.bias"].data.data(), split);
     if (rc) return rc;
   }
   // plans hold pointers to packed weights: drop those of this precision
@@ -1094,7 +1096,9 @@ int bsmi_unet_forward(bsmi_unet* h, int precision, const void* raw_dev, int raw_
         fa.raw = raw_dev; fa.raw_dtype = raw_dtype;
         fa.D = plan.steps[0].out.D; fa.H = plan.steps[0].out.H; fa.W = plan.steps[0].out.W;
         fa.out = (uint16_t*)st.out.ptr;
-        fa.w1a = h->first_pass.w1a; fa.w2a = h->first_pass.w2a; fa.vec = h->first_pass.vec;
+        const FirstPassWeights& fw = precision == BSMI_PREC_BF16X3 ? h->first_pass_x3 : h->first_pass;
+        fa.w1a = fw.w1a; fa.w2a = fw.w2a; fa.vec = fw.vec;
+        fa.split = fw.split;
         rc = launch_first_pass(fa, h->sk_grid > 0 ? h->sk_grid : 256, s);
         if (rc) return rc;
       }
@@ -1104,7 +1108,7 @@ int bsmi_unet_forward(bsmi_unet* h, int precision, const void* raw_dev, int raw_
     }
     switch (st.type) {
       case PlanStep::INPUT:
-        rc = launch_input_prep(precision, raw_dev, raw_dtype, st.out.ptr, st.out.lo_off, st.out.C, st.out.Cpad,
+        rc = launch_input_prep(precision, raw_dev, raw_dtype, st.out.ptr, st.out.C, st.out.Cpad,
                                (size_t)st.out.D * st.out.H * st.out.W, s);
         break;
       case PlanStep::CONV:
@@ -1113,11 +1117,11 @@ int bsmi_unet_forward(bsmi_unet* h, int precision, const void* raw_dev, int raw_
                          : launch_conv_igemm(st.conv, precision, st.tile, s, h->sk_ws, h->sk_grid);
         break;
       case PlanStep::POOL:
-        rc = launch_maxpool(precision, st.in.ptr, st.in.lo_off, st.out.ptr, st.out.lo_off, st.in.D, st.in.H, st.in.W, st.in.Cpad,
+        rc = launch_maxpool(precision, st.in.ptr, st.out.ptr, st.in.D, st.in.H, st.in.W, st.in.Cpad,
                             st.f[0], st.f[1], st.f[2], s);
         break;
       case PlanStep::UP:
-        rc = launch_upsample_crop(precision, st.in.ptr, st.in.lo_off, st.out.ptr, st.out.lo_off, st.in.D, st.in.H, st.in.W, st.in.Cpad,
+        rc = launch_upsample_crop(precision, st.in.ptr, st.out.ptr, st.in.D, st.in.H, st.in.W, st.in.Cpad,
                                   st.out.D, st.out.H, st.out.W, st.f[0], st.f[1], st.f[2], st.o[0], st.o[1], st.o[2], s);
         break;
       case PlanStep::HEAD: {
@@ -1125,7 +1129,7 @@ int bsmi_unet_forward(bsmi_unet* h, int precision, const void* raw_dev, int raw_
         float* of = out_f32_dev ? out_f32_dev[st.head] : nullptr;
         uint8_t* ou = out_u8_dev ? out_u8_dev[st.head] : nullptr;
         if (of || ou)
-          rc = launch_head(precision, st.in.ptr, st.in.lo_off, st.in.Cpad, hd.cin, hd.cout, hd.hw, hd.hb, of, ou,
+          rc = launch_head(precision, st.in.ptr, st.in.Cpad, hd.cin, hd.cout, hd.hw, hd.hb, of, ou,
                            (size_t)st.in.D * st.in.H * st.in.W, s);
         break;
       }
@@ -1153,18 +1157,21 @@ int bsmi_unet_debug_activation(bsmi_unet* h, int step, int what, int64_t shape_o
   BSMI_HIP(hipSetDevice(h->device));
   BSMI_HIP(hipDeviceSynchronize());
   const int es = esize(plan->prec);
-  const size_t plane = nvox * t.Cpad * es;
-  std::vector<uint8_t> raw(plane + t.lo_off);
+  const bool split = t.lo_off != 0;
+  const size_t bytes = nvox * t.Cpad * es * (split ? 2 : 1);
+  std::vector<uint8_t> raw(bytes);
   BSMI_HIP(hipMemcpy(raw.data(), t.ptr, raw.size(), hipMemcpyDeviceToHost));
   for (size_t v = 0; v < nvox; ++v)
     for (int c = 0; c < t.C; ++c) {
-      const size_t i = v * t.Cpad + c;
       float x;
       if (plan->prec == BSMI_PREC_F32) {
-        x = ((const float*)raw.data())[i];
-      } else {
+        x = ((const float*)raw.data())[v * t.Cpad + c];
+      } else if (!split) {
+        x = host_bf16_to_f32(((const uint16_t*)raw.data())[v * t.Cpad + c]);
+      } else {  // (hi, lo) vectors of 8 interleaved
+        const size_t i = 2 * v * t.Cpad + (size_t)((c >> 3) << 4) + (c & 7);
         const float hi = host_bf16_to_f32(((const uint16_t*)raw.data())[i]);
-        const float lo = t.lo_off ? host_bf16_to_f32(((const uint16_t*)(raw.data() + t.lo_off))[i]) : 0.f;
+        const float lo = host_bf16_to_f32(((const uint16_t*)raw.data())[i + 8]);
         x = what == 1 ? hi : (what == 2 ? lo : hi + lo);
       }
       host_out[v * t.C + c] = x;

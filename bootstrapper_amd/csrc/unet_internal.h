@@ -71,7 +71,7 @@ struct HeadSite {
 struct TDesc {
   void* ptr = nullptr;
   int C = 0, Cpad = 0, D = 0, H = 0, W = 0;
-  size_t lo_off = 0;  // BSMI_PREC_BF16X3: byte offset of the lo plane behind the hi plane (0 otherwise)
+  size_t lo_off = 0;  // BSMI_PREC_BF16X3: 16 = each 16-byte vector of hi values is followed by that of the lo values; else 0
 };
 
 struct PlanStep {
@@ -144,7 +144,8 @@ struct bsmi_unet {
   int sk_grid = 0;         // 0: not set up yet, -1: disabled
   int sk_request = -1;     // bsmi_unet_set_persistent_grid: -1 = CU count of the device, 0 = off
   bsmi::TrainState* train = nullptr;  // train.hip
-  bsmi::FirstPassWeights first_pass;  // first_pass.hip: weights of the fused first ConvPass (bf16 mode)
+  bsmi::FirstPassWeights first_pass;     // first_pass.hip: weights of the fused first ConvPass (bf16 mode)
+  bsmi::FirstPassWeights first_pass_x3;  // ... and of the split-bf16 mode
 };
 
 namespace bsmi {

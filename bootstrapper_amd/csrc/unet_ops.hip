@@ -48,20 +48,23 @@ struct Vec<uint16_t> {
   }
 };
 
-// One 16-byte channel vector as floats.  SP (BSMI_PREC_BF16X3): the tensor is a (hi, lo) pair of bf16 planes, `lo`
-// elements apart; a value is hi + lo (exact in f32) and is stored as hi = bf16(v), lo = bf16(v - hi).
+// One 16-byte channel vector as floats, at element index `e` (a multiple of the vector length) of the plain
+// [voxel][Cpad] order.  SP (BSMI_PREC_BF16X3): every 16-byte vector of hi values is followed by the 16 bytes of their
+// lo values (conv_dev.h act_index); a value is hi + lo (exact in f32) and is stored as hi = bf16(v), lo = bf16(v - hi).
 template <typename T, bool SP>
-__device__ __forceinline__ void load_vec(const T* p, size_t lo, float* f) {
+__device__ __forceinline__ void load_vec(const T* base, size_t e, float* f) {
+  const T* p = base + (SP ? 2 * e : e);
   Vec<T>::unpack(*(const u32x4_t*)p, f);
   if constexpr (SP) {
     float g[Vec<T>::N];
-    Vec<T>::unpack(*(const u32x4_t*)(p + lo), g);
+    Vec<T>::unpack(*(const u32x4_t*)(p + Vec<T>::N), g);
 #pragma unroll
     for (int k = 0; k < Vec<T>::N; ++k) f[k] += g[k];
   }
 }
 template <typename T, bool SP, bool NT = false>
-__device__ __forceinline__ void store_vec(T* p, size_t lo, const float* f) {
+__device__ __forceinline__ void store_vec(T* base, size_t e, const float* f) {
+  T* p = base + (SP ? 2 * e : e);
   const u32x4_t hv = Vec<T>::pack(f);
   if constexpr (NT) __builtin_nontemporal_store(hv, (u32x4_t*)p);
   else *(u32x4_t*)p = hv;
@@ -71,8 +74,8 @@ __device__ __forceinline__ void store_vec(T* p, size_t lo, const float* f) {
 #pragma unroll
     for (int k = 0; k < Vec<T>::N; ++k) r[k] = f[k] - h[k];
     const u32x4_t lv = Vec<T>::pack(r);
-    if constexpr (NT) __builtin_nontemporal_store(lv, (u32x4_t*)(p + lo));
-    else *(u32x4_t*)(p + lo) = lv;
+    if constexpr (NT) __builtin_nontemporal_store(lv, (u32x4_t*)(p + Vec<T>::N));
+    else *(u32x4_t*)(p + Vec<T>::N) = lv;
   }
 }
 
@@ -81,7 +84,7 @@ __device__ __forceinline__ void store_vec(T* p, size_t lo, const float* f) {
 // (reference models/3d_affs/predict.py:147-149): x = u8 * (1/255) * 2 - 1 in f32;
 // `unit`: gp.Normalize only (x = u8 * (1/255)), the inputs of the second-stage nets.
 template <typename T, typename RAW, bool SP = false>
-__global__ void input_prep_kernel(const RAW* raw, T* out, size_t lo, int cin, int cpad, size_t nvox, int unit) {
+__global__ void input_prep_kernel(const RAW* raw, T* out, int cin, int cpad, size_t nvox, int unit) {
   // one 16-byte channel vector per thread
   constexpr int N = Vec<T>::N;
   const int cv = cpad / N;
@@ -103,31 +106,31 @@ __global__ void input_prep_kernel(const RAW* raw, T* out, size_t lo, int cin, in
     }
     f[k] = x;
   }
-  store_vec<T, SP>(out + i * N, lo, f);
+  store_vec<T, SP>(out, i * N, f);
 }
 
-int launch_input_prep(int precision, const void* raw, int raw_dtype, void* out, size_t out_lo, int cin, int cpad,
+int launch_input_prep(int precision, const void* raw, int raw_dtype, void* out, int cin, int cpad,
                       size_t nvox, hipStream_t s) {
   const int bs = 256;
   const int unit = raw_dtype == BSMI_RAW_U8_UNIT;
   if (precision == BSMI_PREC_F32) {
     const unsigned grid = (unsigned)ceil_div64((int64_t)(nvox * (cpad / 4)), bs);
     if (raw_dtype != BSMI_RAW_F32)
-      hipLaunchKernelGGL((input_prep_kernel<float, uint8_t>), dim3(grid), dim3(bs), 0, s, (const uint8_t*)raw, (float*)out, (size_t)0, cin, cpad, nvox, unit);
+      hipLaunchKernelGGL((input_prep_kernel<float, uint8_t>), dim3(grid), dim3(bs), 0, s, (const uint8_t*)raw, (float*)out, cin, cpad, nvox, unit);
     else
-      hipLaunchKernelGGL((input_prep_kernel<float, float>), dim3(grid), dim3(bs), 0, s, (const float*)raw, (float*)out, (size_t)0, cin, cpad, nvox, 0);
+      hipLaunchKernelGGL((input_prep_kernel<float, float>), dim3(grid), dim3(bs), 0, s, (const float*)raw, (float*)out, cin, cpad, nvox, 0);
   } else if (precision == BSMI_PREC_BF16X3) {
     const unsigned grid = (unsigned)ceil_div64((int64_t)(nvox * (cpad / 8)), bs);
     if (raw_dtype != BSMI_RAW_F32)
-      hipLaunchKernelGGL((input_prep_kernel<uint16_t, uint8_t, true>), dim3(grid), dim3(bs), 0, s, (const uint8_t*)raw, (uint16_t*)out, out_lo / 2, cin, cpad, nvox, unit);
+      hipLaunchKernelGGL((input_prep_kernel<uint16_t, uint8_t, true>), dim3(grid), dim3(bs), 0, s, (const uint8_t*)raw, (uint16_t*)out, cin, cpad, nvox, unit);
     else
-      hipLaunchKernelGGL((input_prep_kernel<uint16_t, float, true>), dim3(grid), dim3(bs), 0, s, (const float*)raw, (uint16_t*)out, out_lo / 2, cin, cpad, nvox, 0);
+      hipLaunchKernelGGL((input_prep_kernel<uint16_t, float, true>), dim3(grid), dim3(bs), 0, s, (const float*)raw, (uint16_t*)out, cin, cpad, nvox, 0);
   } else {
     const unsigned grid = (unsigned)ceil_div64((int64_t)(nvox * (cpad / 8)), bs);
     if (raw_dtype != BSMI_RAW_F32)
-      hipLaunchKernelGGL((input_prep_kernel<uint16_t, uint8_t>), dim3(grid), dim3(bs), 0, s, (const uint8_t*)raw, (uint16_t*)out, (size_t)0, cin, cpad, nvox, unit);
+      hipLaunchKernelGGL((input_prep_kernel<uint16_t, uint8_t>), dim3(grid), dim3(bs), 0, s, (const uint8_t*)raw, (uint16_t*)out, cin, cpad, nvox, unit);
     else
-      hipLaunchKernelGGL((input_prep_kernel<uint16_t, float>), dim3(grid), dim3(bs), 0, s, (const float*)raw, (uint16_t*)out, (size_t)0, cin, cpad, nvox, 0);
+      hipLaunchKernelGGL((input_prep_kernel<uint16_t, float>), dim3(grid), dim3(bs), 0, s, (const float*)raw, (uint16_t*)out, cin, cpad, nvox, 0);
   }
   BSMI_HIP(hipGetLastError());
   return BSMI_OK;
@@ -135,7 +138,7 @@ int launch_input_prep(int precision, const void* raw, int raw_dtype, void* out, 
 
 // ---- max-pool (reference unet.py:79-106 Downsample, MaxPool3d kernel=stride=factor) ---
 template <typename T, bool SP = false>
-__global__ void maxpool_kernel(const T* in, size_t in_lo, T* out, size_t out_lo, int H, int W, int C, int Do, int Ho, int Wo,
+__global__ void maxpool_kernel(const T* in, T* out, int H, int W, int C, int Do, int Ho, int Wo,
                                int fz, int fy, int fx) {
   constexpr int N = Vec<T>::N;
   const int cv = C / N;
@@ -155,29 +158,29 @@ __global__ void maxpool_kernel(const T* in, size_t in_lo, T* out, size_t out_lo,
       for (int dx = 0; dx < fx; ++dx) {
         const size_t src = ((size_t)((z * fz + dz) * H + (y * fy + dy)) * W + (x * fx + dx)) * C + c * N;
         float f[N];
-        load_vec<T, SP>(in + src, in_lo, f);
+        load_vec<T, SP>(in, src, f);
 #pragma unroll
         for (int k = 0; k < N; ++k) m[k] = fmaxf(m[k], f[k]);
       }
-  store_vec<T, SP>(out + i * N, out_lo, m);
+  store_vec<T, SP>(out, i * N, m);
 }
 
-int launch_maxpool(int precision, const void* in, size_t in_lo, void* out, size_t out_lo, int D, int H, int W, int C, int fz,
+int launch_maxpool(int precision, const void* in, void* out, int D, int H, int W, int C, int fz,
                    int fy, int fx, hipStream_t s) {
   const int Do = D / fz, Ho = H / fy, Wo = W / fx;
   const int bs = 256;
   if (precision == BSMI_PREC_F32) {
     const size_t total = (size_t)Do * Ho * Wo * (C / 4);
     hipLaunchKernelGGL(maxpool_kernel<float>, dim3((unsigned)ceil_div64(total, bs)), dim3(bs), 0, s,
-                       (const float*)in, (size_t)0, (float*)out, (size_t)0, H, W, C, Do, Ho, Wo, fz, fy, fx);
+                       (const float*)in, (float*)out, H, W, C, Do, Ho, Wo, fz, fy, fx);
   } else if (precision == BSMI_PREC_BF16X3) {
     const size_t total = (size_t)Do * Ho * Wo * (C / 8);
     hipLaunchKernelGGL((maxpool_kernel<uint16_t, true>), dim3((unsigned)ceil_div64(total, bs)), dim3(bs), 0, s,
-                       (const uint16_t*)in, in_lo / 2, (uint16_t*)out, out_lo / 2, H, W, C, Do, Ho, Wo, fz, fy, fx);
+                       (const uint16_t*)in, (uint16_t*)out, H, W, C, Do, Ho, Wo, fz, fy, fx);
   } else {
     const size_t total = (size_t)Do * Ho * Wo * (C / 8);
     hipLaunchKernelGGL(maxpool_kernel<uint16_t>, dim3((unsigned)ceil_div64(total, bs)), dim3(bs), 0, s,
-                       (const uint16_t*)in, (size_t)0, (uint16_t*)out, (size_t)0, H, W, C, Do, Ho, Wo, fz, fy, fx);
+                       (const uint16_t*)in, (uint16_t*)out, H, W, C, Do, Ho, Wo, fz, fy, fx);
   }
   BSMI_HIP(hipGetLastError());
   return BSMI_OK;
@@ -202,7 +205,7 @@ __device__ __forceinline__ void lin_src(int dst, int f, int n, int& i0, int& i1,
 
 // One output voxel (z, y, x), one channel vector, the general way.
 template <typename T, bool SP>
-__device__ __forceinline__ void upsample_one(const T* in, size_t in_lo, T* out, size_t out_lo, int D, int H, int W, int C, int Ho, int Wo,
+__device__ __forceinline__ void upsample_one(const T* in, T* out, int D, int H, int W, int C, int Ho, int Wo,
                                              int fz, int fy, int fx, int oz, int oy, int ox, int z, int y, int x, int c) {
   constexpr int N = Vec<T>::N;
   int z0, z1, y0, y1, x0, x1;
@@ -212,12 +215,12 @@ __device__ __forceinline__ void upsample_one(const T* in, size_t in_lo, T* out, 
   lin_src(x + ox, fx, W, x0, x1, wx0, wx1);
   auto plane = [&](int zz, float* o) {
     float a[N], b[N], p[N], q[N];
-    load_vec<T, SP>(in + (((size_t)zz * H + y0) * W + x0) * C + c, in_lo, a);
-    load_vec<T, SP>(in + (((size_t)zz * H + y0) * W + x1) * C + c, in_lo, b);
+    load_vec<T, SP>(in, (((size_t)zz * H + y0) * W + x0) * C + c, a);
+    load_vec<T, SP>(in, (((size_t)zz * H + y0) * W + x1) * C + c, b);
 #pragma unroll
     for (int k = 0; k < N; ++k) p[k] = wx0 * a[k] + wx1 * b[k];
-    load_vec<T, SP>(in + (((size_t)zz * H + y1) * W + x0) * C + c, in_lo, a);
-    load_vec<T, SP>(in + (((size_t)zz * H + y1) * W + x1) * C + c, in_lo, b);
+    load_vec<T, SP>(in, (((size_t)zz * H + y1) * W + x0) * C + c, a);
+    load_vec<T, SP>(in, (((size_t)zz * H + y1) * W + x1) * C + c, b);
 #pragma unroll
     for (int k = 0; k < N; ++k) q[k] = wx0 * a[k] + wx1 * b[k];
 #pragma unroll
@@ -234,19 +237,19 @@ __device__ __forceinline__ void upsample_one(const T* in, size_t in_lo, T* out, 
 #pragma unroll
     for (int k = 0; k < N; ++k) acc[k] = wz0 * r[k] + wz1 * r[k];
   }
-  store_vec<T, SP, true>(out + (((size_t)z * Ho + y) * Wo + x) * C + c, out_lo, acc);
+  store_vec<T, SP, true>(out, (((size_t)z * Ho + y) * Wo + x) * C + c, acc);
 }
 
 // General factors: one workgroup per output row (z, y), a thread walks the row's (x, channel vector) pairs.
 template <typename T, bool SP = false>
-__global__ void upsample_crop_kernel(const T* in, size_t in_lo, T* out, size_t out_lo, int D, int H, int W, int C, int Do, int Ho,
+__global__ void upsample_crop_kernel(const T* in, T* out, int D, int H, int W, int C, int Do, int Ho,
                                      int Wo, int fz, int fy, int fx, int oz, int oy, int ox) {
   constexpr int N = Vec<T>::N;
   const int cv = C / N;
   const int y = blockIdx.x % Ho, z = blockIdx.x / Ho;
   for (int i = threadIdx.x; i < Wo * cv; i += blockDim.x) {
     const int x = i / cv, c = (i - x * cv) * N;
-    upsample_one<T, SP>(in, in_lo, out, out_lo, D, H, W, C, Ho, Wo, fz, fy, fx, oz, oy, ox, z, y, x, c);
+    upsample_one<T, SP>(in, out, D, H, W, C, Ho, Wo, fz, fy, fx, oz, oy, ox, z, y, x, c);
   }
 }
 
@@ -256,7 +259,7 @@ __global__ void upsample_crop_kernel(const T* in, size_t in_lo, T* out, size_t o
 // arithmetic is that of upsample_one, operation for operation; patches that touch the border, where the source
 // index is clamped, take the general path.
 template <typename T, bool SP = false>
-__global__ void upsample2x_kernel(const T* in, size_t in_lo, T* out, size_t out_lo, int D, int H, int W, int C, int Do, int Ho, int Wo,
+__global__ void upsample2x_kernel(const T* in, T* out, int D, int H, int W, int C, int Do, int Ho, int Wo,
                                   int oz, int oy, int ox, int py0, int npy, int px0, int npx) {
   constexpr int N = Vec<T>::N;
   const int cv = C / N;
@@ -270,11 +273,11 @@ __global__ void upsample2x_kernel(const T* in, size_t in_lo, T* out, size_t out_
     const int xa = 2 * px - 1 - ox;
     if (row_in && xa >= 0 && xa + 1 < Wo && px - 1 >= 0 && px <= W - 1) {
       float s00[N], s01[N], s10[N], s11[N];
-      const T* base = in + (((size_t)(z + oz) * H + (py - 1)) * W + (px - 1)) * C + c;
-      load_vec<T, SP>(base, in_lo, s00);
-      load_vec<T, SP>(base + C, in_lo, s01);
-      load_vec<T, SP>(base + (size_t)W * C, in_lo, s10);
-      load_vec<T, SP>(base + (size_t)W * C + C, in_lo, s11);
+      const size_t base = (((size_t)(z + oz) * H + (py - 1)) * W + (px - 1)) * C + c;
+      load_vec<T, SP>(in, base, s00);
+      load_vec<T, SP>(in, base + C, s01);
+      load_vec<T, SP>(in, base + (size_t)W * C, s10);
+      load_vec<T, SP>(in, base + (size_t)W * C + C, s11);
 #pragma unroll
       for (int r = 0; r < 2; ++r) {
         const float wy1 = r ? 0.75f : 0.25f, wy0 = 1.f - wy1;
@@ -289,7 +292,7 @@ __global__ void upsample2x_kernel(const T* in, size_t in_lo, T* out, size_t out_
             const float v = wy0 * p + wy1 * qq;
             acc[k] = 1.f * v + 0.f * v;  // the z weights (1, 0) of upsample_one
           }
-          store_vec<T, SP, true>(out + (((size_t)z * Ho + ya + r) * Wo + xa + q) * C + c, out_lo, acc);
+          store_vec<T, SP, true>(out, (((size_t)z * Ho + ya + r) * Wo + xa + q) * C + c, acc);
         }
       }
     } else {
@@ -299,13 +302,13 @@ __global__ void upsample2x_kernel(const T* in, size_t in_lo, T* out, size_t out_
         for (int q = 0; q < 2; ++q) {
           const int y = ya + r, x = xa + q;
           if (y >= 0 && y < Ho && x >= 0 && x < Wo)
-            upsample_one<T, SP>(in, in_lo, out, out_lo, D, H, W, C, Ho, Wo, 1, 2, 2, oz, oy, ox, z, y, x, c);
+            upsample_one<T, SP>(in, out, D, H, W, C, Ho, Wo, 1, 2, 2, oz, oy, ox, z, y, x, c);
         }
     }
   }
 }
 
-int launch_upsample_crop(int precision, const void* in, size_t in_lo, void* out, size_t out_lo, int D, int H, int W, int C, int Do,
+int launch_upsample_crop(int precision, const void* in, void* out, int D, int H, int W, int C, int Do,
                          int Ho, int Wo, int fz, int fy, int fx, int oz, int oy, int ox, hipStream_t s) {
   const int bs = 256;
   const bool sp = precision == BSMI_PREC_BF16X3;
@@ -314,26 +317,26 @@ int launch_upsample_crop(int precision, const void* in, size_t in_lo, void* out,
     const int px0 = (ox + 1) / 2, npx = (ox + Wo) / 2 - px0 + 1;
     const unsigned grid = (unsigned)(Do * npy);
     if (precision == BSMI_PREC_F32)
-      hipLaunchKernelGGL(upsample2x_kernel<float>, dim3(grid), dim3(bs), 0, s, (const float*)in, (size_t)0, (float*)out, (size_t)0, D, H, W, C,
+      hipLaunchKernelGGL(upsample2x_kernel<float>, dim3(grid), dim3(bs), 0, s, (const float*)in, (float*)out, D, H, W, C,
                          Do, Ho, Wo, oz, oy, ox, py0, npy, px0, npx);
     else if (sp)
-      hipLaunchKernelGGL((upsample2x_kernel<uint16_t, true>), dim3(grid), dim3(bs), 0, s, (const uint16_t*)in, in_lo / 2, (uint16_t*)out,
-                         out_lo / 2, D, H, W, C, Do, Ho, Wo, oz, oy, ox, py0, npy, px0, npx);
+      hipLaunchKernelGGL((upsample2x_kernel<uint16_t, true>), dim3(grid), dim3(bs), 0, s, (const uint16_t*)in, (uint16_t*)out,
+                         D, H, W, C, Do, Ho, Wo, oz, oy, ox, py0, npy, px0, npx);
     else
-      hipLaunchKernelGGL(upsample2x_kernel<uint16_t>, dim3(grid), dim3(bs), 0, s, (const uint16_t*)in, (size_t)0, (uint16_t*)out, (size_t)0, D,
+      hipLaunchKernelGGL(upsample2x_kernel<uint16_t>, dim3(grid), dim3(bs), 0, s, (const uint16_t*)in, (uint16_t*)out, D,
                          H, W, C, Do, Ho, Wo, oz, oy, ox, py0, npy, px0, npx);
     BSMI_HIP(hipGetLastError());
     return BSMI_OK;
   }
   const unsigned grid = (unsigned)(Do * Ho);
   if (precision == BSMI_PREC_F32)
-    hipLaunchKernelGGL(upsample_crop_kernel<float>, dim3(grid), dim3(bs), 0, s, (const float*)in, (size_t)0, (float*)out, (size_t)0, D, H, W, C,
+    hipLaunchKernelGGL(upsample_crop_kernel<float>, dim3(grid), dim3(bs), 0, s, (const float*)in, (float*)out, D, H, W, C,
                        Do, Ho, Wo, fz, fy, fx, oz, oy, ox);
   else if (sp)
-    hipLaunchKernelGGL((upsample_crop_kernel<uint16_t, true>), dim3(grid), dim3(bs), 0, s, (const uint16_t*)in, in_lo / 2, (uint16_t*)out,
-                       out_lo / 2, D, H, W, C, Do, Ho, Wo, fz, fy, fx, oz, oy, ox);
+    hipLaunchKernelGGL((upsample_crop_kernel<uint16_t, true>), dim3(grid), dim3(bs), 0, s, (const uint16_t*)in, (uint16_t*)out,
+                       D, H, W, C, Do, Ho, Wo, fz, fy, fx, oz, oy, ox);
   else
-    hipLaunchKernelGGL(upsample_crop_kernel<uint16_t>, dim3(grid), dim3(bs), 0, s, (const uint16_t*)in, (size_t)0, (uint16_t*)out, (size_t)0, D,
+    hipLaunchKernelGGL(upsample_crop_kernel<uint16_t>, dim3(grid), dim3(bs), 0, s, (const uint16_t*)in, (uint16_t*)out, D,
                        H, W, C, Do, Ho, Wo, fz, fy, fx, oz, oy, ox);
   BSMI_HIP(hipGetLastError());
   return BSMI_OK;
@@ -343,7 +346,7 @@ int launch_upsample_crop(int precision, const void* in, size_t in_lo, void* out,
 // reference model.py:54-56 + unet.py:63-76: sigmoid((W1 z + b1) + (W2 z + b2)); f32 math.
 // hw: [cout][2][cin] (conv_pass.0 then residual.0), hb: [cout][2].
 template <typename T, bool SP = false>
-__global__ void head_kernel(const T* z, size_t z_lo, int cpad, int cin, int cout, const float* hw, const float* hb,
+__global__ void head_kernel(const T* z, int cpad, int cin, int cout, const float* hw, const float* hb,
                             float* out_f32, uint8_t* out_u8, size_t nvox) {
   extern __shared__ float sw[];
   float* sb = sw + cout * 2 * cin;
@@ -354,7 +357,7 @@ __global__ void head_kernel(const T* z, size_t z_lo, int cpad, int cin, int cout
   if (v >= nvox) return;
   float f[64];
   constexpr int N = Vec<T>::N;
-  for (int c = 0; c < cpad && c < 64; c += N) load_vec<T, SP>(z + v * cpad + c, z_lo, f + c);
+  for (int c = 0; c < cpad && c < 64; c += N) load_vec<T, SP>(z, v * cpad + c, f + c);
   for (int o = 0; o < cout; ++o) {
     float s1 = 0.f, s2 = 0.f;
     for (int c = 0; c < cin; ++c) {
@@ -369,19 +372,19 @@ __global__ void head_kernel(const T* z, size_t z_lo, int cpad, int cin, int cout
   }
 }
 
-int launch_head(int precision, const void* z, size_t z_lo, int cpad, int cin, int cout, const float* hw,
+int launch_head(int precision, const void* z, int cpad, int cin, int cout, const float* hw,
                 const float* hb, float* out_f32, uint8_t* out_u8, size_t nvox, hipStream_t s) {
   if (cpad > 64) BSMI_FAIL(BSMI_ERR_INVALID, "head kernel supports at most 64 input channels (got %d)", cpad);
   const int bs = 256;
   const size_t smem = (size_t)(cout * 2 * cin + cout * 2) * sizeof(float);
   const unsigned grid = (unsigned)ceil_div64((int64_t)nvox, bs);
   if (precision == BSMI_PREC_F32)
-    hipLaunchKernelGGL(head_kernel<float>, dim3(grid), dim3(bs), smem, s, (const float*)z, (size_t)0, cpad, cin, cout, hw, hb, out_f32, out_u8, nvox);
+    hipLaunchKernelGGL(head_kernel<float>, dim3(grid), dim3(bs), smem, s, (const float*)z, cpad, cin, cout, hw, hb, out_f32, out_u8, nvox);
   else if (precision == BSMI_PREC_BF16X3)
-    hipLaunchKernelGGL((head_kernel<uint16_t, true>), dim3(grid), dim3(bs), smem, s, (const uint16_t*)z, z_lo / 2, cpad, cin, cout, hw, hb, out_f32,
+    hipLaunchKernelGGL((head_kernel<uint16_t, true>), dim3(grid), dim3(bs), smem, s, (const uint16_t*)z, cpad, cin, cout, hw, hb, out_f32,
                        out_u8, nvox);
   else
-    hipLaunchKernelGGL(head_kernel<uint16_t>, dim3(grid), dim3(bs), smem, s, (const uint16_t*)z, (size_t)0, cpad, cin, cout, hw, hb, out_f32, out_u8, nvox);
+    hipLaunchKernelGGL(head_kernel<uint16_t>, dim3(grid), dim3(bs), smem, s, (const uint16_t*)z, cpad, cin, cout, hw, hb, out_f32, out_u8, nvox);
   BSMI_HIP(hipGetLastError());
   return BSMI_OK;
 }
