@@ -90,6 +90,9 @@ def _load():
         "bsmi_lut_relabel": (i32, [C.c_int, vp, C.c_uint64, vp, vp, C.c_uint64, vp, vp]),
         "bsmi_connected_components": (i32, [vp, C.c_uint64, vp, vp, C.c_uint64, C.c_float, vp]),
         "bsmi_cc_affs_u8": (i32, [p, vp, i64p, C.c_int, C.c_int64, vp, vp, vp, vp]),
+        "bsmi_mws_agglom_f64": (i32, [C.c_int, vp, C.c_int, vp, vp, C.c_uint32, i64p, vp, vp]),
+        "bsmi_mws_cluster": (i32, [C.c_uint64, vp, vp, C.c_uint64, vp]),
+        "bsmi_frag_pair_affinity_u8": (i32, [C.c_int, vp, C.c_int, vp, vp, i64p, C.c_uint64, vp, vp, vp, vp, vp]),
         "bsmi_label_table_u64": (i32, [p, vp, i64p, C.c_int64, vp, vp, vp, vp, C.c_uint64, vp, vp]),
         "bsmi_seg_status": (i32, [p, vp]),
         "bsmi_unet_train_begin": (i32, [p, i64p]),

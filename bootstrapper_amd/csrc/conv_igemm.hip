@@ -636,6 +636,7 @@ __device__ __forceinline__ void conv_x3_body(const ConvArgs& a, char* smem, int 
   constexpr int OFF_AL = 0, OFF_AH = 2 * EA, OFF_BH = 4 * EA, OFF_BL = 4 * EA + 2 * EB;
   constexpr int G1 = 2 * A_INSTR + B_INSTR, G2 = B_INSTR;  // LDS-DMA instructions of batch 1 / batch 2 per wave
   constexpr int P1 = (G1 + 1) / 2;                         // batch 1 goes out in two parts
+  constexpr bool PAIRED = NW == 4;
   // outstanding loads allowed at the barriers (see the schedule above): what was issued after the batch that must have landed
   constexpr int NX = LATE ? G1 : G1 + G2;
   constexpr int NY = LATE ? G2 : G1 + G2;
@@ -702,8 +703,10 @@ __device__ __forceinline__ void conv_x3_body(const ConvArgs& a, char* smem, int 
     const cint_ptr_t d = steps + (ha < nsteps ? ha : nsteps - 1) * 4;
     return Desc{d[0], d[1], d[2]};
   };
-  // Batch 1 of K-step h_, instructions [K0_, K1_): k < 2 A_INSTR: the A rows (lo and hi vectors of a row block back to
-  // back: the second finds the 128-byte lines of the first in the vector L1), else B hi.  Macros, not lambdas:
+  // Batch 1 of K-step h_, instructions [K0_, K1_): k < 2 A_INSTR: the A rows, else B hi.  The lo and the hi vectors of a
+  // row share their 128-byte lines: the 4-wave kernels issue them back to back (PAIRED; in the other order the second
+  // access finds the line evicted again: the 360 -> 60 channel layer 3.04 -> 2.48 ms), the 8-wave kernels all lo row blocks
+  // first (measured 3-5 % faster there, two row blocks per wave only).  Macros, not lambdas:
   // a closure that selects among the three row-offset arrays keeps them (and everything else it captures) in scratch.
 #define ISSUE1(h_, ds_, K0_, K1_)                                                                                         \
   do {                                                                                                                     \
@@ -714,8 +717,8 @@ __device__ __forceinline__ void conv_x3_body(const ConvArgs& a, char* smem, int 
     const size_t wi_ = (size_t)(s0 + (h_) < nsteps ? s0 + (h_) : nsteps - 1) * wstep;                                      \
     _Pragma("unroll") for (int k_ = (K0_); k_ < (K1_); ++k_) {                                                             \
       if (k_ < 2 * A_INSTR) {                                                                                              \
-        const int i_ = k_ >> 1;                                                                                            \
-        const bool lo_ = (k_ & 1) == 0;                                                                                    \
+        const int i_ = PAIRED ? k_ >> 1 : (k_ < A_INSTR ? k_ : k_ - A_INSTR);                                              \
+        const bool lo_ = PAIRED ? (k_ & 1) == 0 : k_ < A_INSTR;                                                            \
         const uint32_t r0_ = ro0[i_], r1_ = ro1[i_], r2_ = ro2[i_];                                                        \
         const uint32_t src_ = (t1_ ? r1_ : (t2_ ? r2_ : r0_)) + lofs_ + (lo_ ? 16u : 0u);                                  \
         const lptr_t dst_ = (lptr_t)(smem + (lo_ ? OFF_AL : OFF_AH) + p_ * EA) + (i_ * NW + wave) * 1024;                  \
@@ -1179,7 +1182,7 @@ static int launch_cfg(const ConvArgs& a, TileCfg cfg, hipStream_t stream, float*
     // conv_x3_body: 16x16x32 where the wave tile allows (it needs two halves of B fragments), 32x32x16 for the wide wave tiles
     switch (cfg) {
       case TILE_256x32: return launch_one<T, 256, 32, 4, 1, 16>(a, stream, sk_ws, sk_grid);
-      case TILE_256x64: return launch_one<T, 256, 64, 4, 1, 32>(a, stream, sk_ws, sk_grid);
+      case TILE_256x64: return launch_one<T, 256, 64, 4, 1, 32>(a, stream, sk_ws, sk_grid);  // 8 x 1 waves: measured no faster
       case TILE_256x160: return launch_one<T, 256, 160, 4, 1, 32>(a, stream, sk_ws, sk_grid);
       case TILE_256x320: return launch_one<T, 256, 320, 4, 2, 32>(a, stream, sk_ws, sk_grid);
       case TILE_256x256: return launch_one<T, 256, 256, 4, 2, 16>(a, stream, sk_ws, sk_grid);

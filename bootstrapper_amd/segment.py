@@ -2,8 +2,8 @@
 
 Behavioural mirror of /root/reference/bootstrapper/segment.py:10-163: method DEFAULTS,
 parameter precedence DEFAULTS < TOML `<method>_params` < `-p key=value`, coordinate parsing,
-the blockwise requirements, and the dispatch to the watershed driver.  Only the `ws` method
-runs on this engine; `mws` / `cc` raise.  Pinned by tests/golden/host_cases.json.
+the blockwise requirements, and the dispatch to the `ws` / `mws` / `cc` drivers under post/.
+Pinned by tests/golden/host_cases.json.
 """
 from ast import literal_eval
 
@@ -93,5 +93,6 @@ def run_segmentation(config_file, mode="ws", **kwargs):
         from .post.connected_components import cc_segmentation
         return cc_segmentation(config)
     if mode == "mws":
-        raise NotImplementedError("segmentation method 'mws' (mutex watershed) is outside this engine's hot path")
+        from .post.watershed_mutex import mutex_watershed_segmentation
+        return mutex_watershed_segmentation(config)
     raise ValueError(f"Unknown segmentation mode: {mode}")

@@ -308,6 +308,35 @@ int bsmi_connected_components(const uint64_t *nodes, uint64_t n, const uint64_t 
 int bsmi_cc_affs_u8(bsmi_seg *h, const uint8_t *affs_dev, const int64_t shape[3], int cut, int64_t min_size,
                     uint64_t *frags_dev, uint64_t *seg_dev, uint64_t *num_labels_dev, void *stream);
 
+/* ---- mutex watershed (`bs segment --mws`) ------------------------------------------------------------------
+ * Replaces mwatershed.agglom as the reference calls it (post/mws.py:51-56; the package is third party and absent:
+ * restated from Wolf et al., "The Mutex Watershed", parity unpinned).  affs_dev: f64 [n_offsets][D][H][W] on the
+ * device, already shifted (w > 0 attractive, w < 0 repulsive, 0 / NaN: no edge); offsets / strides: host
+ * int32 [n_offsets][3] (strides NULL = every voxel; random_seed != 0 = the "randomized_strides" form: an edge is kept
+ * with probability 1 / prod(stride)).  Edges in order of |w| descending, ties (channel, voxel) ascending.
+ * labels_dev: u64 [D][H][W], 1 + smallest voxel index of the cluster.  Synchronises `stream` (the sweep over the
+ * sorted edges runs on the host: it is sequential by definition). */
+int bsmi_mws_agglom_f64(int device, const double *affs_dev, int n_offsets, const int32_t *offsets,
+                        const int32_t *strides, uint32_t random_seed, const int64_t shape[3],
+                        uint64_t *labels_dev, void *stream);
+
+/* Mutex watershed on a graph, HOST pointers (volara GraphMWS -> mwatershed.cluster, reference
+ * post/watershed_mutex.py:155-161): edges u64 [m][2] of node indices < n_nodes, scores f64 [m] (sign as above),
+ * labels_out[i] = 1 + smallest node index of node i's cluster. */
+int bsmi_mws_cluster(uint64_t n_nodes, const uint64_t *edges, const double *scores, uint64_t m,
+                     uint64_t *labels_out);
+
+/* Affinity statistics between adjacent fragments over a neighbourhood (volara AffAgglom, reference
+ * post/watershed_mutex.py:143-153, scores={"zyx_aff": neighborhood}).  affs_dev: u8 [n_offsets][D][H][W]; dense_dev:
+ * u64 [D][H][W] of dense fragment indices 1..n < 2^32 (0 = background); for every unordered pair of different
+ * fragments joined by some (p, p + offset_k): pairs_out[i] = {smaller, larger} (HOST, ascending), sums_out[i] = sum
+ * of the affinity bytes, counts_out[i] = number of such voxel pairs.  *n_pairs is always set; BSMI_ERR_INVALID if
+ * it exceeds `capacity`. */
+int bsmi_frag_pair_affinity_u8(int device, const uint8_t *affs_dev, int n_offsets, const int32_t *offsets,
+                               const uint64_t *dense_dev, const int64_t shape[3], uint64_t capacity,
+                               uint64_t *pairs_out, uint64_t *sums_out, uint64_t *counts_out,
+                               uint64_t *n_pairs, void *stream);
+
 /* Label table of a block (`bs refine` statistics: reference refine.py:98-109 `_global_sizes`, :228-250 z extents):
  * the distinct non-zero ids of labels_dev in ascending order with their voxel counts and first / last z slice
  * (z0 = global index of the block's first slice).  *n_dev = number of ids (<= capacity, else bsmi_seg_status
