@@ -140,10 +140,8 @@ class WatershedFrags(_BlockTask):
                  epsilon_agglomerate=0.0, sigma=None, noise_eps=None, bias=None, filter_fragments=0.0,
                  remove_debris=0, device=0, origin=(0, 0, 0)):
         super().__init__(block_size, context, total_shape, device, origin)
-        if seed_eps is not None:
-            raise NotImplementedError("seed_eps is not implemented on the device (the reference default leaves it off)")
         self.epsilon_agglomerate = float(epsilon_agglomerate or 0.0)
-        self.shift = dict(sigma=sigma, noise_eps=noise_eps, bias=bias)
+        self.shift = dict(sigma=sigma, noise_eps=noise_eps, bias=bias, seed_eps=seed_eps)
         self.fragments_in_xy = bool(fragments_in_xy)
         self.min_seed_distance = int(min_seed_distance)
         self.filter_fragments = float(filter_fragments)
@@ -169,7 +167,8 @@ class WatershedFrags(_BlockTask):
         if any(v is not None for v in self.shift.values()):  # compute_fragments, watershed_frags.py:116-145
             from .shifts import boundary_mask_affinities
             src = boundary_mask_affinities(a_dev, self.fragments_in_xy, dtype=torch.float64,
-                                           generator=torch.Generator(device=dev).manual_seed(block_index), **self.shift)
+                                           generator=torch.Generator(device=dev).manual_seed(block_index),
+                                           min_seed_distance=self.min_seed_distance, **self.shift)
         frags, _ = eng.ws_fragments(src, self.fragments_in_xy, self.min_seed_distance)
         if self.epsilon_agglomerate > 0:                     # epsilon_agglomerate_fragments, :158-177
             eng.rag_agglomerate(a_dev.contiguous(), frags, self.epsilon_agglomerate, 256)

@@ -133,8 +133,6 @@ def waterz_pipeline(config, device=None, rank=0, world=1, group=None):
         "filter_fragments": config.get("filter_fragments", 0.0),
         "remove_debris": config.get("remove_debris", 0),
     }
-    if frag_params["seed_eps"] is not None:
-        raise NotImplementedError("seed_eps is not implemented on the device (the reference default leaves it off)")
     voxel_size = affs.voxel_size
     if config.get("roi_offset") is not None:
         roi = (list(config["roi_offset"]), list(config["roi_shape"]))
@@ -162,7 +160,7 @@ def waterz_pipeline(config, device=None, rank=0, world=1, group=None):
                         frag_params["min_seed_distance"], frag_params["filter_fragments"], frag_params["remove_debris"], 256,
                         n_lanes=int(config.get("lanes", 8)), device=device, rank=rank, world=world, group=group, exchange_affs=False,
                         epsilon_agglomerate=frag_params["epsilon_agglomerate"], sigma=frag_params["sigma"],
-                        noise_eps=frag_params["noise_eps"], bias=frag_params["bias"])
+                        noise_eps=frag_params["noise_eps"], bias=frag_params["bias"], seed_eps=frag_params["seed_eps"])
     _fill_affinities(seg, affs, origin, z0, mask)
 
     # fragments + edge scores of this worker's blocks (post/watershed.py:118-153), accounted like daisy tasks

@@ -110,7 +110,7 @@ class SlabSegmenter:
     def __init__(self, slab_shape, block, context, total_layers, layer0, thresholds=(0.2, 0.35, 0.5),
                  fragments_in_xy=True, min_seed_distance=10, filter_fragments=0.0, remove_debris=0, discretize_queue=256,
                  n_lanes=8, device=0, rank=0, world=1, group=None, edge_cap=1 << 17, label_cap=1 << 16, exchange_affs=True,
-                 epsilon_agglomerate=0.0, sigma=None, noise_eps=None, bias=None, noise_seed=0):
+                 epsilon_agglomerate=0.0, sigma=None, noise_eps=None, bias=None, noise_seed=0, seed_eps=None):
         self.shape = tuple(int(s) for s in slab_shape)
         self.block = tuple(int(b) for b in block)
         self.ctx = tuple(int(c) for c in context)
@@ -119,7 +119,7 @@ class SlabSegmenter:
         self.filter_fragments, self.remove_debris = float(filter_fragments), int(remove_debris)
         self.bins = int(discretize_queue)
         self.epsilon = float(epsilon_agglomerate or 0.0)
-        self.shift = dict(sigma=sigma, noise_eps=noise_eps, bias=bias)
+        self.shift = dict(sigma=sigma, noise_eps=noise_eps, bias=bias, seed_eps=seed_eps)
         self.noise_seed = int(noise_seed)
         self.rank, self.world, self.group = int(rank), int(world), group
         # False: the caller fills the context margins of the affinities itself (a driver reads them from the dataset,
@@ -232,7 +232,8 @@ class SlabSegmenter:
                 # watershed_frags.py:116-145: the watershed sees the shifted affinities, everything after it the plain ones
                 from .post.shifts import boundary_mask_affinities
                 gen = torch.Generator(device=self.dev).manual_seed(self.noise_seed + self.block_ids[k])
-                src = boundary_mask_affinities(a, self.fragments_in_xy, dtype=torch.float64, generator=gen, **self.shift)
+                src = boundary_mask_affinities(a, self.fragments_in_xy, dtype=torch.float64, generator=gen, min_seed_distance=self.msd,
+                                               **self.shift)
             else:
                 src = a
             fr, _ = eng.ws_fragments(src, self.fragments_in_xy, self.msd)

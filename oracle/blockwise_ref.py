@@ -24,7 +24,7 @@ def _boxes(total, block):
             for z in grid[0] for y in grid[1] for x in grid[2]]
 
 
-def shifted_mask_affinities(a, fragments_in_xy=True, sigma=None, bias=None, dtype=np.float64):
+def shifted_mask_affinities(a, fragments_in_xy=True, sigma=None, bias=None, dtype=np.float64, seed_eps=None, min_seed_distance=10):
     """watershed_frags.py:116-131 / post/watershed.py:285-303 with scipy, then ws.py's threshold (ws.py:64-77,100): the mask
     of the shifted affinities as 0 / 255 pseudo-affinities (post/ws.py reads nothing else from them)."""
     from scipy.ndimage import gaussian_filter
@@ -35,6 +35,14 @@ def shifted_mask_affinities(a, fragments_in_xy=True, sigma=None, bias=None, dtyp
     if bias is not None:
         b = list(bias) if isinstance(bias, (list, tuple)) else [bias] * x.shape[0]
         shift += np.array([b]).reshape((-1, 1, 1, 1)).astype(dtype)
+    if seed_eps is not None:   # watershed_frags.py:133-141, the scipy calls of the reference
+        from scipy.ndimage import distance_transform_edt, label, maximum_filter
+        boundary_mask = np.mean(x, axis=0) > 0.5
+        boundary_distances = distance_transform_edt(boundary_mask)
+        max_filtered = maximum_filter(boundary_distances, min_seed_distance)
+        seeds, _ = label(max_filtered == boundary_distances)
+        seeds[~boundary_mask] = 0
+        shift -= (seed_eps * distance_transform_edt(seeds == 0)).astype(dtype)
     x = x + shift
     mask = (0.5 * (x[-1] + x[-2]) > 0.5) if fragments_in_xy else (np.mean(x, axis=0) > 0.5)
     return np.repeat((mask.astype(np.uint8) * 255)[None], 3, axis=0)
@@ -54,7 +62,7 @@ def epsilon_agglomerate(a, frags, epsilon, bins=256):
     return out
 
 
-def cpu_blockwise(affs, block, ctx, msd, ff, rd, thresholds, bins=256, workers=1, epsilon=0.0, sigma=None, bias=None):
+def cpu_blockwise(affs, block, ctx, msd, ff, rd, thresholds, bins=256, workers=1, epsilon=0.0, sigma=None, bias=None, seed_eps=None):
     """-> (fragments u64, nodes, edges, scores, [segmentation per threshold]).  workers > 1: the blocks of a stage run on
     a thread pool (the C calls release the GIL), as the reference's stages run on daisy workers."""
     from concurrent.futures import ThreadPoolExecutor
@@ -70,7 +78,8 @@ def cpu_blockwise(affs, block, ctx, msd, ff, rd, thresholds, bins=256, workers=1
         a = pad_read(affs, rb, re, lead=True)
         if a.max() == 0:
             return
-        src = a if sigma is None and bias is None else shifted_mask_affinities(a, True, sigma, bias)
+        src = a if sigma is None and bias is None and seed_eps is None else shifted_mask_affinities(a, True, sigma, bias, seed_eps=seed_eps,
+                                                                                                     min_seed_distance=msd)
         fr, _ = S.ws_fragments_u8(src, True, msd)
         if epsilon > 0:
             fr = epsilon_agglomerate(a, fr, epsilon)

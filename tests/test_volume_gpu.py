@@ -156,3 +156,36 @@ def test_epsilon_agglomeration_and_affinity_shifts():
     segs = seg.run()
     assert np.array_equal(seg.interior(seg.frags).cpu().numpy().view(np.uint64), frags_ref)
     assert np.array_equal(segs[0].cpu().numpy().view(np.uint64), segs_ref[0])
+
+
+def test_seed_eps_shift():
+    """watershed_frags.py:133-141 (`seed_eps`): the affinities decay with the distance from the seeds of a 3-D boundary
+    distance transform.  The device arithmetic (exact Euclidean transform, maximum filter) against the scipy calls the
+    reference makes: the shifted float affinities bit for bit, then the blockwise fragments through SlabSegmenter."""
+    from bootstrapper_amd.volume import SlabSegmenter
+    from bootstrapper_amd.post import shifts
+    from oracle.blockwise_ref import cpu_blockwise, shifted_mask_affinities
+    from scipy import ndimage
+    shape, block, ctx = (12, 96, 80), (6, 48, 40), (1, 6, 5)
+    affs = blobby_affs(shape, 43, empty_corner=False)
+    m = affs.astype(np.float64).mean(axis=0) / 255.0 > 0.5
+    assert np.array_equal(shifts.distance_transform_edt(torch.from_numpy(m).cuda()).cpu().numpy(), ndimage.distance_transform_edt(m))
+    d = ndimage.distance_transform_edt(m)
+    for size in (3, 4, 10):
+        assert np.array_equal(shifts.maximum_filter(torch.from_numpy(d).cuda(), size).cpu().numpy(), ndimage.maximum_filter(d, size))
+    eps = 0.02
+    for xy in (True, False):
+        got = shifts.boundary_mask_affinities(torch.from_numpy(affs).cuda(), xy, dtype=torch.float64, seed_eps=eps, min_seed_distance=4)
+        ref = shifted_mask_affinities(affs, xy, seed_eps=eps, min_seed_distance=4)
+        assert np.array_equal(got.cpu().numpy(), ref), xy
+        plain = shifted_mask_affinities(affs, xy, bias=0.0)
+        assert (ref[0] > 0).sum() < (plain[0] > 0).sum()             # the decay eats into the mask
+    thr = [0.4]
+    frags_ref, nodes, _, _, segs_ref = cpu_blockwise(affs, block, ctx, 4, 0.2, 8, thr, seed_eps=eps)
+    plain, _, _, _, _ = cpu_blockwise(affs, block, ctx, 4, 0.2, 8, thr)
+    assert not np.array_equal(frags_ref, plain)
+    seg = SlabSegmenter(shape, block, ctx, 2, 0, thr, True, 4, 0.2, 8, 256, n_lanes=4, seed_eps=eps)
+    seg.interior(seg.affs).copy_(torch.from_numpy(affs).cuda())
+    segs = seg.run()
+    assert np.array_equal(seg.interior(seg.frags).cpu().numpy().view(np.uint64), frags_ref)
+    assert np.array_equal(segs[0].cpu().numpy().view(np.uint64), segs_ref[0])
