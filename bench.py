@@ -63,29 +63,28 @@ HBM_PEAK_BYTES = 8.0e12
 # HBM-side bytes per conv launch cannot be counted inside this process: they come from the committed
 # rocprofv3 PMC passes of the same kernels on the same block (tools/pmc_traffic.py; FETCH_SIZE and WRITE_SIZE
 # in separate passes, KiB -> bytes, FETCH_SIZE doubled for gfx950 wide reads as the guide prescribes).
-TRAFFIC_PROFILE = os.path.join(ROOT, "profiles", "r01_g_conv_traffic_pmc.json")
+TRAFFIC_PROFILES = {"bf16x3": os.path.join(ROOT, "profiles", "r02_conv_traffic_pmc_bf16x3.json"),
+                    "bf16": os.path.join(ROOT, "profiles", "r01_g_conv_traffic_pmc.json")}
 
 
 def pmc_traffic(precision):
-    if precision != "bf16":
-        return None, None
+    path = TRAFFIC_PROFILES.get(precision)
     try:
-        with open(TRAFFIC_PROFILE) as f:
-            return float(json.load(f)["traffic_bytes_per_conv_launch"]), os.path.relpath(TRAFFIC_PROFILE, ROOT)
-    except (OSError, KeyError, ValueError):
+        with open(path) as f:
+            return float(json.load(f)["traffic_bytes_per_conv_launch"]), os.path.relpath(path, ROOT)
+    except (OSError, KeyError, ValueError, TypeError):
         return None, None
 
 
-SQ_PROFILE = os.path.join(ROOT, "profiles", "r01_g_conv_sq_pmc.json")
+SQ_PROFILES = {"bf16x3": os.path.join(ROOT, "profiles", "r02_conv_sq_pmc_bf16x3.json"),
+               "bf16": os.path.join(ROOT, "profiles", "r01_g_conv_sq_pmc.json")}
 
 
 def pmc_mfma_busy(precision):
     """MFMA-busy fraction of the persistent implicit-GEMM launches (the dominant kernels), from the committed PMC
     passes (tools/run_pmc_passes.sh + tools/pmc_sq.py): SIMD cycles with the matrix pipe busy / SIMD cycles."""
-    if precision != "bf16":
-        return None
     try:
-        with open(SQ_PROFILE) as f:
+        with open(SQ_PROFILES[precision]) as f:
             ks = json.load(f)["kernels"]
         rows = [r for k, r in ks.items() if "conv_igemm_sk_kernel" in k]
         tot = sum(r["chip_cycles_per_launch"] * r["launches"] for r in rows)
@@ -248,7 +247,7 @@ def main():
     ap.add_argument("--no-segment", action="store_true", help="predict only (diagnostic; not the headline metric)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-modes", action="store_true", help="skip the per-precision predict lines (speed and error of f32 / bf16x3 / bf16)")
-    ap.add_argument("--profile-every", type=int, default=1,
+    ap.add_argument("--profile-every", type=int, default=4,
                     help="per-launch HIP-event timing (the roofline figures) on every Nth block of the timed region")
     ap.add_argument("--cpu-predict-blocks", type=int, default=2)
     ap.add_argument("--cpu-segment-blocks", type=int, default=16)
@@ -360,6 +359,8 @@ def main():
                      "traffic_source": traffic_src,
                      "kernel": "bsmi::conv_igemm_kernel / conv_igemm_sk_kernel (all convolution launches of the U-Net)",
                      "launches": int(conv_launches), "avg_launch_ms": conv_ms / max(conv_launches, 1),
+                     "timed": f"HIP events around every launch of every {max(1, args.profile_every)}. block of the timed region",
+                     "mfma_busy_pmc": pmc_mfma_busy(args.precision),
                      "algorithmic_tflop_per_block": flops_block / 1e12,
                      "other_unet_ms_per_block": sum(totals[k][0] for k in ("input", "pool", "upsample", "head")) / max(args.steps, 1)},
     }
