@@ -645,12 +645,18 @@ __device__ __forceinline__ void conv_x3_body(const ConvArgs& a, char* smem, int 
   typedef typename std::conditional<MS == 16, f32x4_t, f32x16_t>::type acc_t;
 
   // every field of the launch arguments this body needs, as locals (the lambdas below capture these, not `a`)
-  const cint_ptr_t steps = (cint_ptr_t)a.steps;
-  const int nsteps = a.nsteps;
-  const gptr_t w_hi = (gptr_t)a.w, w_lo = (gptr_t)a.w_lo;
-  const float* const bias = a.bias;
-  char* const out_base = (char*)a.out;
-  const int aM = a.M, aNpad = a.Npad, aCo = a.Co, aWo = a.Wo, aHo = a.Ho, relu = a.relu;
+  // The launch arguments are read from the kernarg segment through a pointer the optimiser cannot see through, where
+  // they are needed (tile geometry here, output fields in the epilogue): loaded once at kernel entry they would sit in
+  // scalar registers across the whole persistent loop, and the spilled scalars cost the vector registers the 320-wide
+  // tile does not have.  (`a` is the first kernel argument of both kernels.)
+  typedef const __attribute__((address_space(4))) ConvArgs* kargs_t;
+  kargs_t ka = (kargs_t)__builtin_amdgcn_kernarg_segment_ptr();
+  asm volatile("" : "+s"(ka));
+  (void)a;
+  const cint_ptr_t steps = (cint_ptr_t)ka->steps;
+  const int nsteps = ka->nsteps;
+  const gptr_t w_hi = (gptr_t)ka->w, w_lo = (gptr_t)ka->w_lo;
+  const int aM = ka->M, aNpad = ka->Npad, aWo = ka->Wo, aHo = ka->Ho;
   // opaque per call: the lane geometry below is recomputed per tile rather than hoisted out of a persistent
   // kernel's tile loop, where it would stay live across the whole body (the 256x320 form has no registers for that)
   int tid_ = threadIdx.x;
@@ -681,11 +687,11 @@ __device__ __forceinline__ void conv_x3_body(const ConvArgs& a, char* smem, int 
     const int x = m % aWo;
     const int zy = m / aWo;
     const int y = zy % aHo, z = zy / aHo;
-    ro0[i] = (uint32_t)(z * a.t[0].sz + y * a.t[0].sy + x * a.t[0].sx);
-    ro1[i] = (uint32_t)(z * a.t[1].sz + y * a.t[1].sy + x * a.t[1].sx);
-    ro2[i] = (uint32_t)(z * a.t[2].sz + y * a.t[2].sy + x * a.t[2].sx);
+    ro0[i] = (uint32_t)(z * ka->t[0].sz + y * ka->t[0].sy + x * ka->t[0].sx);
+    ro1[i] = (uint32_t)(z * ka->t[1].sz + y * ka->t[1].sy + x * ka->t[1].sx);
+    ro2[i] = (uint32_t)(z * ka->t[2].sz + y * ka->t[2].sy + x * ka->t[2].sx);
   }
-  const uint64_t base0 = a.t[0].base, base1 = a.t[1].base, base2 = a.t[2].base;
+  const uint64_t base0 = ka->t[0].base, base1 = ka->t[1].base, base2 = ka->t[2].base;
   const uint32_t offb = (uint32_t)((n0 + wave * 16 + lrow) * ROWB + ((lchunk ^ skey) << 4));
   const size_t wstep = (size_t)aNpad * ROWB;
 
@@ -883,7 +889,11 @@ __device__ __forceinline__ void conv_x3_body(const ConvArgs& a, char* smem, int 
   constexpr int LO_STRIPS = NW * 16 * PITCH;
   static_assert(2 * LO_STRIPS <= 4 * (EA + EB), "both strip sets fit in the staging area");
   char* strip = smem + wave * (16 * PITCH);
-  T* out = (T*)out_base;
+  kargs_t kb = (kargs_t)__builtin_amdgcn_kernarg_segment_ptr();
+  asm volatile("" : "+s"(kb));
+  const float* const bias = kb->bias;
+  const int aCo = kb->Co, relu = kb->relu;
+  T* out = (T*)kb->out;
   float bv[FN];
 #pragma unroll
   for (int j = 0; j < FN; ++j) {
@@ -1176,6 +1186,9 @@ bool two_waves_per_simd() {
   return on;
 }
 
+#ifndef BSMI_X3_320_MS
+#define BSMI_X3_320_MS 16  // MFMA shape of the fused 256 x 320 tile (dev builds: 32)
+#endif
 template <typename T>
 static int launch_cfg(const ConvArgs& a, TileCfg cfg, hipStream_t stream, float* sk_ws, int sk_grid) {
   if constexpr (IsFused<T>::value) {
@@ -1184,7 +1197,7 @@ static int launch_cfg(const ConvArgs& a, TileCfg cfg, hipStream_t stream, float*
       case TILE_256x32: return launch_one<T, 256, 32, 4, 1, 16>(a, stream, sk_ws, sk_grid);
       case TILE_256x64: return launch_one<T, 256, 64, 4, 1, 32>(a, stream, sk_ws, sk_grid);  // 8 x 1 waves: measured no faster
       case TILE_256x160: return launch_one<T, 256, 160, 4, 1, 32>(a, stream, sk_ws, sk_grid);
-      case TILE_256x320: return launch_one<T, 256, 320, 4, 2, 32>(a, stream, sk_ws, sk_grid);
+      case TILE_256x320: return launch_one<T, 256, 320, 4, 2, BSMI_X3_320_MS>(a, stream, sk_ws, sk_grid);
       case TILE_256x256: return launch_one<T, 256, 256, 4, 2, 16>(a, stream, sk_ws, sk_grid);
       default: BSMI_FAIL(BSMI_ERR_INVALID, "unknown tile config %d", (int)cfg);
     }
