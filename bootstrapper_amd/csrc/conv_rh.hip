@@ -91,7 +91,9 @@ __device__ __forceinline__ void conv_rh_body(const RhArgs& a, char* smem, int ti
 
   const int lrow = lane >> 2, lchunk = lane & 3;
   const int skey = (lane >> 4) & 3;
-  const uint32_t hsrc = (uint32_t)((lchunk ^ skey) << 4);  // source chunk that lands in LDS slot lchunk
+  // source chunk that lands in LDS slot lchunk; split tensors hold (hi, lo) vectors interleaved: the plane's chunks are 32
+  // bytes apart and the phase's byte offset (RhPhase::delta) selects hi (+0) or lo (+16)
+  const uint32_t hsrc = (uint32_t)((lchunk ^ skey) << (IsSplit<T>::value ? 5 : 4));
   static_assert(kMaxConvTensors == 3, "three source slots");
   uint32_t ro0[HP], ro1[HP], ro2[HP];
 #pragma unroll
@@ -106,7 +108,7 @@ __device__ __forceinline__ void conv_rh_body(const RhArgs& a, char* smem, int ti
     ro2[i] = (uint32_t)(z * a.t[2].sz + yy * a.t[2].sy + xx * a.t[2].sx);
   }
   const uint64_t base0 = a.t[0].base, base1 = a.t[1].base, base2 = a.t[2].base;
-  const uint32_t offb = (uint32_t)((n0 + wave * 16 + lrow) * ROWB) + hsrc;
+  const uint32_t offb = (uint32_t)((n0 + wave * 16 + lrow) * ROWB) + (uint32_t)((lchunk ^ skey) << 4);
   const size_t wstep = (size_t)a.Npad * ROWB;
 
   f32x16_t acc[FM][FN];
@@ -249,7 +251,9 @@ __device__ __forceinline__ void conv_rh_body(const RhArgs& a, char* smem, int ti
   constexpr int PITCH = WTN * ESZ + 16;
   constexpr int CPR = WTN * ESZ / 16;
   constexpr int NCH = 16 * CPR;
-  static_assert(NW * 16 * PITCH <= RING + NSLOT * SLOT, "epilogue strips fit in LDS");
+  constexpr bool SPLIT = IsSplit<T>::value;  // (hi, lo) output vectors: the lo values go through a second set of strips
+  constexpr int LO_STRIPS = NW * 16 * PITCH;
+  static_assert((SPLIT ? 2 : 1) * NW * 16 * PITCH <= RING + NSLOT * SLOT, "epilogue strips fit in LDS");
   char* strip = smem + wave * (16 * PITCH);
   T* out = (T*)a.out;
   float bv[FN];
@@ -270,6 +274,7 @@ __device__ __forceinline__ void conv_rh_body(const RhArgs& a, char* smem, int ti
           float v = acc[i][j][hf * 8 + rr] + bv[j];
           if (a.relu) v = v > 0.f ? v : 0.f;
           Elem<T>::store((T*)(strip + row * PITCH) + j * 32 + lr, v);
+          if constexpr (SPLIT) Elem<T>::store((T*)(strip + LO_STRIPS + row * PITCH) + j * 32 + lr, split_lo(v));
         }
       }
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -285,7 +290,11 @@ __device__ __forceinline__ void conv_rh_body(const RhArgs& a, char* smem, int ti
           const int xx = q % a.Win;
           const int zy = q / a.Win;
           const int yy = zy % a.Hin, z = zy / a.Hin;
-          if (xx < a.Wo && yy < a.Ho) store_stream16(out + ((size_t)(z * a.Ho + yy) * a.Wo + xx) * a.Co + n, v);
+          if (xx < a.Wo && yy < a.Ho) {
+            T* dst = out + act_index<T>(((size_t)(z * a.Ho + yy) * a.Wo + xx) * a.Co, n);
+            store_stream16(dst, v);
+            if constexpr (SPLIT) store_stream16(dst + kSplitLoElems, *(const u32x4_t*)(strip + LO_STRIPS + row * PITCH + cc * 16));
+          }
         }
       }
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -410,7 +419,9 @@ __global__ __launch_bounds__(64 * kRhNW) void conv_rh_fixup_kernel(const RhArgs 
     if (xx >= a.Wo || yy >= a.Ho) continue;
     float v = x[r] + bv;
     if (a.relu) v = v > 0.f ? v : 0.f;
-    Elem<T>::store(out + ((size_t)(z * a.Ho + yy) * a.Wo + xx) * a.Co + n, v);
+    T* dst = out + act_index<T>(((size_t)(z * a.Ho + yy) * a.Wo + xx) * a.Co, n);
+    Elem<T>::store(dst, v);
+    if constexpr (IsSplit<T>::value) Elem<T>::store(dst + kSplitLoElems, split_lo(v));
   }
 }
 
@@ -480,6 +491,7 @@ int launch_conv_rh(const RhArgs& a, int precision, TileCfg cfg, hipStream_t stre
     BSMI_FAIL(BSMI_ERR_INVALID, "raster-halo conv launch: bad geometry Q=%d nsteps=%d Npad=%d", a.Q, a.nsteps, a.Npad);
   if (precision == BSMI_PREC_F32) return launch_rh_cfg<float>(a, cfg, stream, sk_ws, sk_grid);
   if (precision == BSMI_PREC_BF16) return launch_rh_cfg<bf16_elem>(a, cfg, stream, sk_ws, sk_grid);
+  if (precision == BSMI_PREC_BF16X3) return launch_rh_cfg<bf16s_elem>(a, cfg, stream, sk_ws, sk_grid);  // listed hi / lo K-steps
   BSMI_FAIL(BSMI_ERR_INVALID, "unknown precision %d", precision);
 }
 

@@ -11,7 +11,8 @@ t0 = time.time(); sd = synthetic_state_dict(NC, 0); print("weights", time.time()
 t0 = time.time(); m = Model(NC, precision=prec).load_state_dict(sd); print("pack+upload", time.time() - t0)
 raw = synthetic_volume(shape, 0)
 m.profile(True)
-for it in range(3):
+iters = int(sys.argv[3]) if len(sys.argv) > 3 else 3
+for it in range(iters):
     torch.cuda.synchronize(); t0 = time.time()
     u8 = m.predict_u8(raw)
     torch.cuda.synchronize(); dt = time.time() - t0
