@@ -920,10 +920,11 @@ int bsmi_unet_create(const bsmi_unet_config* cfg, int device, bsmi_unet** out) {
 }
 
 int bsmi_stream_create_cu_mask(int device, const uint32_t* cu_mask, int n_words, void** stream_out) {
-  if (!cu_mask || n_words < 1 || !stream_out) BSMI_FAIL(BSMI_ERR_INVALID, "null argument");
+  if (!stream_out || (cu_mask && n_words < 1)) BSMI_FAIL(BSMI_ERR_INVALID, "null argument");
   BSMI_HIP(hipSetDevice(device));
   hipStream_t s = nullptr;
-  BSMI_HIP(hipExtStreamCreateWithCUMask(&s, (uint32_t)n_words, cu_mask));
+  if (!cu_mask) BSMI_HIP(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));  // an ordinary stream the caller may destroy again
+  else BSMI_HIP(hipExtStreamCreateWithCUMask(&s, (uint32_t)n_words, cu_mask));
   *stream_out = (void*)s;
   return BSMI_OK;
 }
