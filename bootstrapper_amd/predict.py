@@ -192,8 +192,8 @@ def predict_blocks(cfg, rank=0, world=1, device=None, precision="bf16x3"):
     copy_stream = torch.cuda.Stream(dev)
     pool = cf.ThreadPoolExecutor(max_workers=2, thread_name_prefix="bsmi-write")
     def write_block(blk, hi, u8, ready):
-        with torch.cuda.stream(copy_stream):
-            copy_stream.wait_event(ready)
+        ready.synchronize()  # on this pool thread: a copy stream parked behind a device-side wait is a queue the command
+        with torch.cuda.stream(copy_stream):  # processor polls for the whole forward pass, at the predict stream's expense
             host = [t[:, :hi[0], :hi[1], :hi[2]].to("cpu", non_blocking=True) for t in u8]
             done = torch.cuda.Event()
             done.record(copy_stream)
