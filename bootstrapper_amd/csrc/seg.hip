@@ -1014,18 +1014,58 @@ __device__ __forceinline__ uint64_t agg_norm_key(uint32_t x, uint32_t y) {
   return x < y ? (((uint64_t)x << 32) | y) : (((uint64_t)y << 32) | x);
 }
 
+// ---- RAG path: bin-queue merge loop ---------------------------------------------------------------------------------
+// Where the loop's per-edge state lives.  FAST (ne <= kRagFastEdges, nn <= kRagFastNodes: every 160^3 read box so far):
+// endpoints, queue links, merge clocks, flags (16-bit / 8-bit), affinity sums, counts and stored scores (32-bit) as LDS
+// arrays, 138 KB, so that a pop -- and most pops only find a stale edge to re-score: every merge makes all edges at the
+// survivor stale, ten or more re-scorings per merge -- touches no HBM at all.  Otherwise the arrays of the workspace.
+constexpr int kRagFastEdges = 6144, kRagFastNodes = 6144;
+template <bool FAST>
+struct RagMem {
+  const AggWs& w;
+  uint16_t *eu16, *ev16, *qn16, *et16, *nt16;
+  uint8_t* fl8;
+  uint32_t *sum32, *cnt32;  // a sum of affinity bytes over at most 3 * 160^3 voxel faces fits 32 bits
+  float* sc32;
+  __device__ __forceinline__ unsigned long long sum(uint32_t e) const { if constexpr (FAST) return sum32[e]; else return w.esum[e]; }
+  __device__ __forceinline__ uint32_t cnt(uint32_t e) const { if constexpr (FAST) return cnt32[e]; else return w.ecnt[e]; }
+  __device__ __forceinline__ void fold(uint32_t into, uint32_t from) const {   // the sums of `from` join those of `into`
+    if constexpr (FAST) { sum32[into] += sum32[from]; cnt32[into] += cnt32[from]; }
+    else { w.esum[into] += w.esum[from]; w.ecnt[into] += w.ecnt[from]; }
+  }
+  __device__ __forceinline__ float score(uint32_t e) const { if constexpr (FAST) return sc32[e]; else return w.escore[e]; }
+  __device__ __forceinline__ void set_score(uint32_t e, float v) const { if constexpr (FAST) sc32[e] = v; else w.escore[e] = v; }
+  __device__ __forceinline__ uint32_t eu(uint32_t e) const { if constexpr (FAST) return eu16[e]; else return w.eu[e]; }
+  __device__ __forceinline__ uint32_t ev(uint32_t e) const { if constexpr (FAST) return ev16[e]; else return w.ev[e]; }
+  __device__ __forceinline__ void set_eu(uint32_t e, uint32_t v) const { if constexpr (FAST) eu16[e] = (uint16_t)v; else w.eu[e] = v; }
+  __device__ __forceinline__ void set_ev(uint32_t e, uint32_t v) const { if constexpr (FAST) ev16[e] = (uint16_t)v; else w.ev[e] = v; }
+  __device__ __forceinline__ bool dead(uint32_t e) const { if constexpr (FAST) return fl8[e] & 1; else return w.eflags[e] & 1; }
+  __device__ __forceinline__ void kill(uint32_t e) const { if constexpr (FAST) fl8[e] |= 1; else w.eflags[e] |= 1; }
+  __device__ __forceinline__ uint32_t qnext(uint32_t e) const {
+    if constexpr (FAST) { const uint16_t v = qn16[e]; return v == 0xffffu ? NOEDGE : (uint32_t)v; }
+    else return w.qnext[e];
+  }
+  __device__ __forceinline__ void set_qnext(uint32_t e, uint32_t v) const { if constexpr (FAST) qn16[e] = (uint16_t)v; else w.qnext[e] = v; }
+  __device__ __forceinline__ uint32_t etime(uint32_t e) const { if constexpr (FAST) return et16[e]; else return w.etime[e]; }
+  __device__ __forceinline__ void set_etime(uint32_t e, uint32_t v) const { if constexpr (FAST) et16[e] = (uint16_t)v; else w.etime[e] = v; }
+  __device__ __forceinline__ uint32_t ntime(uint32_t n) const { if constexpr (FAST) return nt16[n]; else return w.ntime[n]; }
+  __device__ __forceinline__ void set_ntime(uint32_t n, uint32_t v) const { if constexpr (FAST) nt16[n] = (uint16_t)v; else w.ntime[n] = v; }
+};
+
 // contract live edge e: b = larger endpoint is absorbed by a (same rewiring as agg_merge_kernel).  Staleness in this path
-// is a clock comparison (rag_merge_kernel), so nothing is flagged here: every edge that ends up incident to a is stale
-// because a's clock moves.
-__device__ __forceinline__ bool agg_contract(const AggWs& w, uint32_t e, uint32_t& a_out, uint32_t& b_out) {
-  const uint32_t eu = w.eu[e], evv = w.ev[e];
+// is a clock comparison (rag_merge_body), so nothing is flagged here: every edge that ends up incident to a is stale
+// because a's clock moves.  Sequential form (one lane).
+template <bool FAST>
+__device__ __forceinline__ bool agg_contract(const RagMem<FAST>& M, uint32_t e) {
+  const AggWs& w = M.w;
+  const uint32_t eu = M.eu(e), evv = M.ev(e);
   const uint32_t a = eu < evv ? eu : evv, b = eu < evv ? evv : eu;
   uint32_t f = w.head[b];
   while (f != NOEDGE) {
-    const uint32_t fu = w.eu[f], fv = w.ev[f];
+    const uint32_t fu = M.eu(f), fv = M.ev(f);
     const bool b_in_u = fu == b;
     const uint32_t nxt = b_in_u ? w.enextu[f] : w.enextv[f];
-    if (f != e && !(w.eflags[f] & 1)) {
+    if (f != e && !M.dead(f)) {
       const uint32_t nb = b_in_u ? fv : fu;
       const uint64_t gkey = agg_norm_key(a, nb);
       const int64_t fs = agg_hfind(w, agg_norm_key(fu, fv));
@@ -1034,20 +1074,18 @@ __device__ __forceinline__ bool agg_contract(const AggWs& w, uint32_t e, uint32_
       bool move_f = true;
       if (gs >= 0) {
         const uint32_t g = w.hvals[gs];
-        if (w.escore[f] > w.escore[g]) {
-          w.esum[g] += w.esum[f];
-          w.ecnt[g] += w.ecnt[f];
-          w.eflags[f] |= 1;
+        if (M.score(f) > M.score(g)) {
+          M.fold(g, f);
+          M.kill(f);
           move_f = false;
         } else {
-          w.esum[f] += w.esum[g];
-          w.ecnt[f] += w.ecnt[g];
-          w.eflags[g] |= 1;
+          M.fold(f, g);
+          M.kill(g);
           w.hvals[gs] = f;
         }
       }
       if (move_f) {
-        if (b_in_u) { w.eu[f] = a; w.enextu[f] = w.head[a]; } else { w.ev[f] = a; w.enextv[f] = w.head[a]; }
+        if (b_in_u) { M.set_eu(f, a); w.enextu[f] = w.head[a]; } else { M.set_ev(f, a); w.enextv[f] = w.head[a]; }
         w.head[a] = f;
         if (gs < 0 && !agg_hput(w, gkey, f)) return false;
       }
@@ -1056,74 +1094,231 @@ __device__ __forceinline__ bool agg_contract(const AggWs& w, uint32_t e, uint32_
   }
   const int64_t es = agg_hfind(w, agg_norm_key(eu, evv));
   if (es >= 0) w.hkeys[es] = HTOMB;
-  w.eflags[e] |= 1;
+  M.kill(e);
   w.parent[b] = a;
-  a_out = a;
-  b_out = b;
   return true;
 }
 
 constexpr int kMaxQueueBins = 1024;
+constexpr int kSweepCap = 2048;  // incident edges the cooperative sweep takes per contraction (more: lane 0 alone, agg_contract)
 
-// One lane replays the sequential bin-queue merge loop and grows the merge tree.
-__global__ __launch_bounds__(64) void rag_merge_kernel(AggWs w, float threshold, int nbins) {
-  __shared__ uint32_t bhead[kMaxQueueBins], btail[kMaxQueueBins];
-  if (!xcd_claim(&w.counters[5], w.xcd_hint)) return;
-  if (w.counters[3]) return;
-  for (int b = threadIdx.x; b < nbins; b += 64) bhead[b] = btail[b] = NOEDGE;
+// agg_contract by the whole wave (all 64 lanes call it with the same e, after a __syncthreads()).  The edges at b are
+// independent of one another -- each meets a different neighbour -- so lane 0 only walks b's list into LDS (one memory
+// round trip per edge) and the lanes then take one incident edge each: the two hash look-ups, the comparison of the stored
+// scores, the fold or the move.  What must keep the order of the sequential loop does: the moved edges are linked into a's
+// list in traversal order.  New hash entries go in by compare-and-swap (the slot an entry lands in may differ from the
+// sequential run's; look-ups do not care).  -> false: hash table full.
+template <bool FAST>
+__device__ __forceinline__ bool agg_contract_wave(const RagMem<FAST>& M, uint32_t e, uint32_t* lst, int* sh, uint32_t& a_out, uint32_t& b_out) {
+  const AggWs& w = M.w;
+  const int lane = threadIdx.x;
+  const uint32_t eu = M.eu(e), evv = M.ev(e);
+  const uint32_t a = eu < evv ? eu : evv, b = eu < evv ? evv : eu;
+  a_out = a;
+  b_out = b;
+  if (lane == 0) {
+    int n = 0;
+    uint32_t f = w.head[b];
+    while (f != NOEDGE && n < kSweepCap) {
+      const uint32_t fu = M.eu(f), nu = w.enextu[f], nv = w.enextv[f];  // independent loads: one round trip per edge
+      lst[n++] = f;
+      f = fu == b ? nu : nv;
+    }
+    sh[0] = f == NOEDGE ? n : -1;
+  }
   __syncthreads();
-  if (threadIdx.x != 0) return;
-  const uint32_t nn = w.counters[0];
-  const uint32_t ne = min(w.counters[1], w.edge_cap);
-  int minbin = nbins;
+  const int n = sh[0];
+  if (n < 0) {  // a hub with more edges than the list holds: the sequential form
+    if (lane == 0) sh[1] = agg_contract<FAST>(M, e) ? 1 : 0;
+    __syncthreads();
+    return sh[1] != 0;
+  }
+  uint32_t head_a = w.head[a];
+  bool fail = false;
+  for (int base = 0; base < n; base += 64) {
+    const int i = base + lane;
+    uint32_t f = NOEDGE;
+    bool live = false, b_in_u = false, move_f = false, put_f = false;
+    uint64_t gkey = 0;
+    if (i < n) {
+      f = lst[i];
+      live = f != e && !M.dead(f);
+    }
+    if (live) {
+      const uint32_t fu = M.eu(f), fv = M.ev(f);
+      b_in_u = fu == b;
+      const uint32_t nb = b_in_u ? fv : fu;
+      gkey = agg_norm_key(a, nb);
+      const int64_t fs = agg_hfind(w, agg_norm_key(fu, fv));
+      const int64_t gs = agg_hfind(w, gkey);
+      if (fs >= 0) w.hkeys[fs] = HTOMB;
+      move_f = true;
+      if (gs >= 0) {
+        const uint32_t g = w.hvals[gs];
+        if (M.score(f) > M.score(g)) {
+          M.fold(g, f);
+          M.kill(f);
+          move_f = false;
+        } else {
+          M.fold(f, g);
+          M.kill(g);
+          w.hvals[gs] = f;
+        }
+      } else {
+        put_f = true;
+      }
+    }
+    // link the moved edges into a's list in traversal order: each one in front of the previous mover
+    const unsigned long long movers = __ballot(move_f);
+    const unsigned long long lower = movers & ((1ull << lane) - 1ull);
+    const int prev_lane = lower ? 63 - __builtin_clzll(lower) : lane;
+    const uint32_t prev_f = __shfl(f, prev_lane);  // every lane takes part
+    if (move_f) {
+      const uint32_t link = lower ? prev_f : head_a;
+      if (b_in_u) { M.set_eu(f, a); w.enextu[f] = link; } else { M.set_ev(f, a); w.enextv[f] = link; }
+    }
+    if (movers) head_a = __shfl(f, 63 - __builtin_clzll(movers));
+    // new entries (a, nb) -> f
+    if (put_f) {
+      uint32_t s = (uint32_t)hmix(gkey) & (w.hcap - 1);
+      bool placed = false;
+      for (uint32_t probe = 0; probe < 2 * w.hcap && !placed; ++probe) {
+        const unsigned long long k = ((volatile unsigned long long*)w.hkeys)[s];
+        if (k == HEMPTY || k == HTOMB) {
+          if (atomicCAS((unsigned long long*)&w.hkeys[s], k, (unsigned long long)gkey) == k) {
+            w.hvals[s] = f;
+            placed = true;
+          }
+          continue;  // lost the slot to another lane this instant: look at it again (it holds that lane's key now)
+        }
+        s = (s + 1) & (w.hcap - 1);
+      }
+      if (!placed) fail = true;
+    }
+    __syncthreads();  // the next chunk's look-ups see this chunk's table
+  }
+  if (lane == 0) {
+    w.head[a] = head_a;
+    const int64_t es = agg_hfind(w, agg_norm_key(eu, evv));
+    if (es >= 0) w.hkeys[es] = HTOMB;
+    M.kill(e);
+    w.parent[b] = a;
+  }
+  const bool any_fail = __any(fail);
+  __syncthreads();  // the sweep's stores are in place before lane 0 goes on
+  return !any_fail;
+}
+
+// One wave replays the sequential bin-queue merge loop and grows the merge tree: lane 0 owns the queue and the
+// decisions, the contraction of a popped edge is shared by the lanes (agg_contract_wave).
+template <bool FAST>
+__device__ __forceinline__ void rag_merge_body(const RagMem<FAST>& M, float threshold, int nbins, uint32_t nn, uint32_t ne, uint32_t* bhead,
+                                               uint32_t* btail, uint32_t* lst, int* sh) {
+  const AggWs& w = M.w;
+  const int lane = threadIdx.x;
+  int minbin = nbins;            // lane 0's
   const float scale = (float)(nbins - 1);
   auto push = [&](uint32_t e, float sc) {
     int b = (int)(sc * scale);
     b = b < 0 ? 0 : (b > nbins - 1 ? nbins - 1 : b);
-    w.qnext[e] = NOEDGE;
-    if (bhead[b] == NOEDGE) bhead[b] = e; else w.qnext[btail[b]] = e;
+    M.set_qnext(e, NOEDGE);
+    if (bhead[b] == NOEDGE) bhead[b] = e; else M.set_qnext(btail[b], e);
     btail[b] = e;
     if (b < minbin) minbin = b;
   };
-  for (uint32_t e = 0; e < ne; ++e) {
-    const float sc = agg_score(w.esum[e], w.ecnt[e]);
-    w.escore[e] = sc;
-    w.etime[e] = 0;
-    if (sc < threshold) push(e, sc);
+  // initial state and scores by all lanes, the pushes (edge order) by lane 0
+  for (uint32_t e = lane; e < ne; e += 64) {
+    if constexpr (FAST) {
+      M.set_eu(e, w.eu[e]);
+      M.set_ev(e, w.ev[e]);
+      M.fl8[e] = 0;  // rag_compact_kernel left every flag at 0
+      M.sum32[e] = (uint32_t)w.esum[e];
+      M.cnt32[e] = w.ecnt[e];
+    }
+    M.set_score(e, agg_score(M.sum(e), M.cnt(e)));
+    M.set_etime(e, 0);
   }
+  if constexpr (FAST)
+    for (uint32_t n = lane; n < nn; n += 64) M.set_ntime(n, 0);  // as rag_rank_kernel left the workspace's
+  __syncthreads();
+  if (lane == 0)
+    for (uint32_t e = 0; e < ne; ++e) {
+      const float sc = M.score(e);
+      if (sc < threshold) push(e, sc);
+    }
   // mergeRegions marks every edge incident to the survivor stale -- its own, the moved and the merged ones alike.
   // That is a clock: a merge stamps its survivor (ntime), scoring stamps the edge (etime), and an edge is stale when
   // one of its endpoints was stamped after it.
-  uint32_t nm = 0, clock = 0;
+  uint32_t nm = 0, clock = 0;    // lane 0's
   for (;;) {
-    while (minbin < nbins && bhead[minbin] == NOEDGE) ++minbin;
-    if (minbin >= nbins) break;
-    const uint32_t e = bhead[minbin];
-    bhead[minbin] = w.qnext[e];
-    if (w.eflags[e] & 1) continue;
-    const uint32_t tu = w.ntime[w.eu[e]], tv = w.ntime[w.ev[e]];
-    if (w.etime[e] < (tu > tv ? tu : tv)) {
-      const float sc = agg_score(w.esum[e], w.ecnt[e]);
-      w.escore[e] = sc;
-      w.etime[e] = clock;
-      if (sc < threshold) push(e, sc);
-      continue;
+    // lane 0: pop until an edge is due for a merge (sh[2] = the edge, NOEDGE: queue empty)
+    if (lane == 0) {
+      uint32_t pick = NOEDGE;
+      for (;;) {
+        while (minbin < nbins && bhead[minbin] == NOEDGE) ++minbin;
+        if (minbin >= nbins) break;
+        const uint32_t e = bhead[minbin];
+        bhead[minbin] = M.qnext(e);
+        if (M.dead(e)) continue;
+        const uint32_t tu = M.ntime(M.eu(e)), tv = M.ntime(M.ev(e));
+        if (M.etime(e) < (tu > tv ? tu : tv)) {
+          const float sc = agg_score(M.sum(e), M.cnt(e));
+          M.set_score(e, sc);
+          M.set_etime(e, clock);
+          if (sc < threshold) push(e, sc);
+          continue;
+        }
+        pick = e;
+        break;
+      }
+      sh[2] = (int)pick;
     }
-    const float sc = w.escore[e];
+    __syncthreads();
+    const uint32_t e = (uint32_t)sh[2];
+    if (e == NOEDGE) break;
     uint32_t a, b;
-    if (!agg_contract(w, e, a, b)) { atomicOr(&w.counters[3], 16u); break; }
-    w.ntime[a] = ++clock;
-    const uint32_t t = nn + nm;
-    w.tnext[w.cur[a]] = t;
-    w.tnext[w.cur[b]] = t;
-    w.cur[a] = t;
-    w.tnext[t] = NOEDGE;
-    w.tscore[t] = sc;
-    w.ha[nm] = a;
-    w.hb[nm] = b;
-    ++nm;
+    if (!agg_contract_wave<FAST>(M, e, lst, sh, a, b)) {
+      if (lane == 0) atomicOr(&w.counters[3], 16u);
+      break;
+    }
+    if (lane == 0) {
+      const float sc = M.score(e);
+      M.set_ntime(a, ++clock);
+      const uint32_t t = nn + nm;
+      w.tnext[w.cur[a]] = t;
+      w.tnext[w.cur[b]] = t;
+      w.cur[a] = t;
+      w.tnext[t] = NOEDGE;
+      w.tscore[t] = sc;
+      w.ha[nm] = a;
+      w.hb[nm] = b;
+      ++nm;
+    }
   }
-  w.counters[4] = nm;
+  if (lane == 0) w.counters[4] = nm;
+}
+
+__global__ __launch_bounds__(64) void rag_merge_kernel(AggWs w, float threshold, int nbins, int allow_fast) {
+  __shared__ uint32_t bhead[kMaxQueueBins], btail[kMaxQueueBins];
+  __shared__ uint32_t lst[kSweepCap];
+  __shared__ int sh[4];
+  __shared__ uint16_t l_eu[kRagFastEdges], l_ev[kRagFastEdges], l_qn[kRagFastEdges], l_et[kRagFastEdges], l_nt[kRagFastNodes];
+  __shared__ uint8_t l_fl[kRagFastEdges];
+  __shared__ uint32_t l_sum[kRagFastEdges], l_cnt[kRagFastEdges];
+  __shared__ float l_sc[kRagFastEdges];
+  if (!xcd_claim(&w.counters[5], w.xcd_hint)) return;
+  if (w.counters[3]) return;
+  for (int b = threadIdx.x; b < nbins; b += 64) bhead[b] = btail[b] = NOEDGE;
+  __syncthreads();
+  const uint32_t nn = w.counters[0];
+  const uint32_t ne = min(w.counters[1], w.edge_cap);
+  if (allow_fast && ne <= (uint32_t)kRagFastEdges && nn <= (uint32_t)kRagFastNodes) {
+    const RagMem<true> M{w, l_eu, l_ev, l_qn, l_et, l_nt, l_fl, l_sum, l_cnt, l_sc};
+    rag_merge_body<true>(M, threshold, nbins, nn, ne, bhead, btail, lst, sh);
+  } else {
+    const RagMem<false> M{w, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    rag_merge_body<false>(M, threshold, nbins, nn, ne, bhead, btail, lst, sh);
+  }
 }
 
 // score of RAG edge {u, v} = score of the lowest common ancestor in the merge tree (tree nodes
@@ -1996,6 +2191,12 @@ int bsmi_ws_fragments_seeds_u8(bsmi_seg* h, const uint8_t* affs_dev, const int64
   return BSMI_OK;
 }
 
+// BSMI_AGG_FAST=0 (tests): the general forms of the merge loops (state in the workspace's HBM arrays)
+static bool agg_fast_enabled() {
+  static const bool fast = [] { const char* e = getenv("BSMI_AGG_FAST"); return !(e && e[0] == '0'); }();
+  return fast;
+}
+
 int bsmi_agglomerate_mean_u8(bsmi_seg* h, const uint8_t* affs_dev, const uint64_t* frags_dev, const int64_t shape[3],
                              const float* thresholds_host, int n_thresholds, uint64_t* segs_dev, void* stream) {
   int rc = check_seg_shape(h, shape);
@@ -2032,8 +2233,7 @@ int bsmi_agglomerate_mean_u8(bsmi_seg* h, const uint8_t* affs_dev, const uint64_
       return hipFuncSetAttribute((const void*)agg_edge_rank_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(kRankMax * sizeof(uint64_t))) == hipSuccess;
     }();
     // BSMI_AGG_FAST=0 (tests): leave the edges unranked, i.e. take the general form of the merge loop
-    static const bool fast = [] { const char* e = getenv("BSMI_AGG_FAST"); return !(e && e[0] == '0'); }();
-    if (attr_set && fast) hipLaunchKernelGGL(agg_edge_rank_kernel, dim3(1), dim3(1024), kRankMax * sizeof(uint64_t), s, g);
+    if (attr_set && agg_fast_enabled()) hipLaunchKernelGGL(agg_edge_rank_kernel, dim3(1), dim3(1024), kRankMax * sizeof(uint64_t), s, g);
   }
   hipLaunchKernelGGL(agg_merge_kernel, dim3(8), dim3(64), 0, s, g, thr, n_thresholds);
   hipLaunchKernelGGL(agg_relabel_kernel, dim3(grid), dim3(bs), 0, s, frags_dev, n, n_thresholds, g, segs_dev);
@@ -2127,7 +2327,7 @@ static int rag_build_and_merge(bsmi_seg* h, const uint8_t* affs_dev, const uint6
   BSMI_HIP(hipcub::DeviceRadixSort::SortPairs(h->sort_tmp, tb, (const uint64_t*)g.hkeys, g.skeys, (const uint32_t*)g.iota, g.sslot,
                                               (int)g.hcap, 0, 64, s));
   hipLaunchKernelGGL(rag_compact_kernel, dim3(std::min<uint32_t>(g.hcap / bs, 2048u)), dim3(bs), 0, s, g);
-  hipLaunchKernelGGL(rag_merge_kernel, dim3(8), dim3(64), 0, s, g, threshold, discretize_queue);
+  hipLaunchKernelGGL(rag_merge_kernel, dim3(8), dim3(64), 0, s, g, threshold, discretize_queue, agg_fast_enabled() ? 1 : 0);
   return BSMI_OK;
 }
 
