@@ -106,10 +106,12 @@ def host_cores():
     return max(1, min(n, int(os.environ.get("BSMI_BENCH_CORES", "16"))))
 
 
-def job_blocks_for(steps, max_edge=8):
-    """(layers, blocks in y, blocks in x) with layers * y * x == steps: the box of blocks a rank takes.  A block can be
-    segmented once the next layer of blocks is predicted, so the cross-section y * x is kept as small as the factors allow
-    while the box still fits the volume (`max_edge` blocks per axis: 1024 / 128); the ranks stack their boxes along z."""
+def job_blocks_for(steps, world=1, max_edge=8):
+    """(layers, blocks in y, blocks in x) with layers * y * x == steps: the box of blocks a rank takes; the ranks stack their
+    boxes along z.  The whole job stays inside the volume where the factors allow (`max_edge` = 1024 / 128 blocks per axis,
+    so at most max_edge // world layers per rank: 8 ranks x 64 blocks = one layer of 8 x 8 blocks each = the 1024^3 volume);
+    among those the smallest cross-section y * x (a block can be segmented once the next layer of blocks is predicted)."""
+    max_layers = max(1, max_edge // max(1, world))
     best = None
     for gx in range(1, steps + 1):
         if steps % gx:
@@ -118,7 +120,7 @@ def job_blocks_for(steps, max_edge=8):
             if (steps // gx) % gy:
                 continue
             gz = steps // gx // gy
-            fits = gz <= max_edge and gy <= max_edge
+            fits = gz <= max_layers and gy <= max_edge
             key = (not fits, gy * gx, gy - gx)
             if best is None or key < best[0]:
                 best = (key, (gz, gy, gx))
@@ -288,7 +290,7 @@ def main():
 
     vol_shape = (args.volume,) * 3
     vol = synthetic_volume(vol_shape, seed=0, device=dev)  # the input store: every rank reads its blocks (+ halo) from it
-    job = job_blocks_for(args.steps)
+    job = job_blocks_for(args.steps, world)
 
     def barrier():
         torch.cuda.synchronize(dev)

@@ -1,4 +1,4 @@
-"""Worker of tests/test_volume_gpu.py::test_two_ranks_equal_one_rank (one process per rank, backend gloo, both on cuda:0)."""
+"""Worker of tests/test_volume_gpu.py::test_ranks_equal_one_rank (one process per rank, backend gloo, both on cuda:0)."""
 import json
 import os
 import sys
