@@ -79,6 +79,8 @@ struct PlanStep {
   ConvArgs conv;
   RhArgs rh;
   bool use_rh = false;
+  RhxArgs rhx;           // fused split-bf16 raster-halo launch (use_rhx)
+  bool use_rhx = false;
   BoxArgs box;           // conv_box.hip launch of this step (use_box)
   bool use_box = false;
   TileCfg tile;

@@ -155,6 +155,16 @@ def test_conv_kernel_variants_in_subprocess(variant, env):
     assert r.returncode == 0, f"{variant}:\n" + r.stdout[-3000:] + r.stderr[-2000:]
 
 
+def test_fused_raster_halo_kernel_in_subprocess():
+    """The fused split-bf16 raster-halo kernel (opt-in, BSMI_USE_RHX=1) takes the 60-output-channel layers of the full net:
+    the full-size parity test again with it switched on."""
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(ROOT, "tests", "test_fullsize_gpu.py"), "-x", "-q", "-s", "-k",
+                        "full_block_vs_cpu_oracle"], env=dict(os.environ, BSMI_USE_RHX="1", BSMI_PLAN_DEBUG="1"), capture_output=True, text=True,
+                       timeout=900, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    assert "fused raster-halo" in r.stderr + r.stdout
+
+
 def test_merge_loop_general_form_in_subprocess():
     """The merge loop has a FAST form for graphs that fit the LDS (every test graph does) and a general one (queue overflow
     in HBM, tie look-ups, flags in HBM): run the segmentation parity module with the FAST form switched off."""
