@@ -300,12 +300,13 @@ def main():
 
     # warm-up: `warmup` blocks through every stage (kernel images, workspaces of the block shapes, process-group channels)
     seg_kw = dict(min_seed_distance=10, filter_fragments=FILTER_FRAGMENTS, remove_debris=REMOVE_DEBRIS)
+    # (the timed pipeline's slabs are allocated first, so that nothing but the barrier lies between the warm-up and the timed region)
+    pipe = VolumePipeline(model, OUT_BLOCK, CONTEXT, job, SEG_CONTEXT, THRESHOLDS, n_lanes=args.seg_lanes, device=local_rank,
+                          rank=rank, world=world, segment=not args.no_segment, overlap=args.overlap, **seg_kw)
     warm = VolumePipeline(model, OUT_BLOCK, CONTEXT, (max(1, args.warmup), 1, 1), SEG_CONTEXT, THRESHOLDS, n_lanes=args.seg_lanes,
                           device=local_rank, rank=rank, world=world, segment=not args.no_segment, **seg_kw)
     warm.run(vol)
     del warm
-    pipe = VolumePipeline(model, OUT_BLOCK, CONTEXT, job, SEG_CONTEXT, THRESHOLDS, n_lanes=args.seg_lanes, device=local_rank,
-                          rank=rank, world=world, segment=not args.no_segment, overlap=args.overlap, **seg_kw)
     model.profile(max(1, args.profile_every))
     model.profile_totals(reset=True)
     barrier()
