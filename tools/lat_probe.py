@@ -1,5 +1,6 @@
 """Dev probe: duration of a pointer chase (memory latency) and of a dependent ALU chain (shader clock) right after a
-heavy predict phase, after idle, and in between."""
+heavy predict phase, after idle, and in between.
+Build the probe kernels first: hipcc -O2 --offload-arch=gfx950 -shared -fPIC -o ab/liblat.so tools/lat_probe.hip"""
 import ctypes as C, os, sys, time
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "24")
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
