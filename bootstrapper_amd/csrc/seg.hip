@@ -17,6 +17,8 @@
 #include <vector>
 
 #include <hipcub/hipcub.hpp>
+#include <thread>
+#include <chrono>
 
 #include "common.h"
 
@@ -2390,28 +2392,87 @@ int bsmi_lut_relabel(int device, const uint64_t* in_dev, uint64_t n, const uint6
 // Host-side union-find over the scored RAG (reference post/watershed.py:182,
 // funlib.segment.graphs.impl.connected_components [EXT]); same contract as oracle seg_connected_components:
 // score <= threshold joins, a component is named by its smallest node id, nodes ascending.
-int bsmi_connected_components(const uint64_t* nodes, uint64_t n, const uint64_t* edges, const float* scores, uint64_t m,
-                              float threshold, uint64_t* components) {
-  if ((n && (!nodes || !components)) || (m && (!edges || !scores))) BSMI_FAIL(BSMI_ERR_INVALID, "null argument");
+int bsmi_connected_components_multi(const uint64_t* nodes, uint64_t n, const uint64_t* edges, const float* scores, uint64_t m,
+                                    const float* thresholds, int n_thresholds, uint64_t* components) {
+  if ((n && (!nodes || !components)) || (m && (!edges || !scores)) || !thresholds || n_thresholds < 1)
+    BSMI_FAIL(BSMI_ERR_INVALID, "null argument");
+  if (n >= 0xffffffffull) BSMI_FAIL(BSMI_ERR_INVALID, "%llu nodes: the union-find indices are 32-bit", (unsigned long long)n);
   for (uint64_t i = 1; i < n; ++i)
     if (nodes[i] <= nodes[i - 1]) BSMI_FAIL(BSMI_ERR_INVALID, "nodes must be strictly ascending");
+  // node ids -> indices, once for all thresholds, on a few host threads (two binary searches per edge)
+  constexpr uint32_t kNone = 0xffffffffu;
+  const double t_begin = std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
+  std::vector<uint32_t> iu(m), iv(m);
+  {
+    const unsigned hw = std::max(1u, std::min(8u, std::thread::hardware_concurrency()));
+    const unsigned T = m < 200000 ? 1u : hw;
+    // two-level search: every 64th id in a table that stays in cache, then the 64 ids of one run (8 cache lines)
+    constexpr uint64_t kRun = 64;
+    std::vector<uint64_t> coarse((n + kRun - 1) / kRun);
+    for (size_t c = 0; c < coarse.size(); ++c) coarse[c] = nodes[c * kRun];
+    auto index_of = [&](uint64_t id) -> uint32_t {
+      if (!n || id < nodes[0]) return kNone;
+      const size_t c = (size_t)(std::upper_bound(coarse.begin(), coarse.end(), id) - coarse.begin()) - 1;
+      const uint64_t* lo = nodes + c * kRun;
+      const uint64_t* hi = nodes + std::min<uint64_t>(n, (c + 1) * kRun);
+      const uint64_t* p = std::lower_bound(lo, hi, id);
+      return (p != hi && *p == id) ? (uint32_t)(p - nodes) : kNone;
+    };
+    auto work = [&](uint64_t e0, uint64_t e1) {
+      for (uint64_t e = e0; e < e1; ++e) {
+        const uint32_t a = index_of(edges[2 * e]), b = index_of(edges[2 * e + 1]);
+        const bool ok = a != kNone && b != kNone;
+        iu[e] = ok ? a : kNone;
+        iv[e] = ok ? b : kNone;
+      }
+    };
+    if (T == 1) {
+      work(0, m);
+    } else {
+      std::vector<std::thread> th;
+      for (unsigned t = 0; t < T; ++t) th.emplace_back(work, m * t / T, m * (t + 1) / T);
+      for (auto& x : th) x.join();
+    }
+  }
+  const bool dbg = getenv("BSMI_CC_DEBUG") != nullptr;
+  auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+  const double t_map = now();
+  if (dbg) fprintf(stderr, "[cc] look-up of %llu edges: %.3f s\n", (unsigned long long)m, t_map - t_begin);
   std::vector<uint32_t> parent(n);
   for (uint64_t i = 0; i < n; ++i) parent[i] = (uint32_t)i;
   auto find = [&](uint32_t x) {
     while (parent[x] != x) { parent[x] = parent[parent[x]]; x = parent[x]; }
     return x;
   };
-  for (uint64_t e = 0; e < m; ++e) {
-    if (!(scores[e] <= threshold)) continue;
-    const uint64_t* pu = std::lower_bound(nodes, nodes + n, edges[2 * e]);
-    const uint64_t* pv = std::lower_bound(nodes, nodes + n, edges[2 * e + 1]);
-    if (pu == nodes + n || *pu != edges[2 * e] || pv == nodes + n || *pv != edges[2 * e + 1]) continue;
-    const uint32_t a = find((uint32_t)(pu - nodes)), b = find((uint32_t)(pv - nodes));
-    if (a == b) continue;
-    if (a < b) parent[b] = a; else parent[a] = b;
+  // thresholds in ascending order: the edges of a lower threshold are among those of a higher one, and with the smaller
+  // index as the root a component's name does not depend on the order of the unions
+  std::vector<int> order(n_thresholds);
+  for (int k = 0; k < n_thresholds; ++k) order[k] = k;
+  std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return thresholds[a] < thresholds[b]; });
+  float prev = -INFINITY;
+  bool first = true;
+  for (int k : order) {
+    const float t = thresholds[k];
+    for (uint64_t e = 0; e < m; ++e) {
+      const float sc = scores[e];
+      if (!(sc <= t) || (!first && sc <= prev) || iu[e] == kNone) continue;
+      const uint32_t a = find(iu[e]), b = find(iv[e]);
+      if (a == b) continue;
+      if (a < b) parent[b] = a; else parent[a] = b;
+    }
+    const double t_un = now();
+    uint64_t* out = components + (size_t)k * n;
+    for (uint64_t i = 0; i < n; ++i) out[i] = nodes[find((uint32_t)i)];
+    if (dbg) fprintf(stderr, "[cc] threshold %g: unions until %.3f, snapshot %.3f s\n", t, t_un - t_map, now() - t_un);
+    prev = t;
+    first = false;
   }
-  for (uint64_t i = 0; i < n; ++i) components[i] = nodes[find((uint32_t)i)];
   return BSMI_OK;
+}
+
+int bsmi_connected_components(const uint64_t* nodes, uint64_t n, const uint64_t* edges, const float* scores, uint64_t m,
+                              float threshold, uint64_t* components) {
+  return bsmi_connected_components_multi(nodes, n, edges, scores, m, &threshold, 1, components);
 }
 
 int bsmi_cc_affs_u8(bsmi_seg* h, const uint8_t* affs_dev, const int64_t shape[3], int cut, int64_t min_size, uint64_t* frags_dev,

@@ -87,6 +87,21 @@ def connected_components(nodes, edges, scores, threshold):
     return out
 
 
+def connected_components_multi(nodes, edges, scores, thresholds):
+    """connected_components for every threshold in one library call -> uint64 [len(thresholds)][len(nodes)]."""
+    import ctypes as C
+    from .._lib import lib, check
+    nodes = np.ascontiguousarray(nodes, dtype=np.uint64)
+    edges = np.ascontiguousarray(edges, dtype=np.uint64).reshape(-1, 2)
+    scores = np.ascontiguousarray(scores, dtype=np.float32)
+    thr = np.ascontiguousarray(thresholds, dtype=np.float32)
+    out = np.zeros((len(thr), len(nodes)), dtype=np.uint64)
+    check(lib.bsmi_connected_components_multi(C.c_void_p(nodes.ctypes.data), len(nodes), C.c_void_p(edges.ctypes.data),
+                                              C.c_void_p(scores.ctypes.data), len(scores), C.c_void_p(thr.ctypes.data), len(thr),
+                                              C.c_void_p(out.ctypes.data)))
+    return out
+
+
 def _fill_affinities(seg, affs, origin, z0, mask=None):
     """The slab's affinities WITH their context margins straight from the dataset (`to_ndarray(read_roi, fill_value=0)`,
     watershed_frags.py:196-201: zeros beyond the array, real data beyond the ROI), first three channels, masked."""

@@ -71,13 +71,14 @@ def exchange_faces(low_out, high_out, low_in, high_in, rank, world, group=None):
 def stitch_components(nodes, edges, scores, thresholds):
     """post/watershed.py:155-186 on the host: drop unscored edges, connected components per threshold.
     -> list of component ids aligned with `nodes` (ascending uint64)."""
-    from .post.watershed import connected_components
     keep = ~np.isnan(scores)
     edges, scores = edges[keep], scores[keep]
-    out = []
-    for t in thresholds:
-        out.append(nodes.copy() if edges.shape[0] == 0 else connected_components(nodes, edges, scores, t))
-    return out
+    if edges.shape[0] == 0:
+        return [nodes.copy() for _ in thresholds]
+    # one library call for all thresholds: the node look-up of the edges once (host threads), the unions of a lower
+    # threshold carried over to the higher ones -- this is what the other ranks wait for at 8 GPUs
+    from .post.watershed import connected_components_multi
+    return list(connected_components_multi(nodes, edges, scores, thresholds))
 
 
 def gather_and_stitch(nodes, edges, scores, thresholds, rank=0, world=1, group=None):
@@ -136,7 +137,10 @@ class SlabSegmenter:
         padded = tuple(s + 2 * c for s, c in zip(self.shape, self.ctx))
         self.affs = torch.zeros((3,) + padded, dtype=torch.uint8, device=self.dev)
         self.frags = torch.zeros(padded, dtype=torch.int64, device=self.dev)
-        self.segs = None
+        # outputs of the stitch, allocated with the slab: a first stitch that allocates them pays for it inside whatever times
+        # the pipeline (whole 1024^3 volume: 26 GB of segmentations + 8.6 GB of interior fragments, a second of hipMalloc)
+        self.segs = torch.empty((len(self.thresholds),) + self.shape, dtype=torch.int64, device=self.dev)
+        self._fr = torch.empty(self.shape, dtype=torch.int64, device=self.dev)
         K = len(self.boxes)
         read_vox = int(np.prod([min(b, s) + 2 * c for b, s, c in zip(self.block, self.shape, self.ctx)]))
         self.edge_cap = max(64, min(int(edge_cap), 3 * read_vox))
@@ -421,10 +425,9 @@ class SlabSegmenter:
                                 for n, bid in zip(self.block_nums, self.block_ids)] or [np.zeros(0, np.uint64)])
         self.nodes, self.luts = gather_and_stitch(nodes, self.rag_edges, self.rag_scores, self.thresholds, self.rank, self.world,
                                                   self.group)
-        fr = self.interior(self.frags).contiguous()
+        fr = self._fr
+        fr.copy_(self.interior(self.frags))
         keys = torch.from_numpy(self.nodes.view(np.int64)).to(self.dev)
-        if self.segs is None:
-            self.segs = torch.empty((len(self.thresholds),) + self.shape, dtype=torch.int64, device=self.dev)
         for t, comp in enumerate(self.luts):
             lut_relabel(fr, keys, torch.from_numpy(comp.view(np.int64)).to(self.dev), out=self.segs[t])
         torch.cuda.synchronize(self.dev)

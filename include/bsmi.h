@@ -299,6 +299,12 @@ int bsmi_lut_relabel(int device, const uint64_t *in_dev, uint64_t n, const uint6
  * node id of node i's component.  Edges naming unknown nodes are ignored. */
 int bsmi_connected_components(const uint64_t *nodes, uint64_t n, const uint64_t *edges,
                               const float *scores, uint64_t m, float threshold, uint64_t *components);
+/* The same for several thresholds in one pass (reference post/watershed.py:177-186 loops over the thresholds): the node
+ * look-up of the edges is done once, on a few host threads, and the unions of a lower threshold carry over to the higher
+ * ones.  components: [n_thresholds][n], row k for thresholds[k]. */
+int bsmi_connected_components_multi(const uint64_t *nodes, uint64_t n, const uint64_t *edges,
+                                    const float *scores, uint64_t m, const float *thresholds,
+                                    int n_thresholds, uint64_t *components);
 
 /* Thresholded-affinity connected components (`bs segment --cc`; reference post/cc.py:7-74 called from
  * post/connected_components.py:77-80, debris removal :97-101).  Voxel p is linked with its +z / +y / +x neighbour when
