@@ -307,6 +307,8 @@ def main():
                           device=local_rank, rank=rank, world=world, segment=not args.no_segment, **seg_kw)
     warm.run(vol)
     del warm
+    if not args.no_segment:
+        pipe.seg.prime()   # the slab-sized reductions / relabel kernels once, on the empty slab
     model.profile(max(1, args.profile_every))
     model.profile_totals(reset=True)
     barrier()

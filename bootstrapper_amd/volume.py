@@ -105,6 +105,28 @@ def gather_and_stitch(nodes, edges, scores, thresholds, rank=0, world=1, group=N
     return luts[0]
 
 
+# HIP streams of the pipelines, one set per device for the life of the process.  Every torch stream that has been used is
+# a hardware queue, and the runtime is told to keep one per stream up to GPU_MAX_HW_QUEUES (24): a second pipeline (a
+# warm-up one, say) that drew fresh streams from torch's pool pushed the count past that, streams began to share queues
+# and the predict stream ran 12 % slower from then on.
+_LANE_STREAMS = {}
+_PREDICT_STREAMS = {}
+
+
+def lane_streams(device, n):
+    pool = _LANE_STREAMS.setdefault(torch.device(device), [])
+    while len(pool) < n:
+        pool.append(torch.cuda.Stream(device))
+    return pool[:n]
+
+
+def predict_stream(device):
+    dev = torch.device(device)
+    if dev not in _PREDICT_STREAMS:
+        _PREDICT_STREAMS[dev] = torch.cuda.Stream(dev, priority=-1)
+    return _PREDICT_STREAMS[dev]
+
+
 class SlabSegmenter:
     """Fragments, RAG scoring, stitching and relabelling of one rank's slab of affinities (see the module docstring)."""
 
@@ -154,8 +176,8 @@ class SlabSegmenter:
         self.frag_done = [None] * K
         read = tuple(min(b, s) + 2 * c for b, s, c in zip(self.block, self.shape, self.ctx))
         self.lanes = []
-        for _ in range(max(1, min(int(n_lanes), K))):
-            self.lanes.append(dict(engine=SegEngine(read, self.dev.index), stream=torch.cuda.Stream(self.dev),
+        for stream in lane_streams(self.dev, max(1, min(int(n_lanes), K))):
+            self.lanes.append(dict(engine=SegEngine(read, self.dev.index), stream=stream,
                                    a=torch.empty((3,) + read, dtype=torch.uint8, device=self.dev),
                                    f=torch.empty(read, dtype=torch.int64, device=self.dev),
                                    lab=torch.empty(tuple(min(b, s) for b, s in zip(self.block, self.shape)), dtype=torch.int64,
@@ -433,6 +455,13 @@ class SlabSegmenter:
         torch.cuda.synchronize(self.dev)
         return self.segs
 
+    def prime(self):
+        """Warm-up of the slab-sized paths behind the block stages (the torch reductions of `_collect`, the gather / LUT /
+        relabel of `stitch`) on the still empty slab: their kernels are picked by tensor size, and the first use of one in a
+        process loads it (on a fresh machine from disk) -- 0.1 s that would otherwise land in the first job."""
+        self._collect()
+        return self.stitch()
+
     def run(self, ready=None, overlap=False):
         if ready is not None and not overlap:
             # Stage by stage: nothing is queued on the lanes before the last block is predicted.  Lanes parked behind a
@@ -462,7 +491,7 @@ class VolumePipeline:
         self.dev = torch.device("cuda", int(device))
         slab = tuple(g * b for g, b in zip(self.job_blocks, self.out_block))
         self.origin = (int(job_origin[0]) + self.rank * slab[0], int(job_origin[1]), int(job_origin[2]))
-        self.pred_stream = torch.cuda.Stream(self.dev, priority=-1)
+        self.pred_stream = predict_stream(self.dev)
         self.seg = SlabSegmenter(slab, self.out_block, seg_context if segment else (0, 0, 0), self.job_blocks[0] * self.world,
                                  self.job_blocks[0] * self.rank, thresholds, True, min_seed_distance, filter_fragments,
                                  remove_debris, 256, n_lanes if segment else 1, device, rank, world, group)
