@@ -370,10 +370,9 @@ def main():
                      "other_unet_ms_per_block": sum(totals[k][0] for k in ("input", "pool", "upsample", "head")) / max(args.steps, 1)},
     }
     if not args.no_segment:
-        # two figures: inside the timed region the stage starts on caches the predict stage has just filled with its own data
-        # (a dependent access then costs ~350 ns from HBM against ~80 ns from the Infinity Cache: tools/lat_probe.py), the
-        # repeated pass finds part of its working set still cached.  The first is what the pipeline pays and what the CPU
-        # ratio is taken from; with --overlap the stage is not separable and only the repeated pass is given.
+        # two figures: the stage inside the timed region (what the pipeline pays, what the CPU ratio is taken from) and the
+        # same stage repeated afterwards; they agree once the slab-sized torch paths have been used before the timed region
+        # (SlabSegmenter.prime).  With --overlap the stage is not separable and only the repeated pass is given.
         t_in = max(dt - t_pred, 1e-9) if not args.overlap else t_seg
         seg_vox_s = nvox / t_in
         out["segment_only"] = {"note": "seconds: end of the predict stage to the end of the timed region (fragments -> relabelled volumes); "
