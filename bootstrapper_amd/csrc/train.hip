@@ -210,6 +210,7 @@ struct WgradArgs {
   int N, C;            // real output / input channels of this slot
   int kz, ky, kx;      // taps of this launch (1,1,1 for the residual)
   float* dw;           // gradient of the weight [N][Cin_total][ntap]
+  float* dwt;          // split-bf16 form: tap-major workspace [ntap][N][Cin_total] (wgrad_finish_kernel adds it into dw)
   int cin_total, cbase, ntap;
   int lines_per_block;
 };
@@ -408,6 +409,314 @@ __global__ __launch_bounds__(256) void wgrad_tiled_kernel(const WgradArgs a) {
   }
 }
 
+// ---- split-bf16 weight gradient -------------------------------------------------------------------------------------
+// The same sums on the bf16 matrix pipe (16x the rate of v_mfma_f32_32x32x2_f32): every f32 operand is split on the fly
+// into hi = bf16(v), lo = bf16(v - hi) and the product is hi*hi + lo*hi + hi*lo with f32 accumulation (what
+// BSMI_PREC_BF16X3 does in the forward pass; relative error ~2^-17 per product).  v_mfma_f32_16x16x32_bf16 contracts 32
+// voxels per instruction and wants 8 consecutive K values (voxels) of one row (channel) per lane, the transpose of the
+// channels-last tensors: a thread loads 8 (+ KX - 1) voxels of ONE channel (the 64 lanes of a wave = 64 consecutive
+// channels of a voxel: 256 contiguous bytes per load), splits them and writes them as one 16-byte vector per plane into
+// channel-major LDS rows; fragments are then plain ds_read_b128.  The K = 32 slots of a chunk are 4 GROUPS of 8
+// consecutive output voxels of a line (the last group of a line padded with zeros: 19-voxel lines fill 79 % of the slots,
+// a whole-line chunk would fill 59 %); the x operand of a group carries KX - 1 more voxels, and the operand of tap t is
+// the group's vector shifted by t values (v_alignbyte for t = 1, the next dwords for t = 2).
+// A workgroup of 2 x 2 waves owns a (32 FNW) x (32 FCW) block of (n, c) for the KX taps of one (kz, ky) tap row and
+// a range of output lines; the next chunk is in flight (registers) while the current one is multiplied.
+typedef __bf16 wg_bf16x2_t __attribute__((ext_vector_type(2)));
+typedef __attribute__((__vector_size__(8 * sizeof(__bf16)))) __bf16 bf16x8_t;
+typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
+typedef float f32x4_t __attribute__((ext_vector_type(4)));
+typedef float wg_f32x2_t __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ void split_pair(float a, float b, uint32_t& hi, uint32_t& lo) {
+  const wg_bf16x2_t h = __builtin_convertvector(wg_f32x2_t{a, b}, wg_bf16x2_t);
+  hi = __builtin_bit_cast(uint32_t, h);
+  const float ha = __uint_as_float(hi << 16), hb = __uint_as_float(hi & 0xffff0000u);
+  const wg_bf16x2_t l = __builtin_convertvector(wg_f32x2_t{a - ha, b - hb}, wg_bf16x2_t);
+  lo = __builtin_bit_cast(uint32_t, l);
+}
+
+template <int KX, int FNW, int FCW>
+__global__ __launch_bounds__(256) void wgrad_x3_kernel(const WgradArgs a) {
+  constexpr int TN = 32 * FNW, TC = 32 * FCW;
+  constexpr int GROW = 80;   // bytes of a g channel row: 4 groups x 16 B, padded (16 rows x one group: 16 different bank quads)
+  constexpr int XROW = 144;  // bytes of an x channel row: 4 groups x 32 B (8 + KX - 1 values), padded likewise
+  constexpr int XV = 8 + KX - 1, XD = (XV + 1) / 2;
+  constexpr int GI = (TN * 4 + 255) / 256, XI = (TC * 4 + 255) / 256;  // (channel, group) items per thread
+  __shared__ __attribute__((aligned(16))) char gs[2][TN * GROW];  // [hi | lo]
+  __shared__ __attribute__((aligned(16))) char xs[2][TC * XROW];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lr = lane & 15, lq = lane >> 4;
+  const int wn = wave >> 1, wc = wave & 1;
+  const int nblocks_c = (a.C + TC - 1) / TC;
+  const int nt = blockIdx.x / nblocks_c, ct = blockIdx.x - nt * nblocks_c;
+  const int trow = blockIdx.y;
+  const int tz = trow / a.ky, ty = trow - tz * a.ky;
+  const int nbase = nt * TN, cbase = ct * TC;
+  bool nuse[FNW], cuse[FCW];
+#pragma unroll
+  for (int i = 0; i < FNW; ++i) nuse[i] = nbase + (wn * FNW + i) * 16 < a.N;
+#pragma unroll
+  for (int j = 0; j < FCW; ++j) cuse[j] = cbase + (wc * FCW + j) * 16 < a.C;
+  const bool nall = nuse[FNW - 1];
+  f32x4_t acc[KX][FNW][FCW];
+#pragma unroll
+  for (int t = 0; t < KX; ++t)
+#pragma unroll
+    for (int i = 0; i < FNW; ++i)
+#pragma unroll
+      for (int j = 0; j < FCW; ++j) acc[t][i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+  const int gpl = (a.Wo + 7) >> 3;  // groups per output line
+  const int nlines = a.Do * a.Ho;
+  const int l0 = blockIdx.z * a.lines_per_block, l1 = min(nlines, l0 + a.lines_per_block);
+  const int ngroups = (l1 - l0) * gpl;
+  const int nchunks = (ngroups + 3) >> 2;
+  const float* xp0 = a.x + tz * a.xsz + ty * a.xsy;
+
+  // per item: channel, and the walking position (group index within the block's range, line = (z, y), first voxel x0)
+  struct Pos { int gi, z, y, x0; };
+  auto start = [&](int grp) {
+    Pos p;
+    p.gi = grp;
+    const int line = l0 + grp / gpl;
+    p.x0 = (grp % gpl) * 8;
+    p.z = line / a.Ho;
+    p.y = line - p.z * a.Ho;
+    return p;
+  };
+  auto advance = [&](Pos& p) {  // four groups on
+    p.gi += 4;
+    p.x0 += 32;
+    while (p.x0 >= gpl * 8) {
+      p.x0 -= gpl * 8;
+      if (++p.y == a.Ho) { p.y = 0; ++p.z; }
+    }
+  };
+  Pos gpos[GI], xpos[XI];
+  int gch[GI], xch[XI];
+#pragma unroll
+  for (int v = 0; v < GI; ++v) {
+    const int item = tid + v * 256;
+    gch[v] = item % TN;
+    gpos[v] = start(item / TN);
+  }
+#pragma unroll
+  for (int v = 0; v < XI; ++v) {
+    const int item = tid + v * 256;
+    xch[v] = item % TC;
+    xpos[v] = start(item / TC);
+  }
+  // Two raw register sets: the loads of chunk ch + 2 go out while chunk ch is multiplied, and chunk ch + 1 (a whole
+  // iteration in flight by then) is split into the packed registers after the MFMAs: no load latency on the path.
+  // Past the end of the block's range (and of a line) the loads read a valid element and g becomes zero.
+  struct Raw { float g[GI][8], x[XI][XV]; int glim[GI]; };
+  auto fetch = [&](Raw& r) __attribute__((always_inline)) {
+#pragma unroll
+    for (int v = 0; v < GI; ++v) {
+      const int n = nbase + gch[v];
+      const bool ok = (TN * 4 % 256 == 0 || tid + v * 256 < TN * 4) && gpos[v].gi < ngroups && n < a.N;
+      // unconditional loads from clamped addresses, then a select: no branch per load
+      const float* gl = ok ? a.g + gpos[v].z * a.gsz + gpos[v].y * a.gsy + (long long)gpos[v].x0 * a.gsx + n : a.g;
+      const int lim = ok ? a.Wo - gpos[v].x0 : 0;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) r.g[v][e] = gl[(e < lim ? e : 0) * a.gsx];
+      r.glim[v] = lim;  // the values past it are zeroed when the chunk is split (a select here would wait for the load)
+      advance(gpos[v]);
+    }
+#pragma unroll
+    for (int v = 0; v < XI; ++v) {
+      const int c = cbase + xch[v];
+      const bool ok = (TC * 4 % 256 == 0 || tid + v * 256 < TC * 4) && xpos[v].gi < ngroups && c < a.C;
+      const float* xl = ok ? xp0 + xpos[v].z * a.xsz + xpos[v].y * a.xsy + (long long)xpos[v].x0 * a.xsx + c : a.x;
+      const int lim = ok ? a.Wo + KX - 1 - xpos[v].x0 : 0;
+#pragma unroll
+      for (int e = 0; e < XV; ++e) r.x[v][e] = xl[(e < lim ? e : 0) * a.xsx];  // slots past the line meet zeros of g: any finite value
+      advance(xpos[v]);
+    }
+  };
+  uint32_t gpk[GI][2][4], xpk[XI][2][XD];
+  auto convert = [&](const Raw& r) __attribute__((always_inline)) {
+#pragma unroll
+    for (int v = 0; v < GI; ++v)
+#pragma unroll
+      for (int d = 0; d < 4; ++d)
+        split_pair(2 * d < r.glim[v] ? r.g[v][2 * d] : 0.f, 2 * d + 1 < r.glim[v] ? r.g[v][2 * d + 1] : 0.f, gpk[v][0][d], gpk[v][1][d]);
+#pragma unroll
+    for (int v = 0; v < XI; ++v)
+#pragma unroll
+      for (int d = 0; d < XD; ++d) split_pair(r.x[v][2 * d], 2 * d + 1 < XV ? r.x[v][2 * d + 1] : 0.f, xpk[v][0][d], xpk[v][1][d]);
+  };
+  const uint32_t aoff = (uint32_t)((wn * FNW * 16 + lr) * GROW + lq * 16);
+  const uint32_t boff = (uint32_t)((wc * FCW * 16 + lr) * XROW + lq * 32);
+  // one chunk: the packed registers go to LDS, `rl` receives the loads of the chunk after next, the chunk is multiplied,
+  // `rc` (the next chunk) is split
+  auto step = [&](Raw& rl, const Raw& rc) __attribute__((always_inline)) {
+    __syncthreads();  // the previous chunk has been multiplied
+#pragma unroll
+    for (int v = 0; v < GI; ++v) {
+      const int item = tid + v * 256;
+      if (TN * 4 % 256 != 0 && item >= TN * 4) break;
+      const uint32_t o = (uint32_t)(gch[v] * GROW + (item / TN) * 16);
+#pragma unroll
+      for (int pl = 0; pl < 2; ++pl) *(u32x4_t*)(gs[pl] + o) = u32x4_t{gpk[v][pl][0], gpk[v][pl][1], gpk[v][pl][2], gpk[v][pl][3]};
+    }
+#pragma unroll
+    for (int v = 0; v < XI; ++v) {
+      const int item = tid + v * 256;
+      if (TC * 4 % 256 != 0 && item >= TC * 4) break;
+      const uint32_t o = (uint32_t)(xch[v] * XROW + (item / TC) * 32);
+#pragma unroll
+      for (int pl = 0; pl < 2; ++pl) {
+        *(u32x4_t*)(xs[pl] + o) = u32x4_t{xpk[v][pl][0], xpk[v][pl][1], xpk[v][pl][2], xpk[v][pl][3]};
+        if constexpr (XD > 4) *(uint32_t*)(xs[pl] + o + 16) = xpk[v][pl][4];
+      }
+    }
+    __syncthreads();
+#ifndef BSMI_WG_NO_LOAD
+    fetch(rl);
+#endif
+    u32x4_t ah[FNW], al[FNW];
+#pragma unroll
+    for (int i = 0; i < FNW; ++i) {
+      ah[i] = *(const u32x4_t*)(gs[0] + aoff + i * 16 * GROW);
+      al[i] = *(const u32x4_t*)(gs[1] + aoff + i * 16 * GROW);
+    }
+#pragma unroll
+    for (int j = 0; j < FCW; ++j) {
+      if (!cuse[j]) continue;
+      uint32_t d[2][5];
+#pragma unroll
+      for (int pl = 0; pl < 2; ++pl) {
+        const u32x4_t q = *(const u32x4_t*)(xs[pl] + boff + j * 16 * XROW);
+        d[pl][0] = q.x; d[pl][1] = q.y; d[pl][2] = q.z; d[pl][3] = q.w;
+        d[pl][4] = XD > 4 ? *(const uint32_t*)(xs[pl] + boff + j * 16 * XROW + 16) : 0u;
+      }
+      bf16x8_t bh[KX], bl[KX];
+#pragma unroll
+      for (int t = 0; t < KX; ++t) {
+        u32x4_t qh, ql;
+        if (t == 0) {
+          qh = u32x4_t{d[0][0], d[0][1], d[0][2], d[0][3]};
+          ql = u32x4_t{d[1][0], d[1][1], d[1][2], d[1][3]};
+        } else if (t == 1) {
+          qh = u32x4_t{__builtin_amdgcn_alignbyte(d[0][1], d[0][0], 2), __builtin_amdgcn_alignbyte(d[0][2], d[0][1], 2),
+                       __builtin_amdgcn_alignbyte(d[0][3], d[0][2], 2), __builtin_amdgcn_alignbyte(d[0][4], d[0][3], 2)};
+          ql = u32x4_t{__builtin_amdgcn_alignbyte(d[1][1], d[1][0], 2), __builtin_amdgcn_alignbyte(d[1][2], d[1][1], 2),
+                       __builtin_amdgcn_alignbyte(d[1][3], d[1][2], 2), __builtin_amdgcn_alignbyte(d[1][4], d[1][3], 2)};
+        } else {
+          qh = u32x4_t{d[0][1], d[0][2], d[0][3], d[0][4]};
+          ql = u32x4_t{d[1][1], d[1][2], d[1][3], d[1][4]};
+        }
+        bh[t] = __builtin_bit_cast(bf16x8_t, qh);
+        bl[t] = __builtin_bit_cast(bf16x8_t, ql);
+      }
+      // three products per accumulator, the accumulators of a product back to back (independent instructions)
+      // (a wave whose n fragments are all real -- every wave but those of a layer's last tile -- runs them without a branch)
+#ifdef BSMI_WG_NO_MFMA
+      if (j > 0) continue;
+#endif
+      if (nall) {
+#pragma unroll
+        for (int pr = 0; pr < 3; ++pr)
+#pragma unroll
+          for (int t = 0; t < KX; ++t)
+#pragma unroll
+            for (int i = 0; i < FNW; ++i) {
+              const bf16x8_t av = __builtin_bit_cast(bf16x8_t, pr == 1 ? al[i] : ah[i]);
+              acc[t][i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av, pr == 2 ? bl[t] : bh[t], acc[t][i][j], 0, 0, 0);
+            }
+      } else {
+#pragma unroll
+        for (int i = 0; i < FNW; ++i) {
+          if (!nuse[i]) continue;
+#pragma unroll
+          for (int pr = 0; pr < 3; ++pr)
+#pragma unroll
+            for (int t = 0; t < KX; ++t) {
+              const bf16x8_t av = __builtin_bit_cast(bf16x8_t, pr == 1 ? al[i] : ah[i]);
+              acc[t][i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av, pr == 2 ? bl[t] : bh[t], acc[t][i][j], 0, 0, 0);
+            }
+        }
+      }
+    }
+    convert(rc);
+  };
+  Raw r0, r1;
+  fetch(r0);
+  fetch(r1);
+  convert(r0);
+  for (int ch = 0; ch < nchunks; ch += 2) {
+    step(r0, r1);
+    if (ch + 1 < nchunks) step(r1, r0);
+  }
+  // acc[r]: row (n) = 4 (lane >> 4) + r, column (c) = lane & 15
+#pragma unroll
+  for (int t = 0; t < KX; ++t) {
+    const int tap = trow * KX + t;
+#pragma unroll
+    for (int i = 0; i < FNW; ++i)
+#pragma unroll
+      for (int j = 0; j < FCW; ++j) {
+#ifdef BSMI_WG_NO_EPI
+        if (i + j > 0) continue;
+#endif
+        const int c = cbase + (wc * FCW + j) * 16 + lr;
+        if (!nuse[i] || !cuse[j] || c >= a.C) continue;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int nn = nbase + (wn * FNW + i) * 16 + 4 * lq + r;
+          // tap-major: the 16 lanes of a row are 64 contiguous bytes (in the OIDHW gradient they are 4 ntap bytes apart --
+          // one cache line per lane -- and the atomics were 60 % of this kernel's time)
+          if (nn < a.N && acc[t][i][j][r] != 0.f) atomicAdd(&a.dwt[((size_t)tap * a.N + nn) * a.cin_total + a.cbase + c], acc[t][i][j][r]);
+        }
+      }
+  }
+}
+
+// dw[n][c][tap] += dwt[tap][n][c]; dwt = 0 (ready for the next step).  One thread per (n, c): reads coalesced over c, each
+// thread writes its ntap contiguous values.
+__global__ void wgrad_finish_kernel(float* __restrict__ dwt, float* __restrict__ dw, size_t nc, int ntap) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= nc) return;
+  for (int t = 0; t < ntap; ++t) {
+    const float v = dwt[(size_t)t * nc + i];
+    if (v != 0.f) {
+      dw[i * ntap + t] += v;
+      dwt[(size_t)t * nc + i] = 0.f;
+    }
+  }
+}
+
+static bool wgrad_x3_enabled() {
+  static const bool on = [] { const char* e = getenv("BSMI_WGRAD_X3"); return !e || e[0] != '0'; }();
+  return on;
+}
+
+template <int KX, int FNW, int FCW>
+static void launch_wgrad_x3_t(WgradArgs a, hipStream_t s) {
+  constexpr int TN = 32 * FNW, TC = 32 * FCW;
+  const int nlines = a.Do * a.Ho, trows = a.kz * a.ky;
+  const int blocks_nc = ((a.N + TN - 1) / TN) * ((a.C + TC - 1) / TC);
+  int zsplit = std::max(1, std::min(nlines, 2048 / std::max(1, blocks_nc * trows)));
+  a.lines_per_block = (nlines + zsplit - 1) / zsplit;
+  zsplit = (nlines + a.lines_per_block - 1) / a.lines_per_block;
+  hipLaunchKernelGGL((wgrad_x3_kernel<KX, FNW, FCW>), dim3(blocks_nc, trows, zsplit), dim3(256), 0, s, a);
+}
+
+// tile = the smallest of 32 / 64 / 128 channels that holds the layer's (or 128-wide blocks of it)
+template <int KX>
+static bool launch_wgrad_x3_k(const WgradArgs& a, hipStream_t s) {
+  const int fn = a.N <= 32 ? 1 : (a.N <= 64 ? 2 : 4), fc = a.C <= 32 ? 1 : (a.C <= 64 ? 2 : 4);
+#define BSMI_WG(FN_, FC_) \
+  if (fn == FN_ && fc == FC_) { launch_wgrad_x3_t<KX, FN_, FC_>(a, s); return true; }
+  BSMI_WG(1, 1) BSMI_WG(1, 2) BSMI_WG(1, 4) BSMI_WG(2, 1) BSMI_WG(2, 2) BSMI_WG(2, 4) BSMI_WG(4, 1) BSMI_WG(4, 2) BSMI_WG(4, 4)
+#undef BSMI_WG
+  return false;
+}
+static bool launch_wgrad_x3(const WgradArgs& a, hipStream_t s) {
+  return a.kx == 1 ? launch_wgrad_x3_k<1>(a, s) : launch_wgrad_x3_k<3>(a, s);
+}
+
 // dst[region at (oz, oy, ox)][cdst + c] += src[..][csrc + c] for c < C (gradient of crop + concat)
 __global__ void scatter_add_kernel(const float* __restrict__ src, int D, int H, int W, int Cs, int csrc, float* __restrict__ dst, int Hd, int Wd,
                                    int Cd, int cdst, int oz, int oy, int ox, int C) {
@@ -528,6 +837,7 @@ struct TrainState {
   std::map<std::string, size_t> index;
   size_t nparams = 0;
   float *w = nullptr, *g = nullptr, *m = nullptr, *v = nullptr;
+  float* gt = nullptr;  // tap-major workspace of the split-bf16 weight gradients (same offsets as g; zero between steps)
   int adam_t = 0;
   // Gradient groups: the parameters of one ConvPass / head are one contiguous range of the flat buffers (their keys share
   // a prefix and the buffers follow the sorted keys); a group's gradients are final once the backward pass has left its
@@ -913,6 +1223,7 @@ int bsmi_unet_train_begin(bsmi_unet* h, const int64_t in_shape[3]) {
   const size_t pb = ts->nparams * sizeof(float);
   if ((rc = talloc(ts.get(), (void**)&ts->w, pb, true))) return rc;
   if ((rc = talloc(ts.get(), (void**)&ts->g, pb, true))) return rc;
+  if (wgrad_x3_enabled() && (rc = talloc(ts.get(), (void**)&ts->gt, pb, true))) return rc;
   if ((rc = talloc(ts.get(), (void**)&ts->m, pb, true))) return rc;
   if ((rc = talloc(ts.get(), (void**)&ts->v, pb, true))) return rc;
   for (const ParamRef& pr : ts->params)
@@ -1121,6 +1432,14 @@ int bsmi_unet_train_forward_backward(bsmi_unet* h, const float* raw_dev, const f
         const int64_t gsx = cb.gp.Cpad, gsy = (int64_t)cb.gp.W * gsx, gsz = (int64_t)cb.gp.H * gsy;
         const float* ginterior = (const float*)cb.gp.ptr + cb.P[0] * gsz + cb.P[1] * gsy + cb.P[2] * gsx;
         const int cin_total = ci == 0 ? p.cin[0] + (p.nslots > 1 ? p.cin[1] : 0) : p.cout;
+        bool used_x3 = false;
+        auto finish = [&](float* dw, int ct, const int* kk) {  // after the launches of one weight tensor
+          if (!used_x3) return;
+          const size_t nc = (size_t)p.cout * ct;
+          hipLaunchKernelGGL(wgrad_finish_kernel, dim3((unsigned)((nc + 255) / 256)), dim3(256), 0, s, ts->gt + (dw - ts->g), dw, nc,
+                             kk[0] * kk[1] * kk[2]);
+          used_x3 = false;
+        };
         auto wgrad = [&](const TDesc& x, const int* org, int C, int cbase, float* dw, int ct, const int* kk) {
           WgradArgs a;
           a.g = ginterior; a.gsz = gsz; a.gsy = gsy; a.gsx = gsx;
@@ -1130,8 +1449,13 @@ int bsmi_unet_train_forward_backward(bsmi_unet* h, const float* raw_dev, const f
           a.N = p.cout; a.C = C;
           a.kz = kk[0]; a.ky = kk[1]; a.kx = kk[2];
           a.dw = dw; a.cin_total = ct; a.cbase = cbase; a.ntap = kk[0] * kk[1] * kk[2];
+          a.dwt = ts->gt ? ts->gt + (dw - ts->g) : nullptr;
           const int nlines = a.Do * a.Ho;
           const int trows = a.kz * a.ky;
+          if (a.dwt && (a.kx == 1 || a.kx == 3) && launch_wgrad_x3(a, s)) {
+            used_x3 = true;
+            return;
+          }
           const bool tiled = a.N > 32 && a.C > 32;  // narrow layers: the per-wave form wastes fewer MFMAs on padding
           const int blocks_nc = tiled ? ((a.N + 127) / 128) * ((a.C + 127) / 128) : ((a.N + 31) / 32) * ((a.C + 63) / 64);
           int zsplit = std::max(1, std::min(nlines, (tiled ? 2048 : 8192) / std::max(1, blocks_nc * trows)));
@@ -1164,6 +1488,7 @@ int bsmi_unet_train_forward_backward(bsmi_unet* h, const float* raw_dev, const f
         } else {
           wgrad(st.slots[0], st.so[0], p.cout, 0, dwm, cin_total, k);
         }
+        finish(dwm, cin_total, k);
         if (last) {
           int crop[3] = {0, 0, 0};
           for (int q = 0; q < n; ++q)
@@ -1179,6 +1504,7 @@ int bsmi_unet_train_forward_backward(bsmi_unet* h, const float* raw_dev, const f
             wgrad(st.slots[first_slot + sl], org, p.cin[sl], cbase, dwr, rin, ones);
             cbase += p.cin[sl];
           }
+          finish(dwr, rin, ones);
         }
         // input gradient
         if (cb.need_dgrad) {
