@@ -410,23 +410,28 @@ __global__ __launch_bounds__(256) void wgrad_tiled_kernel(const WgradArgs a) {
 }
 
 // ---- split-bf16 weight gradient -------------------------------------------------------------------------------------
-// The same sums on the bf16 matrix pipe (16x the rate of v_mfma_f32_32x32x2_f32): every f32 operand is split on the fly
-// into hi = bf16(v), lo = bf16(v - hi) and the product is hi*hi + lo*hi + hi*lo with f32 accumulation (what
-// BSMI_PREC_BF16X3 does in the forward pass; relative error ~2^-17 per product).  v_mfma_f32_16x16x32_bf16 contracts 32
-// voxels per instruction and wants 8 consecutive K values (voxels) of one row (channel) per lane, the transpose of the
-// channels-last tensors: a thread loads 8 (+ KX - 1) voxels of ONE channel (the 64 lanes of a wave = 64 consecutive
-// channels of a voxel: 256 contiguous bytes per load), splits them and writes them as one 16-byte vector per plane into
-// channel-major LDS rows; fragments are then plain ds_read_b128.  The K = 32 slots of a chunk are 4 GROUPS of 8
-// consecutive output voxels of a line (the last group of a line padded with zeros: 19-voxel lines fill 79 % of the slots,
-// a whole-line chunk would fill 59 %); the x operand of a group carries KX - 1 more voxels, and the operand of tap t is
-// the group's vector shifted by t values (v_alignbyte for t = 1, the next dwords for t = 2).
-// A workgroup of 2 x 2 waves owns a (32 FNW) x (32 FCW) block of (n, c) for the KX taps of one (kz, ky) tap row and
-// a range of output lines; the next chunk is in flight (registers) while the current one is multiplied.
+// The same sums on the bf16 matrix pipe (16x the rate of v_mfma_f32_32x32x2_f32): every f32 operand is split into
+// hi = bf16(v), lo = bf16(v - hi) and the product is hi*hi + lo*hi + hi*lo with f32 accumulation (what BSMI_PREC_BF16X3
+// does in the forward pass; relative error ~2^-17 per product).  v_mfma_f32_16x16x32_bf16 contracts 32 voxels per
+// instruction and wants 8 consecutive K values (voxels) of one row (channel) per lane -- the transpose of the channels-last
+// tensors.  So the operands are PACKED first (wgrad_pack_kernel, one elementwise pass per operand and conv stage):
+//   G[group][plane][channel][8]   group = 8 consecutive output voxels of a line (the last group of a line zero-filled),
+//                                 plane = hi | lo, channels padded to the tile; one more all-zero group at the end
+//   X[group][plane][vec][channel][8]   the 8 input voxels under the group and, in vec 1, the next 8 (KX > 1): the operand
+//                                 of kernel tap t is the group's vector shifted by t values
+// so that 64 channels of one (group, plane) are 1 KiB of contiguous memory = ONE LDS-DMA instruction, and the fragments
+// are plain 16-byte LDS reads.  (The first version split the f32 tensors inside the kernel: ~10 VALU instructions per
+// element loaded left the MFMA pipe idle 80 % of the time.)
+// A chunk = 4 groups = the K = 32 of one MFMA (19-voxel lines fill 79 % of the slots; whole-line chunks would fill 59 %).
+// A workgroup of 2 x 2 waves owns a (32 FNW) x (32 FCW) block of (n, c) for the KX taps of one (kz, ky) tap row and a
+// range of output lines; wave w stages group w of every chunk; two LDS buffers: chunk ch + 1 lands while ch is multiplied.
 typedef __bf16 wg_bf16x2_t __attribute__((ext_vector_type(2)));
 typedef __attribute__((__vector_size__(8 * sizeof(__bf16)))) __bf16 bf16x8_t;
 typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
 typedef float f32x4_t __attribute__((ext_vector_type(4)));
 typedef float wg_f32x2_t __attribute__((ext_vector_type(2)));
+typedef const __attribute__((address_space(1))) char* wg_gptr_t;
+typedef __attribute__((address_space(3))) char* wg_lptr_t;
 
 __device__ __forceinline__ void split_pair(float a, float b, uint32_t& hi, uint32_t& lo) {
   const wg_bf16x2_t h = __builtin_convertvector(wg_f32x2_t{a, b}, wg_bf16x2_t);
@@ -436,20 +441,78 @@ __device__ __forceinline__ void split_pair(float a, float b, uint32_t& hi, uint3
   lo = __builtin_bit_cast(uint32_t, l);
 }
 
+// src: f32 tensor at its first (line, voxel) with strides in floats; lines = nz x ny lines of `width` valid voxels, `gpl`
+// groups per line; dst[((group * 2 + plane) * nvec + vec) * cpad + c] = 16-byte vector of voxels 8 (xg + vec) .. + 7 of
+// channel c (zeros past `width` and past `creal`); `nullg` more all-zero groups follow.
+__global__ void wgrad_pack_kernel(const float* __restrict__ src, long long sz, long long sy, long long sx, int nz, int ny, int width, int creal,
+                                  int cpad, int gpl, int nvec, int nullg, u32x4_t* __restrict__ dst) {
+  const size_t ngroups = (size_t)nz * ny * gpl;
+  const size_t total = (ngroups + nullg) * cpad;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int c = (int)(i % cpad);
+    const size_t grp = i / cpad;
+    const int xg = (int)(grp % gpl);
+    const size_t line = grp / gpl;
+    const int y = (int)(line % ny), z = (int)(line / ny);
+    const bool ok = grp < ngroups && c < creal;
+    const float* sp = src + (ok ? z * sz + y * sy + c : 0);
+    for (int v = 0; v < nvec; ++v) {
+      u32x4_t hi, lo;
+#pragma unroll
+      for (int d = 0; d < 4; ++d) {
+        const int x0 = (xg + v) * 8 + 2 * d;
+        const float f0 = (ok && x0 < width) ? sp[x0 * sx] : 0.f;
+        const float f1 = (ok && x0 + 1 < width) ? sp[(x0 + 1) * sx] : 0.f;
+        uint32_t h, l;
+        split_pair(f0, f1, h, l);
+        hi[d] = h;
+        lo[d] = l;
+      }
+      dst[((grp * 2 + 0) * nvec + v) * cpad + c] = hi;
+      dst[((grp * 2 + 1) * nvec + v) * cpad + c] = lo;
+    }
+  }
+}
+
+struct WgradPk {
+  const char* gp;  // packed g: [ngroups + 1][2][Np][16 B]
+  const char* xp;  // packed x: [input lines * gpl][2][XVEC][Cp][16 B]
+  int Np, Cp, gpl;
+  int Do, Ho, Hil;  // output lines Do x Ho; input lines per z: Ho + ky - 1
+  int N, C;         // real channels
+  int kz, ky;
+  float* dwt;       // tap-major workspace [ntap][N][cin_total]
+  int cin_total, cbase, ntap;
+  int lines_per_block, zsplit;
+};
+
 template <int KX, int FNW, int FCW>
-__global__ __launch_bounds__(256) void wgrad_x3_kernel(const WgradArgs a) {
+__global__ __launch_bounds__(256, 2) void wgrad_x3_kernel(const WgradPk a) {
+  // (two workgroups per CU: at most 96 accumulator registers per lane.  The 128 x 128 tile's 192 did not fit beside the
+  // operands: the compiler shuttled fragments through AGPRs, 350 copies per chunk, and one wave per SIMD hid nothing)
   constexpr int TN = 32 * FNW, TC = 32 * FCW;
-  constexpr int GROW = 80;   // bytes of a g channel row: 4 groups x 16 B, padded (16 rows x one group: 16 different bank quads)
-  constexpr int XROW = 144;  // bytes of an x channel row: 4 groups x 32 B (8 + KX - 1 values), padded likewise
-  constexpr int XV = 8 + KX - 1, XD = (XV + 1) / 2;
-  constexpr int GI = (TN * 4 + 255) / 256, XI = (TC * 4 + 255) / 256;  // (channel, group) items per thread
-  __shared__ __attribute__((aligned(16))) char gs[2][TN * GROW];  // [hi | lo]
-  __shared__ __attribute__((aligned(16))) char xs[2][TC * XROW];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lr = lane & 15, lq = lane >> 4;
+  static_assert(KX * FNW * FCW * 4 <= 96, "accumulators");
+  constexpr int XVEC = KX > 1 ? 2 : 1;
+  constexpr int GBYTES = 2 * 4 * TN * 16;          // [plane][group][TN][16 B]
+  constexpr int XBYTES = 2 * XVEC * 4 * TC * 16;   // [plane][vec][group][TC][16 B]
+  constexpr int BUF = GBYTES + XBYTES;
+  extern __shared__ __attribute__((aligned(16))) char smem[];  // two buffers
+  const int tid = threadIdx.x, lane = tid & 63, lr = lane & 15, lq = lane >> 4;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wn = wave >> 1, wc = wave & 1;
+  // Workgroup -> (tile, line range, tap row), XCD-aware: consecutive workgroup ids go round-robin to the 8 XCDs, so the
+  // kz * ky tap rows of one (tile, line range) are made consecutive ON one XCD: they run together and share the tile's
+  // g vectors and (shifted by a line or two) x vectors in that XCD's L2 (id-major order sent the 9 readers of the same
+  // vectors to different XCDs at different times: 3.9 TB/s of L2 misses on the 1500 -> 1500 layer).
   const int nblocks_c = (a.C + TC - 1) / TC;
-  const int nt = blockIdx.x / nblocks_c, ct = blockIdx.x - nt * nblocks_c;
-  const int trow = blockIdx.y;
+  const int ntiles = ((a.N + TN - 1) / TN) * nblocks_c;
+  const int trows = a.kz * a.ky;
+  const int xcd = blockIdx.x & 7, seq = blockIdx.x >> 3;
+  const int trow = seq % trows;
+  const int unit = (seq / trows) * 8 + xcd;
+  if (unit >= ntiles * a.zsplit) return;  // (uniform; the grid is padded to 8 x trows)
+  const int tile = unit % ntiles, zblk = unit / ntiles;
+  const int nt = tile / nblocks_c, ct = tile - nt * nblocks_c;
   const int tz = trow / a.ky, ty = trow - tz * a.ky;
   const int nbase = nt * TN, cbase = ct * TC;
   bool nuse[FNW], cuse[FCW];
@@ -466,120 +529,70 @@ __global__ __launch_bounds__(256) void wgrad_x3_kernel(const WgradArgs a) {
 #pragma unroll
       for (int j = 0; j < FCW; ++j) acc[t][i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 
-  const int gpl = (a.Wo + 7) >> 3;  // groups per output line
+  const int gpl = a.gpl;
   const int nlines = a.Do * a.Ho;
-  const int l0 = blockIdx.z * a.lines_per_block, l1 = min(nlines, l0 + a.lines_per_block);
+  const int l0 = zblk * a.lines_per_block, l1 = min(nlines, l0 + a.lines_per_block);
   const int ngroups = (l1 - l0) * gpl;
   const int nchunks = (ngroups + 3) >> 2;
-  const float* xp0 = a.x + tz * a.xsz + ty * a.xsy;
-
-  // per item: channel, and the walking position (group index within the block's range, line = (z, y), first voxel x0)
-  struct Pos { int gi, z, y, x0; };
-  auto start = [&](int grp) {
-    Pos p;
-    p.gi = grp;
-    const int line = l0 + grp / gpl;
-    p.x0 = (grp % gpl) * 8;
-    p.z = line / a.Ho;
-    p.y = line - p.z * a.Ho;
-    return p;
-  };
-  auto advance = [&](Pos& p) {  // four groups on
-    p.gi += 4;
-    p.x0 += 32;
-    while (p.x0 >= gpl * 8) {
-      p.x0 -= gpl * 8;
-      if (++p.y == a.Ho) { p.y = 0; ++p.z; }
-    }
-  };
-  Pos gpos[GI], xpos[XI];
-  int gch[GI], xch[XI];
-#pragma unroll
-  for (int v = 0; v < GI; ++v) {
-    const int item = tid + v * 256;
-    gch[v] = item % TN;
-    gpos[v] = start(item / TN);
+  // this wave's group of the chunk being staged: index within the block's range, output line (z, y), group of the line
+  int gi = wave, pz, py, pxg;
+  {
+    const int line = l0 + wave / gpl;
+    pxg = wave % gpl;
+    pz = line / a.Ho;
+    py = line - pz * a.Ho;
   }
+  const size_t gvec = (size_t)a.Np * 16, xvec = (size_t)a.Cp * 16;  // bytes of one (group, plane[, vec]) row of all channels
+  const wg_gptr_t gsrc = (wg_gptr_t)a.gp + (size_t)(nbase + lane) * 16;
+  const wg_gptr_t xsrc = (wg_gptr_t)a.xp + (size_t)(cbase + lane) * 16;
+  const size_t gnull = (size_t)nlines * gpl;  // the all-zero group
+  auto stage = [&](int buf) __attribute__((always_inline)) {
+    const bool ok = gi < ngroups;
+    const size_t gabs = ok ? (size_t)l0 * gpl + gi : gnull;
+    const size_t xabs = ok ? ((size_t)(pz + tz) * a.Hil + (py + ty)) * gpl + pxg : 0;  // past the range: any group (g is zero)
+    const wg_lptr_t lg = (wg_lptr_t)(smem + buf * BUF);
+    const wg_lptr_t lx = (wg_lptr_t)(smem + buf * BUF + GBYTES);
 #pragma unroll
-  for (int v = 0; v < XI; ++v) {
-    const int item = tid + v * 256;
-    xch[v] = item % TC;
-    xpos[v] = start(item / TC);
-  }
-  // Two raw register sets: the loads of chunk ch + 2 go out while chunk ch is multiplied, and chunk ch + 1 (a whole
-  // iteration in flight by then) is split into the packed registers after the MFMAs: no load latency on the path.
-  // Past the end of the block's range (and of a line) the loads read a valid element and g becomes zero.
-  struct Raw { float g[GI][8], x[XI][XV]; int glim[GI]; };
-  auto fetch = [&](Raw& r) __attribute__((always_inline)) {
+    for (int pl = 0; pl < 2; ++pl) {
+      // one instruction = 64 channels of a (group, plane); a 32-channel tile uses the lower half of the lanes
 #pragma unroll
-    for (int v = 0; v < GI; ++v) {
-      const int n = nbase + gch[v];
-      const bool ok = (TN * 4 % 256 == 0 || tid + v * 256 < TN * 4) && gpos[v].gi < ngroups && n < a.N;
-      // unconditional loads from clamped addresses, then a select: no branch per load
-      const float* gl = ok ? a.g + gpos[v].z * a.gsz + gpos[v].y * a.gsy + (long long)gpos[v].x0 * a.gsx + n : a.g;
-      const int lim = ok ? a.Wo - gpos[v].x0 : 0;
+      for (int hf = 0; hf < (TN + 63) / 64; ++hf)
+        if (TN >= 64 || lane < TN)
+          __builtin_amdgcn_global_load_lds(gsrc + (gabs * 2 + pl) * gvec + hf * 1024, lg + ((pl * 4 + wave) * TN + hf * 64) * 16, 16, 0, 0);
 #pragma unroll
-      for (int e = 0; e < 8; ++e) r.g[v][e] = gl[(e < lim ? e : 0) * a.gsx];
-      r.glim[v] = lim;  // the values past it are zeroed when the chunk is split (a select here would wait for the load)
-      advance(gpos[v]);
+      for (int v = 0; v < XVEC; ++v)
+#pragma unroll
+        for (int hf = 0; hf < (TC + 63) / 64; ++hf)
+          if (TC >= 64 || lane < TC)
+            __builtin_amdgcn_global_load_lds(xsrc + ((xabs * 2 + pl) * XVEC + v) * xvec + hf * 1024,
+                                             lx + (((pl * XVEC + v) * 4 + wave) * TC + hf * 64) * 16, 16, 0, 0);
     }
-#pragma unroll
-    for (int v = 0; v < XI; ++v) {
-      const int c = cbase + xch[v];
-      const bool ok = (TC * 4 % 256 == 0 || tid + v * 256 < TC * 4) && xpos[v].gi < ngroups && c < a.C;
-      const float* xl = ok ? xp0 + xpos[v].z * a.xsz + xpos[v].y * a.xsy + (long long)xpos[v].x0 * a.xsx + c : a.x;
-      const int lim = ok ? a.Wo + KX - 1 - xpos[v].x0 : 0;
-#pragma unroll
-      for (int e = 0; e < XV; ++e) r.x[v][e] = xl[(e < lim ? e : 0) * a.xsx];  // slots past the line meet zeros of g: any finite value
-      advance(xpos[v]);
+    // four groups on
+    gi += 4;
+    pxg += 4;
+    while (pxg >= gpl) {
+      pxg -= gpl;
+      if (++py == a.Ho) { py = 0; ++pz; }
     }
   };
-  uint32_t gpk[GI][2][4], xpk[XI][2][XD];
-  auto convert = [&](const Raw& r) __attribute__((always_inline)) {
-#pragma unroll
-    for (int v = 0; v < GI; ++v)
-#pragma unroll
-      for (int d = 0; d < 4; ++d)
-        split_pair(2 * d < r.glim[v] ? r.g[v][2 * d] : 0.f, 2 * d + 1 < r.glim[v] ? r.g[v][2 * d + 1] : 0.f, gpk[v][0][d], gpk[v][1][d]);
-#pragma unroll
-    for (int v = 0; v < XI; ++v)
-#pragma unroll
-      for (int d = 0; d < XD; ++d) split_pair(r.x[v][2 * d], 2 * d + 1 < XV ? r.x[v][2 * d + 1] : 0.f, xpk[v][0][d], xpk[v][1][d]);
+  auto mfma = [](f32x4_t c, u32x4_t x, u32x4_t y) __attribute__((always_inline)) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, x), __builtin_bit_cast(bf16x8_t, y), c, 0, 0, 0);
   };
-  const uint32_t aoff = (uint32_t)((wn * FNW * 16 + lr) * GROW + lq * 16);
-  const uint32_t boff = (uint32_t)((wc * FCW * 16 + lr) * XROW + lq * 32);
-  // one chunk: the packed registers go to LDS, `rl` receives the loads of the chunk after next, the chunk is multiplied,
-  // `rc` (the next chunk) is split
-  auto step = [&](Raw& rl, const Raw& rc) __attribute__((always_inline)) {
-    __syncthreads();  // the previous chunk has been multiplied
-#pragma unroll
-    for (int v = 0; v < GI; ++v) {
-      const int item = tid + v * 256;
-      if (TN * 4 % 256 != 0 && item >= TN * 4) break;
-      const uint32_t o = (uint32_t)(gch[v] * GROW + (item / TN) * 16);
-#pragma unroll
-      for (int pl = 0; pl < 2; ++pl) *(u32x4_t*)(gs[pl] + o) = u32x4_t{gpk[v][pl][0], gpk[v][pl][1], gpk[v][pl][2], gpk[v][pl][3]};
-    }
-#pragma unroll
-    for (int v = 0; v < XI; ++v) {
-      const int item = tid + v * 256;
-      if (TC * 4 % 256 != 0 && item >= TC * 4) break;
-      const uint32_t o = (uint32_t)(xch[v] * XROW + (item / TC) * 32);
-#pragma unroll
-      for (int pl = 0; pl < 2; ++pl) {
-        *(u32x4_t*)(xs[pl] + o) = u32x4_t{xpk[v][pl][0], xpk[v][pl][1], xpk[v][pl][2], xpk[v][pl][3]};
-        if constexpr (XD > 4) *(uint32_t*)(xs[pl] + o + 16) = xpk[v][pl][4];
-      }
-    }
-    __syncthreads();
-#ifndef BSMI_WG_NO_LOAD
-    fetch(rl);
-#endif
+  const uint32_t aoff = (uint32_t)((lq * TN + wn * FNW * 16 + lr) * 16);
+  const uint32_t boff = (uint32_t)((lq * TC + wc * FCW * 16 + lr) * 16);
+  if (nchunks > 0) stage(0);
+  for (int ch = 0; ch < nchunks; ++ch) {
+    const int buf = ch & 1;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's group of chunk ch has landed
+    __syncthreads();                                  // ... everybody's has, and chunk ch - 1 has been multiplied
+    if (ch + 1 < nchunks) stage(buf ^ 1);
+    const char* gs = smem + buf * BUF;
+    const char* xs = gs + GBYTES;
     u32x4_t ah[FNW], al[FNW];
 #pragma unroll
     for (int i = 0; i < FNW; ++i) {
-      ah[i] = *(const u32x4_t*)(gs[0] + aoff + i * 16 * GROW);
-      al[i] = *(const u32x4_t*)(gs[1] + aoff + i * 16 * GROW);
+      ah[i] = *(const u32x4_t*)(gs + aoff + i * 256);
+      al[i] = *(const u32x4_t*)(gs + 4 * TN * 16 + aoff + i * 256);
     }
 #pragma unroll
     for (int j = 0; j < FCW; ++j) {
@@ -587,11 +600,12 @@ __global__ __launch_bounds__(256) void wgrad_x3_kernel(const WgradArgs a) {
       uint32_t d[2][5];
 #pragma unroll
       for (int pl = 0; pl < 2; ++pl) {
-        const u32x4_t q = *(const u32x4_t*)(xs[pl] + boff + j * 16 * XROW);
+        const char* xb = xs + pl * XVEC * 4 * TC * 16 + boff + j * 256;
+        const u32x4_t q = *(const u32x4_t*)xb;
         d[pl][0] = q.x; d[pl][1] = q.y; d[pl][2] = q.z; d[pl][3] = q.w;
-        d[pl][4] = XD > 4 ? *(const uint32_t*)(xs[pl] + boff + j * 16 * XROW + 16) : 0u;
+        d[pl][4] = XVEC > 1 ? *(const uint32_t*)(xb + 4 * TC * 16) : 0u;
       }
-      bf16x8_t bh[KX], bl[KX];
+      u32x4_t bh[KX], bl[KX];
 #pragma unroll
       for (int t = 0; t < KX; ++t) {
         u32x4_t qh, ql;
@@ -607,24 +621,18 @@ __global__ __launch_bounds__(256) void wgrad_x3_kernel(const WgradArgs a) {
           qh = u32x4_t{d[0][1], d[0][2], d[0][3], d[0][4]};
           ql = u32x4_t{d[1][1], d[1][2], d[1][3], d[1][4]};
         }
-        bh[t] = __builtin_bit_cast(bf16x8_t, qh);
-        bl[t] = __builtin_bit_cast(bf16x8_t, ql);
+        bh[t] = qh;
+        bl[t] = ql;
       }
       // three products per accumulator, the accumulators of a product back to back (independent instructions)
       // (a wave whose n fragments are all real -- every wave but those of a layer's last tile -- runs them without a branch)
-#ifdef BSMI_WG_NO_MFMA
-      if (j > 0) continue;
-#endif
       if (nall) {
 #pragma unroll
         for (int pr = 0; pr < 3; ++pr)
 #pragma unroll
           for (int t = 0; t < KX; ++t)
 #pragma unroll
-            for (int i = 0; i < FNW; ++i) {
-              const bf16x8_t av = __builtin_bit_cast(bf16x8_t, pr == 1 ? al[i] : ah[i]);
-              acc[t][i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av, pr == 2 ? bl[t] : bh[t], acc[t][i][j], 0, 0, 0);
-            }
+            for (int i = 0; i < FNW; ++i) acc[t][i][j] = mfma(acc[t][i][j], pr == 1 ? al[i] : ah[i], pr == 2 ? bl[t] : bh[t]);
       } else {
 #pragma unroll
         for (int i = 0; i < FNW; ++i) {
@@ -632,22 +640,10 @@ __global__ __launch_bounds__(256) void wgrad_x3_kernel(const WgradArgs a) {
 #pragma unroll
           for (int pr = 0; pr < 3; ++pr)
 #pragma unroll
-            for (int t = 0; t < KX; ++t) {
-              const bf16x8_t av = __builtin_bit_cast(bf16x8_t, pr == 1 ? al[i] : ah[i]);
-              acc[t][i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av, pr == 2 ? bl[t] : bh[t], acc[t][i][j], 0, 0, 0);
-            }
+            for (int t = 0; t < KX; ++t) acc[t][i][j] = mfma(acc[t][i][j], pr == 1 ? al[i] : ah[i], pr == 2 ? bl[t] : bh[t]);
         }
       }
     }
-    convert(rc);
-  };
-  Raw r0, r1;
-  fetch(r0);
-  fetch(r1);
-  convert(r0);
-  for (int ch = 0; ch < nchunks; ch += 2) {
-    step(r0, r1);
-    if (ch + 1 < nchunks) step(r1, r0);
   }
   // acc[r]: row (n) = 4 (lane >> 4) + r, column (c) = lane & 15
 #pragma unroll
@@ -657,16 +653,13 @@ __global__ __launch_bounds__(256) void wgrad_x3_kernel(const WgradArgs a) {
     for (int i = 0; i < FNW; ++i)
 #pragma unroll
       for (int j = 0; j < FCW; ++j) {
-#ifdef BSMI_WG_NO_EPI
-        if (i + j > 0) continue;
-#endif
         const int c = cbase + (wc * FCW + j) * 16 + lr;
         if (!nuse[i] || !cuse[j] || c >= a.C) continue;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const int nn = nbase + (wn * FNW + i) * 16 + 4 * lq + r;
-          // tap-major: the 16 lanes of a row are 64 contiguous bytes (in the OIDHW gradient they are 4 ntap bytes apart --
-          // one cache line per lane -- and the atomics were 60 % of this kernel's time)
+          // tap-major: the 16 lanes of a row are 64 contiguous bytes (in the OIDHW gradient they are 4 ntap bytes apart,
+          // one cache line per lane)
           if (nn < a.N && acc[t][i][j][r] != 0.f) atomicAdd(&a.dwt[((size_t)tap * a.N + nn) * a.cin_total + a.cbase + c], acc[t][i][j][r]);
         }
       }
@@ -692,29 +685,40 @@ static bool wgrad_x3_enabled() {
   return on;
 }
 
+// tile widths the launcher picks (= channel padding of the packed operands): 32 / 64 / 128 output channels x 32 / 64
+// input channels
+static int wgrad_tile_n(int n) { return n <= 32 ? 32 : (n <= 64 ? 64 : 128); }
+static int wgrad_tile_c(int c) { return c <= 32 ? 32 : 64; }
+static int wgrad_pad(int channels, int tile) { return (channels + tile - 1) / tile * tile; }
+
 template <int KX, int FNW, int FCW>
-static void launch_wgrad_x3_t(WgradArgs a, hipStream_t s) {
-  constexpr int TN = 32 * FNW, TC = 32 * FCW;
+static int launch_wgrad_x3_t(WgradPk a, hipStream_t s) {
+  constexpr int TN = 32 * FNW, TC = 32 * FCW, XVEC = KX > 1 ? 2 : 1;
+  constexpr int smem = 2 * (2 * 4 * TN * 16 + 2 * XVEC * 4 * TC * 16);
+  static bool attr = false;
+  if (!attr) {
+    BSMI_HIP(hipFuncSetAttribute((const void*)wgrad_x3_kernel<KX, FNW, FCW>, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
+    attr = true;
+  }
   const int nlines = a.Do * a.Ho, trows = a.kz * a.ky;
   const int blocks_nc = ((a.N + TN - 1) / TN) * ((a.C + TC - 1) / TC);
-  int zsplit = std::max(1, std::min(nlines, 2048 / std::max(1, blocks_nc * trows)));
+  int zsplit = std::max(1, std::min(nlines, 4096 / std::max(1, blocks_nc * trows)));
   a.lines_per_block = (nlines + zsplit - 1) / zsplit;
-  zsplit = (nlines + a.lines_per_block - 1) / a.lines_per_block;
-  hipLaunchKernelGGL((wgrad_x3_kernel<KX, FNW, FCW>), dim3(blocks_nc, trows, zsplit), dim3(256), 0, s, a);
+  a.zsplit = (nlines + a.lines_per_block - 1) / a.lines_per_block;
+  const int units = blocks_nc * a.zsplit;
+  hipLaunchKernelGGL((wgrad_x3_kernel<KX, FNW, FCW>), dim3((units + 7) / 8 * 8 * trows), dim3(256), smem, s, a);
+  return BSMI_OK;
 }
 
-// tile = the smallest of 32 / 64 / 128 channels that holds the layer's (or 128-wide blocks of it)
 template <int KX>
-static bool launch_wgrad_x3_k(const WgradArgs& a, hipStream_t s) {
-  const int fn = a.N <= 32 ? 1 : (a.N <= 64 ? 2 : 4), fc = a.C <= 32 ? 1 : (a.C <= 64 ? 2 : 4);
-#define BSMI_WG(FN_, FC_) \
-  if (fn == FN_ && fc == FC_) { launch_wgrad_x3_t<KX, FN_, FC_>(a, s); return true; }
-  BSMI_WG(1, 1) BSMI_WG(1, 2) BSMI_WG(1, 4) BSMI_WG(2, 1) BSMI_WG(2, 2) BSMI_WG(2, 4) BSMI_WG(4, 1) BSMI_WG(4, 2) BSMI_WG(4, 4)
-#undef BSMI_WG
-  return false;
-}
-static bool launch_wgrad_x3(const WgradArgs& a, hipStream_t s) {
-  return a.kx == 1 ? launch_wgrad_x3_k<1>(a, s) : launch_wgrad_x3_k<3>(a, s);
+static int launch_wgrad_x3_k(const WgradPk& a, hipStream_t s) {
+  const int fn = wgrad_tile_n(a.N) / 32, fc = wgrad_tile_c(a.C) / 32;
+  if (fn == 1 && fc == 1) return launch_wgrad_x3_t<KX, 1, 1>(a, s);
+  if (fn == 1 && fc == 2) return launch_wgrad_x3_t<KX, 1, 2>(a, s);
+  if (fn == 2 && fc == 1) return launch_wgrad_x3_t<KX, 2, 1>(a, s);
+  if (fn == 2 && fc == 2) return launch_wgrad_x3_t<KX, 2, 2>(a, s);
+  if (fn == 4 && fc == 1) return launch_wgrad_x3_t<KX, 4, 1>(a, s);
+  return launch_wgrad_x3_t<KX, 4, 2>(a, s);
 }
 
 // dst[region at (oz, oy, ox)][cdst + c] += src[..][csrc + c] for c < C (gradient of crop + concat)
@@ -838,6 +842,8 @@ struct TrainState {
   size_t nparams = 0;
   float *w = nullptr, *g = nullptr, *m = nullptr, *v = nullptr;
   float* gt = nullptr;  // tap-major workspace of the split-bf16 weight gradients (same offsets as g; zero between steps)
+  char *pk_g = nullptr, *pk_x = nullptr;  // packed operands of the split-bf16 weight gradient (grown on first use)
+  size_t pk_g_bytes = 0, pk_x_bytes = 0;
   int adam_t = 0;
   // Gradient groups: the parameters of one ConvPass / head are one contiguous range of the flat buffers (their keys share
   // a prefix and the buffers follow the sorted keys); a group's gradients are final once the backward pass has left its
@@ -871,6 +877,8 @@ void free_train_state(bsmi_unet* h) {
   for (auto& g : h->train->groups)
     if (g.ev) (void)hipEventDestroy(g.ev);
   for (void* p : h->train->allocs) (void)hipFree(p);
+  if (h->train->pk_g) (void)hipFree(h->train->pk_g);
+  if (h->train->pk_x) (void)hipFree(h->train->pk_x);
   delete h->train;
   h->train = nullptr;
 }
@@ -1432,13 +1440,49 @@ int bsmi_unet_train_forward_backward(bsmi_unet* h, const float* raw_dev, const f
         const int64_t gsx = cb.gp.Cpad, gsy = (int64_t)cb.gp.W * gsx, gsz = (int64_t)cb.gp.H * gsy;
         const float* ginterior = (const float*)cb.gp.ptr + cb.P[0] * gsz + cb.P[1] * gsy + cb.P[2] * gsx;
         const int cin_total = ci == 0 ? p.cin[0] + (p.nslots > 1 ? p.cin[1] : 0) : p.cout;
-        bool used_x3 = false;
+        bool used_x3 = false, g_packed = false;
+        int x3_rc = BSMI_OK;
         auto finish = [&](float* dw, int ct, const int* kk) {  // after the launches of one weight tensor
           if (!used_x3) return;
           const size_t nc = (size_t)p.cout * ct;
           hipLaunchKernelGGL(wgrad_finish_kernel, dim3((unsigned)((nc + 255) / 256)), dim3(256), 0, s, ts->gt + (dw - ts->g), dw, nc,
                              kk[0] * kk[1] * kk[2]);
           used_x3 = false;
+        };
+        auto grow = [&](char** buf, size_t* have, size_t need) -> int {  // first steps only
+          if (need <= *have) return BSMI_OK;
+          BSMI_HIP(hipStreamSynchronize(s));
+          if (*buf) BSMI_HIP(hipFree(*buf));
+          *buf = nullptr;
+          *have = 0;
+          BSMI_HIP(hipMalloc((void**)buf, need + 4096));
+          *have = need;
+          return BSMI_OK;
+        };
+        // split-bf16 form (wgrad_x3_kernel): pack g once per conv stage, x per launch
+        auto wgrad_x3 = [&](const WgradArgs& a) -> int {
+          const int gpl = (a.Wo + 7) / 8, nlines = a.Do * a.Ho;
+          const int Np = wgrad_pad(a.N, wgrad_tile_n(a.N)), Cp = wgrad_pad(a.C, wgrad_tile_c(a.C)), xvec = a.kx > 1 ? 2 : 1;
+          const int Dil = a.Do + a.kz - 1, Hil = a.Ho + a.ky - 1;
+          int rc2;
+          if (!g_packed) {
+            const size_t need = ((size_t)nlines * gpl + 1) * 2 * Np * 16;
+            if ((rc2 = grow(&ts->pk_g, &ts->pk_g_bytes, need))) return rc2;
+            const size_t items = ((size_t)nlines * gpl + 1) * Np;
+            hipLaunchKernelGGL(wgrad_pack_kernel, dim3((unsigned)std::min<size_t>((items + 255) / 256, 65536)), dim3(256), 0, s, a.g, a.gsz, a.gsy,
+                               a.gsx, a.Do, a.Ho, a.Wo, a.N, Np, gpl, 1, 1, (u32x4_t*)ts->pk_g);
+            g_packed = true;
+          }
+          const size_t needx = (size_t)Dil * Hil * gpl * 2 * xvec * Cp * 16;
+          if ((rc2 = grow(&ts->pk_x, &ts->pk_x_bytes, needx))) return rc2;
+          const size_t itemsx = (size_t)Dil * Hil * gpl * Cp;
+          hipLaunchKernelGGL(wgrad_pack_kernel, dim3((unsigned)std::min<size_t>((itemsx + 255) / 256, 65536)), dim3(256), 0, s, a.x, a.xsz, a.xsy, a.xsx,
+                             Dil, Hil, a.Wo + a.kx - 1, a.C, Cp, gpl, xvec, 0, (u32x4_t*)ts->pk_x);
+          WgradPk k;
+          k.gp = ts->pk_g; k.xp = ts->pk_x; k.Np = Np; k.Cp = Cp; k.gpl = gpl;
+          k.Do = a.Do; k.Ho = a.Ho; k.Hil = Hil; k.N = a.N; k.C = a.C; k.kz = a.kz; k.ky = a.ky;
+          k.dwt = a.dwt; k.cin_total = a.cin_total; k.cbase = a.cbase; k.ntap = a.ntap; k.lines_per_block = 0; k.zsplit = 1;
+          return a.kx == 1 ? launch_wgrad_x3_k<1>(k, s) : launch_wgrad_x3_k<3>(k, s);
         };
         auto wgrad = [&](const TDesc& x, const int* org, int C, int cbase, float* dw, int ct, const int* kk) {
           WgradArgs a;
@@ -1452,7 +1496,9 @@ int bsmi_unet_train_forward_backward(bsmi_unet* h, const float* raw_dev, const f
           a.dwt = ts->gt ? ts->gt + (dw - ts->g) : nullptr;
           const int nlines = a.Do * a.Ho;
           const int trows = a.kz * a.ky;
-          if (a.dwt && (a.kx == 1 || a.kx == 3) && launch_wgrad_x3(a, s)) {
+          if (a.dwt && (a.kx == 1 || a.kx == 3)) {
+            const int rc2 = wgrad_x3(a);
+            if (rc2) x3_rc = rc2;
             used_x3 = true;
             return;
           }
@@ -1489,6 +1535,7 @@ int bsmi_unet_train_forward_backward(bsmi_unet* h, const float* raw_dev, const f
           wgrad(st.slots[0], st.so[0], p.cout, 0, dwm, cin_total, k);
         }
         finish(dwm, cin_total, k);
+        if (x3_rc) return x3_rc;
         if (last) {
           int crop[3] = {0, 0, 0};
           for (int q = 0; q < n; ++q)
@@ -1505,6 +1552,7 @@ int bsmi_unet_train_forward_backward(bsmi_unet* h, const float* raw_dev, const f
             cbase += p.cin[sl];
           }
           finish(dwr, rin, ones);
+          if (x3_rc) return x3_rc;
         }
         // input gradient
         if (cb.need_dgrad) {

@@ -353,3 +353,52 @@ def test_bs_train_mtlsd_driver(tmp_path):
         assert lsds_s.shape == (10, 2, 16, 16) and lsds_s.offset == (14 * 40, 46 * 4, 46 * 4) and pa.shape == (3, 2, 16, 16)
         assert pa.dtype == np.float32 and 0 < float(pa[:].mean()) < 1
     assert not (setup / "snapshots" / "batch_3_rank_0.zarr").exists()
+
+
+_WGRAD_CHILD = r"""
+import sys, numpy as np, torch
+sys.path.insert(0, sys.argv[1])
+from bootstrapper_amd.unet import Model
+from bootstrapper_amd.training import Trainer
+from bootstrapper_amd.synth import synthetic_state_dict
+cfg = {"in_channels": 1, "num_fmaps": 12, "fmap_inc_factor": 5, "downsample_factors": [[1, 2, 2], [1, 2, 2]],
+       "kernel_size_down": [[[3, 3, 3], [3, 3, 3]]] * 3, "kernel_size_up": [[[3, 3, 3], [3, 3, 3]]] * 2, "outputs": {"3d_affs": {"dims": 6}}}
+shape = (22, 116, 116)
+sd = synthetic_state_dict(cfg, 3)
+m = Model(cfg, precision="f32").load_state_dict(sd)
+tr = Trainer(m, shape, lr=1e-4)
+g = torch.Generator().manual_seed(5)
+raw = torch.rand((1, 1) + shape, generator=g).cuda()
+out = tr.out_shape
+tg = [torch.rand((6,) + tuple(out), generator=g).cuda()]
+wt = [torch.rand((6,) + tuple(out), generator=g).cuda()]
+tr.forward_backward(raw, tg, wt)
+np.savez(sys.argv[2], **{k: tr.read(k, "grad") for k in sd if k.endswith("weight")})
+tr.close()
+"""
+
+
+def test_split_bf16_weight_gradients_match_f32_form(tmp_path):
+    """wgrad_x3_kernel (packed operands, split-bf16 MFMA, tap-major accumulation) against the f32 MFMA kernels it replaced
+    (BSMI_WGRAD_X3=0, read once per process: two child processes), on a net with 12 / 60 / 300 channels, 3-group and
+    ragged lines: every weight gradient to 2e-5 of its largest entry."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = tmp_path / "child.py"
+    script.write_text(_WGRAD_CHILD)
+    outs = {}
+    for mode in ("1", "0"):
+        path = str(tmp_path / f"g{mode}.npz")
+        env = dict(os.environ, BSMI_WGRAD_X3=mode)
+        subprocess.run([sys.executable, str(script), root, path], check=True, env=env, timeout=300)
+        outs[mode] = np.load(path)
+    assert len(outs["1"].files) >= 10
+    worst = 0.0
+    for k in outs["1"].files:
+        a, b = outs["1"][k], outs["0"][k]
+        scale = max(np.abs(b).max(), 1e-12)
+        err = np.abs(a - b).max() / scale
+        worst = max(worst, err)
+        assert err < 2e-5, (k, err, scale)
+    print("largest relative difference split-bf16 vs f32 weight gradients:", worst)
