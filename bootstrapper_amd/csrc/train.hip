@@ -33,6 +33,23 @@ typedef float f32x16_t __attribute__((ext_vector_type(16)));
 // kernels
 // ------------------------------------------------------------------------------------------------------------
 
+// ---- split-bf16 helpers (weight gradients, input gradients) ----
+typedef __bf16 wg_bf16x2_t __attribute__((ext_vector_type(2)));
+typedef __attribute__((__vector_size__(8 * sizeof(__bf16)))) __bf16 bf16x8_t;
+typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
+typedef float f32x4_t __attribute__((ext_vector_type(4)));
+typedef float wg_f32x2_t __attribute__((ext_vector_type(2)));
+typedef const __attribute__((address_space(1))) char* wg_gptr_t;
+typedef __attribute__((address_space(3))) char* wg_lptr_t;
+
+__device__ __forceinline__ void split_pair(float a, float b, uint32_t& hi, uint32_t& lo) {
+  const wg_bf16x2_t h = __builtin_convertvector(wg_f32x2_t{a, b}, wg_bf16x2_t);
+  hi = __builtin_bit_cast(uint32_t, h);
+  const float ha = __uint_as_float(hi << 16), hb = __uint_as_float(hi & 0xffff0000u);
+  const wg_bf16x2_t l = __builtin_convertvector(wg_f32x2_t{a - ha, b - hb}, wg_bf16x2_t);
+  lo = __builtin_bit_cast(uint32_t, l);
+}
+
 // one unit (8 floats of K) of a packed weight image: dst[(u / 2) * Npad + n][(u % 2) * 8 + kk] =
 // src[wbase + n * sn + (c0 + kk) * sc + tap] for n < nreal, c0 + kk < creal; zero elsewhere
 struct PackUnit {
@@ -55,6 +72,28 @@ __global__ void pack_weights_kernel(const float* __restrict__ params, const Pack
   float* d = dst + ((size_t)(u >> 1) * Npad + n) * 16 + (u & 1) * 8;
 #pragma unroll
   for (int kk = 0; kk < 8; ++kk) d[kk] = v[kk];
+}
+
+// the same for a fused split-bf16 launch: units of 16 channels, rows of 32 bf16, a hi image and a lo image (conv_igemm.h)
+__global__ void pack_weights_x3_kernel(const float* __restrict__ params, const PackUnit* __restrict__ units, int nunits, int Npad, int nreal,
+                                       uint32_t* __restrict__ hi_img, uint32_t* __restrict__ lo_img) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;  // (unit, n)
+  if (i >= (size_t)nunits * Npad) return;
+  const int u = (int)(i / Npad), n = (int)(i - (size_t)u * Npad);
+  const PackUnit pu = units[u];
+  const size_t d = (((size_t)(u >> 1) * Npad + n) * 32 + (u & 1) * 16) / 2;  // in bf16 pairs
+#pragma unroll
+  for (int kk = 0; kk < 16; kk += 2) {
+    float v0 = 0.f, v1 = 0.f;
+    if (pu.wbase >= 0 && n < nreal) {
+      if (pu.c0 + kk < pu.creal) v0 = params[pu.wbase + (long long)n * pu.sn + (long long)(pu.c0 + kk) * pu.sc + pu.tap];
+      if (pu.c0 + kk + 1 < pu.creal) v1 = params[pu.wbase + (long long)n * pu.sn + (long long)(pu.c0 + kk + 1) * pu.sc + pu.tap];
+    }
+    uint32_t h, l;
+    split_pair(v0, v1, h, l);
+    hi_img[d + kk / 2] = h;
+    lo_img[d + kk / 2] = l;
+  }
 }
 
 // bias image of a forward launch: b[n] = params[b0 + n] (+ params[b1 + n])
@@ -160,8 +199,10 @@ __global__ void head_bwd_kernel(const float* __restrict__ z, int zc, const float
 }
 
 // g = dY * [Y > 0], written into the interior of a zero-bordered tensor [D + 2pz][H + 2py][W + 2px][C]
+// `outs` (optional): the same tensor once more in the split-bf16 activation layout (conv_dev.h act_index: per 8 channels 16
+// bytes of hi = bf16(v) then 16 bytes of lo = bf16(v - hi)), the A operand of the split-bf16 input-gradient launch
 __global__ void relu_bwd_pad_kernel(const float* __restrict__ dy, const float* __restrict__ y, int D, int H, int W, int C, int pz, int py,
-                                    int px, float* __restrict__ out) {
+                                    int px, float* __restrict__ out, uint16_t* __restrict__ outs) {
   const size_t total = (size_t)D * H * W * (C / 4);
   const int Hp = H + 2 * py, Wp = W + 2 * px;
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
@@ -174,7 +215,35 @@ __global__ void relu_bwd_pad_kernel(const float* __restrict__ dy, const float* _
     const float4 g = *(const float4*)(dy + src), a = *(const float4*)(y + src);
     float4 r;
     r.x = a.x > 0.f ? g.x : 0.f; r.y = a.y > 0.f ? g.y : 0.f; r.z = a.z > 0.f ? g.z : 0.f; r.w = a.w > 0.f ? g.w : 0.f;
-    *(float4*)(out + ((((size_t)(zz + pz) * Hp + (yy + py)) * Wp + (x + px)) * C + c4 * 4)) = r;
+    const size_t row = (((size_t)(zz + pz) * Hp + (yy + py)) * Wp + (x + px)) * C;
+    *(float4*)(out + row + c4 * 4) = r;
+    if (outs) {
+      const int n = c4 * 4;
+      uint32_t h0, l0, h1, l1;
+      split_pair(r.x, r.y, h0, l0);
+      split_pair(r.z, r.w, h1, l1);
+      uint16_t* d = outs + 2 * row + ((n >> 3) << 4) + (n & 7);
+      *(uint2*)d = make_uint2(h0, h1);
+      *(uint2*)(d + 8) = make_uint2(l0, l1);
+    }
+  }
+}
+
+// f32 tensor out of a split-bf16 one (the split-bf16 input-gradient launch writes its result in the activation layout)
+__global__ void split_to_f32_kernel(const uint4* __restrict__ src, float4* __restrict__ dst, size_t ngroups8) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < ngroups8; i += (size_t)gridDim.x * blockDim.x) {
+    const uint4 h = src[2 * i], l = src[2 * i + 1];
+    float4 a, b;
+    a.x = __uint_as_float(h.x << 16) + __uint_as_float(l.x << 16);
+    a.y = __uint_as_float(h.x & 0xffff0000u) + __uint_as_float(l.x & 0xffff0000u);
+    a.z = __uint_as_float(h.y << 16) + __uint_as_float(l.y << 16);
+    a.w = __uint_as_float(h.y & 0xffff0000u) + __uint_as_float(l.y & 0xffff0000u);
+    b.x = __uint_as_float(h.z << 16) + __uint_as_float(l.z << 16);
+    b.y = __uint_as_float(h.z & 0xffff0000u) + __uint_as_float(l.z & 0xffff0000u);
+    b.z = __uint_as_float(h.w << 16) + __uint_as_float(l.w << 16);
+    b.w = __uint_as_float(h.w & 0xffff0000u) + __uint_as_float(l.w & 0xffff0000u);
+    dst[2 * i] = a;
+    dst[2 * i + 1] = b;
   }
 }
 
@@ -425,22 +494,6 @@ __global__ __launch_bounds__(256) void wgrad_tiled_kernel(const WgradArgs a) {
 // A chunk = 4 groups = the K = 32 of one MFMA (19-voxel lines fill 79 % of the slots; whole-line chunks would fill 59 %).
 // A workgroup of 2 x 2 waves owns a (32 FNW) x (32 FCW) block of (n, c) for the KX taps of one (kz, ky) tap row and a
 // range of output lines; wave w stages group w of every chunk; two LDS buffers: chunk ch + 1 lands while ch is multiplied.
-typedef __bf16 wg_bf16x2_t __attribute__((ext_vector_type(2)));
-typedef __attribute__((__vector_size__(8 * sizeof(__bf16)))) __bf16 bf16x8_t;
-typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
-typedef float f32x4_t __attribute__((ext_vector_type(4)));
-typedef float wg_f32x2_t __attribute__((ext_vector_type(2)));
-typedef const __attribute__((address_space(1))) char* wg_gptr_t;
-typedef __attribute__((address_space(3))) char* wg_lptr_t;
-
-__device__ __forceinline__ void split_pair(float a, float b, uint32_t& hi, uint32_t& lo) {
-  const wg_bf16x2_t h = __builtin_convertvector(wg_f32x2_t{a, b}, wg_bf16x2_t);
-  hi = __builtin_bit_cast(uint32_t, h);
-  const float ha = __uint_as_float(hi << 16), hb = __uint_as_float(hi & 0xffff0000u);
-  const wg_bf16x2_t l = __builtin_convertvector(wg_f32x2_t{a - ha, b - hb}, wg_bf16x2_t);
-  lo = __builtin_bit_cast(uint32_t, l);
-}
-
 // src: f32 tensor at its first (line, voxel) with strides in floats; lines = nz x ny lines of `width` valid voxels, `gpl`
 // groups per line; dst[((group * 2 + plane) * nvec + vec) * cpad + c] = 16-byte vector of voxels 8 (xg + vec) .. + 7 of
 // channel c (zeros past `width` and past `creal`); `nullg` more all-zero groups follow.
@@ -680,6 +733,10 @@ __global__ void wgrad_finish_kernel(float* __restrict__ dwt, float* __restrict__
   }
 }
 
+static bool dgrad_x3_enabled() {  // input gradients as fused split-bf16 launches (8-wave kernels)
+  static const bool on = [] { const char* e = getenv("BSMI_DGRAD_X3"); return (!e || e[0] != '0') && two_waves_per_simd(); }();
+  return on;
+}
 static bool wgrad_x3_enabled() {
   static const bool on = [] { const char* e = getenv("BSMI_WGRAD_X3"); return !e || e[0] != '0'; }();
   return on;
@@ -818,6 +875,7 @@ struct PackJob {  // one packed weight image that must follow the parameters
   PackUnit* units = nullptr;  // device
   int nunits = 0, Npad = 0, nreal = 0;
   float* dst = nullptr;
+  uint32_t *dst_hi = nullptr, *dst_lo = nullptr;  // fused split-bf16 image instead (units of 16 channels)
   // bias image (forward launches only)
   long long b0 = -1, b1 = -1;
   float* bias_dst = nullptr;
@@ -827,6 +885,8 @@ struct ConvBwd {  // backward data of one CONV plan step
   const PlanStep* st = nullptr;
   int P[3] = {0, 0, 0};  // border of the padded gradient
   TDesc gp;              // padded gradient [D + 2P][H + 2P][W + 2P][Cpad]
+  void* gps = nullptr;   // the same in the split-bf16 activation layout (input gradients as split-bf16 launches), or null
+  void* dsplit = nullptr;  // result of the split-bf16 input-gradient launch before split_to_f32_kernel
   bool need_dgrad = false;
   ConvArgs dgrad{};      // implicit-GEMM launch of the input gradient
   TileCfg dtile = TILE_256x32;
@@ -957,8 +1017,12 @@ static int make_forward_job(bsmi_unet* h, TrainState* ts, PassSite& p, int ci) {
 static int run_pack_jobs(TrainState* ts, hipStream_t s) {
   for (const PackJob& j : ts->jobs) {
     const size_t total = (size_t)j.nunits * j.Npad;
-    hipLaunchKernelGGL(pack_weights_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, (const float*)ts->w, (const PackUnit*)j.units,
-                       j.nunits, j.Npad, j.nreal, j.dst);
+    if (j.dst_hi)
+      hipLaunchKernelGGL(pack_weights_x3_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, (const float*)ts->w,
+                         (const PackUnit*)j.units, j.nunits, j.Npad, j.nreal, j.dst_hi, j.dst_lo);
+    else
+      hipLaunchKernelGGL(pack_weights_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, (const float*)ts->w, (const PackUnit*)j.units,
+                         j.nunits, j.Npad, j.nreal, j.dst);
     if (j.bias_dst)
       hipLaunchKernelGGL(pack_bias_kernel, dim3((j.Npad + 255) / 256), dim3(256), 0, s, (const float*)ts->w, j.b0, j.b1, j.nreal, j.Npad, j.bias_dst);
   }
@@ -975,7 +1039,8 @@ static int make_dgrad(bsmi_unet* h, TrainState* ts, ConvBwd& cb, const ConvBwd* 
   const int* k = p.k[ci];
   const int ntap = k[0] * k[1] * k[2];
   const int cin_total = ci == 0 ? p.cin[0] + (p.nslots > 1 ? p.cin[1] : 0) : p.cout;
-  const int SUB = 8;
+  const bool x3 = cb.gps != nullptr;  // split-bf16 launch: units of 16 channels, K-steps of 32
+  const int SUB = x3 ? 16 : 8;
   const std::string base = p.prefix + ".conv_pass." + std::to_string(2 * ci);
   const size_t wm = param_off(ts, base + ".weight"), wr = param_off(ts, p.prefix + ".residual.0.weight");
   int crop[3] = {0, 0, 0};
@@ -1070,8 +1135,9 @@ static int make_dgrad(bsmi_unet* h, TrainState* ts, ConvBwd& cb, const ConvBwd* 
   }
   cb.dcat = out;
   // packed weights + K-steps on the device
-  float* wdev = nullptr;
-  rc = talloc(ts, (void**)&wdev, (steps.size() * (size_t)Npad + kWeightRowSlack) * 16 * sizeof(float), true);
+  float* wdev = nullptr;  // f32: rows of 16 floats; split-bf16: rows of 32 bf16, hi image then lo image (the same 64 bytes per row)
+  const size_t wimg = (steps.size() * (size_t)Npad + kWeightRowSlack) * 16 * sizeof(float);
+  rc = talloc(ts, (void**)&wdev, wimg * (x3 ? 2 : 1), true);
   if (rc) return rc;
   KStep* dks = nullptr;
   rc = talloc(ts, (void**)&dks, steps.size() * sizeof(KStep), false);
@@ -1084,14 +1150,20 @@ static int make_dgrad(bsmi_unet* h, TrainState* ts, ConvBwd& cb, const ConvBwd* 
   job.Npad = Npad;
   job.nreal = cin_total;
   job.dst = wdev;
+  if (x3) {
+    job.dst_hi = (uint32_t*)wdev;
+    job.dst_lo = (uint32_t*)((char*)wdev + wimg);
+  }
   ts->jobs.push_back(job);
   if (Npad > 2048) BSMI_FAIL(BSMI_ERR_INVALID, "dgrad launch wider than the zero-bias buffer");
+  if (x3 && with_res && !last_cb->gps) BSMI_FAIL(BSMI_ERR_STATE, "training plan: the residual source has no split copy");
   ConvArgs& a = cb.dgrad;
   memset(&a, 0, sizeof a);
   const TDesc* srcs[kMaxConvTensors] = {&g0, with_res ? &last_cb->gp : &g0, &g0};
+  const void* sptr[kMaxConvTensors] = {cb.gps, with_res ? last_cb->gps : cb.gps, cb.gps};
   for (int sl = 0; sl < kMaxConvTensors; ++sl) {
     const TDesc& t = *srcs[sl];
-    a.t[sl].base = (uint64_t)(uintptr_t)t.ptr;
+    a.t[sl].base = (uint64_t)(uintptr_t)(x3 ? sptr[sl] : t.ptr);  // (the split layout keeps 4 bytes per channel: same strides)
     a.t[sl].sz = (int32_t)((int64_t)t.H * t.W * t.Cpad * es);
     a.t[sl].sy = (int32_t)((int64_t)t.W * t.Cpad * es);
     a.t[sl].sx = (int32_t)((int64_t)t.Cpad * es);
@@ -1101,6 +1173,13 @@ static int make_dgrad(bsmi_unet* h, TrainState* ts, ConvBwd& cb, const ConvBwd* 
   a.w = wdev;
   a.bias = ts->zero_bias;
   a.out = out.ptr;
+  if (x3) {
+    a.w_lo = (const char*)wdev + wimg;
+    const size_t obytes = (size_t)out.D * out.H * out.W * out.Cpad * sizeof(float);
+    rc = talloc(ts, &cb.dsplit, obytes, true);
+    if (rc) return rc;
+    a.out = cb.dsplit;
+  }
   a.Do = out.D; a.Ho = out.H; a.Wo = out.W; a.Co = out.Cpad;
   a.M = out.D * out.H * out.W;
   a.Npad = Npad;
@@ -1275,6 +1354,7 @@ int bsmi_unet_train_begin(bsmi_unet* h, const int64_t in_shape[3]) {
     const size_t bytes = (size_t)cb.gp.D * cb.gp.H * cb.gp.W * cb.gp.Cpad * sizeof(float);
     const size_t slack = (size_t)8 * cb.gp.W * cb.gp.Cpad * sizeof(float) + 4096;
     if ((rc = talloc(ts.get(), &cb.gp.ptr, bytes + slack, true))) return rc;
+    if (dgrad_x3_enabled() && (rc = talloc(ts.get(), &cb.gps, bytes + slack, true))) return rc;
     TDesc gy;
     if ((rc = grad_tensor(ts.get(), st.out, &gy))) return rc;
     cb.need_dgrad = !(first_conv && st.ci == 0);
@@ -1426,7 +1506,8 @@ int bsmi_unet_train_forward_backward(bsmi_unet* h, const float* raw_dev, const f
         TDesc gy = ts->grad_of[st.out.ptr];
         const size_t total4 = (size_t)st.out.D * st.out.H * st.out.W * (st.out.Cpad / 4);
         hipLaunchKernelGGL(relu_bwd_pad_kernel, dim3((unsigned)std::min<size_t>((total4 + 255) / 256, 16384)), dim3(256), 0, s, (const float*)gy.ptr,
-                           (const float*)st.out.ptr, st.out.D, st.out.H, st.out.W, st.out.Cpad, cb.P[0], cb.P[1], cb.P[2], (float*)cb.gp.ptr);
+                           (const float*)st.out.ptr, st.out.D, st.out.H, st.out.W, st.out.Cpad, cb.P[0], cb.P[1], cb.P[2], (float*)cb.gp.ptr,
+                           (uint16_t*)cb.gps);
         const std::string base = p.prefix + ".conv_pass." + std::to_string(2 * ci);
         float* gb = ts->g + param_off(ts, base + ".bias");
         float* gbr = last ? ts->g + param_off(ts, p.prefix + ".residual.0.bias") : nullptr;
@@ -1556,8 +1637,13 @@ int bsmi_unet_train_forward_backward(bsmi_unet* h, const float* raw_dev, const f
         }
         // input gradient
         if (cb.need_dgrad) {
-          rc = launch_conv_igemm(cb.dgrad, BSMI_PREC_F32, cb.dtile, s, h->sk_ws, h->sk_grid);
+          rc = launch_conv_igemm(cb.dgrad, cb.dsplit ? BSMI_PREC_BF16X3 : BSMI_PREC_F32, cb.dtile, s, h->sk_ws, h->sk_grid);
           if (rc) return rc;
+          if (cb.dsplit) {
+            const size_t g8 = (size_t)cb.dcat.D * cb.dcat.H * cb.dcat.W * cb.dcat.Cpad / 8;
+            hipLaunchKernelGGL(split_to_f32_kernel, dim3((unsigned)std::min<size_t>((g8 + 255) / 256, 16384)), dim3(256), 0, s,
+                               (const uint4*)cb.dsplit, (float4*)cb.dcat.ptr, g8);
+          }
           if (cb.scatter) {
             int cbase = 0;
             for (int sl = 0; sl < p.nslots; ++sl) {
