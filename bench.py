@@ -80,7 +80,8 @@ SQ_PROFILES = {"bf16x3": os.path.join(ROOT, "profiles", "r02_conv_sq_pmc_bf16x3.
                "bf16": os.path.join(ROOT, "profiles", "r01_g_conv_sq_pmc.json")}
 
 
-TRAIN_PEAK = 3.0 / (2.0 / 157.3 + 3.0 / 2500.0)  # TFLOP/s, see run_train
+TRAIN_PEAK_F32 = 3.0 / (2.0 / 157.3 + 3.0 / 2500.0)  # TFLOP/s: `--train-arithmetic f32` (forward, input gradients on the f32 pipe)
+X3_PEAK = 2500.0 / 3.0
 
 
 def pmc_mfma_busy(precision):
@@ -189,48 +190,68 @@ def train_main(args):
     from bootstrapper_amd.training import Trainer
     from bootstrapper_amd.synth import synthetic_state_dict
     shape = (32, 196, 196)
-    model = Model(NET_CONFIG, device=local_rank, precision="f32").load_state_dict(synthetic_state_dict(NET_CONFIG, 0))
-    tr = Trainer(model, shape)
-    g = torch.Generator(device=dev).manual_seed(rank)
-    out = (6,) + tuple(tr.out_shape)
-    batch = {"raw": torch.rand(shape, generator=g, device=dev) * 2 - 1,
-             "gt_affs": (torch.rand(out, generator=g, device=dev) > 0.5).float(),
-             "affs_weights": torch.rand(out, generator=g, device=dev)}
 
     def barrier():
         torch.cuda.synchronize(dev)
         if world > 1:
             dist.barrier()
-    for _ in range(args.warmup):
-        tr.training_step(batch)
-    barrier()
-    t0 = time.perf_counter()
-    loss = 0.0
-    for _ in range(args.steps):
-        loss = tr.training_step(batch)
-    barrier()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
-    fwd = model.flops(shape)
+
+    def run(arithmetic, steps, warmup):
+        """ms per step, last loss and the worst gradient entry (relative) against `ref` gradients if given"""
+        model = Model(NET_CONFIG, device=local_rank, precision="f32").load_state_dict(synthetic_state_dict(NET_CONFIG, 0))
+        tr = Trainer(model, shape, arithmetic=arithmetic)
+        g = torch.Generator(device=dev).manual_seed(rank)
+        out = (6,) + tuple(tr.out_shape)
+        batch = {"raw": torch.rand(shape, generator=g, device=dev) * 2 - 1,
+                 "gt_affs": (torch.rand(out, generator=g, device=dev) > 0.5).float(),
+                 "affs_weights": torch.rand(out, generator=g, device=dev)}
+        tr.forward_backward(batch["raw"], [batch["gt_affs"]], [batch["affs_weights"]])
+        grads = tr.grads.clone()  # of the first step, before any update: what the two arithmetics are compared on
+        for _ in range(warmup):
+            tr.training_step(batch)
+        barrier()
+        t0 = time.perf_counter()
+        loss = 0.0
+        for _ in range(steps):
+            loss = tr.training_step(batch)
+        barrier()
+        dt = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([dt], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+        fwd = model.flops(shape)
+        tr.close()
+        return dt, loss, grads, fwd
+
+    dt, loss, grads, fwd = run(args.train_arithmetic, args.steps, args.warmup)
     step_flops = 3.0 * fwd  # forward + input gradients + weight gradients
     achieved = step_flops * args.steps / dt / 1e12
-    out_json = {"metric": "training samples/s, 3d_affs U-Net fp32 (weight gradients split-bf16), (32,196,196) blocks, batch 1 per GPU", "value": world * args.steps / dt,
+    split = args.train_arithmetic == "split-bf16"
+    # split-bf16: every convolution of the step spends three bf16 MFMAs per product (2500 / 3 TFLOP/s); f32: forward and
+    # input gradients on the f32 matrix pipe (157.3), the weight gradients as split-bf16 all the same
+    peak = X3_PEAK if split else TRAIN_PEAK_F32
+    other = None
+    if rank == 0 and world == 1:  # the other arithmetic beside it: speed, and how far the two sets of gradients are apart
+        o_arith = "f32" if split else "split-bf16"
+        o_dt, o_loss, o_grads, _ = run(o_arith, max(2, args.steps // 2), 1)
+        err = float((grads - o_grads).abs().max() / o_grads.abs().max())
+        other = {"arithmetic": o_arith, "ms_per_step": o_dt / max(2, args.steps // 2) * 1e3, "last_loss": o_loss,
+                 "max_gradient_difference_rel": err, "note": "first-step gradients of the two arithmetics, largest entry difference / largest entry"}
+    out_json = {"metric": "training samples/s, 3d_affs U-Net (fp32 tensors, loss, gradients, Adam; convolutions in %s arithmetic), "
+                          "(32,196,196) blocks, batch 1 per GPU" % args.train_arithmetic, "value": world * args.steps / dt,
                 "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
-                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-                "config": {"workload": "3d_affs U-Net (94.7M params) forward + WeightedMSELoss + backward + Adam, fp32, block (32,196,196) -> "
-                                       "(6,4,104,104), flat-gradient all-reduce over RCCL for N > 1", "last_loss": loss},
-                # two thirds of the flops (forward, input gradients) run on the f32 matrix pipe (157.3 TFLOP/s), the weight gradients
-                # as split-bf16 (three bf16 MFMAs per product: 2500 / 3 TFLOP/s): peak = the rate of a step with both at their peaks
-                "roofline": {"bound": "mfma", "achieved": achieved, "peak": TRAIN_PEAK, "unit": "TFLOP/s", "frac": achieved / TRAIN_PEAK, "traffic": None,
-                             "kernel": "whole step: conv_igemm f32 MFMA (forward, input gradients) + wgrad_x3_kernel (weight gradients, split-bf16 MFMA)",
-                             "peak_note": "3 / (2 / 157.3 + 1 / (2500 / 3)) TFLOP/s; against the f32 pipe alone: %.3f" % (achieved / 157.3),
-                             "algorithmic_tflop_per_step": step_flops / 1e12}}
+                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16x3" if split else "f32", "data": "synthetic",
+                "config": {"workload": "3d_affs U-Net (94.7M params) forward + WeightedMSELoss + backward + Adam, block (32,196,196) -> "
+                                       "(6,4,104,104), gradient groups all-reduced over RCCL during the backward pass for N > 1",
+                           "arithmetic": args.train_arithmetic, "last_loss": loss},
+                "roofline": {"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak, "traffic": None,
+                             "kernel": "whole step: conv_igemm (forward, input gradients) + wgrad_x3_kernel (weight gradients)",
+                             "peak_note": "split-bf16: 2500 / 3 TFLOP/s (three bf16 MFMAs per product); f32: 3 / (2 / 157.3 + 3 / 2500)",
+                             "algorithmic_tflop_per_step": step_flops / 1e12},
+                "other_arithmetic": other}
     if rank == 0:
         print(json.dumps(out_json), flush=True)
-    tr.close()
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
@@ -240,6 +261,8 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--mode", default="predict", choices=["predict", "train"],
                     help="predict = the headline predict + segment benchmark; train = training-step samples/s (secondary)")
+    ap.add_argument("--train-arithmetic", default="split-bf16", choices=["split-bf16", "f32"],
+                    help="--mode train: split-bf16 (default; convolutions as bf16 hi + lo products) or f32 (exact f32 MFMA)")
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=64,
                     help="128^3 blocks per GPU in the timed region: a box of blocks of the 1024^3 volume, the ranks' boxes stacked along z")

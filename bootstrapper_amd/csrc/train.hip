@@ -229,6 +229,20 @@ __global__ void relu_bwd_pad_kernel(const float* __restrict__ dy, const float* _
   }
 }
 
+// split-bf16 copy of an f32 tensor (groups of 8 channels: 16 bytes of hi, 16 bytes of lo)
+__global__ void f32_to_split_kernel(const float4* __restrict__ src, uint4* __restrict__ dst, size_t ngroups8) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < ngroups8; i += (size_t)gridDim.x * blockDim.x) {
+    const float4 a = src[2 * i], b = src[2 * i + 1];
+    uint4 h, l;
+    split_pair(a.x, a.y, h.x, l.x);
+    split_pair(a.z, a.w, h.y, l.y);
+    split_pair(b.x, b.y, h.z, l.z);
+    split_pair(b.z, b.w, h.w, l.w);
+    dst[2 * i] = h;
+    dst[2 * i + 1] = l;
+  }
+}
+
 // f32 tensor out of a split-bf16 one (the split-bf16 input-gradient launch writes its result in the activation layout)
 __global__ void split_to_f32_kernel(const uint4* __restrict__ src, float4* __restrict__ dst, size_t ngroups8) {
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < ngroups8; i += (size_t)gridDim.x * blockDim.x) {
@@ -733,14 +747,15 @@ __global__ void wgrad_finish_kernel(float* __restrict__ dwt, float* __restrict__
   }
 }
 
-static bool dgrad_x3_enabled() {  // input gradients as fused split-bf16 launches (8-wave kernels)
-  static const bool on = [] { const char* e = getenv("BSMI_DGRAD_X3"); return (!e || e[0] != '0') && two_waves_per_simd(); }();
-  return on;
+// Which convolutions of the step run as split-bf16 launches: all of them under bsmi_unet_train_set_arithmetic(h, 1)
+// (the default); BSMI_WGRAD_X3 / BSMI_DGRAD_X3 / BSMI_FWD_X3 = 0 take single ones back to f32 (dev knobs, read at begin).
+static bool env_on(const char* name) {
+  const char* e = getenv(name);
+  return !e || e[0] != '0';
 }
-static bool wgrad_x3_enabled() {
-  static const bool on = [] { const char* e = getenv("BSMI_WGRAD_X3"); return !e || e[0] != '0'; }();
-  return on;
-}
+static bool wgrad_x3_enabled(const bsmi_unet* h) { return h->train_split && env_on("BSMI_WGRAD_X3"); }
+static bool dgrad_x3_enabled(const bsmi_unet* h) { return h->train_split && env_on("BSMI_DGRAD_X3") && two_waves_per_simd(); }
+static bool fwd_x3_enabled(const bsmi_unet* h) { return h->train_split && env_on("BSMI_FWD_X3") && two_waves_per_simd(); }
 
 // tile widths the launcher picks (= channel padding of the packed operands): 32 / 64 / 128 output channels x 32 / 64
 // input channels
@@ -894,7 +909,23 @@ struct ConvBwd {  // backward data of one CONV plan step
   bool scatter = false;
 };
 
+}  // namespace bsmi
+// (declared in unet_internal.h at namespace bsmi scope as PlanStep::tx3's type)
+namespace bsmi {
+struct TrainFwdX3 {  // a forward CONV step as a fused split-bf16 launch
+  ConvArgs a{};
+  TileCfg tile = TILE_256x32;
+  int nconv_src = 0;
+  const void* src_f32[kMaxConvTensors] = {nullptr, nullptr, nullptr};  // sources to split before the launch (null: a split copy exists)
+  void* src_split[kMaxConvTensors] = {nullptr, nullptr, nullptr};
+  size_t src_g8[kMaxConvTensors] = {0, 0, 0};
+  void* out_split = nullptr;  // the launch's result, turned into the step's f32 output tensor afterwards
+  size_t out_g8 = 0;
+};
+
 struct TrainState {
+  std::vector<std::unique_ptr<TrainFwdX3>> fwd_x3;
+  std::map<const void*, void*> split_of;  // f32 activation -> its split copy written by an earlier launch of the forward pass
   int64_t in_shape[3] = {0, 0, 0};
   Plan* plan = nullptr;
   std::vector<ParamRef> params;
@@ -934,6 +965,8 @@ static int talloc(TrainState* ts, void** p, size_t bytes, bool zero) {
 
 void free_train_state(bsmi_unet* h) {
   if (!h->train) return;
+  if (h->train->plan)
+    for (PlanStep& st : h->train->plan->steps) st.tx3 = nullptr;
   for (auto& g : h->train->groups)
     if (g.ev) (void)hipEventDestroy(g.ev);
   for (void* p : h->train->allocs) (void)hipFree(p);
@@ -1032,6 +1065,138 @@ static int run_pack_jobs(TrainState* ts, hipStream_t s) {
 
 // input-gradient launch of conv stage `ci` of pass p (see the file header).  For ci >= 1 the output is the gradient
 // of the previous stage's activation; for ci == 0 it is `dcat`, the gradient of the (cropped, concatenated) pass input.
+// The forward launch of a gather-form CONV step once more as a fused split-bf16 launch (conv_igemm.hip conv_x3_body): the
+// same unit list at 16 channels per unit, K-steps over split copies of the sources (4 bytes per channel like the f32
+// tensors: the strides and offsets are the f32 plan's), hi / lo weight images repacked from the parameters every step,
+// the bias image of the f32 launch.  The result lands in a split tensor -- the next convolution's source as it is -- and
+// is converted to the step's f32 output, which everything else (pooling, upsampling, the backward pass) reads.
+static int make_forward_x3(bsmi_unet* h, TrainState* ts, PlanStep& st) {
+  if (st.use_rh || st.use_rhx || st.use_box) return BSMI_OK;  // raster-halo / box launches stay f32
+  PassSite& p = *st.site;
+  const int ci = st.ci;
+  const PackedConv& pf = p.packed[BSMI_PREC_F32][ci];
+  std::vector<PackEntry> ents;
+  build_entries(p, ci, BSMI_PREC_BF16X3, ents);
+  const bool last = ci == p.nconv - 1;
+  (void)last;
+  const std::string base = p.prefix + ".conv_pass." + std::to_string(2 * ci);
+  const size_t wm = param_off(ts, base + ".weight"), wr = param_off(ts, p.prefix + ".residual.0.weight");
+  const HostWeight& hm = h->weights[base + ".weight"];
+  const HostWeight& hr = h->weights[p.prefix + ".residual.0.weight"];
+  const int64_t cin_m = hm.shape[1], ntap = hm.shape[2] * hm.shape[3] * hm.shape[4], cin_r = hr.shape[1];
+  std::vector<PackUnit> units(ents.size());
+  for (size_t u = 0; u < ents.size(); ++u) {
+    const PackEntry& e = ents[u];
+    PackUnit pu{};
+    if (e.dummy) {
+      pu.wbase = -1;
+    } else if (e.wsrc == 0) {
+      pu.wbase = (long long)wm + (long long)e.cin_base * ntap;
+      pu.sn = (int)(cin_m * ntap); pu.sc = (int)ntap; pu.tap = e.tap;
+    } else {
+      pu.wbase = (long long)wr + e.cin_base;
+      pu.sn = (int)cin_r; pu.sc = 1; pu.tap = 0;
+    }
+    pu.c0 = e.c0;
+    pu.creal = e.creal;
+    units[u] = pu;
+  }
+  const size_t nsteps = ents.size() / kUnitsPerStep;
+  std::vector<KStep> ks(nsteps);
+  const int64_t es = 4;
+  for (size_t s = 0; s < nsteps; ++s) {
+    const int slot = ents[kUnitsPerStep * s].slot;
+    const TDesc& t = st.slots[slot];
+    KStep k;
+    memset(&k, 0, sizeof k);
+    k.tensor = slot;
+    for (int j = 0; j < kUnitsPerStep; ++j) {
+      const PackEntry& e = ents[kUnitsPerStep * s + j];
+      if (e.dummy) continue;
+      const int64_t off = ((((int64_t)(e.dz + st.so[slot][0]) * t.H) + (e.dy + st.so[slot][1])) * t.W + (e.dx + st.so[slot][2])) * t.Cpad + e.c0;
+      k.delta[j] = (int32_t)(off * es);
+    }
+    ks[s] = k;
+  }
+  std::unique_ptr<TrainFwdX3> fx(new TrainFwdX3());
+  fx->tile = pf.tile;
+  int rc;
+  const size_t wimg = (nsteps * (size_t)pf.Npad + kWeightRowSlack) * kStepRowBytes;
+  char* wdev = nullptr;
+  if ((rc = talloc(ts, (void**)&wdev, 2 * wimg, true))) return rc;
+  KStep* dks = nullptr;
+  if ((rc = talloc(ts, (void**)&dks, ks.size() * sizeof(KStep), false))) return rc;
+  BSMI_HIP(hipMemcpy(dks, ks.data(), ks.size() * sizeof(KStep), hipMemcpyHostToDevice));
+  PackJob job;
+  if ((rc = upload_units(ts, units, &job.units))) return rc;
+  job.nunits = (int)units.size();
+  job.Npad = pf.Npad;
+  job.nreal = p.cout;
+  job.dst = (float*)wdev;
+  job.dst_hi = (uint32_t*)wdev;
+  job.dst_lo = (uint32_t*)(wdev + wimg);
+  ts->jobs.push_back(job);
+  ConvArgs& a = fx->a;
+  memset(&a, 0, sizeof a);
+  for (int sl = 0; sl < kMaxConvTensors; ++sl) {
+    const int q = sl < st.nsl ? sl : 0;
+    const TDesc& t = st.slots[q];
+    void* sp = nullptr;
+    if (sl < st.nsl) {
+      auto it = ts->split_of.find(t.ptr);
+      const size_t bytes = (size_t)t.D * t.H * t.W * t.Cpad * sizeof(float);
+      if (it != ts->split_of.end()) {
+        sp = it->second;
+      } else {
+        const size_t slack = (size_t)8 * t.W * t.Cpad * sizeof(float) + 4096;
+        if ((rc = talloc(ts, &sp, bytes + slack, true))) return rc;
+        fx->src_f32[sl] = t.ptr;
+        fx->src_g8[sl] = bytes / 32;
+        ts->split_of[t.ptr] = sp;  // a later launch of the same source (the residual's) finds it split already
+      }
+      fx->src_split[sl] = sp;
+    } else {
+      sp = fx->src_split[0];
+    }
+    a.t[sl].base = (uint64_t)(uintptr_t)sp;
+    a.t[sl].sz = (int32_t)((int64_t)t.H * t.W * t.Cpad * es);
+    a.t[sl].sy = (int32_t)((int64_t)t.W * t.Cpad * es);
+    a.t[sl].sx = (int32_t)((int64_t)t.Cpad * es);
+  }
+  fx->nconv_src = st.nsl;
+  const size_t obytes = (size_t)st.out.D * st.out.H * st.out.W * st.out.Cpad * sizeof(float);
+  const size_t oslack = (size_t)8 * st.out.W * st.out.Cpad * sizeof(float) + 4096;
+  if ((rc = talloc(ts, &fx->out_split, obytes + oslack, true))) return rc;
+  fx->out_g8 = obytes / 32;
+  ts->split_of[st.out.ptr] = fx->out_split;
+  a.steps = dks;
+  a.nsteps = (int)ks.size();
+  a.w = wdev;
+  a.w_lo = wdev + wimg;
+  a.bias = pf.bias;
+  a.out = fx->out_split;
+  a.Do = st.out.D; a.Ho = st.out.H; a.Wo = st.out.W; a.Co = st.out.Cpad;
+  a.M = st.out.D * st.out.H * st.out.W;
+  a.Npad = pf.Npad;
+  a.relu = 1;
+  st.tx3 = fx.get();
+  ts->fwd_x3.push_back(std::move(fx));
+  return BSMI_OK;
+}
+
+int train_forward_conv_x3(bsmi_unet* h, const PlanStep& st, hipStream_t s) {
+  const TrainFwdX3& fx = *st.tx3;
+  for (int sl = 0; sl < fx.nconv_src; ++sl)
+    if (fx.src_f32[sl])
+      hipLaunchKernelGGL(f32_to_split_kernel, dim3((unsigned)std::min<size_t>((fx.src_g8[sl] + 255) / 256, 16384)), dim3(256), 0, s,
+                         (const float4*)fx.src_f32[sl], (uint4*)fx.src_split[sl], fx.src_g8[sl]);
+  const int rc = launch_conv_igemm(fx.a, BSMI_PREC_BF16X3, fx.tile, s, h->sk_ws, h->sk_grid);
+  if (rc) return rc;
+  hipLaunchKernelGGL(split_to_f32_kernel, dim3((unsigned)std::min<size_t>((fx.out_g8 + 255) / 256, 16384)), dim3(256), 0, s,
+                     (const uint4*)fx.out_split, (float4*)st.out.ptr, fx.out_g8);
+  return BSMI_OK;
+}
+
 static int make_dgrad(bsmi_unet* h, TrainState* ts, ConvBwd& cb, const ConvBwd* last_cb) {
   const PlanStep& st = *cb.st;
   PassSite& p = *st.site;
@@ -1287,6 +1452,13 @@ __global__ void balance_kernel(const float* __restrict__ affs, float* __restrict
 
 extern "C" {
 
+int bsmi_unet_train_set_arithmetic(bsmi_unet* h, int split_bf16) {
+  if (!h) BSMI_FAIL(BSMI_ERR_INVALID, "null handle");
+  if (h->train) BSMI_FAIL(BSMI_ERR_STATE, "bsmi_unet_train_set_arithmetic: call before bsmi_unet_train_begin");
+  h->train_split = split_bf16 ? 1 : 0;
+  return BSMI_OK;
+}
+
 int bsmi_unet_train_begin(bsmi_unet* h, const int64_t in_shape[3]) {
   if (!h || !in_shape) BSMI_FAIL(BSMI_ERR_INVALID, "null argument");
   if (!h->finalized[BSMI_PREC_F32]) BSMI_FAIL(BSMI_ERR_STATE, "bsmi_unet_finalize(BSMI_PREC_F32) first: training runs in fp32");
@@ -1310,7 +1482,7 @@ int bsmi_unet_train_begin(bsmi_unet* h, const int64_t in_shape[3]) {
   const size_t pb = ts->nparams * sizeof(float);
   if ((rc = talloc(ts.get(), (void**)&ts->w, pb, true))) return rc;
   if ((rc = talloc(ts.get(), (void**)&ts->g, pb, true))) return rc;
-  if (wgrad_x3_enabled() && (rc = talloc(ts.get(), (void**)&ts->gt, pb, true))) return rc;
+  if (wgrad_x3_enabled(h) && (rc = talloc(ts.get(), (void**)&ts->gt, pb, true))) return rc;
   if ((rc = talloc(ts.get(), (void**)&ts->m, pb, true))) return rc;
   if ((rc = talloc(ts.get(), (void**)&ts->v, pb, true))) return rc;
   for (const ParamRef& pr : ts->params)
@@ -1334,6 +1506,12 @@ int bsmi_unet_train_begin(bsmi_unet* h, const int64_t in_shape[3]) {
       for (int ci = 0; ci < p.nconv; ++ci)
         if ((rc = make_forward_job(h, ts.get(), p, ci))) return rc;
 
+  if (fwd_x3_enabled(h))
+    for (size_t i = 0; i < plan.steps.size(); ++i) {
+      if (plan.steps[i].type != PlanStep::CONV || (plan.fused_first && i < 3)) continue;
+      if ((rc = make_forward_x3(h, ts.get(), plan.steps[i]))) return rc;
+    }
+
   // backward data of the conv steps, in plan order; the first CONV step of the plan is the net's first conv
   ts->convs.resize(plan.steps.size());
   bool first_conv = true;
@@ -1354,7 +1532,7 @@ int bsmi_unet_train_begin(bsmi_unet* h, const int64_t in_shape[3]) {
     const size_t bytes = (size_t)cb.gp.D * cb.gp.H * cb.gp.W * cb.gp.Cpad * sizeof(float);
     const size_t slack = (size_t)8 * cb.gp.W * cb.gp.Cpad * sizeof(float) + 4096;
     if ((rc = talloc(ts.get(), &cb.gp.ptr, bytes + slack, true))) return rc;
-    if (dgrad_x3_enabled() && (rc = talloc(ts.get(), &cb.gps, bytes + slack, true))) return rc;
+    if (dgrad_x3_enabled(h) && (rc = talloc(ts.get(), &cb.gps, bytes + slack, true))) return rc;
     TDesc gy;
     if ((rc = grad_tensor(ts.get(), st.out, &gy))) return rc;
     cb.need_dgrad = !(first_conv && st.ci == 0);
@@ -1448,7 +1626,9 @@ int bsmi_unet_train_forward_backward(bsmi_unet* h, const float* raw_dev, const f
   Plan& plan = *ts->plan;
   const int nheads = (int)h->heads.size();
   // forward (the inference engine), sigmoid outputs kept for the loss
+  h->train_forward = true;  // CONV steps with a split-bf16 form run it (PlanStep::tx3)
   int rc = bsmi_unet_forward(h, BSMI_PREC_F32, raw_dev, BSMI_RAW_F32, ts->in_shape, ts->head_out.data(), nullptr, stream);
+  h->train_forward = false;
   if (rc) return rc;
   // clear gradients
   BSMI_HIP(hipMemsetAsync(ts->g, 0, ts->nparams * sizeof(float), s));

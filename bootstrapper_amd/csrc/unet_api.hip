@@ -1254,7 +1254,8 @@ int bsmi_unet_forward(bsmi_unet* h, int precision, const void* raw_dev, int raw_
                                (size_t)st.out.D * st.out.H * st.out.W, s);
         break;
       case PlanStep::CONV:
-        rc = st.use_box ? launch_conv_box(st.box, s)
+        rc = (st.tx3 && h->train_forward) ? train_forward_conv_x3(h, st, s)
+             : st.use_box ? launch_conv_box(st.box, s)
              : st.use_rhx ? launch_conv_rh_x3(st.rhx, s)
              : st.use_rh ? launch_conv_rh(st.rh, precision, st.tile, s, h->sk_ws, h->sk_grid)
                          : launch_conv_igemm(st.conv, precision, st.tile, s, h->sk_ws, h->sk_grid);

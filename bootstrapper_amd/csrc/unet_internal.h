@@ -94,6 +94,9 @@ struct PlanStep {
   TDesc slots[kMaxConvTensors];      // source tensors of the launch
   int so[kMaxConvTensors][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}};  // their origins (voxels)
   int nsl = 0;
+  // training (train.hip): this launch as a fused split-bf16 one over split copies of its f32 sources; used only while
+  // bsmi_unet::train_forward is set, so the f32 inference mode of the same plan stays exact f32
+  struct TrainFwdX3* tx3 = nullptr;
 };
 
 struct Plan {
@@ -146,6 +149,8 @@ struct bsmi_unet {
   int sk_grid = 0;         // 0: not set up yet, -1: disabled
   int sk_request = -1;     // bsmi_unet_set_persistent_grid: -1 = CU count of the device, 0 = off
   bsmi::TrainState* train = nullptr;  // train.hip
+  bool train_forward = false;         // the forward pass of a training step is running (PlanStep::tx3)
+  int train_split = 1;                // bsmi_unet_train_set_arithmetic
   bsmi::FirstPassWeights first_pass;     // first_pass.hip: weights of the fused first ConvPass (bf16 mode)
   bsmi::FirstPassWeights first_pass_x3;  // ... and of the split-bf16 mode
 };
@@ -154,4 +159,5 @@ namespace bsmi {
 // the cached launch plan of (precision, input shape); built on first use
 int get_plan(bsmi_unet* h, int precision, const int64_t in_shape[3], Plan** out);
 void free_train_state(bsmi_unet* h);
+int train_forward_conv_x3(bsmi_unet* h, const PlanStep& st, hipStream_t s);  // train.hip
 }  // namespace bsmi

@@ -117,7 +117,12 @@ int bsmi_unet_forward(bsmi_unet *h, int precision, const void *raw_dev, int raw_
  * adam_step: torch.optim.Adam semantics (no weight decay); grad_scale multiplies the gradients first (1/world_size
  *   after a summing all-reduce); the packed weight images of all launches are rewritten from the new parameters.
  * read_param: what = 0 parameter, 1 gradient, 2 / 3 Adam moments -> host.  end: frees the training state; the trained
- *   parameters stay the handle's weights (re-finalize BSMI_PREC_BF16 before predicting in bf16). */
+ *   parameters stay the handle's weights (re-finalize BSMI_PREC_BF16 before predicting in bf16).
+ * set_arithmetic (before begin): 1 (default) = the convolutions of the step -- forward, input gradients, weight gradients --
+ *   multiply as split-bf16 (every f32 operand = bf16 hi + bf16 lo, hi*hi + lo*hi + hi*lo accumulated in f32: 2^-17
+ *   relative per product, what BSMI_PREC_BF16X3 is to inference) while every tensor, the loss, the gradient buffer and
+ *   Adam stay fp32; 0 = exact f32 MFMA throughout (half the speed). */
+int bsmi_unet_train_set_arithmetic(bsmi_unet *h, int split_bf16);
 int bsmi_unet_train_begin(bsmi_unet *h, const int64_t in_shape[3]);
 int bsmi_unet_train_forward_backward(bsmi_unet *h, const float *raw_dev, const float *const *targets_dev,
                                      const float *const *weights_dev, float *loss_host, void *stream);

@@ -17,15 +17,23 @@ def _net_config(meta):
             "kernel_size_up": [[[3, 3, 3], [3, 3, 3]]] * 3, "outputs": outs}
 
 
+@pytest.mark.parametrize("arithmetic", ["f32", "split-bf16"])
 @pytest.mark.parametrize("tag", ["affs_f4i2", "affs_f3i3_lr1e-2", "mtlsd_f4i2"])
-def test_training_step_vs_reference_goldens(golden_dir, tag):
+def test_training_step_vs_reference_goldens(golden_dir, tag, arithmetic):
+    """arithmetic "f32": exact f32 MFMA, the reference's own arithmetic.  "split-bf16" (the default of Trainer): the
+    convolutions multiply bf16 hi + lo pairs (2^-17 per product): same loss to 1e-5, gradients to 1e-2 of the largest
+    entry.  Measured per component (tools/probe_train_err.py): weight gradients 3e-6, input gradients 1e-5, forward 2e-5 on two
+    of these nets and 4.6e-3 on the third -- one activation of a 16-channel, few-voxel layer within 1e-5 of zero changes sides
+    of the ReLU, and with it the bias gradient by that voxel's share.  f32: 1e-4, measured 3e-6; the parameters after an Adam step get a wider band, because Adam divides every gradient entry by its own
+    magnitude: an entry near eps = 1e-8 turns an absolute error of 1e-9 into a tenth of a step."""
     from bootstrapper_amd.unet import Model
     from bootstrapper_amd.training import Trainer
+    grad_tol, step_tol = (1e-4, 5e-2) if arithmetic == "f32" else (1e-2, 0.3)
     d = np.load(os.path.join(golden_dir, f"train_{tag}.npz"))
     meta = json.loads(bytes(d["config"]).decode())
     sd = {k[3:]: d[k] for k in d.files if k.startswith("w0:")}
     m = Model(_net_config(meta), precision="f32").load_state_dict(sd)
-    tr = Trainer(m, meta["in_shape"], lr=meta["lr"])
+    tr = Trainer(m, meta["in_shape"], lr=meta["lr"], arithmetic=arithmetic)
     nh = len(m.heads)
     raw = torch.from_numpy(d["x"]).cuda()
     targets = [torch.from_numpy(d[f"gt{i}"][0]).cuda() for i in range(nh)]
@@ -42,12 +50,12 @@ def test_training_step_vs_reference_goldens(golden_dir, tag):
                 got = tr.read(k, "grad")
                 err = np.abs(got - ref).max() / max(1e-6, np.abs(ref).max())
                 worst.append((err, k))
-                assert err < 1e-3, (k, err, np.abs(ref).max())
+                assert err < grad_tol, (k, err, np.abs(ref).max())
         tr.optimizer_step()
         for k in sd:
             ref = d[f"w{step + 1}:" + k].ravel()
             got = tr.read(k, "param")
-            assert np.abs(got - ref).max() <= 1e-5 * max(1.0, np.abs(ref).max()) + meta["lr"] * 5e-2, (step, k)
+            assert np.abs(got - ref).max() <= 1e-5 * max(1.0, np.abs(ref).max()) + meta["lr"] * step_tol, (step, k)
     print("largest relative gradient error:", max(worst))
     tr.close()
 
@@ -198,26 +206,32 @@ def test_full_net_training_step_vs_cpu_oracle():
     from tests.test_lib_cpu import AFFS_NET_CONFIG as NC
     sd = synthetic_state_dict(NC, 0)
     shape = (32, 196, 196)
-    m = Model(NC, precision="f32").load_state_dict(sd)
-    tr = Trainer(m, shape)
     rng = np.random.default_rng(0)
     x = (rng.random(shape, dtype=np.float32) * 2 - 1).astype(np.float32)
-    out = (6,) + tuple(tr.out_shape)
-    gt = (rng.random(out) > 0.5).astype(np.float32)
-    w = rng.random(out).astype(np.float32)
-    w[rng.random(out) < 0.2] = 0
-    loss = tr.forward_backward(torch.from_numpy(x).cuda(), [torch.from_numpy(gt).cuda()], [torch.from_numpy(w).cuda()])
-    torch.set_num_threads(min(16, os.cpu_count() or 1))
-    ref_loss, ref_grads, _ = T.loss_and_grads(R.default_cfg(12, 5), sd, x, [gt[None]], [w[None]], ["affs_head"])
-    assert abs(loss - ref_loss) < 1e-5 * max(1.0, abs(ref_loss)), (loss, ref_loss)
-    worst = (0.0, "")
-    for k, ref in ref_grads.items():
-        got = tr.read(k, "grad").reshape(ref.shape)
-        err = float(np.abs(got - ref).max() / max(1e-12, np.abs(ref).max()))
-        worst = max(worst, (err, k))
-        assert err < 2e-3, (k, err)
-    print("full net: loss", loss, "largest relative gradient error", worst)
-    tr.close()
+    ref_loss = ref_grads = None
+    # exact f32 first (2e-3: the oracle's own autograd differs from it by 2.4e-4), then the default split-bf16 arithmetic
+    for arithmetic, tol in (("f32", 2e-3), ("split-bf16", 5e-3)):
+        m = Model(NC, precision="f32").load_state_dict(sd)
+        tr = Trainer(m, shape, arithmetic=arithmetic)
+        out = (6,) + tuple(tr.out_shape)
+        if ref_grads is None:
+            gt = (rng.random(out) > 0.5).astype(np.float32)
+            w = rng.random(out).astype(np.float32)
+            w[rng.random(out) < 0.2] = 0
+        loss = tr.forward_backward(torch.from_numpy(x).cuda(), [torch.from_numpy(gt).cuda()], [torch.from_numpy(w).cuda()])
+        if ref_grads is None:
+            torch.set_num_threads(min(16, os.cpu_count() or 1))
+            ref_loss, ref_grads, _ = T.loss_and_grads(R.default_cfg(12, 5), sd, x, [gt[None]], [w[None]], ["affs_head"])
+        assert abs(loss - ref_loss) < 1e-5 * max(1.0, abs(ref_loss)), (arithmetic, loss, ref_loss)
+        worst = (0.0, "")
+        for k, ref in ref_grads.items():
+            got = tr.read(k, "grad").reshape(ref.shape)
+            err = float(np.abs(got - ref).max() / max(1e-12, np.abs(ref).max()))
+            worst = max(worst, (err, k))
+            assert err < tol, (arithmetic, k, err)
+        print(f"full net, {arithmetic}: loss", loss, "largest relative gradient error", worst)
+        tr.close()
+        del m
 
 
 @pytest.mark.parametrize("tag", ["2d_mtlsd_f4i2", "from_2d_mtlsd_f3i2", "3d_lsd_f4i2"])
