@@ -24,11 +24,12 @@ def test_training_step_vs_reference_goldens(golden_dir, tag, arithmetic):
     convolutions multiply bf16 hi + lo pairs (2^-17 per product): same loss to 1e-5, gradients to 1e-2 of the largest
     entry.  Measured per component (tools/probe_train_err.py): weight gradients 3e-6, input gradients 1e-5, forward 2e-5 on two
     of these nets and 4.6e-3 on the third -- one activation of a 16-channel, few-voxel layer within 1e-5 of zero changes sides
-    of the ReLU, and with it the bias gradient by that voxel's share.  f32: 1e-4, measured 3e-6; the parameters after an Adam step get a wider band, because Adam divides every gradient entry by its own
-    magnitude: an entry near eps = 1e-8 turns an absolute error of 1e-9 into a tenth of a step."""
+    of the ReLU, and with it the bias gradient by that voxel's share.  f32: 1e-4, measured 3e-6; the parameters after the Adam steps may differ by two steps (2 lr): the first Adam steps move every
+    entry by about lr in the direction of its sign, whatever its magnitude, so an entry within the gradient error of zero may
+    go the other way (f32: a twentieth of a step)."""
     from bootstrapper_amd.unet import Model
     from bootstrapper_amd.training import Trainer
-    grad_tol, step_tol = (1e-4, 5e-2) if arithmetic == "f32" else (1e-2, 0.3)
+    grad_tol, step_tol = (1e-4, 5e-2) if arithmetic == "f32" else (1e-2, 2.1)
     d = np.load(os.path.join(golden_dir, f"train_{tag}.npz"))
     meta = json.loads(bytes(d["config"]).decode())
     sd = {k[3:]: d[k] for k in d.files if k.startswith("w0:")}
