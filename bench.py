@@ -232,7 +232,7 @@ def train_main(args):
     # input gradients on the f32 matrix pipe (157.3), the weight gradients as split-bf16 all the same
     peak = X3_PEAK if split else TRAIN_PEAK_F32
     other = None
-    if rank == 0 and world == 1:  # the other arithmetic beside it: speed, and how far the two sets of gradients are apart
+    if rank == 0 and world == 1 and not args.no_modes:  # the other arithmetic beside it: speed, and how far the two sets of gradients are apart
         o_arith = "f32" if split else "split-bf16"
         o_dt, o_loss, o_grads, _ = run(o_arith, max(2, args.steps // 2), 1)
         err = float((grads - o_grads).abs().max() / o_grads.abs().max())
