@@ -274,13 +274,20 @@ __global__ void colsum_kernel(const float* __restrict__ g, int D, int H, int W, 
   const int lanes = blockDim.x / Cc;  // voxels handled side by side
   if ((int)threadIdx.x >= lanes * Cc) return;
   const int c = c0 + (int)threadIdx.x % Cc;
-  const size_t nvox = (size_t)D * H * W;
+  // one line of the interior per lane group and trip: no division per element (64-bit ones cost more than the load)
+  const int nrows = D * H;
   float acc = 0.f;
-  for (size_t v = (size_t)blockIdx.x * lanes + threadIdx.x / Cc; v < nvox; v += (size_t)gridDim.x * lanes) {
-    const int x = (int)(v % W);
-    const size_t zy = v / W;
-    const int yy = (int)(zy % H), zz = (int)(zy / H);
-    acc += g[(((size_t)(zz + pz) * Hp + (yy + py)) * Wp + (x + px)) * C + c];
+  for (int row = (int)blockIdx.x * lanes + (int)threadIdx.x / Cc; row < nrows; row += (int)gridDim.x * lanes) {
+    const int zz = row / H, yy = row - zz * H;
+    const float* gl = g + (((size_t)(zz + pz) * Hp + (yy + py)) * Wp + px) * C + c;
+    float a0 = 0.f, a1 = 0.f;
+    int x = 0;
+    for (; x + 1 < W; x += 2) {
+      a0 += gl[(size_t)x * C];
+      a1 += gl[(size_t)(x + 1) * C];
+    }
+    if (x < W) a0 += gl[(size_t)x * C];
+    acc += a0 + a1;
   }
   if (c < nreal && acc != 0.f) {
     atomicAdd(&out0[c], acc);
@@ -519,16 +526,17 @@ __global__ __launch_bounds__(256) void wgrad_tiled_kernel(const WgradArgs a) {
 // channel c (zeros past `width` and past `creal`); `nullg` more all-zero groups follow.
 __global__ void wgrad_pack_kernel(const float* __restrict__ src, long long sz, long long sy, long long sx, int nz, int ny, int width, int creal,
                                   int cpad, int gpl, int nvec, int nullg, u32x4_t* __restrict__ dst) {
-  const size_t ngroups = (size_t)nz * ny * gpl;
-  const size_t total = (ngroups + nullg) * cpad;
-  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
-    const int c = (int)(i % cpad);
-    const size_t grp = i / cpad;
-    const int xg = (int)(grp % gpl);
-    const size_t line = grp / gpl;
-    const int y = (int)(line % ny), z = (int)(line / ny);
+  // 32-bit index arithmetic (the host checks the item count): 64-bit divisions cost more than the rest of the body
+  const uint32_t ngroups = (uint32_t)nz * ny * gpl;
+  const uint32_t total = (ngroups + nullg) * cpad;
+  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+    const uint32_t grp = i / (uint32_t)cpad;
+    const int c = (int)(i - grp * cpad);
+    const uint32_t line = grp / (uint32_t)gpl;
+    const int xg = (int)(grp - line * gpl);
+    const int z = (int)(line / (uint32_t)ny), y = (int)(line - (uint32_t)z * ny);
     const bool ok = grp < ngroups && c < creal;
-    const float* sp = src + (ok ? z * sz + y * sy + c : 0);
+    const float* sp = src + (ok ? (long long)z * sz + (long long)y * sy + c : 0);
     for (int v = 0; v < nvec; ++v) {
       u32x4_t hi, lo;
 #pragma unroll
@@ -541,8 +549,8 @@ __global__ void wgrad_pack_kernel(const float* __restrict__ src, long long sz, l
         hi[d] = h;
         lo[d] = l;
       }
-      dst[((grp * 2 + 0) * nvec + v) * cpad + c] = hi;
-      dst[((grp * 2 + 1) * nvec + v) * cpad + c] = lo;
+      dst[(((size_t)grp * 2 + 0) * nvec + v) * cpad + c] = hi;
+      dst[(((size_t)grp * 2 + 1) * nvec + v) * cpad + c] = lo;
     }
   }
 }
@@ -739,17 +747,34 @@ __global__ __launch_bounds__(256, 2) void wgrad_x3_kernel(const WgradPk a) {
   }
 }
 
-// dw[n][c][tap] += dwt[tap][n][c]; dwt = 0 (ready for the next step).  One thread per (n, c): reads coalesced over c, each
-// thread writes its ntap contiguous values.
-__global__ void wgrad_finish_kernel(float* __restrict__ dwt, float* __restrict__ dw, size_t nc, int ntap) {
-  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= nc) return;
-  for (int t = 0; t < ntap; ++t) {
-    const float v = dwt[(size_t)t * nc + i];
-    if (v != 0.f) {
-      dw[i * ntap + t] += v;
-      dwt[(size_t)t * nc + i] = 0.f;
+// dw[n][c][tap] += dwt[tap][n][c]; dwt = 0 (ready for the next step).  A block takes 256 consecutive (n, c): the tap planes
+// are read coalesced over (n, c), transposed through LDS and added into the OIDHW gradient as one contiguous run.
+__global__ __launch_bounds__(256) void wgrad_finish_kernel(float* __restrict__ dwt, float* __restrict__ dw, size_t nc, int ntap) {
+  __shared__ float tile[256 * 28];
+  const size_t i0 = (size_t)blockIdx.x * 256;
+  const int n = (int)min((size_t)256, nc - i0);
+  const int tid = threadIdx.x;
+  if (ntap > 27) {  // (no such kernel in the model family; plain form)
+    if (tid < n)
+      for (int t = 0; t < ntap; ++t) {
+        const float v = dwt[(size_t)t * nc + i0 + tid];
+        if (v != 0.f) { dw[(i0 + tid) * ntap + t] += v; dwt[(size_t)t * nc + i0 + tid] = 0.f; }
+      }
+    return;
+  }
+  if (tid < n)
+    for (int t = 0; t < ntap; ++t) {
+      const float v = dwt[(size_t)t * nc + i0 + tid];
+      tile[tid * 28 + t] = v;
+      if (v != 0.f) dwt[(size_t)t * nc + i0 + tid] = 0.f;
     }
+  __syncthreads();
+  const int total = n * ntap;
+  float* d = dw + i0 * ntap;
+  for (int k = tid; k < total; k += 256) {
+    const int i = k / ntap, t = k - i * ntap;
+    const float v = tile[i * 28 + t];
+    if (v != 0.f) d[k] += v;
   }
 }
 
@@ -1743,6 +1768,7 @@ int bsmi_unet_train_forward_backward(bsmi_unet* h, const float* raw_dev, const f
             const size_t need = ((size_t)nlines * gpl + 1) * 2 * Np * 16;
             if ((rc2 = grow(&ts->pk_g, &ts->pk_g_bytes, need))) return rc2;
             const size_t items = ((size_t)nlines * gpl + 1) * Np;
+            if (items >= ((size_t)1 << 31)) return BSMI_ERR_INVALID;
             hipLaunchKernelGGL(wgrad_pack_kernel, dim3((unsigned)std::min<size_t>((items + 255) / 256, 65536)), dim3(256), 0, s, a.g, a.gsz, a.gsy,
                                a.gsx, a.Do, a.Ho, a.Wo, a.N, Np, gpl, 1, 1, (u32x4_t*)ts->pk_g);
             g_packed = true;
@@ -1750,6 +1776,7 @@ int bsmi_unet_train_forward_backward(bsmi_unet* h, const float* raw_dev, const f
           const size_t needx = (size_t)Dil * Hil * gpl * 2 * xvec * Cp * 16;
           if ((rc2 = grow(&ts->pk_x, &ts->pk_x_bytes, needx))) return rc2;
           const size_t itemsx = (size_t)Dil * Hil * gpl * Cp;
+          if (itemsx >= ((size_t)1 << 31)) return BSMI_ERR_INVALID;
           hipLaunchKernelGGL(wgrad_pack_kernel, dim3((unsigned)std::min<size_t>((itemsx + 255) / 256, 65536)), dim3(256), 0, s, a.x, a.xsz, a.xsy, a.xsx,
                              Dil, Hil, a.Wo + a.kx - 1, a.C, Cp, gpl, xvec, 0, (u32x4_t*)ts->pk_x);
           WgradPk k;
