@@ -923,6 +923,7 @@ struct PackJob {  // one packed weight image that must follow the parameters
   float* dst = nullptr;
   uint32_t *dst_hi = nullptr, *dst_lo = nullptr;  // fused split-bf16 image instead (units of 16 channels)
   int window = 2;  // units of one 32-channel chunk (taps x 2): the thread order of pack_weights_x3_kernel
+  bool shadowed = false;  // f32 image of a forward launch that trains in its split-bf16 form (make_forward_x3)
   // bias image (forward launches only)
   long long b0 = -1, b1 = -1;
   float* bias_dst = nullptr;
@@ -958,6 +959,8 @@ struct TrainFwdX3 {  // a forward CONV step as a fused split-bf16 launch
 struct TrainState {
   std::vector<std::unique_ptr<TrainFwdX3>> fwd_x3;
   std::map<const void*, void*> split_of;  // f32 activation -> its split copy written by an earlier launch of the forward pass
+  std::map<const void*, size_t> fwd_job_of;  // bias image of a forward launch -> index of its pack job
+  bool f32_images_stale = false;
   int64_t in_shape[3] = {0, 0, 0};
   Plan* plan = nullptr;
   std::vector<ParamRef> params;
@@ -1075,26 +1078,32 @@ static int make_forward_job(bsmi_unet* h, TrainState* ts, PassSite& p, int ci) {
   job.b0 = (long long)bm;
   job.b1 = last ? (long long)br : -1;
   job.bias_dst = pc.bias;
+  ts->fwd_job_of[pc.bias] = ts->jobs.size();
   ts->jobs.push_back(job);
   return BSMI_OK;
 }
 
-static int run_pack_jobs(TrainState* ts, hipStream_t s) {
+// `lazy_f32`: leave out the f32 weight image of a forward launch that runs in its split-bf16 form during training
+// (PackJob::shadowed); the images are then stale until train_refresh_f32_images, which an f32 inference call on the same
+// handle triggers (unet_api.hip) -- the bias images and everything the step itself reads are always current.
+static int run_pack_jobs(TrainState* ts, hipStream_t s, bool lazy_f32 = false, bool only_shadowed = false) {
   for (const PackJob& j : ts->jobs) {
+    if (only_shadowed && !j.shadowed) continue;
     const size_t total = (size_t)j.nunits * j.Npad;
-    if (j.dst_hi)
-    {
+    if (j.dst_hi) {
       const int ugw = std::max(2, j.window);
       const size_t padded = (size_t)((j.nunits + ugw - 1) / ugw) * ugw * j.Npad;
       hipLaunchKernelGGL(pack_weights_x3_kernel, dim3((unsigned)((padded + 255) / 256)), dim3(256), 0, s, (const float*)ts->w,
                          (const PackUnit*)j.units, j.nunits, j.Npad, j.nreal, ugw, j.dst_hi, j.dst_lo);
-    }
-    else
+    } else if (!(lazy_f32 && j.shadowed)) {
       hipLaunchKernelGGL(pack_weights_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, (const float*)ts->w, (const PackUnit*)j.units,
                          j.nunits, j.Npad, j.nreal, j.dst);
-    if (j.bias_dst)
+    }
+    if (j.bias_dst && !only_shadowed)
       hipLaunchKernelGGL(pack_bias_kernel, dim3((j.Npad + 255) / 256), dim3(256), 0, s, (const float*)ts->w, j.b0, j.b1, j.nreal, j.Npad, j.bias_dst);
   }
+  if (lazy_f32) ts->f32_images_stale = true;
+  if (only_shadowed) ts->f32_images_stale = false;
   BSMI_HIP(hipGetLastError());
   return BSMI_OK;
 }
@@ -1218,7 +1227,14 @@ static int make_forward_x3(bsmi_unet* h, TrainState* ts, PlanStep& st) {
   a.relu = 1;
   st.tx3 = fx.get();
   ts->fwd_x3.push_back(std::move(fx));
+  auto fj = ts->fwd_job_of.find(pf.bias);
+  if (fj != ts->fwd_job_of.end()) ts->jobs[fj->second].shadowed = true;
   return BSMI_OK;
+}
+
+int train_refresh_f32_images(bsmi_unet* h, hipStream_t s) {
+  if (!h->train || !h->train->f32_images_stale) return BSMI_OK;
+  return run_pack_jobs(h->train, s, false, true);
 }
 
 int train_forward_conv_x3(bsmi_unet* h, const PlanStep& st, hipStream_t s) {
@@ -1954,7 +1970,7 @@ int bsmi_unet_train_adam_step(bsmi_unet* h, float lr, float beta1, float beta2, 
   const float bc2 = 1.f - powf(beta2, (float)ts->adam_t);
   hipLaunchKernelGGL(adam_kernel, dim3(1024), dim3(256), 0, s, ts->w, (const float*)ts->g, ts->m, ts->v, ts->nparams, lr, beta1, beta2, eps, bc1, sqrtf(bc2),
                      grad_scale);
-  int rc = run_pack_jobs(ts, s);
+  int rc = run_pack_jobs(ts, s, /*lazy_f32=*/true);
   if (rc) return rc;
   for (HeadSite& hd : h->heads) {
     const std::string pre = hd.prefix;

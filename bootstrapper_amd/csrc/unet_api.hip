@@ -1228,6 +1228,9 @@ int bsmi_unet_forward(bsmi_unet* h, int precision, const void* raw_dev, int raw_
       BSMI_HIP(hipMemset((char*)h->sk_ws + stream_k_ws_bytes(h->sk_grid) - 64, 0, 64));
     }
   }
+  // f32 inference on a handle that is training: the f32 images of the launches that train in their split-bf16 form are
+  // brought up to date first (train.hip keeps only what the training step itself reads current)
+  if (h->train && precision == BSMI_PREC_F32 && !h->train_forward && (rc = train_refresh_f32_images(h, s))) return rc;
   size_t step_idx = 0;
   for (const PlanStep& st : plan.steps) {
     if (prof) BSMI_HIP(hipEventRecord(plan.events[2 * step_idx], s));

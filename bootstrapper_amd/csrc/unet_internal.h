@@ -160,4 +160,5 @@ namespace bsmi {
 int get_plan(bsmi_unet* h, int precision, const int64_t in_shape[3], Plan** out);
 void free_train_state(bsmi_unet* h);
 int train_forward_conv_x3(bsmi_unet* h, const PlanStep& st, hipStream_t s);  // train.hip
+int train_refresh_f32_images(bsmi_unet* h, hipStream_t s);  // train.hip: f32 weight images left stale by the last optimizer step
 }  // namespace bsmi

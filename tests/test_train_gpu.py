@@ -417,3 +417,32 @@ def test_split_bf16_weight_gradients_match_f32_form(tmp_path):
         worst = max(worst, err)
         assert err < 2e-5, (k, err, scale)
     print("largest relative difference split-bf16 vs f32 weight gradients:", worst)
+
+
+def test_f32_inference_between_training_steps_sees_current_weights():
+    """The f32 weight images of the launches that train in their split-bf16 form are refreshed lazily (an optimizer step
+    leaves them stale; an f32 forward on the handle brings them up to date): the prediction of the training handle after
+    two steps equals that of a fresh model loaded with the trained parameters."""
+    from bootstrapper_amd.unet import Model
+    from bootstrapper_amd.training import Trainer
+    from bootstrapper_amd.synth import synthetic_state_dict
+    cfg = {"in_channels": 1, "num_fmaps": 12, "fmap_inc_factor": 5, "downsample_factors": [[1, 2, 2], [1, 2, 2]],
+           "kernel_size_down": [[[3, 3, 3], [3, 3, 3]]] * 3, "kernel_size_up": [[[3, 3, 3], [3, 3, 3]]] * 2, "outputs": {"3d_affs": {"dims": 6}}}
+    shape = (22, 116, 116)
+    sd = synthetic_state_dict(cfg, 3)
+    m = Model(cfg, precision="f32").load_state_dict(sd)
+    tr = Trainer(m, shape, lr=1e-3)
+    g = torch.Generator().manual_seed(5)
+    raw = torch.rand((1, 1) + shape, generator=g).cuda()
+    out = tuple(tr.out_shape)
+    batch = {"raw": raw, "gt_affs": torch.rand((6,) + out, generator=g).cuda(), "affs_weights": torch.rand((6,) + out, generator=g).cuda()}
+    before = m.forward(raw)[0].clone()
+    for _ in range(2):
+        tr.training_step(batch)
+    after = m.forward(raw)[0].clone()
+    trained = {k: tr.read(k, "param").reshape(np.asarray(v).shape) for k, v in sd.items()}
+    fresh = Model(cfg, precision="f32").load_state_dict(trained)
+    want = fresh.forward(raw)[0]
+    assert float((after - before).abs().max()) > 1e-4          # the steps did move the prediction
+    assert float((after - want).abs().max()) < 1e-6, float((after - want).abs().max())
+    tr.close()
