@@ -2170,6 +2170,9 @@ int bsmi_unet_train_end(bsmi_unet* h) {
     // the trained parameters become the handle's weights: host copies refreshed, the bf16 images re-packed on demand
     BSMI_HIP(hipSetDevice(h->device));
     BSMI_HIP(hipDeviceSynchronize());
+    const int rrc = train_refresh_f32_images(h, nullptr);  // the f32 images stay the handle's: not left stale
+    if (rrc) return rrc;
+    BSMI_HIP(hipDeviceSynchronize());
     for (const ParamRef& pr : h->train->params)
       BSMI_HIP(hipMemcpy(h->weights[pr.key].data.data(), h->train->w + pr.off, pr.count * sizeof(float), hipMemcpyDeviceToHost));
     for (auto* sites : {&h->l_conv, &h->r_conv})

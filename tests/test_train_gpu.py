@@ -445,4 +445,8 @@ def test_f32_inference_between_training_steps_sees_current_weights():
     want = fresh.forward(raw)[0]
     assert float((after - before).abs().max()) > 1e-4          # the steps did move the prediction
     assert float((after - want).abs().max()) < 1e-6, float((after - want).abs().max())
+    tr.training_step(batch)                                    # images stale again when training ends
+    trained = {k: tr.read(k, "param").reshape(np.asarray(v).shape) for k, v in sd.items()}
     tr.close()
+    want = Model(cfg, precision="f32").load_state_dict(trained).forward(raw)[0]
+    assert float((m.forward(raw)[0] - want).abs().max()) < 1e-6
