@@ -242,7 +242,8 @@ def run_training(config_file, device=0, batches=None, log=print):
         log(f"resuming from {ckpt}")
     else:
         model.load_state_dict(default_init(net_config, seed=42))
-    trainer = Trainer(model, net_config["input_shape"])
+    # `arithmetic` (an addition to the reference's train config): "split-bf16" (default) or "f32", see training.Trainer
+    trainer = Trainer(model, net_config["input_shape"], arithmetic=config.get("arithmetic", "split-bf16"))
     if ckpt and load_optimizer_state(trainer, ckpt):
         log(f"optimizer state restored (step {trainer.step_count()})")
     if batches is None:
