@@ -942,9 +942,7 @@ struct ConvBwd {  // backward data of one CONV plan step
   bool scatter = false;
 };
 
-}  // namespace bsmi
-// (declared in unet_internal.h at namespace bsmi scope as PlanStep::tx3's type)
-namespace bsmi {
+// (PlanStep::tx3's type, unet_internal.h)
 struct TrainFwdX3 {  // a forward CONV step as a fused split-bf16 launch
   ConvArgs a{};
   TileCfg tile = TILE_256x32;
