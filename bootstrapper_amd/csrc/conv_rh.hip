@@ -539,15 +539,15 @@ __global__ __launch_bounds__(64 * kRhNW, 1) void conv_rh_x3_kernel(const RhxArgs
       BL_[j_] = *(const u32x4_t*)(wb_ + EB + off_);                                                                   \
     }                                                                                                                 \
   } while (0)
-#define RHX_MMA(I_, AL_, AH_, BH_, BL_)                                                                               \
+  // product PR_ (0: A lo x B hi, 1: A hi x B hi, 2: A hi x B lo) on all FM x FN accumulators: the three MFMAs of one
+  // accumulator are 8 instructions apart (back to back on one accumulator each waits for the one before: the first
+  // version, row block by row block, ran the 24 MFMAs of a K-step as 8 dependent chains of 3)
+#define RHX_MMA(PR_, AL_, AH_, BH_, BL_)                                                                              \
   do {                                                                                                                \
-    _Pragma("unroll") for (int j_ = 0; j_ < FN; ++j_) {                                                               \
-      f32x4_t c_ = acc[I_][j_];                                                                                       \
-      c_ = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, AL_[I_]), __builtin_bit_cast(bf16x8_t, BH_[j_]), c_, 0, 0, 0); \
-      c_ = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, AH_[I_]), __builtin_bit_cast(bf16x8_t, BH_[j_]), c_, 0, 0, 0); \
-      c_ = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, AH_[I_]), __builtin_bit_cast(bf16x8_t, BL_[j_]), c_, 0, 0, 0); \
-      acc[I_][j_] = c_;                                                                                               \
-    }                                                                                                                 \
+    _Pragma("unroll") for (int i_ = 0; i_ < FM; ++i_)                                                                 \
+      _Pragma("unroll") for (int j_ = 0; j_ < FN; ++j_)                                                               \
+        acc[i_][j_] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, (PR_) == 0 ? AL_[i_] : AH_[i_]),      \
+                                                              __builtin_bit_cast(bf16x8_t, (PR_) == 2 ? BL_[j_] : BH_[j_]), acc[i_][j_], 0, 0, 0); \
   } while (0)
   // End of K-step h: everything but the halo piece this step issued LAST must have landed -- the weights of h + 2 (from
   // L2, long back) so that the next step can fetch its fragments a step ahead, and the pieces of earlier steps (loads
@@ -579,6 +579,7 @@ __global__ __launch_bounds__(64 * kRhNW, 1) void conv_rh_x3_kernel(const RhxArgs
       if (!(nbuf >> 16)) RHX_READ(h + 1, nro, nbuf & 1, al1, ah1, bh1, bl1);
       __builtin_amdgcn_sched_barrier(0);
       RHX_MMA(1, al0, ah0, bh0, bl0);
+      RHX_MMA(2, al0, ah0, bh0, bl0);
       RHX_WAIT(issue >= 0 ? pcs >> 8 : 0);
       __builtin_amdgcn_s_barrier();
       if (nbuf >> 16) RHX_READ(h + 1, nro, nbuf & 1, al1, ah1, bh1, bl1);
@@ -596,6 +597,7 @@ __global__ __launch_bounds__(64 * kRhNW, 1) void conv_rh_x3_kernel(const RhxArgs
       if (more && !(nbuf >> 16)) RHX_READ(h + 2, nro, nbuf & 1, al0, ah0, bh0, bl0);
       __builtin_amdgcn_sched_barrier(0);
       RHX_MMA(1, al1, ah1, bh1, bl1);
+      RHX_MMA(2, al1, ah1, bh1, bl1);
       RHX_WAIT(issue >= 0 ? pcs >> 8 : 0);
       __builtin_amdgcn_s_barrier();
       if (more && (nbuf >> 16)) RHX_READ(h + 2, nro, nbuf & 1, al0, ah0, bh0, bl0);
