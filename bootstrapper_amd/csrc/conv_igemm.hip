@@ -1201,6 +1201,9 @@ bool two_waves_per_simd() {
 #ifndef BSMI_X3_64_MS
 #define BSMI_X3_64_MS 16  // MFMA shape of the fused 256 x 64 / 256 x 160 tiles (measured 1-4 % faster than 32)
 #endif
+#ifndef BSMI_X3_64_BM
+#define BSMI_X3_64_BM 256  // rows of the 64-column fused tile (dev builds: 512)
+#endif
 #ifndef BSMI_X3_320_MS
 #define BSMI_X3_320_MS 16  // MFMA shape of the fused 256 x 320 tile (dev builds: 32)
 #endif
@@ -1210,7 +1213,7 @@ static int launch_cfg(const ConvArgs& a, TileCfg cfg, hipStream_t stream, float*
     // conv_x3_body: 16x16x32 where the wave tile allows (it needs two halves of B fragments), 32x32x16 for the wide wave tiles
     switch (cfg) {
       case TILE_256x32: return launch_one<T, 256, 32, 4, 1, 16>(a, stream, sk_ws, sk_grid);
-      case TILE_256x64: return launch_one<T, 256, 64, 4, 1, BSMI_X3_64_MS>(a, stream, sk_ws, sk_grid);  // 8 x 1 waves: measured no faster
+      case TILE_256x64: return launch_one<T, BSMI_X3_64_BM, 64, 4, 1, BSMI_X3_64_MS>(a, stream, sk_ws, sk_grid);  // 8 x 1 waves: measured no faster
       case TILE_256x160: return launch_one<T, 256, 160, 4, 1, BSMI_X3_64_MS>(a, stream, sk_ws, sk_grid);
       case TILE_256x320: return launch_one<T, 256, 320, 4, 2, BSMI_X3_320_MS>(a, stream, sk_ws, sk_grid);
       case TILE_256x256: return launch_one<T, 256, 256, 4, 2, 16>(a, stream, sk_ws, sk_grid);
