@@ -155,8 +155,8 @@ def cpu_baseline(raw_blocks, affs_u8_host, seg_blocks):
     pred_vox_s = len(raw_blocks) * nvox / t_pred
 
     t0 = time.perf_counter()
-    _, nodes, E, _, segs = cpu_blockwise(affs_u8_host, OUT_BLOCK, SEG_CONTEXT, 10, FILTER_FRAGMENTS, REMOVE_DEBRIS, THRESHOLDS, 256,
-                                         workers=cores)
+    frags, nodes, E, _, segs = cpu_blockwise(affs_u8_host, OUT_BLOCK, SEG_CONTEXT, 10, FILTER_FRAGMENTS, REMOVE_DEBRIS, THRESHOLDS, 256,
+                                             workers=cores)
     t_seg = time.perf_counter() - t0
     seg_vox_s = affs_u8_host[0].size / t_seg
     both = 1.0 / (1.0 / pred_vox_s + 1.0 / seg_vox_s)
@@ -167,7 +167,34 @@ def cpu_baseline(raw_blocks, affs_u8_host, seg_blocks):
                    f"RAG scoring, connected components, relabel) on {seg_blocks} blocks of GPU-predicted affinities, {cores} cores, "
                    f"{len(nodes)} fragments, {len(E)} edges, {t_seg:.1f} s -> {seg_vox_s / 1e6:.2f} Mvox/s"),
         "predict_kvox_s": pred_vox_s / 1e3, "segment_Mvox_s": seg_vox_s / 1e6,
-    }, outs
+    }, outs, frags
+
+
+def same_partition(a, b):
+    """Two label volumes describe the same fragments after an id remap: background on background, and the (a, b) id pairs
+    that occur form a bijection."""
+    a, b = a.ravel(), b.ravel()
+    if not np.array_equal(a == 0, b == 0):
+        return False
+    pairs = np.unique(np.stack([a, b]), axis=1)
+    return len(np.unique(pairs[0])) == pairs.shape[1] == len(np.unique(pairs[1]))
+
+
+def check_fragments(gpu_frags, cpu_frags, sub, job):
+    """The CPU restatement's fragments of the sampled sub-box against the GPU pipeline's, block by block, on the blocks whose
+    read box (write box + context) is the same in both runs: every block but those on a face of the sub-box that lies inside
+    the job.  -> (blocks compared, blocks whose fragments differ after an id remap)"""
+    compared = bad = 0
+    for z in range(sub[0]):
+        for y in range(sub[1]):
+            for x in range(sub[2]):
+                b = (z, y, x)
+                if any(b[d] + 1 == sub[d] and sub[d] != job[d] for d in range(3)):
+                    continue
+                sl = tuple(slice(b[d] * OUT_BLOCK[d], (b[d] + 1) * OUT_BLOCK[d]) for d in range(3))
+                compared += 1
+                bad += not same_partition(gpu_frags[sl], cpu_frags[sl])
+    return compared, bad
 
 
 def train_main(args):
@@ -417,9 +444,18 @@ def main():
         sj = job_blocks_for(max(1, min(args.cpu_segment_blocks, args.steps)))
         sj = tuple(min(a, b) for a, b in zip(sj, job))
         affs = pipe.seg.interior(pipe.seg.affs)[:, :sj[0] * 128, :sj[1] * 128, :sj[2] * 128].contiguous().cpu().numpy()
-        out["cpu_baseline"], cpu_outs = cpu_baseline([r.cpu().numpy() for r in raws], affs, sj[0] * sj[1] * sj[2])
+        out["cpu_baseline"], cpu_outs, cpu_frags = cpu_baseline([r.cpu().numpy() for r in raws], affs, sj[0] * sj[1] * sj[2])
         if not args.no_segment:
             out["segment_only"]["gpu_over_cpu"] = out["segment_only"]["Mvoxels_per_s"] / out["cpu_baseline"]["segment_Mvox_s"]
+            out["segment_only"]["gpu_over_cpu_note"] = (f"against {out['cpu_baseline']['cores']} host cores, this GPU's share of the node; at equal share "
+                                                        "the ratio does not grow with the GPU count")
+            # the CPU restatement is also the checker: its fragments on the sampled blocks against what the GPU pipeline produced
+            gpu_frags = pipe.seg.interior(pipe.seg.frags)[:sj[0] * 128, :sj[1] * 128, :sj[2] * 128].cpu().numpy().view(np.uint64)
+            compared, bad = check_fragments(gpu_frags, cpu_frags, sj, job)
+            out["cpu_baseline"]["parity_check"] = {"blocks_compared": compared, "blocks_differing": bad,
+                                                   "what": "fragments of the GPU pipeline vs the CPU restatement on the same affinities, equal after an id remap"}
+            if bad:
+                raise SystemExit(f"parity: the fragments of {bad} of {compared} sampled blocks differ from the CPU restatement's")
         out["predict_only"]["gpu_over_cpu"] = out["predict_only"]["Mvoxels_per_s"] * 1e3 / out["cpu_baseline"]["predict_kvox_s"]
         if not args.no_modes:
             # speed / accuracy of every precision mode on the same blocks, errors against the CPU fp32 restatement

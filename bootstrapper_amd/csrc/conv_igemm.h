@@ -50,6 +50,12 @@ struct ConvArgs {
   int M;     // Do*Ho*Wo
   int Npad;  // multiple of the tile's BN
   int relu;
+  // Batched launches (wino.hip: the 16 transform-domain GEMMs of a Winograd layer), fused split-bf16 kernels only.  A tile
+  // index decodes to (batch, tile of that batch); batch b reads its sources at base + b * a_batch bytes and its weights at
+  // w + b * w_batch bytes (both images) and writes rows [b * M, (b + 1) * M) of `out`.
+  int nbatch;  // 0 or 1: one GEMM
+  int raw;     // 1: the epilogue stores the f32 sums as they are -- no bias, no ReLU, no (hi, lo) split: out = float [rows][Co]
+  int64_t a_batch, w_batch;
 };
 
 enum TileCfg { TILE_256x32 = 0, TILE_256x64, TILE_256x160, TILE_256x320, TILE_256x256, TILE_COUNT };

@@ -655,7 +655,7 @@ __device__ __forceinline__ void conv_x3_body(const ConvArgs& a, char* smem, int 
   (void)a;
   const cint_ptr_t steps = (cint_ptr_t)ka->steps;
   const int nsteps = ka->nsteps;
-  const gptr_t w_hi = (gptr_t)ka->w, w_lo = (gptr_t)ka->w_lo;
+  gptr_t w_hi = (gptr_t)ka->w, w_lo = (gptr_t)ka->w_lo;
   const int aM = ka->M, aNpad = ka->Npad, aWo = ka->Wo, aHo = ka->Ho;
   // opaque per call: the lane geometry below is recomputed per tile rather than hoisted out of a persistent
   // kernel's tile loop, where it would stay live across the whole body (the 256x320 form has no registers for that)
@@ -667,7 +667,10 @@ __device__ __forceinline__ void conv_x3_body(const ConvArgs& a, char* smem, int 
   const int wm = wave / WN, wn = wave % WN;
   const int ntn = aNpad / BN;
   const int nloc = s1 - s0;
-  const int tile_m = tile / ntn, tile_n = tile - tile_m * ntn;
+  // batched launch (ConvArgs::nbatch): the tile rows of batch b follow those of batch b - 1
+  const int ntm = (aM + BM - 1) / BM;
+  const int tile_mb = tile / ntn, tile_n = tile - tile_mb * ntn;
+  const int bat = tile_mb / ntm, tile_m = tile_mb - bat * ntm;
   const int m0 = tile_m * BM, n0 = tile_n * BN;
 
   // staging geometry: as conv_igemm_body (lane l lands at row l >> 2, 16-byte slot l & 3 of its KiB and fetches the
@@ -691,9 +694,15 @@ __device__ __forceinline__ void conv_x3_body(const ConvArgs& a, char* smem, int 
     ro1[i] = (uint32_t)(z * ka->t[1].sz + y * ka->t[1].sy + x * ka->t[1].sx);
     ro2[i] = (uint32_t)(z * ka->t[2].sz + y * ka->t[2].sy + x * ka->t[2].sx);
   }
-  const uint64_t base0 = ka->t[0].base, base1 = ka->t[1].base, base2 = ka->t[2].base;
+  const uint64_t abat = (uint64_t)bat * (uint64_t)ka->a_batch;
+  const uint64_t base0 = ka->t[0].base + abat, base1 = ka->t[1].base + abat, base2 = ka->t[2].base + abat;
   const uint32_t offb = (uint32_t)((n0 + wave * 16 + lrow) * ROWB + ((lchunk ^ skey) << 4));
   const size_t wstep = (size_t)aNpad * ROWB;
+  {
+    const size_t wbat = (size_t)bat * (size_t)ka->w_batch;
+    w_hi += wbat;
+    w_lo += wbat;
+  }
 
   acc_t acc[FM][FN];
 #pragma unroll
@@ -904,13 +913,51 @@ __device__ __forceinline__ void conv_x3_body(const ConvArgs& a, char* smem, int 
   const float* const bias = kb->bias;
   const int aCo = kb->Co, relu = kb->relu;
   T* out = (T*)kb->out;
+  constexpr int NSTRIP = MS / 16;  // 16-row strips per fragment row block
+  const size_t orow0 = (size_t)bat * (size_t)aM;  // first output row of this batch
+  if (kb->raw) {
+    // transform-domain sums of a Winograd layer (wino.hip): f32 as they are, one strip of 16 rows x WTN floats per wave
+    constexpr int PITCHF = WTN * 4 + 16;
+    constexpr int CPRF = WTN * 4 / 16;
+    constexpr int NCHF = 16 * CPRF;
+    static_assert(NW * 16 * PITCHF <= 2 * LO_STRIPS, "f32 strips fit where the (hi, lo) strips do");
+    char* stripf = smem + wave * (16 * PITCHF);
+    float* outf = (float*)kb->out;
+#pragma unroll
+    for (int i = 0; i < FM; ++i) {
+#pragma unroll
+      for (int hf = 0; hf < NSTRIP; ++hf) {
+#pragma unroll
+        for (int j = 0; j < FN; ++j) {
+#pragma unroll
+          for (int rr = 0; rr < (MS == 16 ? 4 : 8); ++rr) {
+            const int row = MS == 16 ? 4 * lq + rr : (rr & 3) + 8 * (rr >> 2) + 4 * lq;
+            *((float*)(stripf + row * PITCHF) + j * MS + lr) = acc[i][j][MS == 16 ? rr : hf * 8 + rr];
+          }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int k = 0; k < (NCHF + 63) / 64; ++k) {
+          const int c = lane + 64 * k;
+          if (c >= NCHF) break;
+          const int row = c / CPRF, cc = c - row * CPRF;
+          const u32x4_t v = *(const u32x4_t*)(stripf + row * PITCHF + cc * 16);
+          const int m = m0 + wm * WTM + i * MS + hf * 16 + row;
+          const int n = n0 + wn * WTN + cc * 4;
+          if (m < aM && n < aCo) store_stream16(outf + (orow0 + (size_t)m) * aCo + n, v);
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    return;
+  }
   float bv[FN];
 #pragma unroll
   for (int j = 0; j < FN; ++j) {
     const int n = n0 + wn * WTN + j * MS + lr;
     bv[j] = n < aNpad ? bias[n] : 0.f;
   }
-  constexpr int NSTRIP = MS / 16;  // 16-row strips per fragment row block
 #pragma unroll
   for (int i = 0; i < FM; ++i) {
 #pragma unroll
@@ -937,7 +984,7 @@ __device__ __forceinline__ void conv_x3_body(const ConvArgs& a, char* smem, int 
         const int m = m0 + wm * WTM + i * MS + hf * 16 + row;
         const int n = n0 + wn * WTN + cc * (16 / ESZ);
         if (m < aM && n < aCo) {
-          T* dst = out + act_index<T>((size_t)m * aCo, n);
+          T* dst = out + act_index<T>((orow0 + (size_t)m) * aCo, n);
           store_stream16(dst, v);
           store_stream16(dst + kSplitLoElems, *(const u32x4_t*)(strip + LO_STRIPS + row * PITCH + cc * 16));
         }
@@ -988,7 +1035,7 @@ __global__ __launch_bounds__(64 * WM * WN, 1) void conv_igemm_kernel(const ConvA
   // XCD-aware tile map: consecutive block ids are dealt round-robin to the 8 XCDs, so give
   // each XCD a contiguous run of tiles; n fastest, so the blocks resident on one XCD cover few
   // row panels x all weight panels and the tap re-reads of an activation line hit its L2.
-  const int ntiles = ((a.M + BM - 1) / BM) * (a.Npad / BN);
+  const int ntiles = ((a.M + BM - 1) / BM) * (a.Npad / BN) * (a.nbatch > 1 ? a.nbatch : 1);
   const int q = ntiles >> 3, r = ntiles & 7;
   const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
   const int tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + j;
@@ -1026,7 +1073,7 @@ template <typename T, int BM, int BN, int WM, int WN, int MS>
 __global__ __launch_bounds__(64 * WM * WN, 1) void conv_igemm_sk_kernel(const ConvArgs a, float* ws, int* counters) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   __shared__ int sh_item;
-  const int ntiles = ((a.M + BM - 1) / BM) * (a.Npad / BN);
+  const int ntiles = ((a.M + BM - 1) / BM) * (a.Npad / BN) * (a.nbatch > 1 ? a.nbatch : 1);
   const int S = a.nsteps;
   // the XCD this workgroup really runs on (blockIdx % 8 is only the usual placement: a CU-masked queue deals differently)
   unsigned xcc;
@@ -1067,13 +1114,15 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_fixup_kernel(const ConvArgs
   constexpr int NR = MS == 16 ? 4 : 16;  // accumulator registers of one fragment
   const int xcd = blockIdx.y, rt = blockIdx.x, frag = blockIdx.z;  // grid: (tail tile, xcd, fragment)
   const int i = frag / FN, j = frag - i * FN;
-  const int ntn = a.Npad / BN;
-  const SkGeom g = sk_geom(((a.M + BM - 1) / BM) * ntn, xcd, G);
+  const int ntn = a.Npad / BN, ntm = (a.M + BM - 1) / BM;
+  const SkGeom g = sk_geom(ntm * ntn * (a.nbatch > 1 ? a.nbatch : 1), xcd, G);
   if (rt >= g.rem || g.P == 1) return;
   const int S = a.nsteps;
   const int tile = g.base + g.rounds * g.per + rt;
-  const int tile_m = tile / ntn, tile_n = tile - tile_m * ntn;
+  const int tile_mb = tile / ntn, tile_n = tile - tile_mb * ntn;
+  const int bat = tile_mb / ntm, tile_m = tile_mb - bat * ntm;  // batched launches: as conv_x3_body
   const int m0 = tile_m * BM, n0 = tile_n * BN;
+  const size_t orow0 = (size_t)bat * (size_t)a.M;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave / WN, wn = wave % WN;
   const float* p0 = ws + ((size_t)xcd * g.per + rt * g.P) * (BM * BN);
@@ -1090,6 +1139,15 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_fixup_kernel(const ConvArgs
   }
   const int n = n0 + wn * WTN + j * MS + (MS == 16 ? (lane & 15) : (lane & 31));
   if (n >= a.Co) return;
+  if (a.raw) {  // transform-domain sums of a Winograd layer: f32 as they are
+#pragma unroll
+    for (int r = 0; r < NR; ++r) {
+      const int row = MS == 16 ? 4 * (lane >> 4) + r : (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+      const int m = m0 + wm * WTM + i * MS + row;
+      if (m < a.M) ((float*)a.out)[(orow0 + (size_t)m) * a.Co + n] = x[r];
+    }
+    return;
+  }
   const float bv = a.bias[n];
   T* out = (T*)a.out;
 #pragma unroll
@@ -1099,7 +1157,7 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_fixup_kernel(const ConvArgs
     if (m < a.M) {
       float v = x[r] + bv;
       if (a.relu) v = v > 0.f ? v : 0.f;
-      T* dst = out + act_index<T>((size_t)m * a.Co, n);
+      T* dst = out + act_index<T>((orow0 + (size_t)m) * a.Co, n);
       Elem<T>::store(dst, v);
       if constexpr (IsSplit<T>::value) Elem<T>::store(dst + kSplitLoElems, split_lo(v));
     }
@@ -1162,11 +1220,13 @@ static int launch_one(const ConvArgs& a, hipStream_t stream, float* sk_ws, int s
     sk_ok = fa.localSizeBytes == 0;
     attr_set = true;
   }
-  const int ntiles = ceil_div(a.M, BM) * (a.Npad / BN);
-  // persistent + split-K tail when whole rounds would leave a large share of the last one idle
+  const int nbatch = a.nbatch > 1 ? a.nbatch : 1;
+  if ((nbatch > 1 || a.raw) && !IsFused<T>::value) BSMI_FAIL(BSMI_ERR_INVALID, "batched / raw-sum conv launches exist in the fused split-bf16 kernels only");
+  const int ntiles = ceil_div(a.M, BM) * (a.Npad / BN) * nbatch;
+  // persistent + split-K tail when whole rounds would leave a large share of the last one idle (a batched launch is long: any round count)
   const bool big_tile = BN >= 256;
   const int rounds = ceil_div(ntiles, sk_grid > 0 ? sk_grid : 1);
-  if (sk_ws && sk_ok && sk_grid >= 8 && big_tile && ntiles % sk_grid != 0 && rounds <= 16 && (size_t)BM * BN <= kStreamKTileElems) {
+  if (sk_ws && sk_ok && sk_grid >= 8 && big_tile && ntiles % sk_grid != 0 && (rounds <= 16 || nbatch > 1) && (size_t)BM * BN <= kStreamKTileElems) {
     int* counters = (int*)(sk_ws + (size_t)sk_grid * kStreamKTileElems);
     hipLaunchKernelGGL(kern_sk, dim3(sk_grid), dim3(64 * WM * WN), smem, stream, a, sk_ws, counters);
     // fix-up grid: only as many tail tiles per XCD as the fullest XCD has (sk_geom's arithmetic); a (32, 8, fragments) grid

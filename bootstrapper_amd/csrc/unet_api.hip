@@ -236,6 +236,99 @@ static int pack_conv(bsmi_unet* h, PassSite& p, int ci, int prec) {
   return BSMI_OK;
 }
 
+// Which 3x3x3 stages of the split-bf16 mode run in their Winograd form (wino.hip).  BSMI_WINO: 0 = none, unset / 1 = where it
+// was measured to win on the 128^3 block (K = 27 Cin large against the 16 + 4 transform passes over the layer's tensors: the
+// 1500 -> 1500 and 1800 -> 300 channel stages), 2 = every stage the kernels can take (tests: small nets).
+static int wino_mode() {
+  static const int m = [] { const char* e = getenv("BSMI_WINO"); return e ? atoi(e) : 1; }();
+  return m;
+}
+static bool wino_eligible(const PassSite& p, int ci) {
+  if (wino_mode() == 0 || p.k[ci][0] != 3 || p.k[ci][1] != 3 || p.k[ci][2] != 3) return false;
+  if (ci == 0 && p.nslots > kWinoMaxSrc) return false;
+  if (!x3_fused_for(choose_tile(p.cout))) return false;
+  if (wino_mode() >= 2) return true;
+  int cin = p.cout;
+  if (ci == 0) {
+    cin = 0;
+    for (int s = 0; s < p.nslots; ++s) cin += p.cin[s];
+  }
+  return cin >= 1024 && p.cout >= 256;
+}
+
+static int pack_wino(bsmi_unet* h, PassSite& p, int ci) {
+  PackedWino& pw = p.wino[ci];
+  if (pw.w) { (void)hipFree(pw.w); pw.w = nullptr; }
+  if (pw.res_w) { (void)hipFree(pw.res_w); pw.res_w = nullptr; }
+  pw.ready = false;
+  if (!wino_eligible(p, ci)) return BSMI_OK;
+  const HostWeight& wm = h->weights[p.prefix + ".conv_pass." + std::to_string(2 * ci) + ".weight"];
+  const HostWeight& wr = h->weights[p.prefix + ".residual.0.weight"];
+  const int cin_m = (int)wm.shape[1];
+  // channels of V: every source tensor keeps its own padding to kChanPad
+  pw.cin_of_v.clear();
+  if (ci == 0) {
+    int base = 0;
+    for (int s = 0; s < p.nslots; ++s) {
+      for (int c = 0; c < round_up(p.cin[s], kChanPad); ++c) pw.cin_of_v.push_back(c < p.cin[s] ? base + c : -1);
+      base += p.cin[s];
+    }
+  } else {
+    for (int c = 0; c < round_up(p.cout, kChanPad); ++c) pw.cin_of_v.push_back(c < p.cout ? c : -1);
+  }
+  pw.Cv = (int)pw.cin_of_v.size();
+  pw.tile = choose_tile(p.cout);
+  pw.Npad = round_up(p.cout, tile_bn(pw.tile));
+  wino_units(pw.Cv, pw.units);
+  {
+    std::vector<uint16_t> packed;
+    size_t image_elems = 0, batch_elems = 0;
+    wino_pack_weights(wm.data.data(), p.cout, cin_m, pw.cin_of_v, pw.Npad, pw.units, packed, image_elems, batch_elems);
+    pw.lo_image_bytes = image_elems * 2;
+    pw.batch_bytes = batch_elems * 2;
+    BSMI_HIP(hipMalloc(&pw.w, packed.size() * 2));
+    BSMI_HIP(hipMemcpy(pw.w, packed.data(), packed.size() * 2, hipMemcpyHostToDevice));
+  }
+  // the cropped 1x1x1 residual branch of the last stage: its K-steps alone
+  pw.res_entries.clear();
+  if (ci == p.nconv - 1) {
+    std::vector<PackEntry> all;
+    build_entries(p, ci, BSMI_PREC_BF16X3, all);
+    for (size_t u = 0; u + 1 < all.size(); u += kUnitsPerStep) {
+      bool res = false;
+      for (int j = 0; j < kUnitsPerStep; ++j) res |= !all[u + j].dummy && all[u + j].wsrc == 1;
+      if (res)
+        for (int j = 0; j < kUnitsPerStep; ++j) pw.res_entries.push_back(all[u + j]);
+    }
+    if ((pw.res_entries.size() / kUnitsPerStep) % 2)
+      for (int j = 0; j < kUnitsPerStep; ++j) pw.res_entries.push_back(PackEntry{0, 0, 0, 0, 0, 0, 0, 0, 0, true, 0});
+    const size_t nsteps = pw.res_entries.size() / kUnitsPerStep;
+    const size_t nelem = (nsteps * (size_t)pw.Npad + kWeightRowSlack) * 32;
+    std::vector<uint16_t> packed(2 * nelem, 0);
+    const int64_t cin_r = wr.shape[1];
+    for (size_t u = 0; u < pw.res_entries.size(); ++u) {
+      const PackEntry& e = pw.res_entries[u];
+      if (e.dummy) continue;
+      const size_t s = u / kUnitsPerStep, j = u % kUnitsPerStep;
+      for (int n = 0; n < p.cout; ++n)
+        for (int kk = 0; kk < 16; ++kk) {
+          const int c = e.c0 + kk;
+          if (c >= e.creal) break;
+          const float v = wr.data[(size_t)n * cin_r + (e.cin_base + c)];
+          const size_t idx = (s * pw.Npad + n) * 32 + j * 16 + kk;
+          const uint16_t hi = host_f32_to_bf16(v);
+          packed[idx] = hi;
+          packed[nelem + idx] = host_f32_to_bf16(v - host_bf16_to_f32(hi));
+        }
+    }
+    pw.res_lo_image_bytes = nelem * 2;
+    BSMI_HIP(hipMalloc(&pw.res_w, packed.size() * 2));
+    BSMI_HIP(hipMemcpy(pw.res_w, packed.data(), packed.size() * 2, hipMemcpyHostToDevice));
+  }
+  pw.ready = true;
+  return BSMI_OK;
+}
+
 struct Planner {
   bsmi_unet* h;
   int prec;
@@ -623,6 +716,129 @@ struct Planner {
     return BSMI_OK;
   }
 
+  // Winograd form of one 3x3x3 stage (wino.hip): the layer's sources are transformed into V (16 batches), one batched launch
+  // of the fused split-bf16 kernel multiplies them with the transformed weights into raw f32 sums, the residual branch of a
+  // last stage runs as a short launch of its own, and the output transform finishes (bias, residual, ReLU, (hi, lo) pairs).
+  int plan_wino(PassSite& p, int ci, const PackedConv& pc, const TDesc* slots, const int (*so)[3], int nsl, const TDesc& o, PlanStep& st) {
+    st.use_wino = false;
+    const PackedWino& pw = p.wino[ci];
+    if (prec != BSMI_PREC_BF16X3 || !pw.ready || (o.H & 1) || (o.W & 1) || st.use_box || st.use_rh || st.use_rhx) return BSMI_OK;
+    const int nsrc = ci == 0 ? p.nslots : 1;
+    const int Dv = o.D + 2, Ty = o.H / 2, Tx = o.W / 2, Cv = pw.Cv;
+    const size_t vbatch = (size_t)Dv * Ty * Tx * Cv * 4;  // bytes of one batch of V: (hi, lo) pairs
+    if (vbatch >= ((size_t)1 << 31)) return BSMI_OK;       // 31-bit byte offsets inside a batch
+    const size_t Mrows = (size_t)o.D * Ty * Tx;
+    void *V = nullptr, *Mbuf = nullptr, *addend = nullptr;
+    BSMI_HIP(hipMalloc(&V, kWinoBatch * vbatch + 4096));
+    plan->allocs.push_back(V);
+    BSMI_HIP(hipMalloc(&Mbuf, kWinoBatch * Mrows * o.Cpad * sizeof(float)));
+    plan->allocs.push_back(Mbuf);
+    plan->bytes += kWinoBatch * (vbatch + Mrows * o.Cpad * sizeof(float));
+    WinoInArgs& wi = st.wino_in;
+    memset(&wi, 0, sizeof wi);
+    int cv0 = 0;
+    for (int q = 0; q < nsrc; ++q) {
+      const TDesc& t = slots[q];
+      wi.src[q] = t.ptr;
+      wi.H[q] = t.H; wi.W[q] = t.W; wi.Cpad[q] = t.Cpad;
+      wi.oz[q] = so[q][0]; wi.oy[q] = so[q][1]; wi.ox[q] = so[q][2];
+      wi.cv0[q] = cv0;
+      cv0 += t.Cpad;
+    }
+    if (cv0 != Cv) BSMI_FAIL(BSMI_ERR_STATE, "%s conv %d: winograd channel layout %d != %d", p.prefix.c_str(), ci, cv0, Cv);
+    wi.nsrc = nsrc;
+    wi.V = V;
+    wi.Dv = Dv; wi.Ty = Ty; wi.Tx = Tx; wi.Cv = Cv;
+    // the batched GEMMs: a (3,1,1) convolution of V[b] with U[b]
+    ConvArgs& g = st.wino_gemm;
+    memset(&g, 0, sizeof g);
+    for (int sl = 0; sl < kMaxConvTensors; ++sl) {
+      g.t[sl].base = (uint64_t)(uintptr_t)V;
+      g.t[sl].sz = (int32_t)((int64_t)Ty * Tx * Cv * 4);
+      g.t[sl].sy = (int32_t)((int64_t)Tx * Cv * 4);
+      g.t[sl].sx = (int32_t)((int64_t)Cv * 4);
+    }
+    {
+      std::vector<KStep> ks(pw.units.size() / kUnitsPerStep);
+      for (size_t s = 0; s < ks.size(); ++s) {
+        KStep k;
+        memset(&k, 0, sizeof k);
+        for (int j = 0; j < kUnitsPerStep; ++j) {
+          const WinoUnit& u = pw.units[kUnitsPerStep * s + j];
+          if (!u.dummy) k.delta[j] = (int32_t)(((int64_t)u.kz * Ty * Tx * Cv + u.vc0) * 4);
+        }
+        ks[s] = k;
+      }
+      KStep* dks = nullptr;
+      BSMI_HIP(hipMalloc((void**)&dks, ks.size() * sizeof(KStep)));
+      plan->allocs.push_back(dks);
+      BSMI_HIP(hipMemcpy(dks, ks.data(), ks.size() * sizeof(KStep), hipMemcpyHostToDevice));
+      g.steps = dks;
+      g.nsteps = (int)ks.size();
+    }
+    g.w = pw.w;
+    g.w_lo = (const char*)pw.w + pw.lo_image_bytes;
+    g.bias = pc.bias;
+    g.out = Mbuf;
+    g.Do = o.D; g.Ho = Ty; g.Wo = Tx; g.Co = o.Cpad;
+    g.M = (int)Mrows;
+    g.Npad = pw.Npad;
+    g.relu = 0;
+    g.nbatch = kWinoBatch;
+    g.raw = 1;
+    g.a_batch = (int64_t)vbatch;
+    g.w_batch = (int64_t)pw.batch_bytes;
+    // residual branch
+    st.wino_has_res = !pw.res_entries.empty();
+    if (st.wino_has_res) {
+      BSMI_HIP(hipMalloc(&addend, (size_t)o.D * o.H * o.W * o.Cpad * sizeof(float)));
+      plan->allocs.push_back(addend);
+      plan->bytes += (size_t)o.D * o.H * o.W * o.Cpad * sizeof(float);
+      ConvArgs& r = st.wino_res;
+      r = st.conv;  // the direct launch's source tensors and output geometry
+      std::vector<KStep> ks(pw.res_entries.size() / kUnitsPerStep);
+      for (size_t s = 0; s < ks.size(); ++s) {
+        KStep k;
+        memset(&k, 0, sizeof k);
+        const PackEntry& e0 = pw.res_entries[kUnitsPerStep * s];
+        k.tensor = e0.dummy ? 0 : e0.slot;
+        for (int j = 0; j < kUnitsPerStep; ++j) {
+          const PackEntry& e = pw.res_entries[kUnitsPerStep * s + j];
+          if (e.dummy) continue;
+          const TDesc& t = slots[e.slot];
+          const int64_t off = ((((int64_t)(e.dz + so[e.slot][0]) * t.H) + (e.dy + so[e.slot][1])) * t.W + (e.dx + so[e.slot][2])) * t.Cpad + e.c0;
+          k.delta[j] = (int32_t)(off * 4);
+        }
+        ks[s] = k;
+      }
+      KStep* dks = nullptr;
+      BSMI_HIP(hipMalloc((void**)&dks, ks.size() * sizeof(KStep)));
+      plan->allocs.push_back(dks);
+      BSMI_HIP(hipMemcpy(dks, ks.data(), ks.size() * sizeof(KStep), hipMemcpyHostToDevice));
+      r.steps = dks;
+      r.nsteps = (int)ks.size();
+      r.w = pw.res_w;
+      r.w_lo = (const char*)pw.res_w + pw.res_lo_image_bytes;
+      r.out = addend;
+      r.Npad = pw.Npad;
+      r.relu = 0;
+      r.raw = 1;
+      r.nbatch = 0;
+    }
+    WinoOutArgs& wo = st.wino_out;
+    memset(&wo, 0, sizeof wo);
+    wo.M = (const float*)Mbuf;
+    wo.addend = (const float*)addend;
+    wo.bias = pc.bias;
+    wo.out = o.ptr;
+    wo.Do = o.D; wo.Ty = Ty; wo.Tx = Tx; wo.Co = o.Cpad;
+    wo.relu = 1;
+    st.tile = pw.tile;
+    st.use_wino = true;
+    (void)nsl;
+    return BSMI_OK;
+  }
+
   // One ConvPass (reference unet.py:63-76).  in[s] with per-slot origin org[s]; `sp` is the
   // logical input extent (the extent of the concatenated, cropped input).
   int pass(PassSite& p, const TDesc* in, const int (*org)[3], const int sp_in[3], TDesc& out) {
@@ -743,9 +959,12 @@ struct Planner {
         if (st.use_rhx) st.use_rh = false;
         rc = plan_box(p, ci, slots, so, nsl, o, st);
         if (rc) return rc;
+        rc = plan_wino(p, ci, pc, slots, so, nsl, o, st);
+        if (rc) return rc;
         if (getenv("BSMI_PLAN_DEBUG"))
           fprintf(stderr, "[bsmi plan] %s conv %d: out (%d,%d,%d)x%d tile BN=%d K-steps %d %s\n", p.prefix.c_str(), ci, o.D, o.H, o.W,
-                  p.cout, tile_bn(st.tile), a.nsteps, st.use_box ? "box-halo" : st.use_rhx ? "fused raster-halo" : st.use_rh ? "raster-halo" : "gather");
+                  p.cout, tile_bn(st.tile), st.use_wino ? st.wino_gemm.nsteps : a.nsteps,
+                  st.use_wino ? "winograd F(2x2,3x3)" : st.use_box ? "box-halo" : st.use_rhx ? "fused raster-halo" : st.use_rh ? "raster-halo" : "gather");
         plan->steps.push_back(st);
       }
       cur = o;
@@ -1057,6 +1276,10 @@ int bsmi_unet_destroy(bsmi_unet* h) {
         if (p.packed[pr][c].w) (void)hipFree(p.packed[pr][c].w);
         if (p.packed[pr][c].bias) (void)hipFree(p.packed[pr][c].bias);
       }
+    for (int c = 0; c < BSMI_MAX_CONVS; ++c) {
+      if (p.wino[c].w) (void)hipFree(p.wino[c].w);
+      if (p.wino[c].res_w) (void)hipFree(p.wino[c].res_w);
+    }
   };
   for (auto& p : h->l_conv) free_site(p);
   for (auto& p : h->r_conv) free_site(p);
@@ -1111,6 +1334,7 @@ int bsmi_unet_finalize(bsmi_unet* h, int precision) {
       pc.ready = false;
       int rc = pack_conv(h, p, c, precision);
       if (rc) return rc;
+      if (precision == BSMI_PREC_BF16X3 && (rc = pack_wino(h, p, c))) return rc;
     }
     return BSMI_OK;
   };
@@ -1257,6 +1481,13 @@ int bsmi_unet_forward(bsmi_unet* h, int precision, const void* raw_dev, int raw_
                                (size_t)st.out.D * st.out.H * st.out.W, s);
         break;
       case PlanStep::CONV:
+        if (st.use_wino && !(st.tx3 && h->train_forward)) {
+          if ((rc = launch_wino_in(st.wino_in, s))) break;
+          if ((rc = launch_conv_igemm(st.wino_gemm, precision, st.tile, s, h->sk_ws, h->sk_grid))) break;
+          if (st.wino_has_res && (rc = launch_conv_igemm(st.wino_res, precision, st.tile, s, h->sk_ws, h->sk_grid))) break;
+          rc = launch_wino_out(st.wino_out, s);
+          break;
+        }
         rc = (st.tx3 && h->train_forward) ? train_forward_conv_x3(h, st, s)
              : st.use_box ? launch_conv_box(st.box, s)
              : st.use_rhx ? launch_conv_rh_x3(st.rhx, s)

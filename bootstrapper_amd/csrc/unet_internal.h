@@ -10,6 +10,7 @@
 #include "conv_rh.h"
 #include "conv_box.h"
 #include "first_pass.h"
+#include "wino.h"
 
 namespace bsmi {
 
@@ -51,6 +52,23 @@ struct PackedConv {
   TileCfg tile = TILE_256x32;
 };
 
+// Winograd form of one 3x3x3 stage in the split-bf16 mode (wino.hip): transformed weights of the 16 batched GEMMs and, for the
+// last stage of a ConvPass, the weights of the cropped 1x1x1 residual branch as a launch of its own (raw sums, added by the
+// output transform).
+struct PackedWino {
+  bool ready = false;
+  std::vector<WinoUnit> units;      // K-step list of every batch
+  std::vector<int> cin_of_v;        // V channel -> input channel of the concatenated input (-1: pad)
+  int Cv = 0;                       // channels of V: every source padded to kChanPad
+  void* w = nullptr;                // hi image, lo image
+  size_t lo_image_bytes = 0, batch_bytes = 0;
+  int Npad = 0;
+  TileCfg tile = TILE_256x32;
+  std::vector<PackEntry> res_entries;  // units of the residual-only launch (empty: no residual branch on this stage)
+  void* res_w = nullptr;
+  size_t res_lo_image_bytes = 0;
+};
+
 struct PassSite {
   std::string prefix;
   int nslots = 1;
@@ -59,6 +77,7 @@ struct PassSite {
   int nconv = 0;
   int k[BSMI_MAX_CONVS][3];
   PackedConv packed[BSMI_NUM_PREC][BSMI_MAX_CONVS];
+  PackedWino wino[BSMI_MAX_CONVS];  // BSMI_PREC_BF16X3 only
 };
 
 struct HeadSite {
@@ -83,6 +102,12 @@ struct PlanStep {
   bool use_rhx = false;
   BoxArgs box;           // conv_box.hip launch of this step (use_box)
   bool use_box = false;
+  // Winograd form of this step (use_wino): input transform, batched GEMMs, [residual-only launch], output transform
+  bool use_wino = false;
+  WinoInArgs wino_in;
+  ConvArgs wino_gemm, wino_res;
+  bool wino_has_res = false;
+  WinoOutArgs wino_out;
   TileCfg tile;
   TDesc in, out;
   int f[3], o[3];

@@ -1,0 +1,52 @@
+// Winograd F(2x2, 3x3) in (y, x) for the 3x3x3 layers of the split-bf16 mode whose K is large (wino.hip).
+#pragma once
+#include <vector>
+
+#include "conv_igemm.h"
+
+namespace bsmi {
+
+constexpr int kWinoBatch = 16;  // transform positions (xi, nu) of a 4 x 4 input tile, b = 4 * xi + nu
+constexpr int kWinoMaxSrc = 2;  // source tensors of the input transform (skip connection + upsampled map)
+
+// Input transform: V[b][z][ty][tx][c] = (B^T d B)[xi][nu] of the 4 x 4 in-plane tile d whose first voxel is
+// (z, 2 ty, 2 tx) of the layer's (cropped, concatenated) input; every source's channels land at its own channel offset.
+struct WinoInArgs {
+  const void* src[kWinoMaxSrc];  // split-bf16 tensors [D][H][W][Cpad]
+  int H[kWinoMaxSrc], W[kWinoMaxSrc], Cpad[kWinoMaxSrc];
+  int oz[kWinoMaxSrc], oy[kWinoMaxSrc], ox[kWinoMaxSrc];  // origin of the layer's input inside the source (the skip connection's crop)
+  int cv0[kWinoMaxSrc];                                   // first channel of the source inside V
+  int nsrc;
+  void* V;  // split-bf16 [16][Dv][Ty][Tx][Cv]
+  int Dv, Ty, Tx, Cv;
+};
+
+// Output transform: out[z][2 ty + p][2 tx + q][c] = relu( (A^T M A)[p][q] + bias[c] + addend[...] ) as (hi, lo) pairs, where
+// M[b] = row (z * Ty + ty) * Tx + tx of batch b of the GEMM's f32 sums.
+struct WinoOutArgs {
+  const float* M;       // [16][Do * Ty * Tx][Co]
+  const float* addend;  // optional raw sums of the cropped 1x1x1 residual branch, [Do * Ho * Wo][Co]
+  const float* bias;    // [>= Co]
+  void* out;            // split-bf16 [Do][2 Ty][2 Tx][Co]
+  int Do, Ty, Tx, Co;
+  int relu;
+};
+
+int launch_wino_in(const WinoInArgs& a, hipStream_t s);
+int launch_wino_out(const WinoOutArgs& a, hipStream_t s);
+
+// One 32-byte unit of K of the transform-domain GEMMs: 16 channels of V at z tap kz (dummy: zero weights, delta 0).
+struct WinoUnit {
+  int kz, vc0;
+  bool dummy;
+};
+// K-step list shared by the 16 batches: 32-channel chunks of V, the three z taps inside a chunk; even number of K-steps.
+void wino_units(int Cv, std::vector<WinoUnit>& out);
+
+// Host side: transformed weights U[b][kz][c][n] = sum_{ky,kx} G[xi][ky] G[nu][kx] w[n][cin(c)][kz][ky][kx], packed as the GEMM's
+// B operand [b][K-step][Npad][64 B], hi image then lo image (each `image_elems` bf16 values, slack rows included).
+// `cin_of_v[c]`: input channel of V channel c, or -1 for a pad channel.  `w`: OIDHW f32 with `cin` input channels.
+void wino_pack_weights(const float* w, int cout, int cin, const std::vector<int>& cin_of_v, int Npad, const std::vector<WinoUnit>& units,
+                       std::vector<uint16_t>& packed, size_t& image_elems, size_t& batch_elems);
+
+}  // namespace bsmi

@@ -1,0 +1,278 @@
+// Winograd F(2x2, 3x3) over the in-plane axes of a 3x3x3 "valid" convolution, split-bf16 mode (BSMI_PREC_BF16X3).
+//
+// out[z][y][x][n] = sum_{kz,ky,kx,c} in[z+kz][y+ky][x+kx][c] w[n][c][kz][ky][kx]   (reference models/3d_affs/unet.py:26-34, a
+// torch.nn.Conv3d) is computed per 2 x 2 in-plane output tile as  Y = A^T [ sum_{kz,c} (G g G^T) . (B^T d B) ] A  with the
+// 4 x 4 input tile d and the kernel plane g = w[n][c][kz]: 16 multiplies per 4 outputs and (kz, c) instead of 36 -- 12 per
+// output instead of 27.  The 16 element-wise products over (kz, c) are 16 independent GEMMs
+//     M[b][m][n] = sum_{kz,c} V[b][z(m)+kz][ty(m)][tx(m)][c] U[b][kz][c][n],      b = 4 xi + nu,
+// i.e. a (3,1,1) convolution of the transformed tensor V[b]: they run as ONE batched launch of the fused split-bf16
+// implicit-GEMM kernel (conv_igemm.hip, ConvArgs::nbatch) with raw f32 sums as its output.  This file holds the two
+// memory-bound transforms around it and the host-side weight transform.
+//   B^T = [1 0 -1 0; 0 1 1 0; 0 -1 1 0; 0 1 0 -1]   G = [1 0 0; .5 .5 .5; .5 -.5 .5; 0 0 1]   A^T = [1 1 1 0; 0 1 -1 -1]
+// Arithmetic: d = hi + lo is exact in f32; B^T d B is sums of four such values (f32 rounding, 2^-24); V and U are stored as
+// (hi, lo) bf16 pairs like every operand of this mode (2^-17 per product); M and A^T M A are f32.  Measured against the direct
+// form on the full-size block: DESIGN.md section 4.
+#include "wino.h"
+
+#include <cstring>
+
+namespace bsmi {
+
+typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
+typedef float f32x4_t __attribute__((ext_vector_type(4)));
+
+namespace {
+
+__device__ __forceinline__ uint16_t to_bf16(float f) {
+  __bf16 h = (__bf16)f;
+  return __builtin_bit_cast(uint16_t, h);
+}
+__device__ __forceinline__ void unpack8(u32x4_t v, float* f) {
+  const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    f[2 * i] = __uint_as_float(w[i] << 16);
+    f[2 * i + 1] = __uint_as_float(w[i] & 0xffff0000u);
+  }
+}
+__device__ __forceinline__ u32x4_t pack8(const float* f) {
+  uint32_t w[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) w[i] = (uint32_t)to_bf16(f[2 * i]) | ((uint32_t)to_bf16(f[2 * i + 1]) << 16);
+  u32x4_t v = {w[0], w[1], w[2], w[3]};
+  return v;
+}
+// 8 channels at element index e (a multiple of 8) of the plain [voxel][Cpad] order of a split tensor: the 16-byte vector of
+// hi values is followed by that of the lo values (conv_dev.h act_index)
+__device__ __forceinline__ void load_split8(const uint16_t* base, size_t e, float* f) {
+  const uint16_t* p = base + 2 * e;
+  float g[8];
+  unpack8(*(const u32x4_t*)p, f);
+  unpack8(*(const u32x4_t*)(p + 8), g);
+#pragma unroll
+  for (int k = 0; k < 8; ++k) f[k] += g[k];
+}
+template <bool NT>
+__device__ __forceinline__ void store_split8(uint16_t* base, size_t e, const float* f) {
+  uint16_t* p = base + 2 * e;
+  const u32x4_t hv = pack8(f);
+  float h[8], r[8];
+  unpack8(hv, h);
+#pragma unroll
+  for (int k = 0; k < 8; ++k) r[k] = f[k] - h[k];
+  const u32x4_t lv = pack8(r);
+  if constexpr (NT) {
+    __builtin_nontemporal_store(hv, (u32x4_t*)p);
+    __builtin_nontemporal_store(lv, (u32x4_t*)(p + 8));
+  } else {
+    *(u32x4_t*)p = hv;
+    *(u32x4_t*)(p + 8) = lv;
+  }
+}
+
+// one thread: the 4 x 4 tile of 8 channels of source `src` at (z, ty, tx)
+__global__ __launch_bounds__(256) void wino_in_kernel(const WinoInArgs a, int src, size_t total) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  const int ncv = a.Cpad[src] >> 3;
+  const int cv = (int)(i % ncv);
+  size_t t = i / ncv;
+  const int tx = (int)(t % a.Tx);
+  t /= a.Tx;
+  const int ty = (int)(t % a.Ty);
+  const int z = (int)(t / a.Ty);
+  const uint16_t* sp = (const uint16_t*)a.src[src];
+  const int H = a.H[src], W = a.W[src], C = a.Cpad[src];
+  float d[4][4][8];
+#pragma unroll
+  for (int r = 0; r < 4; ++r)
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const size_t e = (((size_t)(z + a.oz[src]) * H + (2 * ty + r + a.oy[src])) * W + (2 * tx + c + a.ox[src])) * C + 8 * cv;
+      load_split8(sp, e, d[r][c]);
+    }
+  // B^T d: rows
+#pragma unroll
+  for (int c = 0; c < 4; ++c)
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const float d0 = d[0][c][k], d1 = d[1][c][k], d2 = d[2][c][k], d3 = d[3][c][k];
+      d[0][c][k] = d0 - d2;
+      d[1][c][k] = d1 + d2;
+      d[2][c][k] = d2 - d1;
+      d[3][c][k] = d1 - d3;
+    }
+  // (B^T d) B: columns
+#pragma unroll
+  for (int r = 0; r < 4; ++r)
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const float d0 = d[r][0][k], d1 = d[r][1][k], d2 = d[r][2][k], d3 = d[r][3][k];
+      d[r][0][k] = d0 - d2;
+      d[r][1][k] = d1 + d2;
+      d[r][2][k] = d2 - d1;
+      d[r][3][k] = d1 - d3;
+    }
+  uint16_t* V = (uint16_t*)a.V;
+  const size_t plane = (size_t)a.Dv * a.Ty * a.Tx * a.Cv;  // elements of one batch of V
+  const size_t e0 = (((size_t)z * a.Ty + ty) * a.Tx + tx) * a.Cv + a.cv0[src] + 8 * cv;
+#pragma unroll
+  for (int r = 0; r < 4; ++r)
+#pragma unroll
+    for (int c = 0; c < 4; ++c) store_split8<false>(V, (size_t)(4 * r + c) * plane + e0, d[r][c]);
+}
+
+// one thread: the 2 x 2 output tile of 8 channels at (z, ty, tx)
+__global__ __launch_bounds__(256) void wino_out_kernel(const WinoOutArgs a, size_t total) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  const int ncv = a.Co >> 3;
+  const int cv = (int)(i % ncv);
+  size_t t = i / ncv;
+  const int tx = (int)(t % a.Tx);
+  t /= a.Tx;
+  const int ty = (int)(t % a.Ty);
+  const int z = (int)(t / a.Ty);
+  const size_t Mrows = (size_t)a.Do * a.Ty * a.Tx;
+  const size_t m = ((size_t)z * a.Ty + ty) * a.Tx + tx;
+  float y[2][2][8];
+  // A^T M A = sum_b c_p(xi) c_q(nu) M[b]:  c_0 = (1, 1, 1, 0), c_1 = (0, 1, -1, -1)
+  float tp[2][4][8];  // A^T M: rows
+#pragma unroll
+  for (int nu = 0; nu < 4; ++nu) {
+    float mm[4][8];
+#pragma unroll
+    for (int xi = 0; xi < 4; ++xi) {
+      const float* p = a.M + ((size_t)(4 * xi + nu) * Mrows + m) * a.Co + 8 * cv;
+      const f32x4_t v0 = __builtin_nontemporal_load((const f32x4_t*)p);
+      const f32x4_t v1 = __builtin_nontemporal_load((const f32x4_t*)(p + 4));
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        mm[xi][k] = v0[k];
+        mm[xi][4 + k] = v1[k];
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      tp[0][nu][k] = mm[0][k] + mm[1][k] + mm[2][k];
+      tp[1][nu][k] = mm[1][k] - mm[2][k] - mm[3][k];
+    }
+  }
+#pragma unroll
+  for (int p = 0; p < 2; ++p)
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      y[p][0][k] = tp[p][0][k] + tp[p][1][k] + tp[p][2][k];
+      y[p][1][k] = tp[p][1][k] - tp[p][2][k] - tp[p][3][k];
+    }
+  float bv[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) bv[k] = a.bias[8 * cv + k];
+  const int Ho = 2 * a.Ty, Wo = 2 * a.Tx;
+  uint16_t* out = (uint16_t*)a.out;
+#pragma unroll
+  for (int p = 0; p < 2; ++p)
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      const size_t e = (((size_t)z * Ho + (2 * ty + p)) * Wo + (2 * tx + q)) * a.Co + 8 * cv;
+      float v[8];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) v[k] = y[p][q][k] + bv[k];
+      if (a.addend) {
+        const f32x4_t r0 = __builtin_nontemporal_load((const f32x4_t*)(a.addend + e));
+        const f32x4_t r1 = __builtin_nontemporal_load((const f32x4_t*)(a.addend + e + 4));
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          v[k] += r0[k];
+          v[4 + k] += r1[k];
+        }
+      }
+      if (a.relu) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v[k] = v[k] > 0.f ? v[k] : 0.f;
+      }
+      store_split8<false>(out, e, v);
+    }
+}
+
+}  // namespace
+
+int launch_wino_in(const WinoInArgs& a, hipStream_t s) {
+  if (a.nsrc < 1 || a.nsrc > kWinoMaxSrc || a.Dv <= 0 || a.Ty <= 0 || a.Tx <= 0 || a.Cv % 8) BSMI_FAIL(BSMI_ERR_INVALID, "winograd input transform: bad geometry");
+  for (int q = 0; q < a.nsrc; ++q) {
+    if (a.Cpad[q] % 8 || a.cv0[q] % 8 || a.cv0[q] + a.Cpad[q] > a.Cv) BSMI_FAIL(BSMI_ERR_INVALID, "winograd input transform: bad channel layout of source %d", q);
+    if (a.oy[q] + 2 * a.Ty + 2 > a.H[q] || a.ox[q] + 2 * a.Tx + 2 > a.W[q]) BSMI_FAIL(BSMI_ERR_INVALID, "winograd input transform: tiles leave source %d", q);
+    const size_t total = (size_t)a.Dv * a.Ty * a.Tx * (a.Cpad[q] / 8);
+    hipLaunchKernelGGL(wino_in_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, a, q, total);
+  }
+  BSMI_HIP(hipGetLastError());
+  return BSMI_OK;
+}
+
+int launch_wino_out(const WinoOutArgs& a, hipStream_t s) {
+  if (a.Do <= 0 || a.Ty <= 0 || a.Tx <= 0 || a.Co % 8) BSMI_FAIL(BSMI_ERR_INVALID, "winograd output transform: bad geometry");
+  const size_t total = (size_t)a.Do * a.Ty * a.Tx * (a.Co / 8);
+  hipLaunchKernelGGL(wino_out_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, a, total);
+  BSMI_HIP(hipGetLastError());
+  return BSMI_OK;
+}
+
+void wino_units(int Cv, std::vector<WinoUnit>& out) {
+  out.clear();
+  for (int c32 = 0; c32 < Cv; c32 += 32)
+    for (int kz = 0; kz < 3; ++kz)
+      for (int j = 0; j < kUnitsPerStep; ++j) {
+        const int c = c32 + 16 * j;
+        if (c < Cv) out.push_back(WinoUnit{kz, c, false});
+        else out.push_back(WinoUnit{0, 0, true});
+      }
+  if ((out.size() / kUnitsPerStep) % 2)  // the 16x16x32 kernel body walks K-steps in pairs
+    for (int j = 0; j < kUnitsPerStep; ++j) out.push_back(WinoUnit{0, 0, true});
+}
+
+static inline uint16_t host_bf16(float f) {
+  uint32_t u;
+  memcpy(&u, &f, 4);
+  if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40);
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return (uint16_t)(u >> 16);
+}
+static inline float host_bf16_f32(uint16_t b) {
+  const uint32_t u = (uint32_t)b << 16;
+  float f;
+  memcpy(&f, &u, 4);
+  return f;
+}
+
+void wino_pack_weights(const float* w, int cout, int cin, const std::vector<int>& cin_of_v, int Npad, const std::vector<WinoUnit>& units,
+                       std::vector<uint16_t>& packed, size_t& image_elems, size_t& batch_elems) {
+  const size_t nsteps = units.size() / kUnitsPerStep;
+  batch_elems = nsteps * (size_t)Npad * 32;
+  image_elems = kWinoBatch * batch_elems + (size_t)kWeightRowSlack * 32;
+  packed.assign(2 * image_elems, 0);
+  static const double G[4][3] = {{1, 0, 0}, {.5, .5, .5}, {.5, -.5, .5}, {0, 0, 1}};
+  for (size_t u = 0; u < units.size(); ++u) {
+    const WinoUnit& un = units[u];
+    if (un.dummy) continue;
+    const size_t s = u / kUnitsPerStep, j = u % kUnitsPerStep;
+    for (int n = 0; n < cout; ++n)
+      for (int kk = 0; kk < 16; ++kk) {
+        const int c = cin_of_v[un.vc0 + kk];
+        if (c < 0) continue;
+        const float* g = w + (((size_t)n * cin + c) * 3 + un.kz) * 9;  // [ky][kx]
+        double t[4][3];
+        for (int xi = 0; xi < 4; ++xi)
+          for (int kx = 0; kx < 3; ++kx) t[xi][kx] = G[xi][0] * g[kx] + G[xi][1] * g[3 + kx] + G[xi][2] * g[6 + kx];
+        for (int xi = 0; xi < 4; ++xi)
+          for (int nu = 0; nu < 4; ++nu) {
+            const float v = (float)(t[xi][0] * G[nu][0] + t[xi][1] * G[nu][1] + t[xi][2] * G[nu][2]);
+            const size_t idx = (size_t)(4 * xi + nu) * batch_elems + (s * Npad + n) * 32 + j * 16 + kk;
+            const uint16_t hi = host_bf16(v);
+            packed[idx] = hi;
+            packed[image_elems + idx] = host_bf16(v - host_bf16_f32(hi));
+          }
+      }
+  }
+}
+
+}  // namespace bsmi

@@ -257,10 +257,13 @@ def test_refine_filters(tmp_path):
     assert R.size_filter(store + "/seg", min_size=10, dry_run=True) is None
 
 
-def test_bootstrap_chain_2d_mtlsd_then_second_stage(tmp_path, golden_dir):
+@pytest.mark.parametrize("precision", [None, "f32"])
+def test_bootstrap_chain_2d_mtlsd_then_second_stage(tmp_path, golden_dir, precision):
     """The chain of the CREMI example (2d_mtlsd -> 3d_affs_from_2d_mtlsd) through `run_prediction`: a 2-D setup
     predicted as stacks of sections, then a second-stage setup reading both prediction datasets; each compared
-    with the oracle applied block by block to the same data."""
+    with the oracle applied block by block to the same data.  precision None = the drivers' default (split-bf16:
+    2-D setups, (1,3,3) kernels, u8/255 inputs and num_fmaps_out in that arithmetic), "f32" = exact f32 products."""
+    kw = {} if precision is None else {"precision": precision}
     from bootstrapper_amd.predict import run_prediction
     from bootstrapper_amd.zarr_io import open_ds, prepare_ds
     from oracle import unet_ref as R
@@ -288,7 +291,7 @@ def test_bootstrap_chain_2d_mtlsd_then_second_stage(tmp_path, golden_dir):
                     f'chain_str = "{"" if i == 0 else "2d_mtlsd"}"\nnum_workers = 1\nnum_gpus = 1\n')
     cfg = tmp_path / "pred.toml"
     cfg.write_text("\n".join(toml))
-    run_prediction(str(cfg), "01", precision="f32")
+    run_prediction(str(cfg), "01", **kw)
     lsds, affs = open_ds(store + "/predictions/5/2d_lsds"), open_ds(store + "/predictions/5/2d_affs")
     assert lsds.shape == (6, 19, 40, 45) and lsds.chunks == (6, 1, 24, 24) and affs.dtype == np.uint8
     got = [lsds[:], affs[:]]
@@ -307,7 +310,7 @@ def test_bootstrap_chain_2d_mtlsd_then_second_stage(tmp_path, golden_dir):
         diff = np.abs(g.astype(np.int32) - r.astype(np.int32))
         assert diff.max() <= 1 and (diff == 0).mean() > 0.99
 
-    run_prediction(str(cfg), "02", precision="f32")
+    run_prediction(str(cfg), "02", **kw)
     out = open_ds(store + "/predictions/5--from--2d_mtlsd/3d_affs")
     assert out.shape == (9, 19, 40, 45) and out.chunks == (9, 4, 16, 16)
     got2 = out[:]

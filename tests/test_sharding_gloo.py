@@ -1,7 +1,6 @@
-"""N>1 path on CPU: two gloo ranks shard the block list exactly as the GPU workers do
-(bootstrapper_amd.predict.predict_blocks: blocks[rank::world]; bench.py: grid[(rank + i*world) % len]),
-the shards are disjoint and cover the volume, and the max-over-ranks timing reduction works.
-No collective touches the data path."""
+"""N>1 path on CPU (gloo): the workers' block shards (bootstrapper_amd.predict.rank_blocks: contiguous runs of the z-major
+block list, disjoint and covering), the max-over-ranks timing reduction of bench.py, the gradient sum of the training
+step, and the communication of the volume segmentation (face exchange, edge gather, LUT broadcast)."""
 import os
 
 import pytest
@@ -14,30 +13,28 @@ def _rank_main(rank, world, port, q):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    from bootstrapper_amd.pipeline import block_grid
-    from bootstrapper_amd.predict import enumerate_blocks
-    grid = block_grid((512, 512, 512), (128, 128, 128))
-    steps = len(grid) // world
-    mine = [grid[(rank + i * world) % len(grid)] for i in range(steps)]
+    from bootstrapper_amd.predict import enumerate_blocks, rank_blocks
     cfg = {"output_roi": ([0, 0, 0], [125 * 40, 1250 * 4, 1250 * 4]), "voxel_size": [40, 4, 4], "output_shape": [4, 320, 320]}
     blocks = enumerate_blocks(cfg)
-    shard = blocks[rank::world]
-    # exchange shard sizes + a checksum of block ids, and reduce a fake per-rank time with MAX
-    ids = torch.tensor([sum(hash(b) % 1000003 for b in mine), len(mine), len(shard)], dtype=torch.int64)
+    shard = rank_blocks(blocks, rank, world)
+    # exchange shard sizes + a checksum of block ids, and reduce a fake per-rank time with MAX (bench.py's reduction)
+    ids = torch.tensor([sum(hash(b) % 1000003 for b in shard), len(shard), blocks.index(shard[0])], dtype=torch.int64)
     gathered = [torch.zeros_like(ids) for _ in range(world)]
     dist.all_gather(gathered, ids)
     t = torch.tensor([1.0 + rank], dtype=torch.float64)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     dist.barrier()
-    q.put((rank, mine, shard, [g.tolist() for g in gathered], float(t.item()), len(grid), len(blocks)))
+    q.put((rank, shard, [g.tolist() for g in gathered], float(t.item()), blocks))
     dist.destroy_process_group()
 
 
-def test_two_rank_block_sharding():
-    world = 2
+@pytest.mark.parametrize("world", [2, 3])
+def test_rank_block_sharding(world):
+    """Every block goes to exactly one rank; a rank's blocks are one contiguous run of the z-major list (it reads only the
+    slab of the input that run needs); run lengths differ by at most one."""
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    port = 29500 + os.getpid() % 2000
+    port = 29500 + os.getpid() % 2000 + world
     procs = [ctx.Process(target=_rank_main, args=(r, world, port, q)) for r in range(world)]
     for p in procs:
         p.start()
@@ -45,10 +42,16 @@ def test_two_rank_block_sharding():
     for p in procs:
         p.join(60)
         assert p.exitcode == 0
-    (_, m0, s0, g0, t0, ngrid, nblocks), (_, m1, s1, g1, t1, _, _) = res
-    assert not set(m0) & set(m1) and len(set(m0) | set(m1)) == ngrid == 64
-    assert not set(s0) & set(s1) and len(s0) + len(s1) == nblocks == 512
-    assert g0 == g1 and t0 == t1 == 2.0
+    blocks = res[0][4]
+    assert len(blocks) == 32 * 4 * 4   # (125, 1250, 1250) voxels in (4, 320, 320) blocks, fit = overhang
+    joined = []
+    for rank, shard, gathered, t, _ in res:
+        assert gathered == res[0][2] and t == float(world)
+        assert shard == blocks[gathered[rank][2]:gathered[rank][2] + len(shard)]   # contiguous
+        joined += shard
+    assert joined == blocks
+    sizes = [len(r[1]) for r in res]
+    assert max(sizes) - min(sizes) <= 1
 
 
 def _grad_worker(rank, world, port, q):

@@ -11,10 +11,10 @@ pytestmark = pytest.mark.gpu
 
 # north_star: affinities within 1e-4 of the PyTorch CPU path (f32 MFMA mode)
 TOL_F32 = 1e-4
-# bf16 operands / f32 accumulate: 8-bit mantissa activations through 14+ stacked convs.
-# Measured max |err| on these nets is reported by bench/DESIGN; the gate here is loose
-# enough for bf16 rounding and tight enough to catch indexing bugs (errors would be O(0.1+)).
-TOL_BF16 = 3e-2
+# bf16 operands / f32 accumulate: 8-bit mantissa activations through 14+ stacked convs.  Measured on the golden nets of
+# this module (the prints below): at most 1.7e-3 (4.5e-3 on the full-size net, tests/test_fullsize_gpu.py); the gate is the
+# measured value with a margin of 3.
+TOL_BF16 = 5e-3
 # split bf16 (hi + lo operands, hi*hi + lo*hi + hi*lo on the bf16 MFMA, f32 accumulate): same gate as f32
 TOL_BF16X3 = 1e-4
 
@@ -151,7 +151,7 @@ FAMILY = ["2d_mtlsd_f4i2", "2d_lsd_f3i3", "2d_affs_f4i2", "3d_lsd_f4i2", "from_2
 
 
 @pytest.mark.parametrize("tag", FAMILY)
-@pytest.mark.parametrize("prec,tol", [("f32", TOL_F32), ("bf16", TOL_BF16)])
+@pytest.mark.parametrize("prec,tol", [("f32", TOL_F32), ("bf16x3", TOL_BF16X3), ("bf16", TOL_BF16)])
 def test_model_family_matches_reference_goldens(golden_dir, tag, prec, tol):
     """The other setups of the family: 2-D nets (Conv2d state dicts, (1,C,H,W) inputs), the LSD-only net and the
     second-stage nets (several inputs, num_fmaps_out, (1,3,3) kernels), against outputs of the reference models."""
