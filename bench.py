@@ -197,6 +197,116 @@ def check_fragments(gpu_frags, cpu_frags, sub, job):
     return compared, bad
 
 
+def drivers_leg(raw_box, sd, precision):
+    """`bs predict` + `bs segment --ws` (blockwise) as a user runs them, on an on-disk Zarr store holding the same box of
+    blocks: checkpoint load, chunk decode / encode (Blosc lz4, the zarr default), file reads and writes included.  Outside
+    the timed region; `raw_box`: uint8 host array of the job's output extent (the drivers reflect-pad at its faces)."""
+    import json as _json
+    import shutil
+    import tempfile
+    from bootstrapper_amd.predict import run_prediction
+    from bootstrapper_amd.segment import run_segmentation
+    from bootstrapper_amd.zarr_io import prepare_ds
+    tmp = tempfile.mkdtemp(prefix="bsmi_bench_", dir=os.environ.get("BSMI_BENCH_TMP"))
+    try:
+        setup = os.path.join(tmp, "3d_affs")
+        os.makedirs(setup)
+        nc = dict(NET_CONFIG, input_shape=[o + 2 * c for o, c in zip(OUT_BLOCK, CONTEXT)], output_shape=list(OUT_BLOCK),
+                  shape_increase=[0, 0, 0], inputs={"raw": {"dims": 1}}, outputs={"3d_affs": {"dtype": "uint8", "dims": 6}})
+        with open(os.path.join(setup, "net_config.json"), "w") as f:
+            _json.dump(nc, f)
+        ckpt = os.path.join(setup, "model_checkpoint_1")
+        torch.save({"model_state_dict": {k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()}}, ckpt + ".ckpt")
+        store = os.path.join(tmp, "vol.zarr")
+        ds = prepare_ds(store + "/raw", raw_box.shape, offset=(0, 0, 0), voxel_size=(1, 1, 1), chunk_shape=OUT_BLOCK, dtype=np.uint8,
+                        axis_names=["z", "y", "x"], units=["nm"] * 3)
+        ds[:] = raw_box
+        pred_toml = os.path.join(tmp, "pred.toml")
+        with open(pred_toml, "w") as f:
+            f.write(f'["01-3d_affs"]\nsetup_dir = "{setup}"\ninput_datasets = ["{store}/raw"]\ncheckpoint = "{ckpt}"\n'
+                    f'output_datasets_prefix = "{store}/predictions"\nchain_str = ""\nnum_workers = 1\nnum_gpus = 1\n')
+        seg_toml = os.path.join(tmp, "seg.toml")
+        with open(seg_toml, "w") as f:
+            f.write(f'affs_dataset = "{store}/predictions/1/3d_affs"\nfragments_dataset = "{store}/fragments"\n'
+                    f'seg_dataset_prefix = "{store}/segmentations"\nblockwise = true\nblock_shape = {list(OUT_BLOCK)}\n'
+                    f'context = {list(SEG_CONTEXT)}\nlanes = 16\n[db]\ndb_file = "{tmp}/rag.db"\n[ws_params]\nthresholds = {THRESHOLDS}\n'
+                    f'min_seed_distance = 10\nfilter_fragments = {FILTER_FRAGMENTS}\nremove_debris = {REMOVE_DEBRIS}\n')
+        t0 = time.perf_counter()
+        run_prediction(pred_toml, "01", precision=precision)
+        t_pred = time.perf_counter() - t0
+        t0 = time.perf_counter()
+        written = run_segmentation(seg_toml, "ws")
+        t_seg = time.perf_counter() - t0
+
+        def du(path):
+            return sum(os.path.getsize(os.path.join(d, f)) for d, _, fs in os.walk(path) for f in fs)
+        nvox = raw_box.size
+        return {"what": "`bs predict` then `bs segment --ws` (blockwise, one worker) on an on-disk Zarr store of the same box of blocks: "
+                        "checkpoint load and weight packing, Blosc-lz4 chunk decode / encode and file I/O included (outside the timed region)",
+                "blocks": int(nvox // int(np.prod(OUT_BLOCK))), "predict_seconds": t_pred, "segment_seconds": t_seg,
+                "Mvoxels_per_s": nvox / (t_pred + t_seg) / 1e6, "predict_Mvoxels_per_s": nvox / t_pred / 1e6,
+                "segment_Mvoxels_per_s": nvox / t_seg / 1e6, "datasets_written": len(written) + 1,
+                "store_bytes": du(store), "tmp_dir": os.path.dirname(tmp) or tmp}
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+
+
+TRAIN_SHAPE = (32, 196, 196)
+
+
+def train_run(dev, local_rank, rank, world, arithmetic, steps, warmup):
+    """`steps` training steps of the full 3d_affs net on the reference's training block -> (seconds, last loss, first-step gradients, forward FLOPs)"""
+    import torch.distributed as dist
+    from bootstrapper_amd.unet import Model
+    from bootstrapper_amd.training import Trainer
+    from bootstrapper_amd.synth import synthetic_state_dict
+    shape = TRAIN_SHAPE
+
+    def barrier():
+        torch.cuda.synchronize(dev)
+        if world > 1:
+            dist.barrier()
+    model = Model(NET_CONFIG, device=local_rank, precision="f32").load_state_dict(synthetic_state_dict(NET_CONFIG, 0))
+    tr = Trainer(model, shape, arithmetic=arithmetic)
+    g = torch.Generator(device=dev).manual_seed(rank)
+    out = (6,) + tuple(tr.out_shape)
+    batch = {"raw": torch.rand(shape, generator=g, device=dev) * 2 - 1,
+             "gt_affs": (torch.rand(out, generator=g, device=dev) > 0.5).float(),
+             "affs_weights": torch.rand(out, generator=g, device=dev)}
+    tr.forward_backward(batch["raw"], [batch["gt_affs"]], [batch["affs_weights"]])
+    grads = tr.grads.clone()  # of the first step, before any update: what the two arithmetics are compared on
+    for _ in range(warmup):
+        tr.training_step(batch)
+    barrier()
+    t0 = time.perf_counter()
+    loss = 0.0
+    for _ in range(steps):
+        loss = tr.training_step(batch)
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    fwd = model.flops(shape)
+    tr.close()
+    return dt, loss, grads, fwd
+
+
+def train_leg(dev, local_rank):
+    """The training step beside the headline (default run, one GPU): 10 steps in the default split-bf16 arithmetic, 4 in exact
+    f32, and how far the first-step gradients of the two are apart."""
+    dt, loss, grads, fwd = train_run(dev, local_rank, 0, 1, "split-bf16", 10, 2)
+    dt32, loss32, grads32, _ = train_run(dev, local_rank, 0, 1, "f32", 4, 1)
+    step_flops = 3.0 * fwd
+    return {"what": "3d_affs U-Net (94.7M params) forward + WeightedMSELoss + backward + Adam, block (32,196,196) -> (6,4,104,104), batch 1; "
+                    "`bench.py --mode train` is the full line",
+            "split-bf16": {"ms_per_step": dt / 10 * 1e3, "samples_per_s": 10 / dt, "tflops": step_flops * 10 / dt / 1e12,
+                           "frac_of_split_peak": step_flops * 10 / dt / 1e12 / X3_PEAK, "last_loss": loss},
+            "f32": {"ms_per_step": dt32 / 4 * 1e3, "samples_per_s": 4 / dt32, "tflops": step_flops * 4 / dt32 / 1e12, "last_loss": loss32},
+            "max_gradient_difference_rel": float((grads - grads32).abs().max() / grads32.abs().max())}
+
+
 def train_main(args):
     """Secondary benchmark (`--mode train`): samples/s of the fp32 training step of the full 3d_affs net on the
     reference's training block (32,196,196) -> (4,104,104), batch 1 per GPU, gradients averaged over the ranks."""
@@ -216,40 +326,8 @@ def train_main(args):
     from bootstrapper_amd.unet import Model
     from bootstrapper_amd.training import Trainer
     from bootstrapper_amd.synth import synthetic_state_dict
-    shape = (32, 196, 196)
-
-    def barrier():
-        torch.cuda.synchronize(dev)
-        if world > 1:
-            dist.barrier()
-
     def run(arithmetic, steps, warmup):
-        """ms per step, last loss and the worst gradient entry (relative) against `ref` gradients if given"""
-        model = Model(NET_CONFIG, device=local_rank, precision="f32").load_state_dict(synthetic_state_dict(NET_CONFIG, 0))
-        tr = Trainer(model, shape, arithmetic=arithmetic)
-        g = torch.Generator(device=dev).manual_seed(rank)
-        out = (6,) + tuple(tr.out_shape)
-        batch = {"raw": torch.rand(shape, generator=g, device=dev) * 2 - 1,
-                 "gt_affs": (torch.rand(out, generator=g, device=dev) > 0.5).float(),
-                 "affs_weights": torch.rand(out, generator=g, device=dev)}
-        tr.forward_backward(batch["raw"], [batch["gt_affs"]], [batch["affs_weights"]])
-        grads = tr.grads.clone()  # of the first step, before any update: what the two arithmetics are compared on
-        for _ in range(warmup):
-            tr.training_step(batch)
-        barrier()
-        t0 = time.perf_counter()
-        loss = 0.0
-        for _ in range(steps):
-            loss = tr.training_step(batch)
-        barrier()
-        dt = time.perf_counter() - t0
-        if world > 1:
-            t = torch.tensor([dt], dtype=torch.float64, device=dev)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            dt = float(t.item())
-        fwd = model.flops(shape)
-        tr.close()
-        return dt, loss, grads, fwd
+        return train_run(dev, local_rank, rank, world, arithmetic, steps, warmup)
 
     dt, loss, grads, fwd = run(args.train_arithmetic, args.steps, args.warmup)
     step_flops = 3.0 * fwd  # forward + input gradients + weight gradients
@@ -305,6 +383,8 @@ def main():
     ap.add_argument("--no-segment", action="store_true", help="predict only (diagnostic; not the headline metric)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-modes", action="store_true", help="skip the per-precision predict lines (speed and error of f32 / bf16x3 / bf16)")
+    ap.add_argument("--no-train", action="store_true", help="skip the `train` leg (ms per training step in both arithmetics)")
+    ap.add_argument("--no-drivers", action="store_true", help="skip the `drivers` leg (bs predict + bs segment on an on-disk Zarr store of the box)")
     ap.add_argument("--profile-every", type=int, default=4,
                     help="per-launch HIP-event timing (the roofline figures) on every Nth block of the timed region")
     ap.add_argument("--cpu-predict-blocks", type=int, default=2)
@@ -441,8 +521,13 @@ def main():
         nb = max(1, min(args.cpu_predict_blocks, args.steps))
         raws = [extract_block_reflect(vol, [o + lo - c for o, lo, c in zip(pipe.origin, b, CONTEXT)], in_block)
                 for b, _ in pipe.seg.boxes[:nb]]
-        sj = job_blocks_for(max(1, min(args.cpu_segment_blocks, args.steps)))
-        sj = tuple(min(a, b) for a, b in zip(sj, job))
+        # the CPU sample: whole block layers of the job where a layer fits the budget (the sample then shares every face but
+        # the last layer's with the job, and its fragments can be checked against the GPU's block by block)
+        if job[1] * job[2] <= args.cpu_segment_blocks:
+            sj = (min(job[0], max(1, args.cpu_segment_blocks // (job[1] * job[2]))), job[1], job[2])
+        else:
+            sj = job_blocks_for(max(1, min(args.cpu_segment_blocks, args.steps)))
+            sj = tuple(min(a, b) for a, b in zip(sj, job))
         affs = pipe.seg.interior(pipe.seg.affs)[:, :sj[0] * 128, :sj[1] * 128, :sj[2] * 128].contiguous().cpu().numpy()
         out["cpu_baseline"], cpu_outs, cpu_frags = cpu_baseline([r.cpu().numpy() for r in raws], affs, sj[0] * sj[1] * sj[2])
         if not args.no_segment:
@@ -477,6 +562,19 @@ def main():
                                "max_abs_err_vs_cpu_fp32": err, "within_1e-4": err < 1e-4}
             model.set_precision(args.precision)
             out["modes"] = modes
+    if rank == 0 and world == 1 and not args.no_train:
+        pipe_origin = pipe.origin
+        del pipe, segs
+        torch.cuda.empty_cache()
+        out["train"] = train_leg(dev, local_rank)
+        pipe = segs = None
+    if rank == 0 and world == 1 and not args.no_drivers and not args.no_segment and args.steps <= 64:
+        ext = tuple(j * b for j, b in zip(job, OUT_BLOCK))
+        box = vol[tuple(slice(o, o + e) for o, e in zip(pipe_origin if pipe is None else pipe.origin, ext))].cpu().numpy()
+        pipe = segs = None
+        torch.cuda.empty_cache()
+        out["drivers"] = drivers_leg(box, sd, args.precision)
+        out["drivers"]["resident_Mvoxels_per_s"] = value
     if rank == 0:
         print(json.dumps(out), flush=True)
     if world > 1:

@@ -5,6 +5,7 @@
 #include <cstdarg>
 #include <cstdint>
 #include <cstdio>
+#include <mutex>
 #include <string>
 
 #include "../../include/bsmi.h"
@@ -28,6 +29,26 @@ void set_error(const char* fmt, ...);
     bsmi::set_error(__VA_ARGS__); \
     return (code);                \
   } while (0)
+
+// "Once per kernel" set-up such as hipFuncSetAttribute(MaxDynamicSharedMemorySize) applies to the function object of the
+// CURRENT device, so the done-flag is kept per device (a handle created on a second GPU of the same process would otherwise
+// launch without the attribute), under a lock (two host threads may reach a kernel's first launch together).
+//   static DeviceOnce once;  int rc = once.run([&]() -> int { BSMI_HIP(hipFuncSetAttribute(...)); return BSMI_OK; });
+struct DeviceOnce {
+  std::mutex m;
+  uint64_t done[4] = {0, 0, 0, 0};  // up to 256 devices
+  template <class F>
+  int run(F&& f) {
+    int d = 0;
+    if (hipGetDevice(&d) != hipSuccess) return BSMI_ERR_HIP;
+    d &= 255;
+    std::lock_guard<std::mutex> g(m);
+    if (done[d >> 6] >> (d & 63) & 1) return BSMI_OK;
+    const int rc = f();
+    if (rc == BSMI_OK) done[d >> 6] |= 1ull << (d & 63);
+    return rc;
+  }
+};
 
 static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
 static inline int round_up(int a, int b) { return ceil_div(a, b) * b; }

@@ -1201,11 +1201,11 @@ TileCfg choose_tile(int cout) {
 template <typename T, int BM, int BN, int WM, int WN, int MS = 32>
 static int launch_one(const ConvArgs& a, hipStream_t stream, float* sk_ws, int sk_grid) {
   constexpr int smem = 4 * (BM + BN) * kStepRowBytes;
-  static bool attr_set = false;
+  static DeviceOnce once;
   static bool sk_ok = true;
   auto kern = conv_igemm_kernel<T, BM, BN, WM, WN, MS>;
   auto kern_sk = conv_igemm_sk_kernel<T, BM, BN, WM, WN, MS>;
-  if (!attr_set) {
+  const int rc_once = once.run([&]() -> int {
     BSMI_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
     BSMI_HIP(hipFuncSetAttribute((const void*)kern_sk, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
     // The K loops count their outstanding LDS-DMA groups with s_waitcnt vmcnt(N).  Scratch (spill)
@@ -1218,8 +1218,9 @@ static int launch_one(const ConvArgs& a, hipStream_t stream, float* sk_ws, int s
                 BM, BN, WM * WN, (size_t)fa.localSizeBytes);
     BSMI_HIP(hipFuncGetAttributes(&fa, (const void*)kern_sk));
     sk_ok = fa.localSizeBytes == 0;
-    attr_set = true;
-  }
+    return BSMI_OK;
+  });
+  if (rc_once) return rc_once;
   const int nbatch = a.nbatch > 1 ? a.nbatch : 1;
   if ((nbatch > 1 || a.raw) && !IsFused<T>::value) BSMI_FAIL(BSMI_ERR_INVALID, "batched / raw-sum conv launches exist in the fused split-bf16 kernels only");
   const int ntiles = ceil_div(a.M, BM) * (a.Npad / BN) * nbatch;

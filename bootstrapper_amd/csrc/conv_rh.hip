@@ -670,14 +670,15 @@ int launch_conv_rh_x3(const RhxArgs& a, hipStream_t stream) {
   static_assert(smem <= 160 * 1024 - 64, "LDS budget");
   if (a.Q <= 0 || a.nsteps <= 0 || a.nphases <= 0 || a.Npad != BN) BSMI_FAIL(BSMI_ERR_INVALID, "fused raster-halo conv: bad geometry");
   auto kern = conv_rh_x3_kernel<BN>;
-  static bool attr_set = false;
-  if (!attr_set) {
+  static DeviceOnce once;
+  const int rc_once = once.run([&]() -> int {
     BSMI_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
     hipFuncAttributes fa;
     BSMI_HIP(hipFuncGetAttributes(&fa, (const void*)kern));
     if (fa.localSizeBytes != 0) BSMI_FAIL(BSMI_ERR_STATE, "fused raster-halo conv kernel was compiled with %zu bytes of scratch", (size_t)fa.localSizeBytes);
-    attr_set = true;
-  }
+    return BSMI_OK;
+  });
+  if (rc_once) return rc_once;
   hipLaunchKernelGGL(kern, dim3(ceil_div(a.Q, 256)), dim3(64 * kRhNW), smem, stream, a);
   BSMI_HIP(hipGetLastError());
   return BSMI_OK;
@@ -703,11 +704,11 @@ template <typename T, int BN, int WM, int WN, int HP>
 static int launch_rh_one(const RhArgs& a, hipStream_t stream, float* sk_ws, int sk_grid) {
   constexpr int smem = 2 * HP * kRhNW * 16 * kStepRowBytes + 4 * BN * kStepRowBytes;
   static_assert(smem <= 160 * 1024 - 64, "LDS budget");
-  static bool attr_set = false;
+  static DeviceOnce once;
   static bool sk_ok = true;
   auto kern = conv_rh_kernel<T, BN, WM, WN, HP>;
   auto kern_sk = conv_rh_sk_kernel<T, BN, WM, WN, HP>;
-  if (!attr_set) {
+  const int rc_once = once.run([&]() -> int {
     BSMI_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
     BSMI_HIP(hipFuncSetAttribute((const void*)kern_sk, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
     hipFuncAttributes fa;  // scratch traffic would break the counted vmcnt waits (see conv_igemm.hip)
@@ -717,8 +718,9 @@ static int launch_rh_one(const RhArgs& a, hipStream_t stream, float* sk_ws, int 
                 (size_t)fa.localSizeBytes);
     BSMI_HIP(hipFuncGetAttributes(&fa, (const void*)kern_sk));
     sk_ok = fa.localSizeBytes == 0;
-    attr_set = true;
-  }
+    return BSMI_OK;
+  });
+  if (rc_once) return rc_once;
   const int ntiles = ceil_div(a.Q, 256) * (a.Npad / BN);
   const int rounds = ceil_div(ntiles, sk_grid > 0 ? sk_grid : 1);
   if (sk_ws && sk_ok && sk_grid >= 8 && BN >= 256 && ntiles % sk_grid != 0 && rounds <= 16 && (size_t)256 * BN <= kStreamKTileElems) {

@@ -293,11 +293,12 @@ template <bool RAW_F32, bool SPLIT>
 static int launch_fp(const FirstPassArgs& a, int grid, int ntz, int nty, int ntx, hipStream_t s) {
   using G = FpGeom<SPLIT>;
   auto kern = first_pass_kernel<RAW_F32, SPLIT>;
-  static bool attr_set = false;
-  if (!attr_set) {
+  static DeviceOnce once;
+  const int rc_once = once.run([&]() -> int {
     BSMI_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, G::kLds));
-    attr_set = true;
-  }
+    return BSMI_OK;
+  });
+  if (rc_once) return rc_once;
   hipLaunchKernelGGL(kern, dim3(grid), dim3(G::kT), G::kLds, s, a, ntz, nty, ntx);
   BSMI_HIP(hipGetLastError());
   return BSMI_OK;

@@ -1332,8 +1332,12 @@ __global__ void rag_scores_kernel(AggWs w, uint64_t* __restrict__ edges, float* 
   const uint32_t nn = w.counters[0];
   const uint32_t ne = min(w.counters[1], w.edge_cap);
   const uint32_t nm = w.counters[4];
-  if (ne > cap) {
-    if (blockIdx.x == 0 && threadIdx.x == 0) { atomicOr(&w.counters[3], 32u); atomicOr(w.sticky, 32u); }
+  if (ne > cap) {  // the caller's edge buffer is too small: say so, and how many entries the block needs (counts[0] > capacity)
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+      atomicOr(&w.counters[3], 32u);
+      atomicOr(w.sticky, 32u);
+      counts[0] = ne; counts[1] = nm; counts[2] = nn;
+    }
     return;
   }
   if (blockIdx.x == 0 && threadIdx.x == 0) { counts[0] = ne; counts[1] = nm; counts[2] = nn; }
@@ -2173,11 +2177,12 @@ int bsmi_ws_fragments_seeds_u8(bsmi_seg* h, const uint8_t* affs_dev, const int64
     const size_t lds = (((size_t)H * (W + 2) * 2 + 15) & ~(size_t)15) + (size_t)H * W * 4;
     const bool use_lds = lds <= 158 * 1024 && (size_t)H * H + (size_t)W * W < 65535 && (H + 1) * (H + 1) + W * W < 65535;
     if (use_lds) {
-      static bool attr_set = false;
-      if (!attr_set) {
+      static DeviceOnce once;
+      const int rc_once = once.run([&]() -> int {
         BSMI_HIP(hipFuncSetAttribute((const void*)ws_seeds_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 158 * 1024));
-        attr_set = true;
-      }
+        return BSMI_OK;
+      });
+      if (rc_once) return rc_once;
       hipLaunchKernelGGL(ws_seeds_kernel<true>, dim3(D), dim3(WS_T), lds, s, affs_dev, D, H, W, min_seed_distance, wsx);
     } else {
       hipLaunchKernelGGL(ws_seeds_kernel<false>, dim3(D), dim3(WS_T), 0, s, affs_dev, D, H, W, min_seed_distance, wsx);
@@ -2231,9 +2236,11 @@ int bsmi_agglomerate_mean_u8(bsmi_seg* h, const uint8_t* affs_dev, const uint64_
   hipLaunchKernelGGL(agg_edges_kernel<false>, dim3(grid), dim3(bs), 0, s, affs_dev, frags_dev, D, H, W, g);
   hipLaunchKernelGGL(agg_compact_kernel, dim3(grid), dim3(bs), 0, s, g);
   {
-    static const bool attr_set = [] {
-      return hipFuncSetAttribute((const void*)agg_edge_rank_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(kRankMax * sizeof(uint64_t))) == hipSuccess;
-    }();
+    static DeviceOnce once;
+    const bool attr_set = once.run([&]() -> int {
+      BSMI_HIP(hipFuncSetAttribute((const void*)agg_edge_rank_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(kRankMax * sizeof(uint64_t))));
+      return BSMI_OK;
+    }) == BSMI_OK;
     // BSMI_AGG_FAST=0 (tests): leave the edges unranked, i.e. take the general form of the merge loop
     if (attr_set && agg_fast_enabled()) hipLaunchKernelGGL(agg_edge_rank_kernel, dim3(1), dim3(1024), kRankMax * sizeof(uint64_t), s, g);
   }

@@ -798,11 +798,12 @@ template <int KX, int FNW, int FCW>
 static int launch_wgrad_x3_t(WgradPk a, hipStream_t s) {
   constexpr int TN = 32 * FNW, TC = 32 * FCW, XVEC = KX > 1 ? 2 : 1;
   constexpr int smem = 2 * (2 * 4 * TN * 16 + 2 * XVEC * 4 * TC * 16);
-  static bool attr = false;
-  if (!attr) {
+  static DeviceOnce once;
+  const int rc_once = once.run([&]() -> int {
     BSMI_HIP(hipFuncSetAttribute((const void*)wgrad_x3_kernel<KX, FNW, FCW>, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
-    attr = true;
-  }
+    return BSMI_OK;
+  });
+  if (rc_once) return rc_once;
   const int nlines = a.Do * a.Ho, trows = a.kz * a.ky;
   const int blocks_nc = ((a.N + TN - 1) / TN) * ((a.C + TC - 1) / TC);
   int zsplit = std::max(1, std::min(nlines, 4096 / std::max(1, blocks_nc * trows)));

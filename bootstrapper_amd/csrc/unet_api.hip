@@ -237,8 +237,10 @@ static int pack_conv(bsmi_unet* h, PassSite& p, int ci, int prec) {
 }
 
 // Which 3x3x3 stages of the split-bf16 mode run in their Winograd form (wino.hip).  BSMI_WINO: 0 = none, unset / 1 = where it
-// was measured to win on the 128^3 block (K = 27 Cin large against the 16 + 4 transform passes over the layer's tensors: the
-// 1500 -> 1500 and 1800 -> 300 channel stages), 2 = every stage the kernels can take (tests: small nets).
+// was measured to win on the 128^3 block -- the stages with at least 256 channels on both sides, whose matrix work outweighs
+// the transform passes over the layer's tensors (ms direct -> Winograd: 1500 -> 1500 12.19 -> 7.07, 1800 -> 300 10.55 -> 7.63,
+// 300 -> 1500 3.37 -> 2.27, 300 -> 300 3.22 -> 2.90 and 2.23 -> 2.03; narrower stages lose: 360 -> 60 2.48 -> 3.44,
+// 60 -> 300 0.91 -> 1.20) --, 2 = every stage the kernels can take (tests: small nets).
 static int wino_mode() {
   static const int m = [] { const char* e = getenv("BSMI_WINO"); return e ? atoi(e) : 1; }();
   return m;
@@ -253,7 +255,7 @@ static bool wino_eligible(const PassSite& p, int ci) {
     cin = 0;
     for (int s = 0; s < p.nslots; ++s) cin += p.cin[s];
   }
-  return cin >= 1024 && p.cout >= 256;
+  return cin >= 256 && p.cout >= 256;
 }
 
 static int pack_wino(bsmi_unet* h, PassSite& p, int ci) {

@@ -70,56 +70,69 @@ __device__ __forceinline__ void store_split8(uint16_t* base, size_t e, const flo
   }
 }
 
-// one thread: the 4 x 4 tile of 8 channels of source `src` at (z, ty, tx)
+// One thread: 8 channels of source `src` along one row of tiles (z, ty), tx = 0 .. Tx - 1.  Neighbouring tiles share two of
+// their four input columns: the thread keeps the row-transformed columns (B^T d, a per-column operation) of the previous tile
+// and loads two new columns per tile -- half the loads and half the row arithmetic of a tile-per-thread form.  Blocks are
+// numbered XCD-contiguously (consecutive block ids go to different XCDs): the tile rows ty and ty + 1, which share two of
+// their four input rows, then run on the same XCD and meet in its L2 instead of fetching those rows twice over the fabric.
 __global__ __launch_bounds__(256) void wino_in_kernel(const WinoInArgs a, int src, size_t total) {
-  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const unsigned nb = gridDim.x, q = nb >> 3, r = nb & 7, xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
+  const unsigned blk = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + j;
+  const size_t i = (size_t)blk * blockDim.x + threadIdx.x;
   if (i >= total) return;
   const int ncv = a.Cpad[src] >> 3;
   const int cv = (int)(i % ncv);
-  size_t t = i / ncv;
-  const int tx = (int)(t % a.Tx);
-  t /= a.Tx;
+  const size_t t = i / ncv;
   const int ty = (int)(t % a.Ty);
   const int z = (int)(t / a.Ty);
   const uint16_t* sp = (const uint16_t*)a.src[src];
   const int H = a.H[src], W = a.W[src], C = a.Cpad[src];
-  float d[4][4][8];
-#pragma unroll
-  for (int r = 0; r < 4; ++r)
-#pragma unroll
-    for (int c = 0; c < 4; ++c) {
-      const size_t e = (((size_t)(z + a.oz[src]) * H + (2 * ty + r + a.oy[src])) * W + (2 * tx + c + a.ox[src])) * C + 8 * cv;
-      load_split8(sp, e, d[r][c]);
-    }
-  // B^T d: rows
-#pragma unroll
-  for (int c = 0; c < 4; ++c)
-#pragma unroll
-    for (int k = 0; k < 8; ++k) {
-      const float d0 = d[0][c][k], d1 = d[1][c][k], d2 = d[2][c][k], d3 = d[3][c][k];
-      d[0][c][k] = d0 - d2;
-      d[1][c][k] = d1 + d2;
-      d[2][c][k] = d2 - d1;
-      d[3][c][k] = d1 - d3;
-    }
-  // (B^T d) B: columns
-#pragma unroll
-  for (int r = 0; r < 4; ++r)
-#pragma unroll
-    for (int k = 0; k < 8; ++k) {
-      const float d0 = d[r][0][k], d1 = d[r][1][k], d2 = d[r][2][k], d3 = d[r][3][k];
-      d[r][0][k] = d0 - d2;
-      d[r][1][k] = d1 + d2;
-      d[r][2][k] = d2 - d1;
-      d[r][3][k] = d1 - d3;
-    }
+  // element index of input voxel (row 0 of the tile row, column 0) of this thread's channels
+  const size_t e_in = (((size_t)(z + a.oz[src]) * H + (2 * ty + a.oy[src])) * W + a.ox[src]) * C + 8 * cv;
+  const size_t rstride = (size_t)W * C;
   uint16_t* V = (uint16_t*)a.V;
   const size_t plane = (size_t)a.Dv * a.Ty * a.Tx * a.Cv;  // elements of one batch of V
-  const size_t e0 = (((size_t)z * a.Ty + ty) * a.Tx + tx) * a.Cv + a.cv0[src] + 8 * cv;
+  const size_t e_out = (((size_t)z * a.Ty + ty) * a.Tx) * a.Cv + a.cv0[src] + 8 * cv;
+  float col[4][4][8];  // col[c][xi]: (B^T d)[xi] of input column 2 tx + c
+  auto load_col = [&](int c, int x) __attribute__((always_inline)) {
+    float d[4][8];
 #pragma unroll
-  for (int r = 0; r < 4; ++r)
+    for (int rr = 0; rr < 4; ++rr) load_split8(sp, e_in + rr * rstride + (size_t)x * C, d[rr]);
 #pragma unroll
-    for (int c = 0; c < 4; ++c) store_split8<false>(V, (size_t)(4 * r + c) * plane + e0, d[r][c]);
+    for (int k = 0; k < 8; ++k) {
+      col[c][0][k] = d[0][k] - d[2][k];
+      col[c][1][k] = d[1][k] + d[2][k];
+      col[c][2][k] = d[2][k] - d[1][k];
+      col[c][3][k] = d[1][k] - d[3][k];
+    }
+  };
+  load_col(0, 0);
+  load_col(1, 1);
+  for (int tx = 0; tx < a.Tx; ++tx) {
+    load_col(2, 2 * tx + 2);
+    load_col(3, 2 * tx + 3);
+    const size_t e0 = e_out + (size_t)tx * a.Cv;
+#pragma unroll
+    for (int xi = 0; xi < 4; ++xi) {
+      float v[4][8];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        v[0][k] = col[0][xi][k] - col[2][xi][k];
+        v[1][k] = col[1][xi][k] + col[2][xi][k];
+        v[2][k] = col[2][xi][k] - col[1][xi][k];
+        v[3][k] = col[1][xi][k] - col[3][xi][k];
+      }
+#pragma unroll
+      for (int nu = 0; nu < 4; ++nu) store_split8<false>(V, (size_t)(4 * xi + nu) * plane + e0, v[nu]);
+    }
+#pragma unroll
+    for (int xi = 0; xi < 4; ++xi)
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        col[0][xi][k] = col[2][xi][k];
+        col[1][xi][k] = col[3][xi][k];
+      }
+  }
 }
 
 // one thread: the 2 x 2 output tile of 8 channels at (z, ty, tx)
@@ -202,7 +215,7 @@ int launch_wino_in(const WinoInArgs& a, hipStream_t s) {
   for (int q = 0; q < a.nsrc; ++q) {
     if (a.Cpad[q] % 8 || a.cv0[q] % 8 || a.cv0[q] + a.Cpad[q] > a.Cv) BSMI_FAIL(BSMI_ERR_INVALID, "winograd input transform: bad channel layout of source %d", q);
     if (a.oy[q] + 2 * a.Ty + 2 > a.H[q] || a.ox[q] + 2 * a.Tx + 2 > a.W[q]) BSMI_FAIL(BSMI_ERR_INVALID, "winograd input transform: tiles leave source %d", q);
-    const size_t total = (size_t)a.Dv * a.Ty * a.Tx * (a.Cpad[q] / 8);
+    const size_t total = (size_t)a.Dv * a.Ty * (a.Cpad[q] / 8);  // one thread per (z, tile row, 8 channels)
     hipLaunchKernelGGL(wino_in_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, a, q, total);
   }
   BSMI_HIP(hipGetLastError());

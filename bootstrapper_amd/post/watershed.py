@@ -102,27 +102,104 @@ def connected_components_multi(nodes, edges, scores, thresholds):
     return out
 
 
-def _fill_affinities(seg, affs, origin, z0, mask=None):
-    """The slab's affinities WITH their context margins straight from the dataset (`to_ndarray(read_roi, fill_value=0)`,
-    watershed_frags.py:196-201: zeros beyond the array, real data beyond the ROI), first three channels, masked."""
+IO_WORKERS = 3   # layers of blocks in flight between the store and the device (each request decodes / encodes its chunks on
+                 # zarr_io.IO_THREADS native threads, no GIL)
+
+
+def _fill_affinities(seg, affs, origin, z0, mask=None, y0=0):
+    """The box's affinities WITH their context margins straight from the dataset (`to_ndarray(read_roi, fill_value=0)`,
+    watershed_frags.py:196-201: zeros beyond the array, real data beyond the ROI), first three channels, masked.
+    Streamed: the reference's workers read block by block; here one layer of blocks at a time is decoded by the native
+    chunk codecs on a small pool and copied into the resident slab while the next layers are being read -- the host never
+    holds more than IO_WORKERS layers."""
+    import concurrent.futures as cf
     import torch
     from .blockwise import read_with_fill
-    begin = tuple(o + lo - c for o, lo, c in zip(origin, (z0, 0, 0), seg.ctx))
-    end = tuple(b + s + 2 * c for b, s, c in zip(begin, seg.shape, seg.ctx))
-    a = read_with_fill(affs, begin, end, lead=(affs.shape[0],))[:3]
-    if a.shape[0] == 2:  # 2-channel affinities get an all-zero z channel (post/watershed.py:305-308)
-        a = np.concatenate([np.zeros_like(a[:1]), a])
-    t = torch.from_numpy(np.ascontiguousarray(a)).to(seg.dev)
-    if mask is not None:
-        m = read_with_fill(mask, begin, end)
-        t = t * torch.from_numpy((m > 0).astype(np.uint8)).to(seg.dev)
-    seg.affs.copy_(t)
+    begin = tuple(o + lo - c for o, lo, c in zip(origin, (z0, y0, 0), seg.ctx))
+    full = tuple(s + 2 * c for s, c in zip(seg.shape, seg.ctx))
+    step = max(1, seg.block[0])
+
+    def load(za):
+        zb = min(full[0], za + step)
+        b, e = (begin[0] + za,) + begin[1:], (begin[0] + zb,) + tuple(bb + f for bb, f in zip(begin[1:], full[1:]))
+        a = read_with_fill(affs, b, e, lead=(affs.shape[0],))[:3]
+        if a.shape[0] == 2:  # 2-channel affinities get an all-zero z channel (post/watershed.py:305-308)
+            a = np.concatenate([np.zeros_like(a[:1]), a])
+        t = torch.from_numpy(np.ascontiguousarray(a)).to(seg.dev)
+        if mask is not None:
+            m = read_with_fill(mask, b, e)
+            t = t * torch.from_numpy((m > 0).astype(np.uint8)).to(seg.dev)
+        seg.affs[:, za:zb].copy_(t)
+        torch.cuda.current_stream(seg.dev).synchronize()
+    with cf.ThreadPoolExecutor(max_workers=IO_WORKERS, thread_name_prefix="bsmi-read") as pool:
+        for f in [pool.submit(load, za) for za in range(0, full[0], step)]:
+            f.result()
 
 
-def waterz_pipeline(config, device=None, rank=0, world=1, group=None):
-    """post/watershed.py:8-203 for one worker of `world` (one slab of block layers each, bootstrapper_amd.volume):
-    blockwise fragments with context, per-block RAG edge scoring, global thresholded connected components, LUT, relabel.
-    Returns the list of datasets written (fragments first)."""
+class _LayerWriter:
+    """Write-behind of a rank's resident volumes: a device tensor [Z][Y][X] goes to its dataset one layer of blocks at a
+    time -- device -> host copy on a side stream, chunk encoding and file writes on the pool's threads -- while the caller
+    carries on (the next stage's kernels, the next dataset).  `drain()` waits for everything and re-raises a failure."""
+
+    def __init__(self, dev, step):
+        import concurrent.futures as cf
+        import torch
+        self.dev, self.step = dev, max(1, int(step))
+        self.pool = cf.ThreadPoolExecutor(max_workers=IO_WORKERS, thread_name_prefix="bsmi-write")
+        self.streams = {}
+        self.futures = []
+        self.torch = torch
+
+    def _write(self, ds, src, za, zb, z0, y0, ready):
+        import threading
+        torch = self.torch
+        ready.synchronize()   # host-side wait (a stream parked behind a device-side wait costs the running kernels, DESIGN 6)
+        st = self.streams.setdefault(threading.get_ident(), torch.cuda.Stream(self.dev))
+        with torch.cuda.stream(st):
+            host = src[za:zb].to("cpu", non_blocking=True)
+            done = torch.cuda.Event()
+            done.record(st)
+        done.synchronize()
+        ds[z0 + za:z0 + zb, y0:y0 + src.shape[1]] = host.numpy().view(np.uint64)
+
+    def submit(self, ds, src, z0, y0):
+        """queue `src` (int64 device tensor holding uint64 ids; the producer ran on the current stream) for ds[z0:, y0:]"""
+        ready = self.torch.cuda.Event()
+        ready.record(self.torch.cuda.current_stream(self.dev))
+        for za in range(0, src.shape[0], self.step):
+            self.futures.append(self.pool.submit(self._write, ds, src, za, min(src.shape[0], za + self.step), z0, y0, ready))
+
+    def drain(self):
+        try:
+            for f in self.futures:
+                f.result()
+        finally:
+            self.futures = []
+
+    def close(self):
+        self.pool.shutdown()
+
+
+def worker_grid(config):
+    """(Rz, Ry) of `run_waterz_pipeline`'s workers for this config: `num_workers` ranks over the block layers and block rows
+    of the ROI, as many of them as have blocks (bootstrapper_amd.volume.rank_grid)."""
+    from ..volume import rank_grid
+    affs = open_ds(config["affs_dataset"])
+    if config.get("roi_offset") is not None:
+        roi = (list(config["roi_offset"]), list(config["roi_shape"]))
+    else:
+        roi = (list(affs.roi[0]), list(affs.roi[1]))
+    sl = affs.roi_to_slices(*roi)[-3:]
+    total = tuple(s.stop - s.start for s in sl)
+    block = tuple(config["block_shape"]) if config.get("block_shape") else tuple(affs.chunks[1:])
+    world = int(config.get("num_workers", 1) or 1) if config.get("blockwise", False) else 1
+    return rank_grid(world, -(-total[0] // int(block[0])), -(-total[1] // int(block[1])))
+
+
+def waterz_pipeline(config, device=None, rank=0, world=1, group=None, grid=None, obj_group=None):
+    """post/watershed.py:8-203 for one worker of `world` (a box of whole blocks each: `grid` = (Rz, Ry) parts along z and y,
+    default slabs of block layers; bootstrapper_amd.volume): blockwise fragments with context, per-block RAG edge scoring,
+    global thresholded connected components, LUT, relabel.  Returns the list of datasets written (fragments first)."""
     import torch
     from ..blockwise import check_task_states, TaskState
     from ..volume import SlabSegmenter, slab_layers
@@ -164,19 +241,26 @@ def waterz_pipeline(config, device=None, rank=0, world=1, group=None):
     block_size = tuple(int(b) for b in block_size)   # not clipped to the ROI: ids are block id * voxels of a whole block
 
     device = rank % max(1, torch.cuda.device_count()) if device is None else device
-    layers = -(-total_shape[0] // block_size[0])
-    starts, counts = slab_layers(layers, world)
-    z0 = starts[rank] * block_size[0]
-    z1 = min(total_shape[0], (starts[rank] + counts[rank]) * block_size[0])
-    if z1 <= z0:
-        raise ValueError(f"{world} workers for {layers} layer(s) of blocks: use at most {layers}")
+    layers, rows = -(-total_shape[0] // block_size[0]), -(-total_shape[1] // block_size[1])
+    grid = (world, 1) if grid is None else tuple(grid)
+    rz, ry = divmod(rank, grid[1])
+    zs, zc = slab_layers(layers, grid[0])
+    ys, yc = slab_layers(rows, grid[1])
+    z0, z1 = zs[rz] * block_size[0], min(total_shape[0], (zs[rz] + zc[rz]) * block_size[0])
+    y0, y1 = ys[ry] * block_size[1], min(total_shape[1], (ys[ry] + yc[ry]) * block_size[1])
+    if z1 <= z0 or y1 <= y0:
+        raise ValueError(f"a {grid[0]} x {grid[1]} grid of workers for {layers} layer(s) x {rows} row(s) of blocks leaves rank {rank} without blocks "
+                         "(run_waterz_pipeline sizes the grid with bootstrapper_amd.volume.rank_grid)")
     mask = open_ds(config["mask_dataset"]) if config.get("mask_dataset") else None
-    seg = SlabSegmenter((z1 - z0,) + total_shape[1:], block_size, ctx, layers, starts[rank], thresholds, frag_params["fragments_in_xy"],
+    seg = SlabSegmenter((z1 - z0, y1 - y0, total_shape[2]), block_size, ctx, layers, zs[rz], thresholds, frag_params["fragments_in_xy"],
                         frag_params["min_seed_distance"], frag_params["filter_fragments"], frag_params["remove_debris"], 256,
                         n_lanes=int(config.get("lanes", 8)), device=device, rank=rank, world=world, group=group, exchange_affs=False,
+                        label_cap=int(config.get("label_cap", 1 << 16)), edge_cap=int(config.get("edge_cap", 1 << 17)),
+                        grid=grid, total_rows=rows, row0=ys[ry], obj_group=obj_group,
                         epsilon_agglomerate=frag_params["epsilon_agglomerate"], sigma=frag_params["sigma"],
                         noise_eps=frag_params["noise_eps"], bias=frag_params["bias"], seed_eps=frag_params["seed_eps"])
-    _fill_affinities(seg, affs, origin, z0, mask)
+    _fill_affinities(seg, affs, origin, z0, mask, y0)
+    og = obj_group if obj_group is not None else group   # pickled objects: never through an RCCL group
 
     # fragments + edge scores of this worker's blocks (post/watershed.py:118-153), accounted like daisy tasks
     states = seg.run_blocks_accounted()
@@ -184,7 +268,7 @@ def waterz_pipeline(config, device=None, rank=0, world=1, group=None):
         import torch.distributed as dist
         mine = {k: v.as_tuple() for k, v in states.items()}
         parts = [None] * world
-        dist.all_gather_object(parts, mine, group=group)
+        dist.all_gather_object(parts, mine, group=og)
         states = {k: TaskState(k) for k in mine}
         for p in parts:
             for k, t in p.items():
@@ -203,16 +287,19 @@ def waterz_pipeline(config, device=None, rank=0, world=1, group=None):
         prepare_ds(frags_name, shape=total_shape, **common)
         dump_params(frags_name, {"method": "ws", "blockwise": blockwise, **frag_params})
     barrier()
-    open_ds(frags_name, "r+")[z0:z1] = seg.interior(seg.frags).cpu().numpy().view(np.uint64)
+    # write-behind: fragments now, the segmentations as the stitch produces them; layers of blocks stream out on a pool while
+    # the RAG export and the stitch run (the reference's workers write block by block: watershed_frags.py:222-246)
+    writer = _LayerWriter(seg.dev, block_size[0])
+    writer.submit(open_ds(frags_name, "r+"), seg.interior(seg.frags), z0, y0)
 
     # RAG to the database (rank 0 gathers nodes and all edges, scored or not: post/watershed.py:100-117 db config)
     ids, pos, size = seg.node_table()
-    pos = np.asarray(roi[0], np.float64) + (pos + np.array([z0, 0, 0], np.float64)) * np.asarray(voxel_size, np.float64)
+    pos = np.asarray(roi[0], np.float64) + (pos + np.array([z0, y0, 0], np.float64)) * np.asarray(voxel_size, np.float64)
     mine = (ids, pos, size, seg.rag_edges, seg.rag_scores)
     if world > 1:
         import torch.distributed as dist
         parts = [None] * world if rank == 0 else None
-        dist.gather_object(mine, parts, dst=0, group=group)
+        dist.gather_object(mine, parts, dst=0, group=og)
     else:
         parts = [mine]
     db = config.get("db") or {}
@@ -227,6 +314,8 @@ def waterz_pipeline(config, device=None, rank=0, world=1, group=None):
     written = [frags_name]
     segs = seg.stitch()
     if seg.nodes.size == 0:
+        writer.drain()
+        writer.close()
         return written
     lut_dir = config["lut_dir"]
     for t, threshold in enumerate(thresholds):
@@ -242,37 +331,46 @@ def waterz_pipeline(config, device=None, rank=0, world=1, group=None):
             prepare_ds(seg_name, shape=total_shape, **common)
             dump_params(seg_name, recorded)
         barrier()
-        open_ds(seg_name, "r+")[z0:z1] = segs[t].cpu().numpy().view(np.uint64)
+        writer.submit(open_ds(seg_name, "r+"), segs[t], z0, y0)
         written.append(seg_name)
+    writer.drain()
+    writer.close()
     barrier()
     return written
 
 
-def _waterz_worker(rank, world, config, port, results):
+def _waterz_worker(rank, world, config, port, results, grid):
     import torch
     import torch.distributed as dist
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     # workers that share a GPU (more workers than cards) cannot form an RCCL group: gloo, device tensors staged through the host
-    backend = "nccl" if world <= torch.cuda.device_count() else "gloo"
+    backend = config.get("backend") or ("nccl" if world <= torch.cuda.device_count() else "gloo")
     if backend == "nccl":
         torch.cuda.set_device(rank)
-    dist.init_process_group(backend, rank=rank, world_size=world)
+        dist.init_process_group(backend, rank=rank, world_size=world, device_id=torch.device("cuda", rank))
+    else:
+        dist.init_process_group(backend, rank=rank, world_size=world)
+    # the object collectives (task states, nodes and edges to rank 0, LUTs back) go through a gloo group beside an RCCL one
+    obj_group = dist.new_group(backend="gloo") if backend == "nccl" else None
     try:
-        results[rank] = waterz_pipeline(config, rank=rank, world=world)
+        results[rank] = waterz_pipeline(config, rank=rank, world=world, grid=grid, obj_group=obj_group)
     finally:
         dist.destroy_process_group()
 
 
 def run_waterz_pipeline(config):
-    """One worker per `num_workers` (post/watershed.py:56: only when blockwise), each on GPU rank % (number of GPUs)."""
-    world = int(config.get("num_workers", 1) or 1) if config.get("blockwise", False) else 1
+    """`num_workers` workers (post/watershed.py:56: only when blockwise), each on GPU rank % (number of GPUs), as a grid over
+    the block layers and block rows of the ROI; workers that would be left without blocks are not started (the reference's
+    daisy server hands blocks to any number of workers)."""
+    grid = worker_grid(config) if config.get("blockwise", False) else (1, 1)
+    world = grid[0] * grid[1]
     if world <= 1:
         return waterz_pipeline(config)
     import torch.multiprocessing as mp
     port = 29800 + os.getpid() % 1000
     with mp.Manager() as mgr:
         results = mgr.dict()
-        mp.spawn(_waterz_worker, args=(world, dict(config), port, results), nprocs=world, join=True)
+        mp.spawn(_waterz_worker, args=(world, dict(config), port, results, grid), nprocs=world, join=True)
         return list(results[0])
 
 

@@ -303,4 +303,7 @@ class Trainer:
     def close(self):
         if self.model is not None:
             check(lib.bsmi_unet_train_end(self.model._h))
+            # the library dropped the bf16 / split-bf16 images of the old weights (re-packed from the trained ones on demand):
+            # the mirror's record of what is finalized follows, so a predict in those modes on the same Model re-packs
+            self.model._finalized.intersection_update({_lib.PREC_F32})
             self.model = None

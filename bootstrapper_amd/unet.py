@@ -107,7 +107,7 @@ class Model:
     x255 -> uint8 store (predict.py:147-154).
     """
 
-    def __init__(self, net_config, device=0, precision="bf16"):
+    def __init__(self, net_config, device=0, precision="bf16x3"):
         if isinstance(net_config, (str, os.PathLike)):
             with open(net_config) as f:
                 net_config = json.load(f)

@@ -21,6 +21,13 @@ The exchange steps of the path, and the only communication: the context margins 
 slab faces (point to point with the z-neighbours), the scored edges to rank 0, the LUT back to every rank.
 Blocks are independent inside a stage: they run side by side on `n_lanes` HIP streams, each lane with its own
 segmentation workspace; a stage ends with one host synchronisation.
+
+HBM residency.  Everything of a rank's slab stays on the device: 3 B (affinities) + 8 B (fragments) + 8 B (the interior copy the
+relabel reads) + 8 B per threshold (segmentations) per voxel -- 43 B per voxel at three thresholds, 39 GB for a 1024^3 slab --
+plus per block the node tables (label_cap x 32 B) and the scored edge list (edge_cap x 20 B), plus one workspace per lane.
+`SlabSegmenter.hbm_bytes()` gives the figure; the constructor refuses a slab that does not fit the device's free memory and
+says how many ranks the volume needs.  label_cap / edge_cap are starting sizes: a block that needs more makes the tables grow
+(`_regrow`), only its own part is redone.
 """
 import numpy as np
 import torch
@@ -38,12 +45,26 @@ def slab_layers(n_layers, world):
     return starts, counts
 
 
-def exchange_faces(low_out, high_out, low_in, high_in, rank, world, group=None):
-    """Send this rank's first / last layers to the z-neighbours and receive theirs: `low_out` goes to rank - 1 and
-    arrives there as `high_in`, `high_out` goes to rank + 1 and arrives as its `low_in`.  Device tensors travel over
-    RCCL point to point; under gloo (CPU tests, rehearsals) they are staged through host memory."""
+def rank_grid(world, layers, rows):
+    """(Rz, Ry): the ranks laid out over the block layers (z) and the block rows (y) of a volume so that as many of them as
+    possible have blocks (Rz <= layers, Ry <= rows, Rz * Ry <= world); among equals the grid with more z parts.  The reference
+    hands any block to any worker (post/watershed.py:118-153); here a rank owns a box of blocks and meets its neighbours at the
+    faces, so a flat volume (CREMI: one layer of 10 x 10 blocks) is cut along y."""
+    best = (1, 1)
+    for rz in range(1, min(int(world), int(layers)) + 1):
+        ry = min(int(world) // rz, int(rows))
+        if (rz * ry, rz) > (best[0] * best[1], best[0]):
+            best = (rz, ry)
+    return best
+
+
+def exchange_faces(low_out, high_out, low_in, high_in, lo_peer, hi_peer, group=None):
+    """Send this rank's first / last layers along one axis to its two neighbours and receive theirs: `low_out` goes to rank
+    `lo_peer` and arrives there as `high_in`, `high_out` goes to `hi_peer` and arrives as its `low_in` (a peer of None: the
+    volume ends there).  Device tensors travel over RCCL point to point; under gloo (CPU tests, rehearsals) they are staged
+    through host memory."""
     import torch.distributed as dist
-    if world == 1:
+    if lo_peer is None and hi_peer is None:
         return
     staged = dist.get_backend(group) != "nccl" and low_out.is_cuda
     ops, recvs = [], []
@@ -56,12 +77,12 @@ def exchange_faces(low_out, high_out, low_in, high_in, rank, world, group=None):
             buf = torch.empty(t.shape, dtype=t.dtype, device="cpu" if staged else t.device)
             ops.append(dist.P2POp(dist.irecv, buf, peer, group))
             recvs.append((t, buf))
-    if rank > 0:
-        post("send", low_out, rank - 1)
-        post("recv", low_in, rank - 1)
-    if rank < world - 1:
-        post("send", high_out, rank + 1)
-        post("recv", high_in, rank + 1)
+    if lo_peer is not None:
+        post("send", low_out, lo_peer)
+        post("recv", low_in, lo_peer)
+    if hi_peer is not None:
+        post("send", high_out, hi_peer)
+        post("recv", high_in, hi_peer)
     for req in dist.batch_isend_irecv(ops):
         req.wait()
     for dst, buf in recvs:
@@ -82,7 +103,7 @@ def stitch_components(nodes, edges, scores, thresholds):
 
 
 def gather_and_stitch(nodes, edges, scores, thresholds, rank=0, world=1, group=None):
-    """The one many-to-one step of the path: every rank's fragment ids (ascending; ranks hold ascending id ranges) and
+    """The one many-to-one step of the path: every rank's fragment ids (ascending per rank) and
     scored edges go to rank 0, which computes the components per threshold; every rank gets (all nodes, [components per
     threshold]) back -- the fragment-segment LUTs of post/watershed.py:184-186."""
     import torch.distributed as dist
@@ -98,7 +119,9 @@ def gather_and_stitch(nodes, edges, scores, thresholds, rank=0, world=1, group=N
         edges_all = np.concatenate([p[1] for p in parts])
         scores_all = np.concatenate([p[2] for p in parts])
         if nodes_all.size > 1 and not np.all(nodes_all[1:] > nodes_all[:-1]):
-            raise ValueError("fragment ids of the ranks are not in ascending order")
+            nodes_all = np.sort(nodes_all)   # ranks that share block layers (a y cut) hold interleaved id ranges
+            if not np.all(nodes_all[1:] > nodes_all[:-1]):
+                raise ValueError("two ranks report the same fragment id")
         luts[0] = (nodes_all, stitch_components(nodes_all, edges_all, scores_all, thresholds))
     if world > 1:
         dist.broadcast_object_list(luts, src=0, group=group)
@@ -133,7 +156,13 @@ class SlabSegmenter:
     def __init__(self, slab_shape, block, context, total_layers, layer0, thresholds=(0.2, 0.35, 0.5),
                  fragments_in_xy=True, min_seed_distance=10, filter_fragments=0.0, remove_debris=0, discretize_queue=256,
                  n_lanes=8, device=0, rank=0, world=1, group=None, edge_cap=1 << 17, label_cap=1 << 16, exchange_affs=True,
-                 epsilon_agglomerate=0.0, sigma=None, noise_eps=None, bias=None, noise_seed=0, seed_eps=None):
+                 epsilon_agglomerate=0.0, sigma=None, noise_eps=None, bias=None, noise_seed=0, seed_eps=None,
+                 grid=None, total_rows=None, row0=0, obj_group=None):
+        """slab_shape: this rank's box of the volume (whole blocks but for the volume's far faces).  The ranks form a grid
+        `grid` = (Rz, Ry) over z and y (default: (world, 1), slabs of block layers), rank = rz * Ry + ry; the volume has
+        `total_layers` block layers and `total_rows` block rows, this rank's first ones are `layer0`, `row0`.
+        obj_group: process group of the object collectives (edges to rank 0, LUT back); under an RCCL default group a gloo
+        group beside it, so that pickled objects do not travel through device tensors."""
         self.shape = tuple(int(s) for s in slab_shape)
         self.block = tuple(int(b) for b in block)
         self.ctx = tuple(int(c) for c in context)
@@ -145,6 +174,14 @@ class SlabSegmenter:
         self.shift = dict(sigma=sigma, noise_eps=noise_eps, bias=bias, seed_eps=seed_eps)
         self.noise_seed = int(noise_seed)
         self.rank, self.world, self.group = int(rank), int(world), group
+        self.obj_group = obj_group if obj_group is not None else group
+        self.grid = (int(world), 1) if grid is None else (int(grid[0]), int(grid[1]))
+        if self.grid[0] * self.grid[1] != self.world:
+            raise ValueError(f"rank grid {self.grid} for {self.world} ranks")
+        self.rz, self.ry = divmod(self.rank, self.grid[1])
+        # neighbours along z / y (None: the volume ends at that face)
+        self.peers = ((self.rank - self.grid[1] if self.rz > 0 else None, self.rank + self.grid[1] if self.rz < self.grid[0] - 1 else None),
+                      (self.rank - 1 if self.ry > 0 else None, self.rank + 1 if self.ry < self.grid[1] - 1 else None))
         # False: the caller fills the context margins of the affinities itself (a driver reads them from the dataset,
         # where also the data beyond the ROI is real); the fragments' margins are always exchanged
         self.exchange_affs = bool(exchange_affs)
@@ -152,21 +189,30 @@ class SlabSegmenter:
         self.boxes = shrink_blocks(self.shape, self.block)
         counts = self.counts = [-(-s // b) for s, b in zip(self.shape, self.block)]
         # global z-major block ids (`block.block_id` of the reference's tasks; daisy numbers differently)
-        self.block_ids = [((int(layer0) + iz) * counts[1] + iy) * counts[2] + ix
+        rows = counts[1] if total_rows is None else int(total_rows)
+        self.block_ids = [((int(layer0) + iz) * rows + (int(row0) + iy)) * counts[2] + ix
                           for iz in range(counts[0]) for iy in range(counts[1]) for ix in range(counts[2])]
-        self.total_blocks = int(total_layers) * counts[1] * counts[2]
+        self.total_blocks = int(total_layers) * rows * counts[2]
         self.nvb = int(np.prod(self.block))
         padded = tuple(s + 2 * c for s, c in zip(self.shape, self.ctx))
+        K = len(self.boxes)
+        read_vox = int(np.prod([min(b, s) + 2 * c for b, s, c in zip(self.block, self.shape, self.ctx)]))
+        self.edge_cap = max(64, min(int(edge_cap), 3 * read_vox))
+        self.label_cap = max(64, min(int(label_cap), self.nvb))
+        need = self.hbm_bytes(self.shape, self.ctx, len(self.thresholds), K, self.label_cap, self.edge_cap)
+        free, _total = torch.cuda.mem_get_info(self.dev)
+        free += torch.cuda.memory_reserved(self.dev) - torch.cuda.memory_allocated(self.dev)   # torch's cached, unused blocks count as free
+        if need > free:
+            per_layer = need / max(1, self.counts[0])
+            raise MemoryError(f"a slab of {self.shape} voxels needs {need / 2**30:.1f} GiB of HBM ({need / max(1, int(np.prod(self.shape))):.0f} B per voxel: "
+                              f"affinities, fragments, {len(self.thresholds)} segmentations, per-block tables) and {free / 2**30:.1f} GiB are free on "
+                              f"{self.dev}: give each rank at most {max(1, int(free // per_layer))} block layer(s), i.e. use more workers / GPUs")
         self.affs = torch.zeros((3,) + padded, dtype=torch.uint8, device=self.dev)
         self.frags = torch.zeros(padded, dtype=torch.int64, device=self.dev)
         # outputs of the stitch, allocated with the slab: a first stitch that allocates them pays for it inside whatever times
         # the pipeline (whole 1024^3 volume: 26 GB of segmentations + 8.6 GB of interior fragments, a second of hipMalloc)
         self.segs = torch.empty((len(self.thresholds),) + self.shape, dtype=torch.int64, device=self.dev)
         self._fr = torch.empty(self.shape, dtype=torch.int64, device=self.dev)
-        K = len(self.boxes)
-        read_vox = int(np.prod([min(b, s) + 2 * c for b, s, c in zip(self.block, self.shape, self.ctx)]))
-        self.edge_cap = max(64, min(int(edge_cap), 3 * read_vox))
-        self.label_cap = max(64, min(int(label_cap), self.nvb))
         self.nums = torch.zeros(K, dtype=torch.int64, device=self.dev)
         self.sizes = torch.zeros((K, self.label_cap), dtype=torch.int64, device=self.dev)
         self.sums = torch.zeros((K, self.label_cap, 3), dtype=torch.int64, device=self.dev)
@@ -185,6 +231,13 @@ class SlabSegmenter:
         self.nodes = None
         self.rag_edges = self.rag_scores = None
         self.luts = None
+
+    @staticmethod
+    def hbm_bytes(shape, ctx, n_thresholds, n_blocks, label_cap=1 << 16, edge_cap=1 << 17):
+        """device bytes of a slab (module docstring), the lanes' workspaces not included"""
+        vox = int(np.prod(shape))
+        padded = int(np.prod([s + 2 * c for s, c in zip(shape, ctx)]))
+        return 11 * padded + 8 * vox * (1 + n_thresholds) + n_blocks * (32 * label_cap + 20 * edge_cap + 40)
 
     # -- views ---------------------------------------------------------------------------
     def interior(self, t):
@@ -206,21 +259,43 @@ class SlabSegmenter:
 
     # -- exchange ------------------------------------------------------------------------
     def _exchange(self, t):
-        """context margins of `t` ([..., Zp, Yp, Xp]) at the slab's z faces <- the neighbours' outermost layers.  The
+        """context margins of `t` ([..., Zp, Yp, Xp]) at the faces shared with other ranks <- the neighbours' outermost layers.  The
         caller has made sure those layers are complete; -> an event on the current stream that fires when the margins are."""
-        c, Z = self.ctx[0], self.shape[0]
-        if self.world > 1 and c > 0 and (t is not self.affs or self.exchange_affs):
-            exchange_faces(t[..., c:2 * c, :, :], t[..., Z:Z + c, :, :], t[..., 0:c, :, :], t[..., Z + c:Z + 2 * c, :, :],
-                           self.rank, self.world, self.group)
+        if self.world > 1 and (t is not self.affs or self.exchange_affs):
+            # z faces first, then the y faces over the whole padded z extent: the margins just received travel on, which
+            # fills the corners with the diagonal neighbour's data
+            c, Z = self.ctx[0], self.shape[0]
+            if c > 0:
+                exchange_faces(t[..., c:2 * c, :, :], t[..., Z:Z + c, :, :], t[..., 0:c, :, :], t[..., Z + c:Z + 2 * c, :, :],
+                               self.peers[0][0], self.peers[0][1], self.group)
+            c, Y = self.ctx[1], self.shape[1]
+            if c > 0:
+                exchange_faces(t[..., :, c:2 * c, :], t[..., :, Y:Y + c, :], t[..., :, 0:c, :], t[..., :, Y + c:Y + 2 * c, :],
+                               self.peers[1][0], self.peers[1][1], self.group)
         ev = torch.cuda.Event()
         ev.record(torch.cuda.current_stream(self.dev))
         return ev
 
     # -- stages --------------------------------------------------------------------------
     def _sync(self):
+        """every lane drained and its workspace status read (which also clears it) -> the first overflow error, if any"""
+        err = None
         for lane in self.lanes:
             lane["stream"].synchronize()
-            lane["engine"].status()
+            try:
+                lane["engine"].status()
+            except _lib.BsmiError as exc:
+                if exc.code != _lib.ERR_OVERFLOW:
+                    raise
+                err = err or exc
+        return err
+
+    @staticmethod
+    def _only_edge_buffer(err):
+        """is `err` nothing but "the caller's edge buffer is too small" (flag 32 of bsmi_seg_status)?"""
+        import re
+        m = re.search(r"flags 0x([0-9a-f]+)", str(err))
+        return bool(m) and int(m.group(1), 16) == 32
 
     def _neighbours(self, k):
         """blocks whose write box touches the read box of block k (k itself included)"""
@@ -238,8 +313,11 @@ class SlabSegmenter:
 
     def _on_face(self, k):
         """does block k read context that belongs to another rank's slab?"""
-        iz = k // (self.counts[1] * self.counts[2])
-        return self.ctx[0] > 0 and ((self.rank > 0 and iz == 0) or (self.rank < self.world - 1 and iz == self.counts[0] - 1))
+        iz, r = divmod(k, self.counts[1] * self.counts[2])
+        iy = r // self.counts[2]
+        (zlo, zhi), (ylo, yhi) = self.peers
+        return ((self.ctx[0] > 0 and ((zlo is not None and iz == 0) or (zhi is not None and iz == self.counts[0] - 1))) or
+                (self.ctx[1] > 0 and ((ylo is not None and iy == 0) or (yhi is not None and iy == self.counts[1] - 1))))
 
     def _launch_fragments(self, k, wait=()):
         """post/blockwise/watershed_frags.py:196-246 for block k, asynchronous on its lane.  An all-zero read box yields
@@ -290,10 +368,17 @@ class SlabSegmenter:
     def _collect(self):
         """end of the two block stages: one synchronisation, overflow checks, the edges every block owns (the block that
         created the smaller-id fragment, see post/blockwise.py) to the host"""
-        self._sync()
+        err = self._sync()
         nums = self.nums.cpu().numpy()
-        if nums.max(initial=0) > self.label_cap or nums.max(initial=0) >= self.nvb:
-            raise _lib.BsmiError(_lib.ERR_OVERFLOW, f"a block produced {int(nums.max())} fragments (label_cap {self.label_cap})")
+        if nums.max(initial=0) >= self.nvb:   # ids are block id * voxels per block + label, as the reference's (watershed_frags.py:222-224)
+            raise _lib.BsmiError(_lib.ERR_OVERFLOW, f"a block produced {int(nums.max())} fragments: not below its {self.nvb} voxels")
+        n_edges = self.counts_dev[:, 0].cpu().numpy()
+        if (err is None or self._only_edge_buffer(err)) and (nums.max(initial=0) > self.label_cap or n_edges.max(initial=0) > self.edge_cap):
+            # the per-block tables were sized for typical blocks (label_cap fragments, edge_cap edges); a block needs more:
+            # grow them to what was measured and redo that block's part only (the reference has no such limit)
+            err = self._regrow(nums, n_edges)
+        if err is not None:
+            raise err
         self.block_nums = nums
         ne = self.counts_dev[:, 0]
         take = torch.arange(self.edge_cap, device=self.dev)[None, :] < ne[:, None]
@@ -302,6 +387,34 @@ class SlabSegmenter:
         self.rag_edges = self.edges[own].cpu().numpy().view(np.uint64)
         self.rag_scores = self.scores[own].cpu().numpy()
         return len(self.rag_scores)
+
+    def _regrow(self, nums, n_edges):
+        """Blocks with more fragments than `label_cap` or more edges than `edge_cap`: larger tables (what the fullest block
+        needs and a quarter more), node statistics / edge scoring of those blocks again.  -> a remaining overflow error or None"""
+        K = len(self.boxes)
+        if nums.max(initial=0) > self.label_cap:
+            old, self.label_cap = self.label_cap, min(self.nvb, int(nums.max()) * 5 // 4 + 64)
+            sizes = torch.zeros((K, self.label_cap), dtype=torch.int64, device=self.dev)
+            sums = torch.zeros((K, self.label_cap, 3), dtype=torch.int64, device=self.dev)
+            sizes[:, :old].copy_(self.sizes)
+            sums[:, :old].copy_(self.sums)
+            self.sizes, self.sums = sizes, sums
+            for k in np.nonzero(nums > old)[0]:
+                b, e = self.boxes[k]
+                lane = self.lanes[k % len(self.lanes)]
+                with torch.cuda.stream(lane["stream"]):
+                    lab = self.frags[tuple(slice(c + lo, c + hi) for c, lo, hi in zip(self.ctx, b, e))].contiguous()
+                    lane["engine"].label_stats(lab, self.block_ids[k] * self.nvb, self.label_cap, size=self.sizes[k], sums=self.sums[k])
+        if n_edges.max(initial=0) > self.edge_cap:
+            old, self.edge_cap = self.edge_cap, int(n_edges.max()) * 5 // 4 + 64
+            edges = torch.empty((K, self.edge_cap, 2), dtype=torch.int64, device=self.dev)
+            scores = torch.empty((K, self.edge_cap), dtype=torch.float32, device=self.dev)
+            edges[:, :old].copy_(self.edges)
+            scores[:, :old].copy_(self.scores)
+            self.edges, self.scores = edges, scores
+            for k in np.nonzero(n_edges > old)[0]:
+                self._launch_scores(int(k))
+        return self._sync()
 
     def run_blocks(self, ready=None, overlap=False):
         """Both block stages of the slab.  ready[k]: an event that fires when the affinities of blocks 0..k are in the
@@ -364,9 +477,10 @@ class SlabSegmenter:
                     score_what_can_be([j for j in nb[k] if j in inner_set])
         score_what_can_be(inner)
         if face:
-            for k in range(K):     # the outermost layers feed the neighbours' context
-                iz = k // (self.counts[1] * self.counts[2])
-                if iz == 0 or iz == self.counts[0] - 1:
+            for k in range(K):     # the outermost blocks feed the neighbours' context
+                iz, r = divmod(k, self.counts[1] * self.counts[2])
+                iy = r // self.counts[2]
+                if iz == 0 or iz == self.counts[0] - 1 or iy == 0 or iy == self.counts[1] - 1:
                     self.frag_done[k].synchronize()
             got = self._exchange(self.frags)
             score_what_can_be(face, (got,))
@@ -446,7 +560,7 @@ class SlabSegmenter:
         nodes = np.concatenate([np.arange(1, int(n) + 1, dtype=np.uint64) + np.uint64(bid * self.nvb)
                                 for n, bid in zip(self.block_nums, self.block_ids)] or [np.zeros(0, np.uint64)])
         self.nodes, self.luts = gather_and_stitch(nodes, self.rag_edges, self.rag_scores, self.thresholds, self.rank, self.world,
-                                                  self.group)
+                                                  self.obj_group)
         fr = self._fr
         fr.copy_(self.interior(self.frags))
         keys = torch.from_numpy(self.nodes.view(np.int64)).to(self.dev)

@@ -170,6 +170,18 @@ remove_debris = 12
     assert [r[0] for r in con.execute("SELECT id FROM nodes ORDER BY id").fetchall()] == nodes.tolist()
     con.close()
 
+    # five workers for 3 layers x 3 rows of blocks: a 2 x 2 grid of boxes is started (a worker owns whole blocks; the fifth would
+    # have none), cut along z and y -- the reference's daisy server works with any worker count, so must this
+    from bootstrapper_amd.post.watershed import worker_grid
+    from bootstrapper_amd.segment import get_seg_config
+    cfg5 = tmp_path / "seg5.toml"
+    cfg5.write_text(cfg.read_text().replace("blockwise = true", "blockwise = true\nnum_workers = 5")
+                    .replace("fragments\"", "fragments_w5\"").replace("segmentations\"", "segmentations_w5\"").replace("rag.db", "rag_w5.db"))
+    assert worker_grid(get_seg_config(str(cfg5), "ws")) == (2, 2)
+    written5 = run_segmentation(str(cfg5), "ws")
+    for a, b in zip(written, written5):
+        assert np.array_equal(open_ds(a)[:], open_ds(b)[:]), (a, b)
+
     # block_shape = "roi": one block, no context (post/watershed.py:357-363), same machinery
     cfg2 = tmp_path / "seg2.toml"
     cfg2.write_text(cfg.read_text().replace("blockwise = true", 'blockwise = true\nblock_shape = "roi"')

@@ -134,6 +134,38 @@ def test_full_block_blockwise_stages_bit_exact(full_block):
     assert np.array_equal(scores.cpu().numpy().view(np.uint32), s_ref.view(np.uint32))
 
 
+def test_full_net_volume_pipeline_vs_cpu_blockwise():
+    """The full 94.7 M-parameter net through VolumePipeline (the thing bench.py times) on a box of 2 x 2 x 2 blocks of 128^3
+    in the default precision: the slab's affinities are the blocks the model predicts one by one, and the fragments and the
+    three stitched segmentations are bit-equal to the CPU composition (oracle/blockwise_ref.cpu_blockwise) on those
+    affinities -- context reads across block faces, block ids, edge ownership and the global components at BASELINE size."""
+    from bootstrapper_amd.unet import Model, extract_block_reflect
+    from bootstrapper_amd.synth import synthetic_state_dict, synthetic_volume
+    from bootstrapper_amd.volume import VolumePipeline
+    from oracle.blockwise_ref import cpu_blockwise
+    from tests.test_lib_cpu import AFFS_NET_CONFIG as NC
+    m = Model(NC).load_state_dict(synthetic_state_dict(NC, 0))                  # default precision: bf16x3
+    vol = synthetic_volume((256, 256, 256), 0)
+    thr = [0.2, 0.35, 0.5]
+    pipe = VolumePipeline(m, (128, 128, 128), (14, 46, 46), (2, 2, 2), (16, 16, 16), thr, min_seed_distance=10, filter_fragments=0.1,
+                          remove_debris=64, n_lanes=8)
+    segs = pipe.run(vol)
+    affs = pipe.seg.interior(pipe.seg.affs).cpu().numpy()
+    for (z, y, x) in [(0, 0, 0), (1, 0, 1), (1, 1, 1)]:
+        off = [128 * z - 14, 128 * y - 46, 128 * x - 46]
+        blk = m.predict_u8(extract_block_reflect(vol, off, (156, 220, 220)))[0][:3].cpu().numpy()
+        assert np.array_equal(affs[:, 128 * z:128 * z + 128, 128 * y:128 * y + 128, 128 * x:128 * x + 128], blk), (z, y, x)
+    frags_ref, nodes, E, Sc, segs_ref = cpu_blockwise(affs, (128, 128, 128), (16, 16, 16), 10, 0.1, 64, thr, 256,
+                                                      workers=min(16, os.cpu_count() or 1))
+    assert len(nodes) > 5000 and len(E) > len(nodes)
+    assert np.array_equal(pipe.seg.interior(pipe.seg.frags).cpu().numpy().view(np.uint64), frags_ref)
+    assert np.array_equal(pipe.seg.nodes, nodes)
+    for t in range(len(thr)):
+        assert np.array_equal(segs[t].cpu().numpy().view(np.uint64), segs_ref[t]), thr[t]
+    counts = [len(np.unique(s)) for s in segs_ref]
+    assert counts[0] >= counts[1] >= counts[2] and counts[2] < len(nodes)
+
+
 @pytest.mark.parametrize("variant,env", [
     ("raster-halo kernel", {"BSMI_USE_RH": "1"}),
     ("raster-halo kernel, persistent split-K tail", {"BSMI_USE_RH": "1", "BSMI_SK_GRID": "8", "BSMI_TILE_EFF": "0.01,0.01,0.01,1,0.01"}),

@@ -92,7 +92,8 @@ def _volume_worker(rank, world, port, q):
     vol = torch.arange(3 * world * Z * 4 * 5, dtype=torch.int64).reshape(3, world * Z, 4, 5)
     slab = torch.zeros(3, Z + 2 * c, 4, 5, dtype=torch.int64)
     slab[:, c:c + Z] = vol[:, rank * Z:(rank + 1) * Z]
-    exchange_faces(slab[:, c:2 * c], slab[:, Z:Z + c], slab[:, 0:c], slab[:, Z + c:Z + 2 * c], rank, world)
+    exchange_faces(slab[:, c:2 * c], slab[:, Z:Z + c], slab[:, 0:c], slab[:, Z + c:Z + 2 * c], rank - 1 if rank > 0 else None,
+                   rank + 1 if rank < world - 1 else None)
     want = torch.zeros_like(slab)
     lo, hi = max(rank * Z - c, 0), min((rank + 1) * Z + c, world * Z)
     want[:, lo - (rank * Z - c):hi - (rank * Z - c)] = vol[:, lo:hi]
@@ -136,8 +137,55 @@ def test_slab_exchange_and_stitch_gloo(world):
         assert 1 < ncomp[1] < ncomp[0] < 40
 
 
-def test_slab_layers():
-    from bootstrapper_amd.volume import slab_layers
+def test_slab_layers_and_rank_grid():
+    from bootstrapper_amd.volume import slab_layers, rank_grid
     assert slab_layers(8, 1) == ([0], [8])
     assert slab_layers(8, 3) == ([0, 3, 6], [3, 3, 2])
     assert slab_layers(2, 4) == ([0, 1, 2, 2], [1, 1, 0, 0])
+    # ranks over block layers x block rows: every started rank has blocks; a flat volume is cut along y
+    assert rank_grid(2, 4, 3) == (2, 1) and rank_grid(8, 8, 8) == (8, 1)
+    assert rank_grid(8, 1, 10) == (1, 8)          # CREMI-shaped: one layer of 10 x 10 blocks
+    assert rank_grid(8, 3, 10) == (2, 4)          # three layers on eight GPUs: nobody idle
+    assert rank_grid(8, 1, 3) == (1, 3) and rank_grid(7, 2, 2) == (2, 2) and rank_grid(1, 5, 5) == (1, 1)
+
+
+def _grid_worker(rank, world, port, q, grid):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from bootstrapper_amd.volume import exchange_faces, slab_layers
+    # a (Z, Y, X) volume cut into grid[0] x grid[1] boxes with context c: z faces first, then y faces over the padded z extent
+    c, Z, Y, X = 2, 4, 6, 5
+    gz, gy = grid
+    vol = torch.arange(gz * Z * gy * Y * X, dtype=torch.int64).reshape(gz * Z, gy * Y, X) + 1
+    rz, ry = divmod(rank, gy)
+    box = torch.zeros(Z + 2 * c, Y + 2 * c, X, dtype=torch.int64)
+    box[c:c + Z, c:c + Y] = vol[rz * Z:(rz + 1) * Z, ry * Y:(ry + 1) * Y]
+    zlo, zhi = (rank - gy if rz > 0 else None), (rank + gy if rz < gz - 1 else None)
+    ylo, yhi = (rank - 1 if ry > 0 else None), (rank + 1 if ry < gy - 1 else None)
+    exchange_faces(box[c:2 * c], box[Z:Z + c], box[0:c], box[Z + c:Z + 2 * c], zlo, zhi)
+    exchange_faces(box[:, c:2 * c], box[:, Y:Y + c], box[:, 0:c], box[:, Y + c:Y + 2 * c], ylo, yhi)
+    want = torch.zeros_like(box)
+    padded = torch.zeros(gz * Z + 2 * c, gy * Y + 2 * c, X, dtype=torch.int64)
+    padded[c:-c, c:-c] = vol
+    want.copy_(padded[rz * Z:rz * Z + Z + 2 * c, ry * Y:ry * Y + Y + 2 * c])
+    q.put((rank, bool(torch.equal(box, want))))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("grid", [(2, 2), (1, 3), (3, 2)])
+def test_face_exchange_on_a_rank_grid_gloo(grid):
+    """The two-phase face exchange of SlabSegmenter on a (Rz, Ry) grid of ranks: every box ends with its whole context
+    margin, edges and corners (the diagonal neighbour's voxels) included, zeros beyond the volume."""
+    world = grid[0] * grid[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29900 + os.getpid() % 50 + 7 * world
+    ps = [ctx.Process(target=_grid_worker, args=(r, world, port, q, grid)) for r in range(world)]
+    for p in ps:
+        p.start()
+    res = sorted(q.get(timeout=180) for _ in ps)
+    for p in ps:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert all(ok for _, ok in res), res

@@ -178,6 +178,32 @@ def test_resume_restores_optimizer_state_and_steps_repeat(golden_dir):
         assert d_rr < 1e-4 and d_resume < 1e-4 and d_nostate > 10 * max(d_rr, d_resume, 1e-5)
 
 
+def test_predict_after_training_uses_the_trained_weights(golden_dir):
+    """Trainer.close() hands the trained parameters back to the Model: a predict in the split-bf16 (or bf16) mode on the same
+    Model afterwards re-packs its weight images from them -- equal to a fresh Model loaded with the trained parameters."""
+    from bootstrapper_amd.unet import Model
+    from bootstrapper_amd.training import Trainer
+    d = np.load(os.path.join(golden_dir, "train_affs_f4i2.npz"))
+    meta = json.loads(bytes(d["config"]).decode())
+    sd = {k[3:]: d[k] for k in d.files if k.startswith("w0:")}
+    nc = _net_config(meta)
+    batch = {"raw": torch.from_numpy(d["x"]).cuda(), "gt_affs": torch.from_numpy(d["gt0"][0]).cuda(),
+             "affs_weights": torch.from_numpy(d["w0"][0]).cuda()}
+    m = Model(nc).load_state_dict(sd)                       # default precision (bf16x3): its images exist before training
+    x = torch.from_numpy(d["x"]).cuda()[None, None]
+    before = m(x).clone()
+    tr = Trainer(m, meta["in_shape"], lr=1e-2)
+    for _ in range(3):
+        tr.training_step(batch)
+    trained = {k: tr.read(k).reshape(sd[k].shape) for k in sd}
+    tr.close()
+    for prec in ("bf16x3", "bf16", "f32"):
+        got = m.set_precision(prec)(x)
+        want = Model(nc, precision=prec).load_state_dict(trained)(x)
+        assert torch.equal(got, want), prec
+    assert float((m.set_precision("bf16x3")(x) - before).abs().max()) > 1e-4    # and they are not the old weights
+
+
 def test_ranks_draw_different_samples(tmp_path):
     """`bs train` seeds its sample stream with 42 + rank: two data-parallel ranks must not train on the same crops."""
     from bootstrapper_amd.train import make_sample_source

@@ -56,15 +56,18 @@ def test_slab_segmenter_equals_cpu_blockwise(shape, block, ctx, lanes, overlap):
     assert size[k] == int(m.sum()) and np.allclose(pos[k], np.argwhere(m).mean(axis=0))
 
 
-@pytest.mark.parametrize("nproc", [2, 4])
-def test_ranks_equal_one_rank(tmp_path, nproc):
-    """Several ranks (gloo, all on cuda:0), each with its share of the four block layers -- two layers each, or one layer
-    each so that every block reads a neighbour's context and the middle ranks exchange both faces (the shape of the
-    8-GPU benchmark job): face exchange of affinities and fragments, edges gathered on rank 0, LUT broadcast -- the
-    fragments and segmentations of the slabs put together are bit-equal to the one-rank run and to the CPU composition."""
+@pytest.mark.parametrize("nproc,grid", [(2, "2x1"), (4, "4x1"), (3, "1x3"), (4, "2x2")])
+def test_ranks_equal_one_rank(tmp_path, nproc, grid):
+    """Several ranks (gloo, all on cuda:0), each with its box of the 4 x 3 grid of block layers and block rows -- slabs of
+    two layers or of one layer each (every block then reads a neighbour's context and the middle ranks exchange both faces:
+    the shape of the 8-GPU benchmark job), a flat cut along y (one rank per block row: what a one-layer volume needs), and
+    a 2 x 2 grid (corners come from the diagonal neighbour): face exchange of affinities and fragments, edges gathered on
+    rank 0, LUT broadcast -- the fragments and segmentations of the boxes put together are bit-equal to the one-rank run
+    and to the CPU composition."""
     env = dict(os.environ, MASTER_ADDR="127.0.0.1")
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(nproc), "--master-addr",
-                        "127.0.0.1", "--master-port", str(29621 + nproc), os.path.join(ROOT, "tests", "volume_worker.py"), str(tmp_path)],
+                        "127.0.0.1", "--master-port", str(29621 + nproc + 10 * int(grid[0])), os.path.join(ROOT, "tests", "volume_worker.py"),
+                        str(tmp_path), grid],
                        env=env, capture_output=True, text=True, timeout=900, cwd=ROOT)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
     verdict = json.loads((tmp_path / "verdict.json").read_text())
