@@ -378,6 +378,9 @@ def main():
     ap.add_argument("--seg-lanes", type=int, default=16, help="blocks of a segmentation stage in flight side by side")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="process-group backend for N > 1: nccl (= RCCL, the real thing) or gloo (rehearsal on a box with fewer GPUs)")
+    ap.add_argument("--force-dist", action="store_true",
+                    help="one rank, but with the process group of an N > 1 run: RCCL initialised, the gloo side group for object collectives, "
+                         "the barrier and the max-over-ranks reduction executed (a rehearsal of the distributed plumbing on a one-GPU box)")
     ap.add_argument("--overlap", action="store_true",
                     help="start a block's segmentation as soon as the blocks it reads are predicted (default: stage by stage; +3 %% end to end, conv launches 8 %% slower)")
     ap.add_argument("--no-segment", action="store_true", help="predict only (diagnostic; not the headline metric)")
@@ -407,12 +410,30 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     import torch.distributed as dist
-    if world > 1:
+    use_dist = world > 1 or args.force_dist
+    obj_group = None
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if world == 1:
+            os.environ.setdefault("MASTER_PORT", "29555")
+            os.environ.setdefault("RANK", "0")
+            os.environ.setdefault("WORLD_SIZE", "1")
         if args.backend == "nccl":
             dist.init_process_group("nccl", device_id=dev)
+            # pickled objects (edge lists to rank 0, LUTs back) travel through a gloo group beside the RCCL one
+            obj_group = dist.new_group(backend="gloo")
         else:
             dist.init_process_group("gloo")
+        # the collectives of the volume pipeline once before anything is timed: object gather / broadcast on the side group,
+        # a device all-reduce on the default one
+        parts = [None] * world
+        dist.all_gather_object(parts, {"rank": rank, "device": local_rank}, group=obj_group)
+        hello = [parts if rank == 0 else None]
+        dist.broadcast_object_list(hello, src=0, group=obj_group)
+        assert [p["rank"] for p in hello[0]] == list(range(world))
+        one = torch.ones(1, device=dev if args.backend == "nccl" else "cpu")
+        dist.all_reduce(one)
+        assert int(one.item()) == world
 
     from bootstrapper_amd.unet import Model, extract_block_reflect
     from bootstrapper_amd.synth import synthetic_state_dict, synthetic_volume
@@ -430,7 +451,7 @@ def main():
 
     def barrier():
         torch.cuda.synchronize(dev)
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize(dev)
 
@@ -438,9 +459,9 @@ def main():
     seg_kw = dict(min_seed_distance=10, filter_fragments=FILTER_FRAGMENTS, remove_debris=REMOVE_DEBRIS)
     # (the timed pipeline's slabs are allocated first, so that nothing but the barrier lies between the warm-up and the timed region)
     pipe = VolumePipeline(model, OUT_BLOCK, CONTEXT, job, SEG_CONTEXT, THRESHOLDS, n_lanes=args.seg_lanes, device=local_rank,
-                          rank=rank, world=world, segment=not args.no_segment, overlap=args.overlap, **seg_kw)
+                          rank=rank, world=world, segment=not args.no_segment, overlap=args.overlap, obj_group=obj_group, **seg_kw)
     warm = VolumePipeline(model, OUT_BLOCK, CONTEXT, (max(1, args.warmup), 1, 1), SEG_CONTEXT, THRESHOLDS, n_lanes=args.seg_lanes,
-                          device=local_rank, rank=rank, world=world, segment=not args.no_segment, **seg_kw)
+                          device=local_rank, rank=rank, world=world, segment=not args.no_segment, obj_group=obj_group, **seg_kw)
     warm.run(vol)
     del warm
     if not args.no_segment:
@@ -468,7 +489,7 @@ def main():
             raise SystemExit("the segmentation-only pass does not reproduce the segmentation of the timed run")
         del first, again
 
-    if world > 1:
+    if use_dist:
         t = torch.tensor([dt, t_pred, t_seg], dtype=torch.float64, device=dev if args.backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt, t_pred, t_seg = (float(v) for v in t.tolist())
@@ -577,7 +598,7 @@ def main():
         out["drivers"]["resident_Mvoxels_per_s"] = value
     if rank == 0:
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
 

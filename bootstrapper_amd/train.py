@@ -164,6 +164,65 @@ class SampleSource:
         raise RuntimeError("no training location with at least 5 % labelled voxels found")
 
 
+class PrefetchSource:
+    """Batches produced ahead of the training thread (reference training.py:107-114: `DataLoader(dataset, num_workers=8,
+    persistent_workers=True, pin_memory=True)`): a producer thread walks `source` -- Zarr chunk decoding runs in libbsmi's
+    native threads without the GIL, the target kernels on a side stream -- and keeps up to `depth` finished batches queued,
+    so a 20 ms training step never waits for crops and targets.  One producer: the batches come in the source's own order
+    (same seed, same sequence as the source used directly)."""
+
+    def __init__(self, source, depth=4, device=0):
+        import queue
+        import threading
+        self.source = source
+        self.dev = torch.device("cuda", device)
+        self.q = queue.Queue(maxsize=max(1, int(depth)))
+        self.stream = torch.cuda.Stream(self.dev)
+        self._stop = False
+        self.thread = threading.Thread(target=self._run, name="bsmi-samples", daemon=True)
+        self.thread.start()
+
+    def _run(self):
+        try:
+            with torch.cuda.stream(self.stream):
+                for batch in self.source:
+                    ev = torch.cuda.Event()
+                    ev.record(self.stream)
+                    while not self._stop:
+                        try:
+                            self.q.put((batch, ev), timeout=0.1)
+                            break
+                        except Exception:  # noqa: BLE001 - queue.Full: the trainer is busy, try again
+                            continue
+                    if self._stop:
+                        return
+        except BaseException as exc:  # noqa: BLE001 - handed to the training thread
+            self.q.put(exc)
+
+    def __iter__(self):
+        return self
+
+    def __next__(self):
+        item = self.q.get()
+        if isinstance(item, BaseException):
+            raise item
+        batch, ev = item
+        ev.synchronize()   # host-side: a stream parked behind a device-side wait slows the kernels that run meanwhile (DESIGN 6)
+        cur = torch.cuda.current_stream(self.dev)
+        for t in batch.values():
+            t.record_stream(cur)   # allocated on the producer's stream, used on the trainer's
+        return batch
+
+    def close(self):
+        self._stop = True
+        try:
+            while True:
+                self.q.get_nowait()
+        except Exception:  # noqa: BLE001 - queue.Empty
+            pass
+        self.thread.join(timeout=5)
+
+
 def make_sample_source(config, net_config, device=0, rank=0):
     """The built-in sample stream of `bs train` for this rank: seed 42 + rank, so that data-parallel ranks see different
     samples (with one seed for all, the averaged gradient would be the single-rank gradient computed N times)."""
@@ -249,7 +308,14 @@ def run_training(config_file, device=0, batches=None, log=print):
     if batches is None:
         log("note: the reference's gunpowder augmentations are not part of this engine; samples are random crops")
         batches = make_sample_source(config, net_config, device, rank)
-    n = fit(trainer, batches, max_iterations, int(config.get("save_checkpoints_every", 0)), setup_dir, log=log, start_iteration=done,
-            save_snapshots_every=int(config.get("save_snapshots_every", 0)), voxel_size=config.get("voxel_size"))
+        depth = int(config.get("prefetch", 4))   # an addition to the reference's train config: batches kept ready (0: inline)
+        if depth > 0:
+            batches = PrefetchSource(batches, depth, device)
+    try:
+        n = fit(trainer, batches, max_iterations, int(config.get("save_checkpoints_every", 0)), setup_dir, log=log, start_iteration=done,
+                save_snapshots_every=int(config.get("save_snapshots_every", 0)), voxel_size=config.get("voxel_size"))
+    finally:
+        if isinstance(batches, PrefetchSource):
+            batches.close()
     trainer.close()
     return n

@@ -591,7 +591,7 @@ class VolumePipeline:
 
     def __init__(self, model, out_block, net_context, job_blocks, seg_context=(16, 16, 16), thresholds=(0.2, 0.35, 0.5),
                  min_seed_distance=10, filter_fragments=0.0, remove_debris=0, n_lanes=16, device=0, rank=0, world=1,
-                 group=None, job_origin=(0, 0, 0), segment=True, overlap=False):
+                 group=None, job_origin=(0, 0, 0), segment=True, overlap=False, obj_group=None):
         """job_blocks: (layers per rank, blocks in y, blocks in x): the job is `world` such slabs stacked along z,
         its first voxel at `job_origin` of the raw volume."""
         self.model = model
@@ -608,7 +608,7 @@ class VolumePipeline:
         self.pred_stream = predict_stream(self.dev)
         self.seg = SlabSegmenter(slab, self.out_block, seg_context if segment else (0, 0, 0), self.job_blocks[0] * self.world,
                                  self.job_blocks[0] * self.rank, thresholds, True, min_seed_distance, filter_fragments,
-                                 remove_debris, 256, n_lanes if segment else 1, device, rank, world, group)
+                                 remove_debris, 256, n_lanes if segment else 1, device, rank, world, group, obj_group=obj_group)
         self.segment = bool(segment)
         self.overlap = bool(overlap)
         self.t_predict = 0.0

@@ -148,8 +148,24 @@ def test_mirror_api_generator():
     f3, n3, seeds3 = watershed_from_affinities(torch.from_numpy(af).cuda().double(), fragments_in_xy=False, return_seeds=True, min_seed_distance=5)
     r3, rn3, rs3 = S.ws_fragments_u8(affs, False, 5, return_seeds=True)
     assert n3 == rn3 and np.array_equal(f3.cpu().numpy().view(np.uint64), r3) and np.array_equal(seeds3.cpu().numpy().view(np.uint64), rs3)
-    with pytest.raises(ValueError, match="exactly uint8 / 255"):
-        watershed_from_affinities(af + np.float32(1e-3), fragments_in_xy=True)
+    # anything else -- shifted / continuous floats, more than three channels -- is reduced to ws.py's own boundary mask first
+    # (ws.py:64,77 and :100: the 3-D mode takes the mean over ALL channels); the oracle is fed that mask, computed with numpy
+    shifted = af + rng.normal(0, 0.05, af.shape).astype(np.float32)
+    f4, n4 = watershed_from_affinities(shifted, fragments_in_xy=True, min_seed_distance=4)
+    m4 = (0.5 * (shifted[-1] + shifted[-2]) > 0.5).astype(np.uint8) * 255
+    r4, rn4 = S.ws_fragments_u8(np.stack([m4] * 3), True, 4)
+    assert n4 == rn4 and np.array_equal(f4.cpu().numpy().view(np.uint64), r4)
+    five = np.concatenate([shifted, shifted[:2] * np.float32(0.8)]).astype(np.float32)
+    f5, n5 = watershed_from_affinities(five, fragments_in_xy=False, min_seed_distance=5)
+    m5 = (np.mean(five, axis=0) > 0.5).astype(np.uint8) * 255
+    r5, rn5 = S.ws_fragments_u8(np.stack([m5] * 3), False, 5)
+    assert n5 == rn5 and np.array_equal(f5.cpu().numpy().view(np.uint64), r5)
+    assert not np.array_equal(m5, (np.mean(five[-3:], axis=0) > 0.5).astype(np.uint8) * 255)    # not the last three channels
+    u5 = (np.clip(five, 0, 1) * 255).astype(np.uint8)
+    f6, n6 = watershed_from_affinities(u5, max_affinity_value=255, fragments_in_xy=False, min_seed_distance=5)
+    m6 = (np.mean(u5, axis=0) > 0.5 * 255).astype(np.uint8) * 255
+    r6, rn6 = S.ws_fragments_u8(np.stack([m6] * 3), False, 5)
+    assert n6 == rn6 and np.array_equal(f6.cpu().numpy().view(np.uint64), r6)
     ref = S.agglomerate_mean_u8(affs, ref_frags, [0.2, 0.5])
     work = frags.clone()
     for seg, r in zip(agglomerate(af, [0.2, 0.5], fragments=work), ref):

@@ -220,6 +220,26 @@ def test_ranks_draw_different_samples(tmp_path):
     cfg = {"samples": [{"raw": f"{store}/raw", "labels": f"{store}/labels"}]}
     a, b, a2 = (next(make_sample_source(cfg, nc, 0, r)) for r in (0, 1, 0))
     assert torch.equal(a["raw"], a2["raw"]) and not torch.equal(a["raw"], b["raw"])
+    # the producer thread of `bs train` (training.py:107-114's loader workers): the same batches in the same order, ready ahead
+    from bootstrapper_amd.train import PrefetchSource
+    inline = make_sample_source(cfg, nc, 0, 0)
+    ahead = PrefetchSource(make_sample_source(cfg, nc, 0, 0), depth=3)
+    try:
+        for _ in range(7):
+            x, y = next(inline), next(ahead)
+            assert set(x) == set(y) and all(torch.equal(x[k], y[k]) for k in x)
+    finally:
+        ahead.close()
+    assert not ahead.thread.is_alive()
+
+    class Broken:
+        def __iter__(self):
+            return self
+
+        def __next__(self):
+            raise ValueError("no samples")
+    with pytest.raises(ValueError, match="no samples"):     # a failure in the producer reaches the training thread
+        next(PrefetchSource(Broken()))
 
 
 def test_full_net_training_step_vs_cpu_oracle():
