@@ -84,6 +84,8 @@ def _load():
         "bsmi_rag_agglomerate_u8": (i32, [p, vp, vp, i64p, C.c_float, C.c_int, vp]),
         "bsmi_rag_edge_stats": (i32, [p, vp, vp, C.c_uint64, vp]),
         "bsmi_agglomerate_mean_u8": (i32, [p, vp, vp, i64p, C.POINTER(C.c_float), i32, vp, vp]),
+        "bsmi_agglomerate_hist_u8": (i32, [p, vp, vp, i64p, C.POINTER(C.c_float), i32, i32, i32, vp, vp]),
+        "bsmi_agglomerate_hist_graph": (i32, [C.c_uint32, C.c_uint32, vp, vp, vp, i32, i32, C.POINTER(C.c_float), i32, vp]),
         "bsmi_frag_postprocess_u8": (i32, [p, vp, vp, i64p, C.c_double, C.c_int64, i64p, i64p, C.c_uint64, vp, vp, vp]),
         "bsmi_label_stats": (i32, [p, vp, i64p, C.c_uint64, C.c_uint64, vp, vp, vp]),
         "bsmi_rag_merge_scores_u8": (i32, [p, vp, vp, i64p, C.c_float, C.c_int, vp, vp, C.c_uint64, vp, vp, vp, vp]),

@@ -23,6 +23,12 @@
 #include "common.h"
 
 namespace bsmi {
+// agglo_host.cpp: the merge loop of the histogram-quantile scorers
+void host_agglomerate_hist(uint32_t nn, uint32_t ne, const uint32_t* eu, const uint32_t* ev, uint32_t* hist, int quantile,
+                           int init_with_max, const float* thresholds, int nthr, uint32_t* roots_out);
+}
+
+namespace bsmi {
 
 // ------------------------------------------------------------------------------------------
 // watershed fragments
@@ -602,6 +608,37 @@ __global__ void agg_compact_kernel(AggWs w) {
     w.hvals[s] = e;
     w.enextu[e] = atomicExch(&w.head[u], e);
     w.enextv[e] = atomicExch(&w.head[v], e);
+  }
+}
+
+// Histogram-quantile scorers (reference post/watershed.py:230-243): the 256-bin histogram of every edge's affinities, in a
+// second scan once the edges are numbered (hist [ne][256]; the merge loop of these scorers runs on the host, agglo_host.cpp).
+__global__ void agg_hist_kernel(const uint8_t* __restrict__ affs, const uint64_t* __restrict__ frags, int D, int H, int W, AggWs w,
+                                uint32_t* __restrict__ hist) {
+  if (w.counters[3]) return;
+  const size_t n = (size_t)D * H * W;
+  const size_t hw = (size_t)H * W;
+  for (size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x; p < n; p += (size_t)gridDim.x * blockDim.x) {
+    const uint64_t f1 = frags[p];
+    if (!f1) continue;
+    const int x = (int)(p % W);
+    const int y = (int)((p / W) % H);
+    const int z = (int)(p / hw);
+    const uint32_t r1 = w.rank_of_id[f1];
+    const bool ok[3] = {z > 0, y > 0, x > 0};
+    const size_t st[3] = {hw, (size_t)W, 1};
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+      if (!ok[d]) continue;
+      const uint64_t f2 = frags[p - st[d]];
+      if (!f2 || f2 == f1) continue;
+      const uint32_t r2 = w.rank_of_id[f2];
+      const uint32_t u = r1 < r2 ? r1 : r2, v = r1 < r2 ? r2 : r1;
+      const uint64_t key = ((uint64_t)u << 32) | v;
+      uint32_t slot = (uint32_t)hmix(key) & (w.hcap - 1);
+      while (w.hkeys[slot] != key) slot = (slot + 1) & (w.hcap - 1);  // present: agg_edges_kernel inserted every pair
+      atomicAdd(&hist[(size_t)w.hvals[slot] * 256 + affs[(size_t)d * n + p]], 1u);
+    }
   }
 }
 
@@ -2247,6 +2284,66 @@ int bsmi_agglomerate_mean_u8(bsmi_seg* h, const uint8_t* affs_dev, const uint64_
   hipLaunchKernelGGL(agg_merge_kernel, dim3(8), dim3(64), 0, s, g, thr, n_thresholds);
   hipLaunchKernelGGL(agg_relabel_kernel, dim3(grid), dim3(bs), 0, s, frags_dev, n, n_thresholds, g, segs_dev);
   BSMI_HIP(hipGetLastError());
+  return BSMI_OK;
+}
+
+int bsmi_agglomerate_hist_u8(bsmi_seg* h, const uint8_t* affs_dev, const uint64_t* frags_dev, const int64_t shape[3],
+                             const float* thresholds_host, int n_thresholds, int quantile, int init_with_max, uint64_t* segs_dev,
+                             void* stream) {
+  int rc = check_seg_shape(h, shape);
+  if (rc) return rc;
+  if (!affs_dev || !frags_dev || !thresholds_host || !segs_dev) BSMI_FAIL(BSMI_ERR_INVALID, "null argument");
+  if (n_thresholds < 1 || n_thresholds > kMaxThresholds) BSMI_FAIL(BSMI_ERR_INVALID, "1..%d thresholds supported", kMaxThresholds);
+  if (quantile < 0 || quantile > 100) BSMI_FAIL(BSMI_ERR_INVALID, "quantile %d outside 0..100", quantile);
+  for (int i = 0; i < n_thresholds; ++i) {
+    if (!(thresholds_host[i] >= 0.f)) BSMI_FAIL(BSMI_ERR_INVALID, "thresholds must be >= 0");
+    if (i && thresholds_host[i] < thresholds_host[i - 1]) BSMI_FAIL(BSMI_ERR_INVALID, "thresholds must be ascending");
+  }
+  BSMI_HIP(hipSetDevice(h->device));
+  hipStream_t s = (hipStream_t)stream;
+  const int D = (int)shape[0], H = (int)shape[1], W = (int)shape[2];
+  const size_t n = (size_t)D * H * W;
+  AggWs& g = h->agg;
+  // region graph on the device, as in bsmi_agglomerate_mean_u8
+  BSMI_HIP(hipMemsetAsync(g.counters, 0, 8 * sizeof(uint32_t), s));
+  BSMI_HIP(hipMemsetAsync(g.maxid, 0, sizeof(uint64_t), s));
+  const int bs = 1024;
+  const int grid = (int)std::min<size_t>((n + bs - 1) / bs, (size_t)seg_scan_grid());
+  hipLaunchKernelGGL(seg_clear_kernel, dim3(grid), dim3(bs), 0, s, g);
+  hipLaunchKernelGGL(agg_maxid_kernel, dim3(grid), dim3(bs), 0, s, frags_dev, n, g);
+  hipLaunchKernelGGL(agg_mark_kernel, dim3(grid), dim3(bs), 0, s, frags_dev, n, g);
+  hipLaunchKernelGGL(agg_rank_kernel, dim3(1), dim3(1024), 0, s, g);
+  hipLaunchKernelGGL(agg_edges_kernel<false>, dim3(grid), dim3(bs), 0, s, affs_dev, frags_dev, D, H, W, g);
+  hipLaunchKernelGGL(agg_compact_kernel, dim3(grid), dim3(bs), 0, s, g);
+  BSMI_HIP(hipGetLastError());
+  uint32_t c[8];
+  BSMI_HIP(hipMemcpyAsync(c, g.counters, sizeof c, hipMemcpyDeviceToHost, s));
+  BSMI_HIP(hipStreamSynchronize(s));
+  if (c[3]) BSMI_FAIL(BSMI_ERR_OVERFLOW, "agglomeration workspace overflow (flags 0x%x: 1 id range, 2 nodes, 4 hash, 8 edges)", c[3]);
+  const uint32_t nn = c[0], ne = c[1];
+  // per-edge histograms: second scan, then the merge loop on the host (agglo_host.cpp), then the relabel on the device
+  std::vector<uint32_t> eu(ne), ev(ne), hist((size_t)ne * 256), roots((size_t)n_thresholds * std::max(nn, 1u));
+  if (ne) {
+    uint32_t* hist_dev = nullptr;
+    BSMI_HIP(hipMalloc((void**)&hist_dev, (size_t)ne * 256 * sizeof(uint32_t)));
+    hipError_t err = hipMemsetAsync(hist_dev, 0, (size_t)ne * 256 * sizeof(uint32_t), s);
+    if (err == hipSuccess) {
+      hipLaunchKernelGGL(agg_hist_kernel, dim3(grid), dim3(bs), 0, s, affs_dev, frags_dev, D, H, W, g, hist_dev);
+      err = hipGetLastError();
+    }
+    if (err == hipSuccess) err = hipMemcpyAsync(hist.data(), hist_dev, hist.size() * sizeof(uint32_t), hipMemcpyDeviceToHost, s);
+    if (err == hipSuccess) err = hipMemcpyAsync(eu.data(), g.eu, ne * sizeof(uint32_t), hipMemcpyDeviceToHost, s);
+    if (err == hipSuccess) err = hipMemcpyAsync(ev.data(), g.ev, ne * sizeof(uint32_t), hipMemcpyDeviceToHost, s);
+    if (err == hipSuccess) err = hipStreamSynchronize(s);
+    (void)hipFree(hist_dev);
+    BSMI_HIP(err);
+  }
+  host_agglomerate_hist(nn, ne, eu.data(), ev.data(), hist.data(), quantile, init_with_max, thresholds_host, n_thresholds, roots.data());
+  for (int t = 0; t < n_thresholds && nn; ++t)
+    BSMI_HIP(hipMemcpyAsync(g.roots + (size_t)t * g.node_cap, roots.data() + (size_t)t * nn, nn * sizeof(uint32_t), hipMemcpyHostToDevice, s));
+  hipLaunchKernelGGL(agg_relabel_kernel, dim3(grid), dim3(bs), 0, s, frags_dev, n, n_thresholds, g, segs_dev);
+  BSMI_HIP(hipGetLastError());
+  BSMI_HIP(hipStreamSynchronize(s));  // `roots` (host memory) must outlive the copies
   return BSMI_OK;
 }
 

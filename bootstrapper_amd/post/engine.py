@@ -55,6 +55,22 @@ class SegEngine:
                                            C.c_void_p(segs.data_ptr()), self._stream()))
         return segs
 
+    def agglomerate_hist(self, affs_u8, frags, thresholds, quantile, init_with_max=False):
+        """agglomerate_mean with OneMinus<HistogramQuantileAffinity<., quantile, ., 256, init_with_max>> as the scorer
+        (reference post/watershed.py:230-243); the merge loop runs on the host: synchronises."""
+        if affs_u8.dtype != torch.uint8 or not affs_u8.is_cuda or affs_u8.dim() != 4 or affs_u8.shape[0] != 3:
+            raise ValueError("affs must be a uint8 CUDA tensor of shape (3, D, H, W)")
+        if frags.dtype != torch.int64 or tuple(frags.shape) != tuple(affs_u8.shape[1:]):
+            raise ValueError("fragments must be an int64 tensor of shape (D, H, W)")
+        a = affs_u8.contiguous()
+        f = frags.contiguous()
+        thr = (C.c_float * len(thresholds))(*[float(t) for t in thresholds])
+        segs = torch.empty((len(thresholds),) + tuple(f.shape), dtype=torch.int64, device=a.device)
+        check(lib.bsmi_agglomerate_hist_u8(self._h, C.c_void_p(a.data_ptr()), C.c_void_p(f.data_ptr()), _lib.i64x3(f.shape), thr,
+                                           len(thresholds), int(quantile), 1 if init_with_max else 0, C.c_void_p(segs.data_ptr()),
+                                           self._stream()))
+        return segs
+
     def postprocess_fragments(self, affs_u8, frags, filter_value=0.0, min_size=0, crop_offset=(0, 0, 0),
                               crop_shape=None, id_offset=0, out=None, num=None):
         """Blockwise fragment clean-up (reference post/blockwise/watershed_frags.py:181-224): filter

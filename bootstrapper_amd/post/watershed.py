@@ -27,8 +27,9 @@ def simple_watershed(config, device=0):
     min_seed_distance = config.get("min_seed_distance", 10)
     merge_function = config.get("merge_function", "mean")
     sigma, noise_eps, bias = config.get("sigma"), config.get("noise_eps"), config.get("bias")
-    if merge_function != "mean":
-        raise NotImplementedError(f"merge_function {merge_function!r}: only 'mean' is implemented (the one the reference enables)")
+    from .waterz import MERGE_FUNCTIONS
+    if merge_function not in MERGE_FUNCTIONS:   # the reference's table (post/watershed.py:230-243) raises KeyError here
+        raise KeyError(merge_function)
     if affs.dtype != np.uint8:
         raise NotImplementedError("the device path takes uint8 affinities (what `bs predict` stores)")
 
@@ -63,7 +64,8 @@ def simple_watershed(config, device=0):
     dump_params(frags_name, {"method": "ws", "blockwise": False, **frag_params})
 
     written = [frags_name]
-    for threshold, seg in zip(thresholds, agglomerate(a, thresholds, fragments=frags.clone())):   # a copy, as post/watershed.py:336
+    for threshold, seg in zip(thresholds, agglomerate(a, thresholds, fragments=frags.clone(),     # a copy, as post/watershed.py:336
+                                                      scoring_function=MERGE_FUNCTIONS[merge_function])):
         params = {"merge_function": merge_function, "threshold": threshold, **frag_params}
         seg_name = os.path.join(config["seg_dataset_prefix"], build_name(params))
         out = prepare_ds(seg_name, shape=seg.shape, **common)
@@ -211,8 +213,10 @@ def waterz_pipeline(config, device=None, rank=0, world=1, group=None, grid=None,
         raise NotImplementedError("the device path takes uint8 affinities (what `bs predict` stores)")
     thresholds = config.get("thresholds", [0.2, 0.35, 0.5])
     merge_function = config.get("merge_function", "mean")
-    if merge_function != "mean":
-        raise NotImplementedError(f"merge_function {merge_function!r}: only 'mean' is implemented (the one the reference enables)")
+    if merge_function != "mean":   # post/blockwise/waterz_agglom.py:23-36: the blockwise task knows the mean scorer only
+        raise NotImplementedError(f"merge_function {merge_function!r}: the blockwise pipeline scores edges by their mean affinity "
+                                  "(reference post/blockwise/waterz_agglom.py:23-36); the histogram-quantile scorers belong to the "
+                                  "non-blockwise `simple_watershed` (blockwise = false)")
     blockwise = config.get("blockwise", False)
     frag_params = {
         "fragments_in_xy": config.get("fragments_in_xy", True),

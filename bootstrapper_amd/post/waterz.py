@@ -6,9 +6,11 @@
 A generator, one item per threshold (ascending): the segmentation, or (segmentation, merge_history, region_graph) as
 requested -- merge_history = [{a, b, c, score}] of the merges since the previous threshold (c = a: the surviving id),
 region_graph = [{u, v, score}] of the current graph.  Like waterz, `fragments` is updated IN PLACE and the same array
-comes back at every step.  Only the scoring function the reference enables is implemented
-(post/blockwise/waterz_agglom.py:25 "mean"); anything else raises.
+comes back at every step.  Scoring functions: the mean (post/blockwise/waterz_agglom.py:25, the only one of the blockwise
+path) and, for the exact-queue call of post/watershed.py:333-338, the ten histogram-quantile scorers the reference lists
+(post/watershed.py:230-243); anything else raises.
 """
+import re
 import numpy as np
 import torch
 
@@ -16,6 +18,13 @@ from .engine import lut_relabel
 from .ws import _engine, as_u8_affinities
 
 MEAN = "OneMinus<MeanAffinity<RegionGraphType, ScoreValue>>"
+_HIST = re.compile(r"OneMinus<HistogramQuantileAffinity<RegionGraphType,\s*(\d+),\s*ScoreValue,\s*256,\s*(true|false)>>$")
+
+# merge_function names of the segment config -> waterz scoring functions (reference post/watershed.py:230-243)
+MERGE_FUNCTIONS = {"mean": MEAN}
+for _q in (10, 25, 50, 75, 90):
+    MERGE_FUNCTIONS[f"hist_quant_{_q}"] = f"OneMinus<HistogramQuantileAffinity<RegionGraphType, {_q}, ScoreValue, 256, false>>"
+    MERGE_FUNCTIONS[f"hist_quant_{_q}_initmax"] = f"OneMinus<HistogramQuantileAffinity<RegionGraphType, {_q}, ScoreValue, 256, true>>"
 
 
 def _score(sums, counts):
@@ -25,8 +34,11 @@ def _score(sums, counts):
 
 def agglomerate(affs, thresholds, fragments=None, scoring_function=MEAN, discretize_queue=0,
                 return_merge_history=False, return_region_graph=False, engine=None):
-    if scoring_function != MEAN:
+    hist = _HIST.match(scoring_function.replace(" ", "").replace(",", ", ")) if scoring_function != MEAN else None
+    if scoring_function != MEAN and hist is None:
         raise NotImplementedError(f"scoring function {scoring_function!r} is not implemented")
+    if hist is not None and (discretize_queue or return_merge_history or return_region_graph):
+        raise NotImplementedError("the histogram-quantile scorers serve the exact-queue call of post/watershed.py:333-338 only")
     if fragments is None:
         raise NotImplementedError("waterz's own fragment extraction is not used by the reference path")
     thresholds = [float(t) for t in thresholds]
@@ -47,7 +59,10 @@ def agglomerate(affs, thresholds, fragments=None, scoring_function=MEAN, discret
         return fragments
 
     if not (discretize_queue or return_merge_history or return_region_graph):
-        segs = eng.agglomerate_mean(a, frag.contiguous(), thresholds)
+        if hist is not None:
+            segs = eng.agglomerate_hist(a, frag.contiguous(), thresholds, int(hist.group(1)), hist.group(2) == "true")
+        else:
+            segs = eng.agglomerate_mean(a, frag.contiguous(), thresholds)
         eng.status()
         for i in range(len(thresholds)):
             yield publish(segs[i])

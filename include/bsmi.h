@@ -248,6 +248,22 @@ int bsmi_agglomerate_mean_u8(bsmi_seg *h, const uint8_t *affs_dev, const uint64_
                              const int64_t shape[3], const float *thresholds_host,
                              int n_thresholds, uint64_t *segs_dev, void *stream);
 
+/* The same hierarchical agglomeration with a histogram-quantile scorer (reference post/watershed.py:230-243:
+ * merge_function "hist_quant_<Q>[_initmax]" = "OneMinus<HistogramQuantileAffinity<RegionGraphType, Q, ScoreValue, 256,
+ * init_with_max>>"; waterz call site post/watershed.py:333-338).  The region graph and the 256-bin histogram of every edge's
+ * affinities are built on the device, the merge loop runs on the host (as waterz's does), the relabel on the device.
+ * Synchronises the stream.  Outputs as bsmi_agglomerate_mean_u8.                                                     */
+int bsmi_agglomerate_hist_u8(bsmi_seg *h, const uint8_t *affs_dev, const uint64_t *frags_dev,
+                             const int64_t shape[3], const float *thresholds_host, int n_thresholds,
+                             int quantile, int init_with_max, uint64_t *segs_dev, void *stream);
+
+/* The host half of bsmi_agglomerate_hist_u8 on a region graph given by the caller (no GPU involved): n_nodes nodes, edges
+ * (edge_u[e] < edge_v[e], each pair once) with their 256-bin affinity histograms hist [n_edges][256] (modified); for every
+ * threshold (ascending) roots_out + t * n_nodes receives the smallest node of each node's cluster after mergeUntil.     */
+int bsmi_agglomerate_hist_graph(uint32_t n_nodes, uint32_t n_edges, const uint32_t *edge_u, const uint32_t *edge_v,
+                                uint32_t *hist, int quantile, int init_with_max, const float *thresholds,
+                                int n_thresholds, uint32_t *roots_out);
+
 /* Blockwise fragment post-processing (reference post/blockwise/watershed_frags.py:148-156 filter_avg_fragments,
  * :188-192 remove_small_objects, :221-224 crop to the write ROI + skimage.measure.label + global id offset).
  * frags_dev (the read-ROI fragments of bsmi_ws_fragments_u8) is filtered IN PLACE: a fragment is removed

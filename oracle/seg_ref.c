@@ -318,6 +318,7 @@ typedef struct {
   uint32_t cnt;
   uint8_t deleted, stale;
   float stored;       /* score at the last (re)scoring */
+  uint32_t *hist;     /* histogram-quantile scoring: 256 bins of this edge's affinities (NULL: mean scoring) */
 } edge_t;
 
 static __thread edge_t *g_edges; /* per-thread: the cpu_baseline leg runs one volume per core */
@@ -325,7 +326,27 @@ static inline int q_less(const qitem *a, const qitem *b) {
   if (a->score != b->score) return a->score < b->score;
   return g_edges[a->e].key0 < g_edges[b->e].key0;
 }
+/* OneMinus<HistogramQuantileAffinity<RegionGraphType, Q, ScoreValue, 256, InitWithMax>> (reference post/watershed.py:230-243
+ * enables Q in {10, 25, 50, 75, 90}, each with InitWithMax false / true), restated from upstream's HistogramQuantileProvider
+ * (parity unpinned like the rest of waterz):
+ *   bin of an affinity value x in [0, 1]: min(255, (int)(x * 256)); for the uint8 / 255 values of this path that is the
+ *     uint8 value itself;
+ *   an edge's histogram: every affinity of its voxel pairs (InitWithMax false) or ONE entry, the largest of them
+ *     (InitWithMax true); when two edges are merged their histograms are added;
+ *   quantile value: pivot = Q * total / 100 + 1 (integer arithmetic, 1-based); the first bin whose running count reaches the
+ *     pivot; value = (bin + 0.5) / 256;  score = 1 - value. */
+static __thread int g_quantile = -1;  /* < 0: mean scoring */
 static inline float edge_score(const edge_t *e) {
+  if (e->hist) {
+    uint64_t total = 0;
+    for (int b = 0; b < 256; b++) total += e->hist[b];
+    const uint64_t pivot = (uint64_t)g_quantile * total / 100 + 1;
+    uint64_t run = 0;
+    int bin = 0;
+    for (bin = 0; bin < 256; bin++) { run += e->hist[bin]; if (run >= pivot) break; }
+    if (bin > 255) bin = 255;
+    return 1.0f - ((float)bin + 0.5f) / 256.0f;
+  }
   return 1.0f - (float)((double)e->sum / (255.0 * (double)e->cnt));
 }
 
@@ -374,12 +395,14 @@ static void merge_regions(edge_t *E, uint32_t ei, hmap *em, adj_t *A, uint32_t *
     if (s >= 0 && f->stored > E[em->vals[s]].stored) {
       edge_t *g = &E[em->vals[s]];
       g->sum += f->sum; g->cnt += f->cnt; g->stale = 1;
+      if (g->hist) for (int b = 0; b < 256; b++) g->hist[b] += f->hist[b];
       f->deleted = 1;
       continue;
     }
     if (s >= 0) {
       edge_t *g = &E[em->vals[s]];
       f->sum += g->sum; f->cnt += g->cnt;
+      if (f->hist) for (int b = 0; b < 256; b++) f->hist[b] += g->hist[b];
       g->deleted = 1;
       hm_del(em, gkey);
     }
@@ -393,9 +416,11 @@ static void merge_regions(edge_t *E, uint32_t ei, hmap *em, adj_t *A, uint32_t *
   *b_out = b;
 }
 
-int seg_agglomerate_mean_u8(const uint8_t *affs, const uint64_t *frags, int D, int H, int W,
-                            const float *thresholds, int nthr, uint64_t *segs) {
+/* quantile < 0: OneMinus<MeanAffinity>; else OneMinus<HistogramQuantileAffinity<., quantile, ., 256, init_with_max>> */
+int seg_agglomerate_u8(const uint8_t *affs, const uint64_t *frags, int D, int H, int W,
+                       const float *thresholds, int nthr, uint64_t *segs, int quantile, int init_with_max) {
   const int64_t hw = (int64_t)H * W, n = hw * D;
+  g_quantile = quantile;
   /* nodes: sorted distinct non-zero ids */
   uint64_t *ids = (uint64_t *)malloc(8 * (n + 1));
   int64_t nid = 0;
@@ -441,12 +466,21 @@ int seg_agglomerate_mean_u8(const uint8_t *affs, const uint64_t *frags, int D, i
             }
             e = (uint32_t)ne++;
             E[e].u = u; E[e].v = v; E[e].key0 = key; E[e].sum = 0; E[e].cnt = 0; E[e].deleted = 0; E[e].stale = 0; E[e].stored = 0.f;
+            E[e].hist = quantile >= 0 ? (uint32_t *)calloc(256, 4) : NULL;
             hm_put(&em, key, e); em_n++;
           } else e = em.vals[s];
           E[e].sum += affs[(int64_t)d * n + p];
           E[e].cnt += 1;
+          if (E[e].hist) E[e].hist[affs[(int64_t)d * n + p]] += 1;
         }
       }
+  if (quantile >= 0 && init_with_max)
+    for (int64_t e = 0; e < ne; e++) {
+      int top = 255;
+      while (top > 0 && !E[e].hist[top]) top--;
+      memset(E[e].hist, 0, 256 * 4);
+      E[e].hist[top] = 1;
+    }
   g_edges = E;
   adj_t A;
   A.adj = (uint32_t **)calloc(nn ? nn : 1, sizeof(uint32_t *));
@@ -492,8 +526,15 @@ int seg_agglomerate_mean_u8(const uint8_t *affs, const uint64_t *frags, int D, i
     }
   }
   for (int64_t i = 0; i < nn; i++) free(A.adj[i]);
+  if (quantile >= 0) for (int64_t e = 0; e < ne; e++) free(E[e].hist);
+  g_quantile = -1;
   free(A.adj); free(A.adjn); free(A.adjc); free(heap); free(parent); free(E); hm_free(&em); free(rank); free(ids);
   return 0;
+}
+
+int seg_agglomerate_mean_u8(const uint8_t *affs, const uint64_t *frags, int D, int H, int W,
+                            const float *thresholds, int nthr, uint64_t *segs) {
+  return seg_agglomerate_u8(affs, frags, D, H, W, thresholds, nthr, segs, -1, 0);
 }
 
 /* number of distinct non-zero labels (test helper) */

@@ -20,6 +20,8 @@ def _load():
     lib.seg_ws_fragments_u8.restype = C.c_int
     lib.seg_agglomerate_mean_u8.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int, vp, C.c_int, vp]
     lib.seg_agglomerate_mean_u8.restype = C.c_int
+    lib.seg_agglomerate_u8.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int, vp, C.c_int, vp, C.c_int, C.c_int]
+    lib.seg_agglomerate_u8.restype = C.c_int
     lib.seg_fragment_means_u8.argtypes = [vp, vp, C.c_int64, vp, C.c_int64, vp]
     lib.seg_fragment_means_u8.restype = None
     lib.seg_filter_fragments_u8.argtypes = [vp, vp, C.c_int64, C.c_double, C.c_int64]
@@ -65,6 +67,20 @@ def agglomerate_mean_u8(affs_u8, frags, thresholds):
     segs = np.zeros((len(thr), D, H, W), dtype=np.uint64)
     rc = _lib.seg_agglomerate_mean_u8(a.ctypes.data, f.ctypes.data, D, H, W, thr.ctypes.data, len(thr),
                                       segs.ctypes.data)
+    assert rc == 0
+    return [segs[i] for i in range(len(thr))]
+
+
+def agglomerate_hist_u8(affs_u8, frags, thresholds, quantile, init_with_max=False):
+    """waterz.agglomerate(..., OneMinus<HistogramQuantileAffinity<RegionGraphType, quantile, ScoreValue, 256, init_with_max>>)
+    restatement (reference post/watershed.py:230-243) -> list of uint64 segmentations, one per threshold."""
+    a = np.ascontiguousarray(affs_u8[:3], dtype=np.uint8)
+    f = np.ascontiguousarray(frags, dtype=np.uint64)
+    _, D, H, W = a.shape
+    thr = np.ascontiguousarray(thresholds, dtype=np.float32)
+    segs = np.zeros((len(thr), D, H, W), dtype=np.uint64)
+    rc = _lib.seg_agglomerate_u8(a.ctypes.data, f.ctypes.data, D, H, W, thr.ctypes.data, len(thr), segs.ctypes.data,
+                                 int(quantile), int(bool(init_with_max)))
     assert rc == 0
     return [segs[i] for i in range(len(thr))]
 

@@ -4,8 +4,9 @@ the C code to cross-check it on small volumes.  Test infrastructure only; pure P
 import numpy as np
 
 
-def region_graph(affs, frags):
-    """{(u, v): [sum, count]} with u < v fragment ids; channel d at the higher-index voxel of each pair."""
+def region_graph(affs, frags, values=False):
+    """{(u, v): [sum, count]} with u < v fragment ids; channel d at the higher-index voxel of each pair
+    (values=True: {(u, v): [every affinity of the edge]})."""
     edges = {}
     for d in range(3):
         lo = [slice(None)] * 3
@@ -14,10 +15,22 @@ def region_graph(affs, frags):
         a, b, w = frags[tuple(lo)], frags[tuple(hi)], affs[d][tuple(hi)]
         m = (a != b) & (a != 0) & (b != 0)
         for x, y, v in zip(a[m].tolist(), b[m].tolist(), w[m].tolist()):
+            if values:
+                edges.setdefault((min(x, y), max(x, y)), []).append(int(v))
+                continue
             e = edges.setdefault((min(x, y), max(x, y)), [0, 0])
             e[0] += int(v)
             e[1] += 1
     return edges
+
+
+def _quantile_score(values, q):
+    """OneMinus<HistogramQuantileAffinity<., q, ., 256, .>> of a multiset of uint8 affinities (= their histogram bins):
+    pivot = q * n / 100 + 1 (1-based, integer); value = (the pivot-th smallest bin + 0.5) / 256."""
+    v = sorted(values)
+    pivot = q * len(v) // 100 + 1
+    b = v[min(pivot, len(v)) - 1] if pivot <= len(v) else 255
+    return np.float32(1.0) - (np.float32(b) + np.float32(0.5)) / np.float32(256.0)
 
 
 def _score(sum_, cnt):
@@ -25,16 +38,23 @@ def _score(sum_, cnt):
 
 
 class Merger:
-    def __init__(self, affs, frags, nbins=0):
-        g = region_graph(affs, frags)
+    def __init__(self, affs, frags, nbins=0, quantile=None, init_with_max=False):
+        """quantile None: mean scoring over (sum, count); else histogram-quantile scoring over the edges' affinity multisets
+        (`sum` then holds the list of values and `cnt` is unused: merging two edges concatenates their lists)."""
+        self.quantile = quantile
+        g = region_graph(affs, frags, values=quantile is not None)
         self.key0 = sorted(g)                              # edge index = position in ascending (u, v) order
         self.ends = [list(k) for k in self.key0]
-        self.sum = [g[k][0] for k in self.key0]
-        self.cnt = [g[k][1] for k in self.key0]
+        if quantile is None:
+            self.sum = [g[k][0] for k in self.key0]
+            self.cnt = [g[k][1] for k in self.key0]
+        else:
+            self.sum = [[max(g[k])] if init_with_max else list(g[k]) for k in self.key0]
+            self.cnt = [0 for _ in self.key0]
         ne = len(self.key0)
         self.deleted = [False] * ne
         self.stale = [False] * ne
-        self.stored = [_score(self.sum[e], self.cnt[e]) for e in range(ne)]
+        self.stored = [self._score(e) for e in range(ne)]
         self.parent = {}
         self.nbins = nbins
         self.history = []                                  # (a, b, score)
@@ -44,6 +64,11 @@ class Merger:
                 self._push(e)
         else:
             self.queue = set(range(ne))
+
+    def _score(self, e):
+        if self.quantile is None:
+            return _score(self.sum[e], self.cnt[e])
+        return _quantile_score(self.sum[e], self.quantile)
 
     def _push(self, e):
         if self.nbins:
@@ -88,7 +113,7 @@ class Merger:
                 continue
             if self.stale[e]:
                 self.stale[e] = False
-                self.stored[e] = _score(self.sum[e], self.cnt[e])
+                self.stored[e] = self._score(e)
                 self._push(e)
                 continue
             a, b = min(self.ends[e]), max(self.ends[e])
@@ -102,13 +127,13 @@ class Merger:
                 n = v if u == b else u
                 g = self._find(a, n)
                 if g is not None and self.stored[f] > self.stored[g]:
-                    self.sum[g] += self.sum[f]
+                    self.sum[g] = self.sum[g] + self.sum[f]     # numbers add, lists of values concatenate
                     self.cnt[g] += self.cnt[f]
                     self.deleted[f] = True
                     self.stale[g] = True
                     continue
                 if g is not None:
-                    self.sum[f] += self.sum[g]
+                    self.sum[f] = self.sum[f] + self.sum[g]
                     self.cnt[f] += self.cnt[g]
                     self.deleted[g] = True
                 self.ends[f] = [min(a, n), max(a, n)]
@@ -129,8 +154,8 @@ class Merger:
         return out
 
 
-def agglomerate(affs, frags, thresholds):
-    m = Merger(affs, frags)
+def agglomerate(affs, frags, thresholds, quantile=None, init_with_max=False):
+    m = Merger(affs, frags, quantile=quantile, init_with_max=init_with_max)
     segs = []
     for t in thresholds:
         m.merge_until(t)

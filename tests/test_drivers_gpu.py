@@ -93,6 +93,14 @@ min_seed_distance = 4
         assert np.array_equal(open_ds(w)[:], r)
     with pytest.raises(ValueError, match="Blockwise requires a database config"):
         run_segmentation(str(seg_cfg), "ws", blockwise=True, param=())
+    # one of the histogram-quantile merge functions of the non-blockwise path (post/watershed.py:230-243), `-p` style override
+    written_h = run_segmentation(str(seg_cfg), "ws", param=("merge_function=hist_quant_75",))
+    assert [os.path.relpath(w, store) for w in written_h][1:] == ["segmentations/mfhist_quant_75--t0.3--xy--msd4",
+                                                                  "segmentations/mfhist_quant_75--t0.6--xy--msd4"]
+    for w, r in zip(written_h[1:], S.agglomerate_hist_u8(got[:3], frags_ref, [0.3, 0.6], 75, False)):
+        assert np.array_equal(open_ds(w)[:], r) and open_ds(w).attrs["bs_params"]["merge_function"] == "hist_quant_75"
+    with pytest.raises(KeyError):     # not in the reference's table
+        run_segmentation(str(seg_cfg), "ws", param=("merge_function=max",))
 
 
 from oracle.blockwise_ref import pad_read as _pad_read, cpu_blockwise as _cpu_blockwise  # noqa: E402

@@ -129,3 +129,37 @@ def test_block_task_retries_and_failure_accounting():
         raise FatalBlockError("device lost")
     with pytest.raises(FatalBlockError):
         run_blocks("t", [0, 1], fatal)
+
+
+def test_histogram_quantile_merge_loop_on_the_host():
+    """The host merge loop behind `merge_function = hist_quant_<Q>[_initmax]` (csrc/agglo_host.cpp, through the C ABI; no GPU):
+    on region graphs of small random volumes it produces the clusters of the oracle (oracle/seg_ref.c, itself checked against
+    the literal model in tests/test_oracle_seg.py)."""
+    import ctypes as C
+    from bootstrapper_amd._lib import lib, check
+    from oracle import seg_ref as S
+    from tests.agglo_model import region_graph
+    rng = np.random.default_rng(31)
+    for case in range(8):
+        shape = (int(rng.integers(1, 4)), int(rng.integers(5, 10)), int(rng.integers(5, 10)))
+        frags = rng.integers(0 if case % 2 else 1, int(rng.integers(5, 16)), size=shape).astype(np.uint64)
+        affs = rng.choice(np.array([0, 40, 80, 128, 200, 255]) if case % 3 else np.arange(256), size=(3,) + shape).astype(np.uint8)
+        ids = np.array(sorted(set(frags.ravel().tolist()) - {0}), dtype=np.uint64)
+        rank = {int(v): i for i, v in enumerate(ids)}
+        g = region_graph(affs, frags, values=True)
+        keys = sorted(g)
+        eu = np.array([rank[k[0]] for k in keys], dtype=np.uint32)
+        ev = np.array([rank[k[1]] for k in keys], dtype=np.uint32)
+        thr = np.array([0.3, 0.55, 0.8], dtype=np.float32)
+        for q, initmax in ((50, False), (10, True), (90, False), (75, True)):
+            hist = np.zeros((len(keys), 256), dtype=np.uint32)
+            for e, k in enumerate(keys):
+                np.add.at(hist[e], g[k], 1)
+            roots = np.zeros((3, len(ids)), dtype=np.uint32)
+            check(lib.bsmi_agglomerate_hist_graph(len(ids), len(keys), eu.ctypes.data, ev.ctypes.data, hist.ctypes.data, q, int(initmax),
+                                                  thr.ctypes.data_as(C.POINTER(C.c_float)), 3, roots.ctypes.data))
+            want = S.agglomerate_hist_u8(affs, frags, thr, q, initmax)
+            for t in range(3):
+                lut = np.zeros(int(ids.max()) + 1, dtype=np.uint64)
+                lut[ids.astype(np.int64)] = ids[roots[t]]
+                assert np.array_equal(lut[frags.astype(np.int64)], want[t]), (case, q, initmax, t)

@@ -208,3 +208,31 @@ def test_oracle_equals_literal_python_model():
             _, _, merges, mscores = S.rag_merge_scores_u8(affs, frags, 0.7, nbins)
             assert [(a, b) for a, b, _ in hist] == [tuple(m) for m in merges.tolist()], (case, nbins)
             np.testing.assert_array_equal(np.array([s for _, _, s in hist], dtype=np.float32), mscores)
+
+
+def test_histogram_quantile_oracle_equals_literal_model():
+    """OneMinus<HistogramQuantileAffinity<., q, ., 256, init_with_max>> (reference post/watershed.py:230-243: q in 10, 25, 50,
+    75, 90, each with and without init_with_max): the C restatement against the literal model, and the scoring rule itself on
+    hand-made histograms (parity unpinned: waterz is absent; the rule is stated in oracle/seg_ref.c)."""
+    from tests.agglo_model import agglomerate, _quantile_score
+    # pivot = q * n / 100 + 1, 1-based: 4 values, q = 50 -> the 3rd smallest; q = 90 -> the 4th; q = 10 -> the 1st
+    assert _quantile_score([10, 20, 30, 40], 50) == np.float32(1) - np.float32(30.5) / np.float32(256)
+    assert _quantile_score([10, 20, 30, 40], 90) == np.float32(1) - np.float32(40.5) / np.float32(256)
+    assert _quantile_score([10, 20, 30, 40], 10) == np.float32(1) - np.float32(10.5) / np.float32(256)
+    rng = np.random.default_rng(23)
+    differs = 0
+    for case in range(10):
+        shape = (int(rng.integers(1, 4)), int(rng.integers(4, 9)), int(rng.integers(4, 9)))
+        frags = rng.integers(0 if case % 3 == 0 else 1, int(rng.integers(4, 14)), size=shape).astype(np.uint64)
+        levels = np.array([0, 40, 80, 128, 200, 255]) if case % 2 else np.arange(256)
+        affs = rng.choice(levels, size=(3,) + shape).astype(np.uint8)
+        thr = [0.3, 0.55, 0.8]
+        mean = S.agglomerate_mean_u8(affs, frags, thr)
+        for q in (10, 50, 90):
+            for initmax in (False, True):
+                got = S.agglomerate_hist_u8(affs, frags, thr, q, initmax)
+                want = agglomerate(affs, frags, thr, quantile=q, init_with_max=initmax)
+                for g, w in zip(got, want):
+                    assert np.array_equal(g, w), (case, q, initmax)
+                differs += any(not np.array_equal(g, m) for g, m in zip(got, mean))
+    assert differs > 20      # the scorers are not the mean scorer in disguise

@@ -170,8 +170,22 @@ def test_mirror_api_generator():
     work = frags.clone()
     for seg, r in zip(agglomerate(af, [0.2, 0.5], fragments=work), ref):
         assert seg is work and np.array_equal(seg.cpu().numpy().astype(np.uint64), r)      # in place, the same array every time
+    # the histogram-quantile scorers of the non-blockwise path (post/watershed.py:230-243): device region graph + histograms,
+    # host merge loop, device relabel -- against the oracle; a scorer outside the reference's table is refused
+    from bootstrapper_amd.post.waterz import MERGE_FUNCTIONS
+    assert len(MERGE_FUNCTIONS) == 11 and MERGE_FUNCTIONS["mean"].startswith("OneMinus<MeanAffinity")
+    for name, (q, initmax) in (("hist_quant_50", (50, False)), ("hist_quant_10_initmax", (10, True)), ("hist_quant_90", (90, False)),
+                               ("hist_quant_75_initmax", (75, True))):
+        want = S.agglomerate_hist_u8(affs, ref_frags, [0.2, 0.5, 0.8], q, initmax)
+        work = frags.clone()
+        got = [seg.cpu().numpy().astype(np.uint64) for seg in agglomerate(a, [0.2, 0.5, 0.8], fragments=work, scoring_function=MERGE_FUNCTIONS[name])]
+        for g, w in zip(got, want):
+            assert np.array_equal(g, w), name
+        assert len(np.unique(want[2])) < len(np.unique(want[0])) <= len(np.unique(ref_frags))
     with pytest.raises(NotImplementedError):
-        next(agglomerate(a, [0.2], fragments=frags, scoring_function="OneMinus<HistogramQuantileAffinity<RegionGraphType, 50, ScoreValue, 256, false>>"))
+        next(agglomerate(a, [0.2], fragments=frags, scoring_function="OneMinus<MaxAffinity<RegionGraphType, ScoreValue>>"))
+    with pytest.raises(NotImplementedError):   # merge history needs the discretized queue, which only the mean scorer has
+        next(agglomerate(a, [0.2], fragments=frags, scoring_function=MERGE_FUNCTIONS["hist_quant_50"], discretize_queue=256, return_merge_history=True))
     # the blockwise call (numpy fragments, modified in place like waterz does)
     e_ref, s_ref, m_ref, ms_ref = S.rag_merge_scores_u8(affs, ref_frags, 1.0, 256)
     fr_np = ref_frags.copy()

@@ -24,7 +24,7 @@ def load(root, counter):
         for r in csv.DictReader(open(path)):
             if r["Counter_Name"] != counter:
                 continue
-            name = r["Kernel_Name"].split("(")[0].replace("void ", "")
+            name = r["Kernel_Name"].replace("(anonymous namespace)::", "").split("(")[0].replace("void ", "")
             agg[name][0] += 1
             agg[name][1] += float(r["Counter_Value"])
     return agg
@@ -52,7 +52,7 @@ def main():
         kernels[k] = row
     json.dump({"source": "rocprofv3 --pmc <one counter per pass> -- python3 tools/probe_unet.py", "kernels": kernels}, open(out, "w"), indent=1)
     for k, r in kernels.items():
-        if "conv" in k or "first_pass" in k:
+        if "conv" in k or "first_pass" in k or "wino" in k:
             print(k[:70].ljust(70), {a: round(b, 3) for a, b in r.items() if a != "chip_cycles_per_launch"})
 
 
