@@ -751,7 +751,7 @@ int launch_conv_rh(const RhArgs& a, int precision, TileCfg cfg, hipStream_t stre
     BSMI_FAIL(BSMI_ERR_INVALID, "raster-halo conv launch: bad geometry Q=%d nsteps=%d Npad=%d", a.Q, a.nsteps, a.Npad);
   if (precision == BSMI_PREC_F32) return launch_rh_cfg<float>(a, cfg, stream, sk_ws, sk_grid);
   if (precision == BSMI_PREC_BF16) return launch_rh_cfg<bf16_elem>(a, cfg, stream, sk_ws, sk_grid);
-  if (precision == BSMI_PREC_BF16X3) return launch_rh_cfg<bf16s_elem>(a, cfg, stream, sk_ws, sk_grid);  // listed hi / lo K-steps
+  if (precision == BSMI_PREC_BF16X3) BSMI_FAIL(BSMI_ERR_INVALID, "the raster-halo kernel of the split-bf16 mode is conv_rh_x3_kernel (launch_conv_rh_x3)");
   BSMI_FAIL(BSMI_ERR_INVALID, "unknown precision %d", precision);
 }
 

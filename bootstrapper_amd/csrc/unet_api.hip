@@ -366,14 +366,13 @@ struct Planner {
     // 128^3 block: small-Cout tiles with a long K loop (the 360->60 channel layer: 1.43 -> 1.04 ms); the rows the
     // raster-halo form computes and drops cost the small-plane layers 8-17 %, and short-K layers do not amortise it
     static const int mode = [] { const char* e = getenv("BSMI_USE_RH"); return !e ? 2 : (e[0] == '1' ? 1 : 0); }();
-    // split mode: the halo form exists (K-steps listed per plane through the bf16 kernel, parity-tested with BSMI_USE_RH=1) but
-    // loses to the fused gather kernel on every layer (360 -> 60 channels: 3.16 against 2.41 ms), so never by default
-    const bool enabled = mode == 1 || (mode == 2 && prec != BSMI_PREC_BF16X3 && tile_bn(st.tile) <= 64 && pc.entries.size() / kUnitsPerStep >= 200);
+    // split mode: never (a form that listed the K-steps per plane through the bf16 kernel lost to the fused gather kernel on every
+    // layer -- 360 -> 60 channels: 3.16 against 2.41 ms -- and was removed in round 3; the fused halo form is plan_rhx below)
+    const bool enabled = prec != BSMI_PREC_BF16X3 && (mode == 1 || (mode == 2 && tile_bn(st.tile) <= 64 && pc.entries.size() / kUnitsPerStep >= 200));
     const int* k = p.k[ci];
     const int Hin = o.H + k[1] - 1, Win = o.W + k[2] - 1;
-    const bool split = prec == BSMI_PREC_BF16X3;
-    if (!enabled || (split && pc.ks != 1) || !two_waves_per_simd() || !rh_supported(st.tile, Win, k[1], k[2])) return BSMI_OK;
-    const int64_t es = esize(prec) * (split ? 2 : 1);  // bytes per channel of a row ((hi, lo) interleaved in the split mode)
+    if (!enabled || !two_waves_per_simd() || !rh_supported(st.tile, Win, k[1], k[2])) return BSMI_OK;
+    const int64_t es = esize(prec);  // bytes per channel of a row
     const int SUB = sube(prec);
     const size_t nsteps = pc.entries.size() / kUnitsPerStep;
     std::vector<RhStep> steps(nsteps);
@@ -416,35 +415,6 @@ struct Planner {
       r.buf_phase = (int32_t)(((phases.size() - 1) & 1) | ((phases.size() - 1) << 8));
       r.wait = 0;
       r.issue = -1;
-    }
-    // Split mode, listed through the bf16 kernel: a logical phase becomes a hi-plane phase, whose taps are multiplied with
-    // the hi and then with the lo weights, and a lo-plane phase (the same rows, 16 bytes further) with the hi weights:
-    // hi*hi + hi*lo + lo*hi with each plane's halo staged once.  `wsrc` = (weight image, logical K-step) per listed K-step.
-    std::vector<std::pair<int, size_t>> wsrc;
-    if (split) {
-      std::vector<RhStep> xs;
-      std::vector<RhPhase> xp;
-      std::vector<int> xf;
-      for (size_t q = 0; q < phases.size(); ++q) {
-        const size_t s_begin = (size_t)first_step[q], s_end = q + 1 < phases.size() ? (size_t)first_step[q + 1] : nsteps;
-        for (int plane = 0; plane < 2; ++plane) {
-          RhPhase ph = phases[q];
-          ph.delta += plane ? 16 : 0;
-          ph.buf = (int32_t)(xp.size() & 1);
-          xf.push_back((int)xs.size());
-          for (int wimg = 0; wimg < (plane ? 1 : 2); ++wimg)
-            for (size_t t = s_begin; t < s_end; ++t) {
-              RhStep r = steps[t];
-              r.buf_phase = (int32_t)((xp.size() & 1) | (xp.size() << 8));
-              xs.push_back(r);
-              wsrc.emplace_back(wimg, t);
-            }
-          xp.push_back(ph);
-        }
-      }
-      steps.swap(xs);
-      phases.swap(xp);
-      first_step.swap(xf);
     }
     const size_t nlisted = steps.size();
     const int np = (int)phases.size();
@@ -493,17 +463,6 @@ struct Planner {
     a.nsteps = (int)nlisted;
     a.nphases = np;
     a.w = pc.w;
-    if (split) {  // the weight rows in the listed order, gathered from the hi and lo images of the fused form
-      const size_t row_bytes = (size_t)pc.Npad * kStepRowBytes;
-      char* img = nullptr;
-      BSMI_HIP(hipMalloc((void**)&img, (nlisted * pc.Npad + kWeightRowSlack) * kStepRowBytes));
-      plan->allocs.push_back(img);
-      BSMI_HIP(hipMemset(img + nlisted * row_bytes, 0, (size_t)kWeightRowSlack * kStepRowBytes));
-      for (size_t i = 0; i < nlisted; ++i)
-        BSMI_HIP(hipMemcpy(img + i * row_bytes, (const char*)pc.w + (wsrc[i].first ? pc.lo_image_bytes : 0) + wsrc[i].second * row_bytes, row_bytes,
-                           hipMemcpyDeviceToDevice));
-      a.w = img;
-    }
     a.bias = pc.bias;
     a.out = o.ptr;
     a.Do = o.D; a.Ho = o.H; a.Wo = o.W; a.Co = o.Cpad;

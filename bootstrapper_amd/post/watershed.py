@@ -16,6 +16,16 @@ from ..zarr_io import open_ds, prepare_ds
 from .naming import build_name, dump_params
 
 
+def _warn_3d_fragments(fragments_in_xy, shape):
+    """fragments_in_xy = false (post/ws.py:98-110) floods a whole block as ONE sequential priority queue: bit-exact here, but a
+    single wave's work (13 s for a 128^3 block, where the per-section default takes 12 ms) -- say so instead of looking hung."""
+    if not fragments_in_xy and int(np.prod(shape)) > (1 << 21):
+        import sys
+        print(f"warning: fragments_in_xy = false floods a block of {tuple(int(v) for v in shape)} voxels as one sequential queue "
+              "(seconds per 128^3 block on the device); the default fragments_in_xy = true runs every section as its own queue",
+              file=sys.stderr)
+
+
 def simple_watershed(config, device=0):
     import torch
     from .ws import watershed_from_affinities
@@ -50,6 +60,7 @@ def simple_watershed(config, device=0):
 
     frag_params = {"fragments_in_xy": fragments_in_xy, "min_seed_distance": min_seed_distance,
                    "sigma": sigma, "noise_eps": noise_eps, "bias": bias}
+    _warn_3d_fragments(fragments_in_xy, a.shape[1:])
     if any([sigma, noise_eps, bias]):   # post/watershed.py:285-303: the watershed sees the shifted affinities
         from .shifts import boundary_mask_affinities
         src = boundary_mask_affinities(a, fragments_in_xy, sigma, noise_eps, bias, dtype=torch.float32)
@@ -243,6 +254,8 @@ def waterz_pipeline(config, device=None, rank=0, world=1, group=None, grid=None,
     else:
         block_size, ctx = total_shape, (0, 0, 0)
     block_size = tuple(int(b) for b in block_size)   # not clipped to the ROI: ids are block id * voxels of a whole block
+    if rank == 0:
+        _warn_3d_fragments(frag_params["fragments_in_xy"], [min(b, t) + 2 * c for b, t, c in zip(block_size, total_shape, ctx)])
 
     device = rank % max(1, torch.cuda.device_count()) if device is None else device
     layers, rows = -(-total_shape[0] // block_size[0]), -(-total_shape[1] // block_size[1])
