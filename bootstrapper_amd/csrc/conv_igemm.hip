@@ -672,6 +672,11 @@ __device__ __forceinline__ void conv_x3_body(const ConvArgs& a, char* smem, int 
   const int tile_mb = tile / ntn, tile_n = tile - tile_mb * ntn;
   const int bat = tile_mb / ntm, tile_m = tile_mb - bat * ntm;
   const int m0 = tile_m * BM, n0 = tile_n * BN;
+#ifdef BSMI_STAMP  // dev build: where a tile of a BATCHED launch (the Winograd GEMMs) spends its time, 100 MHz ticks summed over tiles:
+  // [0] K loop, [1] drain + barrier, [2] epilogue (strips + store issue), [3] tiles, [4] prologue (tile start -> loop), [5] store drain, [6] K-steps
+  const bool stamp_on = ka->nbatch > 1;
+  const unsigned long long st_begin = wall_clock64();
+#endif
 
   // staging geometry: as conv_igemm_body (lane l lands at row l >> 2, 16-byte slot l & 3 of its KiB and fetches the
   // source chunk (l & 3) ^ key(row)); the key function belongs to the MFMA shape's fragment reads
@@ -814,6 +819,9 @@ __device__ __forceinline__ void conv_x3_body(const ConvArgs& a, char* smem, int 
 #pragma unroll
   for (int j = 0; j < NH0; ++j) rdB(RB0[j], smem + OFF_BH, j);
   Desc dl = fetch(1);  // late waves: descriptor of the batch 1 whose second part is still to go out
+#ifdef BSMI_STAMP
+  const unsigned long long st_loop = wall_clock64();
+#endif
 
   for (int h = 0; h < nloc; ++h) {
     const int p = h & 1, q = p ^ 1;
@@ -887,9 +895,15 @@ __device__ __forceinline__ void conv_x3_body(const ConvArgs& a, char* smem, int 
       rdA(RA[i], smem + OFF_AL + q * EA, i);
     }
   }
+#ifdef BSMI_STAMP
+  const unsigned long long st0 = wall_clock64();
+#endif
   // drain the run-ahead loads; after the barrier nobody reads or writes the staging area any more
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
+#ifdef BSMI_STAMP
+  const unsigned long long st1 = wall_clock64();
+#endif
 
   if (part) {
     constexpr int NR = MS == 16 ? 4 : 16;
@@ -949,7 +963,22 @@ __device__ __forceinline__ void conv_x3_body(const ConvArgs& a, char* smem, int 
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       }
     }
+#ifdef BSMI_STAMP
+    const unsigned long long st2 = wall_clock64();
+#endif
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#ifdef BSMI_STAMP
+    if (tid == 0 && stamp_on) {
+      const unsigned long long st3 = wall_clock64();
+      atomicAdd(&g_stamp[0], st0 - st_loop);
+      atomicAdd(&g_stamp[1], st1 - st0);
+      atomicAdd(&g_stamp[2], st2 - st1);
+      atomicAdd(&g_stamp[3], 1ull);
+      atomicAdd(&g_stamp[4], st_loop - st_begin);
+      atomicAdd(&g_stamp[5], st3 - st2);
+      atomicAdd(&g_stamp[6], (unsigned long long)nloc);
+    }
+#endif
     return;
   }
   float bv[FN];

@@ -28,6 +28,16 @@ def ls(self, k, wait=()):
     lane = self.lanes[k % len(self.lanes)]
     ev = torch.cuda.Event(enable_timing=True); ev.record(lane["stream"]); marks[("score", k)] = ev
 V.SlabSegmenter._launch_fragments, V.SlabSegmenter._launch_scores = lf, ls
+stage_t = {}
+def timed(name, fn):
+    def w(self, *a, **k):
+        t = time.perf_counter()
+        r = fn(self, *a, **k)
+        stage_t[name] = (t, time.perf_counter())
+        return r
+    return w
+V.SlabSegmenter._collect = timed("collect", V.SlabSegmenter._collect)
+V.SlabSegmenter.stitch = timed("stitch", V.SlabSegmenter.stitch)
 for rep in range(2):
     pipe = V.VolumePipeline(m, OUT_BLOCK, CONTEXT, job_blocks_for(steps), SEG_CONTEXT, THRESHOLDS, n_lanes=lanes)
     marks.clear()
@@ -63,6 +73,8 @@ for rep in range(2):
     th.join()
     print(f"rep {rep}: enqueue of predict {t_enq*1e3:.1f} ms, total {t_all*1e3:.1f} ms ({t_all/steps*1e3:.1f} ms per block)")
     if rep == 1:
+        for name, (a, b) in stage_t.items():
+            print(f"{name}: {1e3 * (a - t0):8.1f} -> {1e3 * (b - t0):8.1f} ms")
         for k in range(steps):
             print(f"block {k:3d}: predicted {times[('pred',k)]*1e3:8.1f}  fragments {times.get(('frag',k),0)*1e3:8.1f}  scores {times.get(('score',k),0)*1e3:8.1f}")
     del pipe
