@@ -21,11 +21,11 @@ orig_lf, orig_ls = V.SlabSegmenter._launch_fragments, V.SlabSegmenter._launch_sc
 marks = {}
 def lf(self, k, wait=()):
     orig_lf(self, k, wait)
-    lane = self.lanes[k % len(self.lanes)]
+    lane = self.lane_of("f", k)
     ev = torch.cuda.Event(enable_timing=True); ev.record(lane["stream"]); marks[("frag", k)] = ev
 def ls(self, k, wait=()):
     orig_ls(self, k, wait)
-    lane = self.lanes[k % len(self.lanes)]
+    lane = self.lane_of("s", k)
     ev = torch.cuda.Event(enable_timing=True); ev.record(lane["stream"]); marks[("score", k)] = ev
 V.SlabSegmenter._launch_fragments, V.SlabSegmenter._launch_scores = lf, ls
 stage_t = {}
