@@ -4,9 +4,12 @@
 
 #include <cstdarg>
 #include <cstdint>
+#include <algorithm>
 #include <cstdio>
 #include <mutex>
 #include <string>
+#include <thread>
+#include <vector>
 
 #include "../../include/bsmi.h"
 
@@ -49,6 +52,22 @@ struct DeviceOnce {
     return rc;
   }
 };
+
+// f(i) for i in [0, n) on up to 16 host threads (weight packing at finalize: independent rows of a packed image)
+template <class F>
+static inline void host_parallel_for(size_t n, F&& f) {
+  const size_t nt = std::min<size_t>(std::max(1u, std::min(16u, std::thread::hardware_concurrency())), n);
+  if (nt <= 1) {
+    for (size_t i = 0; i < n; ++i) f(i);
+    return;
+  }
+  std::vector<std::thread> th;
+  for (size_t t = 0; t < nt; ++t)
+    th.emplace_back([&, t] {
+      for (size_t i = t; i < n; i += nt) f(i);
+    });
+  for (auto& x : th) x.join();
+}
 
 static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
 static inline int round_up(int a, int b) { return ceil_div(a, b) * b; }

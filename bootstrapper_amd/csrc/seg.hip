@@ -80,11 +80,24 @@ __global__ __launch_bounds__(WS_T) void ws_seeds_kernel(const uint8_t* __restric
   __shared__ int sh_cnt[WS_T];
   if (tid == 0) sh_any_bg = 0;
   __syncthreads();
+  // The sequential per-row loops below (row distances, run labelling, numbering) must not walk global memory: a load
+  // per step and row, 160 steps, at the L2 latency of a busy chip made a slice's workgroup -- which holds a whole CU's LDS --
+  // live 0.6 ms, 6.4 ms per block under 16 lanes.  So the LDS path keeps what those loops read in LDS: the mask, and a
+  // flag byte per voxel (is a maximum / is a root).  LDS: sg u16 [H][W+2] | sd2 u16 [H*W] | smask u8 [H*W] | sflag u8 [H*W].
+  uint8_t* smask = nullptr;
+  uint8_t* sflag = nullptr;
+  if constexpr (LDS) {
+    const size_t o_sd2 = ((size_t)H * (W + 2) * 2 + 15) & ~(size_t)15;
+    const size_t o_mask = (o_sd2 + (size_t)n * 2 + 15) & ~(size_t)15;
+    smask = (uint8_t*)(ws_smem + o_mask);
+    sflag = smask + (((size_t)n + 15) & ~(size_t)15);
+  }
   // a. mask  (0.5*(a_y+a_x) > 0.5*255  <=>  a_y + a_x >= 256)
   int bg = 0;
   for (int i = tid; i < n; i += WS_T) {
     const int m = (int)ay[i] + (int)ax[i] >= 256;
     mask[i] = (uint8_t)m;
+    if constexpr (LDS) smask[i] = (uint8_t)m;
     bg |= !m;
   }
   if (bg) sh_any_bg = 1;
@@ -95,18 +108,18 @@ __global__ __launch_bounds__(WS_T) void ws_seeds_kernel(const uint8_t* __restric
     // ---- LDS path: sg = row distances, later the x-filtered d2 (all values < 65535) ----------
     const int Wp = W + 2;  // row stride in uint16: consecutive rows fall into different banks
     uint16_t* sg = (uint16_t*)ws_smem;
-    int32_t* sd2 = (int32_t*)(ws_smem + (((size_t)H * Wp * 2 + 15) & ~(size_t)15));
+    uint16_t* sd2 = (uint16_t*)(ws_smem + (((size_t)H * Wp * 2 + 15) & ~(size_t)15));  // squared distances < 65535 (launcher)
     constexpr int GINF = 0xffff;
     if (any_bg) {
       for (int y = tid; y < H; y += WS_T) {
         int last = -INF;
         for (int x = 0; x < W; ++x) {
-          if (!mask[y * W + x]) last = x;
+          if (!smask[y * W + x]) last = x;
           sg[y * Wp + x] = (uint16_t)(last <= -INF ? GINF : x - last);
         }
         last = INF;
         for (int x = W - 1; x >= 0; --x) {
-          if (!mask[y * W + x]) last = x;
+          if (!smask[y * W + x]) last = x;
           const int d = last >= INF ? GINF : last - x;
           if (d < (int)sg[y * Wp + x]) sg[y * Wp + x] = (uint16_t)d;
         }
@@ -121,14 +134,14 @@ __global__ __launch_bounds__(WS_T) void ws_seeds_kernel(const uint8_t* __restric
           const int v = gg == GINF ? INF : gg * gg + dy * dy;
           best = v < best ? v : best;
         }
-        sd2[i] = best;
+        sd2[i] = (uint16_t)best;
         d2[i] = best;
       }
     } else {
       for (int i = tid; i < n; i += WS_T) {
         const int y = i / W, x = i - y * W;
         const int v = (y + 1) * (y + 1) + x * x;
-        sd2[i] = v;
+        sd2[i] = (uint16_t)v;
         d2[i] = v;
       }
     }
@@ -151,7 +164,7 @@ __global__ __launch_bounds__(WS_T) void ws_seeds_kernel(const uint8_t* __restric
         const int v = sg[reflect_dup(k, H) * Wp + x];
         m = v > m ? v : m;
       }
-      mf[i] = m;
+      sflag[i] = (uint8_t)(m == (int)sd2[i]);   // d. is this voxel a maximum of the filtered distance?
     }
     __syncthreads();
   } else {
@@ -223,7 +236,10 @@ __global__ __launch_bounds__(WS_T) void ws_seeds_kernel(const uint8_t* __restric
     int start = -1;
     for (int x = 0; x < W; ++x) {
       const int i = y * W + x;
-      if (mf[i] == d2[i]) {
+      bool is_max;
+      if constexpr (LDS) is_max = sflag[i] != 0;
+      else is_max = mf[i] == d2[i];
+      if (is_max) {
         if (start < 0) start = i;
         par[i] = start;
       } else {
@@ -259,11 +275,19 @@ __global__ __launch_bounds__(WS_T) void ws_seeds_kernel(const uint8_t* __restric
     unite(i, i - W);
   }
   __syncthreads();
-  // raster-order numbering of the roots (scipy.ndimage.label): chunked scan
+  // raster-order numbering of the roots (scipy.ndimage.label): chunked scan (LDS path: over root flags gathered by a
+  // coalesced pass, not over the global parent array element by element)
+  if constexpr (LDS) {
+    for (int i = tid; i < n; i += WS_T) sflag[i] = (uint8_t)(par[i] == i);
+    __syncthreads();
+  }
   const int chunk = (n + WS_T - 1) / WS_T;
   const int c0 = tid * chunk, c1 = min(n, c0 + chunk);
   int cnt = 0;
-  for (int i = c0; i < c1; ++i) cnt += (par[i] == i);
+  for (int i = c0; i < c1; ++i) {
+    if constexpr (LDS) cnt += sflag[i];
+    else cnt += (par[i] == i);
+  }
   sh_cnt[tid] = cnt;
   __syncthreads();
   if (tid == 0) {
@@ -273,8 +297,12 @@ __global__ __launch_bounds__(WS_T) void ws_seeds_kernel(const uint8_t* __restric
   }
   __syncthreads();
   int id = sh_cnt[tid];
-  for (int i = c0; i < c1; ++i)
-    if (par[i] == i) g[i] = ++id;  // g reused: root index -> label
+  for (int i = c0; i < c1; ++i) {
+    bool root;
+    if constexpr (LDS) root = sflag[i] != 0;
+    else root = par[i] == i;
+    if (root) g[i] = ++id;  // g reused: root index -> label
+  }
   __syncthreads();
   // markers = label * mask (seeds outside the mask vanish inside skimage)
   for (int i = tid; i < n; i += WS_T) {
@@ -282,7 +310,10 @@ __global__ __launch_bounds__(WS_T) void ws_seeds_kernel(const uint8_t* __restric
     if (par[i] >= 0) {
       const int sl = g[find(i)];
       if (s.seedlab) s.seedlab[(size_t)z * n + i] = sl;
-      if (mask[i]) l = sl;
+      bool inside;
+      if constexpr (LDS) inside = smask[i] != 0;
+      else inside = mask[i] != 0;
+      if (inside) l = sl;
     } else if (s.seedlab) {
       s.seedlab[(size_t)z * n + i] = 0;
     }
@@ -2211,7 +2242,9 @@ int bsmi_ws_fragments_seeds_u8(bsmi_seg* h, const uint8_t* affs_dev, const int64
   }
   {
     // squared distances must fit the uint16 intermediates of the LDS path: H^2 + W^2 < 65535
-    const size_t lds = (((size_t)H * (W + 2) * 2 + 15) & ~(size_t)15) + (size_t)H * W * 4;
+    // sg u16 [H][W+2] | sd2 u16 [H*W] | smask u8 [H*W] | sflag u8 [H*W], each 16-byte aligned (ws_seeds_kernel)
+    const size_t hw16 = ((size_t)H * W + 15) & ~(size_t)15;
+    const size_t lds = (((size_t)H * (W + 2) * 2 + 15) & ~(size_t)15) + (((size_t)H * W * 2 + 15) & ~(size_t)15) + 2 * hw16;
     const bool use_lds = lds <= 158 * 1024 && (size_t)H * H + (size_t)W * W < 65535 && (H + 1) * (H + 1) + W * W < 65535;
     if (use_lds) {
       static DeviceOnce once;

@@ -195,9 +195,9 @@ static int pack_conv(bsmi_unet* h, PassSite& p, int ci, int prec) {
 
   pc.lo_image_bytes = fused ? nelem * esize(prec) : 0;
   std::vector<uint8_t> packed(nelem * esize(prec) * (fused ? 2 : 1), 0);
-  for (size_t u = 0; u < pc.entries.size(); ++u) {
+  host_parallel_for(pc.entries.size(), [&](size_t u) {   // every unit writes its own rows of the image(s)
     const PackEntry& e = pc.entries[u];
-    if (e.dummy) continue;
+    if (e.dummy) return;
     const size_t s = u / kUnitsPerStep, j = u % kUnitsPerStep;
     for (int n = 0; n < p.cout; ++n) {
       for (int kk = 0; kk < SUB; ++kk) {
@@ -227,7 +227,7 @@ static int pack_conv(bsmi_unet* h, PassSite& p, int ci, int prec) {
         }
       }
     }
-  }
+  });
   BSMI_HIP(hipMalloc(&pc.w, packed.size()));
   BSMI_HIP(hipMemcpy(pc.w, packed.data(), packed.size(), hipMemcpyHostToDevice));
   BSMI_HIP(hipMalloc((void**)&pc.bias, bias.size() * sizeof(float)));

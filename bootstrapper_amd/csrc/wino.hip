@@ -264,9 +264,9 @@ void wino_pack_weights(const float* w, int cout, int cin, const std::vector<int>
   image_elems = kWinoBatch * batch_elems + (size_t)kWeightRowSlack * 32;
   packed.assign(2 * image_elems, 0);
   static const double G[4][3] = {{1, 0, 0}, {.5, .5, .5}, {.5, -.5, .5}, {0, 0, 1}};
-  for (size_t u = 0; u < units.size(); ++u) {
+  host_parallel_for(units.size(), [&](size_t u) {   // every unit writes its own rows of the images
     const WinoUnit& un = units[u];
-    if (un.dummy) continue;
+    if (un.dummy) return;
     const size_t s = u / kUnitsPerStep, j = u % kUnitsPerStep;
     for (int n = 0; n < cout; ++n)
       for (int kk = 0; kk < 16; ++kk) {
@@ -285,7 +285,7 @@ void wino_pack_weights(const float* w, int cout, int cin, const std::vector<int>
             packed[image_elems + idx] = host_bf16(v - host_bf16_f32(hi));
           }
       }
-  }
+  });
 }
 
 }  // namespace bsmi
