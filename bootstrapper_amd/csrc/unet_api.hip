@@ -262,6 +262,8 @@ static int pack_wino(bsmi_unet* h, PassSite& p, int ci) {
   PackedWino& pw = p.wino[ci];
   if (pw.w) { (void)hipFree(pw.w); pw.w = nullptr; }
   if (pw.res_w) { (void)hipFree(pw.res_w); pw.res_w = nullptr; }
+  for (int part = 0; part < 2; ++part)
+    if (pw.res_part_w[part]) { (void)hipFree(pw.res_part_w[part]); pw.res_part_w[part] = nullptr; }
   pw.ready = false;
   if (!wino_eligible(p, ci)) return BSMI_OK;
   const HostWeight& wm = h->weights[p.prefix + ".conv_pass." + std::to_string(2 * ci) + ".weight"];
@@ -304,38 +306,68 @@ static int pack_wino(bsmi_unet* h, PassSite& p, int ci) {
     }
     if ((pw.res_entries.size() / kUnitsPerStep) % 2)
       for (int j = 0; j < kUnitsPerStep; ++j) pw.res_entries.push_back(PackEntry{0, 0, 0, 0, 0, 0, 0, 0, 0, true, 0});
-    const size_t nsteps = pw.res_entries.size() / kUnitsPerStep;
-    const size_t nelem = (nsteps * (size_t)pw.Npad + kWeightRowSlack) * 32;
-    std::vector<uint16_t> packed(2 * nelem, 0);
     const int64_t cin_r = wr.shape[1];
-    for (size_t u = 0; u < pw.res_entries.size(); ++u) {
-      const PackEntry& e = pw.res_entries[u];
-      if (e.dummy) continue;
-      const size_t s = u / kUnitsPerStep, j = u % kUnitsPerStep;
-      for (int n = 0; n < p.cout; ++n)
-        for (int kk = 0; kk < 16; ++kk) {
-          const int c = e.c0 + kk;
-          if (c >= e.creal) break;
-          const float v = wr.data[(size_t)n * cin_r + (e.cin_base + c)];
-          const size_t idx = (s * pw.Npad + n) * 32 + j * 16 + kk;
-          const uint16_t hi = host_f32_to_bf16(v);
-          packed[idx] = hi;
-          packed[nelem + idx] = host_f32_to_bf16(v - host_bf16_to_f32(hi));
-        }
+    auto pack_res = [&](const std::vector<PackEntry>& ents, void** w_out, size_t* lo_out) -> int {
+      const size_t nsteps = ents.size() / kUnitsPerStep;
+      const size_t nelem = (nsteps * (size_t)pw.Npad + kWeightRowSlack) * 32;
+      std::vector<uint16_t> packed(2 * nelem, 0);
+      for (size_t u = 0; u < ents.size(); ++u) {
+        const PackEntry& e = ents[u];
+        if (e.dummy) continue;
+        const size_t s = u / kUnitsPerStep, j = u % kUnitsPerStep;
+        for (int n = 0; n < p.cout; ++n)
+          for (int kk = 0; kk < 16; ++kk) {
+            const int c = e.c0 + kk;
+            if (c >= e.creal) break;
+            const float v = wr.data[(size_t)n * cin_r + (e.cin_base + c)];
+            const size_t idx = (s * pw.Npad + n) * 32 + j * 16 + kk;
+            const uint16_t hi = host_f32_to_bf16(v);
+            packed[idx] = hi;
+            packed[nelem + idx] = host_f32_to_bf16(v - host_bf16_to_f32(hi));
+          }
+      }
+      *lo_out = nelem * 2;
+      BSMI_HIP(hipMalloc(w_out, packed.size() * 2));
+      BSMI_HIP(hipMemcpy(*w_out, packed.data(), packed.size() * 2, hipMemcpyHostToDevice));
+      return BSMI_OK;
+    };
+    int rc = pack_res(pw.res_entries, &pw.res_w, &pw.res_lo_image_bytes);
+    if (rc) return rc;
+    for (int part = 0; part < 2; ++part) pw.res_part[part].clear();
+    if (p.nslots == 2) {  // the branch cut by source: the skip connection, the upsampled map (the last slot of the launch)
+      const int up_slot = (ci == 0 ? 0 : 1) + 1;
+      for (size_t u = 0; u + 1 < pw.res_entries.size(); u += kUnitsPerStep) {
+        int slot = -1;
+        for (int j = 0; j < kUnitsPerStep; ++j)
+          if (!pw.res_entries[u + j].dummy) slot = pw.res_entries[u + j].slot;
+        if (slot < 0) continue;  // the padding K-step of the whole list
+        for (int j = 0; j < kUnitsPerStep; ++j) pw.res_part[slot == up_slot ? 1 : 0].push_back(pw.res_entries[u + j]);
+      }
+      for (int part = 0; part < 2; ++part) {
+        if ((pw.res_part[part].size() / kUnitsPerStep) % 2)
+          for (int j = 0; j < kUnitsPerStep; ++j) pw.res_part[part].push_back(PackEntry{0, 0, 0, 0, 0, 0, 0, 0, 0, true, 0});
+        if ((rc = pack_res(pw.res_part[part], &pw.res_part_w[part], &pw.res_part_lo[part]))) return rc;
+      }
     }
-    pw.res_lo_image_bytes = nelem * 2;
-    BSMI_HIP(hipMalloc(&pw.res_w, packed.size() * 2));
-    BSMI_HIP(hipMemcpy(pw.res_w, packed.data(), packed.size() * 2, hipMemcpyHostToDevice));
   }
   pw.ready = true;
   return BSMI_OK;
 }
+
+// An upsampled map whose only readers are Winograd stages of the ConvPass that follows it (its first stage's taps, its
+// last stage's residual branch): the stages read the LOW-resolution tensor and interpolate on the fly, the UP step is skipped.
+struct UpFuse {
+  TDesc low;    // the tensor below the upsampling
+  int f[3];     // factors (1, f, f)
+  int o[3];     // crop offset of the upsampled map inside the full upsampling (Upsample.crop_to_factor, unet.py:177-183)
+};
 
 struct Planner {
   bsmi_unet* h;
   int prec;
   Plan* plan;
   bool dry;  // shape / flop arithmetic only: no allocation, no device traffic
+  const UpFuse* fuse_up = nullptr;  // set while the ConvPass behind a fused upsampling is planned
 
   int alloc(TDesc& t) {
     t.Cpad = round_up(t.C, kChanPad);
@@ -683,11 +715,18 @@ struct Planner {
   int plan_wino(PassSite& p, int ci, const PackedConv& pc, const TDesc* slots, const int (*so)[3], int nsl, const TDesc& o, PlanStep& st) {
     st.use_wino = false;
     const PackedWino& pw = p.wino[ci];
-    if (prec != BSMI_PREC_BF16X3 || !pw.ready || (o.H & 1) || (o.W & 1) || st.use_box || st.use_rh || st.use_rhx) return BSMI_OK;
+    const bool wants_fused = fuse_up && (ci == 0 || ci == p.nconv - 1);
+    if (prec != BSMI_PREC_BF16X3 || !pw.ready || (o.H & 1) || (o.W & 1) || st.use_box || st.use_rh || st.use_rhx) {
+      if (wants_fused) BSMI_FAIL(BSMI_ERR_STATE, "%s conv %d: the upsampling was fused into this stage, which cannot take the Winograd form", p.prefix.c_str(), ci);
+      return BSMI_OK;
+    }
     const int nsrc = ci == 0 ? p.nslots : 1;
     const int Dv = o.D + 2, Ty = o.H / 2, Tx = o.W / 2, Cv = pw.Cv;
     const size_t vbatch = (size_t)Dv * Ty * Tx * Cv * 4;  // bytes of one batch of V: (hi, lo) pairs
-    if (vbatch >= ((size_t)1 << 31)) return BSMI_OK;       // 31-bit byte offsets inside a batch
+    if (vbatch >= ((size_t)1 << 31)) {                     // 31-bit byte offsets inside a batch
+      if (wants_fused) BSMI_FAIL(BSMI_ERR_STATE, "%s conv %d: fused upsampling, but the transformed input is too large", p.prefix.c_str(), ci);
+      return BSMI_OK;
+    }
     const size_t Mrows = (size_t)o.D * Ty * Tx;
     void *V = nullptr, *Mbuf = nullptr, *addend = nullptr;
     BSMI_HIP(hipMalloc(&V, kWinoBatch * vbatch + 4096));
@@ -705,6 +744,13 @@ struct Planner {
       wi.oz[q] = so[q][0]; wi.oy[q] = so[q][1]; wi.ox[q] = so[q][2];
       wi.cv0[q] = cv0;
       cv0 += t.Cpad;
+      if (fuse_up && ci == 0 && q == 1) {  // the upsampled map: read below the upsampling
+        if (fuse_up->low.Cpad != t.Cpad) BSMI_FAIL(BSMI_ERR_STATE, "%s: fused upsampling with a different channel padding", p.prefix.c_str());
+        wi.src[q] = fuse_up->low.ptr;
+        wi.H[q] = fuse_up->low.H; wi.W[q] = fuse_up->low.W;
+        wi.oz[q] += fuse_up->o[0]; wi.oy[q] += fuse_up->o[1]; wi.ox[q] += fuse_up->o[2];
+        wi.upf[q] = fuse_up->f[1];
+      }
     }
     if (cv0 != Cv) BSMI_FAIL(BSMI_ERR_STATE, "%s conv %d: winograd channel layout %d != %d", p.prefix.c_str(), ci, cv0, Cv);
     wi.nsrc = nsrc;
@@ -750,21 +796,76 @@ struct Planner {
     g.a_batch = (int64_t)vbatch;
     g.w_batch = (int64_t)pw.batch_bytes;
     // residual branch
-    st.wino_has_res = !pw.res_entries.empty();
+    const bool last = ci == p.nconv - 1;
+    const bool cut = fuse_up && last;  // the branch in two parts: the skip connection here, the upsampled map below the upsampling
+    if (cut && (pw.res_part[0].empty() || pw.res_part[1].empty())) BSMI_FAIL(BSMI_ERR_STATE, "%s: fused upsampling without a cut residual branch", p.prefix.c_str());
+    const std::vector<PackEntry>& res_entries = cut ? pw.res_part[0] : pw.res_entries;
+    st.wino_has_res = !res_entries.empty();
+    st.wino_has_res_low = false;
+    void* low = nullptr;
+    int low_off[3] = {0, 0, 0};
+    if (cut) {
+      const TDesc& g = fuse_up->low;
+      const size_t Mlow = (size_t)g.D * g.H * g.W;
+      BSMI_HIP(hipMalloc(&low, Mlow * o.Cpad * sizeof(float)));
+      plan->allocs.push_back(low);
+      plan->bytes += Mlow * o.Cpad * sizeof(float);
+      ConvArgs& r = st.wino_res_low;
+      memset(&r, 0, sizeof r);
+      for (int sl = 0; sl < kMaxConvTensors; ++sl) {
+        r.t[sl].base = (uint64_t)(uintptr_t)g.ptr;
+        r.t[sl].sz = (int32_t)((int64_t)g.H * g.W * g.Cpad * 4);
+        r.t[sl].sy = (int32_t)((int64_t)g.W * g.Cpad * 4);
+        r.t[sl].sx = (int32_t)((int64_t)g.Cpad * 4);
+      }
+      const std::vector<PackEntry>& ents = pw.res_part[1];
+      std::vector<KStep> ks(ents.size() / kUnitsPerStep);
+      int up_slot = -1;
+      for (size_t s = 0; s < ks.size(); ++s) {
+        KStep k;
+        memset(&k, 0, sizeof k);
+        for (int j = 0; j < kUnitsPerStep; ++j) {
+          const PackEntry& e = ents[kUnitsPerStep * s + j];
+          if (e.dummy) continue;
+          k.delta[j] = (int32_t)((int64_t)e.c0 * 4);  // a 1x1x1 convolution of the low-resolution tensor itself: no spatial offset here
+          up_slot = e.slot;
+          low_off[0] = e.dz; low_off[1] = e.dy; low_off[2] = e.dx;  // the branch's crop: applied by the output transform
+        }
+        ks[s] = k;
+      }
+      if (up_slot < 0) BSMI_FAIL(BSMI_ERR_STATE, "%s: empty low-resolution residual", p.prefix.c_str());
+      for (int d = 0; d < 3; ++d) low_off[d] += so[up_slot][d] + fuse_up->o[d];
+      KStep* dks = nullptr;
+      BSMI_HIP(hipMalloc((void**)&dks, ks.size() * sizeof(KStep)));
+      plan->allocs.push_back(dks);
+      BSMI_HIP(hipMemcpy(dks, ks.data(), ks.size() * sizeof(KStep), hipMemcpyHostToDevice));
+      r.steps = dks;
+      r.nsteps = (int)ks.size();
+      r.w = pw.res_part_w[1];
+      r.w_lo = (const char*)pw.res_part_w[1] + pw.res_part_lo[1];
+      r.bias = pc.bias;
+      r.out = low;
+      r.Do = g.D; r.Ho = g.H; r.Wo = g.W; r.Co = o.Cpad;
+      r.M = (int)Mlow;
+      r.Npad = pw.Npad;
+      r.relu = 0;
+      r.raw = 1;
+      st.wino_has_res_low = true;
+    }
     if (st.wino_has_res) {
       BSMI_HIP(hipMalloc(&addend, (size_t)o.D * o.H * o.W * o.Cpad * sizeof(float)));
       plan->allocs.push_back(addend);
       plan->bytes += (size_t)o.D * o.H * o.W * o.Cpad * sizeof(float);
       ConvArgs& r = st.wino_res;
       r = st.conv;  // the direct launch's source tensors and output geometry
-      std::vector<KStep> ks(pw.res_entries.size() / kUnitsPerStep);
+      std::vector<KStep> ks(res_entries.size() / kUnitsPerStep);
       for (size_t s = 0; s < ks.size(); ++s) {
         KStep k;
         memset(&k, 0, sizeof k);
-        const PackEntry& e0 = pw.res_entries[kUnitsPerStep * s];
+        const PackEntry& e0 = res_entries[kUnitsPerStep * s];
         k.tensor = e0.dummy ? 0 : e0.slot;
         for (int j = 0; j < kUnitsPerStep; ++j) {
-          const PackEntry& e = pw.res_entries[kUnitsPerStep * s + j];
+          const PackEntry& e = res_entries[kUnitsPerStep * s + j];
           if (e.dummy) continue;
           const TDesc& t = slots[e.slot];
           const int64_t off = ((((int64_t)(e.dz + so[e.slot][0]) * t.H) + (e.dy + so[e.slot][1])) * t.W + (e.dx + so[e.slot][2])) * t.Cpad + e.c0;
@@ -778,8 +879,8 @@ struct Planner {
       BSMI_HIP(hipMemcpy(dks, ks.data(), ks.size() * sizeof(KStep), hipMemcpyHostToDevice));
       r.steps = dks;
       r.nsteps = (int)ks.size();
-      r.w = pw.res_w;
-      r.w_lo = (const char*)pw.res_w + pw.res_lo_image_bytes;
+      r.w = cut ? pw.res_part_w[0] : pw.res_w;
+      r.w_lo = (const char*)r.w + (cut ? pw.res_part_lo[0] : pw.res_lo_image_bytes);
       r.out = addend;
       r.Npad = pw.Npad;
       r.relu = 0;
@@ -790,6 +891,12 @@ struct Planner {
     memset(&wo, 0, sizeof wo);
     wo.M = (const float*)Mbuf;
     wo.addend = (const float*)addend;
+    if (cut) {
+      wo.low = (const float*)low;
+      wo.lD = fuse_up->low.D; wo.lH = fuse_up->low.H; wo.lW = fuse_up->low.W;
+      wo.lf = fuse_up->f[1];
+      wo.loz = low_off[0]; wo.loy = low_off[1]; wo.lox = low_off[2];
+    }
     wo.bias = pc.bias;
     wo.out = o.ptr;
     wo.Do = o.D; wo.Ty = Ty; wo.Tx = Tx; wo.Co = o.Cpad;
@@ -997,15 +1104,46 @@ struct Planner {
         BSMI_FAIL(BSMI_ERR_INVALID, "skip connection (%d,%d,%d) smaller than upsampled map (%d,%d,%d)",
                   dims[0], dims[1], dims[2], target[0], target[1], target[2]);
     }
+    // Fused upsampling (BSMI_FUSE_UP=0: off): when the first and the last stage of the ConvPass both run in Winograd form, they
+    // read the map below the upsampling and interpolate on the fly -- the first stage's input transform, and the last stage's
+    // residual branch as a 1x1x1 convolution BELOW the upsampling (it commutes with the per-channel interpolation) whose sums
+    // the output transform interpolates.  The upsampled map (1.3 GB for the 1500-channel one of the 128^3 block) is then
+    // neither written nor read: 0.54 ms of upsampling, 1 GB of transform reads and four fifths of the residual GEMM saved.
+    UpFuse uf;
+    bool fuse = false;
+    if (!dry && prec == BSMI_PREC_BF16X3 && f[0] == 1 && f[1] == 2 && f[2] == 2 && rp.nslots == 2 && rp.wino[0].ready &&
+        rp.wino[rp.nconv - 1].ready && !rp.wino[rp.nconv - 1].res_part[1].empty() && g_out.ptr) {
+      static const bool on = [] { const char* e = getenv("BSMI_FUSE_UP"); return !(e && e[0] == '0'); }();
+      static const bool rhx = [] { const char* e = getenv("BSMI_USE_RHX"); return e && e[0] == '1'; }();
+      fuse = on && !rhx;
+      int sp[3] = {target[0], target[1], target[2]};
+      for (int c = 0; c < rp.nconv && fuse; ++c) {
+        for (int d = 0; d < 3; ++d) sp[d] -= rp.k[c][d] - 1;
+        if ((c == 0 || c == rp.nconv - 1) && ((sp[1] & 1) || (sp[2] & 1) || sp[0] <= 0 || sp[1] <= 0 || sp[2] <= 0)) fuse = false;
+        if ((c == 0 || c == rp.nconv - 1) && (size_t)(sp[0] + 2) * (sp[1] / 2) * (sp[2] / 2) * rp.wino[c].Cv * 4 >= ((size_t)1 << 31)) fuse = false;
+      }
+    }
+    size_t up_index = 0;
     if (!dry) {
       PlanStep st;
       st.type = PlanStep::UP;
       st.in = g_out; st.out = g_c;
       for (int d = 0; d < 3; ++d) { st.f[d] = f[d]; st.o[d] = (up[d] - target[d]) / 2; }
+      st.skip = fuse;
+      up_index = plan->steps.size();
       plan->steps.push_back(st);
     }
+    if (fuse) {
+      uf.low = g_out;
+      for (int d = 0; d < 3; ++d) { uf.f[d] = f[d]; uf.o[d] = (up[d] - target[d]) / 2; }
+      fuse_up = &uf;
+      if (getenv("BSMI_PLAN_DEBUG")) fprintf(stderr, "[bsmi plan] %s: upsampling fused into the Winograd stages\n", rp.prefix.c_str());
+    }
     const TDesc ins[2] = {f_left, g_c};
-    return pass(rp, ins, so, target, f_out);
+    rc = pass(rp, ins, so, target, f_out);
+    fuse_up = nullptr;
+    (void)up_index;
+    return rc;
   }
 
   int run(const int64_t in_shape[3]) {
@@ -1240,6 +1378,8 @@ int bsmi_unet_destroy(bsmi_unet* h) {
     for (int c = 0; c < BSMI_MAX_CONVS; ++c) {
       if (p.wino[c].w) (void)hipFree(p.wino[c].w);
       if (p.wino[c].res_w) (void)hipFree(p.wino[c].res_w);
+      for (int part = 0; part < 2; ++part)
+        if (p.wino[c].res_part_w[part]) (void)hipFree(p.wino[c].res_part_w[part]);
     }
   };
   for (auto& p : h->l_conv) free_site(p);
@@ -1446,6 +1586,7 @@ int bsmi_unet_forward(bsmi_unet* h, int precision, const void* raw_dev, int raw_
           if ((rc = launch_wino_in(st.wino_in, s))) break;
           if ((rc = launch_conv_igemm(st.wino_gemm, precision, st.tile, s, h->sk_ws, h->sk_grid))) break;
           if (st.wino_has_res && (rc = launch_conv_igemm(st.wino_res, precision, st.tile, s, h->sk_ws, h->sk_grid))) break;
+          if (st.wino_has_res_low && (rc = launch_conv_igemm(st.wino_res_low, precision, st.tile, s, h->sk_ws, h->sk_grid))) break;
           rc = launch_wino_out(st.wino_out, s);
           break;
         }
@@ -1460,6 +1601,7 @@ int bsmi_unet_forward(bsmi_unet* h, int precision, const void* raw_dev, int raw_
                             st.f[0], st.f[1], st.f[2], s);
         break;
       case PlanStep::UP:
+        if (st.skip) break;  // its readers interpolate on the fly (Planner::rec, fused upsampling)
         rc = launch_upsample_crop(precision, st.in.ptr, st.out.ptr, st.in.D, st.in.H, st.in.W, st.in.Cpad,
                                   st.out.D, st.out.H, st.out.W, st.f[0], st.f[1], st.f[2], st.o[0], st.o[1], st.o[2], s);
         break;

@@ -67,6 +67,12 @@ struct PackedWino {
   std::vector<PackEntry> res_entries;  // units of the residual-only launch (empty: no residual branch on this stage)
   void* res_w = nullptr;
   size_t res_lo_image_bytes = 0;
+  // the same branch cut in two for a ConvPass whose second source is an upsampled map (unet.py:215-223): [0] the units of the
+  // skip connection (a launch at full resolution), [1] those of the upsampled map, which then run BELOW the upsampling
+  // (plan_wino, fuse_up); each list padded to an even number of K-steps, each with its own weight images
+  std::vector<PackEntry> res_part[2];
+  void* res_part_w[2] = {nullptr, nullptr};
+  size_t res_part_lo[2] = {0, 0};
 };
 
 struct PassSite {
@@ -105,12 +111,13 @@ struct PlanStep {
   // Winograd form of this step (use_wino): input transform, batched GEMMs, [residual-only launch], output transform
   bool use_wino = false;
   WinoInArgs wino_in;
-  ConvArgs wino_gemm, wino_res;
-  bool wino_has_res = false;
+  ConvArgs wino_gemm, wino_res, wino_res_low;
+  bool wino_has_res = false, wino_has_res_low = false;
   WinoOutArgs wino_out;
   TileCfg tile;
   TDesc in, out;
   int f[3], o[3];
+  bool skip = false;     // UP step whose map nobody reads: its consumers upsample on the fly (plan_wino, fuse_up)
   int head = 0;
   double flops = 0;  // algorithmic FLOPs of this launch
   // what the backward pass (train.hip) needs to know about a CONV step

@@ -16,6 +16,11 @@ struct WinoInArgs {
   int H[kWinoMaxSrc], W[kWinoMaxSrc], Cpad[kWinoMaxSrc];
   int oz[kWinoMaxSrc], oy[kWinoMaxSrc], ox[kWinoMaxSrc];  // origin of the layer's input inside the source (the skip connection's crop)
   int cv0[kWinoMaxSrc];                                   // first channel of the source inside V
+  // upf[q] = f > 0: source q is read through an in-plane linear upsampling by f (torch's Upsample(scale (1, f, f), "trilinear",
+  // align_corners = False), reference unet.py:143): the layer's input is upsample(src)[oz + z][oy + y][ox + x] and H, W are
+  // the dimensions of the LOW-resolution tensor -- the upsampled map is never written (round 3: the 1500-channel map of the
+  // 128^3 block is 1.3 GB that the stage's transform was the only reader of besides a residual branch, see WinoOutArgs)
+  int upf[kWinoMaxSrc];
   int nsrc;
   void* V;  // split-bf16 [16][Dv][Ty][Tx][Cv]
   int Dv, Ty, Tx, Cv;
@@ -26,6 +31,11 @@ struct WinoInArgs {
 struct WinoOutArgs {
   const float* M;       // [16][Do * Ty * Tx][Co]
   const float* addend;  // optional raw sums of the cropped 1x1x1 residual branch, [Do * Ho * Wo][Co]
+  // optional: the part of the residual branch that reads an upsampled map, computed BELOW the upsampling (a 1x1x1 convolution
+  // commutes with the per-channel interpolation): raw sums [lD * lH * lW][Co] at low resolution, added as
+  // upsample_lf(low)[loz + z][loy + y][lox + x]
+  const float* low;
+  int lD, lH, lW, lf, loz, loy, lox;
   const float* bias;    // [>= Co]
   void* out;            // split-bf16 [Do][2 Ty][2 Tx][Co]
   int Do, Ty, Tx, Co;

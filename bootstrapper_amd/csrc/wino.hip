@@ -70,6 +70,19 @@ __device__ __forceinline__ void store_split8(uint16_t* base, size_t e, const flo
   }
 }
 
+// source index pair and weights of one output index of torch's linear upsampling (align_corners = False); the arithmetic of
+// unet_ops.hip lin_src, operation for operation
+__device__ __forceinline__ void lin_src(int dst, int f, int n, int& i0, int& i1, float& w0, float& w1) {
+  float src = ((float)dst + 0.5f) * (1.0f / (float)f) - 0.5f;
+  src = src < 0.f ? 0.f : src;
+  i0 = (int)src;
+  i0 = i0 < n - 1 ? i0 : n - 1;
+  i1 = i0 + 1 < n ? i0 + 1 : n - 1;
+  w1 = src - (float)i0;
+  w1 = w1 < 0.f ? 0.f : (w1 > 1.f ? 1.f : w1);
+  w0 = 1.f - w1;
+}
+
 // One thread: 8 channels of source `src` along one row of tiles (z, ty), tx = 0 .. Tx - 1.  Neighbouring tiles share two of
 // their four input columns: the thread keeps the row-transformed columns (B^T d, a per-column operation) of the previous tile
 // and loads two new columns per tile -- half the loads and half the row arithmetic of a tile-per-thread form.  Blocks are
@@ -135,7 +148,99 @@ __global__ __launch_bounds__(256) void wino_in_kernel(const WinoInArgs a, int sr
   }
 }
 
+// The input transform of a source that is read through a factor-2 in-plane upsampling (WinoInArgs::upf = 2).  A 4 x 4 tile of
+// the upsampled map interpolates a 4 x 4 window L of the low-resolution tensor, d = Uy L Ux^T, so the transform is
+// V = (B^T Uy) L (B^T Ux)^T with constant 4 x 4 matrices that depend only on the parity of the tile's first upsampled index:
+//   even (rows 2a .. 2a+3 from low rows a-1 .. a+2):  Uy = [.25 .75 0 0; 0 .75 .25 0; 0 .25 .75 0; 0 0 .75 .25]
+//   odd  (rows 2a+1 .. 2a+4 from low rows a .. a+3):   Uy = [.75 .25 0 0; .25 .75 0 0; 0 .75 .25 0; 0 .25 .75 0]
+// (torch's weights for scale 2, align_corners = False; at the faces the window repeats the outermost row / column, which is
+// what the clamped source index of the reference amounts to, to within the rounding of .25 x + .75 x against x).  All
+// coefficients are exact binary fractions.  The thread walks a row of tiles: the window moves by ONE low-resolution column per
+// tile, so a tile costs four loads -- half of what the plain transform needs -- and no upsampled map exists anywhere.
+template <int PAR>
+struct UpT {  // T = B^T U_PAR, row xi over the window's four entries
+  static constexpr float v[4][4] = {
+      {PAR ? 0.75f : 0.25f, PAR ? -0.5f : 0.5f, PAR ? -0.25f : -0.75f, 0.f},   // U0 - U2
+      {PAR ? 0.25f : 0.f, PAR ? 1.5f : 1.f, PAR ? 0.25f : 1.f, 0.f},            // U1 + U2
+      {PAR ? -0.25f : 0.f, PAR ? 0.f : -0.5f, PAR ? 0.25f : 0.5f, 0.f},         // U2 - U1
+      {PAR ? 0.25f : 0.f, PAR ? 0.5f : 0.75f, PAR ? -0.75f : -0.5f, PAR ? 0.f : -0.25f}};  // U1 - U3
+};
+template <int PY, int PX>
+__global__ __launch_bounds__(256) void wino_in_up_kernel(const WinoInArgs a, int src, size_t total) {
+  const unsigned nb = gridDim.x, q = nb >> 3, r = nb & 7, xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
+  const unsigned blk = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + j;
+  const size_t i = (size_t)blk * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  const int ncv = a.Cpad[src] >> 3;
+  const int cv = (int)(i % ncv);
+  const size_t t = i / ncv;
+  const int ty = (int)(t % a.Ty);
+  const int z = (int)(t / a.Ty);
+  const uint16_t* sp = (const uint16_t*)a.src[src];
+  const int H = a.H[src], W = a.W[src], C = a.Cpad[src];
+  const size_t e_low = ((size_t)(z + a.oz[src]) * H) * W * C + 8 * cv;
+  // low-resolution rows of the window (clamped) and the column of its first entry for tile 0
+  const int ay = ((2 * ty + a.oy[src]) >> 1) - 1 + PY;
+  int wy[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int y = ay + k;
+    wy[k] = y < 0 ? 0 : (y > H - 1 ? H - 1 : y);
+  }
+  const int bx = (a.ox[src] >> 1) - 1 + PX;
+  uint16_t* V = (uint16_t*)a.V;
+  const size_t plane = (size_t)a.Dv * a.Ty * a.Tx * a.Cv;
+  const size_t e_out = (((size_t)z * a.Ty + ty) * a.Tx) * a.Cv + a.cv0[src] + 8 * cv;
+  float ct[4][4][8];  // ct[c][xi] = sum_k Ty[xi][k] L[k][window column c]
+  auto load_ct = [&](int c, int xlow) __attribute__((always_inline)) {
+    const int x = xlow < 0 ? 0 : (xlow > W - 1 ? W - 1 : xlow);
+    float L[4][8];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) load_split8(sp, e_low + ((size_t)wy[k] * W + x) * C, L[k]);
+#pragma unroll
+    for (int xi = 0; xi < 4; ++xi)
+#pragma unroll
+      for (int ch = 0; ch < 8; ++ch) {
+        float acc = 0.f;
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+          if (UpT<PY>::v[xi][k] != 0.f) acc += UpT<PY>::v[xi][k] * L[k][ch];
+        ct[c][xi][ch] = acc;
+      }
+  };
+  load_ct(0, bx);
+  load_ct(1, bx + 1);
+  load_ct(2, bx + 2);
+  for (int tx = 0; tx < a.Tx; ++tx) {
+    load_ct(3, bx + tx + 3);
+    const size_t e0 = e_out + (size_t)tx * a.Cv;
+#pragma unroll
+    for (int xi = 0; xi < 4; ++xi) {
+#pragma unroll
+      for (int nu = 0; nu < 4; ++nu) {
+        float v[8];
+#pragma unroll
+        for (int ch = 0; ch < 8; ++ch) {
+          float acc = 0.f;
+#pragma unroll
+          for (int c = 0; c < 4; ++c)
+            if (UpT<PX>::v[nu][c] != 0.f) acc += UpT<PX>::v[nu][c] * ct[c][xi][ch];
+          v[ch] = acc;
+        }
+        store_split8<false>(V, (size_t)(4 * xi + nu) * plane + e0, v);
+      }
+    }
+#pragma unroll
+    for (int c = 0; c < 3; ++c)
+#pragma unroll
+      for (int xi = 0; xi < 4; ++xi)
+#pragma unroll
+        for (int ch = 0; ch < 8; ++ch) ct[c][xi][ch] = ct[c + 1][xi][ch];
+  }
+}
+
 // one thread: the 2 x 2 output tile of 8 channels at (z, ty, tx)
+template <bool LOW>
 __global__ __launch_bounds__(256) void wino_out_kernel(const WinoOutArgs a, size_t total) {
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= total) return;
@@ -200,6 +305,32 @@ __global__ __launch_bounds__(256) void wino_out_kernel(const WinoOutArgs a, size
           v[4 + k] += r1[k];
         }
       }
+      if constexpr (LOW) {  // the residual branch's sums over the upsampled map, interpolated from their low-resolution form
+        int y0, y1, x0, x1;
+        float wy0, wy1, wx0, wx1;
+        lin_src(2 * ty + p + a.loy, a.lf, a.lH, y0, y1, wy0, wy1);
+        lin_src(2 * tx + q + a.lox, a.lf, a.lW, x0, x1, wx0, wx1);
+        const float* base = a.low + ((size_t)(z + a.loz) * a.lH * a.lW) * a.Co + 8 * cv;
+        float r[4][8];
+        const size_t o[4] = {((size_t)y0 * a.lW + x0) * a.Co, ((size_t)y0 * a.lW + x1) * a.Co, ((size_t)y1 * a.lW + x0) * a.Co,
+                             ((size_t)y1 * a.lW + x1) * a.Co};
+#pragma unroll
+        for (int t4 = 0; t4 < 4; ++t4) {
+          const f32x4_t r0 = *(const f32x4_t*)(base + o[t4]);
+          const f32x4_t r1 = *(const f32x4_t*)(base + o[t4] + 4);
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            r[t4][k] = r0[k];
+            r[t4][4 + k] = r1[k];
+          }
+        }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+          const float pa = wx0 * r[0][k] + wx1 * r[1][k];
+          const float pb = wx0 * r[2][k] + wx1 * r[3][k];
+          v[k] += wy0 * pa + wy1 * pb;
+        }
+      }
       if (a.relu) {
 #pragma unroll
         for (int k = 0; k < 8; ++k) v[k] = v[k] > 0.f ? v[k] : 0.f;
@@ -214,9 +345,20 @@ int launch_wino_in(const WinoInArgs& a, hipStream_t s) {
   if (a.nsrc < 1 || a.nsrc > kWinoMaxSrc || a.Dv <= 0 || a.Ty <= 0 || a.Tx <= 0 || a.Cv % 8) BSMI_FAIL(BSMI_ERR_INVALID, "winograd input transform: bad geometry");
   for (int q = 0; q < a.nsrc; ++q) {
     if (a.Cpad[q] % 8 || a.cv0[q] % 8 || a.cv0[q] + a.Cpad[q] > a.Cv) BSMI_FAIL(BSMI_ERR_INVALID, "winograd input transform: bad channel layout of source %d", q);
-    if (a.oy[q] + 2 * a.Ty + 2 > a.H[q] || a.ox[q] + 2 * a.Tx + 2 > a.W[q]) BSMI_FAIL(BSMI_ERR_INVALID, "winograd input transform: tiles leave source %d", q);
+    const int upf = a.upf[q] > 0 ? a.upf[q] : 1;  // an upsampled source is upf times as large in the plane
+    if (a.oy[q] + 2 * a.Ty + 2 > a.H[q] * upf || a.ox[q] + 2 * a.Tx + 2 > a.W[q] * upf) BSMI_FAIL(BSMI_ERR_INVALID, "winograd input transform: tiles leave source %d", q);
     const size_t total = (size_t)a.Dv * a.Ty * (a.Cpad[q] / 8);  // one thread per (z, tile row, 8 channels)
-    hipLaunchKernelGGL(wino_in_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, a, q, total);
+    const dim3 grid((unsigned)((total + 255) / 256));
+    if (a.upf[q] > 0) {
+      if (a.upf[q] != 2 || a.oy[q] < 0 || a.ox[q] < 0) BSMI_FAIL(BSMI_ERR_INVALID, "winograd input transform: only a factor-2 upsampling can be fused");
+      const int par = 2 * (a.oy[q] & 1) + (a.ox[q] & 1);
+      if (par == 0) hipLaunchKernelGGL((wino_in_up_kernel<0, 0>), grid, dim3(256), 0, s, a, q, total);
+      else if (par == 1) hipLaunchKernelGGL((wino_in_up_kernel<0, 1>), grid, dim3(256), 0, s, a, q, total);
+      else if (par == 2) hipLaunchKernelGGL((wino_in_up_kernel<1, 0>), grid, dim3(256), 0, s, a, q, total);
+      else hipLaunchKernelGGL((wino_in_up_kernel<1, 1>), grid, dim3(256), 0, s, a, q, total);
+    } else {
+      hipLaunchKernelGGL(wino_in_kernel, grid, dim3(256), 0, s, a, q, total);
+    }
   }
   BSMI_HIP(hipGetLastError());
   return BSMI_OK;
@@ -224,8 +366,11 @@ int launch_wino_in(const WinoInArgs& a, hipStream_t s) {
 
 int launch_wino_out(const WinoOutArgs& a, hipStream_t s) {
   if (a.Do <= 0 || a.Ty <= 0 || a.Tx <= 0 || a.Co % 8) BSMI_FAIL(BSMI_ERR_INVALID, "winograd output transform: bad geometry");
+  if (a.low && (a.lf < 1 || a.loz < 0 || a.loz + a.Do > a.lD || a.loy < 0 || a.loy + 2 * a.Ty > a.lH * a.lf || a.lox < 0 || a.lox + 2 * a.Tx > a.lW * a.lf))
+    BSMI_FAIL(BSMI_ERR_INVALID, "winograd output transform: the low-resolution residual does not cover the output");
   const size_t total = (size_t)a.Do * a.Ty * a.Tx * (a.Co / 8);
-  hipLaunchKernelGGL(wino_out_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, a, total);
+  if (a.low) hipLaunchKernelGGL(wino_out_kernel<true>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, a, total);
+  else hipLaunchKernelGGL(wino_out_kernel<false>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, a, total);
   BSMI_HIP(hipGetLastError());
   return BSMI_OK;
 }

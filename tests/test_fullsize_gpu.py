@@ -177,6 +177,13 @@ def test_full_net_volume_pipeline_vs_cpu_blockwise():
     ("fused and listed split-bf16 layers in one forward", {"BSMI_X3_FUSED": "3"}),
     ("fused split-bf16 kernel on 256x160 tiles", {"BSMI_TILE_EFF": "0.01,0.01,1,0.01,0.01"}),
     ("implicit GEMM for the first pass and the small-Cout layers (no first_pass / conv_box)", {"BSMI_FUSED_FIRST": "0", "BSMI_USE_BOX": "0"}),
+    ("Winograd F(2x2,3x3) form on every 3x3x3 stage of the split mode, upsampling fused into its consumers", {"BSMI_WINO": "2"}),
+    ("Winograd on every stage, upsampled maps materialised", {"BSMI_WINO": "2", "BSMI_FUSE_UP": "0"}),
+    ("Winograd on every stage, batched persistent launches with split-K tails (256x256 tiles)",
+     {"BSMI_WINO": "2", "BSMI_SK_GRID": "8", "BSMI_TILE_EFF": "0.01,0.01,0.01,1,0.01"}),
+    ("Winograd on every stage, batched persistent launches with split-K tails (256x320 tiles)",
+     {"BSMI_WINO": "2", "BSMI_SK_GRID": "16", "BSMI_TILE_EFF": "0.01,0.01,0.01,0.01,1"}),
+    ("no Winograd stage", {"BSMI_WINO": "0"}),
 ])
 def test_conv_kernel_variants_in_subprocess(variant, env):
     """The conv kernel variants that the golden nets do not reach by themselves (they are chosen by layer
