@@ -618,15 +618,20 @@ __device__ __forceinline__ void conv_igemm_body16(const ConvArgs& a, char* smem,
 // row block while g1 runs (and A hi by the next K-step's A lo during g5); the two B register halves alternate.
 // Early waves (all waves of a 4-wave kernel, waves 0-3 of an 8-wave one) stage batch 1 in g2 / g3 and batch 2 in g5,
 // LATE waves batch 1 in g5 / g0 and batch 2 in g2, so the two waves of a SIMD do not sit in LDS-DMA issue together.
-template <int BM, int BN, int WM, int WN, int MS, int B_INSTR, bool LATE>
+// CUT: column blocks (of MS) at the end of this wave's tile that are padding and not multiplied -- N = 300 in a 320-column
+// tile: the waves of the second column half (the late waves: wn = wave / WM in the 8-wave kernels) own columns 160 .. 319 of
+// which 304 .. 319 meet nothing but zero weights and masked stores, so they run 9 column blocks instead of 10 and every SIMD,
+// which hosts one wave of each half, 19 MFMA blocks per row block instead of 20.
+template <int BM, int BN, int WM, int WN, int MS, int B_INSTR, bool LATE, int CUT = 0>
 __device__ __forceinline__ void conv_x3_body(const ConvArgs& a, char* smem, int tile, int s0, int s1, float* part) {
   using T = bf16f_elem;
   constexpr int NW = WM * WN;
   static_assert(NW == 4 || NW == 8, "one or two waves per SIMD");
   static_assert(!LATE || NW == 8, "late waves exist in 8-wave kernels only");
+  static_assert(CUT == 0 || (LATE && MS == 16), "the cut belongs to the late waves (second column half)");
   constexpr int ROWB = kStepRowBytes;
   constexpr int WTM = BM / WM, WTN = BN / WN;
-  constexpr int FM = WTM / MS, FN = WTN / MS;
+  constexpr int FM = WTM / MS, FN = WTN / MS - CUT;
   constexpr int NH0 = FN / 2, NH1 = FN - NH0;
   static_assert(MS == 16 || MS == 32, "MFMA shape");
   static_assert(WTM % MS == 0 && WTN % MS == 0 && NH0 >= 1, "wave tile: whole fragments, two B halves");
@@ -664,7 +669,8 @@ __device__ __forceinline__ void conv_x3_body(const ConvArgs& a, char* smem, int 
   const int tid = tid_;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = wave / WN, wn = wave % WN;
+  // 8-wave kernels: waves 0-3 (early) own the first column half, waves 4-7 (late) the second: a SIMD hosts one of each
+  const int wm = NW == 8 ? wave % WM : wave / WN, wn = NW == 8 ? wave / WM : wave % WN;
   const int ntn = aNpad / BN;
   const int nloc = s1 - s0;
   // batched launch (ConvArgs::nbatch): the tile rows of batch b follow those of batch b - 1
@@ -910,7 +916,7 @@ __device__ __forceinline__ void conv_x3_body(const ConvArgs& a, char* smem, int 
 #pragma unroll
     for (int i = 0; i < FM; ++i)
 #pragma unroll
-      for (int j = 0; j < FN; ++j) *(acc_t*)(part + ((size_t)(i * FN + j) * (64 * NW) + tid) * NR) = acc[i][j];
+      for (int j = 0; j < FN; ++j) *(acc_t*)(part + ((size_t)(i * (WTN / MS) + j) * (64 * NW) + tid) * NR) = acc[i][j];  // conv_fixup_kernel's fragment order (a cut wave leaves its last fragments unwritten: padding columns, never stored)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     return;
   }
@@ -1031,14 +1037,14 @@ __device__ __forceinline__ void conv_x3_body(const ConvArgs& a, char* smem, int 
 // wave -> (weight-piece count, early/late) instantiation of the body; MS = MFMA shape (32: 32x32x16 /
 // 32x32x2, 16: v_mfma_f32_16x16x32_bf16, which holds a ~12 % higher clock on real data: MI355X_MICROARCH.md,
 // DVFS give-back item 7)
-template <typename T, int BM, int BN, int WM, int WN, int MS, int BI, bool LATE>
+template <typename T, int BM, int BN, int WM, int WN, int MS, int BI, bool LATE, int CUT = 0>
 __device__ __forceinline__ void conv_igemm_body_ms(const ConvArgs& a, char* smem, int tile, int s0, int s1, float* part) {
-  if constexpr (IsFused<T>::value) conv_x3_body<BM, BN, WM, WN, MS, BI, LATE>(a, smem, tile, s0, s1, part);
+  if constexpr (IsFused<T>::value) conv_x3_body<BM, BN, WM, WN, MS, BI, LATE, CUT>(a, smem, tile, s0, s1, part);
   else if constexpr (MS == 16) conv_igemm_body16<T, BM, BN, WM, WN, BI, LATE>(a, smem, tile, s0, s1, part);
   else conv_igemm_body<T, BM, BN, WM, WN, BI, LATE>(a, smem, tile, s0, s1, part);
 }
 
-template <typename T, int BM, int BN, int WM, int WN, int MS>
+template <typename T, int BM, int BN, int WM, int WN, int MS, int CUT = 0>
 __device__ __forceinline__ void conv_igemm_dispatch(const ConvArgs& a, char* smem, int tile, int s0, int s1, float* part) {
   constexpr int NW = WM * WN, NBP = BN / 16;
   constexpr int HI = (NBP + NW - 1) / NW, LO = NBP / NW;
@@ -1046,7 +1052,7 @@ __device__ __forceinline__ void conv_igemm_dispatch(const ConvArgs& a, char* sme
   if constexpr (NW == 8) {
     static_assert(HI == LO || NBP % NW == 4, "the uneven split must coincide with the early/late split");
     if (wave < 4) conv_igemm_body_ms<T, BM, BN, WM, WN, MS, HI, false>(a, smem, tile, s0, s1, part);
-    else conv_igemm_body_ms<T, BM, BN, WM, WN, MS, LO, true>(a, smem, tile, s0, s1, part);
+    else conv_igemm_body_ms<T, BM, BN, WM, WN, MS, LO, true, CUT>(a, smem, tile, s0, s1, part);
   } else if constexpr (HI == LO) {
     conv_igemm_body_ms<T, BM, BN, WM, WN, MS, HI, false>(a, smem, tile, s0, s1, part);
   } else {
@@ -1058,7 +1064,7 @@ __device__ __forceinline__ void conv_igemm_dispatch(const ConvArgs& a, char* sme
 // T: element type; BM x BN block tile; WM x WN waves: 4 (one per SIMD, up to 512 registers
 // each: 128x128 register tiles) or 8 (two per SIMD, 256 registers each: while one wave of a
 // SIMD sits in the 60-185 cycles an LDS-DMA instruction costs its issuer, the other multiplies).
-template <typename T, int BM, int BN, int WM, int WN, int MS>
+template <typename T, int BM, int BN, int WM, int WN, int MS, int CUT = 0>
 __global__ __launch_bounds__(64 * WM * WN, 1) void conv_igemm_kernel(const ConvArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];  // [NSLOT][A: BM rows | B: BN rows][64 B]
   // XCD-aware tile map: consecutive block ids are dealt round-robin to the 8 XCDs, so give
@@ -1068,7 +1074,7 @@ __global__ __launch_bounds__(64 * WM * WN, 1) void conv_igemm_kernel(const ConvA
   const int q = ntiles >> 3, r = ntiles & 7;
   const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
   const int tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + j;
-  conv_igemm_dispatch<T, BM, BN, WM, WN, MS>(a, smem, tile, 0, a.nsteps, nullptr);
+  conv_igemm_dispatch<T, BM, BN, WM, WN, MS, CUT>(a, smem, tile, 0, a.nsteps, nullptr);
 }
 
 // Persistent form with a split-K tail: one workgroup per CU.  A plain launch of 779 tiles on 256
@@ -1098,7 +1104,7 @@ __device__ __forceinline__ SkGeom sk_geom(int ntiles, int xcd, int G) {
 // helps the others, so a CU that other streams keep busy (the segmentation lanes of the block
 // pipeline) only delays its own share by one tile; a workgroup that becomes resident late finds
 // the queues empty and leaves.  conv_fixup_kernel re-zeroes the counters for the next launch.
-template <typename T, int BM, int BN, int WM, int WN, int MS>
+template <typename T, int BM, int BN, int WM, int WN, int MS, int CUT = 0>
 __global__ __launch_bounds__(64 * WM * WN, 1) void conv_igemm_sk_kernel(const ConvArgs a, float* ws, int* counters) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   __shared__ int sh_item;
@@ -1128,7 +1134,7 @@ __global__ __launch_bounds__(64 * WM * WN, 1) void conv_igemm_sk_kernel(const Co
         dst = g.P == 1 ? nullptr : ws + ((size_t)xcd * g.per + r) * (BM * BN);
         tile_i = g.base + nfull + rt;
       }
-      if (sb > sa) conv_igemm_dispatch<T, BM, BN, WM, WN, MS>(a, smem, tile_i, sa, sb, dst);
+      if (sb > sa) conv_igemm_dispatch<T, BM, BN, WM, WN, MS, CUT>(a, smem, tile_i, sa, sb, dst);
     }
   }
 }
@@ -1153,7 +1159,8 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_fixup_kernel(const ConvArgs
   const int m0 = tile_m * BM, n0 = tile_n * BN;
   const size_t orow0 = (size_t)bat * (size_t)a.M;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wm = wave / WN, wn = wave % WN;
+  constexpr bool HALVES = IsFused<T>::value && WM * WN == 8;  // conv_x3_body: waves 0-3 own the first column half
+  const int wm = HALVES ? wave % WM : wave / WN, wn = HALVES ? wave / WM : wave % WN;
   const float* p0 = ws + ((size_t)xcd * g.per + rt * g.P) * (BM * BN);
   const size_t o = ((size_t)frag * (64 * NW) + tid) * NR;
   float x[NR];
@@ -1227,13 +1234,13 @@ TileCfg choose_tile(int cout) {
   return best;
 }
 
-template <typename T, int BM, int BN, int WM, int WN, int MS = 32>
+template <typename T, int BM, int BN, int WM, int WN, int MS = 32, int CUT = 0>
 static int launch_one(const ConvArgs& a, hipStream_t stream, float* sk_ws, int sk_grid) {
   constexpr int smem = 4 * (BM + BN) * kStepRowBytes;
   static DeviceOnce once;
   static bool sk_ok = true;
-  auto kern = conv_igemm_kernel<T, BM, BN, WM, WN, MS>;
-  auto kern_sk = conv_igemm_sk_kernel<T, BM, BN, WM, WN, MS>;
+  auto kern = conv_igemm_kernel<T, BM, BN, WM, WN, MS, CUT>;
+  auto kern_sk = conv_igemm_sk_kernel<T, BM, BN, WM, WN, MS, CUT>;
   const int rc_once = once.run([&]() -> int {
     BSMI_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
     BSMI_HIP(hipFuncSetAttribute((const void*)kern_sk, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
@@ -1305,7 +1312,12 @@ static int launch_cfg(const ConvArgs& a, TileCfg cfg, hipStream_t stream, float*
       case TILE_256x32: return launch_one<T, 256, 32, 4, 1, 16>(a, stream, sk_ws, sk_grid);
       case TILE_256x64: return launch_one<T, BSMI_X3_64_BM, 64, 4, 1, BSMI_X3_64_MS>(a, stream, sk_ws, sk_grid);  // 8 x 1 waves: measured no faster
       case TILE_256x160: return launch_one<T, 256, 160, 4, 1, BSMI_X3_64_MS>(a, stream, sk_ws, sk_grid);
-      case TILE_256x320: return launch_one<T, 256, 320, 4, 2, BSMI_X3_320_MS>(a, stream, sk_ws, sk_grid);
+      case TILE_256x320: {
+        // one tile column whose last 16 columns are padding (N = 300): the second column half runs 9 blocks of 16 instead of 10
+        static const bool cut_on = [] { const char* e = getenv("BSMI_X3_CUT"); return !(e && e[0] == '0'); }();
+        if (BSMI_X3_320_MS == 16 && cut_on && a.Npad == 320 && a.Co <= 304) return launch_one<T, 256, 320, 4, 2, 16, 1>(a, stream, sk_ws, sk_grid);
+        return launch_one<T, 256, 320, 4, 2, BSMI_X3_320_MS>(a, stream, sk_ws, sk_grid);
+      }
       case TILE_256x256: return launch_one<T, 256, 256, 4, 2, 16>(a, stream, sk_ws, sk_grid);
       default: BSMI_FAIL(BSMI_ERR_INVALID, "unknown tile config %d", (int)cfg);
     }
