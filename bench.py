@@ -383,6 +383,7 @@ def main():
                          "the barrier and the max-over-ranks reduction executed (a rehearsal of the distributed plumbing on a one-GPU box)")
     ap.add_argument("--overlap", action="store_true",
                     help="start a block's segmentation as soon as the blocks it reads are predicted (default: stage by stage; +3 %% end to end, conv launches 8 %% slower)")
+    ap.add_argument("--overlap-lanes", type=int, default=3, help="--overlap: lanes that take tasks while blocks are still being predicted")
     ap.add_argument("--no-segment", action="store_true", help="predict only (diagnostic; not the headline metric)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-modes", action="store_true", help="skip the per-precision predict lines (speed and error of f32 / bf16x3 / bf16)")
@@ -462,6 +463,8 @@ def main():
                           rank=rank, world=world, segment=not args.no_segment, overlap=args.overlap, obj_group=obj_group, **seg_kw)
     warm = VolumePipeline(model, OUT_BLOCK, CONTEXT, (max(1, args.warmup), 1, 1), SEG_CONTEXT, THRESHOLDS, n_lanes=args.seg_lanes,
                           device=local_rank, rank=rank, world=world, segment=not args.no_segment, obj_group=obj_group, **seg_kw)
+    if not args.no_segment:
+        pipe.seg.overlap_lanes = args.overlap_lanes
     warm.run(vol)
     del warm
     if not args.no_segment:

@@ -233,6 +233,8 @@ class SlabSegmenter:
         self.luts = None
         self._lane_load = [0] * len(self.lanes)   # tasks queued per lane by the run in progress (_take_lane)
         self._lane_of = {}
+        self._lane_limit = len(self.lanes)        # lanes _take_lane may use (overlap mode: few while the predict stream runs)
+        self.overlap_lanes = 3
 
     @staticmethod
     def hbm_bytes(shape, ctx, n_thresholds, n_blocks, label_cap=1 << 16, edge_cap=1 << 17):
@@ -326,7 +328,7 @@ class SlabSegmenter:
         stream).  A fixed block -> lane map (k mod lanes) put a block's fragments AND its edge scoring on one lane: with 20
         blocks on 16 lanes, four lanes got four tasks and twelve got two, and the stage took four task times instead of the
         three that 40 tasks on 16 lanes need (tools/probe_volume.py: tail of the driver's job 145 -> 105 ms under the probe)."""
-        i = min(range(len(self.lanes)), key=lambda j: (self._lane_load[j], j))
+        i = min(range(min(len(self.lanes), self._lane_limit)), key=lambda j: (self._lane_load[j], j))
         self._lane_load[i] += 1
         self._lane_of[(kind, k)] = i
         return self.lanes[i]
@@ -443,6 +445,7 @@ class SlabSegmenter:
         K = len(self.boxes)
         self._lane_load = [0] * len(self.lanes)
         self._lane_of = {}
+        self._lane_limit = len(self.lanes)
         last = [max(self._neighbours(k)) for k in range(K)]
         face = [k for k in range(K) if self._on_face(k)]
         inner = [k for k in range(K) if not self._on_face(k)]
@@ -491,6 +494,9 @@ class SlabSegmenter:
             todo_s = [j for j in inner if all(i in inner_set for i in nb[j])]   # the others follow the face blocks below
             while todo_f or todo_s:
                 moved = False
+                # while blocks are still being predicted only a few lanes take tasks: every flood / merge workgroup keeps a
+                # whole-CU conv workgroup off its CU, and a block per predict time is all the lanes need to keep up with
+                self._lane_limit = len(self.lanes) if ready[K - 1].query() else max(1, min(self.overlap_lanes, len(self.lanes)))
                 while todo_f and ready[last[todo_f[0]]].query():
                     k = todo_f.pop(0)
                     self._launch_fragments(k, ())
@@ -506,6 +512,7 @@ class SlabSegmenter:
                     time.sleep(0.0002)
         if overlap:
             guarded(launch_overlapped)
+            self._lane_limit = len(self.lanes)
         if not overlap:
             guarded(launch_inner)
         if face:
@@ -635,6 +642,18 @@ class SlabSegmenter:
         """Warm-up of the slab-sized paths behind the block stages (the torch reductions of `_collect`, the gather / LUT /
         relabel of `stitch`) on the still empty slab: their kernels are picked by tensor size, and the first use of one in a
         process loads it (on a fresh machine from disk) -- 0.1 s that would otherwise land in the first job."""
+        # ... and of every lane's workspace: a lane's hash tables, heaps and scratch volumes are fresh allocations whose
+        # first touch (page-table set-up) would otherwise fall into the first job -- 20-30 ms of the driver's 20-block job
+        # on some boxes.  One block's two tasks on the still empty slab per lane: trivial work, every buffer touched.
+        if len(self.boxes):
+            for i in range(len(self.lanes)):
+                self._lane_load = [1] * len(self.lanes)
+                self._lane_load[i] = 0
+                self._launch_fragments(0)
+                self._lane_load = [1] * len(self.lanes)
+                self._lane_load[i] = 0
+                self._launch_scores(0)
+            self._lane_load = [0] * len(self.lanes)
         self._collect()
         return self.stitch()
 
