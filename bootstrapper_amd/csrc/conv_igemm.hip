@@ -730,6 +730,12 @@ __device__ __forceinline__ void conv_x3_body(const ConvArgs& a, char* smem, int 
     const cint_ptr_t d = steps + (ha < nsteps ? ha : nsteps - 1) * 4;
     return Desc{d[0], d[1], d[2]};
   };
+#ifdef BSMI_DBG_SKIP_A  // dev build, WRONG RESULTS: the activation rows of 8 of 9 K-steps are not staged -- what the loop would cost if a
+  // halo form cut the LDS-DMA fill of the A operand ninefold (timing experiment for the narrow layers)
+#define X3_DBG_SKIP_A(h_) (BN <= 64 && (s0 + (h_)) % 9 != 0)
+#else
+#define X3_DBG_SKIP_A(h_) false
+#endif
   // Batch 1 of K-step h_, instructions [K0_, K1_): k < 2 A_INSTR: the A rows, else B hi.  The lo and the hi vectors of a
   // row share their 128-byte lines: the 4-wave kernels issue them back to back (PAIRED; in the other order the second
   // access finds the line evicted again: the 360 -> 60 channel layer 3.04 -> 2.48 ms), the 8-wave kernels all lo row blocks
@@ -744,6 +750,7 @@ __device__ __forceinline__ void conv_x3_body(const ConvArgs& a, char* smem, int 
     const size_t wi_ = (size_t)(s0 + (h_) < nsteps ? s0 + (h_) : nsteps - 1) * wstep;                                      \
     _Pragma("unroll") for (int k_ = (K0_); k_ < (K1_); ++k_) {                                                             \
       if (k_ < 2 * A_INSTR) {                                                                                              \
+        if (X3_DBG_SKIP_A(h_)) continue;                                                                                   \
         const int i_ = PAIRED ? k_ >> 1 : (k_ < A_INSTR ? k_ : k_ - A_INSTR);                                              \
         const bool lo_ = PAIRED ? (k_ & 1) == 0 : k_ < A_INSTR;                                                            \
         const uint32_t r0_ = ro0[i_], r1_ = ro1[i_], r2_ = ro2[i_];                                                        \
@@ -1107,7 +1114,9 @@ __device__ __forceinline__ SkGeom sk_geom(int ntiles, int xcd, int G) {
 template <typename T, int BM, int BN, int WM, int WN, int MS, int CUT = 0>
 __global__ __launch_bounds__(64 * WM * WN, 1) void conv_igemm_sk_kernel(const ConvArgs a, float* ws, int* counters) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  __shared__ int sh_item;
+  // the queue item travels through the first word of the staging area (free between two tiles): a static variable would push
+  // the 64-column tiles (80 KB of staging, two workgroups per CU) over half a CU's LDS
+  volatile int* sh_item = (volatile int*)smem;
   const int ntiles = ((a.M + BM - 1) / BM) * (a.Npad / BN) * (a.nbatch > 1 ? a.nbatch : 1);
   const int S = a.nsteps;
   // the XCD this workgroup really runs on (blockIdx % 8 is only the usual placement: a CU-masked queue deals differently)
@@ -1118,10 +1127,11 @@ __global__ __launch_bounds__(64 * WM * WN, 1) void conv_igemm_sk_kernel(const Co
     const SkGeom g = sk_geom(ntiles, xcd, gridDim.x);
     const int nfull = g.rounds * g.per, nitems = nfull + g.rem * g.P;
     for (;;) {
+      __syncthreads();  // the previous tile's epilogue strips are read
+      if (threadIdx.x == 0) *sh_item = atomicAdd(&counters[xcd], 1);
       __syncthreads();
-      if (threadIdx.x == 0) sh_item = atomicAdd(&counters[xcd], 1);
-      __syncthreads();
-      const int it = __builtin_amdgcn_readfirstlane(sh_item);
+      const int it = __builtin_amdgcn_readfirstlane(*sh_item);
+      __syncthreads();  // everybody has the item before the next prologue stages over it
       if (it >= nitems) break;
       // one call site for full tiles and tail parts (the body is large: two inlined copies cost the fused kernels their registers)
       int tile_i = g.base + it, sa = 0, sb = S;
@@ -1262,22 +1272,31 @@ static int launch_one(const ConvArgs& a, hipStream_t stream, float* sk_ws, int s
   const int ntiles = ceil_div(a.M, BM) * (a.Npad / BN) * nbatch;
   // persistent + split-K tail when whole rounds would leave a large share of the last one idle (a batched launch is long: any round count)
   const bool big_tile = BN >= 256;
-  const int rounds = ceil_div(ntiles, sk_grid > 0 ? sk_grid : 1);
-  if (sk_ws && sk_ok && sk_grid >= 8 && big_tile && ntiles % sk_grid != 0 && (rounds <= 16 || nbatch > 1) && (size_t)BM * BN <= kStreamKTileElems) {
+  // the fused 64-column tile: two workgroups per CU (80 KB of staging each).  The 2 565 tiles of the 360 -> 60 channel layer are
+  // 5.01 rounds of 512, and the five tiles of the sixth had a tenth of the launch to themselves: 2.62 -> 2.51 ms in the
+  // persistent form; with a last round that is more than half full the plain launch is as fast or faster (60 -> 60: 0.54 / 0.57)
+  static const bool sk64 = [] { const char* e = getenv("BSMI_X3_SK64"); return !(e && e[0] == '0'); }();
+  const bool two_per_cu = IsFused<T>::value && BN == 64 && 2 * smem <= 160 * 1024 && sk64;
+  const int grid_sk = two_per_cu ? 2 * sk_grid : sk_grid;
+  const int rounds = ceil_div(ntiles, grid_sk > 0 ? grid_sk : 1);
+  const bool thin_tail = grid_sk > 0 && 2 * (ntiles % grid_sk) < grid_sk;
+  if (sk_ws && sk_ok && sk_grid >= 8 && (big_tile || (two_per_cu && rounds >= 2 && rounds <= 8 && thin_tail)) && ntiles % grid_sk != 0 && (rounds <= 16 || nbatch > 1) &&
+      (size_t)BM * BN * (two_per_cu ? 2 : 1) <= kStreamKTileElems) {
     int* counters = (int*)(sk_ws + (size_t)sk_grid * kStreamKTileElems);
-    hipLaunchKernelGGL(kern_sk, dim3(sk_grid), dim3(64 * WM * WN), smem, stream, a, sk_ws, counters);
+    const int sk_grid_arg = grid_sk;
+    hipLaunchKernelGGL(kern_sk, dim3(sk_grid_arg), dim3(64 * WM * WN), smem, stream, a, sk_ws, counters);
     // fix-up grid: only as many tail tiles per XCD as the fullest XCD has (sk_geom's arithmetic); a (32, 8, fragments) grid
     // dispatched thousands of workgroups that left at once, 75-99 us per launch
     int max_rem = 0;
     {
-      const int q = ntiles >> 3, r = ntiles & 7, per = sk_grid >> 3;
+      const int q = ntiles >> 3, r = ntiles & 7, per = grid_sk >> 3;
       for (int x = 0; x < 8; ++x) {
         const int count = q + (x < r ? 1 : 0);
         max_rem = std::max(max_rem, count - count / per * per);
       }
     }
     hipLaunchKernelGGL((conv_fixup_kernel<T, BM, BN, WM, WN, MS>), dim3(std::max(max_rem, 1), 8, (BM / WM / MS) * (BN / WN / MS)),
-                       dim3(64 * WM * WN), 0, stream, a, (const float*)sk_ws, sk_grid, counters);
+                       dim3(64 * WM * WN), 0, stream, a, (const float*)sk_ws, grid_sk, counters);
   } else {
     hipLaunchKernelGGL(kern, dim3(ntiles), dim3(64 * WM * WN), smem, stream, a);
   }

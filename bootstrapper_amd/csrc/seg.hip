@@ -362,6 +362,9 @@ __global__ __launch_bounds__(64 * FLOOD_WAVES) void ws_flood_kernel(int D, int H
     int items = 0;
     // the heap is written by lane 0 alone; its HBM spill is also read by lane 0 alone (and broadcast), so that those loads
     // follow that lane's stores in its own program order; LDS operations of a wave execute in order anyway
+    // (Tried: the first 64 entries -- the six top levels every sift-down walks -- in registers, entry i in lane i, read with
+    // v_readlane: fragments of a 128^3 block 12.7 -> 12.6 ms.  The chain of a pop is the global round trip for the
+    // neighbours' state, not the sift.)
     auto hget = [&](int i) -> uint64_t {
       if (i < FLOOD_LDS_HEAP) return hl[i];
       uint64_t v = 0;
@@ -2542,7 +2545,7 @@ int bsmi_connected_components_multi(const uint64_t* nodes, uint64_t n, const uin
   std::vector<uint32_t> iu(m), iv(m);
   {
     const unsigned hw = std::max(1u, std::min(8u, std::thread::hardware_concurrency()));
-    const unsigned T = m < 200000 ? 1u : hw;
+    const unsigned T = m < 20000 ? 1u : hw;  // 143 000 edges on one thread: 5 ms of the job's last 9
     // two-level search: every 64th id in a table that stays in cache, then the 64 ids of one run (8 cache lines)
     constexpr uint64_t kRun = 64;
     std::vector<uint64_t> coarse((n + kRun - 1) / kRun);
