@@ -102,6 +102,65 @@ __global__ void pack_weights_x3_kernel(const float* __restrict__ params, const P
   }
 }
 
+// The same through LDS, for windows of a 3 x 3 x 3 layer (ugw = 2 x 27 units of one 32-channel chunk, ordered [tap][half]): a
+// workgroup takes PK_NB output channels of one window, reads their 32 x 27 weights in the order they lie in the parameter
+// buffer (one run of 3 456 bytes per output channel; the kernel above has every lane walk its own 16 channels, 108 bytes
+// apart) and writes the K-steps' rows PK_NB at a time (512 contiguous bytes per image and K-step instead of 32).  The unit
+// fields are used as they are: a window that is not of that form (a residual's, padding) is packed correctly, only slower.
+constexpr int PK_NB = 8;
+template <int NT>  // taps per window (27: constant divisors); 0: ugw / 2 at run time
+__global__ __launch_bounds__(256) void pack_weights_x3_t_kernel(const float* __restrict__ params, const PackUnit* __restrict__ units, int nunits,
+                                                                int Npad, int nreal, int ugw, uint32_t* __restrict__ hi_img,
+                                                                uint32_t* __restrict__ lo_img) {
+  extern __shared__ __attribute__((aligned(16))) float pk_sv[];  // [PK_NB][32 channels][taps] values (the order of an OIDHW weight), then the window's units
+  PackUnit* su = (PackUnit*)(pk_sv + (size_t)PK_NB * ugw * 16);
+  const int tid = threadIdx.x;
+  const int nt = NT ? NT : ugw / 2;
+  const int u0 = blockIdx.x * ugw, n0 = blockIdx.y * PK_NB;
+  for (int i = tid; i < ugw; i += 256) {
+    PackUnit pu{};
+    pu.wbase = -1;
+    if (u0 + i < nunits) pu = units[u0 + i];
+    su[i] = pu;
+  }
+  __syncthreads();
+  const int per_n = 32 * nt;
+  // forward image: n is the weight's output channel (the outermost index of OIDHW): tap fastest, then the chunk's 32 channels;
+  // input-gradient image: n is the weight's INPUT channel (make_dgrad: sn = taps): tap fastest, then the PK_NB values of n
+  const bool n_inner = su[0].wbase >= 0 && su[0].sn < su[0].sc;
+  for (int e = tid; e < PK_NB * per_n; e += 256) {
+    int nl, c, tap;
+    if (n_inner) {
+      c = e / (PK_NB * nt);
+      const int r = e - c * (PK_NB * nt);
+      nl = r / nt;
+      tap = r - nl * nt;
+    } else {
+      nl = e / per_n;
+      const int r = e - nl * per_n;
+      c = r / nt;
+      tap = r - c * nt;
+    }
+    const PackUnit& pu = su[tap * 2 + (c >> 4)];
+    const int n = n0 + nl, kk = c & 15;
+    float v = 0.f;
+    if (pu.wbase >= 0 && n < nreal && pu.c0 + kk < pu.creal) v = params[pu.wbase + (long long)n * pu.sn + (long long)(pu.c0 + kk) * pu.sc + pu.tap];
+    pk_sv[nl * per_n + c * nt + tap] = v;  // consecutive lanes, consecutive words (a [unit][16] layout: one bank for the whole wave)
+  }
+  __syncthreads();
+  for (int e = tid; e < ugw * PK_NB * 8; e += 256) {
+    const int pr = e & 7, half = (e >> 3) & 1, nl = (e >> 4) % PK_NB, ksl = e / (16 * PK_NB);
+    const int ul = ksl * 2 + half, u = u0 + ul, n = n0 + nl;
+    if (u >= nunits || n >= Npad) continue;
+    const float* v = pk_sv + nl * per_n + (half * 16 + 2 * pr) * nt + ksl;
+    uint32_t h, l;
+    split_pair(v[0], v[nt], h, l);
+    const size_t d = (((size_t)(u >> 1) * Npad + n) * 32 + (u & 1) * 16) / 2 + pr;
+    hi_img[d] = h;
+    lo_img[d] = l;
+  }
+}
+
 // bias image of a forward launch: b[n] = params[b0 + n] (+ params[b1 + n])
 __global__ void pack_bias_kernel(const float* __restrict__ params, long long b0, long long b1, int nreal, int Npad, float* __restrict__ dst) {
   const int n = blockIdx.x * blockDim.x + threadIdx.x;
@@ -207,10 +266,21 @@ __global__ void head_bwd_kernel(const float* __restrict__ z, int zc, const float
 // g = dY * [Y > 0], written into the interior of a zero-bordered tensor [D + 2pz][H + 2py][W + 2px][C]
 // `outs` (optional): the same tensor once more in the split-bf16 activation layout (conv_dev.h act_index: per 8 channels 16
 // bytes of hi = bf16(v) then 16 bytes of lo = bf16(v - hi)), the A operand of the split-bf16 input-gradient launch
+// `cs0` (optional): the column sums of g -- the bias gradient -- are added to cs0[c] (and cs1[c]) for c < nreal: per workgroup
+// in LDS (dynamic, C floats), one global atomic per channel and workgroup at the end (colsum_kernel read the tensor again).
 __global__ void relu_bwd_pad_kernel(const float* __restrict__ dy, const float* __restrict__ y, int D, int H, int W, int C, int pz, int py,
-                                    int px, float* __restrict__ out, uint16_t* __restrict__ outs) {
+                                    int px, float* __restrict__ out, uint16_t* __restrict__ outs, int nreal, float* __restrict__ cs0,
+                                    float* __restrict__ cs1) {
+  extern __shared__ float rb_sum[];  // [C] when cs0
+  if (cs0) {
+    for (int c = threadIdx.x; c < C; c += blockDim.x) rb_sum[c] = 0.f;
+    __syncthreads();
+  }
   const size_t total = (size_t)D * H * W * (C / 4);
   const int Hp = H + 2 * py, Wp = W + 2 * px;
+  // the channel group of a thread is fixed when the grid's stride is a multiple of C / 4 (the launcher sees to it): sums in registers
+  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+  const bool fixed_c = ((size_t)gridDim.x * blockDim.x) % (size_t)(C / 4) == 0;
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
     const int c4 = (int)(i % (C / 4));
     size_t v = i / (C / 4);
@@ -223,6 +293,14 @@ __global__ void relu_bwd_pad_kernel(const float* __restrict__ dy, const float* _
     r.x = a.x > 0.f ? g.x : 0.f; r.y = a.y > 0.f ? g.y : 0.f; r.z = a.z > 0.f ? g.z : 0.f; r.w = a.w > 0.f ? g.w : 0.f;
     const size_t row = (((size_t)(zz + pz) * Hp + (yy + py)) * Wp + (x + px)) * C;
     *(float4*)(out + row + c4 * 4) = r;
+    if (cs0) {
+      if (fixed_c) {
+        acc.x += r.x; acc.y += r.y; acc.z += r.z; acc.w += r.w;
+      } else {
+        atomicAdd(&rb_sum[c4 * 4 + 0], r.x); atomicAdd(&rb_sum[c4 * 4 + 1], r.y);
+        atomicAdd(&rb_sum[c4 * 4 + 2], r.z); atomicAdd(&rb_sum[c4 * 4 + 3], r.w);
+      }
+    }
     if (outs) {
       const int n = c4 * 4;
       uint32_t h0, l0, h1, l1;
@@ -231,6 +309,24 @@ __global__ void relu_bwd_pad_kernel(const float* __restrict__ dy, const float* _
       uint16_t* d = outs + 2 * row + ((n >> 3) << 4) + (n & 7);
       *(uint2*)d = make_uint2(h0, h1);
       *(uint2*)(d + 8) = make_uint2(l0, l1);
+    }
+  }
+  if (cs0) {
+    if (fixed_c) {
+      const size_t i0 = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+      if (i0 < total) {
+        const int c4 = (int)(i0 % (C / 4));
+        atomicAdd(&rb_sum[c4 * 4 + 0], acc.x); atomicAdd(&rb_sum[c4 * 4 + 1], acc.y);
+        atomicAdd(&rb_sum[c4 * 4 + 2], acc.z); atomicAdd(&rb_sum[c4 * 4 + 3], acc.w);
+      }
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < C && c < nreal; c += blockDim.x) {
+      const float v = rb_sum[c];
+      if (v != 0.f) {
+        atomicAdd(&cs0[c], v);
+        if (cs1) atomicAdd(&cs1[c], v);
+      }
     }
   }
 }
@@ -935,7 +1031,8 @@ struct ConvBwd {  // backward data of one CONV plan step
   int P[3] = {0, 0, 0};  // border of the padded gradient
   TDesc gp;              // padded gradient [D + 2P][H + 2P][W + 2P][Cpad]
   void* gps = nullptr;   // the same in the split-bf16 activation layout (input gradients as split-bf16 launches), or null
-  void* dsplit = nullptr;  // result of the split-bf16 input-gradient launch before split_to_f32_kernel
+  void* dsplit = nullptr;  // result of the split-bf16 input-gradient launch before split_to_f32_kernel (null: the launch writes f32 sums itself)
+  bool dx3 = false;        // the input gradient is a split-bf16 launch
   bool need_dgrad = false;
   ConvArgs dgrad{};      // implicit-GEMM launch of the input gradient
   TileCfg dtile = TILE_256x32;
@@ -1091,9 +1188,21 @@ static int run_pack_jobs(TrainState* ts, hipStream_t s, bool lazy_f32 = false, b
     const size_t total = (size_t)j.nunits * j.Npad;
     if (j.dst_hi) {
       const int ugw = std::max(2, j.window);
-      const size_t padded = (size_t)((j.nunits + ugw - 1) / ugw) * ugw * j.Npad;
-      hipLaunchKernelGGL(pack_weights_x3_kernel, dim3((unsigned)((padded + 255) / 256)), dim3(256), 0, s, (const float*)ts->w,
-                         (const PackUnit*)j.units, j.nunits, j.Npad, j.nreal, ugw, j.dst_hi, j.dst_lo);
+      static const bool pack_t = env_on("BSMI_PACK_T");
+      if (ugw >= 16 && ugw % 2 == 0 && j.Npad % PK_NB == 0 && pack_t) {
+        const size_t lds = (size_t)PK_NB * ugw * 16 * sizeof(float) + (size_t)ugw * sizeof(PackUnit);
+        const dim3 grid((unsigned)((j.nunits + ugw - 1) / ugw), (unsigned)(j.Npad / PK_NB));
+        if (ugw == 54)
+          hipLaunchKernelGGL(pack_weights_x3_t_kernel<27>, grid, dim3(256), lds, s, (const float*)ts->w, (const PackUnit*)j.units, j.nunits, j.Npad,
+                             j.nreal, ugw, j.dst_hi, j.dst_lo);
+        else
+          hipLaunchKernelGGL(pack_weights_x3_t_kernel<0>, grid, dim3(256), lds, s, (const float*)ts->w, (const PackUnit*)j.units, j.nunits, j.Npad,
+                             j.nreal, ugw, j.dst_hi, j.dst_lo);
+      } else {
+        const size_t padded = (size_t)((j.nunits + ugw - 1) / ugw) * ugw * j.Npad;
+        hipLaunchKernelGGL(pack_weights_x3_kernel, dim3((unsigned)((padded + 255) / 256)), dim3(256), 0, s, (const float*)ts->w,
+                           (const PackUnit*)j.units, j.nunits, j.Npad, j.nreal, ugw, j.dst_hi, j.dst_lo);
+      }
     } else if (!(lazy_f32 && j.shadowed)) {
       hipLaunchKernelGGL(pack_weights_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, (const float*)ts->w, (const PackUnit*)j.units,
                          j.nunits, j.Npad, j.nreal, j.dst);
@@ -1393,10 +1502,18 @@ static int make_dgrad(bsmi_unet* h, TrainState* ts, ConvBwd& cb, const ConvBwd* 
   a.out = out.ptr;
   if (x3) {
     a.w_lo = (const char*)wdev + wimg;
-    const size_t obytes = (size_t)out.D * out.H * out.W * out.Cpad * sizeof(float);
-    rc = talloc(ts, &cb.dsplit, obytes, true);
-    if (rc) return rc;
-    a.out = cb.dsplit;
+    cb.dx3 = true;
+    // no bias, no ReLU, and the reader wants f32: the launch stores its raw sums (ConvArgs::raw, the epilogue of the
+    // Winograd GEMMs) straight into the gradient tensor instead of (hi, lo) pairs that split_to_f32_kernel took apart again
+    static const bool raw_out = env_on("BSMI_DGRAD_RAW");
+    if (raw_out && out.Cpad % 4 == 0) {
+      a.raw = 1;
+    } else {
+      const size_t obytes = (size_t)out.D * out.H * out.W * out.Cpad * sizeof(float);
+      rc = talloc(ts, &cb.dsplit, obytes, true);
+      if (rc) return rc;
+      a.out = cb.dsplit;
+    }
   }
   a.Do = out.D; a.Ho = out.H; a.Wo = out.W; a.Co = out.Cpad;
   a.M = out.D * out.H * out.W;
@@ -1738,17 +1855,34 @@ int bsmi_unet_train_forward_backward(bsmi_unet* h, const float* raw_dev, const f
         const int* k = p.k[ci];
         TDesc gy = ts->grad_of[st.out.ptr];
         const size_t total4 = (size_t)st.out.D * st.out.H * st.out.W * (st.out.Cpad / 4);
-        hipLaunchKernelGGL(relu_bwd_pad_kernel, dim3((unsigned)std::min<size_t>((total4 + 255) / 256, 16384)), dim3(256), 0, s, (const float*)gy.ptr,
-                           (const float*)st.out.ptr, st.out.D, st.out.H, st.out.W, st.out.Cpad, cb.P[0], cb.P[1], cb.P[2], (float*)cb.gp.ptr,
-                           (uint16_t*)cb.gps);
         const std::string base = p.prefix + ".conv_pass." + std::to_string(2 * ci);
         float* gb = ts->g + param_off(ts, base + ".bias");
         float* gbr = last ? ts->g + param_off(ts, p.prefix + ".residual.0.bias") : nullptr;
-        for (int c0 = 0; c0 < st.out.Cpad; c0 += 512) {
-          const int Cc = std::min(512, st.out.Cpad - c0);
-          const int threads = std::max(Cc, 256 / Cc * Cc);
-          hipLaunchKernelGGL(colsum_kernel, dim3(256), dim3(threads), 0, s, (const float*)cb.gp.ptr, st.out.D, st.out.H, st.out.W, st.out.Cpad, c0, Cc,
-                             cb.P[0], cb.P[1], cb.P[2], p.cout, gb, gbr);
+        static const bool fuse_colsum = env_on("BSMI_TRAIN_FUSE_COLSUM");
+        if (fuse_colsum) {
+          // the bias gradient (column sums of g) in the same pass: a grid whose stride is a multiple of the channel groups keeps a
+          // thread on its four channels; few workgroups, each ends with one atomic per channel
+          const int c4n = st.out.Cpad / 4;
+          size_t blocks = std::min<size_t>((total4 + 255) / 256, 1024);
+          if (c4n % 256 != 0) {  // stride = blocks * 256 = 0 mod c4n  <=  blocks = 0 mod (c4n / gcd(c4n, 256))
+            int a = c4n, b = 256;
+            while (b) { const int t = a % b; a = b; b = t; }
+            const size_t q = (size_t)c4n / a;
+            if (blocks >= q) blocks = blocks / q * q;
+          }
+          hipLaunchKernelGGL(relu_bwd_pad_kernel, dim3((unsigned)blocks), dim3(256), (size_t)st.out.Cpad * sizeof(float), s, (const float*)gy.ptr,
+                             (const float*)st.out.ptr, st.out.D, st.out.H, st.out.W, st.out.Cpad, cb.P[0], cb.P[1], cb.P[2], (float*)cb.gp.ptr,
+                             (uint16_t*)cb.gps, p.cout, gb, gbr);
+        } else {
+          hipLaunchKernelGGL(relu_bwd_pad_kernel, dim3((unsigned)std::min<size_t>((total4 + 255) / 256, 16384)), dim3(256), 0, s, (const float*)gy.ptr,
+                             (const float*)st.out.ptr, st.out.D, st.out.H, st.out.W, st.out.Cpad, cb.P[0], cb.P[1], cb.P[2], (float*)cb.gp.ptr,
+                             (uint16_t*)cb.gps, 0, (float*)nullptr, (float*)nullptr);
+          for (int c0 = 0; c0 < st.out.Cpad; c0 += 512) {
+            const int Cc = std::min(512, st.out.Cpad - c0);
+            const int threads = std::max(Cc, 256 / Cc * Cc);
+            hipLaunchKernelGGL(colsum_kernel, dim3(256), dim3(threads), 0, s, (const float*)cb.gp.ptr, st.out.D, st.out.H, st.out.W, st.out.Cpad, c0, Cc,
+                               cb.P[0], cb.P[1], cb.P[2], p.cout, gb, gbr);
+          }
         }
         // weight gradients
         const int64_t gsx = cb.gp.Cpad, gsy = (int64_t)cb.gp.W * gsx, gsz = (int64_t)cb.gp.H * gsy;
@@ -1872,7 +2006,7 @@ int bsmi_unet_train_forward_backward(bsmi_unet* h, const float* raw_dev, const f
         }
         // input gradient
         if (cb.need_dgrad) {
-          rc = launch_conv_igemm(cb.dgrad, cb.dsplit ? BSMI_PREC_BF16X3 : BSMI_PREC_F32, cb.dtile, s, h->sk_ws, h->sk_grid);
+          rc = launch_conv_igemm(cb.dgrad, cb.dx3 ? BSMI_PREC_BF16X3 : BSMI_PREC_F32, cb.dtile, s, h->sk_ws, h->sk_grid);
           if (rc) return rc;
           if (cb.dsplit) {
             const size_t g8 = (size_t)cb.dcat.D * cb.dcat.H * cb.dcat.W * cb.dcat.Cpad / 8;
