@@ -354,6 +354,104 @@ static int pack_wino(bsmi_unet* h, PassSite& p, int ci) {
   return BSMI_OK;
 }
 
+// Which stages run in the halo-resident form (conv_h16.hip).  BSMI_H16: 0 = none, unset / 1 = the stages with at most 64 output
+// channels whose launch is large enough to fill the chip, 2 = every stage the kernel can take (tests: small nets).
+static int h16_mode() {
+  static const int m = [] { const char* e = getenv("BSMI_H16"); return e ? atoi(e) : 1; }();
+  return m;
+}
+
+// unit list of the halo-resident form: per source slot, 16-channel chunk and z tap a phase; its in-plane taps two per K-step
+static void build_entries_h16(const PassSite& p, int ci, std::vector<PackEntry>& out, std::vector<H16PhaseHost>& phases) {
+  const bool last = ci == p.nconv - 1;
+  const int* k = p.k[ci];
+  const PackEntry dummy{0, 0, 0, 0, 0, 0, 0, 0, 0, true, 0};
+  auto add_taps = [&](int slot, int cin_base, int creal) {
+    const int cpad = round_up(creal, kChanPad);
+    // z tap outermost: two consecutive 16-channel chunks of a voxel share a 128-byte line, so every other phase finds its
+    // rows in L2
+    for (int z = 0; z < k[0]; ++z)
+      for (int c0 = 0; c0 < cpad; c0 += 16) {
+        H16PhaseHost ph{slot, c0, z, 0, (int)(out.size() / kUnitsPerStep), 0};
+        const int ntap = k[1] * k[2];
+        for (int i = 0; i < ntap; i += 2) {
+          for (int j = 0; j < 2; ++j) {
+            if (i + j < ntap) {
+              const int y = (i + j) / k[2], x = (i + j) % k[2];
+              out.push_back(PackEntry{slot, z, y, x, c0, 0, (z * k[1] + y) * k[2] + x, cin_base, creal, false, (int)phases.size()});
+            } else {
+              out.push_back(dummy);
+            }
+          }
+          ++ph.nsteps;
+        }
+        phases.push_back(ph);
+      }
+  };
+  if (ci == 0) {
+    int base = 0;
+    for (int s = 0; s < p.nslots; ++s) {
+      add_taps(s, base, p.cin[s]);
+      base += p.cin[s];
+    }
+  } else {
+    add_taps(0, 0, p.cout);
+  }
+  if (last) {
+    int crop[3] = {0, 0, 0};
+    for (int i = 0; i < p.nconv; ++i)
+      for (int d = 0; d < 3; ++d) crop[d] += p.k[i][d] - 1;
+    const int first_slot = ci == 0 ? 0 : 1;
+    int base = 0;
+    for (int s = 0; s < p.nslots; ++s) {
+      const int cpad = round_up(p.cin[s], kChanPad);
+      for (int c0 = 0; c0 < cpad; c0 += 16) {
+        phases.push_back(H16PhaseHost{first_slot + s, c0, crop[0] / 2, 1, (int)(out.size() / kUnitsPerStep), 1});
+        out.push_back(PackEntry{first_slot + s, crop[0] / 2, crop[1] / 2, crop[2] / 2, c0, 1, 0, base, p.cin[s], false, (int)phases.size() - 1});
+        out.push_back(dummy);
+      }
+      base += p.cin[s];
+    }
+  }
+}
+
+static int pack_h16(bsmi_unet* h, PassSite& p, int ci) {
+  PackedH16& ph = p.h16[ci];
+  if (ph.w) { (void)hipFree(ph.w); ph.w = nullptr; }
+  ph.ready = false;
+  if (h16_mode() == 0 || p.cout > 64) return BSMI_OK;
+  ph.entries.clear();
+  ph.phases.clear();
+  build_entries_h16(p, ci, ph.entries, ph.phases);
+  ph.Npad = p.cout <= 16 ? 16 : 64;
+  const HostWeight& wm = h->weights[p.prefix + ".conv_pass." + std::to_string(2 * ci) + ".weight"];
+  const HostWeight& wr = h->weights[p.prefix + ".residual.0.weight"];
+  const int64_t cin_m = wm.shape[1], ntap_m = wm.shape[2] * wm.shape[3] * wm.shape[4], cin_r = wr.shape[1];
+  const size_t nsteps = ph.entries.size() / kUnitsPerStep;
+  const size_t nelem = (nsteps * (size_t)ph.Npad + kWeightRowSlack) * 32;
+  std::vector<uint16_t> packed(2 * nelem, 0);
+  host_parallel_for(ph.entries.size(), [&](size_t u) {
+    const PackEntry& e = ph.entries[u];
+    if (e.dummy) return;
+    const size_t s = u / kUnitsPerStep, j = u % kUnitsPerStep;
+    for (int n = 0; n < p.cout; ++n)
+      for (int kk = 0; kk < 16; ++kk) {
+        const int c = e.c0 + kk;
+        if (c >= e.creal) break;
+        const float v = e.wsrc == 0 ? wm.data[((size_t)n * cin_m + (e.cin_base + c)) * ntap_m + e.tap] : wr.data[(size_t)n * cin_r + (e.cin_base + c)];
+        const size_t idx = (s * ph.Npad + n) * 32 + j * 16 + kk;
+        const uint16_t hi = host_f32_to_bf16(v);
+        packed[idx] = hi;
+        packed[nelem + idx] = host_f32_to_bf16(v - host_bf16_to_f32(hi));
+      }
+  });
+  ph.lo_image_bytes = nelem * 2;
+  BSMI_HIP(hipMalloc(&ph.w, packed.size() * 2));
+  BSMI_HIP(hipMemcpy(ph.w, packed.data(), packed.size() * 2, hipMemcpyHostToDevice));
+  ph.ready = true;
+  return BSMI_OK;
+}
+
 // An upsampled map whose only readers are Winograd stages of the ConvPass that follows it (its first stage's taps, its
 // last stage's residual branch): the stages read the LOW-resolution tensor and interpolate on the fly, the UP step is skipped.
 struct UpFuse {
@@ -598,6 +696,88 @@ struct Planner {
     a.Npad = pc.Npad;
     a.relu = 1;
     st.use_rhx = true;
+    return BSMI_OK;
+  }
+
+  // Halo-resident launch of a stage with at most 64 output channels (conv_h16.hip), split-bf16 mode.
+  int plan_h16(PassSite& p, int ci, const PackedConv& pc, const TDesc* slots, const int (*so)[3], const TDesc& o, PlanStep& st) {
+    st.use_h16 = false;
+    const PackedH16& ph = p.h16[ci];
+    const int* k = p.k[ci];
+    const int Hin = o.H + k[1] - 1, Win = o.W + k[2] - 1;
+    if (prec != BSMI_PREC_BF16X3 || !ph.ready || h16_mode() == 0 || pc.bias == nullptr) return BSMI_OK;
+    static const int only_npad = [] { const char* e = getenv("BSMI_H16_NPAD"); return e ? atoi(e) : 0; }();  // dev: one column count only
+    if (only_npad && only_npad != ph.Npad) return BSMI_OK;
+    int max_r = 0;
+    const int rows = h16_halo_rows(Win, k[1], k[2], ph.Npad, &max_r);
+    if (!rows || Hin > 2047 || Win > 2047 || o.D > 1023) return BSMI_OK;
+    const int64_t Q = (int64_t)o.D * Hin * Win;
+    if (Q >= ((int64_t)1 << 31)) return BSMI_OK;
+    // a launch that cannot fill the chip (two workgroups of 512 rows per CU) stays with the gather kernel's 256-row tiles
+    if (h16_mode() == 1 && Q < (int64_t)2 * 256 * kH16TileRows) return BSMI_OK;
+    // A residual branch costs this form one phase -- a halo load -- per 16 channels for half a K-step's worth of multiplies.
+    // The second stage of unet.r_conv.0.1 (60 -> 60 channels, residual from 360): 23 such phases beside 12 of nine taps,
+    // 0.60 ms against 0.56 for the gather kernel.
+    if (h16_mode() == 1 && ph.Npad == 64) {
+      int main_steps = 0, res_steps = 0;
+      for (const H16PhaseHost& hp : ph.phases) (hp.kind ? res_steps : main_steps) += hp.nsteps;
+      if (3 * res_steps > main_steps) return BSMI_OK;
+    }
+    const int64_t es = 4;  // bytes per channel of a row: (hi, lo) interleaved
+    std::vector<H16Phase> phases(ph.phases.size());
+    std::vector<H16Step> steps(ph.entries.size() / kUnitsPerStep);
+    for (size_t q = 0; q < ph.phases.size(); ++q) {
+      const H16PhaseHost& hp = ph.phases[q];
+      const TDesc& t = slots[hp.slot];
+      const PackEntry& e0 = ph.entries[(size_t)kUnitsPerStep * hp.first_step];
+      // kind 0: the taps' (dy, dx) are row offsets into the halo; kind 1 (the residual's crop centre): folded into the origin
+      const int oz = so[hp.slot][0] + hp.dz;
+      const int oy = so[hp.slot][1] + (hp.kind ? e0.dy : 0);
+      const int ox = so[hp.slot][2] + (hp.kind ? e0.dx : 0);
+      const int64_t delta = ((((int64_t)oz * t.H + oy) * t.W + ox) * t.Cpad + hp.c0) * es;
+      if (delta >= ((int64_t)1 << 31)) return BSMI_OK;
+      phases[q] = H16Phase{hp.slot, (int32_t)delta, hp.kind ? kH16TileRows : kH16TileRows + (k[1] - 1) * Win + (k[2] - 1), hp.nsteps};
+      for (int s = hp.first_step; s < hp.first_step + hp.nsteps; ++s) {
+        const PackEntry& ea = ph.entries[(size_t)kUnitsPerStep * s];
+        const PackEntry& eb = ph.entries[(size_t)kUnitsPerStep * s + 1];
+        const int offa = hp.kind ? 0 : ea.dy * Win + ea.dx;
+        const int offb = (hp.kind || eb.dummy) ? offa : eb.dy * Win + eb.dx;
+        steps[s] = H16Step{offa, offb, 0, 0};
+      }
+    }
+    H16Args& a = st.h16;
+    memset(&a, 0, sizeof a);
+    for (int sl = 0; sl < kMaxConvTensors; ++sl) a.t[sl] = st.conv.t[sl];
+    H16Phase* dphases = nullptr;
+    H16Step* dsteps = nullptr;
+    BSMI_HIP(hipMalloc((void**)&dphases, phases.size() * sizeof(H16Phase)));
+    plan->allocs.push_back(dphases);
+    BSMI_HIP(hipMalloc((void**)&dsteps, steps.size() * sizeof(H16Step)));
+    plan->allocs.push_back(dsteps);
+    BSMI_HIP(hipMemcpy(dphases, phases.data(), phases.size() * sizeof(H16Phase), hipMemcpyHostToDevice));
+    BSMI_HIP(hipMemcpy(dsteps, steps.data(), steps.size() * sizeof(H16Step), hipMemcpyHostToDevice));
+    a.phases = dphases;
+    a.steps = dsteps;
+    a.nphases = (int)phases.size();
+    a.nsteps = (int)steps.size();
+    a.w = ph.w;
+    a.w_lo = (const char*)ph.w + ph.lo_image_bytes;
+    a.bias = pc.bias;  // (pc.Npad >= ph.Npad rows)
+    a.out = o.ptr;
+    a.Do = o.D; a.Ho = o.H; a.Wo = o.W; a.Co = o.Cpad;
+    a.Hin = Hin; a.Win = Win;
+    a.Q = (int)Q;
+    a.Npad = ph.Npad;
+    a.relu = 1;
+    {
+      static const bool balanced = [] { const char* e = getenv("BSMI_H16_BALANCE"); return !(e && e[0] == '0'); }();
+      int n_cus = 256;
+      hipDeviceProp_t prop;
+      if (hipGetDeviceProperties(&prop, h->device) == hipSuccess && prop.multiProcessorCount > 0) n_cus = prop.multiProcessorCount;
+      h16_tiling(Q, ph.Npad, rows, max_r, balanced ? n_cus : 0, &a.ntiles, &a.n_big, &a.r_small);
+    }
+    st.h16_rows = rows;
+    st.use_h16 = true;
     return BSMI_OK;
   }
 
@@ -1029,10 +1209,14 @@ struct Planner {
         if (rc) return rc;
         rc = plan_wino(p, ci, pc, slots, so, nsl, o, st);
         if (rc) return rc;
+        if (!st.use_wino && !st.use_box && !st.use_rhx) {
+          rc = plan_h16(p, ci, pc, slots, so, o, st);
+          if (rc) return rc;
+        }
         if (getenv("BSMI_PLAN_DEBUG"))
           fprintf(stderr, "[bsmi plan] %s conv %d: out (%d,%d,%d)x%d tile BN=%d K-steps %d %s\n", p.prefix.c_str(), ci, o.D, o.H, o.W,
                   p.cout, tile_bn(st.tile), st.use_wino ? st.wino_gemm.nsteps : a.nsteps,
-                  st.use_wino ? "winograd F(2x2,3x3)" : st.use_box ? "box-halo" : st.use_rhx ? "fused raster-halo" : st.use_rh ? "raster-halo" : "gather");
+                  st.use_wino ? "winograd F(2x2,3x3)" : st.use_h16 ? "halo-resident" : st.use_box ? "box-halo" : st.use_rhx ? "fused raster-halo" : st.use_rh ? "raster-halo" : "gather");
         plan->steps.push_back(st);
       }
       cur = o;
@@ -1376,6 +1560,7 @@ int bsmi_unet_destroy(bsmi_unet* h) {
         if (p.packed[pr][c].bias) (void)hipFree(p.packed[pr][c].bias);
       }
     for (int c = 0; c < BSMI_MAX_CONVS; ++c) {
+      if (p.h16[c].w) (void)hipFree(p.h16[c].w);
       if (p.wino[c].w) (void)hipFree(p.wino[c].w);
       if (p.wino[c].res_w) (void)hipFree(p.wino[c].res_w);
       for (int part = 0; part < 2; ++part)
@@ -1436,6 +1621,7 @@ int bsmi_unet_finalize(bsmi_unet* h, int precision) {
       int rc = pack_conv(h, p, c, precision);
       if (rc) return rc;
       if (precision == BSMI_PREC_BF16X3 && (rc = pack_wino(h, p, c))) return rc;
+      if (precision == BSMI_PREC_BF16X3 && (rc = pack_h16(h, p, c))) return rc;
     }
     return BSMI_OK;
   };
@@ -1591,6 +1777,7 @@ int bsmi_unet_forward(bsmi_unet* h, int precision, const void* raw_dev, int raw_
           break;
         }
         rc = (st.tx3 && h->train_forward) ? train_forward_conv_x3(h, st, s)
+             : st.use_h16 ? launch_conv_h16(st.h16, st.h16_rows, s)
              : st.use_box ? launch_conv_box(st.box, s)
              : st.use_rhx ? launch_conv_rh_x3(st.rhx, s)
              : st.use_rh ? launch_conv_rh(st.rh, precision, st.tile, s, h->sk_ws, h->sk_grid)

@@ -8,6 +8,7 @@
 
 #include "conv_igemm.h"
 #include "conv_rh.h"
+#include "conv_h16.h"
 #include "conv_box.h"
 #include "first_pass.h"
 #include "wino.h"
@@ -75,6 +76,21 @@ struct PackedWino {
   size_t res_part_lo[2] = {0, 0};
 };
 
+// Halo-resident form of a stage with at most 64 output channels in the split-bf16 mode (conv_h16.hip): its own K-step list --
+// per (source, 16-channel chunk, z tap) a phase whose K-steps pair two in-plane taps -- and weight images.
+struct H16PhaseHost {
+  int slot, c0, dz, kind;  // kind 1: the residual's single tap (dz, dy, dx of its entry = the crop centre)
+  int first_step, nsteps;
+};
+struct PackedH16 {
+  bool ready = false;
+  std::vector<PackEntry> entries;  // two units per K-step: (tap a, c0), (tap b, c0) or a dummy
+  std::vector<H16PhaseHost> phases;
+  void* w = nullptr;               // hi image, lo image
+  size_t lo_image_bytes = 0;
+  int Npad = 0;                    // 16 or 64
+};
+
 struct PassSite {
   std::string prefix;
   int nslots = 1;
@@ -84,6 +100,7 @@ struct PassSite {
   int k[BSMI_MAX_CONVS][3];
   PackedConv packed[BSMI_NUM_PREC][BSMI_MAX_CONVS];
   PackedWino wino[BSMI_MAX_CONVS];  // BSMI_PREC_BF16X3 only
+  PackedH16 h16[BSMI_MAX_CONVS];    // BSMI_PREC_BF16X3 only
 };
 
 struct HeadSite {
@@ -106,6 +123,9 @@ struct PlanStep {
   bool use_rh = false;
   RhxArgs rhx;           // fused split-bf16 raster-halo launch (use_rhx)
   bool use_rhx = false;
+  H16Args h16;           // halo-resident split-bf16 launch of a narrow stage (use_h16)
+  bool use_h16 = false;
+  int h16_rows = 0;      // rows of its halo buffer
   BoxArgs box;           // conv_box.hip launch of this step (use_box)
   bool use_box = false;
   // Winograd form of this step (use_wino): input transform, batched GEMMs, [residual-only launch], output transform

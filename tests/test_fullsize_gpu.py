@@ -184,6 +184,9 @@ def test_full_net_volume_pipeline_vs_cpu_blockwise():
     ("Winograd on every stage, batched persistent launches with split-K tails (256x320 tiles)",
      {"BSMI_WINO": "2", "BSMI_SK_GRID": "16", "BSMI_TILE_EFF": "0.01,0.01,0.01,0.01,1"}),
     ("no Winograd stage", {"BSMI_WINO": "0"}),
+    ("halo-resident form (conv_h16.hip) on every stage of at most 64 output channels", {"BSMI_H16": "2"}),
+    ("halo-resident form on every such stage, the first ConvPass included", {"BSMI_H16": "2", "BSMI_FUSED_FIRST": "0", "BSMI_WINO": "0"}),
+    ("no halo-resident stage", {"BSMI_H16": "0"}),
 ])
 def test_conv_kernel_variants_in_subprocess(variant, env):
     """The conv kernel variants that the golden nets do not reach by themselves (they are chosen by layer
