@@ -522,7 +522,7 @@ def main():
                      "peak_note": MFMA_PEAK_NOTE[args.precision],
                      "traffic": traffic, "traffic_unit": "bytes per launch (memory side of L2, Infinity-Cache hits included)",
                      "traffic_source": traffic_src,
-                     "kernel": "every convolution stage of the U-Net: bsmi::conv_igemm_kernel / conv_igemm_sk_kernel launches and, for the five stages in Winograd F(2x2,3x3) form, wino_in_kernel + the batched conv_igemm_sk_kernel launch + wino_out_kernel (their time is inside the stage's; FLOPs are the direct convolution's)",
+                     "kernel": "every convolution stage of the U-Net: bsmi::conv_igemm_kernel / conv_igemm_sk_kernel launches, conv_h16_kernel for five of the six stages with at most 64 output channels and, for the five stages in Winograd F(2x2,3x3) form, wino_in_kernel + the batched conv_igemm_sk_kernel launch + wino_out_kernel (their time is inside the stage's; FLOPs are the direct convolution's)",
                      "launches": int(conv_launches), "avg_launch_ms": conv_ms / max(conv_launches, 1),
                      "timed": f"HIP events around every launch of every {max(1, args.profile_every)}. block of the timed region",
                      "mfma_busy_pmc": pmc_mfma_busy(args.precision),

@@ -24,7 +24,9 @@
 // row r lands at slot s ^ ((r >> 2) & 1): a ds_read_b128 lane group (MI355X_MICROARCH.md, LDS) takes rows {0-3, 12-15} of one
 // slot and rows {4-11} of the slot two further, and with that key its 16 lanes hit 16 different slots of the 256-byte bank
 // row at ANY row offset (found by search over the 4-periodic keys; the plain layout is 2-way).  The weight slots keep the
-// chunk swizzle of conv_igemm.hip.  (Tried: one dword per row of the NEXT phase requested a phase ahead, to have its lines in
+// chunk swizzle of conv_igemm.hip.  (Tried: the weight fragments straight from global memory into registers, a K-step ahead,
+// no ring and no barrier inside a phase -- slower at 16 columns (72 -> 12 channels 0.56 -> 0.61 ms) and at 64 (360 -> 60:
+// 2.19 -> 2.55): whatever goes through the L1 competes with the halo loads.  Also tried: one dword per row of the NEXT phase requested a phase ahead, to have its lines in
 // L2 when the LDS-DMA loads go out -- slower, 360 -> 60 channels 2.23 -> 2.38 ms, 72 -> 12 0.71 -> 0.97: the extra L1 accesses
 // cost more than the shorter round trip saves.)
 #include "conv_h16.h"
@@ -68,7 +70,7 @@ __global__ __launch_bounds__(64 * kNW, 2) void conv_h16_kernel(const H16Args a) 
   constexpr int SLOT = 2 * EB;         // hi, lo
   constexpr int JW = HR / 16 / kNW;    // halo LDS-DMA instructions per wave (16 rows each)
   static_assert(HR % (16 * kNW) == 0, "the waves share the halo rows evenly");
-  constexpr int G = FNB >= 4 ? 1 : (FNB == 2 ? 2 : 4);  // row blocks multiplied side by side: >= 4 MFMAs between two on one accumulator
+  constexpr int G = FNB >= 4 ? 1 : (FNB == 2 ? 2 : 8);  // row blocks multiplied side by side: >= 4 MFMAs between two on one accumulator
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
