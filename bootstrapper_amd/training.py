@@ -138,18 +138,21 @@ def fit(trainer, batches, max_iterations, save_checkpoints_every=0, setup_dir=No
         save_snapshots_every=0, voxel_size=None):
     """The training loop of training.py:96-137 without Lightning: `batches` is any iterable of reference-style batch
     dicts ("raw", "gt_affs", "affs_weights"[, "gt_lsds", "lsds_weights"]) of CUDA float32 tensors.  Every `log_every`
-    steps the loss also goes to `<setup_dir>/log/train_loss.csv` (the reference logs the same scalar to TensorBoard,
-    whose writer is not in this image); snapshots as SnapshotCallback writes them (step 1 and every
+    steps the loss goes to a TensorBoard event file under `<setup_dir>/log/version_<n>/` -- the layout of the reference's
+    TensorBoardLogger(setup_dir, name="log"), training.py:130, written by tb_events.ScalarWriter -- and to
+    `<setup_dir>/log/train_loss.csv`; snapshots as SnapshotCallback writes them (step 1 and every
     `save_snapshots_every` steps)."""
     import os
     it = int(start_iteration)
     rank = torch.distributed.get_rank() if torch.distributed.is_available() and torch.distributed.is_initialized() else 0
-    scalars = None
+    scalars = events = None
     if setup_dir and rank == 0:
+        from .tb_events import ScalarWriter
         os.makedirs(os.path.join(setup_dir, "log"), exist_ok=True)
         scalars = open(os.path.join(setup_dir, "log", "train_loss.csv"), "a")
         if scalars.tell() == 0:
             scalars.write("step,train_loss\n")
+        events = ScalarWriter(os.path.join(setup_dir, "log"))
     for batch in batches:
         if it >= max_iterations:
             break
@@ -160,6 +163,7 @@ def fit(trainer, batches, max_iterations, save_checkpoints_every=0, setup_dir=No
         if scalars and it % log_every == 0:
             scalars.write(f"{it},{loss:.8g}\n")
             scalars.flush()
+            events.add_scalar("train_loss", loss, it)
         if save_snapshots_every and setup_dir and voxel_size is not None and (it == 1 or it % save_snapshots_every == 0):
             data = dict(batch)
             data.update(trainer.predictions())
@@ -170,6 +174,7 @@ def fit(trainer, batches, max_iterations, save_checkpoints_every=0, setup_dir=No
                 save_checkpoint(trainer, os.path.join(setup_dir, f"model_checkpoint_{it}.ckpt"), it)
     if scalars:
         scalars.close()
+        events.close()
     return it
 
 

@@ -163,3 +163,31 @@ def test_histogram_quantile_merge_loop_on_the_host():
                 lut = np.zeros(int(ids.max()) + 1, dtype=np.uint64)
                 lut[ids.astype(np.int64)] = ids[roots[t]]
                 assert np.array_equal(lut[frags.astype(np.int64)], want[t]), (case, q, initmax, t)
+
+
+def test_tensorboard_event_file_round_trip(tmp_path):
+    """tb_events: TFRecord framing and the Event / Summary fields TensorBoard reads scalars from (reference training.py:130
+    logs `train_loss` through Lightning's TensorBoardLogger).  Known answers: CRC-32C of "123456789" is 0xE3069283 (RFC 3720
+    B.4); the record of an empty payload."""
+    import struct
+    from bootstrapper_amd import tb_events as T
+    assert T.crc32c(b"123456789") == 0xE3069283
+    assert T.crc32c(b"") == 0
+    assert T.record_bytes(b"")[:8] == struct.pack("<Q", 0) and len(T.record_bytes(b"abc")) == 8 + 4 + 3 + 4
+    with T.ScalarWriter(str(tmp_path / "log")) as w:
+        for step, v in [(10, 0.5), (20, 0.25), (300000, 1e-3)]:
+            w.add_scalar("train_loss", v, step)
+        path = w.path
+    assert os.path.basename(os.path.dirname(path)) == "version_0" and os.path.basename(path).startswith("events.out.tfevents.")
+    version, scalars = T.read_scalars(path)
+    assert version == "brain.Event:2"
+    assert [(s, t) for s, t, _, _ in scalars] == [(10, "train_loss"), (20, "train_loss"), (300000, "train_loss")]
+    assert np.allclose([v for _, _, v, _ in scalars], [0.5, 0.25, 1e-3], rtol=1e-7)
+    with T.ScalarWriter(str(tmp_path / "log")) as w2:   # a second run gets its own version directory
+        assert os.path.basename(w2.dir) == "version_1"
+    raw = bytearray(open(path, "rb").read())
+    raw[-6] ^= 1                                         # a flipped payload bit is caught by the checksum
+    bad = tmp_path / "bad"
+    bad.write_bytes(bytes(raw))
+    with pytest.raises(ValueError):
+        T.read_scalars(str(bad))

@@ -118,11 +118,16 @@ def test_bs_train_driver(tmp_path):
     ckpt, step = latest_checkpoint(str(setup))
     assert step == 3 and os.path.basename(ckpt) == "model_checkpoint_3.ckpt"
     assert any("train_loss" in l for l in logs)
+    import glob
+    from bootstrapper_amd.tb_events import read_scalars
+    events = glob.glob(str(setup / "log" / "version_0" / "events.out.tfevents.*"))   # TensorBoardLogger(setup_dir, name="log"), training.py:130
+    assert len(events) == 1 and read_scalars(events[0])[0] == "brain.Event:2"
     m = Model(nc, precision="f32").load_checkpoint(ckpt)            # the predict worker's loader (predict.py:98-108)
     y = m(torch.zeros(1, 1, 30, 108, 108, device="cuda"))
     assert tuple(y.shape) == (1, 3, 2, 16, 16) and bool(torch.isfinite(y).all())
     cfg.write_text(cfg.read_text().replace("max_iterations = 3", "max_iterations = 5").replace("save_checkpoints_every = 3", "save_checkpoints_every = 5"))
     assert run_training(str(cfg), log=logs.append) == 5 and latest_checkpoint(str(setup))[1] == 5
+    assert glob.glob(str(setup / "log" / "version_1" / "events.out.tfevents.*"))     # the resumed run logs under its own version
     assert any("resuming from" in l for l in logs)
 
 
