@@ -98,6 +98,7 @@ def _load():
         "bsmi_frag_pair_affinity_u8": (i32, [C.c_int, vp, C.c_int, vp, vp, i64p, C.c_uint64, vp, vp, vp, vp, vp]),
         "bsmi_label_table_u64": (i32, [p, vp, i64p, C.c_int64, vp, vp, vp, vp, C.c_uint64, vp, vp]),
         "bsmi_seg_status": (i32, [p, vp]),
+        "bsmi_seg_set_host_flood": (i32, [p, i32]),
         "bsmi_unet_train_set_arithmetic": (i32, [p, i32]),
         "bsmi_unet_train_begin": (i32, [p, i64p]),
         "bsmi_unet_train_forward_backward": (i32, [p, vp, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_float), vp]),

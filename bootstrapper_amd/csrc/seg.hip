@@ -2019,6 +2019,11 @@ __global__ __launch_bounds__(64) void ws3_flood_kernel(int D, int H, int W, WsSc
   }
 }
 
+// fragments of the 3-D mode = the flooded labels (bsmi_seg_set_host_flood: the flood ran on the host)
+__global__ void ws3_labels_out_kernel(const int32_t* __restrict__ lab, size_t n, uint64_t* __restrict__ frags) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) frags[i] = (uint64_t)(uint32_t)lab[i];
+}
+
 // per-label voxel count and coordinate sums (RAG node attributes, watershed_frags.py:230-246)
 __global__ void label_stats_kernel(const uint64_t* __restrict__ lab, int D, int H, int W, uint64_t id_offset, uint64_t num,
                                    unsigned long long* __restrict__ size, unsigned long long* __restrict__ sums) {
@@ -2073,7 +2078,12 @@ struct bsmi_seg {
   uint64_t* rag_counts = nullptr;  // [4] ne, nm, nn of the last RAG call
   float* thr_dev = nullptr;
   int* status_dev = nullptr;
+  bool host_flood3 = false;  // bsmi_seg_set_host_flood: the 3-D watershed's flood runs on the host (flood_host.cpp)
 };
+
+namespace bsmi {
+void host_flood3(int D, int H, int W, const uint8_t* mask, const int32_t* d2, int32_t* lab);  // flood_host.cpp
+}
 
 namespace bsmi {
 template <typename T>
@@ -2228,6 +2238,22 @@ int bsmi_ws_fragments_seeds_u8(bsmi_seg* h, const uint8_t* affs_dev, const int64
     hipLaunchKernelGGL(cc26_scan_kernel, dim3(1), dim3(1024), 0, s, nblk, f, max_id_dev);
     hipLaunchKernelGGL(cc26_rank_kernel, dim3(nblk), dim3(1024), 0, s, n, f);
     hipLaunchKernelGGL(ws3_markers_kernel, dim3(grid), dim3(bs), 0, s, (const uint64_t*)h->crop_tmp, (const uint8_t*)w.mask, n, f, w.lab, seeds_dev);
+    if (h->host_flood3) {
+      // the caller waits for this one result: mask, distances and markers to the host, the sequential flood there, labels back
+      BSMI_HIP(hipGetLastError());
+      std::vector<uint8_t> hmask(n);
+      std::vector<int32_t> hd2(n), hlab(n);
+      BSMI_HIP(hipMemcpyAsync(hmask.data(), w.mask, n, hipMemcpyDeviceToHost, s));
+      BSMI_HIP(hipMemcpyAsync(hd2.data(), w.d2, n * sizeof(int32_t), hipMemcpyDeviceToHost, s));
+      BSMI_HIP(hipMemcpyAsync(hlab.data(), w.lab, n * sizeof(int32_t), hipMemcpyDeviceToHost, s));
+      BSMI_HIP(hipStreamSynchronize(s));
+      host_flood3(D, H, W, hmask.data(), hd2.data(), hlab.data());
+      BSMI_HIP(hipMemcpyAsync(w.lab, hlab.data(), n * sizeof(int32_t), hipMemcpyHostToDevice, s));
+      hipLaunchKernelGGL(ws3_labels_out_kernel, dim3(grid), dim3(bs), 0, s, (const int32_t*)w.lab, n, frags_dev);
+      BSMI_HIP(hipGetLastError());
+      BSMI_HIP(hipStreamSynchronize(s));  // (the host buffers go out of scope)
+      return BSMI_OK;
+    }
     hipLaunchKernelGGL(ws3_flood_kernel, dim3(1), dim3(64), 0, s, D, H, W, w, h->flood_spill, frags_dev);
     BSMI_HIP(hipGetLastError());
     return BSMI_OK;
@@ -2670,6 +2696,12 @@ int bsmi_label_table_u64(bsmi_seg* h, const uint64_t* labels_dev, const int64_t 
   BSMI_HIP(hipcub::DeviceRadixSort::SortPairs(h->sort_tmp, tb, (const uint64_t*)g.idu, g.ids, (const uint32_t*)g.ha, g.hb, (int)g.node_cap, 0, 64, s));
   hipLaunchKernelGGL(ltab_gather_kernel, dim3(256), dim3(256), 0, s, g, ids_dev, counts_dev, zmin_dev, zmax_dev, capacity, n_dev);
   BSMI_HIP(hipGetLastError());
+  return BSMI_OK;
+}
+
+int bsmi_seg_set_host_flood(bsmi_seg* h, int on) {
+  if (!h) BSMI_FAIL(BSMI_ERR_INVALID, "null handle");
+  h->host_flood3 = on != 0;
   return BSMI_OK;
 }
 

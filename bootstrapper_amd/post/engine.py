@@ -8,11 +8,15 @@ from .._lib import lib, check
 
 
 class SegEngine:
-    def __init__(self, max_shape, device=0):
+    def __init__(self, max_shape, device=0, host_flood=True):
+        """host_flood: the one sequential flood of the 3-D fragments mode (fragments_in_xy = False) runs on the host and
+        ws_fragments returns when it is done (0.16 s per 128^3 block; the device's single-wave replay of the same loop takes
+        12.8 s, 0.8 s per block with 16 lanes side by side); False keeps the call asynchronous on the device."""
         self.device = int(device)
         self.max_shape = tuple(int(s) for s in max_shape)
         self._h = C.c_void_p()
         check(lib.bsmi_seg_create(self.device, _lib.i64x3(self.max_shape), C.byref(self._h)))
+        check(lib.bsmi_seg_set_host_flood(self._h, 1 if host_flood else 0))
 
     def __del__(self):
         h = getattr(self, "_h", None)
@@ -25,7 +29,8 @@ class SegEngine:
 
     def ws_fragments(self, affs_u8, fragments_in_xy=True, min_seed_distance=10, return_seeds=False):
         """affs_u8: uint8 CUDA tensor [3][D][H][W] -> (fragments int64 [D][H][W] holding the
-        uint64 ids, max_id tensor int64[1][, seeds int64 [D][H][W]]); asynchronous on the current stream."""
+        uint64 ids, max_id tensor int64[1][, seeds int64 [D][H][W]]); asynchronous on the current stream (except the 3-D
+        mode of an engine with host_flood, which returns when the fragments are written)."""
         if affs_u8.dtype != torch.uint8 or not affs_u8.is_cuda or affs_u8.dim() != 4 or affs_u8.shape[0] != 3:
             raise ValueError("affs must be a uint8 CUDA tensor of shape (3, D, H, W)")
         a = affs_u8.contiguous()

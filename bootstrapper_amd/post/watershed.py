@@ -17,12 +17,13 @@ from .naming import build_name, dump_params
 
 
 def _warn_3d_fragments(fragments_in_xy, shape):
-    """fragments_in_xy = false (post/ws.py:98-110) floods a whole block as ONE sequential priority queue: bit-exact here, but a
-    single wave's work (13 s for a 128^3 block, where the per-section default takes 12 ms) -- say so instead of looking hung."""
+    """fragments_in_xy = false (post/ws.py:98-110) floods a whole block as ONE sequential priority queue: bit-exact here, on the
+    host (csrc/flood_host.cpp: 0.16 s per 128^3 block, one block at a time) where the per-section default takes 12 ms on the
+    device with 16 blocks in flight -- say so instead of looking slow."""
     if not fragments_in_xy and int(np.prod(shape)) > (1 << 21):
         import sys
         print(f"warning: fragments_in_xy = false floods a block of {tuple(int(v) for v in shape)} voxels as one sequential queue "
-              "(seconds per 128^3 block on the device); the default fragments_in_xy = true runs every section as its own queue",
+              "on the host (0.2 s per 128^3 block, block after block); the default fragments_in_xy = true runs every section as its own queue on the device",
               file=sys.stderr)
 
 

@@ -372,6 +372,12 @@ int bsmi_label_table_u64(bsmi_seg *h, const uint64_t *labels_dev, const int64_t 
                          uint64_t *ids_dev, uint64_t *counts_dev, int32_t *zmin_dev, int32_t *zmax_dev,
                          uint64_t capacity, uint64_t *n_dev, void *stream);
 
+/* fragments_in_xy = 0 (reference post/ws.py:98-110) floods the block from ONE priority queue.  on = 1: that flood runs on the
+ * host (csrc/flood_host.cpp: 0.16 s per 128^3 block instead of 12.8 s for the device's single-wave replay) and
+ * bsmi_ws_fragments_seeds_u8 returns when the fragments are written (the Python engines switch it on); 0 (the handle's
+ * default): the device loop, asynchronous like every other call. */
+int bsmi_seg_set_host_flood(bsmi_seg *h, int on);
+
 /* status of the asynchronous seg calls on this handle since the previous bsmi_seg_status (an overflow of any of
  * them is remembered on the device until it is read here; synchronises `stream`): BSMI_OK or BSMI_ERR_OVERFLOW.
  * After an overflow the outputs of that call are undefined. */

@@ -51,10 +51,15 @@ def test_fragments_3d_mode_bit_exact(golden_dir):
     rng = np.random.default_rng(12)
     cases = [(_blobby(rng, (20, 48, 40), (2, 3, 3)), 5), (_blobby(rng, (9, 33, 70), (1, 2, 2)), 3),
              (np.full((3, 6, 20, 20), 255, np.uint8), 4), (np.zeros((3, 4, 10, 12), np.uint8), 4)]
+    from bootstrapper_amd.post.engine import SegEngine
     for affs, msd in cases:
         ref, ref_max = S.ws_fragments_u8(affs, False, msd)
-        frags, mx = watershed_from_affinities(torch.from_numpy(affs).cuda(), fragments_in_xy=False, min_seed_distance=msd)
+        frags, mx = watershed_from_affinities(torch.from_numpy(affs).cuda(), fragments_in_xy=False, min_seed_distance=msd)   # flood on the host
         assert mx == ref_max and np.array_equal(frags.cpu().numpy().astype(np.uint64), ref)
+        # the block pipeline's lanes keep the flood on the device (asynchronous): the same fragments
+        f2, m2 = watershed_from_affinities(torch.from_numpy(affs).cuda(), fragments_in_xy=False, min_seed_distance=msd,
+                                           engine=SegEngine(affs.shape[1:], 0, host_flood=False))
+        assert m2 == ref_max and np.array_equal(f2.cpu().numpy().astype(np.uint64), ref)
 
 
 @pytest.mark.parametrize("shape,sigma,msd", [((16, 128, 128), (1, 4, 4), 10), ((5, 160, 160), (1, 6, 6), 10),
