@@ -34,7 +34,10 @@ namespace bsmi {
 // watershed fragments
 // ------------------------------------------------------------------------------------------
 constexpr int WS_T = 256;            // threads per slice workgroup (seeds kernel)
-constexpr int FLOOD_WAVES = 16;     // slices per flood workgroup (one wave each): a workgroup pins its CU, so pack it
+#ifndef BSMI_FLOOD_WAVES
+#define BSMI_FLOOD_WAVES 16
+#endif
+constexpr int FLOOD_WAVES = BSMI_FLOOD_WAVES;  // slices per flood workgroup (one wave each): a workgroup pins its CU, so pack it (dev builds: 8, 4)
 constexpr int FLOOD_LDS_HEAP = 1024; // heap entries per slice kept in LDS (8 B each); the rest spills to HBM
 
 __device__ __forceinline__ int reflect_dup(int i, int n) {
