@@ -51,30 +51,7 @@ bool rh_supported(TileCfg cfg, int Win, int ky, int kx);
 
 int launch_conv_rh(const RhArgs& a, int precision, TileCfg cfg, hipStream_t stream, float* sk_ws = nullptr, int sk_grid = 0);
 
-// ---- fused split-bf16 form (BSMI_PREC_BF16X3, 256 x 64 tile): conv_rh_x3_kernel --------------------------------------
-// One K-step = one in-plane tap x 32 channels, multiplied as A lo x B hi + A hi x B hi + A hi x B lo out of the phase's
-// halo (both planes of the (hi, lo)-interleaved rows, staged once per phase) and the step's hi / lo weight rows.
-struct RhxStep {
-  int32_t rowoff;   // halo row offset of the tap
-  int32_t buf;      // halo buffer of the step's own phase (0 / 1); bit 16: its halo lands with the previous K-step
-  int32_t issue;    // phase whose halo pieces go out with this step (-1: none)
-  int32_t pieces;   // first piece | count << 8 (pieces per wave: 0 .. 2 * HP - 1, lo plane first)
-};
-static_assert(sizeof(RhxStep) == 16, "RhxStep layout");
-struct RhxArgs {
-  ConvSrc t[kMaxConvTensors];
-  const RhxStep* steps;   // device
-  const RhPhase* phases;  // device: tensor, delta of the hi vectors (lo: +16), buf
-  int nsteps, nphases;
-  const void* w;          // hi weight image [nsteps][Npad][64 B]
-  const void* w_lo;       // lo image, same layout
-  const float* bias;
-  void* out;              // (hi, lo)-interleaved [Do][Ho][Wo][Co]
-  int Do, Ho, Wo, Co;
-  int Hin, Win, Q, Npad, relu;
-};
-constexpr int kRhxHaloPieces = 4;  // 16-row pieces per wave and plane: 8 waves -> 512 halo rows (Win <= 127 with 3 x 3 taps)
-bool rhx_supported(TileCfg cfg, int Win, int ky, int kx);
-int launch_conv_rh_x3(const RhxArgs& a, hipStream_t stream);
+// (A fused split-bf16 form of this kernel, conv_rh_x3_kernel -- 32 x 64 wave tiles, one barrier per K-step of 24 MFMAs -- existed in
+// rounds 2 and 3 as an opt-in and lost to the gather kernel; conv_h16.hip is the halo form of the split mode.)
 
 }  // namespace bsmi

@@ -425,265 +425,6 @@ __global__ __launch_bounds__(64 * kRhNW) void conv_rh_fixup_kernel(const RhArgs 
   }
 }
 
-// ---- fused split-bf16 raster-halo kernel ----------------------------------------------------------------------------
-// 256 input-raster rows x 64 output channels per workgroup, 8 waves of 32 rows x 64 columns on v_mfma_f32_16x16x32_bf16.
-// LDS: [halo buffer 0 | 1][lo plane | hi plane][512 rows x 64 B] (128 KB) + [weights of K-step parity 0 | 1][hi | lo][64
-// rows x 64 B] (16 KB).  Schedule of K-step h: issue the weights of h + 1 and the halo pieces the host listed for this step
-// (the next phase's halo, spread over this phase's steps); read the step's fragments; 24 MFMAs per wave; drain
-// (`vmcnt(0)`: an LDS-DMA is back after 250-400 cycles, a step multiplies for >= 770) ; ONE barrier.  Against the gather
-// kernel (conv_x3_body) the activation rows enter the CU once per phase instead of once per tap.
-template <int BN>
-__global__ __launch_bounds__(64 * kRhNW, 1) void conv_rh_x3_kernel(const RhxArgs a) {
-  using T = bf16f_elem;
-  constexpr int NW = kRhNW, HP = kRhxHaloPieces, ROWB = kStepRowBytes;
-  constexpr int HROWS = HP * NW * 16;          // rows of one halo plane
-  constexpr int PLANE = HROWS * ROWB;          // bytes
-  constexpr int HBUF = 2 * PLANE;              // lo plane, hi plane
-  constexpr int OFF_B = 2 * HBUF;
-  constexpr int EB = BN * ROWB;                // one weight plane of one K-step; three K-steps' weights are resident
-  constexpr int FM = 2, FN = BN / 16;          // wave tile: 32 rows x BN columns (the K loop names the two row blocks)
-  constexpr int BP = BN / 16;                  // 16-row weight pieces per plane: waves 0 .. BP-1 stage one each
-  static_assert(BP <= NW, "weight pieces fit the waves");
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int ntiles = (a.Q + 255) / 256;
-  // XCD-contiguous tile order as conv_igemm_kernel
-  const int qn = ntiles >> 3, rn = ntiles & 7;
-  const int xcd = blockIdx.x & 7, jn = blockIdx.x >> 3;
-  const int tile = (xcd < rn ? xcd * (qn + 1) : rn * (qn + 1) + (xcd - rn) * qn) + jn;
-  const int q0 = tile * 256;
-  const cint_ptr_t steps = (cint_ptr_t)a.steps;
-  const cint_ptr_t phases = (cint_ptr_t)a.phases;
-  const int nsteps = a.nsteps;
-
-  // staging geometry (16x16x32 swizzle keys, as conv_x3_body): lane l lands at row l >> 2, slot l & 3 of its piece
-  const int lrow = lane >> 2, lchunk = lane & 3;
-  const int skey = swz16((lane >> 4) & 3);
-  const uint32_t hsrc = (uint32_t)((lchunk ^ skey) << 5);  // (hi, lo) vectors interleaved: a plane's chunks are 32 B apart
-  static_assert(kMaxConvTensors == 3, "three source slots");
-  uint32_t ro0[HP], ro1[HP], ro2[HP];
-#pragma unroll
-  for (int i = 0; i < HP; ++i) {
-    int q = q0 + (i * NW + wave) * 16 + lrow;
-    q = q < a.Q ? q : a.Q - 1;
-    const int xx = q % a.Win;
-    const int zy = q / a.Win;
-    const int yy = zy % a.Hin, z = zy / a.Hin;
-    ro0[i] = (uint32_t)(z * a.t[0].sz + yy * a.t[0].sy + xx * a.t[0].sx);
-    ro1[i] = (uint32_t)(z * a.t[1].sz + yy * a.t[1].sy + xx * a.t[1].sx);
-    ro2[i] = (uint32_t)(z * a.t[2].sz + yy * a.t[2].sy + xx * a.t[2].sx);
-  }
-  const uint64_t base0 = a.t[0].base, base1 = a.t[1].base, base2 = a.t[2].base;
-  const uint32_t offb = (uint32_t)((wave * 16 + lrow) * ROWB + ((lchunk ^ skey) << 4));
-  const size_t wstep = (size_t)a.Npad * ROWB;
-  const gptr_t w_hi = (gptr_t)a.w, w_lo = (gptr_t)a.w_lo;
-
-  // pieces [k0, k0 + n) of phase p: piece k < HP: lo plane row block k, else hi plane row block k - HP.  Macros, not
-  // lambdas: a closure that selects among the row-offset arrays ends up in scratch.
-#define RHX_ISSUE_HALO(p_, k0_, n_)                                                                                  \
-  do {                                                                                                                \
-    const cint_ptr_t d_ = phases + (p_) * 4;                                                                          \
-    const int t_ = d_[0], delta_ = d_[1], buf_ = d_[2];                                                               \
-    const bool t1_ = t_ == 1, t2_ = t_ == 2;                                                                          \
-    const gptr_t hb_ = (gptr_t)(t1_ ? base1 : (t2_ ? base2 : base0));                                                 \
-    const lptr_t lh_ = (lptr_t)(smem + buf_ * HBUF);                                                                  \
-    const int ka_ = (k0_), kb_ = (k0_) + (n_);                                                                        \
-    _Pragma("unroll") for (int k_ = 0; k_ < 2 * HP; ++k_) {                                                           \
-      const int i_ = k_ < HP ? k_ : k_ - HP;                                                                          \
-      const uint32_t r0_ = ro0[i_], r1_ = ro1[i_], r2_ = ro2[i_];                                                     \
-      const uint32_t src_ = (t1_ ? r1_ : (t2_ ? r2_ : r0_)) + (uint32_t)delta_ + hsrc + (k_ < HP ? 16u : 0u);         \
-      if (k_ >= ka_ && k_ < kb_)                                                                                      \
-        __builtin_amdgcn_global_load_lds(hb_ + (size_t)src_, lh_ + (k_ < HP ? 0 : PLANE) + (i_ * NW + wave) * 1024, 16, 0, 0); \
-    }                                                                                                                 \
-  } while (0)
-#define RHX_ISSUE_W(h_)                                                                                               \
-  do {                                                                                                                \
-    if (wave < BP) {                                                                                                  \
-      const size_t wi_ = (size_t)((h_) < nsteps ? (h_) : nsteps - 1) * wstep;                                         \
-      const lptr_t lb_ = (lptr_t)(smem + OFF_B + ((h_) % 3) * 2 * EB) + wave * 1024;                                  \
-      __builtin_amdgcn_global_load_lds(w_hi + wi_ + offb, lb_, 16, 0, 0);                                             \
-      __builtin_amdgcn_global_load_lds(w_lo + wi_ + offb, lb_ + EB, 16, 0, 0);                                        \
-    }                                                                                                                 \
-  } while (0)
-
-  f32x4_t acc[FM][FN];
-#pragma unroll
-  for (int i = 0; i < FM; ++i)
-#pragma unroll
-    for (int j = 0; j < FN; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-
-  // prologue: the first phase's halo and the weights of K-steps 0 and 1
-  RHX_ISSUE_HALO(0, 0, 2 * HP);
-  RHX_ISSUE_W(0);
-  RHX_ISSUE_W(1);
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __builtin_amdgcn_s_barrier();
-
-  const int lr = lane & 15, lq = lane >> 4;
-  // fragments of K-step h_ into the register set (AL_, AH_, BH_, BL_)
-#define RHX_READ(h_, rowoff_, buf_, AL_, AH_, BH_, BL_)                                                               \
-  do {                                                                                                                \
-    const char* hl_ = smem + (buf_) * HBUF;                                                                           \
-    const char* wb_ = smem + OFF_B + ((h_) % 3) * 2 * EB;                                                             \
-    _Pragma("unroll") for (int i_ = 0; i_ < FM; ++i_) {                                                               \
-      const uint32_t t_ = (uint32_t)(wave * 32 + i_ * 16 + lr + (rowoff_));                                           \
-      const uint32_t off_ = t_ * ROWB + (uint32_t)((lq ^ swz16((t_ >> 2) & 3)) << 4);                                 \
-      AL_[i_] = *(const u32x4_t*)(hl_ + off_);                                                                        \
-      AH_[i_] = *(const u32x4_t*)(hl_ + PLANE + off_);                                                                \
-    }                                                                                                                 \
-    _Pragma("unroll") for (int j_ = 0; j_ < FN; ++j_) {                                                               \
-      const uint32_t r_ = (uint32_t)(lr + j_ * 16);                                                                   \
-      const uint32_t off_ = r_ * ROWB + (uint32_t)((lq ^ swz16((r_ >> 2) & 3)) << 4);                                 \
-      BH_[j_] = *(const u32x4_t*)(wb_ + off_);                                                                        \
-      BL_[j_] = *(const u32x4_t*)(wb_ + EB + off_);                                                                   \
-    }                                                                                                                 \
-  } while (0)
-  // product PR_ (0: A lo x B hi, 1: A hi x B hi, 2: A hi x B lo) on all FM x FN accumulators: the three MFMAs of one
-  // accumulator are 8 instructions apart (back to back on one accumulator each waits for the one before: the first
-  // version, row block by row block, ran the 24 MFMAs of a K-step as 8 dependent chains of 3)
-#define RHX_MMA(PR_, AL_, AH_, BH_, BL_)                                                                              \
-  do {                                                                                                                \
-    _Pragma("unroll") for (int i_ = 0; i_ < FM; ++i_)                                                                 \
-      _Pragma("unroll") for (int j_ = 0; j_ < FN; ++j_)                                                               \
-        acc[i_][j_] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, (PR_) == 0 ? AL_[i_] : AH_[i_]),      \
-                                                              __builtin_bit_cast(bf16x8_t, (PR_) == 2 ? BL_[j_] : BH_[j_]), acc[i_][j_], 0, 0, 0); \
-  } while (0)
-  // End of K-step h: everything but the halo piece this step issued LAST must have landed -- the weights of h + 2 (from
-  // L2, long back) so that the next step can fetch its fragments a step ahead, and the pieces of earlier steps (loads
-  // return in order); the piece itself, a cold read, gets another step.  The host lets the last step of a phase carry
-  // none.  More than one piece per step (short phases): drain.
-#define RHX_WAIT(np_)                                                                                                 \
-  do {                                                                                                                \
-    if ((np_) == 1) asm volatile("s_waitcnt vmcnt(1) lgkmcnt(0)" ::: "memory");                                       \
-    else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");                                                  \
-  } while (0)
-  // two register sets: while one K-step multiplies, the next one's fragments arrive (its weights landed a step ago; its
-  // halo is resident unless the step opens a phase whose last pieces went out with the previous step -- the host marks
-  // those steps `late`, bit 16 of the buffer word, and they read after the barrier)
-  u32x4_t al0[FM], ah0[FM], bh0[FN], bl0[FN], al1[FM], ah1[FM], bh1[FN], bl1[FN];
-  {
-    const cint_ptr_t d0 = steps;
-    RHX_READ(0, d0[0], d0[1] & 1, al0, ah0, bh0, bl0);
-  }
-  for (int h = 0; h < nsteps; h += 2) {   // nsteps is even
-    {
-      const cint_ptr_t d = steps + h * 4, dn = steps + (h + 1) * 4;
-      const int issue = d[2], pcs = d[3];
-      const int nro = dn[0], nbuf = dn[1];
-      // the first row block multiplies while this wave sits in LDS-DMA issue; the next step's fragments follow
-      RHX_MMA(0, al0, ah0, bh0, bl0);
-      __builtin_amdgcn_sched_barrier(0);
-      RHX_ISSUE_W(h + 2);
-      if (issue >= 0) RHX_ISSUE_HALO(issue, pcs & 0xff, pcs >> 8);
-      if (!(nbuf >> 16)) RHX_READ(h + 1, nro, nbuf & 1, al1, ah1, bh1, bl1);
-      __builtin_amdgcn_sched_barrier(0);
-      RHX_MMA(1, al0, ah0, bh0, bl0);
-      RHX_MMA(2, al0, ah0, bh0, bl0);
-      RHX_WAIT(issue >= 0 ? pcs >> 8 : 0);
-      __builtin_amdgcn_s_barrier();
-      if (nbuf >> 16) RHX_READ(h + 1, nro, nbuf & 1, al1, ah1, bh1, bl1);
-    }
-    {
-      const cint_ptr_t d = steps + (h + 1) * 4;
-      const int issue = d[2], pcs = d[3];
-      const bool more = h + 2 < nsteps;
-      const cint_ptr_t dn = steps + (more ? h + 2 : h + 1) * 4;
-      const int nro = dn[0], nbuf = dn[1];
-      RHX_MMA(0, al1, ah1, bh1, bl1);
-      __builtin_amdgcn_sched_barrier(0);
-      RHX_ISSUE_W(h + 3);
-      if (issue >= 0) RHX_ISSUE_HALO(issue, pcs & 0xff, pcs >> 8);
-      if (more && !(nbuf >> 16)) RHX_READ(h + 2, nro, nbuf & 1, al0, ah0, bh0, bl0);
-      __builtin_amdgcn_sched_barrier(0);
-      RHX_MMA(1, al1, ah1, bh1, bl1);
-      RHX_MMA(2, al1, ah1, bh1, bl1);
-      RHX_WAIT(issue >= 0 ? pcs >> 8 : 0);
-      __builtin_amdgcn_s_barrier();
-      if (more && (nbuf >> 16)) RHX_READ(h + 2, nro, nbuf & 1, al0, ah0, bh0, bl0);
-    }
-  }
-#undef RHX_READ
-#undef RHX_MMA
-#undef RHX_WAIT
-
-  // epilogue: bias (+ReLU), (hi, lo) through per-wave LDS strips, 16-byte streaming stores; raster rows that are no
-  // output voxel (xx >= Wo, yy >= Ho) are dropped
-  constexpr int PITCH = BN * 2 + 16;
-  constexpr int CPR = BN * 2 / 16;
-  constexpr int NCH = 16 * CPR;
-  constexpr int LO_STRIPS = NW * 16 * PITCH;
-  static_assert(2 * LO_STRIPS <= 2 * HBUF, "strips fit in the halo area");
-  char* strip = smem + wave * (16 * PITCH);
-  T* out = (T*)a.out;
-  float bv[FN];
-#pragma unroll
-  for (int j = 0; j < FN; ++j) {
-    const int n = j * 16 + lr;
-    bv[j] = n < a.Npad ? a.bias[n] : 0.f;
-  }
-#pragma unroll
-  for (int i = 0; i < FM; ++i) {
-#pragma unroll
-    for (int j = 0; j < FN; ++j)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        float v = acc[i][j][r] + bv[j];   // 16x16: register r holds row 4 (lane >> 4) + r, column lane & 15
-        if (a.relu) v = v > 0.f ? v : 0.f;
-        Elem<T>::store((T*)(strip + (4 * lq + r) * PITCH) + j * 16 + lr, v);
-        Elem<T>::store((T*)(strip + LO_STRIPS + (4 * lq + r) * PITCH) + j * 16 + lr, split_lo(v));
-      }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#pragma unroll
-    for (int k = 0; k < (NCH + 63) / 64; ++k) {
-      const int c = lane + 64 * k;
-      if (c >= NCH) break;
-      const int row = c / CPR, cc = c - row * CPR;
-      const u32x4_t v = *(const u32x4_t*)(strip + row * PITCH + cc * 16);
-      const int q = q0 + wave * 32 + i * 16 + row;
-      const int n = cc * 8;
-      if (q < a.Q && n < a.Co) {
-        const int xx = q % a.Win;
-        const int zy = q / a.Win;
-        const int yy = zy % a.Hin, z = zy / a.Hin;
-        if (xx < a.Wo && yy < a.Ho) {
-          T* dst = out + act_index<T>(((size_t)(z * a.Ho + yy) * a.Wo + xx) * a.Co, n);
-          store_stream16(dst, v);
-          store_stream16(dst + kSplitLoElems, *(const u32x4_t*)(strip + LO_STRIPS + row * PITCH + cc * 16));
-        }
-      }
-    }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-  }
-}
-
-#undef RHX_ISSUE_HALO
-#undef RHX_ISSUE_W
-
-bool rhx_supported(TileCfg cfg, int Win, int ky, int kx) {
-  return cfg == TILE_256x64 && 256 + (ky - 1) * Win + (kx - 1) <= kRhxHaloPieces * kRhNW * 16;
-}
-
-int launch_conv_rh_x3(const RhxArgs& a, hipStream_t stream) {
-  constexpr int BN = 64;
-  constexpr int smem = 4 * kRhxHaloPieces * kRhNW * 16 * kStepRowBytes + 6 * BN * kStepRowBytes;
-  static_assert(smem <= 160 * 1024 - 64, "LDS budget");
-  if (a.Q <= 0 || a.nsteps <= 0 || a.nphases <= 0 || a.Npad != BN) BSMI_FAIL(BSMI_ERR_INVALID, "fused raster-halo conv: bad geometry");
-  auto kern = conv_rh_x3_kernel<BN>;
-  static DeviceOnce once;
-  const int rc_once = once.run([&]() -> int {
-    BSMI_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
-    hipFuncAttributes fa;
-    BSMI_HIP(hipFuncGetAttributes(&fa, (const void*)kern));
-    if (fa.localSizeBytes != 0) BSMI_FAIL(BSMI_ERR_STATE, "fused raster-halo conv kernel was compiled with %zu bytes of scratch", (size_t)fa.localSizeBytes);
-    return BSMI_OK;
-  });
-  if (rc_once) return rc_once;
-  hipLaunchKernelGGL(kern, dim3(ceil_div(a.Q, 256)), dim3(64 * kRhNW), smem, stream, a);
-  BSMI_HIP(hipGetLastError());
-  return BSMI_OK;
-}
-
 // ---- host side ---------------------------------------------------------------------------
 int rh_halo_pieces(TileCfg cfg) {
   switch (cfg) {

@@ -1224,7 +1224,7 @@ static int run_pack_jobs(TrainState* ts, hipStream_t s, bool lazy_f32 = false, b
 // the bias image of the f32 launch.  The result lands in a split tensor -- the next convolution's source as it is -- and
 // is converted to the step's f32 output, which everything else (pooling, upsampling, the backward pass) reads.
 static int make_forward_x3(bsmi_unet* h, TrainState* ts, PlanStep& st) {
-  if (st.use_rhx || st.use_box) return BSMI_OK;  // (forms of the other precisions; an f32 raster-halo step has its gather form in st.conv too)
+  if (st.use_box) return BSMI_OK;  // (forms of the other precisions; an f32 raster-halo step has its gather form in st.conv too)
   PassSite& p = *st.site;
   const int ci = st.ci;
   const PackedConv& pf = p.packed[BSMI_PREC_F32][ci];

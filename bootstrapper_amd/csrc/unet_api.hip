@@ -497,7 +497,7 @@ struct Planner {
     // raster-halo form computes and drops cost the small-plane layers 8-17 %, and short-K layers do not amortise it
     static const int mode = [] { const char* e = getenv("BSMI_USE_RH"); return !e ? 2 : (e[0] == '1' ? 1 : 0); }();
     // split mode: never (a form that listed the K-steps per plane through the bf16 kernel lost to the fused gather kernel on every
-    // layer -- 360 -> 60 channels: 3.16 against 2.41 ms -- and was removed in round 3; the fused halo form is plan_rhx below)
+    // layer -- 360 -> 60 channels: 3.16 against 2.41 ms -- and was removed in round 3, as was its fused variant; the halo form of the split mode is plan_h16 below)
     const bool enabled = prec != BSMI_PREC_BF16X3 && (mode == 1 || (mode == 2 && tile_bn(st.tile) <= 64 && pc.entries.size() / kUnitsPerStep >= 200));
     const int* k = p.k[ci];
     const int Hin = o.H + k[1] - 1, Win = o.W + k[2] - 1;
@@ -602,100 +602,6 @@ struct Planner {
     a.relu = 1;
     st.use_rh = true;
     (void)nsl;
-    return BSMI_OK;
-  }
-
-  // Fused split-bf16 raster-halo launch (conv_rh.hip conv_rh_x3_kernel): 256 x 64 tiles whose halo fits, source tensors of
-  // whole 32-channel chunks.  BSMI_USE_RHX=1 (opt-in, parity-tested on the full-size block): it stages the activation rows
-  // once per phase instead of once per tap, but its one-barrier-per-K-step loop (24 MFMAs per wave and step) runs the
-  // 360 -> 60 channel layer in 3.04 ms against 2.44 ms for the gather kernel, so it is off by default.
-  int plan_rhx(const PassSite& p, int ci, const PackedConv& pc, const TDesc* slots, const int (*so)[3], const TDesc& o, PlanStep& st) {
-    st.use_rhx = false;
-    static const int mode = [] { const char* e = getenv("BSMI_USE_RHX"); return (e && e[0] == '1') ? 1 : 0; }();
-    const int* k = p.k[ci];
-    const int Hin = o.H + k[1] - 1, Win = o.W + k[2] - 1;
-    if (mode == 0 || prec != BSMI_PREC_BF16X3 || pc.ks != 1 || !two_waves_per_simd() || pc.Npad != 64 || !rhx_supported(st.tile, Win, k[1], k[2]))
-      return BSMI_OK;
-    const int64_t es = 2 * esize(prec);
-    const int SUB = sube(prec);
-    const size_t nsteps = pc.entries.size() / kUnitsPerStep;
-    std::vector<RhxStep> steps(nsteps);
-    std::vector<RhPhase> phases;
-    std::vector<int> first_step;
-    int pslot = -1, pc32 = -1, pz = -1, pkind = -1;
-    for (size_t s = 0; s < nsteps; ++s) {
-      const PackEntry& e0 = pc.entries[kUnitsPerStep * s];
-      const PackEntry& e1 = pc.entries[kUnitsPerStep * s + 1];
-      if (e0.dummy) {  // the all-zero K-step that makes the count even: any resident halo row will do
-        if (phases.empty() || !e1.dummy) return BSMI_OK;
-        steps[s] = RhxStep{0, (int32_t)((phases.size() - 1) & 1), -1, 0};
-        continue;
-      }
-      const TDesc& t = slots[e0.slot];
-      if (t.Cpad == SUB) return BSMI_OK;  // 16-channel tensors pair two taps per K-step: the gather kernel
-      const int c32 = e0.c0 / (kUnitsPerStep * SUB) * (kUnitsPerStep * SUB);
-      const int kind = e0.wsrc;
-      if (!e1.dummy) {
-        const bool same_tap = e1.dz == e0.dz && e1.dy == e0.dy && e1.dx == e0.dx && e1.c0 == e0.c0 + SUB && e1.slot == e0.slot;
-        if (!same_tap) return BSMI_OK;
-      }
-      if (e0.slot != pslot || c32 != pc32 || e0.dz != pz || kind != pkind) {
-        RhPhase ph;
-        ph.tensor = e0.slot;
-        const int oz = so[e0.slot][0] + e0.dz;
-        const int oy = so[e0.slot][1] + (kind ? e0.dy : 0);
-        const int ox = so[e0.slot][2] + (kind ? e0.dx : 0);
-        ph.delta = (int32_t)(((((int64_t)oz * t.H + oy) * t.W + ox) * t.Cpad + c32) * es);
-        ph.buf = (int32_t)(phases.size() & 1);
-        ph.issue_step = -1;
-        phases.push_back(ph);
-        first_step.push_back((int)s);
-        pslot = e0.slot; pc32 = c32; pz = e0.dz; pkind = kind;
-      }
-      steps[s] = RhxStep{kind ? 0 : e0.dy * Win + e0.dx, (int32_t)((phases.size() - 1) & 1), -1, 0};
-    }
-    // the halo of phase q + 1 goes out in pieces with the K-steps of phase q
-    const int np = (int)phases.size();
-    const int pieces = 2 * kRhxHaloPieces;
-    for (int q = 0; q + 1 < np; ++q) {
-      const int s0 = first_step[q], s1 = first_step[q + 1];
-      const int n = s1 - s0, per = (pieces + n - 1) / n;
-      int k0 = 0;
-      for (int s = s0; s < s1 && k0 < pieces; ++s) {
-        const int cnt = std::min(per, pieces - k0);
-        steps[s].issue = q + 1;
-        steps[s].pieces = k0 | (cnt << 8);
-        k0 += cnt;
-      }
-      // pieces that go out with the phase's last K-step land while it multiplies: the next phase's first K-step may
-      // read its fragments only after that step's barrier, not a step ahead (bit 16 of the buffer word)
-      if (steps[s1 - 1].issue == q + 1) steps[s1].buf |= 1 << 16;
-    }
-    RhxArgs& a = st.rhx;
-    memset(&a, 0, sizeof a);
-    for (int sl = 0; sl < kMaxConvTensors; ++sl) a.t[sl] = st.conv.t[sl];
-    RhxStep* dsteps = nullptr;
-    RhPhase* dphases = nullptr;
-    BSMI_HIP(hipMalloc((void**)&dsteps, steps.size() * sizeof(RhxStep)));
-    plan->allocs.push_back(dsteps);
-    BSMI_HIP(hipMalloc((void**)&dphases, phases.size() * sizeof(RhPhase)));
-    plan->allocs.push_back(dphases);
-    BSMI_HIP(hipMemcpy(dsteps, steps.data(), steps.size() * sizeof(RhxStep), hipMemcpyHostToDevice));
-    BSMI_HIP(hipMemcpy(dphases, phases.data(), phases.size() * sizeof(RhPhase), hipMemcpyHostToDevice));
-    a.steps = dsteps;
-    a.phases = dphases;
-    a.nsteps = (int)nsteps;
-    a.nphases = np;
-    a.w = pc.w;
-    a.w_lo = (const char*)pc.w + pc.lo_image_bytes;
-    a.bias = pc.bias;
-    a.out = o.ptr;
-    a.Do = o.D; a.Ho = o.H; a.Wo = o.W; a.Co = o.Cpad;
-    a.Hin = Hin; a.Win = Win;
-    a.Q = o.D * Hin * Win;
-    a.Npad = pc.Npad;
-    a.relu = 1;
-    st.use_rhx = true;
     return BSMI_OK;
   }
 
@@ -896,7 +802,7 @@ struct Planner {
     st.use_wino = false;
     const PackedWino& pw = p.wino[ci];
     const bool wants_fused = fuse_up && (ci == 0 || ci == p.nconv - 1);
-    if (prec != BSMI_PREC_BF16X3 || !pw.ready || (o.H & 1) || (o.W & 1) || st.use_box || st.use_rh || st.use_rhx) {
+    if (prec != BSMI_PREC_BF16X3 || !pw.ready || (o.H & 1) || (o.W & 1) || st.use_box || st.use_rh) {
       if (wants_fused) BSMI_FAIL(BSMI_ERR_STATE, "%s conv %d: the upsampling was fused into this stage, which cannot take the Winograd form", p.prefix.c_str(), ci);
       return BSMI_OK;
     }
@@ -1202,21 +1108,18 @@ struct Planner {
         st.out = o;
         rc = plan_rh(p, ci, pc, slots, so, nsl, o, st);
         if (rc) return rc;
-        rc = plan_rhx(p, ci, pc, slots, so, o, st);
-        if (rc) return rc;
-        if (st.use_rhx) st.use_rh = false;
         rc = plan_box(p, ci, slots, so, nsl, o, st);
         if (rc) return rc;
         rc = plan_wino(p, ci, pc, slots, so, nsl, o, st);
         if (rc) return rc;
-        if (!st.use_wino && !st.use_box && !st.use_rhx) {
+        if (!st.use_wino && !st.use_box) {
           rc = plan_h16(p, ci, pc, slots, so, o, st);
           if (rc) return rc;
         }
         if (getenv("BSMI_PLAN_DEBUG"))
           fprintf(stderr, "[bsmi plan] %s conv %d: out (%d,%d,%d)x%d tile BN=%d K-steps %d %s\n", p.prefix.c_str(), ci, o.D, o.H, o.W,
                   p.cout, tile_bn(st.tile), st.use_wino ? st.wino_gemm.nsteps : a.nsteps,
-                  st.use_wino ? "winograd F(2x2,3x3)" : st.use_h16 ? "halo-resident" : st.use_box ? "box-halo" : st.use_rhx ? "fused raster-halo" : st.use_rh ? "raster-halo" : "gather");
+                  st.use_wino ? "winograd F(2x2,3x3)" : st.use_h16 ? "halo-resident" : st.use_box ? "box-halo" : st.use_rh ? "raster-halo" : "gather");
         plan->steps.push_back(st);
       }
       cur = o;
@@ -1298,8 +1201,7 @@ struct Planner {
     if (!dry && prec == BSMI_PREC_BF16X3 && f[0] == 1 && f[1] == 2 && f[2] == 2 && rp.nslots == 2 && rp.wino[0].ready &&
         rp.wino[rp.nconv - 1].ready && !rp.wino[rp.nconv - 1].res_part[1].empty() && g_out.ptr) {
       static const bool on = [] { const char* e = getenv("BSMI_FUSE_UP"); return !(e && e[0] == '0'); }();
-      static const bool rhx = [] { const char* e = getenv("BSMI_USE_RHX"); return e && e[0] == '1'; }();
-      fuse = on && !rhx;
+      fuse = on;
       int sp[3] = {target[0], target[1], target[2]};
       for (int c = 0; c < rp.nconv && fuse; ++c) {
         for (int d = 0; d < 3; ++d) sp[d] -= rp.k[c][d] - 1;
@@ -1779,7 +1681,6 @@ int bsmi_unet_forward(bsmi_unet* h, int precision, const void* raw_dev, int raw_
         rc = (st.tx3 && h->train_forward) ? train_forward_conv_x3(h, st, s)
              : st.use_h16 ? launch_conv_h16(st.h16, st.h16_rows, s)
              : st.use_box ? launch_conv_box(st.box, s)
-             : st.use_rhx ? launch_conv_rh_x3(st.rhx, s)
              : st.use_rh ? launch_conv_rh(st.rh, precision, st.tile, s, h->sk_ws, h->sk_grid)
                          : launch_conv_igemm(st.conv, precision, st.tile, s, h->sk_ws, h->sk_grid);
         break;

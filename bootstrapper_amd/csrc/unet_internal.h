@@ -121,8 +121,6 @@ struct PlanStep {
   ConvArgs conv;
   RhArgs rh;
   bool use_rh = false;
-  RhxArgs rhx;           // fused split-bf16 raster-halo launch (use_rhx)
-  bool use_rhx = false;
   H16Args h16;           // halo-resident split-bf16 launch of a narrow stage (use_h16)
   bool use_h16 = false;
   int h16_rows = 0;      // rows of its halo buffer

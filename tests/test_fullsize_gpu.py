@@ -197,14 +197,19 @@ def test_conv_kernel_variants_in_subprocess(variant, env):
     assert r.returncode == 0, f"{variant}:\n" + r.stdout[-3000:] + r.stderr[-2000:]
 
 
-def test_fused_raster_halo_kernel_in_subprocess():
-    """The fused split-bf16 raster-halo kernel (opt-in, BSMI_USE_RHX=1) takes the 60-output-channel layers of the full net:
-    the full-size parity test again with it switched on."""
+def test_halo_resident_kernel_takes_the_narrow_stages_in_subprocess():
+    """The halo-resident kernel (conv_h16.hip) takes five of the six stages with at most 64 output channels of the full net by
+    the default rule: the full-size parity test again with the plan printed, and once more with the form switched off."""
     r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(ROOT, "tests", "test_fullsize_gpu.py"), "-x", "-q", "-s", "-k",
-                        "full_block_vs_cpu_oracle"], env=dict(os.environ, BSMI_USE_RHX="1", BSMI_PLAN_DEBUG="1"), capture_output=True, text=True,
+                        "full_block_vs_cpu_oracle"], env=dict(os.environ, BSMI_PLAN_DEBUG="1"), capture_output=True, text=True,
                        timeout=900, cwd=ROOT)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
-    assert "fused raster-halo" in r.stderr + r.stdout
+    assert (r.stderr + r.stdout).count("halo-resident") >= 5
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(ROOT, "tests", "test_fullsize_gpu.py"), "-x", "-q", "-s", "-k",
+                        "full_block_vs_cpu_oracle"], env=dict(os.environ, BSMI_PLAN_DEBUG="1", BSMI_H16="0"), capture_output=True, text=True,
+                       timeout=900, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    assert "halo-resident" not in r.stderr + r.stdout
 
 
 def test_merge_loop_general_form_in_subprocess():
