@@ -195,11 +195,16 @@ static int pack_conv(bsmi_unet* h, PassSite& p, int ci, int prec) {
 
   pc.lo_image_bytes = fused ? nelem * esize(prec) : 0;
   std::vector<uint8_t> packed(nelem * esize(prec) * (fused ? 2 : 1), 0);
-  host_parallel_for(pc.entries.size(), [&](size_t u) {   // every unit writes its own rows of the image(s)
-    const PackEntry& e = pc.entries[u];
-    if (e.dummy) return;
-    const size_t s = u / kUnitsPerStep, j = u % kUnitsPerStep;
-    for (int n = 0; n < p.cout; ++n) {
+  // one output channel per task: its weights (cin x taps floats, contiguous) are read once and stay in the core's cache, its
+  // rows of the image(s) are whole 64-byte lines of its own (unit-major, as this loop ran before, every element was a cache
+  // miss 160 KB from the last: loading the 95 M parameters of the 3d_affs net took 1.34 s of `bs predict`'s start, 0.71 s now;
+  // tools/probe_load.py)
+  host_parallel_for((size_t)p.cout, [&](size_t n_) {
+    const int n = (int)n_;
+    for (size_t u = 0; u < pc.entries.size(); ++u) {
+      const PackEntry& e = pc.entries[u];
+      if (e.dummy) continue;
+      const size_t s = u / kUnitsPerStep, j = u % kUnitsPerStep;
       for (int kk = 0; kk < SUB; ++kk) {
         const int c = e.c0 + kk;
         if (c >= e.creal) break;
@@ -430,11 +435,12 @@ static int pack_h16(bsmi_unet* h, PassSite& p, int ci) {
   const size_t nsteps = ph.entries.size() / kUnitsPerStep;
   const size_t nelem = (nsteps * (size_t)ph.Npad + kWeightRowSlack) * 32;
   std::vector<uint16_t> packed(2 * nelem, 0);
-  host_parallel_for(ph.entries.size(), [&](size_t u) {
-    const PackEntry& e = ph.entries[u];
-    if (e.dummy) return;
-    const size_t s = u / kUnitsPerStep, j = u % kUnitsPerStep;
-    for (int n = 0; n < p.cout; ++n)
+  host_parallel_for((size_t)p.cout, [&](size_t n_) {   // one output channel per task (pack_conv)
+    const int n = (int)n_;
+    for (size_t u = 0; u < ph.entries.size(); ++u) {
+      const PackEntry& e = ph.entries[u];
+      if (e.dummy) continue;
+      const size_t s = u / kUnitsPerStep, j = u % kUnitsPerStep;
       for (int kk = 0; kk < 16; ++kk) {
         const int c = e.c0 + kk;
         if (c >= e.creal) break;
@@ -444,6 +450,7 @@ static int pack_h16(bsmi_unet* h, PassSite& p, int ci) {
         packed[idx] = hi;
         packed[nelem + idx] = host_f32_to_bf16(v - host_bf16_to_f32(hi));
       }
+    }
   });
   ph.lo_image_bytes = nelem * 2;
   BSMI_HIP(hipMalloc(&ph.w, packed.size() * 2));

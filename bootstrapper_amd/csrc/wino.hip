@@ -409,11 +409,12 @@ void wino_pack_weights(const float* w, int cout, int cin, const std::vector<int>
   image_elems = kWinoBatch * batch_elems + (size_t)kWeightRowSlack * 32;
   packed.assign(2 * image_elems, 0);
   static const double G[4][3] = {{1, 0, 0}, {.5, .5, .5}, {.5, -.5, .5}, {0, 0, 1}};
-  host_parallel_for(units.size(), [&](size_t u) {   // every unit writes its own rows of the images
-    const WinoUnit& un = units[u];
-    if (un.dummy) return;
-    const size_t s = u / kUnitsPerStep, j = u % kUnitsPerStep;
-    for (int n = 0; n < cout; ++n)
+  host_parallel_for((size_t)cout, [&](size_t n_) {   // one output channel per task: its weights read once, its image rows its own lines
+    const int n = (int)n_;
+    for (size_t u = 0; u < units.size(); ++u) {
+      const WinoUnit& un = units[u];
+      if (un.dummy) continue;
+      const size_t s = u / kUnitsPerStep, j = u % kUnitsPerStep;
       for (int kk = 0; kk < 16; ++kk) {
         const int c = cin_of_v[un.vc0 + kk];
         if (c < 0) continue;
@@ -430,6 +431,7 @@ void wino_pack_weights(const float* w, int cout, int cin, const std::vector<int>
             packed[image_elems + idx] = host_bf16(v - host_bf16_f32(hi));
           }
       }
+    }
   });
 }
 

@@ -161,6 +161,7 @@ class _LayerWriter:
         self.dev, self.step = dev, max(1, int(step))
         self.pool = cf.ThreadPoolExecutor(max_workers=IO_WORKERS, thread_name_prefix="bsmi-write")
         self.streams = {}
+        self.pinned = {}   # thread -> page-locked staging buffer (a pageable destination makes the runtime stage the copy itself)
         self.futures = []
         self.torch = torch
 
@@ -168,9 +169,15 @@ class _LayerWriter:
         import threading
         torch = self.torch
         ready.synchronize()   # host-side wait (a stream parked behind a device-side wait costs the running kernels)
-        st = self.streams.setdefault(threading.get_ident(), torch.cuda.Stream(self.dev))
+        tid = threading.get_ident()
+        st = self.streams.setdefault(tid, torch.cuda.Stream(self.dev))
+        part = src[za:zb]
+        buf = self.pinned.get(tid)
+        if buf is None or buf.numel() < part.numel() or buf.dtype != part.dtype:
+            buf = self.pinned[tid] = torch.empty(part.numel(), dtype=part.dtype, pin_memory=True)
+        host = buf[:part.numel()].view(part.shape)
         with torch.cuda.stream(st):
-            host = src[za:zb].to("cpu", non_blocking=True)
+            host.copy_(part, non_blocking=True)
             done = torch.cuda.Event()
             done.record(st)
         done.synchronize()
