@@ -12,6 +12,7 @@
 // loop follows): pop by the STORED score, a stale edge is re-scored and pushed back, on a merge the dearer of two edges to a
 // shared neighbour is folded into the cheaper one, every edge at the survivor becomes stale; ties by the edge's initial key.
 // Score of an edge: pivot = Q * total / 100 + 1 (1-based), the first bin whose running count reaches it, 1 - (bin + 0.5) / 256.
+#include <algorithm>
 #include <cstddef>
 #include <cstdint>
 #include <queue>
@@ -145,5 +146,185 @@ extern "C" int bsmi_agglomerate_hist_graph(uint32_t n_nodes, uint32_t n_edges, c
   for (int t = 1; t < n_thresholds; ++t)
     if (thresholds[t] < thresholds[t - 1]) return BSMI_ERR_INVALID;
   bsmi::host_agglomerate_hist(n_nodes, n_edges, edge_u, edge_v, hist, quantile, init_with_max, thresholds, n_thresholds, roots_out);
+  return BSMI_OK;
+}
+
+// ---- blockwise RAG scoring on the host -------------------------------------------------------------------------------
+// post/blockwise/waterz_agglom.py:106-170 scores the edges of a block's region graph by agglomerating it to the end
+// (waterz, OneMinus<MeanAffinity>, discretize_queue bins) and reading every edge's score off the merge tree.  The device
+// builds the graph (seg.hip: rag_ids / agg_edges / rag_compact kernels -- the pass over the 160^3 read box); the merge
+// loop is a sequential queue algorithm over a few thousand edges, which one wave replays in 12 ms per block (seg.hip:
+// rag_merge_kernel, kept: bsmi_rag_merge_scores_u8) and a host core in a fraction of a millisecond.  The block pipeline
+// (volume.SlabSegmenter) needs the scores on the host anyway -- the global connected components run there -- so it exports
+// the graphs (bsmi_rag_graph_u8) and calls this for all blocks of a slab at once, blocks side by side on host threads.
+//
+// Algorithm: exactly rag_merge_body / agg_contract / rag_scores_kernel of seg.hip (which are bit-exact to oracle/seg_ref.c):
+// scores 1 - sum / (255 cnt) in double, rounded to float; bin queue of `nbins` FIFO bins, bin = (int)(score * (nbins - 1));
+// initial pushes in edge order; a popped edge whose endpoint merged after its last scoring is re-scored and re-queued; a
+// merge absorbs the larger rank into the smaller, folds the dearer (by STORED score) of two parallel edges into the cheaper;
+// tree node nn + m for merge m; an edge's score is that of the lowest common ancestor of its two fragments (NaN: none).
+#include <atomic>
+#include <cmath>
+#include <thread>
+
+namespace bsmi {
+
+namespace {
+
+constexpr uint32_t kNoEdge = 0xffffffffu;
+
+void rag_merge_scores_one(uint64_t ne, const uint64_t* edges, const uint64_t* sums, const uint32_t* cnts, float threshold, int nbins,
+                          float* scores) {
+  if (!ne) return;
+  // fragment ids -> ranks (ascending with the ids, as the device's): only their order matters
+  std::vector<uint64_t> ids(2 * ne);
+  for (uint64_t i = 0; i < 2 * ne; ++i) ids[i] = edges[i];
+  std::sort(ids.begin(), ids.end());
+  ids.erase(std::unique(ids.begin(), ids.end()), ids.end());
+  const uint32_t nn = (uint32_t)ids.size();
+  auto rank_of = [&](uint64_t id) { return (uint32_t)(std::lower_bound(ids.begin(), ids.end(), id) - ids.begin()); };
+  std::vector<uint32_t> eu(ne), ev(ne), x0(ne), y0(ne), cnt(ne), etime(ne, 0), qnext(ne, kNoEdge);
+  std::vector<uint64_t> sum(ne);
+  std::vector<float> score(ne);
+  std::vector<uint8_t> dead(ne, 0);
+  std::vector<std::vector<uint32_t>> inc(nn);
+  std::unordered_map<uint64_t, uint32_t> by_key;
+  by_key.reserve(2 * ne);
+  auto key_of = [](uint32_t a, uint32_t b) { return a < b ? ((uint64_t)a << 32) | b : ((uint64_t)b << 32) | a; };
+  auto edge_score = [](uint64_t s, uint32_t c) { return 1.0f - (float)((double)s / (255.0 * (double)c)); };
+  for (uint32_t e = 0; e < ne; ++e) {
+    const uint32_t a = rank_of(edges[2 * (size_t)e]), b = rank_of(edges[2 * (size_t)e + 1]);
+    eu[e] = x0[e] = a;
+    ev[e] = y0[e] = b;
+    sum[e] = sums[e];
+    cnt[e] = cnts[e];
+    score[e] = edge_score(sum[e], cnt[e]);
+    inc[a].push_back(e);
+    inc[b].push_back(e);
+    by_key[key_of(a, b)] = e;
+  }
+  std::vector<uint32_t> bhead(nbins, kNoEdge), btail(nbins, kNoEdge);
+  int minbin = nbins;
+  const float scale = (float)(nbins - 1);
+  auto push = [&](uint32_t e, float sc) {
+    int b = (int)(sc * scale);
+    b = b < 0 ? 0 : (b > nbins - 1 ? nbins - 1 : b);
+    qnext[e] = kNoEdge;
+    if (bhead[b] == kNoEdge) bhead[b] = e; else qnext[btail[b]] = e;
+    btail[b] = e;
+    if (b < minbin) minbin = b;
+  };
+  for (uint32_t e = 0; e < ne; ++e)
+    if (score[e] < threshold) push(e, score[e]);
+  std::vector<uint32_t> ntime(nn, 0), cur(nn), tnext((size_t)nn + nn, kNoEdge);
+  std::vector<float> tscore((size_t)nn + nn, 0.f);
+  for (uint32_t i = 0; i < nn; ++i) cur[i] = i;
+  uint32_t nm = 0, clock = 0;
+  for (;;) {
+    uint32_t pick = kNoEdge;
+    for (;;) {
+      while (minbin < nbins && bhead[minbin] == kNoEdge) ++minbin;
+      if (minbin >= nbins) break;
+      const uint32_t e = bhead[minbin];
+      bhead[minbin] = qnext[e];
+      if (dead[e]) continue;
+      const uint32_t tu = ntime[eu[e]], tv = ntime[ev[e]];
+      if (etime[e] < (tu > tv ? tu : tv)) {
+        const float sc = edge_score(sum[e], cnt[e]);
+        score[e] = sc;
+        etime[e] = clock;
+        if (sc < threshold) push(e, sc);
+        continue;
+      }
+      pick = e;
+      break;
+    }
+    if (pick == kNoEdge) break;
+    const uint32_t e = pick;
+    const uint32_t a = eu[e] < ev[e] ? eu[e] : ev[e], b = eu[e] < ev[e] ? ev[e] : eu[e];
+    for (const uint32_t f : inc[b]) {
+      if (f == e || dead[f]) continue;
+      const uint32_t fu = eu[f], fv = ev[f];
+      if (fu != b && fv != b) continue;  // (cannot happen: an edge leaves a node's list only with the node)
+      const uint32_t nb = fu == b ? fv : fu;
+      by_key.erase(key_of(fu, fv));
+      const uint64_t gkey = key_of(a, nb);
+      auto it = by_key.find(gkey);
+      bool move_f = true;
+      if (it != by_key.end()) {
+        const uint32_t g = it->second;
+        if (score[f] > score[g]) {
+          sum[g] += sum[f];
+          cnt[g] += cnt[f];
+          dead[f] = 1;
+          move_f = false;
+        } else {
+          sum[f] += sum[g];
+          cnt[f] += cnt[g];
+          dead[g] = 1;
+          it->second = f;
+        }
+      }
+      if (move_f) {
+        if (fu == b) eu[f] = a; else ev[f] = a;
+        inc[a].push_back(f);
+        if (it == by_key.end()) by_key[gkey] = f;
+      }
+    }
+    by_key.erase(key_of(eu[e], ev[e]));
+    dead[e] = 1;
+    inc[b].clear();
+    inc[b].shrink_to_fit();
+    ntime[a] = ++clock;
+    const uint32_t t = nn + nm;
+    tnext[cur[a]] = t;
+    tnext[cur[b]] = t;
+    cur[a] = t;
+    tnext[t] = kNoEdge;
+    tscore[t] = score[e];
+    ++nm;
+  }
+  for (uint32_t e = 0; e < ne; ++e) {
+    uint32_t x = x0[e], y = y0[e];
+    float sc = std::nanf("");
+    for (;;) {
+      if (x == y) { sc = tscore[x]; break; }
+      if (x < y) { const uint32_t nx = tnext[x]; if (nx == kNoEdge) break; x = nx; }
+      else { const uint32_t ny = tnext[y]; if (ny == kNoEdge) break; y = ny; }
+    }
+    scores[e] = sc;
+  }
+}
+
+}  // namespace
+
+}  // namespace bsmi
+
+extern "C" int bsmi_rag_merge_scores_host(int n_graphs, const uint64_t* n_edges, const uint64_t* const* edges, const uint64_t* const* sums,
+                                          const uint32_t* const* counts, float threshold, int discretize_queue, float* const* scores,
+                                          int n_threads) {
+  if (n_graphs < 0 || (n_graphs && (!n_edges || !edges || !sums || !counts || !scores)) || discretize_queue < 1 || discretize_queue > 1024 ||
+      !(threshold > 0.f))
+    return BSMI_ERR_INVALID;
+  for (int g = 0; g < n_graphs; ++g) {
+    if (n_edges[g] >= 0xffffffffull) return BSMI_ERR_INVALID;
+    if (n_edges[g] && (!edges[g] || !sums[g] || !counts[g] || !scores[g])) return BSMI_ERR_INVALID;
+    for (uint64_t e = 0; e < n_edges[g]; ++e)
+      if (!counts[g][e] || edges[g][2 * e] == edges[g][2 * e + 1]) return BSMI_ERR_INVALID;
+  }
+  std::atomic<int> next{0};
+  auto work = [&] {
+    for (int g = next.fetch_add(1); g < n_graphs; g = next.fetch_add(1))
+      bsmi::rag_merge_scores_one(n_edges[g], edges[g], sums[g], counts[g], threshold, discretize_queue, scores[g]);
+  };
+  const int hw = (int)std::max(1u, std::thread::hardware_concurrency());
+  const int nt = std::max(1, std::min(std::min(n_threads > 0 ? n_threads : 16, hw), n_graphs));
+  if (nt <= 1) {
+    work();
+  } else {
+    std::vector<std::thread> th;
+    for (int t = 0; t < nt; ++t) th.emplace_back(work);
+    for (auto& x : th) x.join();
+  }
   return BSMI_OK;
 }

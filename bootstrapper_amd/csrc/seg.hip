@@ -1436,6 +1436,31 @@ __global__ void rag_scores_kernel(AggWs w, uint64_t* __restrict__ edges, float* 
     }
 }
 
+// the region graph as it stands after rag_compact_kernel, for a merge loop elsewhere (agglo_host.cpp: bsmi_rag_merge_scores_host):
+// edge e in the order of its (rank, rank) key = ascending (id, id); affinity sum and voxel-pair count of its faces
+__global__ void rag_graph_out_kernel(AggWs w, uint64_t* __restrict__ edges, uint64_t* __restrict__ sums, uint32_t* __restrict__ cnts,
+                                     uint64_t cap, uint64_t* __restrict__ counts) {
+  keep_overflow(w);
+  if (w.counters[3]) return;
+  const uint32_t nn = w.counters[0];
+  const uint32_t ne = min(w.counters[1], w.edge_cap);
+  if (blockIdx.x == 0 && threadIdx.x == 0) { counts[0] = ne; counts[1] = 0; counts[2] = nn; }
+  if (ne > cap) {  // the caller's buffers are too small: say so, and how many entries the block needs (counts[0] > capacity)
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+      atomicOr(&w.counters[3], 32u);
+      atomicOr(w.sticky, 32u);
+    }
+    return;
+  }
+  for (uint32_t e = blockIdx.x * blockDim.x + threadIdx.x; e < ne; e += gridDim.x * blockDim.x) {
+    const uint64_t key = w.ekey0[e];
+    edges[2 * (size_t)e] = w.ids[(uint32_t)(key >> 32)];
+    edges[2 * (size_t)e + 1] = w.ids[(uint32_t)key];
+    sums[e] = w.esum[e];
+    cnts[e] = w.ecnt[e];
+  }
+}
+
 // fragments -> ids of their merged clusters after rag_merge_kernel, in place (a cluster is named by its smallest id: the
 // survivor of every merge is the smaller rank, and ranks ascend with the ids)
 __global__ void rag_relabel_kernel(uint64_t* __restrict__ frags, size_t n, AggWs w) {
@@ -2474,7 +2499,7 @@ int bsmi_label_stats(bsmi_seg* h, const uint64_t* labels_dev, const int64_t shap
 
 // ids -> ranks, region graph, bin-queue merge loop up to `threshold` (the common front of the two RAG entry points)
 static int rag_build_and_merge(bsmi_seg* h, const uint8_t* affs_dev, const uint64_t* frags_dev, const int64_t shape[3], float threshold,
-                               int discretize_queue, uint64_t* counts_dev, hipStream_t s) {
+                               int discretize_queue, uint64_t* counts_dev, hipStream_t s, bool merge = true) {
   BSMI_HIP(hipSetDevice(h->device));
   const size_t n = (size_t)shape[0] * shape[1] * shape[2];
   const int D = (int)shape[0], H = (int)shape[1], W = (int)shape[2];
@@ -2498,7 +2523,20 @@ static int rag_build_and_merge(bsmi_seg* h, const uint8_t* affs_dev, const uint6
   BSMI_HIP(hipcub::DeviceRadixSort::SortPairs(h->sort_tmp, tb, (const uint64_t*)g.hkeys, g.skeys, (const uint32_t*)g.iota, g.sslot,
                                               (int)g.hcap, 0, 64, s));
   hipLaunchKernelGGL(rag_compact_kernel, dim3(std::min<uint32_t>(g.hcap / bs, 2048u)), dim3(bs), 0, s, g);
-  hipLaunchKernelGGL(rag_merge_kernel, dim3(8), dim3(64), 0, s, g, threshold, discretize_queue, agg_fast_enabled() ? 1 : 0);
+  if (merge) hipLaunchKernelGGL(rag_merge_kernel, dim3(8), dim3(64), 0, s, g, threshold, discretize_queue, agg_fast_enabled() ? 1 : 0);
+  return BSMI_OK;
+}
+
+int bsmi_rag_graph_u8(bsmi_seg* h, const uint8_t* affs_dev, const uint64_t* frags_dev, const int64_t shape[3], uint64_t* edges_dev,
+                      uint64_t* sums_dev, uint32_t* pair_counts_dev, uint64_t edge_capacity, uint64_t* counts_dev, void* stream) {
+  int rc = check_seg_shape(h, shape);
+  if (rc) return rc;
+  if (!affs_dev || !frags_dev || !edges_dev || !sums_dev || !pair_counts_dev || !counts_dev) BSMI_FAIL(BSMI_ERR_INVALID, "null argument");
+  hipStream_t s = (hipStream_t)stream;
+  rc = rag_build_and_merge(h, affs_dev, frags_dev, shape, 1.f, 1, counts_dev, s, /*merge=*/false);
+  if (rc) return rc;
+  hipLaunchKernelGGL(rag_graph_out_kernel, dim3(256), dim3(256), 0, s, h->agg, edges_dev, sums_dev, pair_counts_dev, edge_capacity, counts_dev);
+  BSMI_HIP(hipGetLastError());
   return BSMI_OK;
 }
 

@@ -186,6 +186,22 @@ class SegEngine:
                                            C.c_void_p(merge_scores.data_ptr()) if merge_scores is not None else None,
                                            C.c_void_p(counts.data_ptr()), self._stream()))
 
+    def rag_graph_async(self, affs_u8, frags, edges, sums, pair_counts, counts):
+        """The block's region graph without the merge loop, into caller-owned CUDA buffers, asynchronous on the current stream:
+        edges int64 [cap][2] (id pairs, ascending), sums int64 [cap], pair_counts int32 [cap], counts int64 [>= 3] (edges, 0,
+        nodes); status() reports a too small buffer.  `rag_merge_scores_host` scores such graphs on the host."""
+        if affs_u8.dtype != torch.uint8 or not affs_u8.is_cuda or affs_u8.dim() != 4 or affs_u8.shape[0] != 3 or not affs_u8.is_contiguous():
+            raise ValueError("affs must be a contiguous uint8 CUDA tensor of shape (3, D, H, W)")
+        if frags.dtype != torch.int64 or tuple(frags.shape) != tuple(affs_u8.shape[1:]) or not frags.is_contiguous():
+            raise ValueError("fragments must be a contiguous int64 tensor of shape (D, H, W)")
+        if (edges.dtype != torch.int64 or sums.dtype != torch.int64 or pair_counts.dtype != torch.int32 or counts.dtype != torch.int64
+                or not (edges.is_contiguous() and sums.is_contiguous() and pair_counts.is_contiguous() and counts.is_contiguous())
+                or not edges.shape[0] == sums.shape[0] == pair_counts.shape[0]):
+            raise ValueError("edges int64 [cap][2], sums int64 [cap], pair_counts int32 [cap], counts int64: contiguous, one capacity")
+        check(lib.bsmi_rag_graph_u8(self._h, C.c_void_p(affs_u8.data_ptr()), C.c_void_p(frags.data_ptr()), _lib.i64x3(frags.shape),
+                                    C.c_void_p(edges.data_ptr()), C.c_void_p(sums.data_ptr()), C.c_void_p(pair_counts.data_ptr()),
+                                    int(edges.shape[0]), C.c_void_p(counts.data_ptr()), self._stream()))
+
     def cc_affs(self, affs_u8, threshold=0.5, remove_debris=0):
         """Thresholded-affinity connected components (reference post/cc.py; post/connected_components.py:77-101).
         -> (fragments int64, segmentation int64 (debris removed), count int64[1]); asynchronous."""
@@ -222,6 +238,25 @@ class SegEngine:
 
     def status(self):
         check(lib.bsmi_seg_status(self._h, self._stream()))
+
+
+def rag_merge_scores_host(n_edges, edges, sums, pair_counts, threshold=1.0, discretize_queue=256, threads=0):
+    """waterz_agglom.py:106-170 for many blocks at once on host threads (csrc/agglo_host.cpp): graphs as SegEngine.rag_graph_async
+    exports them, copied to the host -- edges uint64 / int64 [G][cap][2], sums [G][cap], pair_counts uint32 / int32 [G][cap]
+    (numpy, C-contiguous), n_edges [G].  -> scores float32 [G][cap] (entries past n_edges[g] untouched: NaN)."""
+    import numpy as np
+    ne = np.ascontiguousarray(n_edges, dtype=np.uint64)
+    G = int(ne.shape[0])
+    e = np.ascontiguousarray(edges).view(np.uint64)
+    s = np.ascontiguousarray(sums).view(np.uint64)
+    c = np.ascontiguousarray(pair_counts).view(np.uint32)
+    if e.shape[:1] != (G,) or e.ndim != 3 or e.shape[2] != 2 or s.shape != e.shape[:2] or c.shape != e.shape[:2] or int(ne.max(initial=0)) > e.shape[1]:
+        raise ValueError("edges [G][cap][2], sums [G][cap], pair_counts [G][cap], n_edges [G] <= cap")
+    scores = np.full(e.shape[:2], np.nan, dtype=np.float32)
+    ptrs = lambda a, stride: (C.c_void_p * G)(*[a.ctypes.data + g * stride for g in range(G)])
+    check(lib.bsmi_rag_merge_scores_host(G, ne.ctypes.data_as(C.c_void_p), ptrs(e, e.strides[0]), ptrs(s, s.strides[0]), ptrs(c, c.strides[0]),
+                                         float(threshold), int(discretize_queue), ptrs(scores, scores.strides[0]), int(threads)))
+    return scores
 
 
 def lut_relabel(labels, keys, vals, out=None):

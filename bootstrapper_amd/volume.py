@@ -157,12 +157,16 @@ class SlabSegmenter:
                  fragments_in_xy=True, min_seed_distance=10, filter_fragments=0.0, remove_debris=0, discretize_queue=256,
                  n_lanes=8, device=0, rank=0, world=1, group=None, edge_cap=1 << 17, label_cap=1 << 16, exchange_affs=True,
                  epsilon_agglomerate=0.0, sigma=None, noise_eps=None, bias=None, noise_seed=0, seed_eps=None,
-                 grid=None, total_rows=None, row0=0, obj_group=None):
+                 grid=None, total_rows=None, row0=0, obj_group=None, host_scores=True):
         """slab_shape: this rank's box of the volume (whole blocks but for the volume's far faces).  The ranks form a grid
         `grid` = (Rz, Ry) over z and y (default: (world, 1), slabs of block layers), rank = rz * Ry + ry; the volume has
         `total_layers` block layers and `total_rows` block rows, this rank's first ones are `layer0`, `row0`.
         obj_group: process group of the object collectives (edges to rank 0, LUT back); under an RCCL default group a gloo
-        group beside it, so that pickled objects do not travel through device tensors."""
+        group beside it, so that pickled objects do not travel through device tensors.
+        host_scores: the merge loop of a block's edge scoring runs on host threads for all blocks at once (`_collect`; the lanes
+        only build the region graphs) instead of as one wave per block on the lanes: the scores are needed on the host anyway,
+        and a host core replays that loop in a fraction of the 12 ms a wave takes."""
+        self.host_scores = bool(host_scores)
         self.shape = tuple(int(s) for s in slab_shape)
         self.block = tuple(int(b) for b in block)
         self.ctx = tuple(int(c) for c in context)
@@ -217,7 +221,8 @@ class SlabSegmenter:
         self.sizes = torch.zeros((K, self.label_cap), dtype=torch.int64, device=self.dev)
         self.sums = torch.zeros((K, self.label_cap, 3), dtype=torch.int64, device=self.dev)
         self.edges = torch.empty((K, self.edge_cap, 2), dtype=torch.int64, device=self.dev)
-        self.scores = torch.empty((K, self.edge_cap), dtype=torch.float32, device=self.dev)
+        self.scores = torch.empty((K, self.edge_cap), dtype=torch.float32, device=self.dev)   # host_scores: the edges' voxel-pair counts (int32 view)
+        self.esums = torch.empty((K, self.edge_cap), dtype=torch.int64, device=self.dev) if self.host_scores else None
         self.counts_dev = torch.zeros((K, 4), dtype=torch.int64, device=self.dev)
         self.frag_done = [None] * K
         read = tuple(min(b, s) + 2 * c for b, s, c in zip(self.block, self.shape, self.ctx))
@@ -241,7 +246,7 @@ class SlabSegmenter:
         """device bytes of a slab (module docstring), the lanes' workspaces not included"""
         vox = int(np.prod(shape))
         padded = int(np.prod([s + 2 * c for s, c in zip(shape, ctx)]))
-        return 11 * padded + 8 * vox * (1 + n_thresholds) + n_blocks * (32 * label_cap + 20 * edge_cap + 40)
+        return 11 * padded + 8 * vox * (1 + n_thresholds) + n_blocks * (32 * label_cap + 28 * edge_cap + 40)
 
     # -- views ---------------------------------------------------------------------------
     def interior(self, t):
@@ -381,7 +386,10 @@ class SlabSegmenter:
             a.copy_(self.affs[(slice(None),) + self._read_slices(k)])
             f = self._buf(lane["f"], rshape)
             f.copy_(self.frags[self._read_slices(k)])
-            lane["engine"].rag_merge_scores_async(a, f, 1.0, self.bins, self.edges[k], self.scores[k], self.counts_dev[k])
+            if self.host_scores:   # the graph only: `_collect` scores all blocks' graphs on host threads
+                lane["engine"].rag_graph_async(a, f, self.edges[k], self.esums[k], self.scores[k].view(torch.int32), self.counts_dev[k])
+            else:
+                lane["engine"].rag_merge_scores_async(a, f, 1.0, self.bins, self.edges[k], self.scores[k], self.counts_dev[k])
 
     def _collect(self):
         """end of the two block stages: one synchronisation, overflow checks, the edges every block owns (the block that
@@ -398,6 +406,21 @@ class SlabSegmenter:
         if err is not None:
             raise err
         self.block_nums = nums
+        if self.host_scores:
+            from .post.engine import rag_merge_scores_host
+            m = int(n_edges.max(initial=0))
+            if m == 0:
+                self.rag_edges, self.rag_scores = np.zeros((0, 2), np.uint64), np.zeros(0, np.float32)
+                return 0
+            E = self.edges[:, :m].cpu().numpy().view(np.uint64)
+            S = self.esums[:, :m].cpu().numpy()
+            C = self.scores.view(torch.int32)[:, :m].cpu().numpy()
+            sc = rag_merge_scores_host(n_edges, E, S, C, 1.0, self.bins)
+            take = np.arange(m)[None, :] < n_edges[:, None]
+            own = take & ((E[:, :, 0].astype(np.int64) - 1) // self.nvb == np.asarray(self.block_ids, np.int64)[:, None])
+            self.rag_edges = np.ascontiguousarray(E[own])
+            self.rag_scores = np.ascontiguousarray(sc[own])
+            return len(self.rag_scores)
         ne = self.counts_dev[:, 0]
         take = torch.arange(self.edge_cap, device=self.dev)[None, :] < ne[:, None]
         bid = torch.tensor(self.block_ids, dtype=torch.int64, device=self.dev)[:, None].expand(-1, self.edge_cap)
@@ -430,6 +453,10 @@ class SlabSegmenter:
             edges[:, :old].copy_(self.edges)
             scores[:, :old].copy_(self.scores)
             self.edges, self.scores = edges, scores
+            if self.host_scores:
+                esums = torch.empty((K, self.edge_cap), dtype=torch.int64, device=self.dev)
+                esums[:, :old].copy_(self.esums)
+                self.esums = esums
             for k in np.nonzero(n_edges > old)[0]:
                 self._launch_scores(int(k))
         return self._sync()

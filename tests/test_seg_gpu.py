@@ -312,6 +312,53 @@ def test_rag_merge_scores_bit_exact_vs_oracle(shape, sigma, msd, bins, id_base):
     assert np.array_equal(s.cpu().numpy().view(np.uint32), s_ref.view(np.uint32))     # NaNs included
 
 
+@pytest.mark.parametrize("shape,sigma,msd,bins,thr", [((12, 96, 96), (1, 3, 3), 5, 256, 1.0), ((4, 160, 160), (1, 5, 5), 10, 256, 1.0),
+                                                      ((6, 80, 80), (1, 3, 3), 5, 256, 0.45), ((8, 64, 72), (1, 2, 2), 3, 16, 1.0)])
+def test_rag_scores_on_the_host_equal_the_device_loop_and_the_oracle(shape, sigma, msd, bins, thr):
+    """The block pipeline's edge scoring: the device exports the region graph (bsmi_rag_graph_u8), the merge loop and the
+    merge-tree look-ups run on host threads (bsmi_rag_merge_scores_host) -- the same edges and bit for bit the same scores as the
+    device loop (bsmi_rag_merge_scores_u8) and the oracle, several graphs in one call."""
+    from bootstrapper_amd.post.engine import SegEngine, rag_merge_scores_host
+    from oracle import seg_ref as S
+    rng = np.random.default_rng(shape[1] + bins)
+    graphs, refs = [], []
+    eng = SegEngine(shape)
+    for g in range(3):
+        affs = _blobby(rng, shape, sigma)
+        frags, _ = S.ws_fragments_u8(affs, True, msd)
+        big = frags > np.median(frags[frags > 0])
+        frags = np.where(frags > 0, frags + np.uint64(1000 * g) + np.where(big, np.uint64(2_097_152), np.uint64(0)), np.uint64(0))
+        e_ref, s_ref, _, _ = S.rag_merge_scores_u8(affs, frags, thr, bins)
+        a, f = torch.from_numpy(affs).cuda(), torch.from_numpy(frags.view(np.int64)).cuda()
+        e_dev, s_dev = eng.rag_merge_scores(a, f, thr, bins)
+        assert np.array_equal(_as_u64(e_dev), e_ref) and np.array_equal(s_dev.cpu().numpy().view(np.uint32), s_ref.view(np.uint32))
+        cap = len(e_ref) + 7
+        edges = torch.zeros((cap, 2), dtype=torch.int64, device="cuda")
+        sums = torch.zeros(cap, dtype=torch.int64, device="cuda")
+        cnts = torch.zeros(cap, dtype=torch.int32, device="cuda")
+        counts = torch.zeros(4, dtype=torch.int64, device="cuda")
+        eng.rag_graph_async(a, f, edges, sums, cnts, counts)
+        eng.status()
+        assert int(counts[0]) == len(e_ref)
+        graphs.append((edges.cpu().numpy(), sums.cpu().numpy(), cnts.cpu().numpy()))
+        refs.append((e_ref, s_ref))
+    cap = max(len(g[0]) for g in graphs)
+    E = np.zeros((3, cap, 2), np.int64); Sm = np.zeros((3, cap), np.int64); Cn = np.zeros((3, cap), np.int32)
+    for g, (e, s, c) in enumerate(graphs):
+        E[g, :len(e)], Sm[g, :len(s)], Cn[g, :len(c)] = e, s, c
+    ne = np.array([len(r[0]) for r in refs])
+    sc = rag_merge_scores_host(ne, E, Sm, Cn, thr, bins, threads=2)
+    for g, (e_ref, s_ref) in enumerate(refs):
+        assert np.array_equal(E[g, :ne[g]].view(np.uint64), e_ref)
+        assert np.array_equal(sc[g, :ne[g]].view(np.uint32), s_ref.view(np.uint32))     # NaNs included
+    # a too small buffer is reported with the count the block needs, as by the device loop's call
+    small = torch.zeros((4, 2), dtype=torch.int64, device="cuda")
+    eng.rag_graph_async(a, f, small, torch.zeros(4, dtype=torch.int64, device="cuda"), torch.zeros(4, dtype=torch.int32, device="cuda"), counts)
+    with pytest.raises(Exception):
+        eng.status()
+    assert int(counts[0]) == ne[2]
+
+
 def test_rag_merge_scores_threshold_leaves_unmerged_edges():
     from bootstrapper_amd.post.engine import SegEngine
     from oracle import seg_ref as S
