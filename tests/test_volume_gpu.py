@@ -25,17 +25,20 @@ def blobby_affs(shape, seed, empty_corner=True):
     return affs
 
 
-@pytest.mark.parametrize("shape,block,ctx,lanes,overlap", [((20, 150, 130), (8, 64, 64), (1, 8, 8), 5, False),
-                                                          ((24, 96, 96), (8, 32, 32), (2, 4, 4), 16, False),
-                                                          ((24, 96, 96), (8, 32, 32), (2, 4, 4), 3, True)])
-def test_slab_segmenter_equals_cpu_blockwise(shape, block, ctx, lanes, overlap):
+@pytest.mark.parametrize("shape,block,ctx,lanes,overlap,host_scores", [((20, 150, 130), (8, 64, 64), (1, 8, 8), 5, False, True),
+                                                                      ((24, 96, 96), (8, 32, 32), (2, 4, 4), 16, False, True),
+                                                                      ((24, 96, 96), (8, 32, 32), (2, 4, 4), 3, True, True),
+                                                                      ((20, 150, 130), (8, 64, 64), (1, 8, 8), 5, False, False),
+                                                                      ((24, 96, 96), (8, 32, 32), (2, 4, 4), 3, True, False)])
+def test_slab_segmenter_equals_cpu_blockwise(shape, block, ctx, lanes, overlap, host_scores):
+    """host_scores: the edge scoring's merge loop on host threads (the default) or as one wave per block on the lanes"""
     from bootstrapper_amd.volume import SlabSegmenter
     from oracle.blockwise_ref import cpu_blockwise
     affs = blobby_affs(shape, 21)
     thr = [0.3, 0.45]
     frags_ref, nodes, E, Sc, segs_ref = cpu_blockwise(affs, block, ctx, 4, 0.35, 12, thr)
     layers = -(-shape[0] // block[0])
-    seg = SlabSegmenter(shape, block, ctx, layers, 0, thr, True, 4, 0.35, 12, 256, n_lanes=lanes)
+    seg = SlabSegmenter(shape, block, ctx, layers, 0, thr, True, 4, 0.35, 12, 256, n_lanes=lanes, host_scores=host_scores)
     seg.interior(seg.affs).copy_(torch.from_numpy(affs).cuda())
     segs = seg.run(overlap=overlap)
     assert np.array_equal(seg.interior(seg.frags).cpu().numpy().view(np.uint64), frags_ref)
