@@ -59,6 +59,35 @@ def test_slab_segmenter_equals_cpu_blockwise(shape, block, ctx, lanes, overlap, 
     assert size[k] == int(m.sum()) and np.allclose(pos[k], np.argwhere(m).mean(axis=0))
 
 
+@pytest.mark.parametrize("host_scores", [True, False])
+def test_block_tables_grow_on_demand(host_scores):
+    """The per-block tables are sized for typical blocks (label_cap fragments, edge_cap edges); a block that needs more makes
+    `_collect` grow them to what was measured and redo that block's statistics / edge scoring (the reference has no such limit):
+    caps far too small for every block, the same result as the CPU composition."""
+    from bootstrapper_amd.volume import SlabSegmenter
+    from oracle.blockwise_ref import cpu_blockwise
+    shape, block, ctx, thr = (20, 150, 130), (8, 64, 64), (1, 8, 8), [0.3, 0.45]
+    affs = blobby_affs(shape, 21)
+    frags_ref, nodes, E, Sc, segs_ref = cpu_blockwise(affs, block, ctx, 4, 0.35, 12, thr)
+    seg = SlabSegmenter(shape, block, ctx, -(-shape[0] // block[0]), 0, thr, True, 4, 0.35, 12, 256, n_lanes=4, edge_cap=64, label_cap=64,
+                        host_scores=host_scores)
+    assert seg.edge_cap == 64 and seg.label_cap == 64
+    seg.interior(seg.affs).copy_(torch.from_numpy(affs).cuda())
+    segs = seg.run()
+    assert seg.edge_cap > 64                         # grown: some block has more edges than the cap
+    assert np.array_equal(seg.interior(seg.frags).cpu().numpy().view(np.uint64), frags_ref)
+    order = np.lexsort((seg.rag_edges[:, 1], seg.rag_edges[:, 0]))
+    order_ref = np.lexsort((E[:, 1], E[:, 0]))
+    assert np.array_equal(seg.rag_edges[order], E[order_ref])
+    np.testing.assert_array_equal(seg.rag_scores[order], Sc[order_ref])
+    for t in range(len(thr)):
+        assert np.array_equal(segs[t].cpu().numpy().view(np.uint64), segs_ref[t])
+    ids, pos, size = seg.node_table()
+    assert np.array_equal(ids, nodes)
+    k = len(ids) // 2
+    assert size[k] == int((frags_ref == ids[k]).sum())
+
+
 @pytest.mark.parametrize("nproc,grid", [(2, "2x1"), (4, "4x1"), (3, "1x3"), (4, "2x2")])
 def test_ranks_equal_one_rank(tmp_path, nproc, grid):
     """Several ranks (gloo, all on cuda:0), each with its box of the 4 x 3 grid of block layers and block rows -- slabs of
