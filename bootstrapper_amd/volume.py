@@ -440,6 +440,9 @@ class SlabSegmenter:
             sizes[:, :old].copy_(self.sizes)
             sums[:, :old].copy_(self.sums)
             self.sizes, self.sums = sizes, sums
+            # the new tables were filled on the current stream, the blocks' statistics are redone on the lanes' streams: without
+            # this wait a lane could write a block's row before the zero fill / the copy of the old rows reached it
+            torch.cuda.current_stream(self.dev).synchronize()
             for k in np.nonzero(nums > old)[0]:
                 b, e = self.boxes[k]
                 lane = self._take_lane("n", int(k))
@@ -457,6 +460,7 @@ class SlabSegmenter:
                 esums = torch.empty((K, self.edge_cap), dtype=torch.int64, device=self.dev)
                 esums[:, :old].copy_(self.esums)
                 self.esums = esums
+            torch.cuda.current_stream(self.dev).synchronize()   # (as above: the copies of the old rows before the lanes write new ones)
             for k in np.nonzero(n_edges > old)[0]:
                 self._launch_scores(int(k))
         return self._sync()
@@ -629,6 +633,7 @@ class SlabSegmenter:
         torch.cuda.synchronize(self.dev)
         self._exchange(self.frags).synchronize()
         self.counts_dev.zero_()
+        torch.cuda.current_stream(self.dev).synchronize()   # before the lanes write their blocks' counts
         st_s = run_blocks(names[1], list(range(K)), one(self._launch_scores, "s"), max_retries, upstream_failed=st_f.failed_blocks,
                           depends_on=self._neighbours)
         self._collect()

@@ -84,8 +84,12 @@ def test_block_tables_grow_on_demand(host_scores):
         assert np.array_equal(segs[t].cpu().numpy().view(np.uint64), segs_ref[t])
     ids, pos, size = seg.node_table()
     assert np.array_equal(ids, nodes)
-    k = len(ids) // 2
-    assert size[k] == int((frags_ref == ids[k]).sum())
+    ref_ids, ref_size = np.unique(frags_ref[frags_ref > 0], return_counts=True)
+    assert np.array_equal(ids, ref_ids) and np.array_equal(size, ref_size)          # every fragment's voxel count, regrown blocks included
+    zz, yy, xx = np.nonzero(frags_ref)
+    lut = np.searchsorted(ref_ids, frags_ref[zz, yy, xx])
+    com = np.stack([np.bincount(lut, weights=c, minlength=len(ref_ids)) for c in (zz, yy, xx)], axis=1) / ref_size[:, None]
+    assert np.allclose(pos, com)
 
 
 @pytest.mark.parametrize("nproc,grid", [(2, "2x1"), (4, "4x1"), (3, "1x3"), (4, "2x2")])
