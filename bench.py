@@ -237,15 +237,26 @@ def drivers_leg(raw_box, sd, precision):
         t0 = time.perf_counter()
         written = run_segmentation(seg_toml, "ws")
         t_seg = time.perf_counter() - t0
+        # ... and the `filter` step of a bootstrap round (BASELINE config 4: predict -> segment -> filter): `bs refine` size filter
+        # on the last threshold's segmentation (refine.py:131-257: object table, rule, relabelled copy of the dataset)
+        import contextlib
+        import io
+        from bootstrapper_amd.refine import size_filter
+        t0 = time.perf_counter()
+        with contextlib.redirect_stdout(io.StringIO()):
+            filtered = size_filter(written[-1], min_size=500)
+        t_filter = time.perf_counter() - t0
 
         def du(path):
             return sum(os.path.getsize(os.path.join(d, f)) for d, _, fs in os.walk(path) for f in fs)
         nvox = raw_box.size
         return {"what": "`bs predict` then `bs segment --ws` (blockwise, one worker) on an on-disk Zarr store of the same box of blocks: "
-                        "checkpoint load and weight packing, Blosc-lz4 chunk decode / encode and file I/O included (outside the timed region)",
-                "blocks": int(nvox // int(np.prod(OUT_BLOCK))), "predict_seconds": t_pred, "segment_seconds": t_seg,
+                        "checkpoint load and weight packing, Blosc-lz4 chunk decode / encode and file I/O included (outside the timed region); "
+                        "then `bs refine` size filter on the last segmentation (filter_seconds, not in Mvoxels_per_s)",
+                "blocks": int(nvox // int(np.prod(OUT_BLOCK))), "predict_seconds": t_pred, "segment_seconds": t_seg, "filter_seconds": t_filter,
                 "Mvoxels_per_s": nvox / (t_pred + t_seg) / 1e6, "predict_Mvoxels_per_s": nvox / t_pred / 1e6,
-                "segment_Mvoxels_per_s": nvox / t_seg / 1e6, "datasets_written": len(written) + 1,
+                "segment_Mvoxels_per_s": nvox / t_seg / 1e6, "round_Mvoxels_per_s": nvox / (t_pred + t_seg + t_filter) / 1e6,
+                "datasets_written": len(written) + 1 + (1 if filtered else 0),
                 "store_bytes": du(store), "tmp_dir": os.path.dirname(tmp) or tmp}
     finally:
         shutil.rmtree(tmp, ignore_errors=True)
