@@ -46,18 +46,32 @@ class _Device:
         self.dev = torch.device("cuda", device)
         cz = int(in_ds.chunks[0])
         self.engine = SegEngine((min(cz, in_ds.shape[0]), min(tile, in_ds.shape[1]), min(tile, in_ds.shape[2])), device)
-        self.tile = tile
+        self.tile_edge = tile
+
+        # tiles read for the object table stay on the device for the pass that writes the filtered copy (a rule is evaluated
+        # between two passes over the same volume: the second read and decode of a dataset that fits is saved)
+        self.kept, self.kept_bytes, self.budget = {}, 0, 8 << 30
 
     def upload(self, block):
         return self.torch.from_numpy(np.ascontiguousarray(block).astype(np.uint64).view(np.int64)).to(self.dev)
 
+    def tile(self, in_ds, sl, keep=False):
+        key = tuple((s.start, s.stop) for s in sl)
+        t = self.kept.get(key)
+        if t is None:
+            t = self.upload(in_ds[sl])
+            if keep and self.kept_bytes + t.numel() * 8 <= self.budget:
+                self.kept[key] = t
+                self.kept_bytes += t.numel() * 8
+        return t
 
-def label_table(in_ds, device=0):
+
+def label_table(in_ds, device=0, holder=None):
     """-> (ids ascending u64, sizes, zmin, zmax) over the whole volume (refine.py:98-109, 228-250)."""
-    d = _Device(in_ds, device)
+    d = holder or _Device(in_ds, device)
     parts = []
-    for iz, sl in _tiles(in_ds, d.tile):
-        parts.append(d.engine.label_table(d.upload(in_ds[sl]), iz))
+    for iz, sl in _tiles(in_ds, d.tile_edge):
+        parts.append(d.engine.label_table(d.tile(in_ds, sl, keep=holder is not None), iz))
     if not parts:
         z = np.zeros(0, np.int64)
         return np.zeros(0, np.uint64), z, z, z
@@ -71,16 +85,16 @@ def label_table(in_ds, device=0):
     return uniq, sizes, zmin, zmax
 
 
-def _apply_mapping(in_ds, out_array, keys, vals, device=0):
+def _apply_mapping(in_ds, out_array, keys, vals, device=0, holder=None):
     """out = in with keys[k] -> vals[k] (ids not listed stay), tile by tile through bsmi_lut_relabel."""
     from .post.engine import lut_relabel
-    d = _Device(in_ds, device)
+    d = holder or _Device(in_ds, device)
     out_ds = _empty_copy(in_ds, out_array)
     order = np.argsort(keys, kind="stable")
     k = d.torch.from_numpy(np.asarray(keys, np.uint64)[order].view(np.int64)).to(d.dev)
     v = d.torch.from_numpy(np.asarray(vals, np.uint64)[order].view(np.int64)).to(d.dev)
-    for _, sl in _tiles(in_ds, d.tile):
-        lab = d.upload(in_ds[sl])
+    for _, sl in _tiles(in_ds, d.tile_edge):
+        lab = d.tile(in_ds, sl)
         out_ds[sl] = lut_relabel(lab, k, v).cpu().numpy().view(np.uint64).astype(in_ds.dtype)
     return out_ds
 
@@ -91,7 +105,8 @@ class ObjectTable:
     def __init__(self, in_array, device=0):
         self.path = in_array
         self.ds = open_ds(in_array)
-        self.ids, self.sizes, self.zmin, self.zmax = label_table(self.ds, device)
+        self.holder = _Device(self.ds, device)
+        self.ids, self.sizes, self.zmin, self.zmax = label_table(self.ds, device, self.holder)
         if self.ids.size == 0:
             raise click.ClickException(f"{in_array} holds no labelled voxels")
 
@@ -155,7 +170,7 @@ def run_filter(kind, in_array, out_array=None, dry_run=False, device=0, **option
     target = out_array or derived_dataset(in_array, suffix)
     print(f"-> {target}")
     gone = table.ids[drop]
-    _apply_mapping(table.ds, target, gone, np.zeros(gone.size, np.uint64), device)
+    _apply_mapping(table.ds, target, gone, np.zeros(gone.size, np.uint64), device, table.holder)
     return target
 
 
