@@ -191,3 +191,58 @@ def test_tensorboard_event_file_round_trip(tmp_path):
     bad.write_bytes(bytes(raw))
     with pytest.raises(ValueError):
         T.read_scalars(str(bad))
+
+
+def _numpy_region_graph(affs, frags):
+    """edges (ascending id pairs), affinity sums and voxel-pair counts of the faces between different fragments: the pair
+    (p, p - 1 along axis d) counts with affs[d][p] (seg.hip agg_edges_kernel; waterz's region graph)"""
+    keys, vals = [], []
+    for d in range(3):
+        hi = [slice(None)] * 3
+        lo = [slice(None)] * 3
+        hi[d], lo[d] = slice(1, None), slice(None, -1)
+        a, b, w = frags[tuple(hi)], frags[tuple(lo)], affs[d][tuple(hi)]
+        m = (a > 0) & (b > 0) & (a != b)
+        u, v = np.minimum(a[m], b[m]), np.maximum(a[m], b[m])
+        keys.append(np.stack([u, v], axis=1))
+        vals.append(w[m].astype(np.uint64))
+    keys, vals = np.concatenate(keys), np.concatenate(vals)
+    uniq, inv = np.unique(keys, axis=0, return_inverse=True)
+    inv = inv.reshape(-1)
+    sums = np.bincount(inv, weights=vals.astype(np.float64), minlength=len(uniq)).astype(np.uint64)
+    cnts = np.bincount(inv, minlength=len(uniq)).astype(np.uint32)
+    return uniq.astype(np.uint64), sums, cnts
+
+
+@pytest.mark.parametrize("shape,sigma,msd,bins,thr", [((8, 64, 64), (1, 3, 3), 5, 256, 1.0), ((6, 80, 80), (1, 3, 3), 5, 256, 0.45),
+                                                      ((10, 48, 56), (1, 2, 2), 3, 16, 1.0), ((3, 50, 70), (0, 1, 1), 3, 1, 1.0)])
+def test_host_merge_loop_of_the_edge_scoring_equals_the_oracle(shape, sigma, msd, bins, thr):
+    """bsmi_rag_merge_scores_host (csrc/agglo_host.cpp: the block pipeline's edge scoring on host threads) against the C
+    restatement of waterz_agglom.py:106-170, on region graphs built here in numpy: the same edges, bit for bit the same
+    scores (NaN = never merged), with coarse and single-bin queues and a threshold that leaves edges unmerged."""
+    from scipy.ndimage import gaussian_filter
+    from bootstrapper_amd.post.engine import rag_merge_scores_host
+    from oracle import seg_ref as S
+    rng = np.random.default_rng(shape[1] * 7 + bins)
+    graphs, refs = [], []
+    for g in range(3):
+        a = gaussian_filter(rng.random((3,) + shape), sigma=(0,) + sigma)
+        affs = ((a - a.min()) / (a.max() - a.min()) * 255).astype(np.uint8)
+        frags, _ = S.ws_fragments_u8(affs, True, msd)
+        frags = np.where(frags > 0, frags + np.uint64((1 << 40) * g), np.uint64(0))     # ids beyond 32 bits
+        e_ref, s_ref, _, _ = S.rag_merge_scores_u8(affs, frags, thr, bins)
+        e, sums, cnts = _numpy_region_graph(affs, frags)
+        assert np.array_equal(e, e_ref)
+        graphs.append((e, sums, cnts))
+        refs.append(s_ref)
+    cap = max(len(g[0]) for g in graphs) + 3
+    E = np.zeros((3, cap, 2), np.uint64); Sm = np.zeros((3, cap), np.uint64); Cn = np.ones((3, cap), np.uint32)
+    for g, (e, s, c) in enumerate(graphs):
+        E[g, :len(e)], Sm[g, :len(e)], Cn[g, :len(e)] = e, s, c
+    ne = np.array([len(g[0]) for g in graphs])
+    sc = rag_merge_scores_host(ne, E, Sm, Cn, thr, bins, threads=2)
+    for g, s_ref in enumerate(refs):
+        assert np.array_equal(sc[g, :ne[g]].view(np.uint32), s_ref.view(np.uint32))
+        assert np.isnan(sc[g, ne[g]:]).all()
+    if thr < 1.0:
+        assert np.isnan(refs[0]).any() and (~np.isnan(refs[0])).any()
