@@ -90,6 +90,7 @@ def _load():
         "bsmi_label_stats": (i32, [p, vp, i64p, C.c_uint64, C.c_uint64, vp, vp, vp]),
         "bsmi_rag_merge_scores_u8": (i32, [p, vp, vp, i64p, C.c_float, C.c_int, vp, vp, C.c_uint64, vp, vp, vp, vp]),
         "bsmi_lut_relabel": (i32, [C.c_int, vp, C.c_uint64, vp, vp, C.c_uint64, vp, vp]),
+        "bsmi_lut_relabel_multi": (i32, [i32, vp, C.c_uint64, vp, vp, C.c_uint64, i32, vp, vp]),
         "bsmi_connected_components": (i32, [vp, C.c_uint64, vp, vp, C.c_uint64, C.c_float, vp]),
         "bsmi_connected_components_multi": (i32, [vp, C.c_uint64, vp, vp, C.c_uint64, vp, C.c_int, vp]),
         "bsmi_cc_affs_u8": (i32, [p, vp, i64p, C.c_int, C.c_int64, vp, vp, vp, vp]),

@@ -276,6 +276,27 @@ def lut_relabel(labels, keys, vals, out=None):
     return out
 
 
+def lut_relabel_multi(labels, keys, vals, out=None):
+    """lut_relabel for several value columns at once -- one segmentation per threshold out of one fragment volume: vals int64
+    [T][m] (CUDA or host), -> out int64 [T] + labels.shape.  One look-up per run of equal ids serves every column."""
+    if labels.dtype != torch.int64 or not labels.is_cuda:
+        raise ValueError("labels must be an int64 CUDA tensor")
+    lab = labels.contiguous()
+    keys = keys.to(device=lab.device, dtype=torch.int64).contiguous()
+    vals = vals.to(device=lab.device, dtype=torch.int64).contiguous()
+    if vals.dim() != 2 or vals.shape[1] != keys.numel():
+        raise ValueError("vals must have shape (columns, len(keys))")
+    T = int(vals.shape[0])
+    if out is None:
+        out = torch.empty((T,) + tuple(lab.shape), dtype=torch.int64, device=lab.device)
+    if not out.is_contiguous() or tuple(out.shape) != (T,) + tuple(lab.shape) or out.dtype != torch.int64:
+        raise ValueError("out must be a contiguous int64 tensor of shape (columns,) + labels.shape")
+    stream = C.c_void_p(torch.cuda.current_stream(lab.device).cuda_stream)
+    check(lib.bsmi_lut_relabel_multi(lab.device.index, C.c_void_p(lab.data_ptr()), lab.numel(), C.c_void_p(keys.data_ptr()),
+                                     C.c_void_p(vals.data_ptr()), keys.numel(), T, C.c_void_p(out.data_ptr()), stream))
+    return out
+
+
 def threshold_to_cut(threshold):
     """The uint8 cut equivalent to the reference's `affs.astype(float32) / 255.0 > threshold`
     (post/connected_components.py:49-52,77): the largest v with not (float32(v) / 255 > float32(threshold)), -1 if none."""

@@ -665,8 +665,12 @@ class SlabSegmenter:
         fr = self._fr
         fr.copy_(self.interior(self.frags))
         keys = torch.from_numpy(self.nodes.view(np.int64)).to(self.dev)
-        for t, comp in enumerate(self.luts):
-            lut_relabel(fr, keys, torch.from_numpy(comp.view(np.int64)).to(self.dev), out=self.segs[t])
+        if 1 <= len(self.luts) <= 8:   # every threshold's LUT in one pass over the fragments
+            from .post.engine import lut_relabel_multi
+            lut_relabel_multi(fr, keys, torch.from_numpy(np.stack([c.view(np.int64) for c in self.luts])).to(self.dev), out=self.segs)
+        else:
+            for t, comp in enumerate(self.luts):
+                lut_relabel(fr, keys, torch.from_numpy(comp.view(np.int64)).to(self.dev), out=self.segs[t])
         torch.cuda.synchronize(self.dev)
         return self.segs
 

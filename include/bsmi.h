@@ -327,6 +327,10 @@ int bsmi_rag_edge_stats(bsmi_seg *h, uint64_t *sums_dev, uint64_t *counts_dev, u
  * (keys ascending); 0 stays 0; ids without a key are copied.  in_dev == out_dev is allowed. */
 int bsmi_lut_relabel(int device, const uint64_t *in_dev, uint64_t n, const uint64_t *keys_dev,
                      const uint64_t *vals_dev, uint64_t m, uint64_t *out_dev, void *stream);
+/* The same with n_columns value columns at once (one segmentation per threshold): vals_dev [n_columns][m], out_dev
+ * [n_columns][n]; one look-up per run of equal ids serves every column.  out_dev must not overlap in_dev. */
+int bsmi_lut_relabel_multi(int device, const uint64_t *in_dev, uint64_t n, const uint64_t *keys_dev,
+                           const uint64_t *vals_dev, uint64_t m, int n_columns, uint64_t *out_dev, void *stream);
 
 /* Global thresholded connected components of the scored RAG on the HOST (plain host pointers; reference
  * post/watershed.py:182 calls funlib.segment.graphs.impl.connected_components, a host C++ routine).

@@ -386,6 +386,25 @@ def test_lut_relabel():
     assert np.array_equal(out.cpu().numpy(), ref)
 
 
+def test_lut_relabel_multi_equals_single_columns():
+    """every threshold's LUT applied in one pass (runs of equal ids share a look-up) = one lut_relabel per column"""
+    from bootstrapper_amd.post.engine import lut_relabel, lut_relabel_multi
+    rng = np.random.default_rng(3)
+    keys = np.unique(rng.integers(1, 1 << 45, size=3000)).astype(np.int64)
+    vals = rng.integers(1, 1 << 45, size=(3, keys.size)).astype(np.int64)
+    # compact regions (long runs along x), zeros, ids without a key, a length that is no multiple of the run
+    base = rng.choice(np.concatenate([keys, [0, 0, 7, (1 << 50) + 1]]), size=(5, 37, 9)).astype(np.int64)
+    lab = np.repeat(base, 7, axis=2)[:, :, :61]
+    out = lut_relabel_multi(torch.from_numpy(lab).cuda(), torch.from_numpy(keys), torch.from_numpy(vals))
+    for t in range(3):
+        ref = lut_relabel(torch.from_numpy(lab).cuda(), torch.from_numpy(keys), torch.from_numpy(vals[t]))
+        assert torch.equal(out[t], ref)
+    one = lut_relabel_multi(torch.from_numpy(lab).cuda(), torch.from_numpy(keys), torch.from_numpy(vals[:1]))
+    assert torch.equal(one[0], out[0])
+    none = lut_relabel_multi(torch.from_numpy(lab).cuda(), torch.zeros(0, dtype=torch.int64), torch.zeros((2, 0), dtype=torch.int64))
+    assert torch.equal(none[0], torch.from_numpy(lab).cuda()) and torch.equal(none[1], none[0])
+
+
 def test_cc_affs_bit_exact_vs_reference_goldens_and_oracle(golden_dir):
     """`bs segment --cc` labelling: goldens produced by the reference post/cc.py, then larger volumes against the oracle,
     then debris removal."""

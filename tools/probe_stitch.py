@@ -9,7 +9,7 @@ from bench import NET_CONFIG, OUT_BLOCK, CONTEXT, SEG_CONTEXT, THRESHOLDS, job_b
 from bootstrapper_amd.unet import Model
 from bootstrapper_amd.synth import synthetic_state_dict, synthetic_volume
 from bootstrapper_amd import volume as V
-from bootstrapper_amd.post.engine import lut_relabel
+from bootstrapper_amd.post.engine import lut_relabel, lut_relabel_multi
 
 steps = int(sys.argv[1]) if len(sys.argv) > 1 else 20
 dev = torch.device("cuda", 0)
@@ -48,6 +48,10 @@ for rep in range(3):
         lut_relabel(fr, keys, v, out=s.segs[t])
     torch.cuda.synchronize()
     t6 = time.perf_counter()
+    lut_relabel_multi(fr, keys, torch.stack(vals), out=s.segs)
+    torch.cuda.synchronize()
+    t7 = time.perf_counter()
+    print(f"        one pass for the three: {1e3*(t7-t6):.2f} ms")
     print(f"rep {rep}: blocks+collect {1e3*(t1-t0):.1f}  nodes {1e3*(t2-t1):.2f}  components {1e3*(t3-t2):.2f}  interior copy {1e3*(t4-t3):.2f}  "
           f"LUT upload {1e3*(t5-t4):.2f}  3 relabels {1e3*(t6-t5):.2f} ms;  {len(nodes)} nodes, {len(s.rag_scores)} edges")
 # the host part of _collect alone: run the blocks, wait for the lanes, then time it
