@@ -173,35 +173,86 @@ namespace {
 
 constexpr uint32_t kNoEdge = 0xffffffffu;
 
+// (node pair) -> edge: open addressing, linear probing, deletion by backward shift (no tombstones: the merge loop erases and
+// inserts a key per relinked edge).  std::unordered_map here was most of the loop's time (a heap node per key).
+struct PairMap {
+  static constexpr uint64_t kEmpty = ~0ull;
+  std::vector<uint64_t> k;
+  std::vector<uint32_t> v;
+  uint32_t mask;
+  int shift;
+  explicit PairMap(uint64_t n) {
+    int bits = 4;
+    while ((1ull << bits) < 2 * n + 8) ++bits;
+    k.assign((size_t)1 << bits, kEmpty);
+    v.resize((size_t)1 << bits);
+    mask = (uint32_t)((1ull << bits) - 1);
+    shift = 64 - bits;
+  }
+  uint32_t home(uint64_t key) const { return (uint32_t)((key * 0x9E3779B97F4A7C15ull) >> shift); }
+  // slot of `key`, or the empty slot where it would go
+  uint32_t slot(uint64_t key) const {
+    uint32_t i = home(key);
+    while (k[i] != kEmpty && k[i] != key) i = (i + 1) & mask;
+    return i;
+  }
+  void erase_slot(uint32_t i) {
+    uint32_t j = i;
+    for (;;) {
+      j = (j + 1) & mask;
+      if (k[j] == kEmpty) break;
+      const uint32_t h = home(k[j]);
+      // the entry at j may move to the hole at i unless its home lies cyclically in (i, j]
+      const bool stays = i <= j ? (h > i && h <= j) : (h > i || h <= j);
+      if (!stays) { k[i] = k[j]; v[i] = v[j]; i = j; }
+    }
+    k[i] = kEmpty;
+  }
+  void erase(uint64_t key) {
+    const uint32_t i = slot(key);
+    if (k[i] == key) erase_slot(i);
+  }
+};
+
 void rag_merge_scores_one(uint64_t ne, const uint64_t* edges, const uint64_t* sums, const uint32_t* cnts, float threshold, int nbins,
                           float* scores) {
   if (!ne) return;
-  // fragment ids -> ranks (ascending with the ids, as the device's): only their order matters
-  std::vector<uint64_t> ids(2 * ne);
-  for (uint64_t i = 0; i < 2 * ne; ++i) ids[i] = edges[i];
-  std::sort(ids.begin(), ids.end());
-  ids.erase(std::unique(ids.begin(), ids.end()), ids.end());
-  const uint32_t nn = (uint32_t)ids.size();
-  auto rank_of = [&](uint64_t id) { return (uint32_t)(std::lower_bound(ids.begin(), ids.end(), id) - ids.begin()); };
-  std::vector<uint32_t> eu(ne), ev(ne), x0(ne), y0(ne), cnt(ne), etime(ne, 0), qnext(ne, kNoEdge);
+  // The order in which edges leave the bin queue is the algorithm (and is replayed as the device loop and the oracle do it); how
+  // the graph is held is not.  Nodes are numbered as they appear (nothing below looks at their order); the edge lists of a node
+  // are intrusive (an edge is linked once through each end); of two merging nodes the one with the shorter list is relinked
+  // (which one carries on is free: keys, time stamps and scores treat them alike); an edge that meets a parallel one is absorbed
+  // by it or absorbs it, and the score of an input edge is the score at which the edge that absorbed it -- through however many
+  // steps -- was merged: there is exactly one live edge between two regions, so the merge that joins an input edge's two regions
+  // pops that representative.  (The device loop finds the same value by walking a merge tree.)
+  PairMap node_of(2 * ne);
+  uint32_t nn = 0;
+  auto number = [&](uint64_t id) {
+    const uint32_t sl = node_of.slot(id);
+    if (node_of.k[sl] != id) { node_of.k[sl] = id; node_of.v[sl] = nn++; }
+    return node_of.v[sl];
+  };
+  std::vector<uint32_t> eu(ne), ev(ne), cnt(ne), etime(ne, 0), qnext(ne, kNoEdge), nu(ne), nv(ne), into(ne, kNoEdge);
   std::vector<uint64_t> sum(ne);
-  std::vector<float> score(ne);
+  std::vector<float> score(ne), merged_at(ne, std::nanf(""));
   std::vector<uint8_t> dead(ne, 0);
-  std::vector<std::vector<uint32_t>> inc(nn);
-  std::unordered_map<uint64_t, uint32_t> by_key;
-  by_key.reserve(2 * ne);
+  for (uint32_t e = 0; e < ne; ++e) {
+    eu[e] = number(edges[2 * (size_t)e]);
+    ev[e] = number(edges[2 * (size_t)e + 1]);
+  }
+  std::vector<uint32_t> head(nn, kNoEdge), deg(nn, 0), ntime(nn, 0);
+  PairMap by_key(ne);
   auto key_of = [](uint32_t a, uint32_t b) { return a < b ? ((uint64_t)a << 32) | b : ((uint64_t)b << 32) | a; };
   auto edge_score = [](uint64_t s, uint32_t c) { return 1.0f - (float)((double)s / (255.0 * (double)c)); };
   for (uint32_t e = 0; e < ne; ++e) {
-    const uint32_t a = rank_of(edges[2 * (size_t)e]), b = rank_of(edges[2 * (size_t)e + 1]);
-    eu[e] = x0[e] = a;
-    ev[e] = y0[e] = b;
+    const uint32_t a = eu[e], b = ev[e];
     sum[e] = sums[e];
     cnt[e] = cnts[e];
     score[e] = edge_score(sum[e], cnt[e]);
-    inc[a].push_back(e);
-    inc[b].push_back(e);
-    by_key[key_of(a, b)] = e;
+    nu[e] = head[a]; head[a] = e; ++deg[a];
+    nv[e] = head[b]; head[b] = e; ++deg[b];
+    const uint32_t sl = by_key.slot(key_of(a, b));
+    by_key.k[sl] = key_of(a, b);
+    by_key.v[sl] = e;
   }
   std::vector<uint32_t> bhead(nbins, kNoEdge), btail(nbins, kNoEdge);
   int minbin = nbins;
@@ -216,10 +267,7 @@ void rag_merge_scores_one(uint64_t ne, const uint64_t* edges, const uint64_t* su
   };
   for (uint32_t e = 0; e < ne; ++e)
     if (score[e] < threshold) push(e, score[e]);
-  std::vector<uint32_t> ntime(nn, 0), cur(nn), tnext((size_t)nn + nn, kNoEdge);
-  std::vector<float> tscore((size_t)nn + nn, 0.f);
-  for (uint32_t i = 0; i < nn; ++i) cur[i] = i;
-  uint32_t nm = 0, clock = 0;
+  uint32_t clock = 0;
   for (;;) {
     uint32_t pick = kNoEdge;
     for (;;) {
@@ -241,58 +289,58 @@ void rag_merge_scores_one(uint64_t ne, const uint64_t* edges, const uint64_t* su
     }
     if (pick == kNoEdge) break;
     const uint32_t e = pick;
-    const uint32_t a = eu[e] < ev[e] ? eu[e] : ev[e], b = eu[e] < ev[e] ? ev[e] : eu[e];
-    for (const uint32_t f : inc[b]) {
-      if (f == e || dead[f]) continue;
-      const uint32_t fu = eu[f], fv = ev[f];
-      if (fu != b && fv != b) continue;  // (cannot happen: an edge leaves a node's list only with the node)
-      const uint32_t nb = fu == b ? fv : fu;
-      by_key.erase(key_of(fu, fv));
-      const uint64_t gkey = key_of(a, nb);
-      auto it = by_key.find(gkey);
-      bool move_f = true;
-      if (it != by_key.end()) {
-        const uint32_t g = it->second;
-        if (score[f] > score[g]) {
-          sum[g] += sum[f];
-          cnt[g] += cnt[f];
-          dead[f] = 1;
-          move_f = false;
-        } else {
-          sum[f] += sum[g];
-          cnt[f] += cnt[g];
-          dead[g] = 1;
-          it->second = f;
+    uint32_t a = eu[e], b = ev[e];
+    if (deg[a] < deg[b]) { const uint32_t t = a; a = b; b = t; }
+    for (uint32_t f = head[b]; f != kNoEdge;) {
+      const bool uside = eu[f] == b;
+      const uint32_t next = uside ? nu[f] : nv[f];
+      if (f != e && !dead[f]) {
+        const uint32_t nb = uside ? ev[f] : eu[f];
+        by_key.erase(key_of(b, nb));
+        const uint64_t gkey = key_of(a, nb);
+        const uint32_t sl = by_key.slot(gkey);
+        const bool found = by_key.k[sl] == gkey;
+        bool move_f = true;
+        if (found) {
+          const uint32_t g = by_key.v[sl];
+          if (score[f] > score[g]) {
+            sum[g] += sum[f];
+            cnt[g] += cnt[f];
+            dead[f] = 1;
+            into[f] = g;
+            move_f = false;
+          } else {
+            sum[f] += sum[g];
+            cnt[f] += cnt[g];
+            dead[g] = 1;
+            into[g] = f;
+            by_key.v[sl] = f;
+          }
+        }
+        if (move_f) {
+          if (uside) { eu[f] = a; nu[f] = head[a]; } else { ev[f] = a; nv[f] = head[a]; }
+          head[a] = f;
+          ++deg[a];
+          if (!found) { by_key.k[sl] = gkey; by_key.v[sl] = f; }
         }
       }
-      if (move_f) {
-        if (fu == b) eu[f] = a; else ev[f] = a;
-        inc[a].push_back(f);
-        if (it == by_key.end()) by_key[gkey] = f;
-      }
+      f = next;
     }
-    by_key.erase(key_of(eu[e], ev[e]));
+    by_key.erase(key_of(a, b));
     dead[e] = 1;
-    inc[b].clear();
-    inc[b].shrink_to_fit();
+    merged_at[e] = score[e];
+    head[b] = kNoEdge;
+    deg[b] = 0;
     ntime[a] = ++clock;
-    const uint32_t t = nn + nm;
-    tnext[cur[a]] = t;
-    tnext[cur[b]] = t;
-    cur[a] = t;
-    tnext[t] = kNoEdge;
-    tscore[t] = score[e];
-    ++nm;
   }
   for (uint32_t e = 0; e < ne; ++e) {
-    uint32_t x = x0[e], y = y0[e];
-    float sc = std::nanf("");
-    for (;;) {
-      if (x == y) { sc = tscore[x]; break; }
-      if (x < y) { const uint32_t nx = tnext[x]; if (nx == kNoEdge) break; x = nx; }
-      else { const uint32_t ny = tnext[y]; if (ny == kNoEdge) break; y = ny; }
+    uint32_t r = e;
+    while (into[r] != kNoEdge) {
+      const uint32_t up = into[r];
+      if (into[up] != kNoEdge) into[r] = into[up];  // path halving
+      r = up;
     }
-    scores[e] = sc;
+    scores[e] = merged_at[r];
   }
 }
 
@@ -312,13 +360,19 @@ extern "C" int bsmi_rag_merge_scores_host(int n_graphs, const uint64_t* n_edges,
     for (uint64_t e = 0; e < n_edges[g]; ++e)
       if (!counts[g][e] || edges[g][2 * e] == edges[g][2 * e + 1]) return BSMI_ERR_INVALID;
   }
+  // largest graphs first: the threads take them from one queue, and the last ones taken decide when all are done
+  std::vector<int> order(n_graphs);
+  for (int g = 0; g < n_graphs; ++g) order[g] = g;
+  std::stable_sort(order.begin(), order.end(), [&](int x, int y) { return n_edges[x] > n_edges[y]; });
   std::atomic<int> next{0};
   auto work = [&] {
-    for (int g = next.fetch_add(1); g < n_graphs; g = next.fetch_add(1))
+    for (int i = next.fetch_add(1); i < n_graphs; i = next.fetch_add(1)) {
+      const int g = order[i];
       bsmi::rag_merge_scores_one(n_edges[g], edges[g], sums[g], counts[g], threshold, discretize_queue, scores[g]);
+    }
   };
   const int hw = (int)std::max(1u, std::thread::hardware_concurrency());
-  const int nt = std::max(1, std::min(std::min(n_threads > 0 ? n_threads : 16, hw), n_graphs));
+  const int nt = std::max(1, std::min(std::min(n_threads > 0 ? n_threads : 24, hw), n_graphs));
   if (nt <= 1) {
     work();
   } else {

@@ -33,7 +33,7 @@ namespace bsmi {
 // ------------------------------------------------------------------------------------------
 // watershed fragments
 // ------------------------------------------------------------------------------------------
-constexpr int WS_T = 256;            // threads per slice workgroup (seeds kernel)
+constexpr int WS_T = 1024;           // threads per slice workgroup (seeds kernel): 16 waves, so that its LDS loops hide their latency
 #ifndef BSMI_FLOOD_WAVES
 #define BSMI_FLOOD_WAVES 16
 #endif
@@ -46,6 +46,8 @@ __device__ __forceinline__ int reflect_dup(int i, int n) {
   if (i < 0) i += p;
   return i < n ? i : p - 1 - i;
 }
+// the same for -n <= i < 2 n (a filter window no wider than the axis), without the division
+__device__ __forceinline__ int reflect_near(int i, int n) { return i < 0 ? -i - 1 : (i >= n ? 2 * n - 1 - i : i); }
 
 // scratch per slice (global memory, L2 resident): mask u8, g/d2/mf int32, parent int32, lab int32
 struct WsScratch {
@@ -80,7 +82,8 @@ __global__ __launch_bounds__(WS_T) void ws_seeds_kernel(const uint8_t* __restric
   int32_t* lab = s.lab + (size_t)z * n;
   const int tid = threadIdx.x;
   __shared__ int sh_any_bg;
-  __shared__ int sh_cnt[WS_T];
+  __shared__ int sh_wave[WS_T / 64];
+  const bool near = msd <= H && msd <= W;  // the maximum filter's window reflects at most once
   if (tid == 0) sh_any_bg = 0;
   __syncthreads();
   // The sequential per-row loops below (row distances, run labelling, numbering) must not walk global memory: a load
@@ -130,12 +133,20 @@ __global__ __launch_bounds__(WS_T) void ws_seeds_kernel(const uint8_t* __restric
       __syncthreads();
       for (int i = tid; i < n; i += WS_T) {
         const int y = i / W, x = i - y * W;
-        int best = INF;
-        for (int yy = 0; yy < H; ++yy) {
-          const int gg = sg[yy * Wp + x];
-          const int dy = y - yy;
-          const int v = gg == GINF ? INF : gg * gg + dy * dy;
-          best = v < best ? v : best;
+        // min over rows of g(row, x)^2 + (y - row)^2, outwards from the own row: a row k away cannot improve on a best <= k^2
+        const int g0 = sg[y * Wp + x];
+        int best = g0 == GINF ? INF : g0 * g0;
+        for (int k = 1; k < H && k * k < best; ++k) {
+          if (y - k >= 0) {
+            const int gg = sg[(y - k) * Wp + x];
+            const int v = gg == GINF ? INF : gg * gg + k * k;
+            best = v < best ? v : best;
+          }
+          if (y + k < H) {
+            const int gg = sg[(y + k) * Wp + x];
+            const int v = gg == GINF ? INF : gg * gg + k * k;
+            best = v < best ? v : best;
+          }
         }
         sd2[i] = (uint16_t)best;
         d2[i] = best;
@@ -154,7 +165,7 @@ __global__ __launch_bounds__(WS_T) void ws_seeds_kernel(const uint8_t* __restric
       const int y = i / W, x = i - y * W;
       int m = INT32_MIN;
       for (int k = x - left; k <= x + right; ++k) {
-        const int v = sd2[y * W + reflect_dup(k, W)];
+        const int v = sd2[y * W + (near ? reflect_near(k, W) : reflect_dup(k, W))];
         m = v > m ? v : m;
       }
       sg[y * Wp + x] = (uint16_t)m;
@@ -164,7 +175,7 @@ __global__ __launch_bounds__(WS_T) void ws_seeds_kernel(const uint8_t* __restric
       const int y = i / W, x = i - y * W;
       int m = INT32_MIN;
       for (int k = y - left; k <= y + right; ++k) {
-        const int v = sg[reflect_dup(k, H) * Wp + x];
+        const int v = sg[(near ? reflect_near(k, H) : reflect_dup(k, H)) * Wp + x];
         m = v > m ? v : m;
       }
       sflag[i] = (uint8_t)(m == (int)sd2[i]);   // d. is this voxel a maximum of the filtered distance?
@@ -215,7 +226,7 @@ __global__ __launch_bounds__(WS_T) void ws_seeds_kernel(const uint8_t* __restric
     const int y = i / W, x = i - y * W;
     int m = INT32_MIN;
     for (int k = x - left; k <= x + right; ++k) {
-      const int v = d2[y * W + reflect_dup(k, W)];
+      const int v = d2[y * W + (near ? reflect_near(k, W) : reflect_dup(k, W))];
       m = v > m ? v : m;
     }
     g[i] = m;
@@ -225,7 +236,7 @@ __global__ __launch_bounds__(WS_T) void ws_seeds_kernel(const uint8_t* __restric
     const int y = i / W, x = i - y * W;
     int m = INT32_MIN;
     for (int k = y - left; k <= y + right; ++k) {
-      const int v = g[reflect_dup(k, H) * W + x];
+      const int v = g[(near ? reflect_near(k, H) : reflect_dup(k, H)) * W + x];
       m = v > m ? v : m;
     }
     mf[i] = m;
@@ -291,15 +302,26 @@ __global__ __launch_bounds__(WS_T) void ws_seeds_kernel(const uint8_t* __restric
     if constexpr (LDS) cnt += sflag[i];
     else cnt += (par[i] == i);
   }
-  sh_cnt[tid] = cnt;
+  // exclusive scan of the chunk counts over the workgroup's threads: in a wave by shuffles, the 16 wave totals by wave 0
+  const int lane = tid & 63, wave = tid >> 6;
+  int incl = cnt;
+  for (int o = 1; o < 64; o <<= 1) {
+    const int t = __shfl_up(incl, o);
+    if (lane >= o) incl += t;
+  }
+  if (lane == 63) sh_wave[wave] = incl;
   __syncthreads();
-  if (tid == 0) {
-    int acc = 0;
-    for (int t = 0; t < WS_T; ++t) { const int c = sh_cnt[t]; sh_cnt[t] = acc; acc += c; }
-    s.nseeds[z] = acc;
+  if (wave == 0) {
+    int w = lane < WS_T / 64 ? sh_wave[lane] : 0;
+    for (int o = 1; o < WS_T / 64; o <<= 1) {
+      const int t = __shfl_up(w, o);
+      if (lane >= o) w += t;
+    }
+    if (lane < WS_T / 64) sh_wave[lane] = w;
   }
   __syncthreads();
-  int id = sh_cnt[tid];
+  int id = (wave ? sh_wave[wave - 1] : 0) + incl - cnt;
+  if (tid == WS_T - 1) s.nseeds[z] = id + cnt;
   for (int i = c0; i < c1; ++i) {
     bool root;
     if constexpr (LDS) root = sflag[i] != 0;
@@ -2114,6 +2136,45 @@ __global__ void seg_clear_kernel(AggWs w) {
   }
 }
 
+// Several buffers set to a 32-bit pattern by ONE launch.  The runtime's fill (hipMemsetAsync) is a launch per buffer and a narrow one:
+// the 33 MB sum table of the fragment filter took 0.84 ms beside the lanes' floods, the three tables together 1.7 ms of a block's
+// 22 ms chain, and every launch is host time of the one thread that queues all lanes (kernel trace of the driver's job).
+constexpr int kMaxFills = 6;
+struct FillList {
+  uint32_t* p[kMaxFills];
+  size_t words[kMaxFills];
+  uint32_t value[kMaxFills];
+  int n;
+};
+__global__ __launch_bounds__(256) void fill_list_kernel(FillList L) {
+  const size_t stride = (size_t)gridDim.x * blockDim.x, t0 = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  for (int j = 0; j < L.n; ++j) {
+    uint32_t* p = L.p[j];
+    const size_t w = L.words[j];
+    const uint32_t v = L.value[j];
+    size_t head = (size_t)((0 - (uintptr_t)p) >> 2) & 3;  // words up to 16-byte alignment
+    head = head < w ? head : w;
+    if (t0 < head) p[t0] = v;
+    uint4* q = (uint4*)(p + head);
+    const size_t nv = (w - head) >> 2;
+    for (size_t i = t0; i < nv; i += stride) q[i] = make_uint4(v, v, v, v);
+    const size_t done = head + 4 * nv;
+    if (t0 < w - done) p[done + t0] = v;
+  }
+}
+struct Fills {
+  FillList L{};
+  size_t most = 0;
+  void add(void* p, size_t bytes, uint32_t value = 0) {  // 4-byte aligned, whole words (every table here is)
+    L.p[L.n] = (uint32_t*)p; L.words[L.n] = bytes / 4; L.value[L.n] = value; ++L.n;
+    most = std::max(most, bytes / 16);
+  }
+  void launch(hipStream_t s) const {
+    const unsigned grid = (unsigned)std::min<size_t>((most + 255) / 256 + 1, 2048);
+    hipLaunchKernelGGL(fill_list_kernel, dim3(grid), dim3(256), 0, s, L);
+  }
+};
+
 int seg_scan_grid() {
   static const int g = [] { const char* e = getenv("BSMI_SEG_SCAN_GRID"); const int v = e ? atoi(e) : 32; return v < 1 ? 1 : v; }();
   return g;
@@ -2491,10 +2552,16 @@ int bsmi_frag_postprocess_u8(bsmi_seg* h, const uint8_t* affs_dev, uint64_t* fra
   const int bs = 256;
   const int grid = (int)std::min<size_t>((n + bs - 1) / bs, 4096);
   const int gridc = (int)std::min<size_t>((nc + bs - 1) / bs, 4096);
-  BSMI_HIP(hipMemsetAsync(f.flags, 0, 4 * sizeof(uint32_t), s));
+  {
+    Fills fl;
+    fl.add(f.flags, 4 * sizeof(uint32_t));
+    if (filter_value > 0.0 || min_size > 0) {
+      fl.add(f.lsum, (size_t)f.id_cap * sizeof(unsigned long long));
+      fl.add(f.lcnt, (size_t)f.id_cap * sizeof(uint32_t));
+    }
+    fl.launch(s);
+  }
   if (filter_value > 0.0 || min_size > 0) {
-    BSMI_HIP(hipMemsetAsync(f.lsum, 0, (size_t)f.id_cap * sizeof(unsigned long long), s));
-    BSMI_HIP(hipMemsetAsync(f.lcnt, 0, (size_t)f.id_cap * sizeof(uint32_t), s));
     hipLaunchKernelGGL(frag_stats_kernel, dim3(grid), dim3(bs), 0, s, affs_dev, (const uint64_t*)frags_dev, n, f);
     hipLaunchKernelGGL(frag_decide_kernel, dim3(grid), dim3(bs), 0, s, affs_dev, (const uint64_t*)frags_dev, n, f, filter_value,
                        (long long)min_size);
@@ -2523,8 +2590,12 @@ int bsmi_label_stats(bsmi_seg* h, const uint64_t* labels_dev, const int64_t shap
   BSMI_HIP(hipSetDevice(h->device));
   hipStream_t s = (hipStream_t)stream;
   const size_t n = (size_t)shape[0] * shape[1] * shape[2];
-  BSMI_HIP(hipMemsetAsync(size_dev, 0, num * sizeof(uint64_t), s));
-  BSMI_HIP(hipMemsetAsync(sums_dev, 0, 3 * num * sizeof(uint64_t), s));
+  {
+    Fills fl;
+    fl.add(size_dev, num * sizeof(uint64_t));
+    fl.add(sums_dev, 3 * num * sizeof(uint64_t));
+    fl.launch(s);
+  }
   const int bs = 256;
   hipLaunchKernelGGL(label_stats_kernel, dim3((int)std::min<size_t>((n + bs - 1) / bs, 4096)), dim3(bs), 0, s, labels_dev,
                      (int)shape[0], (int)shape[1], (int)shape[2], id_offset, num, (unsigned long long*)size_dev,
@@ -2540,12 +2611,16 @@ static int rag_build_and_merge(bsmi_seg* h, const uint8_t* affs_dev, const uint6
   const size_t n = (size_t)shape[0] * shape[1] * shape[2];
   const int D = (int)shape[0], H = (int)shape[1], W = (int)shape[2];
   AggWs& g = h->agg;
-  BSMI_HIP(hipMemsetAsync(g.counters, 0, 8 * sizeof(uint32_t), s));
-  if (counts_dev) BSMI_HIP(hipMemsetAsync(counts_dev, 0, 3 * sizeof(uint64_t), s));
-  BSMI_HIP(hipMemsetAsync(g.idkeys, 0xff, (size_t)g.icap * sizeof(uint64_t), s));
-  BSMI_HIP(hipMemsetAsync(g.hkeys, 0xff, (size_t)g.hcap * sizeof(uint64_t), s));
-  BSMI_HIP(hipMemsetAsync(g.hsum, 0, (size_t)g.hcap * sizeof(unsigned long long), s));
-  BSMI_HIP(hipMemsetAsync(g.hcnt, 0, (size_t)g.hcap * sizeof(uint32_t), s));
+  {
+    Fills fl;
+    fl.add(g.counters, 8 * sizeof(uint32_t));
+    if (counts_dev) fl.add(counts_dev, 3 * sizeof(uint64_t));
+    fl.add(g.idkeys, (size_t)g.icap * sizeof(uint64_t), 0xffffffffu);
+    fl.add(g.hkeys, (size_t)g.hcap * sizeof(uint64_t), 0xffffffffu);
+    fl.add(g.hsum, (size_t)g.hcap * sizeof(unsigned long long));
+    fl.add(g.hcnt, (size_t)g.hcap * sizeof(uint32_t));
+    fl.launch(s);
+  }
   const int bs = 256;
   const int grid = (int)std::min<size_t>((n + bs - 1) / bs, 4096);
   hipLaunchKernelGGL(rag_ids_kernel, dim3(grid), dim3(bs), 0, s, frags_dev, n, W, g);

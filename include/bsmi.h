@@ -305,8 +305,9 @@ int bsmi_rag_graph_u8(bsmi_seg *h, const uint8_t *affs_dev, const uint64_t *frag
                       uint64_t *edges_dev, uint64_t *sums_dev, uint32_t *pair_counts_dev, uint64_t edge_capacity,
                       uint64_t *counts_dev, void *stream);
 /* waterz_agglom.py:106-170 on the host for n_graphs graphs of bsmi_rag_graph_u8 (host copies) side by side on up to n_threads
- * threads (<= 0: 16): agglomeration to `threshold` with OneMinus<MeanAffinity> and a `discretize_queue`-bin queue, every edge's
- * score read off the merge tree (NaN: its fragments never merged) -> scores[g][e].  Same results as bsmi_rag_merge_scores_u8. */
+ * threads (<= 0: 24), largest first: agglomeration to `threshold` with OneMinus<MeanAffinity> and a `discretize_queue`-bin queue,
+ * every edge's score = the score at which its two regions merged (NaN: never) -> scores[g][e].  Same results as
+ * bsmi_rag_merge_scores_u8. */
 int bsmi_rag_merge_scores_host(int n_graphs, const uint64_t *n_edges, const uint64_t *const *edges, const uint64_t *const *sums,
                                const uint32_t *const *pair_counts, float threshold, int discretize_queue, float *const *scores,
                                int n_threads);

@@ -11,8 +11,8 @@ ev = sorted((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"
 heads = [e for e in ev if "head_kernel" in e[2]]
 t0 = heads[nheads - 1][1]
 relabels = [e for e in ev if "lut_relabel" in e[2] and e[0] > t0]
-t1 = relabels[2][1]
-print(f"tail: last predicted block -> third relabel = {(t1 - t0) / 1e6:.1f} ms")
+t1 = relabels[0][1] if "multi" in relabels[0][2] else relabels[2][1]
+print(f"tail: last predicted block -> end of the relabel = {(t1 - t0) / 1e6:.1f} ms")
 win = [e for e in ev if e[0] >= t0 and e[1] <= t1]
 GROUPS = [("seeds", ("ws_seeds",)), ("flood", ("ws_flood",)), ("frag post", ("frag_", "cc26_", "crop_u64", "label_stats", "ws_offsets")),
           ("rag scans", ("rag_ids", "agg_edges", "agg_compact", "rag_", "rocprim", "seg_clear")), ("merge loop", ("rag_merge_kernel",)),
