@@ -386,7 +386,7 @@ def main():
     ap.add_argument("--precision", default="bf16x3", choices=["bf16x3", "bf16", "f32"],
                     help="bf16x3 (default): split bf16, within the 1e-4 parity gate; bf16: throughput mode (4e-3); f32: exact f32 MFMA")
     ap.add_argument("--volume", type=int, default=1024, help="edge of the synthetic cubic volume")
-    ap.add_argument("--seg-lanes", type=int, default=16, help="blocks of a segmentation stage in flight side by side")
+    ap.add_argument("--seg-lanes", type=int, default=20, help="blocks of a segmentation stage in flight side by side")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="process-group backend for N > 1: nccl (= RCCL, the real thing) or gloo (rehearsal on a box with fewer GPUs)")
     ap.add_argument("--force-dist", action="store_true",

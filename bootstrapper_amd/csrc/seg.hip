@@ -35,9 +35,13 @@ namespace bsmi {
 // ------------------------------------------------------------------------------------------
 constexpr int WS_T = 1024;           // threads per slice workgroup (seeds kernel): 16 waves, so that its LDS loops hide their latency
 #ifndef BSMI_FLOOD_WAVES
-#define BSMI_FLOOD_WAVES 16
+#define BSMI_FLOOD_WAVES 8
 #endif
-constexpr int FLOOD_WAVES = BSMI_FLOOD_WAVES;  // slices per flood workgroup (one wave each): a workgroup pins its CU, so pack it (dev builds: 8, 4)
+// slices per flood workgroup (one wave each).  8, i.e. 20 workgroups of 64 KB of LDS per 160-slice block, two to a CU: with the
+// stages run one after the other (the default) the chip is the lanes' alone, and spread over twice the CUs the floods of 20
+// blocks side by side finish in 32 ms where 16 waves per workgroup took 41 (4 waves: as 8).  16 suited the overlapped mode, where
+// a flood workgroup keeps a convolution workgroup off its CU.
+constexpr int FLOOD_WAVES = BSMI_FLOOD_WAVES;
 constexpr int FLOOD_LDS_HEAP = 1024; // heap entries per slice kept in LDS (8 B each); the rest spills to HBM
 
 __device__ __forceinline__ int reflect_dup(int i, int n) {

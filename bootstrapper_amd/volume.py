@@ -417,7 +417,8 @@ class SlabSegmenter:
             C = self.scores.view(torch.int32)[:, :m].cpu().numpy()
             sc = rag_merge_scores_host(n_edges, E, S, C, 1.0, self.bins)
             take = np.arange(m)[None, :] < n_edges[:, None]
-            own = take & ((E[:, :, 0].astype(np.int64) - 1) // self.nvb == np.asarray(self.block_ids, np.int64)[:, None])
+            first = (np.asarray(self.block_ids, np.uint64) * np.uint64(self.nvb) + np.uint64(1))[:, None]   # a block's ids: first .. first + nvb - 1
+            own = take & (E[:, :, 0] >= first) & (E[:, :, 0] < first + np.uint64(self.nvb))
             self.rag_edges = np.ascontiguousarray(E[own])
             self.rag_scores = np.ascontiguousarray(sc[own])
             return len(self.rag_scores)
@@ -707,7 +708,7 @@ class VolumePipeline:
     """Predict + segment a box of blocks of a raw volume resident in HBM: this rank's slab of the job."""
 
     def __init__(self, model, out_block, net_context, job_blocks, seg_context=(16, 16, 16), thresholds=(0.2, 0.35, 0.5),
-                 min_seed_distance=10, filter_fragments=0.0, remove_debris=0, n_lanes=16, device=0, rank=0, world=1,
+                 min_seed_distance=10, filter_fragments=0.0, remove_debris=0, n_lanes=20, device=0, rank=0, world=1,
                  group=None, job_origin=(0, 0, 0), segment=True, overlap=False, obj_group=None):
         """job_blocks: (layers per rank, blocks in y, blocks in x): the job is `world` such slabs stacked along z,
         its first voxel at `job_origin` of the raw volume."""
