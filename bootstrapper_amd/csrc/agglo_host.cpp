@@ -348,8 +348,37 @@ void rag_merge_scores_one(uint64_t ne, const uint64_t* edges, const uint64_t* su
 
 }  // namespace bsmi
 
-extern "C" int bsmi_rag_merge_scores_host(int n_graphs, const uint64_t* n_edges, const uint64_t* const* edges, const uint64_t* const* sums,
-                                          const uint32_t* const* counts, float threshold, int discretize_queue, float* const* scores,
+namespace bsmi {
+namespace {
+// a graph as bsmi_rag_graph_u8 leaves it (edge hash table order) -> ascending (id, id) order, in place: the order the merge loop's
+// queue is filled in, and the one the device loop and the oracle number their edges in
+void sort_graph(uint64_t ne, uint64_t* edges, uint64_t* sums, uint32_t* cnts) {
+  bool sorted = true;
+  for (uint64_t e = 1; e < ne && sorted; ++e)
+    sorted = edges[2 * e - 2] < edges[2 * e] || (edges[2 * e - 2] == edges[2 * e] && edges[2 * e - 1] <= edges[2 * e + 1]);
+  if (sorted) return;
+  std::vector<uint32_t> perm(ne);
+  for (uint64_t e = 0; e < ne; ++e) perm[e] = (uint32_t)e;
+  std::sort(perm.begin(), perm.end(), [&](uint32_t x, uint32_t y) {
+    return edges[2 * (size_t)x] != edges[2 * (size_t)y] ? edges[2 * (size_t)x] < edges[2 * (size_t)y] : edges[2 * (size_t)x + 1] < edges[2 * (size_t)y + 1];
+  });
+  std::vector<uint64_t> e2(2 * ne), s2(ne);
+  std::vector<uint32_t> c2(ne);
+  for (uint64_t e = 0; e < ne; ++e) {
+    e2[2 * e] = edges[2 * (size_t)perm[e]];
+    e2[2 * e + 1] = edges[2 * (size_t)perm[e] + 1];
+    s2[e] = sums[perm[e]];
+    c2[e] = cnts[perm[e]];
+  }
+  std::copy(e2.begin(), e2.end(), edges);
+  std::copy(s2.begin(), s2.end(), sums);
+  std::copy(c2.begin(), c2.end(), cnts);
+}
+}  // namespace
+}  // namespace bsmi
+
+extern "C" int bsmi_rag_merge_scores_host(int n_graphs, const uint64_t* n_edges, uint64_t* const* edges, uint64_t* const* sums,
+                                          uint32_t* const* counts, float threshold, int discretize_queue, float* const* scores,
                                           int n_threads) {
   if (n_graphs < 0 || (n_graphs && (!n_edges || !edges || !sums || !counts || !scores)) || discretize_queue < 1 || discretize_queue > 1024 ||
       !(threshold > 0.f))
@@ -368,6 +397,7 @@ extern "C" int bsmi_rag_merge_scores_host(int n_graphs, const uint64_t* n_edges,
   auto work = [&] {
     for (int i = next.fetch_add(1); i < n_graphs; i = next.fetch_add(1)) {
       const int g = order[i];
+      bsmi::sort_graph(n_edges[g], edges[g], sums[g], counts[g]);
       bsmi::rag_merge_scores_one(n_edges[g], edges[g], sums[g], counts[g], threshold, discretize_queue, scores[g]);
     }
   };

@@ -71,7 +71,7 @@ struct WsScratch {
 // 160 x 160); LDS = false: same algorithm on the global scratch arrays (any slice size).
 template <bool LDS>
 __global__ __launch_bounds__(WS_T) void ws_seeds_kernel(const uint8_t* __restrict__ affs, int D, int H, int W,
-                                                        int msd, WsScratch s) {
+                                                        int msd, WsScratch s, int compact) {
   extern __shared__ __attribute__((aligned(16))) char ws_smem[];
   const int z = blockIdx.x;
   const int n = H * W;
@@ -96,8 +96,13 @@ __global__ __launch_bounds__(WS_T) void ws_seeds_kernel(const uint8_t* __restric
   // flag byte per voxel (is a maximum / is a root).  LDS: sg u16 [H][W+2] | sd2 u16 [H*W] | smask u8 [H*W] | sflag u8 [H*W].
   uint8_t* smask = nullptr;
   uint8_t* sflag = nullptr;
+  const uint16_t* sd2_lds = nullptr;
+  // compact (LDS path only): the flood's state of a voxel is ONE 32-bit record in `lab` -- marker label | squared distance << 16,
+  // inside the mask <=> distance > 0 -- instead of three arrays (see ws_flood_kernel); mask and d2 then stay out of HBM
+  if constexpr (!LDS) compact = 0;
   if constexpr (LDS) {
     const size_t o_sd2 = ((size_t)H * (W + 2) * 2 + 15) & ~(size_t)15;
+    sd2_lds = (const uint16_t*)(ws_smem + o_sd2);
     const size_t o_mask = (o_sd2 + (size_t)n * 2 + 15) & ~(size_t)15;
     smask = (uint8_t*)(ws_smem + o_mask);
     sflag = smask + (((size_t)n + 15) & ~(size_t)15);
@@ -106,7 +111,7 @@ __global__ __launch_bounds__(WS_T) void ws_seeds_kernel(const uint8_t* __restric
   int bg = 0;
   for (int i = tid; i < n; i += WS_T) {
     const int m = (int)ay[i] + (int)ax[i] >= 256;
-    mask[i] = (uint8_t)m;
+    if (!compact) mask[i] = (uint8_t)m;
     if constexpr (LDS) smask[i] = (uint8_t)m;
     bg |= !m;
   }
@@ -153,14 +158,14 @@ __global__ __launch_bounds__(WS_T) void ws_seeds_kernel(const uint8_t* __restric
           }
         }
         sd2[i] = (uint16_t)best;
-        d2[i] = best;
+        if (!compact) d2[i] = best;
       }
     } else {
       for (int i = tid; i < n; i += WS_T) {
         const int y = i / W, x = i - y * W;
         const int v = (y + 1) * (y + 1) + x * x;
         sd2[i] = (uint16_t)v;
-        d2[i] = v;
+        if (!compact) d2[i] = v;
       }
     }
     __syncthreads();
@@ -346,7 +351,8 @@ __global__ __launch_bounds__(WS_T) void ws_seeds_kernel(const uint8_t* __restric
     } else if (s.seedlab) {
       s.seedlab[(size_t)z * n + i] = 0;
     }
-    lab[i] = l;
+    if (compact) ((uint32_t*)lab)[i] = (uint32_t)l | ((uint32_t)sd2_lds[i] << 16);
+    else lab[i] = l;
   }
 }
 
@@ -368,6 +374,11 @@ __device__ __forceinline__ uint64_t bcast0(uint64_t v) {
 // Ordering ignores the index bits (skimage compares (value, age) only).
 __device__ __forceinline__ bool flood_smaller(uint64_t a, uint64_t b) { return (a >> 20) < (b >> 20); }
 
+// COMPACT: a voxel's state is the 32-bit record ws_seeds_kernel leaves in `lab` (label | squared distance << 16; in the mask <=>
+// distance > 0): a pop touches three cache lines (the rows above, of and below the voxel) instead of nine, and a slice is 100 KB
+// instead of 230 -- side by side, the floods of a stage's blocks are bound by the lines they pull through L2, not by one wave's
+// latency chain.
+template <bool COMPACT>
 __global__ __launch_bounds__(64 * FLOOD_WAVES) void ws_flood_kernel(int D, int H, int W, WsScratch s, uint64_t* heap_spill,
                                                      size_t spill_stride, uint64_t* __restrict__ frags, int* status) {
   __shared__ uint64_t hl_all[FLOOD_WAVES][FLOOD_LDS_HEAP];
@@ -416,15 +427,17 @@ __global__ __launch_bounds__(64 * FLOOD_WAVES) void ws_flood_kernel(int D, int H
       hset(c, it);
     };
     // seeds in raster order, age 0
+    uint32_t* rec = (uint32_t*)lab;
     for (int i0 = 0; i0 < n; i0 += 64) {
       const int i = i0 + lane;
-      const int li = i < n ? lab[i] : 0;
+      const int li = i < n ? (COMPACT ? (int)(rec[i] & 0xffffu) : lab[i]) : 0;
       unsigned long long seeds = __ballot(li != 0);
       while (seeds) {
         const int k = __ffsll(seeds) - 1;
         seeds &= seeds - 1;
         const int j = i0 + k;
-        push(((MAXD2 - (uint64_t)d2[j]) << 40) | (uint64_t)j);
+        const uint64_t dj = COMPACT ? (uint64_t)(rec[j] >> 16) : (uint64_t)d2[j];
+        push(((MAXD2 - dj) << 40) | (uint64_t)j);
       }
     }
     uint32_t age = 0;
@@ -441,10 +454,18 @@ __global__ __launch_bounds__(64 * FLOOD_WAVES) void ws_flood_kernel(int D, int H
       const int qk = okk ? idx + dq : idx;
       int lme = 0, mk = 0, lk = 0, dk = 0;
       if (lane < 4) {
-        lme = lab[idx];
-        mk = mask[qk];
-        lk = lab[qk];
-        dk = d2[qk];
+        if constexpr (COMPACT) {
+          const uint32_t rme = rec[idx], rk = rec[qk];
+          lme = (int)(rme & 0xffffu);
+          lk = (int)(rk & 0xffffu);
+          dk = (int)(rk >> 16);
+          mk = dk != 0;
+        } else {
+          lme = lab[idx];
+          mk = mask[qk];
+          lk = lab[qk];
+          dk = d2[qk];
+        }
       }
       const int l = __builtin_amdgcn_readfirstlane(lme);
       if (items > 0) {
@@ -475,7 +496,10 @@ __global__ __launch_bounds__(64 * FLOOD_WAVES) void ws_flood_kernel(int D, int H
         const int q = __shfl(qk, k);
         const uint64_t dd = (uint64_t)(uint32_t)__shfl(dk, k);
         ++age;
-        if (lane < 4) lab[q] = l;
+        if (lane < 4) {
+          if constexpr (COMPACT) rec[q] = (uint32_t)l | ((uint32_t)dd << 16);
+          else lab[q] = l;
+        }
         push(((MAXD2 - dd) << 40) | ((uint64_t)age << 20) | (uint64_t)q);
       }
     }
@@ -487,7 +511,7 @@ __global__ __launch_bounds__(64 * FLOOD_WAVES) void ws_flood_kernel(int D, int H
   const uint64_t off = s.offs[z];
   uint64_t* out = frags + (size_t)z * n;
   for (int i = lane; i < n; i += 64) {
-    const int l = lab[i];
+    const int l = COMPACT ? (int)(((const uint32_t*)lab)[i] & 0xffffu) : lab[i];
     out[i] = l ? (uint64_t)l + off : 0ull;
   }
   (void)status;
@@ -1032,7 +1056,12 @@ __global__ void rag_ids_kernel(const uint64_t* __restrict__ frags, size_t n, int
       const unsigned long long old = atomicCAS((unsigned long long*)&w.idkeys[s], HEMPTY, f);
       if (old == HEMPTY) {
         const uint32_t i = atomicAdd(&w.counters[0], 1u);
-        if (i < w.node_cap) w.idu[i] = f; else atomicOr(&w.counters[3], 2u);
+        if (i < w.node_cap) {
+          w.idu[i] = f;
+          w.idvals[s] = i;  // number in order of insertion (bsmi_rag_graph_u8 works with these; rag_rank_kernel replaces them by ranks)
+        } else {
+          atomicOr(&w.counters[3], 2u);
+        }
         done = true;
         break;
       }
@@ -1463,28 +1492,27 @@ __global__ void rag_scores_kernel(AggWs w, uint64_t* __restrict__ edges, float* 
     }
 }
 
-// the region graph as it stands after rag_compact_kernel, for a merge loop elsewhere (agglo_host.cpp: bsmi_rag_merge_scores_host):
-// edge e in the order of its (rank, rank) key = ascending (id, id); affinity sum and voxel-pair count of its faces
-__global__ void rag_graph_out_kernel(AggWs w, uint64_t* __restrict__ edges, uint64_t* __restrict__ sums, uint32_t* __restrict__ cnts,
-                                     uint64_t cap, uint64_t* __restrict__ counts) {
+// The region graph straight out of the edge hash table, for bsmi_rag_graph_u8: nodes carry the numbers rag_ids_kernel gave them
+// (insertion order), edges leave in table order; bsmi_rag_merge_scores_host brings them into ascending (id, id) order.  No sort
+// on the device: the two radix sorts of the ordered form are 46 of its 60 launches, and a block's task is launch-bound.
+__global__ void rag_graph_hash_out_kernel(AggWs w, uint64_t* __restrict__ edges, uint64_t* __restrict__ sums, uint32_t* __restrict__ cnts,
+                                          uint64_t cap, uint64_t* __restrict__ counts) {
   keep_overflow(w);
   if (w.counters[3]) return;
-  const uint32_t nn = w.counters[0];
-  const uint32_t ne = min(w.counters[1], w.edge_cap);
-  if (blockIdx.x == 0 && threadIdx.x == 0) { counts[0] = ne; counts[1] = 0; counts[2] = nn; }
-  if (ne > cap) {  // the caller's buffers are too small: say so, and how many entries the block needs (counts[0] > capacity)
-    if (blockIdx.x == 0 && threadIdx.x == 0) {
-      atomicOr(&w.counters[3], 32u);
+  if (blockIdx.x == 0 && threadIdx.x == 0) counts[2] = w.counters[0];
+  for (uint32_t sl = blockIdx.x * blockDim.x + threadIdx.x; sl < w.hcap; sl += gridDim.x * blockDim.x) {
+    const uint64_t key = w.hkeys[sl];
+    if (key == HEMPTY) continue;
+    const unsigned long long e = atomicAdd((unsigned long long*)&counts[0], 1ull);  // (zeroed with the call's tables)
+    if (e >= cap) {  // the caller's buffers are too small: say so; counts[0] ends at the number of entries the block needs
       atomicOr(w.sticky, 32u);
+      continue;
     }
-    return;
-  }
-  for (uint32_t e = blockIdx.x * blockDim.x + threadIdx.x; e < ne; e += gridDim.x * blockDim.x) {
-    const uint64_t key = w.ekey0[e];
-    edges[2 * (size_t)e] = w.ids[(uint32_t)(key >> 32)];
-    edges[2 * (size_t)e + 1] = w.ids[(uint32_t)key];
-    sums[e] = w.esum[e];
-    cnts[e] = w.ecnt[e];
+    const uint64_t a = w.idu[(uint32_t)(key >> 32)], b = w.idu[(uint32_t)key];
+    edges[2 * (size_t)e] = a < b ? a : b;
+    edges[2 * (size_t)e + 1] = a < b ? b : a;
+    sums[e] = w.hsum[sl];
+    cnts[e] = w.hcnt[sl];
   }
 }
 
@@ -2388,6 +2416,7 @@ int bsmi_ws_fragments_seeds_u8(bsmi_seg* h, const uint8_t* affs_dev, const int64
     return BSMI_OK;
   }
   WsScratch wsx = h->ws;
+  bool compact = false;  // the flood's per-voxel state as one 32-bit record (set with the seeds kernel's LDS path below)
   wsx.seedlab = nullptr;
   if (seeds_dev) {
     if (!h->seedlab) {  // allocated on first use
@@ -2404,6 +2433,9 @@ int bsmi_ws_fragments_seeds_u8(bsmi_seg* h, const uint8_t* affs_dev, const int64
     const size_t hw16 = ((size_t)H * W + 15) & ~(size_t)15;
     const size_t lds = (((size_t)H * (W + 2) * 2 + 15) & ~(size_t)15) + (((size_t)H * W * 2 + 15) & ~(size_t)15) + 2 * hw16;
     const bool use_lds = lds <= 158 * 1024 && (size_t)H * H + (size_t)W * W < 65535 && (H + 1) * (H + 1) + W * W < 65535;
+    // (then also H * W < 32768: a slice's marker labels and voxel indices fit the compact record's 16 bits)
+    static const bool compact_ok = [] { const char* e = getenv("BSMI_FLOOD_COMPACT"); return !(e && e[0] == '0'); }();
+    compact = use_lds && compact_ok;
     if (use_lds) {
       static DeviceOnce once;
       const int rc_once = once.run([&]() -> int {
@@ -2411,17 +2443,21 @@ int bsmi_ws_fragments_seeds_u8(bsmi_seg* h, const uint8_t* affs_dev, const int64
         return BSMI_OK;
       });
       if (rc_once) return rc_once;
-      hipLaunchKernelGGL(ws_seeds_kernel<true>, dim3(D), dim3(WS_T), lds, s, affs_dev, D, H, W, min_seed_distance, wsx);
+      hipLaunchKernelGGL(ws_seeds_kernel<true>, dim3(D), dim3(WS_T), lds, s, affs_dev, D, H, W, min_seed_distance, wsx, compact ? 1 : 0);
     } else {
-      hipLaunchKernelGGL(ws_seeds_kernel<false>, dim3(D), dim3(WS_T), 0, s, affs_dev, D, H, W, min_seed_distance, wsx);
+      hipLaunchKernelGGL(ws_seeds_kernel<false>, dim3(D), dim3(WS_T), 0, s, affs_dev, D, H, W, min_seed_distance, wsx, 0);
     }
   }
   hipLaunchKernelGGL(ws_offsets_kernel, dim3(1), dim3(64), 0, s, D, h->ws, max_id_dev);
   if (seeds_dev)
     hipLaunchKernelGGL(ws_seeds_out_kernel, dim3((unsigned)std::min<size_t>(((size_t)D * H * W + 255) / 256, 4096)), dim3(256), 0, s, D,
                        (size_t)H * W, wsx, seeds_dev);
-  hipLaunchKernelGGL(ws_flood_kernel, dim3((D + FLOOD_WAVES - 1) / FLOOD_WAVES), dim3(64 * FLOOD_WAVES), 0, s, D, H, W, h->ws, h->flood_spill, h->flood_spill_stride,
-                     frags_dev, h->status_dev);
+  if (compact)
+    hipLaunchKernelGGL(ws_flood_kernel<true>, dim3((D + FLOOD_WAVES - 1) / FLOOD_WAVES), dim3(64 * FLOOD_WAVES), 0, s, D, H, W, h->ws, h->flood_spill,
+                       h->flood_spill_stride, frags_dev, h->status_dev);
+  else
+    hipLaunchKernelGGL(ws_flood_kernel<false>, dim3((D + FLOOD_WAVES - 1) / FLOOD_WAVES), dim3(64 * FLOOD_WAVES), 0, s, D, H, W, h->ws, h->flood_spill,
+                       h->flood_spill_stride, frags_dev, h->status_dev);
   BSMI_HIP(hipGetLastError());
   return BSMI_OK;
 }
@@ -2610,7 +2646,7 @@ int bsmi_label_stats(bsmi_seg* h, const uint64_t* labels_dev, const int64_t shap
 
 // ids -> ranks, region graph, bin-queue merge loop up to `threshold` (the common front of the two RAG entry points)
 static int rag_build_and_merge(bsmi_seg* h, const uint8_t* affs_dev, const uint64_t* frags_dev, const int64_t shape[3], float threshold,
-                               int discretize_queue, uint64_t* counts_dev, hipStream_t s, bool merge = true) {
+                               int discretize_queue, uint64_t* counts_dev, hipStream_t s) {
   BSMI_HIP(hipSetDevice(h->device));
   const size_t n = (size_t)shape[0] * shape[1] * shape[2];
   const int D = (int)shape[0], H = (int)shape[1], W = (int)shape[2];
@@ -2638,7 +2674,7 @@ static int rag_build_and_merge(bsmi_seg* h, const uint8_t* affs_dev, const uint6
   BSMI_HIP(hipcub::DeviceRadixSort::SortPairs(h->sort_tmp, tb, (const uint64_t*)g.hkeys, g.skeys, (const uint32_t*)g.iota, g.sslot,
                                               (int)g.hcap, 0, 64, s));
   hipLaunchKernelGGL(rag_compact_kernel, dim3(std::min<uint32_t>(g.hcap / bs, 2048u)), dim3(bs), 0, s, g);
-  if (merge) hipLaunchKernelGGL(rag_merge_kernel, dim3(8), dim3(64), 0, s, g, threshold, discretize_queue, agg_fast_enabled() ? 1 : 0);
+  hipLaunchKernelGGL(rag_merge_kernel, dim3(8), dim3(64), 0, s, g, threshold, discretize_queue, agg_fast_enabled() ? 1 : 0);
   return BSMI_OK;
 }
 
@@ -2648,9 +2684,25 @@ int bsmi_rag_graph_u8(bsmi_seg* h, const uint8_t* affs_dev, const uint64_t* frag
   if (rc) return rc;
   if (!affs_dev || !frags_dev || !edges_dev || !sums_dev || !pair_counts_dev || !counts_dev) BSMI_FAIL(BSMI_ERR_INVALID, "null argument");
   hipStream_t s = (hipStream_t)stream;
-  rc = rag_build_and_merge(h, affs_dev, frags_dev, shape, 1.f, 1, counts_dev, s, /*merge=*/false);
-  if (rc) return rc;
-  hipLaunchKernelGGL(rag_graph_out_kernel, dim3(256), dim3(256), 0, s, h->agg, edges_dev, sums_dev, pair_counts_dev, edge_capacity, counts_dev);
+  BSMI_HIP(hipSetDevice(h->device));
+  const size_t n = (size_t)shape[0] * shape[1] * shape[2];
+  AggWs& g = h->agg;
+  {
+    Fills fl;
+    fl.add(g.counters, 8 * sizeof(uint32_t));
+    fl.add(counts_dev, 3 * sizeof(uint64_t));
+    fl.add(g.idkeys, (size_t)g.icap * sizeof(uint64_t), 0xffffffffu);
+    fl.add(g.hkeys, (size_t)g.hcap * sizeof(uint64_t), 0xffffffffu);
+    fl.add(g.hsum, (size_t)g.hcap * sizeof(unsigned long long));
+    fl.add(g.hcnt, (size_t)g.hcap * sizeof(uint32_t));
+    fl.launch(s);
+  }
+  const int bs = 256;
+  const int grid = (int)std::min<size_t>((n + bs - 1) / bs, 4096);
+  hipLaunchKernelGGL(rag_ids_kernel, dim3(grid), dim3(bs), 0, s, frags_dev, n, (int)shape[2], g);
+  hipLaunchKernelGGL(agg_edges_kernel<true>, dim3(grid), dim3(bs), 0, s, affs_dev, frags_dev, (int)shape[0], (int)shape[1], (int)shape[2], g);
+  hipLaunchKernelGGL(rag_graph_hash_out_kernel, dim3(std::min<uint32_t>(g.hcap / bs, 2048u)), dim3(bs), 0, s, g, edges_dev, sums_dev, pair_counts_dev,
+                     edge_capacity, counts_dev);
   BSMI_HIP(hipGetLastError());
   return BSMI_OK;
 }

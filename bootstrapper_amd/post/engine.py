@@ -243,13 +243,18 @@ class SegEngine:
 def rag_merge_scores_host(n_edges, edges, sums, pair_counts, threshold=1.0, discretize_queue=256, threads=0):
     """waterz_agglom.py:106-170 for many blocks at once on host threads (csrc/agglo_host.cpp): graphs as SegEngine.rag_graph_async
     exports them, copied to the host -- edges uint64 / int64 [G][cap][2], sums [G][cap], pair_counts uint32 / int32 [G][cap]
-    (numpy, C-contiguous), n_edges [G].  -> scores float32 [G][cap] (entries past n_edges[g] untouched: NaN)."""
+    (numpy, C-contiguous, writable), n_edges [G].  The device leaves a graph's edges in the order of its hash table: every graph
+    is first sorted by (id, id) IN PLACE -- edges, sums and pair_counts permuted together --, which is the order the scores come
+    back in.  -> scores float32 [G][cap] (entries past n_edges[g] untouched: NaN)."""
     import numpy as np
     ne = np.ascontiguousarray(n_edges, dtype=np.uint64)
     G = int(ne.shape[0])
-    e = np.ascontiguousarray(edges).view(np.uint64)
-    s = np.ascontiguousarray(sums).view(np.uint64)
-    c = np.ascontiguousarray(pair_counts).view(np.uint32)
+    for a in (edges, sums, pair_counts):
+        if not (isinstance(a, np.ndarray) and a.flags.c_contiguous and a.flags.writeable):
+            raise ValueError("edges, sums and pair_counts must be C-contiguous writable numpy arrays (they are sorted in place)")
+    e = edges.view(np.uint64)
+    s = sums.view(np.uint64)
+    c = pair_counts.view(np.uint32)
     if e.shape[:1] != (G,) or e.ndim != 3 or e.shape[2] != 2 or s.shape != e.shape[:2] or c.shape != e.shape[:2] or int(ne.max(initial=0)) > e.shape[1]:
         raise ValueError("edges [G][cap][2], sums [G][cap], pair_counts [G][cap], n_edges [G] <= cap")
     scores = np.full(e.shape[:2], np.nan, dtype=np.float32)

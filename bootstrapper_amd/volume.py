@@ -416,11 +416,15 @@ class SlabSegmenter:
             S = self.esums[:, :m].cpu().numpy()
             C = self.scores.view(torch.int32)[:, :m].cpu().numpy()
             sc = rag_merge_scores_host(n_edges, E, S, C, 1.0, self.bins)
-            take = np.arange(m)[None, :] < n_edges[:, None]
-            first = (np.asarray(self.block_ids, np.uint64) * np.uint64(self.nvb) + np.uint64(1))[:, None]   # a block's ids: first .. first + nvb - 1
-            own = take & (E[:, :, 0] >= first) & (E[:, :, 0] < first + np.uint64(self.nvb))
-            self.rag_edges = np.ascontiguousarray(E[own])
-            self.rag_scores = np.ascontiguousarray(sc[own])
+            # a block owns the edges whose smaller id is one of its own (first .. first + nvb - 1): one run of its sorted graph
+            es, ss = [], []
+            for k in range(len(self.boxes)):
+                first = np.uint64(self.block_ids[k]) * np.uint64(self.nvb) + np.uint64(1)
+                lo, hi = np.searchsorted(E[k, :n_edges[k], 0], [first, first + np.uint64(self.nvb)])
+                es.append(E[k, lo:hi])
+                ss.append(sc[k, lo:hi])
+            self.rag_edges = np.concatenate(es)
+            self.rag_scores = np.concatenate(ss)
             return len(self.rag_scores)
         ne = self.counts_dev[:, 0]
         take = torch.arange(self.edge_cap, device=self.dev)[None, :] < ne[:, None]

@@ -298,18 +298,20 @@ int bsmi_rag_merge_scores_u8(bsmi_seg *h, const uint8_t *affs_dev, const uint64_
                              void *stream);
 
 /* The region graph of a block without the merge loop, for bsmi_rag_merge_scores_host: edges_dev [edge_capacity][2] fragment id
- * pairs (smaller id first) in ascending (id, id) order, sums_dev [edge_capacity] affinity sums and pair_counts_dev
- * [edge_capacity] voxel-pair counts of their faces, counts_dev[0..2] = number of edges, 0, nodes.  bsmi_seg_status reports an
- * edge_capacity overflow (counts_dev[0] then says how many entries the block needs). */
+ * pairs (smaller id first) in the order of the device's edge table (NOT sorted, and not the same from run to run:
+ * bsmi_rag_merge_scores_host sorts), sums_dev [edge_capacity] affinity sums and pair_counts_dev [edge_capacity] voxel-pair counts
+ * of their faces, counts_dev[0..2] = number of edges, 0, nodes.  bsmi_seg_status reports an edge_capacity overflow (counts_dev[0]
+ * then says how many entries the block needs).  Four launches; the ordered form behind bsmi_rag_merge_scores_u8 is sixty. */
 int bsmi_rag_graph_u8(bsmi_seg *h, const uint8_t *affs_dev, const uint64_t *frags_dev, const int64_t shape[3],
                       uint64_t *edges_dev, uint64_t *sums_dev, uint32_t *pair_counts_dev, uint64_t edge_capacity,
                       uint64_t *counts_dev, void *stream);
 /* waterz_agglom.py:106-170 on the host for n_graphs graphs of bsmi_rag_graph_u8 (host copies) side by side on up to n_threads
- * threads (<= 0: 24), largest first: agglomeration to `threshold` with OneMinus<MeanAffinity> and a `discretize_queue`-bin queue,
- * every edge's score = the score at which its two regions merged (NaN: never) -> scores[g][e].  Same results as
- * bsmi_rag_merge_scores_u8. */
-int bsmi_rag_merge_scores_host(int n_graphs, const uint64_t *n_edges, const uint64_t *const *edges, const uint64_t *const *sums,
-                               const uint32_t *const *pair_counts, float threshold, int discretize_queue, float *const *scores,
+ * threads (<= 0: 24), largest first.  Every graph is first brought into ascending (id, id) order IN PLACE (edges, sums and
+ * pair_counts permuted together), then agglomerated to `threshold` with OneMinus<MeanAffinity> and a `discretize_queue`-bin queue;
+ * every edge's score = the score at which its two regions merged (NaN: never) -> scores[g][e], e in the sorted order.  Same
+ * results as bsmi_rag_merge_scores_u8. */
+int bsmi_rag_merge_scores_host(int n_graphs, const uint64_t *n_edges, uint64_t *const *edges, uint64_t *const *sums,
+                               uint32_t *const *pair_counts, float threshold, int discretize_queue, float *const *scores,
                                int n_threads);
 
 /* Epsilon agglomeration of a block's fragments IN PLACE (reference post/blockwise/watershed_frags.py:158-177:

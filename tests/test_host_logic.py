@@ -240,8 +240,13 @@ def test_host_merge_loop_of_the_edge_scoring_equals_the_oracle(shape, sigma, msd
     for g, (e, s, c) in enumerate(graphs):
         E[g, :len(e)], Sm[g, :len(e)], Cn[g, :len(e)] = e, s, c
     ne = np.array([len(g[0]) for g in graphs])
+    # the device hands a graph over in the order of its hash table: two of the three arrive shuffled and are sorted in place
+    for g in (0, 2):
+        perm = rng.permutation(ne[g])
+        E[g, :ne[g]], Sm[g, :ne[g]], Cn[g, :ne[g]] = E[g, perm], Sm[g, perm], Cn[g, perm]
     sc = rag_merge_scores_host(ne, E, Sm, Cn, thr, bins, threads=2)
     for g, s_ref in enumerate(refs):
+        assert np.array_equal(E[g, :ne[g]], graphs[g][0]) and np.array_equal(Sm[g, :ne[g]], graphs[g][1]) and np.array_equal(Cn[g, :ne[g]], graphs[g][2])
         assert np.array_equal(sc[g, :ne[g]].view(np.uint32), s_ref.view(np.uint32))
         assert np.isnan(sc[g, ne[g]:]).all()
     if thr < 1.0:

@@ -43,11 +43,27 @@ def _cpu(t, *a, **k):
     r = _orig_cpu(t, *a, **k); mark(f"D2H {tuple(t.shape)}"); return r
 torch.Tensor.cpu = _cpu
 wrap(W, "connected_components_multi", "components done")
+# device-side times without a profiler: an event behind every block's flood, fragment task and score task on its lane
+evs = {"flood": [], "frag task": [], "score task": []}
+def after(obj, name, kind):
+    fn = getattr(obj, name)
+    def w(*a, **k):
+        r = fn(*a, **k)
+        e = torch.cuda.Event(enable_timing=True); e.record(torch.cuda.current_stream(dev)); evs[kind].append(e)
+        return r
+    setattr(obj, name, w)
+for lane in s.lanes:
+    after(lane["engine"], "ws_fragments", "flood")
+    after(lane["engine"], "label_stats", "frag task")
+    after(lane["engine"], "rag_graph_async", "score task")
 for rep in range(3):
     ready = pipe.predict(vol)
     ready[-1].synchronize()
     del marks[:]
     _nf[0] = 0
+    for v in evs.values():
+        del v[:]
+    ev0 = torch.cuda.Event(enable_timing=True); ev0.record(torch.cuda.current_stream(dev))
     t0 = time.perf_counter()
     s.run_blocks(ready, False)
     mark("run_blocks returns")
@@ -55,3 +71,7 @@ for rep in range(3):
     mark("stitch done")
     # when did the fragment tasks finish on the device?  (events recorded at the end of each)
     print(f"rep {rep}: " + "; ".join(f"{n} {1e3 * (t - t0):.1f}" for n, t in marks))
+    for kind, es in evs.items():
+        ts = sorted(ev0.elapsed_time(e) for e in es)
+        if ts:
+            print(f"        {kind}s end (device, ms after the start): first {ts[0]:.1f}, median {ts[len(ts) // 2]:.1f}, last {ts[-1]:.1f}")
