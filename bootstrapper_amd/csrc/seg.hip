@@ -372,7 +372,11 @@ __device__ __forceinline__ uint64_t bcast0(uint64_t v) {
 
 // heap entry: [63:40] = MAXD2 - d2 (24 bit) | [39:20] = age (20 bit) | [19:0] = voxel index.
 // Ordering ignores the index bits (skimage compares (value, age) only).
-__device__ __forceinline__ bool flood_smaller(uint64_t a, uint64_t b) { return (a >> 20) < (b >> 20); }
+// (The scalar unit, where the wave-uniform flood loop runs, has no 64-bit ordered compare: the vector compare's result goes
+// through v_readfirstlane, or every index that depends on it is dragged into vector registers and exec-mask branches.)
+__device__ __forceinline__ bool flood_smaller(uint64_t a, uint64_t b) {
+  return __builtin_amdgcn_readfirstlane((int)((a >> 20) < (b >> 20))) != 0;
+}
 
 // COMPACT: a voxel's state is the 32-bit record ws_seeds_kernel leaves in `lab` (label | squared distance << 16; in the mask <=>
 // distance > 0): a pop touches three cache lines (the rows above, of and below the voxel) instead of nine, and a slice is 100 KB
@@ -382,7 +386,8 @@ template <bool COMPACT>
 __global__ __launch_bounds__(64 * FLOOD_WAVES) void ws_flood_kernel(int D, int H, int W, WsScratch s, uint64_t* heap_spill,
                                                      size_t spill_stride, uint64_t* __restrict__ frags, int* status) {
   __shared__ uint64_t hl_all[FLOOD_WAVES][FLOOD_LDS_HEAP];
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int z = blockIdx.x * FLOOD_WAVES + wave;
   if (z >= D) return;  // whole wave exits; no workgroup barrier is used below
   uint64_t* hl = hl_all[wave];
@@ -397,17 +402,22 @@ __global__ __launch_bounds__(64 * FLOOD_WAVES) void ws_flood_kernel(int D, int H
   // loads -- where a single lane would chain up to twelve dependent global loads per voxel.  Label stores are issued by
   // all four fetching lanes (same address, same value), so that each lane's later loads follow its own stores in program
   // order.
+  // The compiler must KNOW that the loop is uniform: every value that comes out of memory goes through v_readfirstlane /
+  // v_readlane (bcast0, uni), so that counters, heap indices and comparison results live in scalar registers and the loops
+  // branch on the scalar unit.  Left to its divergence analysis it guarded each `if` of the sift loops with exec-mask
+  // save / restore sequences -- about 100 instructions per heap level, 1000 per pop -- and the floods of a stage's blocks,
+  // three waves to a SIMD, paid for it in instruction issue (20 blocks side by side: the last flood ends after 25.6 ms instead of 29.3).
   {
     constexpr uint64_t MAXD2 = (1u << 24) - 1;
+    auto uni = [](int v) { return __builtin_amdgcn_readfirstlane(v); };
     int items = 0;
     // the heap is written by lane 0 alone; its HBM spill is also read by lane 0 alone (and broadcast), so that those loads
     // follow that lane's stores in its own program order; LDS operations of a wave execute in order anyway
     // (Tried: the first 64 entries -- the six top levels every sift-down walks -- in registers, entry i in lane i, read with
-    // v_readlane: fragments of a 128^3 block 12.7 -> 12.6 ms.  The chain of a pop is the global round trip for the
-    // neighbours' state, not the sift.  Also tried: label, distance and mask bit of a voxel packed into one 8-byte record,
-    // five loads per pop instead of thirteen: 12.6 -> 11.8 ms alone, nothing under the pipeline's 16 lanes.)
+    // v_readlane: fragments of a 128^3 block 12.7 -> 12.6 ms.  Also tried: label, distance and mask bit of a voxel packed into
+    // one 8-byte record, five loads per pop instead of thirteen: 12.6 -> 11.8 ms alone, nothing under the pipeline's 16 lanes.)
     auto hget = [&](int i) -> uint64_t {
-      if (i < FLOOD_LDS_HEAP) return hl[i];
+      if (i < FLOOD_LDS_HEAP) return bcast0(hl[i]);
       uint64_t v = 0;
       if (lane == 0) v = hg[i - FLOOD_LDS_HEAP];
       return bcast0(v);
@@ -418,11 +428,11 @@ __global__ __launch_bounds__(64 * FLOOD_WAVES) void ws_flood_kernel(int D, int H
       }
     };
     auto push = [&](uint64_t it) {
-      int c = items++;
+      int c = uni(items++);
       while (c > 0) {
         const int p = (c + 1) / 2 - 1;
         const uint64_t pv = hget(p);
-        if (flood_smaller(it, pv)) { hset(c, pv); c = p; } else break;
+        if (flood_smaller(it, pv)) { hset(c, pv); c = uni(p); } else break;  // (uni: the loop-carried index stays scalar)
       }
       hset(c, it);
     };
@@ -436,19 +446,22 @@ __global__ __launch_bounds__(64 * FLOOD_WAVES) void ws_flood_kernel(int D, int H
         const int k = __ffsll(seeds) - 1;
         seeds &= seeds - 1;
         const int j = i0 + k;
-        const uint64_t dj = COMPACT ? (uint64_t)(rec[j] >> 16) : (uint64_t)d2[j];
+        const uint64_t dj = (uint64_t)(uint32_t)uni(COMPACT ? (int)(rec[j] >> 16) : d2[j]);
         push(((MAXD2 - dj) << 40) | (uint64_t)j);
       }
     }
     uint32_t age = 0;
     const int k4 = lane & 3;
     const int dq = k4 == 0 ? -W : (k4 == 1 ? -1 : (k4 == 2 ? 1 : W));
+    // y = idx / W without the division (idx < 2^20): exact for W < 4096 with the rounded-up reciprocal
+    const bool rcp_ok = W > 1 && W < 4096;  // (W = 1: the reciprocal is 2^32)
+    const uint32_t rcpW = (uint32_t)((((uint64_t)1 << 32) + (uint32_t)W - 1) / (uint32_t)W);
     while (items > 0) {
       const uint64_t e = hget(0);
       --items;
       // the popped voxel's label and its neighbours' state are requested first: their latency hides behind the sift
       const int idx = (int)(e & 0xfffffu);
-      const int y = idx / W, x = idx - y * W;
+      const int y = rcp_ok ? (int)__umulhi((uint32_t)idx, rcpW) : idx / W, x = idx - y * W;
       // neighbour order [-W, -1, +1, +W]: lane k < 4 looks at neighbour k; the other lanes stay out of global memory
       const bool okk = k4 == 0 ? y > 0 : (k4 == 1 ? x > 0 : (k4 == 2 ? x < W - 1 : y < H - 1));
       const int qk = okk ? idx + dq : idx;
@@ -467,7 +480,6 @@ __global__ __launch_bounds__(64 * FLOOD_WAVES) void ws_flood_kernel(int D, int H
           dk = d2[qk];
         }
       }
-      const int l = __builtin_amdgcn_readfirstlane(lme);
       if (items > 0) {
         // sift the last element down from the root (skimage heappop order)
         const uint64_t last = hget(items);
@@ -475,26 +487,32 @@ __global__ __launch_bounds__(64 * FLOOD_WAVES) void ws_flood_kernel(int D, int H
         for (;;) {
           const int c1 = 2 * i + 1, c2 = c1 + 1;
           if (c1 >= items) break;
-          uint64_t v1 = hget(c1);
+          uint64_t v1, v2;
+          if (c2 < FLOOD_LDS_HEAP) {  // both children with one LDS round trip (entry c2 = items is read and not looked at)
+            const uint64_t r1 = hl[c1], r2 = hl[c2];
+            v1 = bcast0(r1);
+            v2 = bcast0(r2);
+          } else {
+            v1 = hget(c1);
+            v2 = c2 < items ? hget(c2) : 0;
+          }
           int sm = i;
           uint64_t smv = last;
           if (flood_smaller(v1, smv)) { sm = c1; smv = v1; }
-          if (c2 < items) {
-            const uint64_t v2 = hget(c2);
-            if (flood_smaller(v2, smv)) { sm = c2; smv = v2; }
-          }
+          if (c2 < items && flood_smaller(v2, smv)) { sm = c2; smv = v2; }
           if (sm == i) break;
           hset(i, smv);
-          i = sm;
+          i = uni(sm);
         }
         hset(i, last);
       }
+      const int l = uni(lme);
       const int cand = (okk && mk && lk == 0) ? 1 : 0;
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
-        if (!__shfl(cand, k)) continue;  // wave uniform
-        const int q = __shfl(qk, k);
-        const uint64_t dd = (uint64_t)(uint32_t)__shfl(dk, k);
+        if (!__builtin_amdgcn_readlane(cand, k)) continue;  // wave uniform
+        const int q = __builtin_amdgcn_readlane(qk, k);
+        const uint64_t dd = (uint64_t)(uint32_t)__builtin_amdgcn_readlane(dk, k);
         ++age;
         if (lane < 4) {
           if constexpr (COMPACT) rec[q] = (uint32_t)l | ((uint32_t)dd << 16);
