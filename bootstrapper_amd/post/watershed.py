@@ -279,7 +279,7 @@ def waterz_pipeline(config, device=None, rank=0, world=1, group=None, grid=None,
     mask = open_ds(config["mask_dataset"]) if config.get("mask_dataset") else None
     seg = SlabSegmenter((z1 - z0, y1 - y0, total_shape[2]), block_size, ctx, layers, zs[rz], thresholds, frag_params["fragments_in_xy"],
                         frag_params["min_seed_distance"], frag_params["filter_fragments"], frag_params["remove_debris"], 256,
-                        n_lanes=int(config.get("lanes", 8)), device=device, rank=rank, world=world, group=group, exchange_affs=False,
+                        n_lanes=int(config.get("lanes", 20)), device=device, rank=rank, world=world, group=group, exchange_affs=False,
                         label_cap=int(config.get("label_cap", 1 << 16)), edge_cap=int(config.get("edge_cap", 1 << 17)),
                         grid=grid, total_rows=rows, row0=ys[ry], obj_group=obj_group,
                         epsilon_agglomerate=frag_params["epsilon_agglomerate"], sigma=frag_params["sigma"],

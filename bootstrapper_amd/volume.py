@@ -92,10 +92,9 @@ def exchange_faces(low_out, high_out, low_in, high_in, lo_peer, hi_peer, group=N
 def stitch_components(nodes, edges, scores, thresholds):
     """post/watershed.py:155-186 on the host: drop unscored edges, connected components per threshold.
     -> list of component ids aligned with `nodes` (ascending uint64)."""
-    keep = ~np.isnan(scores)
-    edges, scores = edges[keep], scores[keep]
-    if edges.shape[0] == 0:
+    if edges.shape[0] == 0 or np.isnan(scores).all():
         return [nodes.copy() for _ in thresholds]
+    # (unscored edges -- NaN -- stay in the arrays: no threshold admits them, and copying 460 000 edges to drop a few was 3 ms)
     # one library call for all thresholds: the node look-up of the edges once (host threads), the unions of a lower
     # threshold carried over to the higher ones -- this is what the other ranks wait for at 8 GPUs
     from .post.watershed import connected_components_multi
