@@ -76,6 +76,43 @@ def test_fragments_bit_exact_vs_oracle(shape, sigma, msd):
     assert np.array_equal(frags.cpu().numpy().astype(np.uint64), ref)
 
 
+@pytest.mark.parametrize("shape,sigma,msd,kind", [
+    ((2, 300, 260), (0, 2, 2), 10, "blobs"),    # slices too large for the LDS form of the marker kernel: global scratch, three-array flood
+    ((3, 40, 6), (0, 1, 1), 10, "blobs"),       # filter window wider than the rows: the general reflection
+    ((2, 9, 1), (0, 1, 0), 3, "blobs"),         # one column (no reciprocal for the row index)
+    ((2, 1, 23), (0, 0, 1), 3, "blobs"),        # one row
+    ((2, 20, 30), None, 10, "full"),            # no background voxel at all (scipy's distance transform as if one sat at (-1, 0))
+    ((2, 20, 30), None, 10, "empty"),           # nothing inside the mask
+    ((2, 160, 160), None, 10, "half")])         # a straight edge: plateaus of equal distance, long runs of tied seeds
+def test_fragments_of_odd_slices_bit_exact_vs_oracle(shape, sigma, msd, kind):
+    from bootstrapper_amd.post.engine import SegEngine
+    from oracle import seg_ref as S
+    rng = np.random.default_rng(shape[1] * 3 + shape[2])
+    if kind == "blobs":
+        affs = _blobby(rng, shape, sigma)
+    elif kind == "full":
+        affs = np.full((3,) + shape, 255, np.uint8)
+    elif kind == "empty":
+        affs = np.zeros((3,) + shape, np.uint8)
+    else:
+        affs = np.zeros((3,) + shape, np.uint8)
+        affs[:, :, :, shape[2] // 3:] = 200
+    ref, ref_max = S.ws_fragments_u8(affs, True, msd)
+    frags, mx = SegEngine(shape).ws_fragments(torch.from_numpy(affs).cuda(), True, msd)
+    assert int(mx.item()) == ref_max
+    assert np.array_equal(frags.cpu().numpy().astype(np.uint64), ref)
+
+
+def test_three_array_flood_in_subprocess():
+    """BSMI_FLOOD_COMPACT=0 (read once per process): the flood on the mask / label / distance arrays instead of the 32-bit record"""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(root, "tests", "test_seg_gpu.py"), "-x", "-q", "-k",
+                        "test_fragments_bit_exact_vs_oracle or test_fragments_white_noise_heap_spill"],
+                       env=dict(os.environ, BSMI_FLOOD_COMPACT="0"), capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+
+
 def test_fragments_white_noise_heap_spill():
     """White-noise affinities: thousands of one-voxel seeds per slice -> exercises large heaps."""
     from bootstrapper_amd.post.engine import SegEngine
