@@ -526,7 +526,7 @@ def main():
                                "relabel: one consistent segmentation per threshold",
                    "blocks_per_gpu": args.steps, "job_blocks_per_gpu": list(job),
                    "parallelism": f"slabs of block layers over {world} GPU(s); face exchange of affinities and fragments, edges to rank 0, LUT broadcast",
-                   "seg_lanes": args.seg_lanes, "overlap": bool(args.overlap)},
+                   "seg_lanes": len(pipe.seg.lanes), "overlap": bool(args.overlap)},
         "predict_only": {"Mvoxels_per_s": nvox / t_pred / 1e6, "seconds": t_pred, "mfma_frac": flops_block * args.steps / t_pred / 1e12 / peak,
                          "note": "start of the timed region to the last predicted block" + ("; the segmentation lanes already run meanwhile" if args.overlap else "")},
         "roofline": {"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,

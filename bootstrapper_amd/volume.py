@@ -226,6 +226,13 @@ class SlabSegmenter:
         self.frag_done = [None] * K
         read = tuple(min(b, s) + 2 * c for b, s, c in zip(self.block, self.shape, self.ctx))
         self.lanes = []
+        # Hardware queues: the runtime keeps one per stream up to GPU_MAX_HW_QUEUES (24); past that, streams share queues and
+        # the predict stream's launches wait behind lane work.  20 lanes + the predict and default streams fit; RCCL brings
+        # streams of its own (one rank under `--force-dist`: 20 lanes 55.3 Mvoxels/s, predict 34.5 ms per block; 16 lanes
+        # 65.0, 28.9 ms), so a rank of an RCCL job stops at 16.
+        import torch.distributed as dist
+        if int(n_lanes) > 16 and dist.is_available() and dist.is_initialized() and "nccl" in str(dist.get_backend()):
+            n_lanes = 16
         for stream in lane_streams(self.dev, max(1, min(int(n_lanes), K))):
             self.lanes.append(dict(engine=SegEngine(read, self.dev.index), stream=stream,
                                    a=torch.empty((3,) + read, dtype=torch.uint8, device=self.dev),
