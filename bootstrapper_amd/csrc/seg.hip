@@ -372,11 +372,10 @@ __device__ __forceinline__ uint64_t bcast0(uint64_t v) {
 
 // heap entry: [63:40] = MAXD2 - d2 (24 bit) | [39:20] = age (20 bit) | [19:0] = voxel index.
 // Ordering ignores the index bits (skimage compares (value, age) only).
-// (The scalar unit, where the wave-uniform flood loop runs, has no 64-bit ordered compare: the vector compare's result goes
-// through v_readfirstlane, or every index that depends on it is dragged into vector registers and exec-mask branches.)
-__device__ __forceinline__ bool flood_smaller(uint64_t a, uint64_t b) {
-  return __builtin_amdgcn_readfirstlane((int)((a >> 20) < (b >> 20))) != 0;
-}
+// (The scalar unit, where the wave-uniform flood loop runs, has no 64-bit ordered compare; a vector compare and the trip of its
+// result back to a scalar register are ten instructions, and the floods of a stage's blocks side by side are bound by
+// instruction issue.  The sign of the difference of the two 44-bit keys is scalar work: two shifts, a subtract with borrow.)
+__device__ __forceinline__ bool flood_smaller(uint64_t a, uint64_t b) { return (int64_t)((a >> 20) - (b >> 20)) < 0; }
 
 // COMPACT: a voxel's state is the 32-bit record ws_seeds_kernel leaves in `lab` (label | squared distance << 16; in the mask <=>
 // distance > 0): a pop touches three cache lines (the rows above, of and below the voxel) instead of nine, and a slice is 100 KB
@@ -429,10 +428,21 @@ __global__ __launch_bounds__(64 * FLOOD_WAVES) void ws_flood_kernel(int D, int H
     };
     auto push = [&](uint64_t it) {
       int c = uni(items++);
+      if (c < FLOOD_LDS_HEAP) {  // the whole path to the root is in LDS: no range checks per level
+        while (c > 0) {
+          const int p = (c - 1) >> 1;
+          const uint64_t pv = bcast0(hl[p]);
+          if (!flood_smaller(it, pv)) break;
+          if (lane == 0) hl[c] = pv;
+          c = uni(p);  // (uni: the loop-carried index stays scalar)
+        }
+        if (lane == 0) hl[c] = it;
+        return;
+      }
       while (c > 0) {
         const int p = (c + 1) / 2 - 1;
         const uint64_t pv = hget(p);
-        if (flood_smaller(it, pv)) { hset(c, pv); c = uni(p); } else break;  // (uni: the loop-carried index stays scalar)
+        if (flood_smaller(it, pv)) { hset(c, pv); c = uni(p); } else break;
       }
       hset(c, it);
     };
@@ -484,7 +494,21 @@ __global__ __launch_bounds__(64 * FLOOD_WAVES) void ws_flood_kernel(int D, int H
         // sift the last element down from the root (skimage heappop order)
         const uint64_t last = hget(items);
         int i = 0;
-        for (;;) {
+        // the levels whose two children both exist and live in LDS (all but the last one of a heap that fits): the smaller
+        // child (the left one on a tie), then that one against `last` -- the same choice as the general form below makes
+        const int lim = items < FLOOD_LDS_HEAP ? items : FLOOD_LDS_HEAP;
+        bool placed = false;
+        while (2 * i + 2 < lim) {
+          const int c1 = 2 * i + 1;
+          const uint64_t r1 = hl[c1], r2 = hl[c1 + 1];
+          const uint64_t v1 = bcast0(r1), v2 = bcast0(r2);
+          const bool right = flood_smaller(v2, v1);
+          const uint64_t cv = right ? v2 : v1;
+          if (!flood_smaller(cv, last)) { placed = true; break; }
+          if (lane == 0) hl[i] = cv;
+          i = uni(c1 + (right ? 1 : 0));
+        }
+        for (; !placed;) {
           const int c1 = 2 * i + 1, c2 = c1 + 1;
           if (c1 >= items) break;
           uint64_t v1, v2;
