@@ -409,6 +409,15 @@ __global__ __launch_bounds__(64 * FLOOD_WAVES) void ws_flood_kernel(int D, int H
   {
     constexpr uint64_t MAXD2 = (1u << 24) - 1;
     auto uni = [](int v) { return __builtin_amdgcn_readfirstlane(v); };
+    // queue entry: [63:40] MAXD2 - d2 | [39:20] age | [19:0] voxel.  COMPACT (d2 < 2^16, fewer than 2^15 voxels, so fewer pushes):
+    // [63:48] 65535 - d2 | [47:32] age | [31:0] voxel -- the same order, and the whole key is the upper word: one scalar compare
+    auto entry = [](uint64_t dd, uint32_t age_, uint64_t q_) -> uint64_t {
+      return COMPACT ? ((65535ull - dd) << 48) | ((uint64_t)age_ << 32) | q_ : ((MAXD2 - dd) << 40) | ((uint64_t)age_ << 20) | q_;
+    };
+    auto smaller = [](uint64_t a_, uint64_t b_) -> bool {
+      if constexpr (COMPACT) return (uint32_t)(a_ >> 32) < (uint32_t)(b_ >> 32);
+      else return flood_smaller(a_, b_);
+    };
     int items = 0;
     // the heap is written by lane 0 alone; its HBM spill is also read by lane 0 alone (and broadcast), so that those loads
     // follow that lane's stores in its own program order; LDS operations of a wave execute in order anyway
@@ -432,7 +441,7 @@ __global__ __launch_bounds__(64 * FLOOD_WAVES) void ws_flood_kernel(int D, int H
         while (c > 0) {
           const int p = (c - 1) >> 1;
           const uint64_t pv = bcast0(hl[p]);
-          if (!flood_smaller(it, pv)) break;
+          if (!smaller(it, pv)) break;
           if (lane == 0) hl[c] = pv;
           c = uni(p);  // (uni: the loop-carried index stays scalar)
         }
@@ -442,7 +451,7 @@ __global__ __launch_bounds__(64 * FLOOD_WAVES) void ws_flood_kernel(int D, int H
       while (c > 0) {
         const int p = (c + 1) / 2 - 1;
         const uint64_t pv = hget(p);
-        if (flood_smaller(it, pv)) { hset(c, pv); c = uni(p); } else break;
+        if (smaller(it, pv)) { hset(c, pv); c = uni(p); } else break;
       }
       hset(c, it);
     };
@@ -457,7 +466,7 @@ __global__ __launch_bounds__(64 * FLOOD_WAVES) void ws_flood_kernel(int D, int H
         seeds &= seeds - 1;
         const int j = i0 + k;
         const uint64_t dj = (uint64_t)(uint32_t)uni(COMPACT ? (int)(rec[j] >> 16) : d2[j]);
-        push(((MAXD2 - dj) << 40) | (uint64_t)j);
+        push(entry(dj, 0u, (uint64_t)j));
       }
     }
     uint32_t age = 0;
@@ -470,7 +479,7 @@ __global__ __launch_bounds__(64 * FLOOD_WAVES) void ws_flood_kernel(int D, int H
       const uint64_t e = hget(0);
       --items;
       // the popped voxel's label and its neighbours' state are requested first: their latency hides behind the sift
-      const int idx = (int)(e & 0xfffffu);
+      const int idx = COMPACT ? (int)(uint32_t)e : (int)(e & 0xfffffu);
       const int y = rcp_ok ? (int)__umulhi((uint32_t)idx, rcpW) : idx / W, x = idx - y * W;
       // neighbour order [-W, -1, +1, +W]: lane k < 4 looks at neighbour k; the other lanes stay out of global memory
       const bool okk = k4 == 0 ? y > 0 : (k4 == 1 ? x > 0 : (k4 == 2 ? x < W - 1 : y < H - 1));
@@ -502,9 +511,9 @@ __global__ __launch_bounds__(64 * FLOOD_WAVES) void ws_flood_kernel(int D, int H
           const int c1 = 2 * i + 1;
           const uint64_t r1 = hl[c1], r2 = hl[c1 + 1];
           const uint64_t v1 = bcast0(r1), v2 = bcast0(r2);
-          const bool right = flood_smaller(v2, v1);
+          const bool right = smaller(v2, v1);
           const uint64_t cv = right ? v2 : v1;
-          if (!flood_smaller(cv, last)) { placed = true; break; }
+          if (!smaller(cv, last)) { placed = true; break; }
           if (lane == 0) hl[i] = cv;
           i = uni(c1 + (right ? 1 : 0));
         }
@@ -522,8 +531,8 @@ __global__ __launch_bounds__(64 * FLOOD_WAVES) void ws_flood_kernel(int D, int H
           }
           int sm = i;
           uint64_t smv = last;
-          if (flood_smaller(v1, smv)) { sm = c1; smv = v1; }
-          if (c2 < items && flood_smaller(v2, smv)) { sm = c2; smv = v2; }
+          if (smaller(v1, smv)) { sm = c1; smv = v1; }
+          if (c2 < items && smaller(v2, smv)) { sm = c2; smv = v2; }
           if (sm == i) break;
           hset(i, smv);
           i = uni(sm);
@@ -542,7 +551,7 @@ __global__ __launch_bounds__(64 * FLOOD_WAVES) void ws_flood_kernel(int D, int H
           if constexpr (COMPACT) rec[q] = (uint32_t)l | ((uint32_t)dd << 16);
           else lab[q] = l;
         }
-        push(((MAXD2 - dd) << 40) | ((uint64_t)age << 20) | (uint64_t)q);
+        push(entry(dd, age, (uint64_t)q));
       }
     }
   }
