@@ -437,13 +437,28 @@ __global__ __launch_bounds__(64 * FLOOD_WAVES) void ws_flood_kernel(int D, int H
     };
     auto push = [&](uint64_t it) {
       int c = uni(items++);
+      if constexpr (COMPACT) {
+        if (c < FLOOD_LDS_HEAP) {  // (as below, with the key and the voxel of an entry as two 32-bit scalars)
+          const uint32_t ik = (uint32_t)uni((int)(it >> 32)), ix = (uint32_t)uni((int)it);
+          while (c > 0) {
+            const int p = (c - 1) >> 1;
+            const uint64_t pr = hl[p];
+            const uint32_t pk = (uint32_t)uni((int)(pr >> 32)), px = (uint32_t)uni((int)pr);
+            if (!(ik < pk)) break;
+            if (lane == 0) hl[c] = ((uint64_t)pk << 32) | px;
+            c = p;
+          }
+          if (lane == 0) hl[c] = ((uint64_t)ik << 32) | ix;
+          return;
+        }
+      }
       if (c < FLOOD_LDS_HEAP) {  // the whole path to the root is in LDS: no range checks per level
         while (c > 0) {
           const int p = (c - 1) >> 1;
           const uint64_t pv = bcast0(hl[p]);
           if (!smaller(it, pv)) break;
           if (lane == 0) hl[c] = pv;
-          c = uni(p);  // (uni: the loop-carried index stays scalar)
+          c = p;
         }
         if (lane == 0) hl[c] = it;
         return;
@@ -507,7 +522,21 @@ __global__ __launch_bounds__(64 * FLOOD_WAVES) void ws_flood_kernel(int D, int H
         // child (the left one on a tie), then that one against `last` -- the same choice as the general form below makes
         const int lim = items < FLOOD_LDS_HEAP ? items : FLOOD_LDS_HEAP;
         bool placed = false;
-        while (2 * i + 2 < lim) {
+        if constexpr (COMPACT) {  // (the loop below with the key and the voxel of an entry as two 32-bit scalars)
+          const uint32_t lk = (uint32_t)uni((int)(last >> 32));
+          while (2 * i + 2 < lim) {
+            const int c1 = 2 * i + 1;
+            const uint64_t r1 = hl[c1], r2 = hl[c1 + 1];
+            const uint32_t k1 = (uint32_t)uni((int)(r1 >> 32)), k2 = (uint32_t)uni((int)(r2 >> 32));
+            const uint32_t x1 = (uint32_t)uni((int)r1), x2 = (uint32_t)uni((int)r2);
+            const bool right = k2 < k1;
+            const uint32_t ck = right ? k2 : k1, cx = right ? x2 : x1;
+            if (!(ck < lk)) { placed = true; break; }
+            if (lane == 0) hl[i] = ((uint64_t)ck << 32) | cx;
+            i = c1 + (right ? 1 : 0);
+          }
+        }
+        while (!COMPACT && 2 * i + 2 < lim) {
           const int c1 = 2 * i + 1;
           const uint64_t r1 = hl[c1], r2 = hl[c1 + 1];
           const uint64_t v1 = bcast0(r1), v2 = bcast0(r2);
@@ -515,7 +544,7 @@ __global__ __launch_bounds__(64 * FLOOD_WAVES) void ws_flood_kernel(int D, int H
           const uint64_t cv = right ? v2 : v1;
           if (!smaller(cv, last)) { placed = true; break; }
           if (lane == 0) hl[i] = cv;
-          i = uni(c1 + (right ? 1 : 0));
+          i = c1 + (right ? 1 : 0);
         }
         for (; !placed;) {
           const int c1 = 2 * i + 1, c2 = c1 + 1;
