@@ -445,10 +445,10 @@ __global__ __launch_bounds__(64 * FLOOD_WAVES) void ws_flood_kernel(int D, int H
             const uint64_t pr = hl[p];
             const uint32_t pk = (uint32_t)uni((int)(pr >> 32)), px = (uint32_t)uni((int)pr);
             if (!(ik < pk)) break;
-            if (lane == 0) hl[c] = ((uint64_t)pk << 32) | px;
+            hl[c] = ((uint64_t)pk << 32) | px;
             c = p;
           }
-          if (lane == 0) hl[c] = ((uint64_t)ik << 32) | ix;
+          hl[c] = ((uint64_t)ik << 32) | ix;
           return;
         }
       }
@@ -457,10 +457,10 @@ __global__ __launch_bounds__(64 * FLOOD_WAVES) void ws_flood_kernel(int D, int H
           const int p = (c - 1) >> 1;
           const uint64_t pv = bcast0(hl[p]);
           if (!smaller(it, pv)) break;
-          if (lane == 0) hl[c] = pv;
+          hl[c] = pv;
           c = p;
         }
-        if (lane == 0) hl[c] = it;
+        hl[c] = it;
         return;
       }
       while (c > 0) {
@@ -490,6 +490,10 @@ __global__ __launch_bounds__(64 * FLOOD_WAVES) void ws_flood_kernel(int D, int H
     // y = idx / W without the division (idx < 2^20): exact for W < 4096 with the rounded-up reciprocal
     const bool rcp_ok = W > 1 && W < 4096;  // (W = 1: the reciprocal is 2^32)
     const uint32_t rcpW = (uint32_t)((((uint64_t)1 << 32) + (uint32_t)W - 1) / (uint32_t)W);
+    // The pops run with lanes 0-3 alone (the four neighbour fetchers): inside, nothing is guarded by a lane test any more --
+    // the heap writes of the LDS-only loops are issued by all active lanes (same address, same value) -- and the exec-mask
+    // save / restore around every such write is gone.
+    if (lane < 4)
     while (items > 0) {
       const uint64_t e = hget(0);
       --items;
@@ -500,7 +504,7 @@ __global__ __launch_bounds__(64 * FLOOD_WAVES) void ws_flood_kernel(int D, int H
       const bool okk = k4 == 0 ? y > 0 : (k4 == 1 ? x > 0 : (k4 == 2 ? x < W - 1 : y < H - 1));
       const int qk = okk ? idx + dq : idx;
       int lme = 0, mk = 0, lk = 0, dk = 0;
-      if (lane < 4) {
+      {
         if constexpr (COMPACT) {
           const uint32_t rme = rec[idx], rk = rec[qk];
           lme = (int)(rme & 0xffffu);
@@ -532,7 +536,7 @@ __global__ __launch_bounds__(64 * FLOOD_WAVES) void ws_flood_kernel(int D, int H
             const bool right = k2 < k1;
             const uint32_t ck = right ? k2 : k1, cx = right ? x2 : x1;
             if (!(ck < lk)) { placed = true; break; }
-            if (lane == 0) hl[i] = ((uint64_t)ck << 32) | cx;
+            hl[i] = ((uint64_t)ck << 32) | cx;
             i = c1 + (right ? 1 : 0);
           }
         }
@@ -543,7 +547,7 @@ __global__ __launch_bounds__(64 * FLOOD_WAVES) void ws_flood_kernel(int D, int H
           const bool right = smaller(v2, v1);
           const uint64_t cv = right ? v2 : v1;
           if (!smaller(cv, last)) { placed = true; break; }
-          if (lane == 0) hl[i] = cv;
+          hl[i] = cv;
           i = c1 + (right ? 1 : 0);
         }
         for (; !placed;) {
@@ -576,10 +580,8 @@ __global__ __launch_bounds__(64 * FLOOD_WAVES) void ws_flood_kernel(int D, int H
         const int q = __builtin_amdgcn_readlane(qk, k);
         const uint64_t dd = (uint64_t)(uint32_t)__builtin_amdgcn_readlane(dk, k);
         ++age;
-        if (lane < 4) {
-          if constexpr (COMPACT) rec[q] = (uint32_t)l | ((uint32_t)dd << 16);
-          else lab[q] = l;
-        }
+        if constexpr (COMPACT) rec[q] = (uint32_t)l | ((uint32_t)dd << 16);
+        else lab[q] = l;
         push(entry(dd, age, (uint64_t)q));
       }
     }
