@@ -438,12 +438,12 @@ __global__ __launch_bounds__(64 * FLOOD_WAVES) void ws_flood_kernel(int D, int H
     auto push = [&](uint64_t it) {
       int c = uni(items++);
       if constexpr (COMPACT) {
-        if (c < FLOOD_LDS_HEAP) {  // (as below, with the key and the voxel of an entry as two 32-bit scalars)
-          const uint32_t ik = (uint32_t)uni((int)(it >> 32)), ix = (uint32_t)uni((int)it);
+        if (c < FLOOD_LDS_HEAP) {  // (as below, with the key and the voxel of an entry as two 32-bit values; loads from a uniform LDS address are uniform to the compiler: no v_readfirstlane needed)
+          const uint32_t ik = (uint32_t)(it >> 32), ix = (uint32_t)it;
           while (c > 0) {
             const int p = (c - 1) >> 1;
             const uint64_t pr = hl[p];
-            const uint32_t pk = (uint32_t)uni((int)(pr >> 32)), px = (uint32_t)uni((int)pr);
+            const uint32_t pk = (uint32_t)(pr >> 32), px = (uint32_t)pr;
             if (!(ik < pk)) break;
             hl[c] = ((uint64_t)pk << 32) | px;
             c = p;
@@ -526,13 +526,13 @@ __global__ __launch_bounds__(64 * FLOOD_WAVES) void ws_flood_kernel(int D, int H
         // child (the left one on a tie), then that one against `last` -- the same choice as the general form below makes
         const int lim = items < FLOOD_LDS_HEAP ? items : FLOOD_LDS_HEAP;
         bool placed = false;
-        if constexpr (COMPACT) {  // (the loop below with the key and the voxel of an entry as two 32-bit scalars)
-          const uint32_t lk = (uint32_t)uni((int)(last >> 32));
+        if constexpr (COMPACT) {  // (the loop below with the key and the voxel of an entry as two 32-bit values)
+          const uint32_t lk = (uint32_t)(last >> 32);
           while (2 * i + 2 < lim) {
             const int c1 = 2 * i + 1;
             const uint64_t r1 = hl[c1], r2 = hl[c1 + 1];
-            const uint32_t k1 = (uint32_t)uni((int)(r1 >> 32)), k2 = (uint32_t)uni((int)(r2 >> 32));
-            const uint32_t x1 = (uint32_t)uni((int)r1), x2 = (uint32_t)uni((int)r2);
+            const uint32_t k1 = (uint32_t)(r1 >> 32), k2 = (uint32_t)(r2 >> 32);
+            const uint32_t x1 = (uint32_t)r1, x2 = (uint32_t)r2;
             const bool right = k2 < k1;
             const uint32_t ck = right ? k2 : k1, cx = right ? x2 : x1;
             if (!(ck < lk)) { placed = true; break; }
