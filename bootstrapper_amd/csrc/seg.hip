@@ -425,7 +425,7 @@ __global__ __launch_bounds__(64 * FLOOD_WAVES) void ws_flood_kernel(int D, int H
     // v_readlane: fragments of a 128^3 block 12.7 -> 12.6 ms.  Also tried: label, distance and mask bit of a voxel packed into
     // one 8-byte record, five loads per pop instead of thirteen: 12.6 -> 11.8 ms alone, nothing under the pipeline's 16 lanes.)
     auto hget = [&](int i) -> uint64_t {
-      if (i < FLOOD_LDS_HEAP) return bcast0(hl[i]);
+      if (i < FLOOD_LDS_HEAP) return hl[i];
       uint64_t v = 0;
       if (lane == 0) v = hg[i - FLOOD_LDS_HEAP];
       return bcast0(v);
@@ -455,7 +455,7 @@ __global__ __launch_bounds__(64 * FLOOD_WAVES) void ws_flood_kernel(int D, int H
       if (c < FLOOD_LDS_HEAP) {  // the whole path to the root is in LDS: no range checks per level
         while (c > 0) {
           const int p = (c - 1) >> 1;
-          const uint64_t pv = bcast0(hl[p]);
+          const uint64_t pv = hl[p];
           if (!smaller(it, pv)) break;
           hl[c] = pv;
           c = p;
@@ -543,7 +543,7 @@ __global__ __launch_bounds__(64 * FLOOD_WAVES) void ws_flood_kernel(int D, int H
         while (!COMPACT && 2 * i + 2 < lim) {
           const int c1 = 2 * i + 1;
           const uint64_t r1 = hl[c1], r2 = hl[c1 + 1];
-          const uint64_t v1 = bcast0(r1), v2 = bcast0(r2);
+          const uint64_t v1 = r1, v2 = r2;
           const bool right = smaller(v2, v1);
           const uint64_t cv = right ? v2 : v1;
           if (!smaller(cv, last)) { placed = true; break; }
@@ -556,8 +556,8 @@ __global__ __launch_bounds__(64 * FLOOD_WAVES) void ws_flood_kernel(int D, int H
           uint64_t v1, v2;
           if (c2 < FLOOD_LDS_HEAP) {  // both children with one LDS round trip (entry c2 = items is read and not looked at)
             const uint64_t r1 = hl[c1], r2 = hl[c2];
-            v1 = bcast0(r1);
-            v2 = bcast0(r2);
+            v1 = r1;
+            v2 = r2;
           } else {
             v1 = hget(c1);
             v2 = c2 < items ? hget(c2) : 0;
