@@ -410,9 +410,11 @@ __global__ __launch_bounds__(64 * FLOOD_WAVES) void ws_flood_kernel(int D, int H
     constexpr uint64_t MAXD2 = (1u << 24) - 1;
     auto uni = [](int v) { return __builtin_amdgcn_readfirstlane(v); };
     // queue entry: [63:40] MAXD2 - d2 | [39:20] age | [19:0] voxel.  COMPACT (d2 < 2^16, fewer than 2^15 voxels, so fewer pushes):
-    // [63:48] 65535 - d2 | [47:32] age | [31:0] voxel -- the same order, and the whole key is the upper word: one scalar compare
-    auto entry = [](uint64_t dd, uint32_t age_, uint64_t q_) -> uint64_t {
-      return COMPACT ? ((65535ull - dd) << 48) | ((uint64_t)age_ << 32) | q_ : ((MAXD2 - dd) << 40) | ((uint64_t)age_ << 20) | q_;
+    // [63:48] 65535 - d2 | [47:32] age | [31:16] label | [15:0] voxel -- the same order, the whole key is the upper word (one
+    // scalar compare), and the label the voxel was given travels with it: a pop does not read the voxel's own record
+    auto entry = [](uint64_t dd, uint32_t age_, uint64_t q_, uint32_t lbl_) -> uint64_t {
+      return COMPACT ? ((65535ull - dd) << 48) | ((uint64_t)age_ << 32) | ((uint64_t)lbl_ << 16) | q_
+                     : ((MAXD2 - dd) << 40) | ((uint64_t)age_ << 20) | q_;
     };
     auto smaller = [](uint64_t a_, uint64_t b_) -> bool {
       if constexpr (COMPACT) return (uint32_t)(a_ >> 32) < (uint32_t)(b_ >> 32);
@@ -480,8 +482,9 @@ __global__ __launch_bounds__(64 * FLOOD_WAVES) void ws_flood_kernel(int D, int H
         const int k = __ffsll(seeds) - 1;
         seeds &= seeds - 1;
         const int j = i0 + k;
-        const uint64_t dj = (uint64_t)(uint32_t)uni(COMPACT ? (int)(rec[j] >> 16) : d2[j]);
-        push(entry(dj, 0u, (uint64_t)j));
+        const uint32_t rj = COMPACT ? (uint32_t)uni((int)rec[j]) : 0u;
+        const uint64_t dj = COMPACT ? (uint64_t)(rj >> 16) : (uint64_t)(uint32_t)uni(d2[j]);
+        push(entry(dj, 0u, (uint64_t)j, rj & 0xffffu));
       }
     }
     uint32_t age = 0;
@@ -498,7 +501,7 @@ __global__ __launch_bounds__(64 * FLOOD_WAVES) void ws_flood_kernel(int D, int H
       const uint64_t e = hget(0);
       --items;
       // the popped voxel's label and its neighbours' state are requested first: their latency hides behind the sift
-      const int idx = COMPACT ? (int)(uint32_t)e : (int)(e & 0xfffffu);
+      const int idx = COMPACT ? (int)((uint32_t)e & 0xffffu) : (int)(e & 0xfffffu);
       const int y = rcp_ok ? (int)__umulhi((uint32_t)idx, rcpW) : idx / W, x = idx - y * W;
       // neighbour order [-W, -1, +1, +W]: lane k < 4 looks at neighbour k; the other lanes stay out of global memory
       const bool okk = k4 == 0 ? y > 0 : (k4 == 1 ? x > 0 : (k4 == 2 ? x < W - 1 : y < H - 1));
@@ -506,8 +509,8 @@ __global__ __launch_bounds__(64 * FLOOD_WAVES) void ws_flood_kernel(int D, int H
       int lme = 0, mk = 0, lk = 0, dk = 0;
       {
         if constexpr (COMPACT) {
-          const uint32_t rme = rec[idx], rk = rec[qk];
-          lme = (int)(rme & 0xffffu);
+          const uint32_t rk = rec[qk];  // (a neighbour beyond the slice: the voxel's own record -- labelled, so no candidate)
+          lme = (int)(((uint32_t)e >> 16) & 0xffffu);
           lk = (int)(rk & 0xffffu);
           dk = (int)(rk >> 16);
           mk = dk != 0;
@@ -573,16 +576,16 @@ __global__ __launch_bounds__(64 * FLOOD_WAVES) void ws_flood_kernel(int D, int H
         hset(i, last);
       }
       const int l = uni(lme);
-      const int cand = (okk && mk && lk == 0) ? 1 : 0;
-#pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        if (!__builtin_amdgcn_readlane(cand, k)) continue;  // wave uniform
+      const bool cand = okk && mk && lk == 0;
+      // the neighbours to take, in the order [-W, -1, +1, +W] (a voxel is taken once, so one per pop on average)
+      for (uint32_t m = (uint32_t)__ballot(cand) & 0xfu; m; m &= m - 1) {
+        const int k = __ffs((int)m) - 1;
         const int q = __builtin_amdgcn_readlane(qk, k);
         const uint64_t dd = (uint64_t)(uint32_t)__builtin_amdgcn_readlane(dk, k);
         ++age;
         if constexpr (COMPACT) rec[q] = (uint32_t)l | ((uint32_t)dd << 16);
         else lab[q] = l;
-        push(entry(dd, age, (uint64_t)q));
+        push(entry(dd, age, (uint64_t)q, (uint32_t)l));
       }
     }
   }
