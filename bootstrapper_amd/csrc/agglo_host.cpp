@@ -219,16 +219,24 @@ void rag_merge_scores_one(uint64_t ne, const uint64_t* edges, const uint64_t* su
   if (!ne) return;
   // The order in which edges leave the bin queue is the algorithm (and is replayed as the device loop and the oracle do it); how
   // the graph is held is not.  Nodes are numbered as they appear (nothing below looks at their order); the edge lists of a node
-  // are intrusive (an edge is linked once through each end); of two merging nodes the one with the shorter list is relinked
-  // (which one carries on is free: keys, time stamps and scores treat them alike); an edge that meets a parallel one is absorbed
-  // by it or absorbs it, and the score of an input edge is the score at which the edge that absorbed it -- through however many
-  // steps -- was merged: there is exactly one live edge between two regions, so the merge that joins an input edge's two regions
-  // pops that representative.  (The device loop finds the same value by walking a merge tree.)
+  // are intrusive (an edge is linked once through each end); of two merging nodes the one with the shorter list is relinked.
+  // Which list is walked is free, the TIE RULE between two parallel edges is not: the specification (oracle/seg_ref.c,
+  // agg_contract in seg.hip) folds the edge of the ABSORBED region (the larger fragment id) into the survivor's only when it is
+  // strictly dearer; on equal stored scores the absorbed region's edge lives on, with its place in its bin.  So every node carries
+  // the smallest fragment id of its region, and when the walked list belongs to the region that survives by id the comparison is
+  // taken from the other side (>= instead of >).  (Round 3 compared one way whichever list it walked: with tied scores -- u8
+  // affinities saturate at 0 / 255, ties are the normal case -- a different edge survived and the merge order diverged.)
+  // An edge that meets a parallel one is absorbed by it or absorbs it, and the score of an input edge is the score at which the
+  // edge that absorbed it -- through however many steps -- was merged: there is exactly one live edge between two regions, so the
+  // merge that joins an input edge's two regions pops that representative.  (The device loop finds the same value by walking a
+  // merge tree.)
   PairMap node_of(2 * ne);
   uint32_t nn = 0;
+  std::vector<uint64_t> region_id;  // per node: the smallest fragment id of the region it stands for
+  region_id.reserve(2 * ne);
   auto number = [&](uint64_t id) {
     const uint32_t sl = node_of.slot(id);
-    if (node_of.k[sl] != id) { node_of.k[sl] = id; node_of.v[sl] = nn++; }
+    if (node_of.k[sl] != id) { node_of.k[sl] = id; node_of.v[sl] = nn++; region_id.push_back(id); }
     return node_of.v[sl];
   };
   std::vector<uint32_t> eu(ne), ev(ne), cnt(ne), etime(ne, 0), qnext(ne, kNoEdge), nu(ne), nv(ne), into(ne, kNoEdge);
@@ -291,6 +299,8 @@ void rag_merge_scores_one(uint64_t ne, const uint64_t* edges, const uint64_t* su
     const uint32_t e = pick;
     uint32_t a = eu[e], b = ev[e];
     if (deg[a] < deg[b]) { const uint32_t t = a; a = b; b = t; }
+    // b's list is walked.  The specification absorbs the region with the larger id: is that b?
+    const bool b_absorbed = region_id[b] > region_id[a];
     for (uint32_t f = head[b]; f != kNoEdge;) {
       const bool uside = eu[f] == b;
       const uint32_t next = uside ? nu[f] : nv[f];
@@ -303,7 +313,7 @@ void rag_merge_scores_one(uint64_t ne, const uint64_t* edges, const uint64_t* su
         bool move_f = true;
         if (found) {
           const uint32_t g = by_key.v[sl];
-          if (score[f] > score[g]) {
+          if (b_absorbed ? score[f] > score[g] : score[f] >= score[g]) {
             sum[g] += sum[f];
             cnt[g] += cnt[f];
             dead[f] = 1;
@@ -331,6 +341,7 @@ void rag_merge_scores_one(uint64_t ne, const uint64_t* edges, const uint64_t* su
     merged_at[e] = score[e];
     head[b] = kNoEdge;
     deg[b] = 0;
+    if (b_absorbed == false) region_id[a] = region_id[b];
     ntime[a] = ++clock;
   }
   for (uint32_t e = 0; e < ne; ++e) {

@@ -15,6 +15,7 @@
 //     (min-queue over the total order (score, initial edge key)), then a parallel relabel.
 #include <atomic>
 #include <vector>
+#include <new>
 
 #include <hipcub/hipcub.hpp>
 #include <thread>
@@ -2634,7 +2635,22 @@ int bsmi_agglomerate_hist_u8(bsmi_seg* h, const uint8_t* affs_dev, const uint64_
   if (c[3]) BSMI_FAIL(BSMI_ERR_OVERFLOW, "agglomeration workspace overflow (flags 0x%x: 1 id range, 2 nodes, 4 hash, 8 edges)", c[3]);
   const uint32_t nn = c[0], ne = c[1];
   // per-edge histograms: second scan, then the merge loop on the host (agglo_host.cpp), then the relabel on the device
-  std::vector<uint32_t> eu(ne), ev(ne), hist((size_t)ne * 256), roots((size_t)n_thresholds * std::max(nn, 1u));
+  // 1 KiB of histogram per edge, on the device and again on the host: say so before a few million edges end in a bare
+  // out-of-memory error (this entry point serves the whole-ROI simple_watershed; the block pipeline never builds histograms)
+  const size_t hist_bytes = (size_t)ne * 256 * sizeof(uint32_t);
+  {
+    size_t free_b = 0, total_b = 0;
+    BSMI_HIP(hipMemGetInfo(&free_b, &total_b));
+    if (hist_bytes > free_b - free_b / 8)
+      BSMI_FAIL(BSMI_ERR_OVERFLOW, "histogram-quantile agglomeration of %u edges needs %.1f GB of histograms (1 KiB per edge) on the device and the host, %.1f GB of device memory are free: segment the volume blockwise, or with the mean scorer", ne,
+                hist_bytes / 1e9, free_b / 1e9);
+  }
+  std::vector<uint32_t> eu, ev, hist, roots;
+  try {
+    eu.resize(ne); ev.resize(ne); hist.resize((size_t)ne * 256); roots.resize((size_t)n_thresholds * std::max(nn, 1u));
+  } catch (const std::bad_alloc&) {
+    BSMI_FAIL(BSMI_ERR_OVERFLOW, "histogram-quantile agglomeration of %u edges: no %.1f GB of host memory for the histograms", ne, hist_bytes / 1e9);
+  }
   if (ne) {
     uint32_t* hist_dev = nullptr;
     BSMI_HIP(hipMalloc((void**)&hist_dev, (size_t)ne * 256 * sizeof(uint32_t)));

@@ -572,15 +572,22 @@ class SlabSegmenter:
         guarded(lambda: score_what_can_be(inner))
         if face:
             def await_outer():
-                for k in range(K):     # the outermost blocks feed the neighbours' context
+                # the outermost blocks feed the neighbours' context -- on the faces that HAVE a neighbour (on a (world, 1) grid of
+                # slabs the first and last block ROWS are nobody's context; waiting for them too held the exchange, and the
+                # scoring queued behind it, until the whole fragments stage was over)
+                (zlo, zhi), (ylo, yhi) = self.peers
+                for k in range(K):
                     iz, r = divmod(k, self.counts[1] * self.counts[2])
                     iy = r // self.counts[2]
-                    if iz == 0 or iz == self.counts[0] - 1 or iy == 0 or iy == self.counts[1] - 1:
+                    if ((zlo is not None and iz == 0) or (zhi is not None and iz == self.counts[0] - 1) or
+                            (ylo is not None and iy == 0) or (yhi is not None and iy == self.counts[1] - 1)):
                         self.frag_done[k].synchronize()
             guarded(await_outer)
             self._agree(err)
             got = self._exchange(self.frags)
             score_what_can_be(face, (got,))
+        if err is not None:   # no shared face (context 0 along every cut): nothing above agreed on, or raised, a guarded failure
+            raise err
         return self._collect()
 
     def _agree(self, err):

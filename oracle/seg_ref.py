@@ -7,7 +7,8 @@ import subprocess
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_SO = os.path.join(_HERE, "_build", "libsegref.so")
+# BSMI_ORACLE_SO: another build of the same source (tests/test_sanitizers.py points it at `make -C oracle asan`'s library)
+_SO = os.environ.get("BSMI_ORACLE_SO") or os.path.join(_HERE, "_build", "libsegref.so")
 
 
 def _load():

@@ -214,20 +214,30 @@ def _numpy_region_graph(affs, frags):
     return uniq.astype(np.uint64), sums, cnts
 
 
-@pytest.mark.parametrize("shape,sigma,msd,bins,thr", [((8, 64, 64), (1, 3, 3), 5, 256, 1.0), ((6, 80, 80), (1, 3, 3), 5, 256, 0.45),
-                                                      ((10, 48, 56), (1, 2, 2), 3, 16, 1.0), ((3, 50, 70), (0, 1, 1), 3, 1, 1.0)])
-def test_host_merge_loop_of_the_edge_scoring_equals_the_oracle(shape, sigma, msd, bins, thr):
+@pytest.mark.parametrize("shape,sigma,msd,bins,thr,levels", [
+    ((8, 64, 64), (1, 3, 3), 5, 256, 1.0, 0), ((6, 80, 80), (1, 3, 3), 5, 256, 0.45, 0),
+    ((10, 48, 56), (1, 2, 2), 3, 16, 1.0, 0), ((3, 50, 70), (0, 1, 1), 3, 1, 1.0, 0),
+    # tie-heavy graphs: affinities quantised to a few levels (u8 predictions saturate at 0 / 255), so that parallel edges meet
+    # with EQUAL stored scores and which of the two lives on decides the merge order (the host loop walked the
+    # shorter list and compared one way; 23 of 60 such graphs differed from the oracle)
+    ((8, 64, 64), (1, 3, 3), 5, 256, 1.0, 2), ((6, 80, 80), (1, 2, 2), 3, 256, 1.0, 3), ((6, 80, 80), (1, 3, 3), 5, 256, 0.6, 4),
+    ((10, 48, 56), (1, 2, 2), 3, 16, 1.0, 3), ((4, 50, 70), (0, 1, 1), 3, 1, 1.0, 2), ((8, 64, 64), (1, 2, 2), 3, 256, 1.0, 8)])
+def test_host_merge_loop_of_the_edge_scoring_equals_the_oracle(shape, sigma, msd, bins, thr, levels):
     """bsmi_rag_merge_scores_host (csrc/agglo_host.cpp: the block pipeline's edge scoring on host threads) against the C
     restatement of waterz_agglom.py:106-170, on region graphs built here in numpy: the same edges, bit for bit the same
     scores (NaN = never merged), with coarse and single-bin queues and a threshold that leaves edges unmerged."""
     from scipy.ndimage import gaussian_filter
     from bootstrapper_amd.post.engine import rag_merge_scores_host
     from oracle import seg_ref as S
-    rng = np.random.default_rng(shape[1] * 7 + bins)
+    rng = np.random.default_rng(shape[1] * 7 + bins + 1000 * levels)
     graphs, refs = [], []
     for g in range(3):
         a = gaussian_filter(rng.random((3,) + shape), sigma=(0,) + sigma)
-        affs = ((a - a.min()) / (a.max() - a.min()) * 255).astype(np.uint8)
+        a = (a - a.min()) / (a.max() - a.min())
+        if levels:
+            a = np.clip((a - 0.5) * 2.5 + 0.5, 0, 1)                     # saturate like a trained net's output
+            a = np.round(a * (levels - 1)) / (levels - 1)
+        affs = (a * 255).astype(np.uint8)
         frags, _ = S.ws_fragments_u8(affs, True, msd)
         frags = np.where(frags > 0, frags + np.uint64((1 << 40) * g), np.uint64(0))     # ids beyond 32 bits
         e_ref, s_ref, _, _ = S.rag_merge_scores_u8(affs, frags, thr, bins)

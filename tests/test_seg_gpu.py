@@ -349,9 +349,12 @@ def test_rag_merge_scores_bit_exact_vs_oracle(shape, sigma, msd, bins, id_base):
     assert np.array_equal(s.cpu().numpy().view(np.uint32), s_ref.view(np.uint32))     # NaNs included
 
 
-@pytest.mark.parametrize("shape,sigma,msd,bins,thr", [((12, 96, 96), (1, 3, 3), 5, 256, 1.0), ((4, 160, 160), (1, 5, 5), 10, 256, 1.0),
-                                                      ((6, 80, 80), (1, 3, 3), 5, 256, 0.45), ((8, 64, 72), (1, 2, 2), 3, 16, 1.0)])
-def test_rag_scores_on_the_host_equal_the_device_loop_and_the_oracle(shape, sigma, msd, bins, thr):
+@pytest.mark.parametrize("shape,sigma,msd,bins,thr,levels", [
+    ((12, 96, 96), (1, 3, 3), 5, 256, 1.0, 0), ((4, 160, 160), (1, 5, 5), 10, 256, 1.0, 0),
+    ((6, 80, 80), (1, 3, 3), 5, 256, 0.45, 0), ((8, 64, 72), (1, 2, 2), 3, 16, 1.0, 0),
+    # saturated / coarsely quantised affinities: parallel edges tie, the tie rule decides the order (tests/test_host_logic.py)
+    ((8, 80, 80), (1, 2, 2), 3, 256, 1.0, 3), ((8, 64, 72), (1, 2, 2), 3, 16, 1.0, 2), ((6, 96, 96), (1, 3, 3), 5, 256, 1.0, 6)])
+def test_rag_scores_on_the_host_equal_the_device_loop_and_the_oracle(shape, sigma, msd, bins, thr, levels):
     """The block pipeline's edge scoring: the device exports the region graph (bsmi_rag_graph_u8), the merge loop and the
     merge-tree look-ups run on host threads (bsmi_rag_merge_scores_host) -- the same edges and bit for bit the same scores as the
     device loop (bsmi_rag_merge_scores_u8) and the oracle, several graphs in one call."""
@@ -362,6 +365,9 @@ def test_rag_scores_on_the_host_equal_the_device_loop_and_the_oracle(shape, sigm
     eng = SegEngine(shape)
     for g in range(3):
         affs = _blobby(rng, shape, sigma)
+        if levels:
+            q = np.clip((affs.astype(np.float64) / 255 - 0.5) * 2.5 + 0.5, 0, 1)
+            affs = (np.round(q * (levels - 1)) / (levels - 1) * 255).astype(np.uint8)
         frags, _ = S.ws_fragments_u8(affs, True, msd)
         big = frags > np.median(frags[frags > 0])
         frags = np.where(frags > 0, frags + np.uint64(1000 * g) + np.where(big, np.uint64(2_097_152), np.uint64(0)), np.uint64(0))
