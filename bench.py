@@ -155,19 +155,21 @@ def cpu_baseline(raw_blocks, affs_u8_host, seg_blocks):
     pred_vox_s = len(raw_blocks) * nvox / t_pred
 
     t0 = time.perf_counter()
-    frags, nodes, E, _, segs = cpu_blockwise(affs_u8_host, OUT_BLOCK, SEG_CONTEXT, 10, FILTER_FRAGMENTS, REMOVE_DEBRIS, THRESHOLDS, 256,
-                                             workers=cores)
+    frags, nodes, E, Sc, segs = cpu_blockwise(affs_u8_host, OUT_BLOCK, SEG_CONTEXT, 10, FILTER_FRAGMENTS, REMOVE_DEBRIS, THRESHOLDS, 256,
+                                              workers=cores)
     t_seg = time.perf_counter() - t0
     seg_vox_s = affs_u8_host[0].size / t_seg
     both = 1.0 / (1.0 / pred_vox_s + 1.0 / seg_vox_s)
     return {
-        "value": both / 1e6, "unit": "Mvoxels/s", "cores": cores, "kind": "port",
+        "value": both / 1e6, "unit": "Mvoxels/s", "cores": cores, "cores_affinity": len(os.sched_getaffinity(0)), "kind": "port",
         "sample": (f"predict: torch-CPU fp32 restatement, {len(raw_blocks)} blocks (156,220,220)->128^3 of the job in {t_pred:.1f} s "
                    f"-> {pred_vox_s / 1e3:.2f} kvox/s; segment: blockwise pipeline of the C restatement (fragments with context 16, "
                    f"RAG scoring, connected components, relabel) on {seg_blocks} blocks of GPU-predicted affinities, {cores} cores, "
                    f"{len(nodes)} fragments, {len(E)} edges, {t_seg:.1f} s -> {seg_vox_s / 1e6:.2f} Mvox/s"),
         "predict_kvox_s": pred_vox_s / 1e3, "segment_Mvox_s": seg_vox_s / 1e6,
-    }, outs, frags
+        "cores_note": "cores = threads used (torch intra-op threads of the predict restatement, pool threads of the segment one): the affinity mask, "
+                      "capped by the cgroup CPU quota and by BSMI_BENCH_CORES (default 16 = one GPU's share of the node's host cores); cores_affinity = the uncapped mask",
+    }, outs, frags, (E, Sc)
 
 
 def same_partition(a, b):
@@ -195,6 +197,46 @@ def check_fragments(gpu_frags, cpu_frags, sub, job):
                 compared += 1
                 bad += not same_partition(gpu_frags[sl], cpu_frags[sl])
     return compared, bad
+
+
+def regrid_ids(ids, sub, job):
+    """fragment ids of a run over the sub-box `sub` (blocks) -> the ids the same fragments carry in a run over the box `job` that
+    starts at the same corner: id = block index (z-major in the run's own grid) * voxels per block + label."""
+    nv = np.uint64(int(np.prod(OUT_BLOCK)))
+    ids = np.asarray(ids, np.uint64)
+    b, lab = (ids - np.uint64(1)) // nv, (ids - np.uint64(1)) % nv
+    z, r = b // np.uint64(sub[1] * sub[2]), b % np.uint64(sub[1] * sub[2])
+    y, x = r // np.uint64(sub[2]), r % np.uint64(sub[2])
+    out = ((z * np.uint64(job[1]) + y) * np.uint64(job[2]) + x) * nv + lab + np.uint64(1)
+    return np.where(ids > 0, out, np.uint64(0))
+
+
+def check_edges(gpu_edges, gpu_scores, cpu_edges, cpu_scores, sub, job):
+    """The scored edges (what decides the segmentations) of the GPU pipeline against the CPU restatement's, on the blocks whose
+    scoring read the same fragments in both runs: a block's read box holds its 26 neighbours' fragments, so the block and all its
+    neighbours inside the job must have had the same read box -- every block at least two away from a face of the sub-box that
+    lies inside the job.  Bit for bit: same edges, same float32 scores (NaN = never merged).  -> (blocks compared, edges compared,
+    blocks that differ)"""
+    nv = int(np.prod(OUT_BLOCK))
+    ce = regrid_ids(cpu_edges, sub, job).reshape(-1, 2)
+    g_owner = (gpu_edges[:, 0] - np.uint64(1)) // np.uint64(nv)
+    c_owner = (ce[:, 0] - np.uint64(1)) // np.uint64(nv)
+    blocks = n_edges = bad = 0
+    for z in range(sub[0]):
+        for y in range(sub[1]):
+            for x in range(sub[2]):
+                b = (z, y, x)
+                if any(b[d] + 2 >= sub[d] and sub[d] != job[d] for d in range(3)):
+                    continue
+                bid = (z * job[1] + y) * job[2] + x
+                ge, gs = gpu_edges[g_owner == bid], gpu_scores[g_owner == bid]
+                ee, es = ce[c_owner == bid], cpu_scores[c_owner == bid]
+                go, eo = np.lexsort((ge[:, 1], ge[:, 0])), np.lexsort((ee[:, 1], ee[:, 0]))
+                same = len(ge) == len(ee) and np.array_equal(ge[go], ee[eo]) and np.array_equal(gs[go].view(np.uint32), es[eo].view(np.uint32))
+                blocks += 1
+                n_edges += len(ee)
+                bad += not same
+    return blocks, n_edges, bad
 
 
 def drivers_leg(raw_box, sd, precision):
@@ -243,8 +285,12 @@ def drivers_leg(raw_box, sd, precision):
         import io
         from bootstrapper_amd.refine import size_filter
         t0 = time.perf_counter()
-        with contextlib.redirect_stdout(io.StringIO()):
-            filtered = size_filter(written[-1], min_size=500)
+        filter_error = None
+        try:
+            with contextlib.redirect_stdout(io.StringIO()):
+                filtered = size_filter(written[-1], min_size=500)
+        except Exception as exc:  # noqa: BLE001 - reported in the line; the two commands the leg is about have run
+            filtered, filter_error = None, f"{type(exc).__name__}: {exc}"
         t_filter = time.perf_counter() - t0
 
         def du(path):
@@ -256,7 +302,7 @@ def drivers_leg(raw_box, sd, precision):
                 "blocks": int(nvox // int(np.prod(OUT_BLOCK))), "predict_seconds": t_pred, "segment_seconds": t_seg, "filter_seconds": t_filter,
                 "Mvoxels_per_s": nvox / (t_pred + t_seg) / 1e6, "predict_Mvoxels_per_s": nvox / t_pred / 1e6,
                 "segment_Mvoxels_per_s": nvox / t_seg / 1e6, "round_Mvoxels_per_s": nvox / (t_pred + t_seg + t_filter) / 1e6,
-                "datasets_written": len(written) + 1 + (1 if filtered else 0),
+                "datasets_written": len(written) + 1 + (1 if filtered else 0), "filter_error": filter_error,
                 "store_bytes": du(store), "tmp_dir": os.path.dirname(tmp) or tmp}
     finally:
         shutil.rmtree(tmp, ignore_errors=True)
@@ -373,6 +419,68 @@ def train_main(args):
         dist.destroy_process_group()
 
 
+def whole_volume_leg(model, vol, args, dev, local_rank, rank, world, obj_group, use_dist, seg_kw, barrier, flops_block, peak, check):
+    """BASELINE.json's metric on its own configuration: predict + segment of the WHOLE synthetic volume (1024^3 = 8 x 8 x 8 blocks
+    of 128^3), resident in HBM, the block layers dealt to the ranks (8 / N layers of 8 x 8 blocks each: at N = 1 one GPU takes all
+    512 blocks, at N = 8 every rank one layer -- the same volume at every N, i.e. the strong-scaling reading of the metric beside the
+    weak-scaling `value`).  Timed like the headline: barrier + synchronize on both sides, max over ranks."""
+    import torch.distributed as dist
+    from bootstrapper_amd.volume import VolumePipeline
+    edge = args.volume // OUT_BLOCK[0]
+    job = (edge // world, edge, edge)
+    nblocks = job[0] * job[1] * job[2]
+    pipe = VolumePipeline(model, OUT_BLOCK, CONTEXT, job, SEG_CONTEXT, THRESHOLDS, n_lanes=args.seg_lanes, device=local_rank,
+                          rank=rank, world=world, overlap=args.overlap, obj_group=obj_group, **seg_kw)
+    pipe.seg.overlap_lanes = args.overlap_lanes
+    pipe.seg.prime()
+    barrier()
+    t0 = time.perf_counter()
+    pipe.run(vol)
+    barrier()
+    dt = time.perf_counter() - t0
+    t_pred = pipe.t_predict
+    mine = {"rank": rank, "blocks": nblocks, "predict_seconds": t_pred, **{k + "_seconds": v for k, v in pipe.seg.timers.items()},
+            "fragments": int(sum(int(n) for n in pipe.seg.block_nums)), "scored_edges": int(len(pipe.seg.rag_scores))}
+    if use_dist:
+        t = torch.tensor([dt, t_pred], dtype=torch.float64, device=dev if args.backend == "nccl" else "cpu")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt, t_pred = (float(v) for v in t.tolist())
+        parts = [None] * world
+        dist.all_gather_object(parts, mine, group=obj_group)
+    else:
+        parts = [mine]
+    nvox = args.volume ** 3
+    res = {"what": f"the whole synthetic {args.volume}^3 volume = {edge}x{edge}x{edge} blocks of 128^3 through the same pipeline (predict every block "
+                   f"into the resident slabs, fragments with context, RAG scoring, global connected components, LUT, relabel), {edge // world} block "
+                   f"layer(s) of {edge}x{edge} blocks per GPU on {world} GPU(s); outside the weak-scaling timed region, timed the same way",
+           "blocks": nblocks * world, "n_gpus": world, "seconds": dt, "Mvoxels_per_s": nvox / dt / 1e6, "ms_per_block_per_gpu": dt / nblocks * 1e3,
+           "predict_seconds": t_pred, "segment_seconds": dt - t_pred,
+           "predict_mfma_frac": flops_block * nblocks / t_pred / 1e12 / peak,
+           "fragments": int(len(pipe.seg.nodes)), "scored_edges": int(sum(p["scored_edges"] for p in parts)),
+           "segments": [int(len(np.unique(c))) for c in pipe.seg.luts], "per_rank": parts}
+    if check:
+        # spot check against the CPU restatement: the 3 x 3 x 3 blocks at the volume's corner through the C pipeline; fragments
+        # of the 8 blocks and scored edges of the one block whose inputs are the same in both runs
+        from oracle.blockwise_ref import cpu_blockwise
+        sub = tuple(min(3, j) for j in job)
+        a = pipe.seg.interior(pipe.seg.affs)[:, :sub[0] * 128, :sub[1] * 128, :sub[2] * 128].contiguous().cpu().numpy()
+        t1 = time.perf_counter()
+        cf, _, ce, cs, _ = cpu_blockwise(a, OUT_BLOCK, SEG_CONTEXT, 10, FILTER_FRAGMENTS, REMOVE_DEBRIS, THRESHOLDS, 256, workers=host_cores())
+        t_cpu = time.perf_counter() - t1
+        gf = pipe.seg.interior(pipe.seg.frags)[:sub[0] * 128, :sub[1] * 128, :sub[2] * 128].cpu().numpy().view(np.uint64)
+        compared, bad = check_fragments(gf, cf, sub, job)
+        exact = bool(np.array_equal(gf[:128 * (sub[0] - 1), :128 * (sub[1] - 1), :128 * (sub[2] - 1)],
+                                    regrid_ids(cf, sub, job)[:128 * (sub[0] - 1), :128 * (sub[1] - 1), :128 * (sub[2] - 1)]))
+        eb, ne, ebad = check_edges(pipe.seg.rag_edges, pipe.seg.rag_scores, ce, cs, sub, job)
+        res["parity_check"] = {"what": f"CPU restatement on the {sub[0]}x{sub[1]}x{sub[2]} blocks at the volume's corner ({t_cpu:.1f} s): fragments equal after an id "
+                                       "remap on the blocks with the same read box, their ids equal outright, scored edges equal bit for bit where both runs scored the same fragments",
+                               "blocks_compared": compared, "blocks_differing": bad, "ids_equal": exact,
+                               "edge_blocks_compared": eb, "edges_compared": ne, "edge_blocks_differing": ebad}
+        if bad or ebad or not exact:
+            raise SystemExit(f"parity (whole volume): fragments of {bad}/{compared} blocks, edges of {ebad}/{eb} blocks differ from the CPU restatement's (ids equal: {exact})")
+    return res
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--mode", default="predict", choices=["predict", "train"],
@@ -399,7 +507,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-modes", action="store_true", help="skip the per-precision predict lines (speed and error of f32 / bf16x3 / bf16)")
     ap.add_argument("--no-train", action="store_true", help="skip the `train` leg (ms per training step in both arithmetics)")
-    ap.add_argument("--no-drivers", action="store_true", help="skip the `drivers` leg (bs predict + bs segment on an on-disk Zarr store of the box)")
+    ap.add_argument("--no-drivers", action="store_true", help="skip the `drivers` leg (bs predict + bs segment on an on-disk Zarr store of the whole volume)")
+    ap.add_argument("--drivers-box", action="store_true", help="`drivers` leg on the box of --steps blocks instead of the whole volume")
+    ap.add_argument("--no-whole-volume", action="store_true", help="skip the `whole_volume` leg (the whole 1024^3 volume, resident, over all ranks)")
     ap.add_argument("--profile-every", type=int, default=4,
                     help="per-launch HIP-event timing (the roofline figures) on every Nth block of the timed region")
     ap.add_argument("--cpu-predict-blocks", type=int, default=2)
@@ -564,7 +674,7 @@ def main():
             sj = job_blocks_for(max(1, min(args.cpu_segment_blocks, args.steps)))
             sj = tuple(min(a, b) for a, b in zip(sj, job))
         affs = pipe.seg.interior(pipe.seg.affs)[:, :sj[0] * 128, :sj[1] * 128, :sj[2] * 128].contiguous().cpu().numpy()
-        out["cpu_baseline"], cpu_outs, cpu_frags = cpu_baseline([r.cpu().numpy() for r in raws], affs, sj[0] * sj[1] * sj[2])
+        out["cpu_baseline"], cpu_outs, cpu_frags, cpu_edges = cpu_baseline([r.cpu().numpy() for r in raws], affs, sj[0] * sj[1] * sj[2])
         if not args.no_segment:
             out["segment_only"]["gpu_over_cpu"] = out["segment_only"]["Mvoxels_per_s"] / out["cpu_baseline"]["segment_Mvox_s"]
             out["segment_only"]["gpu_over_cpu_note"] = (f"against {out['cpu_baseline']['cores']} host cores, this GPU's share of the node; at equal share "
@@ -576,6 +686,13 @@ def main():
                                                    "what": "fragments of the GPU pipeline vs the CPU restatement on the same affinities, equal after an id remap"}
             if bad:
                 raise SystemExit(f"parity: the fragments of {bad} of {compared} sampled blocks differ from the CPU restatement's")
+            # ... and its scored edges (the host merge loops' output, which the fragments alone would not catch) where both runs
+            # scored the same fragments
+            eb, ne, ebad = check_edges(pipe.seg.rag_edges, pipe.seg.rag_scores, cpu_edges[0], cpu_edges[1], sj, job)
+            out["cpu_baseline"]["parity_check"].update({"edge_blocks_compared": eb, "edges_compared": ne, "edge_blocks_differing": ebad,
+                                                        "edges_what": "scored RAG edges of those blocks whose 26 neighbours had the same read box in both runs: same edges, float32 scores bit for bit"})
+            if ebad:
+                raise SystemExit(f"parity: the scored edges of {ebad} of {eb} sampled blocks differ from the CPU restatement's")
         out["predict_only"]["gpu_over_cpu"] = out["predict_only"]["Mvoxels_per_s"] * 1e3 / out["cpu_baseline"]["predict_kvox_s"]
         if not args.no_modes:
             # speed / accuracy of every precision mode on the same blocks, errors against the CPU fp32 restatement
@@ -597,19 +714,54 @@ def main():
                                "max_abs_err_vs_cpu_fp32": err, "within_1e-4": err < 1e-4}
             model.set_precision(args.precision)
             out["modes"] = modes
-    if rank == 0 and world == 1 and not args.no_train:
-        pipe_origin = pipe.origin
+    # ---- the metric's own configuration: the WHOLE volume (1024^3 = 8 x 8 x 8 blocks), resident, over all ranks -----------------
+    per_rank = {"rank": rank, "predict_seconds": pipe.t_predict, **{k + "_seconds": v for k, v in pipe.seg.timers.items()}} if not args.no_segment else None
+    if use_dist and per_rank is not None:
+        parts = [None] * world
+        dist.all_gather_object(parts, per_rank, group=obj_group)
+        out["per_rank"] = parts
+    elif per_rank is not None:
+        out["per_rank"] = [per_rank]
+    pipe_origin = pipe.origin
+    edge = args.volume // OUT_BLOCK[0]
+    if not args.no_segment and not args.no_whole_volume and edge % world == 0 and (args.steps, job) != (edge ** 3 // world, (edge // world, edge, edge)):
         del pipe, segs
-        torch.cuda.empty_cache()
-        out["train"] = train_leg(dev, local_rank)
-        pipe = segs = None
-    if rank == 0 and world == 1 and not args.no_drivers and not args.no_segment and args.steps <= 64:
-        ext = tuple(j * b for j, b in zip(job, OUT_BLOCK))
-        box = vol[tuple(slice(o, o + e) for o, e in zip(pipe_origin if pipe is None else pipe.origin, ext))].cpu().numpy()
         pipe = segs = None
         torch.cuda.empty_cache()
-        out["drivers"] = drivers_leg(box, sd, args.precision)
-        out["drivers"]["resident_Mvoxels_per_s"] = value
+        out["whole_volume"] = whole_volume_leg(model, vol, args, dev, local_rank, rank, world, obj_group, use_dist, seg_kw, barrier,
+                                               flops_block, peak, check=(rank == 0 and world == 1 and not args.no_cpu_baseline))
+        out["config"]["whole_volume"] = out["whole_volume"]["what"]
+    elif not args.no_segment and not args.no_whole_volume and edge % world == 0:
+        out["whole_volume"] = {"what": "the timed region above IS the whole volume", "Mvoxels_per_s": value, "seconds": dt}
+    if rank == 0 and world == 1 and not args.no_train:
+        pipe = segs = None
+        torch.cuda.empty_cache()
+        try:
+            out["train"] = train_leg(dev, local_rank)
+        except Exception as exc:  # noqa: BLE001 - a secondary leg: its failure is reported in the line, the headline stands
+            out["train"] = {"error": f"{type(exc).__name__}: {exc}"}
+    if rank == 0 and world == 1 and not args.no_drivers and not args.no_segment:
+        # the commands a user runs, on the whole volume as an on-disk Zarr store (the box of `--steps` blocks when the volume's
+        # datasets would not fit the temporary directory)
+        import shutil
+        tmp_root = os.environ.get("BSMI_BENCH_TMP") or __import__("tempfile").gettempdir()
+        whole = shutil.disk_usage(tmp_root).free > 14 * args.volume ** 3 and not args.drivers_box
+        if whole:
+            box = vol.cpu().numpy()
+        else:
+            ext = tuple(j * b for j, b in zip(job, OUT_BLOCK))
+            box = vol[tuple(slice(o, o + e) for o, e in zip(pipe_origin, ext))].cpu().numpy()
+        pipe = segs = None
+        torch.cuda.empty_cache()
+        try:
+            out["drivers"] = drivers_leg(box, sd, args.precision)
+        except Exception as exc:  # noqa: BLE001
+            import traceback
+            out["drivers"] = {"error": f"{type(exc).__name__}: {exc}", "traceback": traceback.format_exc()[-1500:], "Mvoxels_per_s": 0.0}
+        out["drivers"]["whole_volume"] = bool(whole)
+        resident = out.get("whole_volume", {}).get("Mvoxels_per_s") if whole else value
+        out["drivers"]["resident_Mvoxels_per_s"] = resident
+        out["drivers"]["frac_of_resident"] = out["drivers"]["Mvoxels_per_s"] / resident if resident else None
     if rank == 0:
         print(json.dumps(out), flush=True)
     if use_dist:

@@ -215,7 +215,7 @@ struct PairMap {
 };
 
 void rag_merge_scores_one(uint64_t ne, const uint64_t* edges, const uint64_t* sums, const uint32_t* cnts, float threshold, int nbins,
-                          float* scores) {
+                          int bin_rule, float* scores) {
   if (!ne) return;
   // The order in which edges leave the bin queue is the algorithm (and is replayed as the device loop and the oracle do it); how
   // the graph is held is not.  Nodes are numbered as they appear (nothing below looks at their order); the edge lists of a node
@@ -264,7 +264,9 @@ void rag_merge_scores_one(uint64_t ne, const uint64_t* edges, const uint64_t* su
   }
   std::vector<uint32_t> bhead(nbins, kNoEdge), btail(nbins, kNoEdge);
   int minbin = nbins;
-  const float scale = (float)(nbins - 1);
+  // bin of a score: BSMI_QUEUE_BINS_N_MINUS_1 (the specification, oracle/seg_ref.c) bin = (int)(score * (N - 1)), or
+  // BSMI_QUEUE_BINS_N bin = min(N - 1, (int)(score * N)) -- upstream's binning cannot be checked here (waterz absent)
+  const float scale = bin_rule == BSMI_QUEUE_BINS_N ? (float)nbins : (float)(nbins - 1);
   auto push = [&](uint32_t e, float sc) {
     int b = (int)(sc * scale);
     b = b < 0 ? 0 : (b > nbins - 1 ? nbins - 1 : b);
@@ -391,6 +393,14 @@ void sort_graph(uint64_t ne, uint64_t* edges, uint64_t* sums, uint32_t* cnts) {
 extern "C" int bsmi_rag_merge_scores_host(int n_graphs, const uint64_t* n_edges, uint64_t* const* edges, uint64_t* const* sums,
                                           uint32_t* const* counts, float threshold, int discretize_queue, float* const* scores,
                                           int n_threads) {
+  return bsmi_rag_merge_scores_host_rule(n_graphs, n_edges, edges, sums, counts, threshold, discretize_queue, BSMI_QUEUE_BINS_N_MINUS_1,
+                                         scores, n_threads);
+}
+
+extern "C" int bsmi_rag_merge_scores_host_rule(int n_graphs, const uint64_t* n_edges, uint64_t* const* edges, uint64_t* const* sums,
+                                               uint32_t* const* counts, float threshold, int discretize_queue, int bin_rule,
+                                               float* const* scores, int n_threads) {
+  if (bin_rule != BSMI_QUEUE_BINS_N_MINUS_1 && bin_rule != BSMI_QUEUE_BINS_N) return BSMI_ERR_INVALID;
   if (n_graphs < 0 || (n_graphs && (!n_edges || !edges || !sums || !counts || !scores)) || discretize_queue < 1 || discretize_queue > 1024 ||
       !(threshold > 0.f))
     return BSMI_ERR_INVALID;
@@ -409,7 +419,7 @@ extern "C" int bsmi_rag_merge_scores_host(int n_graphs, const uint64_t* n_edges,
     for (int i = next.fetch_add(1); i < n_graphs; i = next.fetch_add(1)) {
       const int g = order[i];
       bsmi::sort_graph(n_edges[g], edges[g], sums[g], counts[g]);
-      bsmi::rag_merge_scores_one(n_edges[g], edges[g], sums[g], counts[g], threshold, discretize_queue, scores[g]);
+      bsmi::rag_merge_scores_one(n_edges[g], edges[g], sums[g], counts[g], threshold, discretize_queue, bin_rule, scores[g]);
     }
   };
   const int hw = (int)std::max(1u, std::thread::hardware_concurrency());

@@ -240,10 +240,14 @@ class SegEngine:
         check(lib.bsmi_seg_status(self._h, self._stream()))
 
 
-def rag_merge_scores_host(n_edges, edges, sums, pair_counts, threshold=1.0, discretize_queue=256, threads=0):
+QUEUE_BINS_FORMULAS = {"n_minus_1": 0, "n": 1}   # include/bsmi.h BSMI_QUEUE_BINS_*
+
+
+def rag_merge_scores_host(n_edges, edges, sums, pair_counts, threshold=1.0, discretize_queue=256, threads=0, bins_formula="n_minus_1"):
     """waterz_agglom.py:106-170 for many blocks at once on host threads (csrc/agglo_host.cpp): graphs as SegEngine.rag_graph_async
     exports them, copied to the host -- edges uint64 / int64 [G][cap][2], sums [G][cap], pair_counts uint32 / int32 [G][cap]
-    (numpy, C-contiguous, writable), n_edges [G].  The device leaves a graph's edges in the order of its hash table: every graph
+    (numpy, C-contiguous, writable), n_edges [G].  bins_formula: "n_minus_1" (bin = (int)(score (N-1)), the specification) or "n"
+    (min(N-1, (int)(score N))): waterz's own rule is unpinned.  The device leaves a graph's edges in the order of its hash table: every graph
     is first sorted by (id, id) IN PLACE -- edges, sums and pair_counts permuted together --, which is the order the scores come
     back in.  -> scores float32 [G][cap] (entries past n_edges[g] untouched: NaN)."""
     import numpy as np
@@ -259,8 +263,11 @@ def rag_merge_scores_host(n_edges, edges, sums, pair_counts, threshold=1.0, disc
         raise ValueError("edges [G][cap][2], sums [G][cap], pair_counts [G][cap], n_edges [G] <= cap")
     scores = np.full(e.shape[:2], np.nan, dtype=np.float32)
     ptrs = lambda a, stride: (C.c_void_p * G)(*[a.ctypes.data + g * stride for g in range(G)])
-    check(lib.bsmi_rag_merge_scores_host(G, ne.ctypes.data_as(C.c_void_p), ptrs(e, e.strides[0]), ptrs(s, s.strides[0]), ptrs(c, c.strides[0]),
-                                         float(threshold), int(discretize_queue), ptrs(scores, scores.strides[0]), int(threads)))
+    if bins_formula not in QUEUE_BINS_FORMULAS:
+        raise ValueError(f"queue_bins_formula {bins_formula!r}: one of {sorted(QUEUE_BINS_FORMULAS)}")
+    check(lib.bsmi_rag_merge_scores_host_rule(G, ne.ctypes.data_as(C.c_void_p), ptrs(e, e.strides[0]), ptrs(s, s.strides[0]), ptrs(c, c.strides[0]),
+                                              float(threshold), int(discretize_queue), QUEUE_BINS_FORMULAS[bins_formula],
+                                              ptrs(scores, scores.strides[0]), int(threads)))
     return scores
 
 

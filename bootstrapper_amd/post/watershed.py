@@ -237,6 +237,13 @@ def waterz_pipeline(config, device=None, rank=0, world=1, group=None, grid=None,
                                   "(reference post/blockwise/waterz_agglom.py:23-36); the histogram-quantile scorers belong to the "
                                   "non-blockwise `simple_watershed` (blockwise = false)")
     blockwise = config.get("blockwise", False)
+    # choices of waterz / funlib.segment that this repository cannot check (both absent): config keys, so that
+    # whoever runs tools/gen_goldens_waterz.py and finds the other answer switches without touching code
+    tie_order = config.get("queue_tie_order", "edge_key")
+    if tie_order != "edge_key":
+        raise NotImplementedError(f"queue_tie_order {tie_order!r}: equal scores leave the exact queue in the order of the edges' initial "
+                                  "(smaller id, larger id) key and an N-bin queue first in, first out -- the one specified order "
+                                  "(oracle/seg_ref.c); tests/test_waterz_pin.py says whether waterz agrees once its vectors exist")
     frag_params = {
         "fragments_in_xy": config.get("fragments_in_xy", True),
         "min_seed_distance": config.get("min_seed_distance", 10),
@@ -282,6 +289,7 @@ def waterz_pipeline(config, device=None, rank=0, world=1, group=None, grid=None,
                         n_lanes=int(config.get("lanes", 20)), device=device, rank=rank, world=world, group=group, exchange_affs=False,
                         label_cap=int(config.get("label_cap", 1 << 16)), edge_cap=int(config.get("edge_cap", 1 << 17)),
                         grid=grid, total_rows=rows, row0=ys[ry], obj_group=obj_group,
+                        cc_inclusive=bool(config.get("cc_inclusive", True)), queue_bins_formula=config.get("queue_bins_formula", "n_minus_1"),
                         epsilon_agglomerate=frag_params["epsilon_agglomerate"], sigma=frag_params["sigma"],
                         noise_eps=frag_params["noise_eps"], bias=frag_params["bias"], seed_eps=frag_params["seed_eps"])
     _fill_affinities(seg, affs, origin, z0, mask, y0)

@@ -29,7 +29,7 @@ def _empty_copy(in_ds, out_array):
     return prepare_ds(out_array, **keep)
 
 
-def _tiles(in_ds, tile=1024):
+def _tiles(in_ds, tile=512):
     nz, ny, nx = in_ds.shape
     cz = int(in_ds.chunks[0])
     for iz in range(0, nz, cz):
@@ -39,7 +39,7 @@ def _tiles(in_ds, tile=1024):
 
 
 class _Device:
-    def __init__(self, in_ds, device=0, tile=1024):
+    def __init__(self, in_ds, device=0, tile=512):   # a workspace takes sections of fewer than 2^20 voxels (bsmi_seg_create)
         import torch
         from .post.engine import SegEngine
         self.torch = torch

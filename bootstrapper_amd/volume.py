@@ -156,7 +156,7 @@ class SlabSegmenter:
                  fragments_in_xy=True, min_seed_distance=10, filter_fragments=0.0, remove_debris=0, discretize_queue=256,
                  n_lanes=8, device=0, rank=0, world=1, group=None, edge_cap=1 << 17, label_cap=1 << 16, exchange_affs=True,
                  epsilon_agglomerate=0.0, sigma=None, noise_eps=None, bias=None, noise_seed=0, seed_eps=None,
-                 grid=None, total_rows=None, row0=0, obj_group=None, host_scores=True):
+                 grid=None, total_rows=None, row0=0, obj_group=None, host_scores=True, cc_inclusive=True, queue_bins_formula="n_minus_1"):
         """slab_shape: this rank's box of the volume (whole blocks but for the volume's far faces).  The ranks form a grid
         `grid` = (Rz, Ry) over z and y (default: (world, 1), slabs of block layers), rank = rz * Ry + ry; the volume has
         `total_layers` block layers and `total_rows` block rows, this rank's first ones are `layer0`, `row0`.
@@ -166,6 +166,17 @@ class SlabSegmenter:
         only build the region graphs) instead of as one wave per block on the lanes: the scores are needed on the host anyway,
         and a host core replays that loop in a fraction of the 12 ms a wave takes."""
         self.host_scores = bool(host_scores)
+        # The two choices that waterz / funlib.segment make and that cannot be checked in this repository (DESIGN.md section 2;
+        # tools/gen_goldens_waterz.py makes the vectors that decide; segment config keys of the same names):
+        #   cc_inclusive       an edge joins two fragments when score <= threshold (True, the specification) or score < threshold
+        #   queue_bins_formula bin of a score in the N-bin queue: "n_minus_1" (int)(score (N-1)) (the specification) or "n" min(N-1, (int)(score N))
+        self.cc_inclusive = bool(cc_inclusive)
+        self.queue_bins_formula = str(queue_bins_formula)
+        from .post.engine import QUEUE_BINS_FORMULAS
+        if self.queue_bins_formula not in QUEUE_BINS_FORMULAS:
+            raise ValueError(f"queue_bins_formula {queue_bins_formula!r}: one of {sorted(QUEUE_BINS_FORMULAS)}")
+        if self.queue_bins_formula != "n_minus_1" and not self.host_scores:
+            raise NotImplementedError("the device merge loop (host_scores=False) implements the specified bin rule only")
         self.shape = tuple(int(s) for s in slab_shape)
         self.block = tuple(int(b) for b in block)
         self.ctx = tuple(int(c) for c in context)
@@ -246,6 +257,10 @@ class SlabSegmenter:
         self._lane_of = {}
         self._lane_limit = len(self.lanes)        # lanes _take_lane may use (overlap mode: few while the predict stream runs)
         self.overlap_lanes = 3
+        # host seconds of the last run's parts, per rank (bench.py prints every rank's, so that a slow rank shows): the face
+        # exchanges (posting + completion of the point-to-point transfers as the host sees them), the two block stages up to
+        # the collected edges (exchanges included), the stitch (edge gather, connected components on rank 0, LUT broadcast, relabel)
+        self.timers = {"exchange": 0.0, "blocks": 0.0, "stitch": 0.0}
 
     @staticmethod
     def hbm_bytes(shape, ctx, n_thresholds, n_blocks, label_cap=1 << 16, edge_cap=1 << 17):
@@ -276,6 +291,8 @@ class SlabSegmenter:
     def _exchange(self, t):
         """context margins of `t` ([..., Zp, Yp, Xp]) at the faces shared with other ranks <- the neighbours' outermost layers.  The
         caller has made sure those layers are complete; -> an event on the current stream that fires when the margins are."""
+        import time
+        t_in = time.perf_counter()
         if self.world > 1 and (t is not self.affs or self.exchange_affs):
             # z faces first, then the y faces over the whole padded z extent: the margins just received travel on, which
             # fills the corners with the diagonal neighbour's data
@@ -289,6 +306,7 @@ class SlabSegmenter:
                                self.peers[1][0], self.peers[1][1], self.group)
         ev = torch.cuda.Event()
         ev.record(torch.cuda.current_stream(self.dev))
+        self.timers["exchange"] += time.perf_counter() - t_in
         return ev
 
     # -- stages --------------------------------------------------------------------------
@@ -421,7 +439,7 @@ class SlabSegmenter:
             E = self.edges[:, :m].cpu().numpy().view(np.uint64)
             S = self.esums[:, :m].cpu().numpy()
             C = self.scores.view(torch.int32)[:, :m].cpu().numpy()
-            sc = rag_merge_scores_host(n_edges, E, S, C, 1.0, self.bins)
+            sc = rag_merge_scores_host(n_edges, E, S, C, 1.0, self.bins, bins_formula=self.queue_bins_formula)
             # a block owns the edges whose smaller id is one of its own (first .. first + nvb - 1): one run of its sorted graph
             es, ss = [], []
             for k in range(len(self.boxes)):
@@ -678,8 +696,9 @@ class SlabSegmenter:
         components per threshold; the LUT comes back and every rank relabels its slab.  -> segs [thresholds][Z][Y][X]."""
         nodes = np.concatenate([np.arange(1, int(n) + 1, dtype=np.uint64) + np.uint64(bid * self.nvb)
                                 for n, bid in zip(self.block_nums, self.block_ids)] or [np.zeros(0, np.uint64)])
-        self.nodes, self.luts = gather_and_stitch(nodes, self.rag_edges, self.rag_scores, self.thresholds, self.rank, self.world,
-                                                  self.obj_group)
+        # score < t  <=>  score <= the float32 just below t: the strict rule through the same library call
+        thr = self.thresholds if self.cc_inclusive else [float(np.nextafter(np.float32(t), np.float32(-np.inf))) for t in self.thresholds]
+        self.nodes, self.luts = gather_and_stitch(nodes, self.rag_edges, self.rag_scores, thr, self.rank, self.world, self.obj_group)
         fr = self._fr
         fr.copy_(self.interior(self.frags))
         keys = torch.from_numpy(self.nodes.view(np.int64)).to(self.dev)
@@ -717,8 +736,14 @@ class SlabSegmenter:
             # wait on that event are 16 hardware queues the command processor keeps polling, and the predict stream's
             # launches pay for it: 42.9 against 39.1 ms per block (bench, 64 blocks), although the lanes do nothing.
             ready[-1].synchronize()
+        import time
+        self.timers = {"exchange": 0.0, "blocks": 0.0, "stitch": 0.0}
+        t0 = time.perf_counter()
         self.run_blocks(ready, overlap)
-        return self.stitch()
+        t1 = time.perf_counter()
+        segs = self.stitch()
+        self.timers["blocks"], self.timers["stitch"] = t1 - t0, time.perf_counter() - t1
+        return segs
 
 
 class VolumePipeline:

@@ -313,6 +313,16 @@ int bsmi_rag_graph_u8(bsmi_seg *h, const uint8_t *affs_dev, const uint64_t *frag
 int bsmi_rag_merge_scores_host(int n_graphs, const uint64_t *n_edges, uint64_t *const *edges, uint64_t *const *sums,
                                uint32_t *const *pair_counts, float threshold, int discretize_queue, float *const *scores,
                                int n_threads);
+/* The same with the queue's bin rule as an argument.  waterz's `discretize_queue` binning (reference
+ * post/blockwise/waterz_agglom.py:136; waterz is an unpinned git dependency that is not in /root/reference) cannot be checked
+ * in this repository, so the rule is a documented choice (segment config key `queue_bins_formula`):
+ * BSMI_QUEUE_BINS_N_MINUS_1 (default, what the oracle and the device loop do) bin = (int)(score * (N - 1));
+ * BSMI_QUEUE_BINS_N bin = min(N - 1, (int)(score * N)).  tools/gen_goldens_waterz.py produces the vectors that decide. */
+#define BSMI_QUEUE_BINS_N_MINUS_1 0
+#define BSMI_QUEUE_BINS_N 1
+int bsmi_rag_merge_scores_host_rule(int n_graphs, const uint64_t *n_edges, uint64_t *const *edges, uint64_t *const *sums,
+                                    uint32_t *const *pair_counts, float threshold, int discretize_queue, int bin_rule,
+                                    float *const *scores, int n_threads);
 
 /* Epsilon agglomeration of a block's fragments IN PLACE (reference post/blockwise/watershed_frags.py:158-177:
  * waterz.agglomerate(thresholds=[epsilon], fragments, "OneMinus<MeanAffinity>", discretize_queue=256), result written

@@ -336,6 +336,10 @@ static inline int q_less(const qitem *a, const qitem *b) {
  *   quantile value: pivot = Q * total / 100 + 1 (integer arithmetic, 1-based); the first bin whose running count reaches the
  *     pivot; value = (bin + 0.5) / 256;  score = 1 - value. */
 static __thread int g_quantile = -1;  /* < 0: mean scoring */
+/* bin rule of the discretized queue: 0 (the specification) bin = (int)(score * (N - 1)); 1: min(N - 1, (int)(score * N)).
+ * waterz's own rule is unpinned; the alternative exists so that tools/gen_goldens_waterz.py's vectors can decide. */
+static int g_bin_rule = 0;
+void seg_set_bin_rule(int rule) { g_bin_rule = rule ? 1 : 0; }
 static inline float edge_score(const edge_t *e) {
   if (e->hist) {
     uint64_t total = 0;
@@ -731,7 +735,7 @@ int64_t seg_rag_merge_scores_u8(const uint8_t *affs, const uint64_t *frags, int 
   uint32_t *bhead = (uint32_t *)malloc(4 * nbins), *btail = (uint32_t *)malloc(4 * nbins);
   for (int b = 0; b < nbins; b++) bhead[b] = btail[b] = 0xffffffffu;
   int minbin = nbins;
-#define BPUSH(e_, sc_) do { int b_ = (int)((sc_) * (float)(nbins - 1)); if (b_ < 0) b_ = 0; if (b_ > nbins - 1) b_ = nbins - 1; \
+#define BPUSH(e_, sc_) do { int b_ = (int)((sc_) * (float)(g_bin_rule ? nbins : nbins - 1)); if (b_ < 0) b_ = 0; if (b_ > nbins - 1) b_ = nbins - 1; \
     qnext[e_] = 0xffffffffu; if (bhead[b_] == 0xffffffffu) bhead[b_] = (e_); else qnext[btail[b_]] = (e_); btail[b_] = (e_); \
     if (b_ < minbin) minbin = b_; } while (0)
   /* an edge whose stored score is not below the threshold can never be popped before the loop ends: it is left out

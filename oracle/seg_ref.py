@@ -37,6 +37,8 @@ def _load():
     lib.seg_cc_cut.restype = C.c_int
     lib.seg_cc_affs_u8.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int, vp]
     lib.seg_cc_affs_u8.restype = C.c_int64
+    lib.seg_set_bin_rule.argtypes = [C.c_int]
+    lib.seg_set_bin_rule.restype = None
     lib.seg_count_labels.argtypes = [vp, C.c_int64]
     lib.seg_count_labels.restype = C.c_int64
     return lib
@@ -112,9 +114,11 @@ def label26(x):
     return lab, int(n)
 
 
-def rag_merge_scores_u8(affs_u8, frags, threshold=1.0, discretize_queue=256):
+def rag_merge_scores_u8(affs_u8, frags, threshold=1.0, discretize_queue=256, bins_formula="n_minus_1"):
     """waterz_agglom.py:106-170 for one block -> (edges uint64 [ne][2] ascending, scores float32 [ne]
-    (NaN = never merged), merges uint64 [nm][2] (survivor, absorbed), merge scores float32 [nm])."""
+    (NaN = never merged), merges uint64 [nm][2] (survivor, absorbed), merge scores float32 [nm]).
+    bins_formula: "n_minus_1" (the specification) or "n" (the documented alternative; process-wide while the call runs)."""
+    _lib.seg_set_bin_rule({"n_minus_1": 0, "n": 1}[bins_formula])
     a = np.ascontiguousarray(affs_u8[:3], dtype=np.uint8)
     f = np.ascontiguousarray(frags, dtype=np.uint64)
     _, D, H, W = a.shape
@@ -127,6 +131,7 @@ def rag_merge_scores_u8(affs_u8, frags, threshold=1.0, discretize_queue=256):
     ne = _lib.seg_rag_merge_scores_u8(a.ctypes.data, f.ctypes.data, D, H, W, float(threshold), int(discretize_queue),
                                       edges.ctypes.data, scores.ctypes.data, cap, merges.ctypes.data,
                                       mscores.ctypes.data, C.addressof(nm))
+    _lib.seg_set_bin_rule(0)
     return edges[:ne].copy(), scores[:ne].copy(), merges[:nm.value].copy(), mscores[:nm.value].copy()
 
 

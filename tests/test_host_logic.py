@@ -261,3 +261,40 @@ def test_host_merge_loop_of_the_edge_scoring_equals_the_oracle(shape, sigma, msd
         assert np.isnan(sc[g, ne[g]:]).all()
     if thr < 1.0:
         assert np.isnan(refs[0]).any() and (~np.isnan(refs[0])).any()
+
+
+def test_queue_bin_rule_and_cc_inclusivity_are_switchable():
+    """The two documented choices where waterz / funlib.segment are unpinned (segment config keys
+    `queue_bins_formula`, `cc_inclusive`): the alternative bin rule in the host merge loop equals the oracle run with the same
+    rule (and is a different merge order on a coarse queue), the strict connected-components rule is the inclusive one at the
+    float32 just below the threshold."""
+    from scipy.ndimage import gaussian_filter
+    from bootstrapper_amd.post.engine import rag_merge_scores_host
+    from bootstrapper_amd.post.watershed import connected_components_multi
+    from oracle import seg_ref as S
+    rng = np.random.default_rng(77)
+    differ = 0
+    for bins in (16, 256):
+        a = gaussian_filter(rng.random((3, 6, 64, 64)), sigma=(0, 1, 2, 2))
+        affs = ((a - a.min()) / (a.max() - a.min()) * 255).astype(np.uint8)
+        frags, _ = S.ws_fragments_u8(affs, True, 3)
+        e, sums, cnts = _numpy_region_graph(affs, frags)
+        out = {}
+        for rule in ("n_minus_1", "n"):
+            e_ref, s_ref, _, _ = S.rag_merge_scores_u8(affs, frags, 1.0, bins, bins_formula=rule)
+            E, Sm, Cn = e[None].copy(), sums[None].copy(), cnts[None].copy()
+            sc = rag_merge_scores_host(np.array([len(e)]), E, Sm, Cn, 1.0, bins, bins_formula=rule)
+            assert np.array_equal(e_ref, e) and np.array_equal(sc[0].view(np.uint32), s_ref.view(np.uint32)), (bins, rule)
+            out[rule] = s_ref
+        differ += not np.array_equal(out["n"].view(np.uint32), out["n_minus_1"].view(np.uint32))
+    assert differ >= 1
+    with pytest.raises(ValueError):
+        rag_merge_scores_host(np.array([0]), np.zeros((1, 1, 2), np.uint64), np.zeros((1, 1), np.uint64), np.ones((1, 1), np.uint32), bins_formula="floor")
+    # connected components: score == threshold joins under the inclusive rule only
+    nodes = np.arange(1, 7, dtype=np.uint64)
+    edges = np.array([[1, 2], [2, 3], [4, 5], [5, 6]], dtype=np.uint64)
+    scores = np.array([0.5, 0.25, np.nextafter(np.float32(0.5), np.float32(1)), np.nextafter(np.float32(0.5), np.float32(0))], dtype=np.float32)
+    incl = connected_components_multi(nodes, edges, scores, [0.5])[0]
+    strict = connected_components_multi(nodes, edges, scores, [float(np.nextafter(np.float32(0.5), np.float32(-np.inf)))])[0]
+    assert list(incl) == [1, 1, 1, 4, 5, 5] and list(strict) == [1, 2, 2, 4, 5, 5]
+    assert np.array_equal(incl, S.connected_components(nodes, edges, scores, 0.5))
