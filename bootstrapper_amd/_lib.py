@@ -42,6 +42,12 @@ class Codec(C.Structure):
                 ("typesize", C.c_int32), ("blocksize", C.c_int32)]
 
 
+class ChunkCopy(C.Structure):
+    """bsmi_chunk_copy of include/bsmi_io.h"""
+    _fields_ = [("path", C.c_char_p), ("base", C.c_void_p), ("start", C.c_int64 * 4), ("extent", C.c_int64 * 4),
+                ("stride", C.c_int64 * 4), ("read_modify_write", C.c_int32), ("reserved", C.c_int32)]
+
+
 CODEC_RAW, CODEC_ZLIB, CODEC_GZIP, CODEC_ZSTD, CODEC_LZ4, CODEC_BLOSC = range(6)
 BLOSC_LZ4, BLOSC_ZLIB, BLOSC_ZSTD = 1, 3, 4
 CHUNK_MISSING = 1
@@ -132,6 +138,8 @@ def _load():
                                    C.POINTER(C.c_size_t), C.POINTER(i32), i32]),
         "bsmi_chunks_write": (i32, [C.POINTER(Codec), i32, C.POINTER(C.c_char_p), C.POINTER(vp), C.POINTER(C.c_size_t),
                                     C.POINTER(i32), i32]),
+        "bsmi_chunks_read_into": (i32, [C.POINTER(Codec), i32, C.POINTER(ChunkCopy), i64p, i32, vp, C.POINTER(i32), i32]),
+        "bsmi_chunks_write_from": (i32, [C.POINTER(Codec), i32, C.POINTER(ChunkCopy), i64p, i32, vp, C.POINTER(i32), i32]),
     }
     for name, (res, args) in sigs.items():
         fn = getattr(lib, name)  # AttributeError if the symbol is missing: fail loudly

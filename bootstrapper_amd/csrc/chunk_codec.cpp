@@ -180,7 +180,16 @@ size_t lz4_encode(const uint8_t* src, size_t n, uint8_t* dst, size_t cap) {
       table[h] = (uint32_t)(ip + 1);
       if (cand && ip - (cand - 1) <= 65535 && load32(src + cand - 1) == seq) {
         size_t ref = cand - 1, ml = 4;
+        // eight bytes per step (label volumes are long runs: the byte loop was most of the encoder's time on them)
+        while (ip + ml + 8 <= match_end) {
+          uint64_t a, b;
+          memcpy(&a, src + ref + ml, 8);
+          memcpy(&b, src + ip + ml, 8);
+          if (a != b) { ml += (size_t)(__builtin_ctzll(a ^ b) >> 3); goto extended; }
+          ml += 8;
+        }
         while (ip + ml < match_end && src[ref + ml] == src[ip + ml]) ++ml;
+      extended:
         while (ip > anchor && ref > 0 && src[ip - 1] == src[ref - 1]) {  // extend backwards
           --ip; --ref; ++ml;
         }
@@ -404,7 +413,8 @@ int64_t inner_decode(int fmt, const uint8_t* src, size_t n, uint8_t* dst, size_t
   }
 }
 
-int blosc_decode(const uint8_t* src, size_t n, uint8_t* dst, size_t cap, size_t* out_len) {
+// need: only the first `need` bytes of the chunk are wanted (blocks are independent: the others are not decoded)
+int blosc_decode(const uint8_t* src, size_t n, uint8_t* dst, size_t cap, size_t* out_len, size_t need = ~(size_t)0) {
   if (n < 16) BSMI_IO_FAIL("blosc: buffer shorter than the 16-byte header");
   unsigned flags = src[2];
   size_t ts = src[3] ? src[3] : 1;
@@ -416,7 +426,7 @@ int blosc_decode(const uint8_t* src, size_t n, uint8_t* dst, size_t cap, size_t*
   if (nbytes == 0) return BSMI_OK;
   if (flags & 2) {
     if (16 + nbytes > n) BSMI_IO_FAIL("blosc: stored frame is truncated");
-    memcpy(dst, src + 16, nbytes);
+    memcpy(dst, src + 16, nbytes < need ? nbytes : need);
     return BSMI_OK;
   }
   if (blocksize == 0 || blocksize > nbytes) BSMI_IO_FAIL("blosc: block size %zu does not fit a frame of %zu bytes", blocksize, nbytes);
@@ -426,7 +436,7 @@ int blosc_decode(const uint8_t* src, size_t n, uint8_t* dst, size_t cap, size_t*
   bool bytesh = (flags & 1) && ts > 1, bitsh = !bytesh && (flags & 4) && blocksize >= ts;
   static thread_local std::vector<uint8_t> tmp;
   if (bytesh || bitsh) tmp.resize(blocksize);
-  for (size_t b = 0; b < nblocks; ++b) {
+  for (size_t b = 0; b < nblocks && b * blocksize < need; ++b) {
     bool last_short = (b == nblocks - 1) && leftover;
     size_t bsize = last_short ? leftover : blocksize;
     size_t nsplits = (!(flags & 16) && ts <= (size_t)kMaxSplits && blocksize / ts >= (size_t)kMinBuffer && !last_short) ? ts : 1;
@@ -527,11 +537,11 @@ int blosc_encode(const uint8_t* src, size_t n, int cname, int clevel, int shuffl
   return BSMI_OK;
 }
 
-int decode_any(const bsmi_codec* c, const uint8_t* src, size_t n, uint8_t* dst, size_t cap, size_t* out_len) {
+int decode_any(const bsmi_codec* c, const uint8_t* src, size_t n, uint8_t* dst, size_t cap, size_t* out_len, size_t need = ~(size_t)0) {
   switch (c->id) {
     case BSMI_CODEC_RAW:
       if (n > cap) BSMI_IO_FAIL("raw chunk of %zu bytes, destination has room for %zu", n, cap);
-      memcpy(dst, src, n);
+      memcpy(dst, src, n < need ? n : need);
       *out_len = n;
       return BSMI_OK;
     case BSMI_CODEC_ZLIB:
@@ -559,7 +569,7 @@ int decode_any(const bsmi_codec* c, const uint8_t* src, size_t n, uint8_t* dst, 
       return BSMI_OK;
     }
     case BSMI_CODEC_BLOSC:
-      return blosc_decode(src, n, dst, cap, out_len);
+      return blosc_decode(src, n, dst, cap, out_len, need);
     default:
       BSMI_IO_FAIL("unknown chunk codec id %d", c->id);
   }
@@ -718,6 +728,148 @@ int bsmi_chunks_write(const bsmi_codec* codec, int n, const char* const* paths, 
     if (!write_file_atomic(paths[i], buf.data(), len, &err)) {
       status[i] = BSMI_ERR_INVALID;
       msgs[i] = std::string(paths[i]) + ": " + strerror(err);
+    }
+  });
+  for (int i = 0; i < n; ++i)
+    if (status[i] < 0) BSMI_IO_FAIL("%s", msgs[i].c_str());
+  return BSMI_OK;
+}
+
+
+// ---- chunks <-> a strided host array, without a chunk-sized detour through the caller ---------------------------------------
+extern "C++" {
+namespace {
+struct Region {
+  size_t item, row_bytes, chunk_bytes, first, need;   // first / need: byte offset of the region's first element / end of its last
+  int64_t cs[4], cstride[4];                          // chunk shape, byte strides inside the (C-order) chunk
+};
+bool region_of(const bsmi_chunk_copy& c, const int64_t cs[4], int itemsize, Region* r) {
+  r->item = (size_t)itemsize;
+  int64_t st = itemsize;
+  for (int d = 3; d >= 0; --d) {
+    r->cs[d] = cs[d];
+    r->cstride[d] = st;
+    st *= cs[d];
+    if (c.start[d] < 0 || c.extent[d] < 1 || c.start[d] + c.extent[d] > cs[d]) return false;
+  }
+  if (c.stride[3] != itemsize) return false;
+  r->chunk_bytes = (size_t)st;
+  r->row_bytes = (size_t)c.extent[3] * r->item;
+  r->first = 0;
+  size_t last = 0;
+  for (int d = 0; d < 4; ++d) {
+    r->first += (size_t)(c.start[d] * r->cstride[d]);
+    last += (size_t)((c.start[d] + c.extent[d] - 1) * r->cstride[d]);
+  }
+  r->need = last + r->item;
+  return true;
+}
+template <class F>
+void for_rows(const bsmi_chunk_copy& c, const Region& r, F&& f) {   // f(chunk byte offset, host pointer) per row of extent[3] items
+  for (int64_t a = 0; a < c.extent[0]; ++a)
+    for (int64_t b = 0; b < c.extent[1]; ++b)
+      for (int64_t d = 0; d < c.extent[2]; ++d)
+        f((size_t)((c.start[0] + a) * r.cstride[0] + (c.start[1] + b) * r.cstride[1] + (c.start[2] + d) * r.cstride[2] + c.start[3] * r.cstride[3]),
+          (uint8_t*)c.base + a * c.stride[0] + b * c.stride[1] + d * c.stride[2]);
+}
+void fill_bytes(uint8_t* p, size_t n, const uint8_t* pat, size_t item) {
+  bool zero = true;
+  for (size_t i = 0; i < item; ++i) zero &= pat[i] == 0;
+  if (zero) { memset(p, 0, n); return; }
+  for (size_t i = 0; i + item <= n; i += item) memcpy(p + i, pat, item);
+}
+}  // namespace
+}  // extern "C++"
+
+int bsmi_chunks_read_into(const bsmi_codec* codec, int n, const bsmi_chunk_copy* copies, const int64_t chunk_shape[4], int itemsize,
+                          const void* fill_value, int* status, int threads) {
+  if (!codec || n < 0 || (n && (!copies || !status)) || !chunk_shape || itemsize < 1 || itemsize > 16) BSMI_IO_FAIL("bsmi_chunks_read_into: bad argument");
+  uint8_t fill[16] = {0};
+  if (fill_value) memcpy(fill, fill_value, (size_t)itemsize);
+  for (int i = 0; i < n; ++i) {
+    Region r;
+    if (!copies[i].path || !copies[i].base || !region_of(copies[i], chunk_shape, itemsize, &r))
+      BSMI_IO_FAIL("bsmi_chunks_read_into: region %d lies outside its chunk, or the host array's last axis is not contiguous", i);
+  }
+  std::vector<std::string> msgs((size_t)n);
+  run_pool(n, threads, [&](int i) {
+    static thread_local std::vector<uint8_t> file, plain;
+    const bsmi_chunk_copy& c = copies[i];
+    Region r;
+    region_of(c, chunk_shape, itemsize, &r);
+    int err = 0;
+    if (!read_file(c.path, file, &err)) {
+      if (err != ENOENT) { status[i] = BSMI_ERR_INVALID; msgs[i] = std::string(c.path) + ": " + strerror(err); return; }
+      status[i] = BSMI_CHUNK_MISSING;
+      for_rows(c, r, [&](size_t, uint8_t* host) { fill_bytes(host, r.row_bytes, fill, r.item); });
+      return;
+    }
+    plain.resize(r.chunk_bytes);
+    size_t len = 0;
+    status[i] = decode_any(codec, file.data(), file.size(), plain.data(), plain.size(), &len, r.need);
+    if (status[i] != BSMI_OK) { msgs[i] = std::string(c.path) + ": " + bsmi_last_error(); return; }
+    if (len != r.chunk_bytes) {
+      status[i] = BSMI_ERR_INVALID;
+      msgs[i] = std::string(c.path) + ": chunk decodes to " + std::to_string(len) + " bytes, expected " + std::to_string(r.chunk_bytes);
+      return;
+    }
+    for_rows(c, r, [&](size_t off, uint8_t* host) { memcpy(host, plain.data() + off, r.row_bytes); });
+  });
+  for (int i = 0; i < n; ++i)
+    if (status[i] < 0) BSMI_IO_FAIL("%s", msgs[i].c_str());
+  return BSMI_OK;
+}
+
+int bsmi_chunks_write_from(const bsmi_codec* codec, int n, const bsmi_chunk_copy* copies, const int64_t chunk_shape[4], int itemsize,
+                           const void* fill_value, int* status, int threads) {
+  if (!codec || n < 0 || (n && (!copies || !status)) || !chunk_shape || itemsize < 1 || itemsize > 16) BSMI_IO_FAIL("bsmi_chunks_write_from: bad argument");
+  uint8_t fill[16] = {0};
+  if (fill_value) memcpy(fill, fill_value, (size_t)itemsize);
+  for (int i = 0; i < n; ++i) {
+    Region r;
+    if (!copies[i].path || !copies[i].base || !region_of(copies[i], chunk_shape, itemsize, &r))
+      BSMI_IO_FAIL("bsmi_chunks_write_from: region %d lies outside its chunk, or the host array's last axis is not contiguous", i);
+  }
+  std::vector<std::string> msgs((size_t)n);
+  run_pool(n, threads, [&](int i) {
+    static thread_local std::vector<uint8_t> file, plain, enc;
+    const bsmi_chunk_copy& c = copies[i];
+    Region r;
+    region_of(c, chunk_shape, itemsize, &r);
+    plain.resize(r.chunk_bytes);
+    bool whole = true;
+    for (int d = 0; d < 4; ++d) whole &= c.start[d] == 0 && c.extent[d] == r.cs[d];
+    status[i] = BSMI_OK;
+    if (!whole) {
+      // the rest of the chunk: what the file holds (read_modify_write: the region covers only part of the chunk's valid extent),
+      // else the fill value
+      bool have = false;
+      int err = 0;
+      if (c.read_modify_write && read_file(c.path, file, &err)) {
+        size_t len = 0;
+        int rc = decode_any(codec, file.data(), file.size(), plain.data(), plain.size(), &len);
+        if (rc != BSMI_OK || len != r.chunk_bytes) {
+          status[i] = BSMI_ERR_INVALID;
+          msgs[i] = std::string(c.path) + ": existing chunk cannot be read back: " + (rc != BSMI_OK ? bsmi_last_error() : "wrong size");
+          return;
+        }
+        have = true;
+      } else if (c.read_modify_write && err != ENOENT) {
+        status[i] = BSMI_ERR_INVALID;
+        msgs[i] = std::string(c.path) + ": " + strerror(err);
+        return;
+      }
+      if (!have) fill_bytes(plain.data(), r.chunk_bytes, fill, r.item);
+    }
+    for_rows(c, r, [&](size_t off, uint8_t* host) { memcpy(plain.data() + off, host, r.row_bytes); });
+    enc.resize(bound_any(codec, r.chunk_bytes));
+    size_t len = 0;
+    status[i] = encode_any(codec, plain.data(), r.chunk_bytes, enc.data(), enc.size(), &len);
+    if (status[i] != BSMI_OK) { msgs[i] = std::string(c.path) + ": " + bsmi_last_error(); return; }
+    int err = 0;
+    if (!write_file_atomic(c.path, enc.data(), len, &err)) {
+      status[i] = BSMI_ERR_INVALID;
+      msgs[i] = std::string(c.path) + ": " + strerror(err);
     }
   });
   for (int i = 0; i < n; ++i)

@@ -120,40 +120,95 @@ IO_WORKERS = 3   # layers of blocks in flight between the store and the device (
                  # zarr_io.IO_THREADS native threads, no GIL)
 
 
+PIECE_BYTES = 512 << 20   # staging buffers between the store and the device: page-locked, pooled for the life of the process
+
+
+class _PinnedPool:
+    """Page-locked staging buffers, handed out and taken back (locking a gigabyte takes the runtime a few tenths of a second:
+    the readers' buffers serve the writers afterwards instead of each stage locking its own)."""
+
+    def __init__(self):
+        import threading
+        self.free, self.lock = [], threading.Lock()
+
+    def take(self, nbytes):
+        import torch
+        with self.lock:
+            for i, b in enumerate(self.free):
+                if b.numel() >= nbytes:
+                    return self.free.pop(i)
+        return torch.empty(max(int(nbytes), PIECE_BYTES), dtype=torch.uint8, pin_memory=True)
+
+    def give(self, buf):
+        with self.lock:
+            self.free.append(buf)
+
+
+_PINNED = _PinnedPool()
+
+
 def _fill_affinities(seg, affs, origin, z0, mask=None, y0=0):
     """The box's affinities WITH their context margins straight from the dataset (`to_ndarray(read_roi, fill_value=0)`,
     watershed_frags.py:196-201: zeros beyond the array, real data beyond the ROI), first three channels, masked.
     Streamed: the reference's workers read block by block; here one layer of blocks at a time is decoded by the native
-    chunk codecs on a small pool and copied into the resident slab while the next layers are being read -- the host never
-    holds more than IO_WORKERS layers."""
+    chunk codecs -- the chunk's first three channels only, straight into a page-locked staging buffer (`read_into`: no
+    chunk-sized arrays in the interpreter) -- and copied into the resident slab while the next layers are being read;
+    the host never holds more than IO_WORKERS layers."""
     import concurrent.futures as cf
+    import threading
     import torch
     from .blockwise import read_with_fill
     begin = tuple(o + lo - c for o, lo, c in zip(origin, (z0, y0, 0), seg.ctx))
     full = tuple(s + 2 * c for s, c in zip(seg.shape, seg.ctx))
     step = max(1, seg.block[0])
+    nch = min(3, affs.shape[0])
+    ch0 = 3 - nch    # 2-channel affinities get an all-zero z channel (post/watershed.py:305-308): the slab starts zeroed
+    vol = affs.shape[-3:]
+    staging, streams = {}, {}
 
     def load(za):
         zb = min(full[0], za + step)
-        b, e = (begin[0] + za,) + begin[1:], (begin[0] + zb,) + tuple(bb + f for bb, f in zip(begin[1:], full[1:]))
-        a = read_with_fill(affs, b, e, lead=(affs.shape[0],))[:3]
-        if a.shape[0] == 2:  # 2-channel affinities get an all-zero z channel (post/watershed.py:305-308)
-            a = np.concatenate([np.zeros_like(a[:1]), a])
-        t = torch.from_numpy(np.ascontiguousarray(a)).to(seg.dev)
-        if mask is not None:
+        b = (begin[0] + za,) + begin[1:]
+        e = (begin[0] + zb,) + tuple(bb + f for bb, f in zip(begin[1:], full[1:]))
+        if mask is not None:   # (rare) the masked form through the interpreter
+            a = read_with_fill(affs, b, e, lead=(affs.shape[0],))[:3]
+            t = torch.from_numpy(np.ascontiguousarray(a)).to(seg.dev)
             m = read_with_fill(mask, b, e)
             t = t * torch.from_numpy((m > 0).astype(np.uint8)).to(seg.dev)
-        seg.affs[:, za:zb].copy_(t)
-        torch.cuda.current_stream(seg.dev).synchronize()
-    with cf.ThreadPoolExecutor(max_workers=IO_WORKERS, thread_name_prefix="bsmi-read") as pool:
-        for f in [pool.submit(load, za) for za in range(0, full[0], step)]:
-            f.result()
+            seg.affs[ch0:, za:zb].copy_(t)
+            torch.cuda.current_stream(seg.dev).synchronize()
+            return
+        lo = [max(bb, 0) for bb in b]
+        hi = [min(ee, n) for ee, n in zip(e, vol)]
+        if any(h <= l for l, h in zip(lo, hi)):
+            return   # wholly outside the array: the slab is zero there already
+        tid = threading.get_ident()
+        if tid not in staging:
+            staging[tid] = _PINNED.take(nch * step * full[1] * full[2])
+            streams[tid] = torch.cuda.Stream(seg.dev)
+        ext = tuple(h - l for l, h in zip(lo, hi))
+        host = staging[tid][:nch * ext[0] * ext[1] * ext[2]].view((nch,) + ext)
+        affs.read_into((slice(0, nch),) + tuple(slice(l, h) for l, h in zip(lo, hi)), host.numpy())
+        dst = seg.affs[(slice(ch0, 3),) + tuple(slice(l - bb + off, h - bb + off) for l, h, bb, off in zip(lo, hi, b, (za, 0, 0)))]
+        with torch.cuda.stream(streams[tid]):
+            dst.copy_(host, non_blocking=True)
+        streams[tid].synchronize()
+    # pieces of at most PIECE_BYTES: whole block layers where they fit, else a layer in runs of sections
+    step = max(1, min(step, PIECE_BYTES // max(1, nch * full[1] * full[2])))
+    try:
+        with cf.ThreadPoolExecutor(max_workers=IO_WORKERS, thread_name_prefix="bsmi-read") as pool:
+            for f in [pool.submit(load, za) for za in range(0, full[0], step)]:
+                f.result()
+    finally:
+        for b in staging.values():
+            _PINNED.give(b)
 
 
 class _LayerWriter:
     """Write-behind of a rank's resident volumes: a device tensor [Z][Y][X] goes to its dataset one layer of blocks at a
-    time -- device -> host copy on a side stream, chunk encoding and file writes on the pool's threads -- while the caller
-    carries on (the next stage's kernels, the next dataset).  `drain()` waits for everything and re-raises a failure."""
+    time -- device -> host copy on a side stream into page-locked memory, then the library's threads gather, encode and write the
+    layer's chunks straight from that buffer (`write_from`) -- while the caller carries on (the next stage's kernels, the next
+    dataset).  `drain()` waits for everything and re-raises a failure."""
 
     def __init__(self, dev, step):
         import concurrent.futures as cf
@@ -165,30 +220,38 @@ class _LayerWriter:
         self.futures = []
         self.torch = torch
 
-    def _write(self, ds, src, za, zb, z0, y0, ready):
+    def _write(self, ds, src, za, zb, ya, yb, z0, y0, ready):
         import threading
         torch = self.torch
         ready.synchronize()   # host-side wait (a stream parked behind a device-side wait costs the running kernels)
         tid = threading.get_ident()
         st = self.streams.setdefault(tid, torch.cuda.Stream(self.dev))
-        part = src[za:zb]
+        part = src[za:zb, ya:yb]
+        nbytes = part.numel() * part.element_size()
         buf = self.pinned.get(tid)
-        if buf is None or buf.numel() < part.numel() or buf.dtype != part.dtype:
-            buf = self.pinned[tid] = torch.empty(part.numel(), dtype=part.dtype, pin_memory=True)
-        host = buf[:part.numel()].view(part.shape)
+        if buf is None or buf.numel() < nbytes:
+            if buf is not None:
+                _PINNED.give(buf)
+            buf = self.pinned[tid] = _PINNED.take(nbytes)
+        host = buf[:nbytes].view(part.dtype).view(part.shape)
         with torch.cuda.stream(st):
             host.copy_(part, non_blocking=True)
             done = torch.cuda.Event()
             done.record(st)
         done.synchronize()
-        ds[z0 + za:z0 + zb, y0:y0 + src.shape[1]] = host.numpy().view(np.uint64)
+        ds.write_from((slice(z0 + za, z0 + zb), slice(y0 + ya, y0 + yb)), host.numpy().view(np.uint64))
 
     def submit(self, ds, src, z0, y0):
         """queue `src` (int64 device tensor holding uint64 ids; the producer ran on the current stream) for ds[z0:, y0:]"""
         ready = self.torch.cuda.Event()
         ready.record(self.torch.cuda.current_stream(self.dev))
+        # pieces of whole chunks and at most PIECE_BYTES: a layer of blocks, cut along y at chunk rows where it is larger
+        cy = int(ds.chunks[1])
+        rows = max(cy, PIECE_BYTES // max(1, self.step * src.shape[2] * 8) // cy * cy)
         for za in range(0, src.shape[0], self.step):
-            self.futures.append(self.pool.submit(self._write, ds, src, za, min(src.shape[0], za + self.step), z0, y0, ready))
+            for ya in range(0, src.shape[1], rows):
+                self.futures.append(self.pool.submit(self._write, ds, src, za, min(src.shape[0], za + self.step), ya,
+                                                     min(src.shape[1], ya + rows), z0, y0, ready))
 
     def drain(self):
         try:
@@ -199,6 +262,9 @@ class _LayerWriter:
 
     def close(self):
         self.pool.shutdown()
+        for b in self.pinned.values():
+            _PINNED.give(b)
+        self.pinned = {}
 
 
 def worker_grid(config):

@@ -132,7 +132,15 @@ def predict_blocks(cfg, rank=0, world=1, device=None, precision="bf16x3"):
     device = rank % max(1, torch.cuda.device_count()) if device is None else device
     torch.cuda.set_device(device)
     dev = torch.device("cuda", device)
-    model = Model(cfg["net_config"], device=device, precision=precision).load_checkpoint(cfg["checkpoint"])
+    import concurrent.futures as cf
+    import threading
+    # The checkpoint (379 MB for 3d_affs: torch.load, weight packing, Winograd weight transforms, upload: 0.7 s) is loaded on a
+    # thread of its own while this one opens the datasets and starts the input read; the first block waits for both.
+    def load_model():
+        torch.cuda.set_device(device)
+        return Model(cfg["net_config"], device=device, precision=precision).load_checkpoint(cfg["checkpoint"])
+    side = cf.ThreadPoolExecutor(max_workers=2, thread_name_prefix="bsmi-load")
+    model_future = side.submit(load_model)
     in_ds = open_ds(cfg["input_datasets"][0])
     outs = [open_ds(p, "r+") for p in cfg["output_datasets"]]
     vs = cfg["voxel_size"]
@@ -145,6 +153,8 @@ def predict_blocks(cfg, rank=0, world=1, device=None, precision="bf16x3"):
     mine = rank_blocks(enumerate_blocks(cfg), rank, world)
     if not mine:
         from .blockwise import TaskState
+        model_future.result()
+        side.shutdown()
         return TaskState("PredictBlockwiseTask", 0)
     # The slab of the input this worker's blocks read (with context), clipped to the dataset: z only -- y and x stay
     # whole, so the reflect padding about the dataset faces (gp.Pad on the array source) is the padding about the faces
@@ -159,11 +169,59 @@ def predict_blocks(cfg, rank=0, world=1, device=None, precision="bf16x3"):
         hi = max(hi, 1 - z_need[0])
     whole = nz <= 2 * (in_shape[0] + 1)  # a dataset this thin may be mirrored more than once: keep all of it
     z_lo, z_hi = (0, nz) if whole else (max(0, lo), min(nz, hi))
-    vols = []
+    # The slab streams in behind the first blocks: runs of sections are decoded by the library's threads into page-locked
+    # memory (`read_into`) and copied up on a side stream, in z order; a block starts once the sections it reads -- mirror
+    # images included -- are resident (`loaded`: the slab is resident up to this section).
+    vols, plans = [], []
     for path in cfg["input_datasets"]:
         ds = open_ds(path)
-        a = ds[(slice(None),) * (len(ds.shape) - 3) + (slice(z_lo, z_hi),)]
-        vols += [torch.from_numpy(a).to(dev)] if a.ndim == 3 else [torch.from_numpy(c).to(dev) for c in a]
+        lead = ds.shape[:-3]
+        nlead = int(np.prod(lead)) if lead else 1
+        if len(lead) > 1:
+            raise ValueError(f"{path}: input datasets have at most one channel axis")
+        t = torch.empty((nlead, z_hi - z_lo) + tuple(ds.shape[-2:]), dtype=torch.uint8 if ds.dtype == np.uint8 else torch.from_numpy(np.zeros(0, ds.dtype)).dtype,
+                        device=dev)
+        plans.append((ds, t, bool(lead)))
+        vols += [t[c] for c in range(nlead)]
+    loaded = {"z": z_lo, "error": None}
+    loaded_cv = threading.Condition()
+
+    def load_inputs():
+        try:
+            torch.cuda.set_device(device)
+            st = torch.cuda.Stream(dev)
+            run = max(1, min(out_shape[0], (256 << 20) // max(1, int(np.prod(vols[0].shape[1:])) * len(vols) * vols[0].element_size())))
+            bufs = [torch.empty((t.shape[0], run) + tuple(t.shape[2:]), dtype=t.dtype, pin_memory=True) for _, t, _ in plans]
+            for za in range(z_lo, z_hi, run):
+                zb = min(z_hi, za + run)
+                for (ds, t, has_lead), buf in zip(plans, bufs):
+                    host = buf[:, :zb - za]
+                    if has_lead:
+                        ds.read_into((slice(None), slice(za, zb)), host.numpy())
+                    else:
+                        ds.read_into((slice(za, zb),), host.numpy()[0])
+                    with torch.cuda.stream(st):
+                        t[:, za - z_lo:zb - z_lo].copy_(host, non_blocking=True)
+                st.synchronize()
+                with loaded_cv:
+                    loaded["z"] = zb
+                    loaded_cv.notify_all()
+        except BaseException as exc:  # noqa: BLE001 - handed to the thread that waits for the sections
+            with loaded_cv:
+                loaded["error"] = exc
+                loaded_cv.notify_all()
+    load_future = side.submit(load_inputs)
+
+    def await_sections(blk):
+        """the block's reads, mirror images about the dataset's first / last section included, lie below this section"""
+        lo_r, hi_r = org[0] + blk[0] - ctx[0], org[0] + blk[0] - ctx[0] + in_shape[0]
+        need = z_hi if hi_r > nz else min(z_hi, max(hi_r, 1 - lo_r))
+        with loaded_cv:
+            while loaded["z"] < need and loaded["error"] is None:
+                loaded_cv.wait()
+            if loaded["error"] is not None:
+                raise loaded["error"]
+    model = model_future.result()
     two_d = model.two_d
     adj = int(cfg["net_config"].get("adj_slices", 1))
     if (len(vols) if not two_d else adj * len(vols)) != model._cfg.in_channels:
@@ -186,24 +244,33 @@ def predict_blocks(cfg, rank=0, world=1, device=None, precision="bf16x3"):
         plane = extract_block_reflect(v, [0, off[1], off[2]], [v.shape[0], in_shape[1], in_shape[2]])
         return plane.index_select(0, idx)
 
-    # Write-behind: the device -> host copy of a block's outputs runs on its own stream and the chunk encoding + file
-    # writes (native threads, no GIL: zarr_io / codecs) on a small pool, while the next blocks are predicted.
-    import concurrent.futures as cf
-    copy_stream = torch.cuda.Stream(dev)
-    pool = cf.ThreadPoolExecutor(max_workers=2, thread_name_prefix="bsmi-write")
+    # Write-behind: the device -> host copy of a block's outputs runs on a side stream into page-locked memory and the chunk
+    # encoding + file writes (the library's threads, straight from that buffer: zarr_io.write_from) on a small pool, while the
+    # next blocks are predicted.
+    WRITERS = 4
+    pool = cf.ThreadPoolExecutor(max_workers=WRITERS, thread_name_prefix="bsmi-write")
+    pinned, copy_streams = {}, {}
+
     def write_block(blk, hi, u8, ready):
         ready.synchronize()  # on this pool thread: a copy stream parked behind a device-side wait is a queue the command
-        with torch.cuda.stream(copy_stream):  # processor polls for the whole forward pass, at the predict stream's expense
-            host = [t[:, :hi[0], :hi[1], :hi[2]].to("cpu", non_blocking=True) for t in u8]
-            done = torch.cuda.Event()
-            done.record(copy_stream)
-        done.synchronize()
+        tid = threading.get_ident()   # processor polls for the whole forward pass, at the predict stream's expense
+        if tid not in pinned:
+            pinned[tid] = [torch.empty(t.shape, dtype=t.dtype, pin_memory=True) for t in u8]
+            copy_streams[tid] = torch.cuda.Stream(dev)
+        host = []
+        with torch.cuda.stream(copy_streams[tid]):
+            for buf, t in zip(pinned[tid], u8):
+                h = buf[:, :hi[0], :hi[1], :hi[2]]
+                h.copy_(t[:, :hi[0], :hi[1], :hi[2]], non_blocking=True)
+                host.append(h)
+        copy_streams[tid].synchronize()
         for ds, t in zip(outs, host):
-            ds[(slice(None),) + tuple(slice(blk[d], blk[d] + hi[d]) for d in range(3))] = t.numpy()
+            ds.write_from((slice(None),) + tuple(slice(blk[d], blk[d] + hi[d]) for d in range(3)), t.numpy())
 
     inflight, redo = [], []
 
     def predict_and_submit(blk):
+        await_sections(blk)
         chans = [read_block(v, blk) for v in vols]
         if two_d:  # section z of the stack sees sections z .. z + adj - 1 of the read block as its channels
             chans = [c[i:i + out_shape[0]] for c in chans for i in range(adj)]
@@ -224,7 +291,7 @@ def predict_blocks(cfg, rank=0, world=1, device=None, precision="bf16x3"):
 
     def process(blk):
         inflight.append((blk, predict_and_submit(blk)))
-        settle(4)
+        settle(2 * WRITERS)
     try:
         state = run_blocks("PredictBlockwiseTask", mine, process, MAX_RETRIES)
         settle(0)
@@ -235,6 +302,8 @@ def predict_blocks(cfg, rank=0, world=1, device=None, precision="bf16x3"):
             state.failed_blocks += again.failed_blocks
     finally:
         pool.shutdown()
+        load_future.result()
+        side.shutdown()
     return state
 
 

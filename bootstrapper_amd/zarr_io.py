@@ -18,7 +18,17 @@ import numpy as np
 
 from . import codecs
 
-IO_THREADS = int(os.environ.get("BSMI_IO_THREADS", "8"))
+def _default_threads():
+    """native threads of one read / write request: the cores this process may use, at most 32 (a GPU's share of a node's host
+    cores; `bs segment` keeps a few requests in flight, each on its own set)"""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except (AttributeError, OSError):
+        n = os.cpu_count() or 8
+    return max(4, min(32, n))
+
+
+IO_THREADS = int(os.environ.get("BSMI_IO_THREADS", "0")) or _default_threads()
 
 
 def split_store(path):
@@ -153,8 +163,82 @@ class ZarrArray:
             covers &= lo == ci * c and hi == min((ci + 1) * c, n)
         return tuple(inner), tuple(outer), covers
 
-    def __getitem__(self, key):
+    def _copies(self, box, host, rmw):
+        """the chunks under `box` as bsmi_chunk_copy records against the host array `host` (shape = the box's extents)"""
+        import ctypes as C
+        from . import _lib
+        nd = len(self.shape)
+        grid = self._chunk_grid(box)
+        arr = (_lib.ChunkCopy * max(1, len(grid)))()
+        pad = 4 - nd
+        item = self.dtype.itemsize
+        paths = []
+        for rec, cidx in zip(arr, grid):
+            inner, outer, covers = self._overlap(box, cidx)
+            p = self._chunk_path(cidx).encode()
+            paths.append(p)
+            rec.path = p
+            off = sum(o.start * st for o, st in zip(outer, host.strides))
+            rec.base = host.ctypes.data + off
+            for d in range(4):
+                if d < pad:
+                    rec.start[d], rec.extent[d], rec.stride[d] = 0, 1, 0
+                else:
+                    sl = inner[d - pad]
+                    rec.start[d], rec.extent[d], rec.stride[d] = sl.start, sl.stop - sl.start, host.strides[d - pad]
+            rec.stride[3] = item
+            rec.read_modify_write = 1 if (rmw and not covers) else 0
+        cs = (C.c_int64 * 4)(*([1] * pad + list(self.chunks)))
+        return arr, grid, cs, paths
+
+    def _fill_bytes(self):
+        return np.asarray(self.fill_value, dtype=self.dtype).tobytes()
+
+    def read_into(self, key, out):
+        """self[key] -> the host array `out` (numpy, shape of the selection, last axis contiguous; e.g. a view of page-locked
+        memory), decoded and copied by the library's threads chunk by chunk (no chunk-sized arrays in the interpreter).  A
+        selection that stops before a chunk's last leading index (three of six channels) decodes only that part of a Blosc chunk."""
+        import ctypes as C
+        from . import _lib
         box = self._norm(key)
+        shape = tuple(b - a for a, b in box)
+        if tuple(out.shape) != shape or out.dtype != self.dtype:
+            raise ValueError(f"read_into: destination {out.shape} {out.dtype}, selection {shape} {self.dtype}")
+        if len(self.shape) > 4 or (out.ndim and out.strides[-1] != self.dtype.itemsize) or not out.flags.writeable:
+            out[...] = self._getitem_python(box)
+            return out
+        if out.size == 0:
+            return out
+        arr, grid, cs, _paths = self._copies(box, out, False)
+        status = (C.c_int * len(grid))()
+        fill = self._fill_bytes()
+        _lib.check(_lib.lib.bsmi_chunks_read_into(C.byref(self.codec), len(grid), arr, cs, self.dtype.itemsize,
+                                                  C.c_char_p(fill), status, IO_THREADS))
+        return out
+
+    def write_from(self, key, src):
+        """self[key] = src (numpy, shape of the selection, last axis contiguous): rows gathered, chunks encoded and written by the
+        library's threads; chunks the selection covers only partly are read back first (inside the same threads)."""
+        import ctypes as C
+        from . import _lib
+        if self.mode == "r":
+            raise PermissionError("array opened read-only")
+        box = self._norm(key)
+        shape = tuple(b - a for a, b in box)
+        if tuple(src.shape) != shape or src.dtype != self.dtype or len(self.shape) > 4 or (src.ndim and src.strides[-1] != self.dtype.itemsize) \
+                or any(st < 0 for st in src.strides) or (src.ndim and 0 in src.strides[:-1] and src.size > shape[-1]):
+            src = np.ascontiguousarray(np.broadcast_to(np.asarray(src, dtype=self.dtype), shape))
+        if src.size == 0:
+            return
+        arr, grid, cs, paths = self._copies(box, src, True)
+        for d in {os.path.dirname(p) for p in paths}:
+            os.makedirs(d, exist_ok=True)
+        status = (C.c_int * len(grid))()
+        fill = self._fill_bytes()
+        _lib.check(_lib.lib.bsmi_chunks_write_from(C.byref(self.codec), len(grid), arr, cs, self.dtype.itemsize,
+                                                   C.c_char_p(fill), status, IO_THREADS))
+
+    def _getitem_python(self, box):
         out = np.empty([b - a for a, b in box], dtype=self.dtype)
         grid = self._chunk_grid(box)
         for cidx, chunk in zip(grid, self._read_chunks(grid)):
@@ -162,22 +246,19 @@ class ZarrArray:
             out[outer] = chunk[inner]
         return out
 
+    def __getitem__(self, key):
+        box = self._norm(key)
+        return self.read_into(key, np.empty([b - a for a, b in box], dtype=self.dtype))
+
     def __setitem__(self, key, value):
         if self.mode == "r":
             raise PermissionError("array opened read-only")
         box = self._norm(key)
-        value = np.broadcast_to(np.asarray(value, dtype=self.dtype), [b - a for a, b in box])
-        grid = self._chunk_grid(box)
-        overlaps = [self._overlap(box, cidx) for cidx in grid]
-        # chunks the write covers only partly are read back first (one threaded batch), the others start from fill_value
-        partial = [cidx for cidx, (_, _, covers) in zip(grid, overlaps) if not covers]
-        old = dict(zip(partial, self._read_chunks(partial)))
-        chunks = []
-        for cidx, (inner, outer, covers) in zip(grid, overlaps):
-            chunk = np.full(self.chunks, self.fill_value, dtype=self.dtype) if covers else old[cidx].copy()
-            chunk[inner] = value[outer]
-            chunks.append(chunk)
-        self._write_chunks(grid, chunks)
+        shape = [b - a for a, b in box]
+        v = np.asarray(value, dtype=self.dtype)
+        if list(v.shape) != shape:
+            v = np.ascontiguousarray(np.broadcast_to(v, shape))
+        self.write_from(key, v)
 
     # -- world-unit ROI access ------------------------------------------------------------------
     def roi_to_slices(self, roi_offset, roi_shape):

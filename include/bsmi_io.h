@@ -69,6 +69,31 @@ int bsmi_chunks_read(const bsmi_codec *codec, int n, const char *const *paths, v
 int bsmi_chunks_write(const bsmi_codec *codec, int n, const char *const *paths, const void *const *srcs,
                       const size_t *sizes, int *status, int threads);
 
+/* One chunk <-> one region of a strided host array (arrays of up to 4 axes; fewer: leading axes of length 1).  What zarr-python's
+ * _chunk_getitems / _chunk_setitems do chunk by chunk in the caller's interpreter (decode into a chunk-sized array, then copy the
+ * overlap; reference reads: funlib.persistence Array.to_ndarray under post/blockwise/watershed_frags.py:196-201, writes:
+ * `array[roi] = data` at :222-226) happens here inside the worker thread that decodes / encodes the chunk. */
+typedef struct bsmi_chunk_copy {
+  const char *path;          /* the chunk's file                                                               */
+  void *base;                /* host address of the region's first element                                     */
+  int64_t start[4];          /* first element of the region inside the chunk, per axis                         */
+  int64_t extent[4];         /* elements per axis (>= 1)                                                       */
+  int64_t stride[4];         /* byte strides of the host array; stride[3] must equal the item size             */
+  int32_t read_modify_write; /* write: the region covers only part of the chunk's valid extent -- keep the rest of
+                                what the file holds (0: the rest becomes the fill value)                       */
+  int32_t reserved;
+} bsmi_chunk_copy;
+
+/* Read n regions: decode each chunk (Blosc: only the blocks up to the region's last byte -- reading three of six channels of an
+ * affinity chunk decodes half of it) and copy the region's rows into the host array.  A missing file fills the region with
+ * fill_value (itemsize bytes; NULL = zeros) and sets status[i] = BSMI_CHUNK_MISSING. */
+int bsmi_chunks_read_into(const bsmi_codec *codec, int n, const bsmi_chunk_copy *copies, const int64_t chunk_shape[4],
+                          int itemsize, const void *fill_value, int *status, int threads);
+/* Write n regions: gather the rows from the host array into a chunk image (the rest fill_value, or the file's old content
+ * when read_modify_write), encode, write to a temporary name, rename. */
+int bsmi_chunks_write_from(const bsmi_codec *codec, int n, const bsmi_chunk_copy *copies, const int64_t chunk_shape[4],
+                           int itemsize, const void *fill_value, int *status, int threads);
+
 #ifdef __cplusplus
 }
 #endif

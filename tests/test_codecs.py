@@ -158,3 +158,57 @@ def test_threaded_chunk_files(tmp_path):
         codecs.read_chunks(cd, paths, arrays[0].nbytes, threads=3)
     with pytest.raises(BsmiError, match="No such file"):
         codecs.write_chunks(cd, [str(tmp_path / "nodir" / "x")], arrays[:1])
+
+
+@pytest.mark.parametrize("compressor", ["default", None, "zstd", {"id": "blosc", "cname": "lz4", "clevel": 5, "shuffle": 1, "blocksize": 4096}])
+def test_region_reads_and_writes_against_numpy(tmp_path, compressor):
+    """bsmi_chunks_read_into / bsmi_chunks_write_from (zarr_io.ZarrArray.read_into / write_from, and through them __getitem__ /
+    __setitem__): arbitrary boxes over 2-, 3- and 4-axis arrays -- chunks covered partly (read-modify-write), boxes that end inside
+    a chunk, missing chunks (fill value), a leading-axis prefix (three of six channels: a Blosc chunk is decoded only so far),
+    strided destinations and sources -- against a numpy mirror of the array."""
+    from bootstrapper_amd.zarr_io import prepare_ds, open_ds
+    rng = np.random.default_rng(3)
+    for case, (shape, chunks, dtype) in enumerate([((37, 53), (16, 20), np.uint8), ((20, 33, 41), (8, 16, 16), np.uint64),
+                                                    ((6, 12, 30, 28), (6, 8, 16, 16), np.uint8), ((5, 9, 17, 21), (2, 4, 8, 8), np.float32)]):
+        path = str(tmp_path / f"v{case}.zarr") + "/a"
+        ds = prepare_ds(path, shape, chunk_shape=chunks, dtype=dtype, compressor=compressor,
+                        voxel_size=(1,) * min(3, len(shape)), offset=(0,) * min(3, len(shape)))
+        mirror = np.zeros(shape, dtype)
+        for _ in range(12):
+            lo = [int(rng.integers(0, s)) for s in shape]
+            hi = [int(rng.integers(l + 1, s + 1)) for l, s in zip(lo, shape)]
+            key = tuple(slice(a, b) for a, b in zip(lo, hi))
+            ext = [b - a for a, b in zip(lo, hi)]
+            if dtype == np.float32:
+                val = rng.random(ext).astype(dtype)
+            else:
+                val = (rng.integers(0, 5, ext) * rng.integers(0, 2, ext)).astype(dtype)   # compressible, with runs
+            if _ % 3 == 0:   # a strided source: every other row of a larger array
+                big = np.zeros([2 * e for e in ext[:-1]] + [ext[-1] + 3], dtype)
+                view = big[tuple(slice(0, 2 * e, 2) for e in ext[:-1]) + (slice(1, 1 + ext[-1]),)]
+                view[...] = val
+                ds.write_from(key, view)
+            else:
+                ds[key] = val
+            mirror[key] = val
+            ds2 = open_ds(path)
+            lo = [int(rng.integers(0, s)) for s in shape]
+            hi = [int(rng.integers(l + 1, s + 1)) for l, s in zip(lo, shape)]
+            key = tuple(slice(a, b) for a, b in zip(lo, hi))
+            assert np.array_equal(ds2[key], mirror[key]), (case, key)
+            assert np.array_equal(ds2._getitem_python(ds2._norm(key)), mirror[key])
+            # into a strided destination
+            ext = [b - a for a, b in zip(lo, hi)]
+            big = np.full([e + 2 for e in ext], 7, dtype)
+            dst = big[tuple(slice(1, 1 + e) for e in ext)]
+            ds2.read_into(key, dst)
+            assert np.array_equal(dst, mirror[key]) and big.flat[0] == 7 and big.flat[-1] == 7
+        assert np.array_equal(open_ds(path)[:], mirror)
+        if len(shape) == 4:   # the first channels only
+            assert np.array_equal(open_ds(path)[:3], mirror[:3])
+    # errors: a destination of the wrong shape, a read-only array
+    ds = open_ds(path)
+    with pytest.raises(ValueError):
+        ds.read_into((slice(0, 2),), np.zeros((3, 9, 17, 21), np.float32))
+    with pytest.raises(PermissionError):
+        ds[:1] = 0
