@@ -188,7 +188,9 @@ def _fill_affinities(seg, affs, origin, z0, mask=None, y0=0):
             streams[tid] = torch.cuda.Stream(seg.dev)
         ext = tuple(h - l for l, h in zip(lo, hi))
         host = staging[tid][:nch * ext[0] * ext[1] * ext[2]].view((nch,) + ext)
-        affs.read_into((slice(0, nch),) + tuple(slice(l, h) for l, h in zip(lo, hi)), host.numpy())
+        from .. import _trace
+        with _trace.span("reader: decode", True):
+            affs.read_into((slice(0, nch),) + tuple(slice(l, h) for l, h in zip(lo, hi)), host.numpy())
         dst = seg.affs[(slice(ch0, 3),) + tuple(slice(l - bb + off, h - bb + off) for l, h, bb, off in zip(lo, hi, b, (za, 0, 0)))]
         with torch.cuda.stream(streams[tid]):
             dst.copy_(host, non_blocking=True)
@@ -239,7 +241,9 @@ class _LayerWriter:
             done = torch.cuda.Event()
             done.record(st)
         done.synchronize()
-        ds.write_from((slice(z0 + za, z0 + zb), slice(y0 + ya, y0 + yb)), host.numpy().view(np.uint64))
+        from .. import _trace
+        with _trace.span("writer: encode + write", True):
+            ds.write_from((slice(z0 + za, z0 + zb), slice(y0 + ya, y0 + yb)), host.numpy().view(np.uint64))
 
     def submit(self, ds, src, z0, y0):
         """queue `src` (int64 device tensor holding uint64 ids; the producer ran on the current stream) for ds[z0:, y0:]"""
@@ -288,6 +292,7 @@ def waterz_pipeline(config, device=None, rank=0, world=1, group=None, grid=None,
     default slabs of block layers; bootstrapper_amd.volume): blockwise fragments with context, per-block RAG edge scoring,
     global thresholded connected components, LUT, relabel.  Returns the list of datasets written (fragments first)."""
     import torch
+    from .. import _trace
     from ..blockwise import check_task_states, TaskState
     from ..volume import SlabSegmenter, slab_layers
     from .blockwise import RagStore
@@ -350,6 +355,8 @@ def waterz_pipeline(config, device=None, rank=0, world=1, group=None, grid=None,
         raise ValueError(f"a {grid[0]} x {grid[1]} grid of workers for {layers} layer(s) x {rows} row(s) of blocks leaves rank {rank} without blocks "
                          "(run_waterz_pipeline sizes the grid with bootstrapper_amd.volume.rank_grid)")
     mask = open_ds(config["mask_dataset"]) if config.get("mask_dataset") else None
+    t_slab = _trace.span("segment: slab + lane workspaces allocated")
+    t_slab.__enter__()
     seg = SlabSegmenter((z1 - z0, y1 - y0, total_shape[2]), block_size, ctx, layers, zs[rz], thresholds, frag_params["fragments_in_xy"],
                         frag_params["min_seed_distance"], frag_params["filter_fragments"], frag_params["remove_debris"], 256,
                         n_lanes=int(config.get("lanes", 20)), device=device, rank=rank, world=world, group=group, exchange_affs=False,
@@ -358,11 +365,14 @@ def waterz_pipeline(config, device=None, rank=0, world=1, group=None, grid=None,
                         cc_inclusive=bool(config.get("cc_inclusive", True)), queue_bins_formula=config.get("queue_bins_formula", "n_minus_1"),
                         epsilon_agglomerate=frag_params["epsilon_agglomerate"], sigma=frag_params["sigma"],
                         noise_eps=frag_params["noise_eps"], bias=frag_params["bias"], seed_eps=frag_params["seed_eps"])
-    _fill_affinities(seg, affs, origin, z0, mask, y0)
+    t_slab.__exit__(None, None, None)
+    with _trace.span("segment: affinities read into the slab"):
+        _fill_affinities(seg, affs, origin, z0, mask, y0)
     og = obj_group if obj_group is not None else group   # pickled objects: never through an RCCL group
 
     # fragments + edge scores of this worker's blocks (post/watershed.py:118-153), accounted like daisy tasks
-    states = seg.run_blocks_accounted()
+    with _trace.span("segment: fragments + edge scores of the blocks"):
+        states = seg.run_blocks_accounted()
     if world > 1:
         import torch.distributed as dist
         mine = {k: v.as_tuple() for k, v in states.items()}
@@ -392,6 +402,9 @@ def waterz_pipeline(config, device=None, rank=0, world=1, group=None, grid=None,
     writer.submit(open_ds(frags_name, "r+"), seg.interior(seg.frags), z0, y0)
 
     # RAG to the database (rank 0 gathers nodes and all edges, scored or not: post/watershed.py:100-117 db config)
+    import concurrent.futures as cf
+    aux = cf.ThreadPoolExecutor(max_workers=2, thread_name_prefix="bsmi-aux")   # the database and the LUT files, beside the stitch
+    aux_jobs = []
     ids, pos, size = seg.node_table()
     pos = np.asarray(roi[0], np.float64) + (pos + np.array([z0, y0, 0], np.float64)) * np.asarray(voxel_size, np.float64)
     mine = (ids, pos, size, seg.rag_edges, seg.rag_scores)
@@ -403,18 +416,25 @@ def waterz_pipeline(config, device=None, rank=0, world=1, group=None, grid=None,
         parts = [mine]
     db = config.get("db") or {}
     if rank == 0 and "db_file" in db:
-        rag = RagStore()
-        for p in parts:
-            rag.add_nodes(p[0], p[1], p[2])
-            rag.add_edges(p[3], p[4])
-        rag.to_sqlite(db["db_file"])
+        def export():
+            with _trace.span("segment: RAG -> SQLite (beside the stitch)"):
+                rag = RagStore()
+                for p in parts:
+                    rag.add_nodes(p[0], p[1], p[2])
+                    rag.add_edges(p[3], p[4])
+                rag.to_sqlite(db["db_file"])
+        aux_jobs.append(aux.submit(export))
 
     # global segmentation: thresholded connected components -> LUT -> relabel (post/watershed.py:155-203)
     written = [frags_name]
-    segs = seg.stitch()
+    with _trace.span("segment: stitch (connected components, LUT, relabel)"):
+        segs = seg.stitch()
     if seg.nodes.size == 0:
         writer.drain()
         writer.close()
+        for j in aux_jobs:
+            j.result()
+        aux.shutdown()
         return written
     lut_dir = config["lut_dir"]
     for t, threshold in enumerate(thresholds):
@@ -425,15 +445,21 @@ def waterz_pipeline(config, device=None, rank=0, world=1, group=None, grid=None,
         if rank == 0:
             os.makedirs(lut_dir, exist_ok=True)
             lut_path = os.path.join(lut_dir, name)
-            np.savez_compressed(lut_path + ".npz", fragment_segment_lut=np.array([seg.nodes, seg.luts[t]]))
+            aux_jobs.append(aux.submit(np.savez_compressed, lut_path + ".npz", fragment_segment_lut=np.array([seg.nodes, seg.luts[t]])))
             dump_lut_params(lut_path, recorded)
             prepare_ds(seg_name, shape=total_shape, **common)
             dump_params(seg_name, recorded)
         barrier()
         writer.submit(open_ds(seg_name, "r+"), segs[t], z0, y0)
         written.append(seg_name)
-    writer.drain()
+    with _trace.span("segment: wait for the dataset writers"):
+        writer.drain()
     writer.close()
+    with _trace.span("segment: wait for the database / LUT files"):
+        for j in aux_jobs:
+            j.result()
+    aux.shutdown()
+    _trace.report("segment: ")
     barrier()
     return written
 

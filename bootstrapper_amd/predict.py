@@ -134,11 +134,13 @@ def predict_blocks(cfg, rank=0, world=1, device=None, precision="bf16x3"):
     dev = torch.device("cuda", device)
     import concurrent.futures as cf
     import threading
+    from . import _trace
     # The checkpoint (379 MB for 3d_affs: torch.load, weight packing, Winograd weight transforms, upload: 0.7 s) is loaded on a
     # thread of its own while this one opens the datasets and starts the input read; the first block waits for both.
     def load_model():
         torch.cuda.set_device(device)
-        return Model(cfg["net_config"], device=device, precision=precision).load_checkpoint(cfg["checkpoint"])
+        with _trace.span("predict: checkpoint -> packed weights on the device"):
+            return Model(cfg["net_config"], device=device, precision=precision).load_checkpoint(cfg["checkpoint"])
     side = cf.ThreadPoolExecutor(max_workers=2, thread_name_prefix="bsmi-load")
     model_future = side.submit(load_model)
     in_ds = open_ds(cfg["input_datasets"][0])
@@ -196,10 +198,11 @@ def predict_blocks(cfg, rank=0, world=1, device=None, precision="bf16x3"):
                 zb = min(z_hi, za + run)
                 for (ds, t, has_lead), buf in zip(plans, bufs):
                     host = buf[:, :zb - za]
-                    if has_lead:
-                        ds.read_into((slice(None), slice(za, zb)), host.numpy())
-                    else:
-                        ds.read_into((slice(za, zb),), host.numpy()[0])
+                    with _trace.span("predict: input sections decoded", True):
+                        if has_lead:
+                            ds.read_into((slice(None), slice(za, zb)), host.numpy())
+                        else:
+                            ds.read_into((slice(za, zb),), host.numpy()[0])
                     with torch.cuda.stream(st):
                         t[:, za - z_lo:zb - z_lo].copy_(host, non_blocking=True)
                 st.synchronize()
@@ -216,12 +219,13 @@ def predict_blocks(cfg, rank=0, world=1, device=None, precision="bf16x3"):
         """the block's reads, mirror images about the dataset's first / last section included, lie below this section"""
         lo_r, hi_r = org[0] + blk[0] - ctx[0], org[0] + blk[0] - ctx[0] + in_shape[0]
         need = z_hi if hi_r > nz else min(z_hi, max(hi_r, 1 - lo_r))
-        with loaded_cv:
+        with _trace.span("predict: block loop waits for input sections", True), loaded_cv:
             while loaded["z"] < need and loaded["error"] is None:
                 loaded_cv.wait()
             if loaded["error"] is not None:
                 raise loaded["error"]
-    model = model_future.result()
+    with _trace.span("predict: wait for the model"):
+        model = model_future.result()
     two_d = model.two_d
     adj = int(cfg["net_config"].get("adj_slices", 1))
     if (len(vols) if not two_d else adj * len(vols)) != model._cfg.in_channels:
@@ -252,7 +256,9 @@ def predict_blocks(cfg, rank=0, world=1, device=None, precision="bf16x3"):
     pinned, copy_streams = {}, {}
 
     def write_block(blk, hi, u8, ready):
-        ready.synchronize()  # on this pool thread: a copy stream parked behind a device-side wait is a queue the command
+        with _trace.span("predict: writer waits for its block", True):
+            ready.synchronize()
+        # ^ on this pool thread: a copy stream parked behind a device-side wait is a queue the command
         tid = threading.get_ident()   # processor polls for the whole forward pass, at the predict stream's expense
         if tid not in pinned:
             pinned[tid] = [torch.empty(t.shape, dtype=t.dtype, pin_memory=True) for t in u8]
@@ -263,9 +269,11 @@ def predict_blocks(cfg, rank=0, world=1, device=None, precision="bf16x3"):
                 h = buf[:, :hi[0], :hi[1], :hi[2]]
                 h.copy_(t[:, :hi[0], :hi[1], :hi[2]], non_blocking=True)
                 host.append(h)
-        copy_streams[tid].synchronize()
-        for ds, t in zip(outs, host):
-            ds.write_from((slice(None),) + tuple(slice(blk[d], blk[d] + hi[d]) for d in range(3)), t.numpy())
+        with _trace.span("predict: device -> host copy", True):
+            copy_streams[tid].synchronize()
+        with _trace.span("predict: encode + write", True):
+            for ds, t in zip(outs, host):
+                ds.write_from((slice(None),) + tuple(slice(blk[d], blk[d] + hi[d]) for d in range(3)), t.numpy())
 
     inflight, redo = [], []
 
@@ -285,7 +293,8 @@ def predict_blocks(cfg, rank=0, world=1, device=None, precision="bf16x3"):
         while len(inflight) > limit:
             blk, fut = inflight.pop(0)
             try:
-                fut.result()
+                with _trace.span("predict: block loop waits for a writer", True):
+                    fut.result()
             except Exception:  # noqa: BLE001 - the block is predicted and written again below
                 redo.append(blk)
 
@@ -293,8 +302,10 @@ def predict_blocks(cfg, rank=0, world=1, device=None, precision="bf16x3"):
         inflight.append((blk, predict_and_submit(blk)))
         settle(2 * WRITERS)
     try:
-        state = run_blocks("PredictBlockwiseTask", mine, process, MAX_RETRIES)
-        settle(0)
+        with _trace.span("predict: block loop"):
+            state = run_blocks("PredictBlockwiseTask", mine, process, MAX_RETRIES)
+        with _trace.span("predict: drain the writers"):
+            settle(0)
         if redo:  # a write failed after its block had been counted: the whole block again, awaited, with the retries left
             again = run_blocks("PredictBlockwiseTask", redo, lambda blk: predict_and_submit(blk).result(), MAX_RETRIES - 1)
             state.completed_count += again.completed_count - len(redo)
@@ -304,6 +315,7 @@ def predict_blocks(cfg, rank=0, world=1, device=None, precision="bf16x3"):
         pool.shutdown()
         load_future.result()
         side.shutdown()
+        _trace.report()
     return state
 
 
