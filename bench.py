@@ -592,12 +592,14 @@ def main():
         pipe.seg.prime()   # the slab-sized reductions / relabel kernels once, on the empty slab
     model.profile(max(1, args.profile_every))
     model.profile_totals(reset=True)
+    model.profile_executed(reset=True)
     barrier()
     t0 = time.perf_counter()
     segs = pipe.run(vol)
     barrier()
     dt = time.perf_counter() - t0
     totals = model.profile_totals(reset=True)
+    executed_flops = model.profile_executed(reset=True)
     model.profile(False)
     t_pred, t_seg = pipe.t_predict, 0.0
     if not args.no_segment:
@@ -646,6 +648,12 @@ def main():
                      "kernel": "every convolution stage of the U-Net: bsmi::conv_igemm_kernel / conv_igemm_sk_kernel launches, conv_h16_kernel for five of the six stages with at most 64 output channels and, for the five stages in Winograd F(2x2,3x3) form, wino_in_kernel + the batched conv_igemm_sk_kernel launch + wino_out_kernel (their time is inside the stage's; FLOPs are the direct convolution's)",
                      "launches": int(conv_launches), "avg_launch_ms": conv_ms / max(conv_launches, 1),
                      "timed": f"HIP events around every launch of every {max(1, args.profile_every)}. block of the timed region",
+                     # the multiplies the matrix pipe was actually given (tile padding, all 16 / 36 batches of a Winograd stage, three bf16
+                     # products per product of the split mode) against the DENSE peak of the pipe: a Winograd stage computes its layer
+                     # with 2.25x (F(2x2)) or 4x (F(4x4)) fewer multiplies than `achieved` counts, so `frac` can pass what the pipe could
+                     # do on the direct form; this figure cannot
+                     "executed_tflops": executed_flops / (conv_ms * 1e-3) / 1e12 if conv_ms > 0 else 0.0,
+                     "executed_mfma_frac": (executed_flops / (conv_ms * 1e-3) / 1e12 / (BF16_DENSE_PEAK_TFLOPS if args.precision != "f32" else MFMA_PEAK_TFLOPS["f32"])) if conv_ms > 0 else 0.0,
                      "mfma_busy_pmc": pmc_mfma_busy(args.precision),
                      "algorithmic_tflop_per_block": flops_block / 1e12,
                      "other_unet_ms_per_block": sum(totals[k][0] for k in ("input", "pool", "upsample", "head")) / max(args.steps, 1)},

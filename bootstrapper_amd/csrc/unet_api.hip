@@ -263,6 +263,25 @@ static bool wino_eligible(const PassSite& p, int ci) {
   return cin >= 256 && p.cout >= 256;
 }
 
+// Which Winograd stages use the F(4x4, 3x3) tile (round 4).  BSMI_WINO4: 0 = none, unset / 1 = the stages with at least 1024
+// input channels (of the 3d_affs net: 1500 -> 1500 and 1800 -> 300, half of a block's multiplies; 36 products per 16 outputs
+// instead of 16 per 4, at four times F(2x2)'s rounding error on a layer -- DESIGN.md section 4 --, which the two stages can
+// afford inside the 1e-4 gate and fourteen could not), 2 = every Winograd stage (tests: small nets).
+static int wino4_mode() {
+  static const int m = [] { const char* e = getenv("BSMI_WINO4"); return e ? atoi(e) : 1; }();
+  return m;
+}
+static int wino_tile_edge(const PassSite& p, int ci) {
+  if (wino4_mode() == 0) return 2;
+  if (wino4_mode() >= 2) return 4;
+  int cin = p.cout;
+  if (ci == 0) {
+    cin = 0;
+    for (int s = 0; s < p.nslots; ++s) cin += p.cin[s];
+  }
+  return cin >= 1024 ? 4 : 2;
+}
+
 static int pack_wino(bsmi_unet* h, PassSite& p, int ci) {
   PackedWino& pw = p.wino[ci];
   if (pw.w) { (void)hipFree(pw.w); pw.w = nullptr; }
@@ -286,13 +305,14 @@ static int pack_wino(bsmi_unet* h, PassSite& p, int ci) {
     for (int c = 0; c < round_up(p.cout, kChanPad); ++c) pw.cin_of_v.push_back(c < p.cout ? c : -1);
   }
   pw.Cv = (int)pw.cin_of_v.size();
+  pw.m = wino_tile_edge(p, ci);
   pw.tile = choose_tile(p.cout);
   pw.Npad = round_up(p.cout, tile_bn(pw.tile));
   wino_units(pw.Cv, pw.units);
   {
     std::vector<uint16_t> packed;
     size_t image_elems = 0, batch_elems = 0;
-    wino_pack_weights(wm.data.data(), p.cout, cin_m, pw.cin_of_v, pw.Npad, pw.units, packed, image_elems, batch_elems);
+    wino_pack_weights(wm.data.data(), p.cout, cin_m, pw.cin_of_v, pw.Npad, pw.units, packed, image_elems, batch_elems, pw.m);
     pw.lo_image_bytes = image_elems * 2;
     pw.batch_bytes = batch_elems * 2;
     BSMI_HIP(hipMalloc(&pw.w, packed.size() * 2));
@@ -809,12 +829,13 @@ struct Planner {
     st.use_wino = false;
     const PackedWino& pw = p.wino[ci];
     const bool wants_fused = fuse_up && (ci == 0 || ci == p.nconv - 1);
-    if (prec != BSMI_PREC_BF16X3 || !pw.ready || (o.H & 1) || (o.W & 1) || st.use_box || st.use_rh) {
+    const int wm = pw.m, nbatch = wino_batches(wm);
+    if (prec != BSMI_PREC_BF16X3 || !pw.ready || (wm == 2 && ((o.H & 1) || (o.W & 1))) || st.use_box || st.use_rh) {
       if (wants_fused) BSMI_FAIL(BSMI_ERR_STATE, "%s conv %d: the upsampling was fused into this stage, which cannot take the Winograd form", p.prefix.c_str(), ci);
       return BSMI_OK;
     }
     const int nsrc = ci == 0 ? p.nslots : 1;
-    const int Dv = o.D + 2, Ty = o.H / 2, Tx = o.W / 2, Cv = pw.Cv;
+    const int Dv = o.D + 2, Ty = (o.H + wm - 1) / wm, Tx = (o.W + wm - 1) / wm, Cv = pw.Cv;   // F(4x4): the last tiles may overhang
     const size_t vbatch = (size_t)Dv * Ty * Tx * Cv * 4;  // bytes of one batch of V: (hi, lo) pairs
     if (vbatch >= ((size_t)1 << 31)) {                     // 31-bit byte offsets inside a batch
       if (wants_fused) BSMI_FAIL(BSMI_ERR_STATE, "%s conv %d: fused upsampling, but the transformed input is too large", p.prefix.c_str(), ci);
@@ -822,11 +843,11 @@ struct Planner {
     }
     const size_t Mrows = (size_t)o.D * Ty * Tx;
     void *V = nullptr, *Mbuf = nullptr, *addend = nullptr;
-    BSMI_HIP(hipMalloc(&V, kWinoBatch * vbatch + 4096));
+    BSMI_HIP(hipMalloc(&V, nbatch * vbatch + 4096));
     plan->allocs.push_back(V);
-    BSMI_HIP(hipMalloc(&Mbuf, kWinoBatch * Mrows * o.Cpad * sizeof(float)));
+    BSMI_HIP(hipMalloc(&Mbuf, nbatch * Mrows * o.Cpad * sizeof(float)));
     plan->allocs.push_back(Mbuf);
-    plan->bytes += kWinoBatch * (vbatch + Mrows * o.Cpad * sizeof(float));
+    plan->bytes += nbatch * (vbatch + Mrows * o.Cpad * sizeof(float));
     WinoInArgs& wi = st.wino_in;
     memset(&wi, 0, sizeof wi);
     int cv0 = 0;
@@ -849,6 +870,7 @@ struct Planner {
     wi.nsrc = nsrc;
     wi.V = V;
     wi.Dv = Dv; wi.Ty = Ty; wi.Tx = Tx; wi.Cv = Cv;
+    wi.m = wm;
     // the batched GEMMs: a (3,1,1) convolution of V[b] with U[b]
     ConvArgs& g = st.wino_gemm;
     memset(&g, 0, sizeof g);
@@ -884,7 +906,7 @@ struct Planner {
     g.M = (int)Mrows;
     g.Npad = pw.Npad;
     g.relu = 0;
-    g.nbatch = kWinoBatch;
+    g.nbatch = nbatch;
     g.raw = 1;
     g.a_batch = (int64_t)vbatch;
     g.w_batch = (int64_t)pw.batch_bytes;
@@ -993,7 +1015,14 @@ struct Planner {
     wo.bias = pc.bias;
     wo.out = o.ptr;
     wo.Do = o.D; wo.Ty = Ty; wo.Tx = Tx; wo.Co = o.Cpad;
+    wo.m = wm; wo.Ho = o.H; wo.Wo = o.W;
     wo.relu = 1;
+    {
+      const double kstep = (double)kUnitsPerStep * sube(prec);
+      st.exec_flops = 2.0 * (double)round_up((int)Mrows, 256) * pw.Npad * ((double)g.nsteps * kstep) * nbatch * 3.0;
+      if (st.wino_has_res) st.exec_flops += 2.0 * (double)round_up(st.wino_res.M, 256) * pw.Npad * ((double)st.wino_res.nsteps * kstep) * 3.0;
+      if (st.wino_has_res_low) st.exec_flops += 2.0 * (double)round_up(st.wino_res_low.M, 256) * pw.Npad * ((double)st.wino_res_low.nsteps * kstep) * 3.0;
+    }
     st.tile = pw.tile;
     st.use_wino = true;
     (void)nsl;
@@ -1105,6 +1134,11 @@ struct Planner {
         a.Npad = pc.Npad;
         a.relu = 1;  // trunk activation is ReLU (model.py passes activation default "ReLU")
         st.flops = 2.0 * M * p.cout * kreal;
+        {
+          const double x3 = prec == BSMI_PREC_BF16X3 ? 3.0 : 1.0;
+          const double kstep = (double)kUnitsPerStep * sube(prec);   // channels x taps of one K-step
+          st.exec_flops = 2.0 * (double)round_up(a.M, 256) * pc.Npad * ((double)(ks.size() / KS) * kstep) * x3;
+        }
         st.site = &p;
         st.ci = ci;
         st.nsl = nsl;
@@ -1126,7 +1160,7 @@ struct Planner {
         if (getenv("BSMI_PLAN_DEBUG"))
           fprintf(stderr, "[bsmi plan] %s conv %d: out (%d,%d,%d)x%d tile BN=%d K-steps %d %s\n", p.prefix.c_str(), ci, o.D, o.H, o.W,
                   p.cout, tile_bn(st.tile), st.use_wino ? st.wino_gemm.nsteps : a.nsteps,
-                  st.use_wino ? "winograd F(2x2,3x3)" : st.use_h16 ? "halo-resident" : st.use_box ? "box-halo" : st.use_rh ? "raster-halo" : "gather");
+                  st.use_wino ? (st.wino_in.m == 4 ? "winograd F(4x4,3x3)" : "winograd F(2x2,3x3)") : st.use_h16 ? "halo-resident" : st.use_box ? "box-halo" : st.use_rh ? "raster-halo" : "gather");
         plan->steps.push_back(st);
       }
       cur = o;
@@ -1212,8 +1246,9 @@ struct Planner {
       int sp[3] = {target[0], target[1], target[2]};
       for (int c = 0; c < rp.nconv && fuse; ++c) {
         for (int d = 0; d < 3; ++d) sp[d] -= rp.k[c][d] - 1;
-        if ((c == 0 || c == rp.nconv - 1) && ((sp[1] & 1) || (sp[2] & 1) || sp[0] <= 0 || sp[1] <= 0 || sp[2] <= 0)) fuse = false;
-        if ((c == 0 || c == rp.nconv - 1) && (size_t)(sp[0] + 2) * (sp[1] / 2) * (sp[2] / 2) * rp.wino[c].Cv * 4 >= ((size_t)1 << 31)) fuse = false;
+        const int wm = rp.wino[c].m;
+        if ((c == 0 || c == rp.nconv - 1) && ((wm == 2 && ((sp[1] & 1) || (sp[2] & 1))) || sp[0] <= 0 || sp[1] <= 0 || sp[2] <= 0)) fuse = false;
+        if ((c == 0 || c == rp.nconv - 1) && (size_t)(sp[0] + 2) * ((sp[1] + wm - 1) / wm) * ((sp[2] + wm - 1) / wm) * rp.wino[c].Cv * 4 >= ((size_t)1 << 31)) fuse = false;
       }
     }
     size_t up_index = 0;
@@ -1295,6 +1330,7 @@ static int harvest(bsmi_unet* h, Plan* plan) {
       const int ty = (plan->fused_first && i < 2) ? (int)PlanStep::CONV : (int)plan->steps[i].type;
       h->prof_ms[ty] += t;
       h->prof_flops[ty] += plan->steps[i].flops;
+      if (ty == 1) h->prof_exec += plan->steps[i].exec_flops > 0 ? plan->steps[i].exec_flops : plan->steps[i].flops * (plan->prec == BSMI_PREC_BF16X3 ? 3.0 : 1.0);
       h->prof_launches[ty] += (plan->fused_first && i < 2) ? 0 : 1;
     }
     plan->spare.push_back(std::move(set));
@@ -1789,6 +1825,13 @@ int bsmi_unet_profile_totals(bsmi_unet* h, double ms_by_type[5], double flops_by
     if (launches_by_type) launches_by_type[i] = h->prof_launches[i];
     if (reset) { h->prof_ms[i] = 0; h->prof_flops[i] = 0; h->prof_launches[i] = 0; }
   }
+  return BSMI_OK;
+}
+
+int bsmi_unet_profile_executed(bsmi_unet* h, double* executed_flops, int reset) {
+  if (!h || !executed_flops) BSMI_FAIL(BSMI_ERR_INVALID, "null argument");
+  *executed_flops = h->prof_exec;
+  if (reset) h->prof_exec = 0;
   return BSMI_OK;
 }
 

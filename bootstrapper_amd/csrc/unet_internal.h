@@ -58,6 +58,7 @@ struct PackedConv {
 // output transform).
 struct PackedWino {
   bool ready = false;
+  int m = 2;                        // output tile edge: F(2x2, 3x3) or F(4x4, 3x3)
   std::vector<WinoUnit> units;      // K-step list of every batch
   std::vector<int> cin_of_v;        // V channel -> input channel of the concatenated input (-1: pad)
   int Cv = 0;                       // channels of V: every source padded to kChanPad
@@ -138,6 +139,11 @@ struct PlanStep {
   bool skip = false;     // UP step whose map nobody reads: its consumers upsample on the fly (plan_wino, fuse_up)
   int head = 0;
   double flops = 0;  // algorithmic FLOPs of this launch
+  // multiply-adds the matrix pipe is actually given (x 2): tile-padded rows x padded columns x padded K, every batch of a Winograd
+  // stage, three bf16 products per one of the split mode -- what `roofline.executed_mfma_frac` of bench.py prices against the
+  // dense bf16 peak.  Exact for the implicit-GEMM and Winograd launches; the halo / box / first-pass kernels count their
+  // algorithmic products (x 3 in the split mode), i.e. without their padding
+  double exec_flops = 0;
   // what the backward pass (train.hip) needs to know about a CONV step
   struct PassSite* site = nullptr;
   int ci = 0;                        // stage index inside the ConvPass
@@ -193,6 +199,7 @@ struct bsmi_unet {
   uint64_t profile_count = 0;
   Plan* last_plan = nullptr;
   double prof_ms[5] = {0, 0, 0, 0, 0}, prof_flops[5] = {0, 0, 0, 0, 0};
+  double prof_exec = 0;  // executed FLOPs of the profiled conv launches (PlanStep::exec_flops)
   int64_t prof_launches[5] = {0, 0, 0, 0, 0};
   std::map<std::vector<int64_t>, std::unique_ptr<Plan>> plans;  // key: prec, D, H, W
   float* sk_ws = nullptr;  // split-K tail partial tiles + work-queue counters (conv_igemm.h)

@@ -1,4 +1,5 @@
-// Winograd F(2x2, 3x3) in (y, x) for the 3x3x3 layers of the split-bf16 mode whose K is large (wino.hip).
+// Winograd F(2x2, 3x3) -- and, round 4, F(4x4, 3x3) for the widest stages -- in (y, x) for the 3x3x3 layers of the split-bf16
+// mode whose K is large (wino.hip).  `m` = output tile edge (2 or 4), T = m + 2 = input tile edge, T * T batches.
 #pragma once
 #include <vector>
 
@@ -6,7 +7,9 @@
 
 namespace bsmi {
 
-constexpr int kWinoBatch = 16;  // transform positions (xi, nu) of a 4 x 4 input tile, b = 4 * xi + nu
+constexpr int kWinoBatch = 16;  // F(2x2): transform positions (xi, nu) of a 4 x 4 input tile, b = 4 * xi + nu
+constexpr int kWinoMaxBatch = 36;  // F(4x4): 6 x 6 input tile, b = 6 * xi + nu
+inline int wino_batches(int m) { return (m + 2) * (m + 2); }
 constexpr int kWinoMaxSrc = 2;  // source tensors of the input transform (skip connection + upsampled map)
 
 // Input transform: V[b][z][ty][tx][c] = (B^T d B)[xi][nu] of the 4 x 4 in-plane tile d whose first voxel is
@@ -22,8 +25,11 @@ struct WinoInArgs {
   // 128^3 block is 1.3 GB that the stage's transform was the only reader of besides a residual branch, see WinoOutArgs)
   int upf[kWinoMaxSrc];
   int nsrc;
-  void* V;  // split-bf16 [16][Dv][Ty][Tx][Cv]
+  void* V;  // split-bf16 [T * T][Dv][Ty][Tx][Cv]
   int Dv, Ty, Tx, Cv;
+  int m;    // 2 (0 reads as 2) or 4: tile (ty, tx) starts at voxel (m ty, m tx); F(4x4) tiles may overhang the layer's input (the
+            // last tile row / column of an extent that is no multiple of 4): reads are clamped to the source, the outputs
+            // that depend on them are never stored
 };
 
 // Output transform: out[z][2 ty + p][2 tx + q][c] = relu( (A^T M A)[p][q] + bias[c] + addend[...] ) as (hi, lo) pairs, where
@@ -37,9 +43,10 @@ struct WinoOutArgs {
   const float* low;
   int lD, lH, lW, lf, loz, loy, lox;
   const float* bias;    // [>= Co]
-  void* out;            // split-bf16 [Do][2 Ty][2 Tx][Co]
+  void* out;            // split-bf16 [Do][Ho][Wo][Co]
   int Do, Ty, Tx, Co;
   int relu;
+  int m, Ho, Wo;        // m = 2 (0 reads as 2): Ho = 2 Ty, Wo = 2 Tx; m = 4: Ho <= 4 Ty, Wo <= 4 Tx (overhanging tiles are cut)
 };
 
 int launch_wino_in(const WinoInArgs& a, hipStream_t s);
@@ -57,6 +64,6 @@ void wino_units(int Cv, std::vector<WinoUnit>& out);
 // B operand [b][K-step][Npad][64 B], hi image then lo image (each `image_elems` bf16 values, slack rows included).
 // `cin_of_v[c]`: input channel of V channel c, or -1 for a pad channel.  `w`: OIDHW f32 with `cin` input channels.
 void wino_pack_weights(const float* w, int cout, int cin, const std::vector<int>& cin_of_v, int Npad, const std::vector<WinoUnit>& units,
-                       std::vector<uint16_t>& packed, size_t& image_elems, size_t& batch_elems);
+                       std::vector<uint16_t>& packed, size_t& image_elems, size_t& batch_elems, int m = 2);
 
 }  // namespace bsmi

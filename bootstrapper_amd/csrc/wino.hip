@@ -339,23 +339,339 @@ __global__ __launch_bounds__(256) void wino_out_kernel(const WinoOutArgs a, size
     }
 }
 
+
+// ---- F(4x4, 3x3) (round 4) ----------------------------------------------------------------------------------------------------
+// 6 x 6 input tile -> 4 x 4 outputs: 36 products per 16 outputs and (kz, c), 2.25 per output where F(2x2) spends 4 (and V holds
+// 2.25 values per input voxel instead of 4, M 2.25 sums per output instead of 4).  Interpolation points 0, +-1/sqrt2, +-sqrt2, inf
+// instead of the textbook 0, +-1, +-2, inf: in this mode the operands V and U are (hi, lo) bf16 pairs, 2^-17 each, and the
+// transforms amplify exactly that rounding -- measured on one 300- and one 1500-channel layer (CPU emulation of the arithmetic,
+// DESIGN.md section 4): largest error relative to the layer's largest output 6e-6 for F(2x2), 8-10e-5 for the textbook points,
+// 2.4e-5 for these (a b = 1 keeps the powers of the points that make up G, B^T and A^T within [1/4, 4]).
+//   B^T = [1 0 -5/2 0 1 0;  0 r 2 -r/2 -1 0;  0 -r 2 r/2 -1 0;  0 -r -1 2r 2 0;  0 r -1 -2r 2 0;  0 1 0 -5/2 0 1]          r = sqrt2
+//   G   = [1 0 0;  2/3 (1, a, 1/2);  2/3 (1, -a, 1/2);  1/12 (1, b, 2);  1/12 (1, -b, 2);  0 0 1]                      a = 1/r, b = r
+//   A^T = [1 1 1 1 1 0;  0 a -a b -b 0;  0 1/2 1/2 2 2 0;  0 a^3 -a^3 b^3 -b^3 1]
+// A thread takes FOUR channels (half of a 16-byte vector: 8 bytes of hi values, 8 of lo values): the 36 intermediate values of
+// a tile are 144 registers at four channels.
+constexpr float kR2 = 1.41421356237309504880f;
+__host__ __device__ constexpr float bt4(int i, int j) {
+  constexpr float B[6][6] = {{1.f, 0.f, -2.5f, 0.f, 1.f, 0.f},
+                             {0.f, kR2, 2.f, -0.5f * kR2, -1.f, 0.f},
+                             {0.f, -kR2, 2.f, 0.5f * kR2, -1.f, 0.f},
+                             {0.f, -kR2, -1.f, 2.f * kR2, 2.f, 0.f},
+                             {0.f, kR2, -1.f, -2.f * kR2, 2.f, 0.f},
+                             {0.f, 1.f, 0.f, -2.5f, 0.f, 1.f}};
+  return B[i][j];
+}
+// r = B^T d for one column of six values, FOUR channels each
+__device__ __forceinline__ void bt4_apply(const float (*d)[4], float (*r)[4]) {
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const float e = 2.f * d[2][k] - d[4][k], o = kR2 * (d[1][k] - 0.5f * d[3][k]);
+    const float e2 = 2.f * d[4][k] - d[2][k], o2 = kR2 * (2.f * d[3][k] - d[1][k]);
+    r[0][k] = d[0][k] - 2.5f * d[2][k] + d[4][k];
+    r[1][k] = e + o;
+    r[2][k] = e - o;
+    r[3][k] = e2 + o2;
+    r[4][k] = e2 - o2;
+    r[5][k] = d[1][k] - 2.5f * d[3][k] + d[5][k];
+  }
+}
+// y = A^T m for six values, four channels each
+__device__ __forceinline__ void at4_apply(const float (*m)[4], float (*y)[4]) {
+  constexpr float a = 0.70710678118654752440f, b = kR2, a3 = 0.35355339059327376220f, b3 = 2.82842712474619009760f;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const float s12 = m[1][k] + m[2][k], d12 = m[1][k] - m[2][k], s34 = m[3][k] + m[4][k], d34 = m[3][k] - m[4][k];
+    y[0][k] = m[0][k] + s12 + s34;
+    y[1][k] = a * d12 + b * d34;
+    y[2][k] = 0.5f * s12 + 2.f * s34;
+    y[3][k] = a3 * d12 + b3 * d34 + m[5][k];
+  }
+}
+typedef uint32_t u32x2_t __attribute__((ext_vector_type(2)));
+// 4 channels (half `hf` of the 8-channel group at element index e) of a split tensor
+__device__ __forceinline__ void load_split4(const uint16_t* base, size_t e, int hf, float* f) {
+  const uint16_t* p = base + 2 * e + 4 * hf;
+  const u32x2_t h = *(const u32x2_t*)p, l = *(const u32x2_t*)(p + 8);
+  f[0] = __uint_as_float(h.x << 16) + __uint_as_float(l.x << 16);
+  f[1] = __uint_as_float(h.x & 0xffff0000u) + __uint_as_float(l.x & 0xffff0000u);
+  f[2] = __uint_as_float(h.y << 16) + __uint_as_float(l.y << 16);
+  f[3] = __uint_as_float(h.y & 0xffff0000u) + __uint_as_float(l.y & 0xffff0000u);
+}
+__device__ __forceinline__ void store_split4(uint16_t* base, size_t e, int hf, const float* f) {
+  uint16_t* p = base + 2 * e + 4 * hf;
+  uint16_t hb[4], lb[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    hb[k] = to_bf16(f[k]);
+    lb[k] = to_bf16(f[k] - __uint_as_float((uint32_t)hb[k] << 16));
+  }
+  const u32x2_t hv = {(uint32_t)hb[0] | ((uint32_t)hb[1] << 16), (uint32_t)hb[2] | ((uint32_t)hb[3] << 16)};
+  const u32x2_t lv = {(uint32_t)lb[0] | ((uint32_t)lb[1] << 16), (uint32_t)lb[2] | ((uint32_t)lb[3] << 16)};
+  *(u32x2_t*)p = hv;
+  *(u32x2_t*)(p + 8) = lv;
+}
+
+// One thread: 4 channels along one row of tiles (z, ty); neighbouring tiles share two of their six input columns, whose
+// row transforms are kept.  Rows / columns past the source (overhanging last tiles) are clamped: whatever they hold only
+// reaches outputs that are never stored.
+__global__ __launch_bounds__(256) void wino4_in_kernel(const WinoInArgs a, int src, size_t total) {
+  const unsigned nb = gridDim.x, q = nb >> 3, r = nb & 7, xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
+  const unsigned blk = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + j;
+  const size_t i = (size_t)blk * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  const int ncg = a.Cpad[src] >> 2;
+  const int cg = (int)(i % ncg), cv = cg >> 1, hf = cg & 1;
+  const size_t t = i / ncg;
+  const int ty = (int)(t % a.Ty);
+  const int z = (int)(t / a.Ty);
+  const uint16_t* sp = (const uint16_t*)a.src[src];
+  const int H = a.H[src], W = a.W[src], C = a.Cpad[src];
+  size_t erow[6];
+#pragma unroll
+  for (int rr = 0; rr < 6; ++rr) {
+    int y = 4 * ty + a.oy[src] + rr;
+    y = y < H - 1 ? y : H - 1;
+    erow[rr] = (((size_t)(z + a.oz[src]) * H + y) * W) * C + 8 * cv;
+  }
+  uint16_t* V = (uint16_t*)a.V;
+  const size_t plane = (size_t)a.Dv * a.Ty * a.Tx * a.Cv;
+  const size_t e_out = (((size_t)z * a.Ty + ty) * a.Tx) * a.Cv + a.cv0[src] + 8 * cv;
+  float col[6][6][4];  // col[c][xi]: (B^T d)[xi] of input column 4 tx + c
+  auto load_col = [&](int c, int x) __attribute__((always_inline)) {
+    x += a.ox[src];
+    x = x < W - 1 ? x : W - 1;
+    float d[6][4];
+#pragma unroll
+    for (int rr = 0; rr < 6; ++rr) load_split4(sp, erow[rr] + (size_t)x * C, hf, d[rr]);
+    bt4_apply(d, col[c]);
+  };
+  load_col(0, 0);
+  load_col(1, 1);
+  for (int tx = 0; tx < a.Tx; ++tx) {
+#pragma unroll
+    for (int c = 2; c < 6; ++c) load_col(c, 4 * tx + c);
+    const size_t e0 = e_out + (size_t)tx * a.Cv;
+#pragma unroll
+    for (int xi = 0; xi < 6; ++xi) {
+      float in[6][4], v[6][4];
+#pragma unroll
+      for (int c = 0; c < 6; ++c)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) in[c][k] = col[c][xi][k];
+      bt4_apply(in, v);
+#pragma unroll
+      for (int nu = 0; nu < 6; ++nu) store_split4(V, (size_t)(6 * xi + nu) * plane + e0, hf, v[nu]);
+    }
+#pragma unroll
+    for (int xi = 0; xi < 6; ++xi)
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        col[0][xi][k] = col[4][xi][k];
+        col[1][xi][k] = col[5][xi][k];
+      }
+  }
+}
+
+// The same through a factor-2 in-plane upsampling (see wino_in_up_kernel): the six upsampled rows of a tile interpolate FIVE
+// low-resolution rows (four when the tile starts at an odd row), d = Uy L Ux^T, V = (B^T Uy) L (B^T Ux)^T; the window moves by
+// two low-resolution columns per tile.
+//   even start 2a   (low rows a-1 .. a+3):  Uy = [.25 .75 0 0 0; 0 .75 .25 0 0; 0 .25 .75 0 0; 0 0 .75 .25 0; 0 0 .25 .75 0; 0 0 0 .75 .25]
+//   odd  start 2a+1 (low rows a .. a+4):    Uy = [.75 .25 0 0 0; .25 .75 0 0 0; 0 .75 .25 0 0; 0 .25 .75 0 0; 0 0 .75 .25 0; 0 0 .25 .75 0]
+__host__ __device__ constexpr float up4(int par, int row, int k) {
+  // entry (row, k) of U_par: upsampled row `row` of the tile blends window rows f and f + 1
+  //   even start: (0,1) (1,2) (1,2) (2,3) (2,3) (3,4), the first with weight .25 on even rows, .75 on odd ones
+  //   odd start:  (0,1) (0,1) (1,2) (1,2) (2,3) (2,3), the first with weight .75 on even rows, .25 on odd ones
+  const int f = par ? row / 2 : (row + 1) / 2;
+  const bool first_heavy = par ? (row & 1) == 0 : (row & 1) == 1;
+  return k == f ? (first_heavy ? 0.75f : 0.25f) : (k == f + 1 ? (first_heavy ? 0.25f : 0.75f) : 0.f);
+}
+__host__ __device__ constexpr float tu4(int par, int xi, int k) {  // (B^T U_par)[xi][k]
+  float s = 0.f;
+  for (int r = 0; r < 6; ++r) s += bt4(xi, r) * up4(par, r, k);
+  return s;
+}
+template <int PY, int PX>
+__global__ __launch_bounds__(256) void wino4_in_up_kernel(const WinoInArgs a, int src, size_t total) {
+  const unsigned nb = gridDim.x, q = nb >> 3, r = nb & 7, xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
+  const unsigned blk = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + j;
+  const size_t i = (size_t)blk * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  const int ncg = a.Cpad[src] >> 2;
+  const int cg = (int)(i % ncg), cv = cg >> 1, hf = cg & 1;
+  const size_t t = i / ncg;
+  const int ty = (int)(t % a.Ty);
+  const int z = (int)(t / a.Ty);
+  const uint16_t* sp = (const uint16_t*)a.src[src];
+  const int H = a.H[src], W = a.W[src], C = a.Cpad[src];
+  const size_t e_low = ((size_t)(z + a.oz[src]) * H) * W * C + 8 * cv;
+  const int ay = ((4 * ty + a.oy[src]) >> 1) - 1 + PY;
+  int wy[5];
+#pragma unroll
+  for (int k = 0; k < 5; ++k) {
+    const int y = ay + k;
+    wy[k] = y < 0 ? 0 : (y > H - 1 ? H - 1 : y);
+  }
+  const int bx = (a.ox[src] >> 1) - 1 + PX;
+  uint16_t* V = (uint16_t*)a.V;
+  const size_t plane = (size_t)a.Dv * a.Ty * a.Tx * a.Cv;
+  const size_t e_out = (((size_t)z * a.Ty + ty) * a.Tx) * a.Cv + a.cv0[src] + 8 * cv;
+  float ct[5][6][4];  // ct[c][xi] = sum_k (B^T Uy)[xi][k] L[k][window column c]
+  auto load_ct = [&](int c, int xlow) __attribute__((always_inline)) {
+    const int x = xlow < 0 ? 0 : (xlow > W - 1 ? W - 1 : xlow);
+    float L[5][4];
+#pragma unroll
+    for (int k = 0; k < 5; ++k) load_split4(sp, e_low + ((size_t)wy[k] * W + x) * C, hf, L[k]);
+#pragma unroll
+    for (int xi = 0; xi < 6; ++xi)
+#pragma unroll
+      for (int ch = 0; ch < 4; ++ch) {
+        float acc = 0.f;
+#pragma unroll
+        for (int k = 0; k < 5; ++k)
+          if (tu4(PY, xi, k) != 0.f) acc += tu4(PY, xi, k) * L[k][ch];
+        ct[c][xi][ch] = acc;
+      }
+  };
+  load_ct(0, bx);
+  load_ct(1, bx + 1);
+  load_ct(2, bx + 2);
+  for (int tx = 0; tx < a.Tx; ++tx) {
+    load_ct(3, bx + 2 * tx + 3);
+    load_ct(4, bx + 2 * tx + 4);
+    const size_t e0 = e_out + (size_t)tx * a.Cv;
+#pragma unroll
+    for (int xi = 0; xi < 6; ++xi) {
+#pragma unroll
+      for (int nu = 0; nu < 6; ++nu) {
+        float v[4];
+#pragma unroll
+        for (int ch = 0; ch < 4; ++ch) {
+          float acc = 0.f;
+#pragma unroll
+          for (int c = 0; c < 5; ++c)
+            if (tu4(PX, nu, c) != 0.f) acc += tu4(PX, nu, c) * ct[c][xi][ch];
+          v[ch] = acc;
+        }
+        store_split4(V, (size_t)(6 * xi + nu) * plane + e0, hf, v);
+      }
+    }
+#pragma unroll
+    for (int c = 0; c < 3; ++c)
+#pragma unroll
+      for (int xi = 0; xi < 6; ++xi)
+#pragma unroll
+        for (int ch = 0; ch < 4; ++ch) ct[c][xi][ch] = ct[c + 2][xi][ch];
+  }
+}
+
+// one thread: the 4 x 4 output tile of 4 channels at (z, ty, tx); outputs past (Ho, Wo) -- overhanging tiles -- are not stored
+template <bool LOW>
+__global__ __launch_bounds__(256) void wino4_out_kernel(const WinoOutArgs a, size_t total) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  const int ncg = a.Co >> 2;
+  const int cg = (int)(i % ncg), cv = cg >> 1, hf = cg & 1;
+  size_t t = i / ncg;
+  const int tx = (int)(t % a.Tx);
+  t /= a.Tx;
+  const int ty = (int)(t % a.Ty);
+  const int z = (int)(t / a.Ty);
+  const size_t Mrows = (size_t)a.Do * a.Ty * a.Tx;
+  const size_t m = ((size_t)z * a.Ty + ty) * a.Tx + tx;
+  float tp[6][4][4];  // tp[nu][p]: (A^T M)[p][nu]
+#pragma unroll
+  for (int nu = 0; nu < 6; ++nu) {
+    float mm[6][4];
+#pragma unroll
+    for (int xi = 0; xi < 6; ++xi) {
+      const f32x4_t v = __builtin_nontemporal_load((const f32x4_t*)(a.M + ((size_t)(6 * xi + nu) * Mrows + m) * a.Co + 4 * cg));
+#pragma unroll
+      for (int k = 0; k < 4; ++k) mm[xi][k] = v[k];
+    }
+    at4_apply(mm, tp[nu]);
+  }
+  float bv[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) bv[k] = a.bias[4 * cg + k];
+  uint16_t* out = (uint16_t*)a.out;
+#pragma unroll
+  for (int p = 0; p < 4; ++p) {
+    float in[6][4], y[4][4];
+#pragma unroll
+    for (int nu = 0; nu < 6; ++nu)
+#pragma unroll
+      for (int k = 0; k < 4; ++k) in[nu][k] = tp[nu][p][k];
+    at4_apply(in, y);
+    const int oy = 4 * ty + p;
+    if (oy >= a.Ho) continue;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int ox = 4 * tx + q;
+      if (ox >= a.Wo) continue;
+      const size_t e8 = (((size_t)z * a.Ho + oy) * a.Wo + ox) * a.Co + 8 * cv;
+      const size_t e = e8 + 4 * hf;
+      float v[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) v[k] = y[q][k] + bv[k];
+      if (a.addend) {
+        const f32x4_t r0 = __builtin_nontemporal_load((const f32x4_t*)(a.addend + e));
+#pragma unroll
+        for (int k = 0; k < 4; ++k) v[k] += r0[k];
+      }
+      if constexpr (LOW) {
+        int y0, y1, x0, x1;
+        float wy0, wy1, wx0, wx1;
+        lin_src(oy + a.loy, a.lf, a.lH, y0, y1, wy0, wy1);
+        lin_src(ox + a.lox, a.lf, a.lW, x0, x1, wx0, wx1);
+        const float* base = a.low + ((size_t)(z + a.loz) * a.lH * a.lW) * a.Co + 4 * cg;
+        const f32x4_t r00 = *(const f32x4_t*)(base + ((size_t)y0 * a.lW + x0) * a.Co), r01 = *(const f32x4_t*)(base + ((size_t)y0 * a.lW + x1) * a.Co);
+        const f32x4_t r10 = *(const f32x4_t*)(base + ((size_t)y1 * a.lW + x0) * a.Co), r11 = *(const f32x4_t*)(base + ((size_t)y1 * a.lW + x1) * a.Co);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const float pa = wx0 * r00[k] + wx1 * r01[k];
+          const float pb = wx0 * r10[k] + wx1 * r11[k];
+          v[k] += wy0 * pa + wy1 * pb;
+        }
+      }
+      if (a.relu) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) v[k] = v[k] > 0.f ? v[k] : 0.f;
+      }
+      store_split4(out, e8, hf, v);
+    }
+  }
+}
+
 }  // namespace
 
 int launch_wino_in(const WinoInArgs& a, hipStream_t s) {
+  const int m = a.m == 4 ? 4 : 2;
+  if (a.m != 0 && a.m != 2 && a.m != 4) BSMI_FAIL(BSMI_ERR_INVALID, "winograd input transform: tile edge %d (2 or 4)", a.m);
   if (a.nsrc < 1 || a.nsrc > kWinoMaxSrc || a.Dv <= 0 || a.Ty <= 0 || a.Tx <= 0 || a.Cv % 8) BSMI_FAIL(BSMI_ERR_INVALID, "winograd input transform: bad geometry");
   for (int q = 0; q < a.nsrc; ++q) {
     if (a.Cpad[q] % 8 || a.cv0[q] % 8 || a.cv0[q] + a.Cpad[q] > a.Cv) BSMI_FAIL(BSMI_ERR_INVALID, "winograd input transform: bad channel layout of source %d", q);
     const int upf = a.upf[q] > 0 ? a.upf[q] : 1;  // an upsampled source is upf times as large in the plane
-    if (a.oy[q] + 2 * a.Ty + 2 > a.H[q] * upf || a.ox[q] + 2 * a.Tx + 2 > a.W[q] * upf) BSMI_FAIL(BSMI_ERR_INVALID, "winograd input transform: tiles leave source %d", q);
-    const size_t total = (size_t)a.Dv * a.Ty * (a.Cpad[q] / 8);  // one thread per (z, tile row, 8 channels)
+    if (m == 2 && (a.oy[q] + 2 * a.Ty + 2 > a.H[q] * upf || a.ox[q] + 2 * a.Tx + 2 > a.W[q] * upf)) BSMI_FAIL(BSMI_ERR_INVALID, "winograd input transform: tiles leave source %d", q);
+    // F(4x4): the last tile row / column may overhang by up to three voxels (clamped reads); more than that is a planning error
+    if (m == 4 && (a.oy[q] < 0 || a.ox[q] < 0 || a.oy[q] + 4 * a.Ty + 2 > a.H[q] * upf + 3 || a.ox[q] + 4 * a.Tx + 2 > a.W[q] * upf + 3))
+      BSMI_FAIL(BSMI_ERR_INVALID, "winograd input transform: F(4x4) tiles leave source %d by more than a tile's overhang", q);
+    const size_t total = (size_t)a.Dv * a.Ty * (a.Cpad[q] / (m == 4 ? 4 : 8));  // one thread per (z, tile row, 8 resp. 4 channels)
     const dim3 grid((unsigned)((total + 255) / 256));
     if (a.upf[q] > 0) {
       if (a.upf[q] != 2 || a.oy[q] < 0 || a.ox[q] < 0) BSMI_FAIL(BSMI_ERR_INVALID, "winograd input transform: only a factor-2 upsampling can be fused");
       const int par = 2 * (a.oy[q] & 1) + (a.ox[q] & 1);
-      if (par == 0) hipLaunchKernelGGL((wino_in_up_kernel<0, 0>), grid, dim3(256), 0, s, a, q, total);
+      if (m == 4) {
+        if (par == 0) hipLaunchKernelGGL((wino4_in_up_kernel<0, 0>), grid, dim3(256), 0, s, a, q, total);
+        else if (par == 1) hipLaunchKernelGGL((wino4_in_up_kernel<0, 1>), grid, dim3(256), 0, s, a, q, total);
+        else if (par == 2) hipLaunchKernelGGL((wino4_in_up_kernel<1, 0>), grid, dim3(256), 0, s, a, q, total);
+        else hipLaunchKernelGGL((wino4_in_up_kernel<1, 1>), grid, dim3(256), 0, s, a, q, total);
+      } else if (par == 0) hipLaunchKernelGGL((wino_in_up_kernel<0, 0>), grid, dim3(256), 0, s, a, q, total);
       else if (par == 1) hipLaunchKernelGGL((wino_in_up_kernel<0, 1>), grid, dim3(256), 0, s, a, q, total);
       else if (par == 2) hipLaunchKernelGGL((wino_in_up_kernel<1, 0>), grid, dim3(256), 0, s, a, q, total);
       else hipLaunchKernelGGL((wino_in_up_kernel<1, 1>), grid, dim3(256), 0, s, a, q, total);
+    } else if (m == 4) {
+      hipLaunchKernelGGL(wino4_in_kernel, grid, dim3(256), 0, s, a, q, total);
     } else {
       hipLaunchKernelGGL(wino_in_kernel, grid, dim3(256), 0, s, a, q, total);
     }
@@ -365,12 +681,20 @@ int launch_wino_in(const WinoInArgs& a, hipStream_t s) {
 }
 
 int launch_wino_out(const WinoOutArgs& a, hipStream_t s) {
+  const int m = a.m == 4 ? 4 : 2;
+  if (a.m != 0 && a.m != 2 && a.m != 4) BSMI_FAIL(BSMI_ERR_INVALID, "winograd output transform: tile edge %d (2 or 4)", a.m);
   if (a.Do <= 0 || a.Ty <= 0 || a.Tx <= 0 || a.Co % 8) BSMI_FAIL(BSMI_ERR_INVALID, "winograd output transform: bad geometry");
-  if (a.low && (a.lf < 1 || a.loz < 0 || a.loz + a.Do > a.lD || a.loy < 0 || a.loy + 2 * a.Ty > a.lH * a.lf || a.lox < 0 || a.lox + 2 * a.Tx > a.lW * a.lf))
+  const int Ho = m == 4 ? a.Ho : 2 * a.Ty, Wo = m == 4 ? a.Wo : 2 * a.Tx;
+  if (m == 4 && (Ho < 1 || Wo < 1 || Ho > 4 * a.Ty || Wo > 4 * a.Tx || Ho + 3 < 4 * a.Ty || Wo + 3 < 4 * a.Tx)) BSMI_FAIL(BSMI_ERR_INVALID, "winograd output transform: output extent and F(4x4) tile counts disagree");
+  if (a.low && (a.lf < 1 || a.loz < 0 || a.loz + a.Do > a.lD || a.loy < 0 || a.loy + Ho > a.lH * a.lf || a.lox < 0 || a.lox + Wo > a.lW * a.lf))
     BSMI_FAIL(BSMI_ERR_INVALID, "winograd output transform: the low-resolution residual does not cover the output");
-  const size_t total = (size_t)a.Do * a.Ty * a.Tx * (a.Co / 8);
-  if (a.low) hipLaunchKernelGGL(wino_out_kernel<true>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, a, total);
-  else hipLaunchKernelGGL(wino_out_kernel<false>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, a, total);
+  const size_t total = (size_t)a.Do * a.Ty * a.Tx * (a.Co / (m == 4 ? 4 : 8));
+  const dim3 grid((unsigned)((total + 255) / 256));
+  if (m == 4) {
+    if (a.low) hipLaunchKernelGGL(wino4_out_kernel<true>, grid, dim3(256), 0, s, a, total);
+    else hipLaunchKernelGGL(wino4_out_kernel<false>, grid, dim3(256), 0, s, a, total);
+  } else if (a.low) hipLaunchKernelGGL(wino_out_kernel<true>, grid, dim3(256), 0, s, a, total);
+  else hipLaunchKernelGGL(wino_out_kernel<false>, grid, dim3(256), 0, s, a, total);
   BSMI_HIP(hipGetLastError());
   return BSMI_OK;
 }
@@ -403,12 +727,19 @@ static inline float host_bf16_f32(uint16_t b) {
 }
 
 void wino_pack_weights(const float* w, int cout, int cin, const std::vector<int>& cin_of_v, int Npad, const std::vector<WinoUnit>& units,
-                       std::vector<uint16_t>& packed, size_t& image_elems, size_t& batch_elems) {
+                       std::vector<uint16_t>& packed, size_t& image_elems, size_t& batch_elems, int m) {
   const size_t nsteps = units.size() / kUnitsPerStep;
+  const int T = m + 2, nbatch = T * T;
   batch_elems = nsteps * (size_t)Npad * 32;
-  image_elems = kWinoBatch * batch_elems + (size_t)kWeightRowSlack * 32;
+  image_elems = nbatch * batch_elems + (size_t)kWeightRowSlack * 32;
   packed.assign(2 * image_elems, 0);
-  static const double G[4][3] = {{1, 0, 0}, {.5, .5, .5}, {.5, -.5, .5}, {0, 0, 1}};
+  static const double G2[4][3] = {{1, 0, 0}, {.5, .5, .5}, {.5, -.5, .5}, {0, 0, 1}};
+  // F(4x4), points 0, +-1/sqrt2, +-sqrt2, inf; the rows carry the scales taken out of B^T (see the kernels above)
+  const double a = 0.70710678118654752440, b = 1.41421356237309504880;
+  const double G4[6][3] = {{1, 0, 0}, {2. / 3, 2. / 3 * a, 1. / 3}, {2. / 3, -2. / 3 * a, 1. / 3}, {1. / 12, b / 12, 1. / 6}, {1. / 12, -b / 12, 1. / 6}, {0, 0, 1}};
+  double G[6][3];
+  for (int i = 0; i < T; ++i)
+    for (int k = 0; k < 3; ++k) G[i][k] = m == 4 ? G4[i][k] : G2[i][k];
   host_parallel_for((size_t)cout, [&](size_t n_) {   // one output channel per task: its weights read once, its image rows its own lines
     const int n = (int)n_;
     for (size_t u = 0; u < units.size(); ++u) {
@@ -419,13 +750,13 @@ void wino_pack_weights(const float* w, int cout, int cin, const std::vector<int>
         const int c = cin_of_v[un.vc0 + kk];
         if (c < 0) continue;
         const float* g = w + (((size_t)n * cin + c) * 3 + un.kz) * 9;  // [ky][kx]
-        double t[4][3];
-        for (int xi = 0; xi < 4; ++xi)
+        double t[6][3];
+        for (int xi = 0; xi < T; ++xi)
           for (int kx = 0; kx < 3; ++kx) t[xi][kx] = G[xi][0] * g[kx] + G[xi][1] * g[3 + kx] + G[xi][2] * g[6 + kx];
-        for (int xi = 0; xi < 4; ++xi)
-          for (int nu = 0; nu < 4; ++nu) {
+        for (int xi = 0; xi < T; ++xi)
+          for (int nu = 0; nu < T; ++nu) {
             const float v = (float)(t[xi][0] * G[nu][0] + t[xi][1] * G[nu][1] + t[xi][2] * G[nu][2]);
-            const size_t idx = (size_t)(4 * xi + nu) * batch_elems + (s * Npad + n) * 32 + j * 16 + kk;
+            const size_t idx = (size_t)(T * xi + nu) * batch_elems + (s * Npad + n) * 32 + j * 16 + kk;
             const uint16_t hi = host_bf16(v);
             packed[idx] = hi;
             packed[image_elems + idx] = host_bf16(v - host_bf16_f32(hi));

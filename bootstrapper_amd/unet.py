@@ -216,6 +216,13 @@ class Model:
         names = ["input", "conv", "pool", "upsample", "head"]
         return {names[i]: (ms[i], fl[i], cnt[i]) for i in range(5)}
 
+    def profile_executed(self, reset=False):
+        """FLOPs the matrix pipe was given by the profiled conv launches since the last reset (padding, Winograd batches and the
+        three products of the split mode counted): bsmi_unet_profile_executed."""
+        v = C.c_double()
+        check(lib.bsmi_unet_profile_executed(self._h, C.byref(v), 1 if reset else 0))
+        return v.value
+
     def debug_activation(self, step, what=0):
         """Development aid: output tensor of launch `step` of the last forward as a float32 (D, H, W, C) array
         (what: 0 value, 1 / 2 the hi / lo plane of the split mode)."""

@@ -203,6 +203,11 @@ int bsmi_unet_profile_read(bsmi_unet *h, int max_n, int *n, int32_t *types, doub
 /* totals over every profiled forward since the last reset, indexed by launch type */
 int bsmi_unet_profile_totals(bsmi_unet *h, double ms_by_type[5], double flops_by_type[5],
                              int64_t launches_by_type[5], int reset);
+/* FLOPs the matrix pipe was actually given by the profiled convolution launches since the last reset (tile padding, every
+ * batch of a Winograd stage, three bf16 products per product of the split mode): the algorithmic count of
+ * bsmi_unet_profile_totals says how fast the layer was computed, this one how busy the MFMA units were -- a Winograd stage
+ * computes a layer with fewer multiplies than the algorithmic count has. */
+int bsmi_unet_profile_executed(bsmi_unet *h, double *executed_flops, int reset);
 
 /* Development aid: the output tensor of launch `step` of the last forward (launch order as in
  * bsmi_unet_profile_read), as float32 channels-last [D][H][W][C] on the host, whatever the precision mode stores
