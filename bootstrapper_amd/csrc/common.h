@@ -56,7 +56,7 @@ struct DeviceOnce {
 // f(i) for i in [0, n) on up to 16 host threads (weight packing at finalize: independent rows of a packed image)
 template <class F>
 static inline void host_parallel_for(size_t n, F&& f) {
-  const size_t nt = std::min<size_t>(std::max(1u, std::min(16u, std::thread::hardware_concurrency())), n);
+  const size_t nt = std::min<size_t>(std::max(1u, std::min(32u, std::thread::hardware_concurrency())), n);
   if (nt <= 1) {
     for (size_t i = 0; i < n; ++i) f(i);
     return;

@@ -15,6 +15,8 @@
 #include <map>
 #include <memory>
 #include <vector>
+#include <chrono>
+#include <thread>
 
 #include "unet_internal.h"
 #include "unet_ops.h"
@@ -250,6 +252,7 @@ static int wino_mode() {
   static const int m = [] { const char* e = getenv("BSMI_WINO"); return e ? atoi(e) : 1; }();
   return m;
 }
+static int wino4_mode();
 static bool wino_eligible(const PassSite& p, int ci) {
   if (wino_mode() == 0 || p.k[ci][0] != 3 || p.k[ci][1] != 3 || p.k[ci][2] != 3) return false;
   if (ci == 0 && p.nslots > kWinoMaxSrc) return false;
@@ -260,26 +263,26 @@ static bool wino_eligible(const PassSite& p, int ci) {
     cin = 0;
     for (int s = 0; s < p.nslots; ++s) cin += p.cin[s];
   }
-  return cin >= 256 && p.cout >= 256;
+  if (cin >= 256 && p.cout >= 256) return true;
+  // with F(4x4) tiles (V 2.25x the input instead of 4x, 2.25 sums per output instead of 4) two narrower stages win as well,
+  // measured on the 128^3 block: 60 -> 300 0.88 -> 0.80 ms, 360 -> 60 2.09 -> 1.94 (60 -> 60 0.87 -> 1.23 and the 12-channel
+  // stages lose)
+  return wino4_mode() == 1 && (int64_t)cin * p.cout >= 16384 && cin >= 32 && p.cout >= 32;
 }
 
-// Which Winograd stages use the F(4x4, 3x3) tile (round 4).  BSMI_WINO4: 0 = none, unset / 1 = the stages with at least 1024
-// input channels (of the 3d_affs net: 1500 -> 1500 and 1800 -> 300, half of a block's multiplies; 36 products per 16 outputs
-// instead of 16 per 4, at four times F(2x2)'s rounding error on a layer -- DESIGN.md section 4 --, which the two stages can
-// afford inside the 1e-4 gate and fourteen could not), 2 = every Winograd stage (tests: small nets).
+// Which Winograd stages use the F(4x4, 3x3) tile (round 4): 36 products per 16 outputs instead of 16 per 4.  BSMI_WINO4: 0 =
+// none (F(2x2) as in round 3), unset / 1 = every Winograd stage, 2 = the same (kept for the tests' spelling).  Measured on the
+// 128^3 block (ms F(2x2) -> F(4x4)): 1500 -> 1500 6.99 -> 4.27, 1800 -> 300 7.07 -> 4.67, 300 -> 300 2.90 -> 1.82 and 1.90 ->
+// 1.38, 300 -> 1500 2.22 -> 1.50; block 28.3 -> 20.5 ms.  Error of the whole net against the CPU fp32 oracle 8.6e-6 -> 9.0e-6
+// (gate 1e-4): the interpolation points 0, +-1/sqrt2, +-sqrt2, inf keep a layer's error at four times F(2x2)'s where the
+// textbook points 0, +-1, +-2 make it fifteen times (wino.hip), and a layer's error reaches the sigmoid outputs attenuated.
 static int wino4_mode() {
   static const int m = [] { const char* e = getenv("BSMI_WINO4"); return e ? atoi(e) : 1; }();
   return m;
 }
 static int wino_tile_edge(const PassSite& p, int ci) {
-  if (wino4_mode() == 0) return 2;
-  if (wino4_mode() >= 2) return 4;
-  int cin = p.cout;
-  if (ci == 0) {
-    cin = 0;
-    for (int s = 0; s < p.nslots; ++s) cin += p.cin[s];
-  }
-  return cin >= 1024 ? 4 : 2;
+  (void)p; (void)ci;
+  return wino4_mode() == 0 ? 2 : 4;
 }
 
 static int pack_wino(bsmi_unet* h, PassSite& p, int ci) {
@@ -1570,8 +1573,28 @@ int bsmi_unet_finalize(bsmi_unet* h, int precision) {
     }
     return BSMI_OK;
   };
-  for (auto& p : h->l_conv) { int rc = repack(p); if (rc) return rc; }
-  for (auto& p : h->r_conv) { int rc = repack(p); if (rc) return rc; }
+  {
+    // the ConvPasses side by side (each packs its stages on host threads of its own and uploads its images): the 1500-channel
+    // pass alone is two thirds of the work, the others hide behind it
+    std::vector<PassSite*> sites;
+    for (auto& p : h->l_conv) sites.push_back(&p);
+    for (auto& p : h->r_conv) sites.push_back(&p);
+    std::vector<int> rcs(sites.size(), BSMI_OK);
+    std::vector<std::string> msgs(sites.size());
+    const bool timing = getenv("BSMI_PLAN_DEBUG") != nullptr;
+    std::vector<std::thread> th;
+    for (size_t i = 0; i < sites.size(); ++i)
+      th.emplace_back([&, i] {
+        (void)hipSetDevice(h->device);
+        const auto t0 = std::chrono::steady_clock::now();
+        rcs[i] = repack(*sites[i]);
+        if (rcs[i]) msgs[i] = bsmi_last_error();
+        if (timing) fprintf(stderr, "[bsmi finalize] %s: %.3f s\n", sites[i]->prefix.c_str(), std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count());
+      });
+    for (auto& t : th) t.join();
+    for (size_t i = 0; i < sites.size(); ++i)
+      if (rcs[i]) { bsmi::set_error("%s", msgs[i].c_str()); return rcs[i]; }
+  }
   for (auto& hd : h->heads) {
     std::vector<float> hw((size_t)hd.cout * 2 * hd.cin), hb((size_t)hd.cout * 2);
     const HostWeight& w1 = h->weights[hd.prefix + ".conv_pass.0.weight"];

@@ -116,11 +116,12 @@ def connected_components_multi(nodes, edges, scores, thresholds):
     return out
 
 
-IO_WORKERS = 3   # layers of blocks in flight between the store and the device (each request decodes / encodes its chunks on
-                 # zarr_io.IO_THREADS native threads, no GIL)
+IO_WORKERS = 8   # pieces in flight between the store and the device (each request decodes / encodes its chunks on up to
+                 # zarr_io.IO_THREADS native threads, no GIL; with 3 the 32 GB of fragments + segmentations of a 1024^3 volume
+                 # left in 2.2 s, bounded by the three requests' encoders)
 
 
-PIECE_BYTES = 512 << 20   # staging buffers between the store and the device: page-locked, pooled for the life of the process
+PIECE_BYTES = 256 << 20   # staging buffers between the store and the device: page-locked, pooled for the life of the process
 
 
 class _PinnedPool:
@@ -355,6 +356,26 @@ def waterz_pipeline(config, device=None, rank=0, world=1, group=None, grid=None,
         raise ValueError(f"a {grid[0]} x {grid[1]} grid of workers for {layers} layer(s) x {rows} row(s) of blocks leaves rank {rank} without blocks "
                          "(run_waterz_pipeline sizes the grid with bootstrapper_amd.volume.rank_grid)")
     mask = open_ds(config["mask_dataset"]) if config.get("mask_dataset") else None
+    # A box that does not fit the device (43 B per voxel: 2048^3 is 369 GB) is taken in passes of block layers that do
+    # (`_waterz_streamed`; `hbm_budget_gb` in the config bounds the device memory a pass may plan for -- default: what is free).
+    nthr = len(thresholds)
+    n_yx = -(-(y1 - y0) // block_size[1]) * -(-total_shape[2] // block_size[2])
+    def slab_bytes(nl):
+        return SlabSegmenter.hbm_bytes((min(nl * block_size[0], z1 - z0), y1 - y0, total_shape[2]), ctx, nthr, nl * n_yx,
+                                       int(config.get("label_cap", 1 << 16)), int(config.get("edge_cap", 1 << 17)))
+    free_b, _tot = torch.cuda.mem_get_info(torch.device("cuda", device))
+    free_b += torch.cuda.memory_reserved(device) - torch.cuda.memory_allocated(device)
+    limit = min(free_b, int(float(config["hbm_budget_gb"]) * 2**30)) if config.get("hbm_budget_gb") is not None else free_b
+    my_layers = -(-(z1 - z0) // block_size[0])
+    if blockwise and slab_bytes(my_layers) > limit:
+        if world > 1:
+            raise MemoryError(f"rank {rank}'s box of {my_layers} block layer(s) needs {slab_bytes(my_layers) / 2**30:.1f} GiB of HBM, {limit / 2**30:.1f} GiB may be "
+                              "used: passes over a box that does not fit are implemented for one worker per volume (num_workers = 1), or use more workers / GPUs")
+        per_pass = max([nl for nl in range(1, my_layers) if slab_bytes(nl + 1) <= limit] or [0])
+        if per_pass < 1:
+            raise MemoryError(f"not even two layers of blocks ({slab_bytes(2) / 2**30:.1f} GiB) fit the {limit / 2**30:.1f} GiB of HBM that may be used: smaller blocks, or a larger hbm_budget_gb")
+        return _waterz_streamed(config, affs, mask, device, thresholds, merge_function, blockwise, frag_params, roi, voxel_size, origin,
+                                total_shape, block_size, ctx, layers, per_pass)
     t_slab = _trace.span("segment: slab + lane workspaces allocated")
     t_slab.__enter__()
     seg = SlabSegmenter((z1 - z0, y1 - y0, total_shape[2]), block_size, ctx, layers, zs[rz], thresholds, frag_params["fragments_in_xy"],
@@ -366,8 +387,28 @@ def waterz_pipeline(config, device=None, rank=0, world=1, group=None, grid=None,
                         epsilon_agglomerate=frag_params["epsilon_agglomerate"], sigma=frag_params["sigma"],
                         noise_eps=frag_params["noise_eps"], bias=frag_params["bias"], seed_eps=frag_params["seed_eps"])
     t_slab.__exit__(None, None, None)
+    # The lanes' workspaces, the slab-sized reductions and the relabel kernels are touched for the first time while the
+    # affinities stream in (SlabSegmenter.prime: block 0's two tasks on every lane, a collect and a stitch, on whatever the slab
+    # holds at that moment -- results discarded; first touch of 40 GB of fresh allocations was half a second of the block stage)
+    import threading
+
+    def warm():
+        torch.cuda.set_device(seg.dev)
+        with _trace.span("segment: lanes and slab-sized kernels warmed beside the read"):
+            try:
+                seg.prime()
+            except Exception:  # noqa: BLE001 - a warm-up on half-read data: an overflow there means nothing
+                pass
+    warm_thread = threading.Thread(target=warm, name="bsmi-warm") if world == 1 else None   # (several ranks: prime's stitch is collective)
+    if warm_thread is not None:
+        warm_thread.start()
     with _trace.span("segment: affinities read into the slab"):
         _fill_affinities(seg, affs, origin, z0, mask, y0)
+    if warm_thread is not None:
+        warm_thread.join()
+        seg.frags.zero_()
+        seg.nums.zero_()
+        seg.counts_dev.zero_()
     og = obj_group if obj_group is not None else group   # pickled objects: never through an RCCL group
 
     # fragments + edge scores of this worker's blocks (post/watershed.py:118-153), accounted like daisy tasks
@@ -461,6 +502,122 @@ def waterz_pipeline(config, device=None, rank=0, world=1, group=None, grid=None,
     aux.shutdown()
     _trace.report("segment: ")
     barrier()
+    return written
+
+
+def _waterz_streamed(config, affs, mask, device, thresholds, merge_function, blockwise, frag_params, roi, voxel_size, origin,
+                     total_shape, block_size, ctx, layers, per_pass):
+    """waterz_pipeline for a volume larger than the device: `per_pass` block layers at a time (post/watershed.py:75-153 streams
+    any volume block by block through its workers; here a pass is as many layers as fit).  A pass holds one MORE layer than it
+    finishes: the layer above, whose fragments the scoring of the pass's top layer reads in its context margin (a block's
+    fragments depend on its own read box only, so the next pass computes that layer again, bit for bit the same, and finishes
+    it); the margin BELOW comes from the previous pass's top `context` sections, kept on the device.  Fragments go to their
+    dataset pass by pass, nodes and scored edges of the finished layers collect on the host, one global connected components,
+    then the fragments come back from the store pass by pass for the relabelled copies.  Same datasets, LUTs and database as
+    the resident form, bit for bit (tests/test_drivers_gpu.py)."""
+    import torch
+    from .. import _trace
+    from ..blockwise import check_task_states, TaskState
+    from ..volume import SlabSegmenter, stitch_components
+    from .blockwise import RagStore
+    from .engine import lut_relabel_multi
+    from .naming import dump_lut_params
+    dev = torch.device("cuda", device)
+    bz = block_size[0]
+    rows, cols = -(-total_shape[1] // block_size[1]), -(-total_shape[2] // block_size[2])
+    nvb = int(np.prod(block_size))
+    frags_name = os.path.join(config["fragments_dataset"], build_name(frag_params))
+    common = dict(offset=roi[0], voxel_size=voxel_size, axis_names=affs.axis_names[1:], units=affs.units, dtype=np.uint64,
+                  chunk_shape=tuple(min(b, t) for b, t in zip(block_size, total_shape)))
+    prepare_ds(frags_name, shape=total_shape, **common)
+    dump_params(frags_name, {"method": "ws", "blockwise": blockwise, **frag_params})
+    frag_ds = open_ds(frags_name, "r+")
+    writer = _LayerWriter(dev, bz)
+    states = {n: TaskState(n) for n in ("WatershedFrags", "WaterzAgglom")}
+    all_ids, all_pos, all_size, all_edges, all_scores = [], [], [], [], []
+    carry = None
+    passes = [(a, min(layers, a + per_pass)) for a in range(0, layers, per_pass)]
+    for a, b in passes:
+        top = 1 if b < layers else 0
+        z0, z1 = a * bz, min(total_shape[0], (b + top) * bz)
+        with _trace.span(f"segment (streamed): layers {a}..{b - 1} of {layers}"):
+            seg = SlabSegmenter((z1 - z0, total_shape[1], total_shape[2]), block_size, ctx, layers, a, thresholds, frag_params["fragments_in_xy"],
+                                frag_params["min_seed_distance"], frag_params["filter_fragments"], frag_params["remove_debris"], 256,
+                                n_lanes=int(config.get("lanes", 20)), device=device, exchange_affs=False,
+                                label_cap=int(config.get("label_cap", 1 << 16)), edge_cap=int(config.get("edge_cap", 1 << 17)),
+                                total_rows=rows, epsilon_agglomerate=frag_params["epsilon_agglomerate"], sigma=frag_params["sigma"],
+                                noise_eps=frag_params["noise_eps"], bias=frag_params["bias"], seed_eps=frag_params["seed_eps"],
+                                cc_inclusive=bool(config.get("cc_inclusive", True)), queue_bins_formula=config.get("queue_bins_formula", "n_minus_1"))
+            _fill_affinities(seg, affs, origin, z0, mask, 0)
+            if carry is not None:
+                seg.frags[:ctx[0]].copy_(carry)    # the margin below: the previous pass's last `context` sections of fragments
+            st = seg.run_blocks_accounted()
+            for k, v in st.items():
+                # the layer above is counted by the pass that finishes it
+                done = TaskState(k, (b - a) * rows * cols)
+                done.completed_count = min(v.completed_count, done.total_block_count) if not v.failed_count else v.completed_count
+                done.failed_count, done.failed_blocks, done.orphaned_count = v.failed_count, list(v.failed_blocks), v.orphaned_count
+                states[k].merge(done)
+            hi_id = np.uint64(b * rows * cols * nvb)    # ids of blocks in layers >= b belong to the next pass
+            ids, pos, size = seg.node_table()
+            keep = ids <= hi_id
+            pos = np.asarray(roi[0], np.float64) + (pos + np.array([z0, 0, 0], np.float64)) * np.asarray(voxel_size, np.float64)
+            all_ids.append(ids[keep]); all_pos.append(pos[keep]); all_size.append(size[keep])
+            own = seg.rag_edges[:, 0] <= hi_id if len(seg.rag_edges) else np.zeros(0, bool)
+            all_edges.append(seg.rag_edges[own]); all_scores.append(seg.rag_scores[own])
+            nz = min(total_shape[0], b * bz) - z0
+            inner = seg.interior(seg.frags)
+            writer.submit(frag_ds, inner[:nz], z0, 0)
+            if top:
+                carry = seg.frags[nz:nz + ctx[0]].clone()
+            writer.drain()      # the slab goes away with the pass
+            del seg, inner
+            torch.cuda.empty_cache()
+    check_task_states(states)
+    nodes = np.concatenate(all_ids) if all_ids else np.zeros(0, np.uint64)
+    edges = np.concatenate(all_edges) if all_edges else np.zeros((0, 2), np.uint64)
+    scores = np.concatenate(all_scores) if all_scores else np.zeros(0, np.float32)
+    db = config.get("db") or {}
+    if "db_file" in db:
+        rag = RagStore()
+        rag.add_nodes(nodes, np.concatenate(all_pos) if all_pos else np.zeros((0, 3)), np.concatenate(all_size) if all_size else np.zeros(0, np.int64))
+        rag.add_edges(edges, scores)
+        rag.to_sqlite(db["db_file"])
+    written = [frags_name]
+    if nodes.size == 0:
+        writer.close()
+        return written
+    thr = thresholds if bool(config.get("cc_inclusive", True)) else [float(np.nextafter(np.float32(t), np.float32(-np.inf))) for t in thresholds]
+    luts = stitch_components(nodes, edges, scores, thr)
+    lut_dir = config["lut_dir"]
+    seg_ds = []
+    for t, threshold in enumerate(thresholds):
+        params = {"merge_function": merge_function, "threshold": threshold, **frag_params}
+        name = build_name(params)
+        recorded = {"method": "ws", "blockwise": blockwise, **params}
+        seg_name = os.path.join(config["seg_dataset_prefix"], name)
+        os.makedirs(lut_dir, exist_ok=True)
+        np.savez_compressed(os.path.join(lut_dir, name) + ".npz", fragment_segment_lut=np.array([nodes, luts[t]]))
+        dump_lut_params(os.path.join(lut_dir, name), recorded)
+        prepare_ds(seg_name, shape=total_shape, **common)
+        dump_params(seg_name, recorded)
+        seg_ds.append(open_ds(seg_name, "r+"))
+        written.append(seg_name)
+    # relabel: the fragments come back from the store, as many layers at a time as a pass held
+    keys = torch.from_numpy(nodes.view(np.int64)).to(dev)
+    vals = torch.from_numpy(np.stack([c.view(np.int64) for c in luts])).to(dev)
+    rd = open_ds(frags_name)
+    step = per_pass * bz
+    for z0 in range(0, total_shape[0], step):
+        z1 = min(total_shape[0], z0 + step)
+        with _trace.span(f"segment (streamed): relabel sections {z0}..{z1 - 1}"):
+            fr = torch.from_numpy(rd[z0:z1].view(np.int64)).to(dev)
+            out = lut_relabel_multi(fr, keys, vals)
+            for t, ds in enumerate(seg_ds):
+                writer.submit(ds, out[t], z0, 0)
+            writer.drain()
+            del fr, out
+    writer.close()
     return written
 
 

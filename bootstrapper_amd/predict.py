@@ -251,7 +251,7 @@ def predict_blocks(cfg, rank=0, world=1, device=None, precision="bf16x3"):
     # Write-behind: the device -> host copy of a block's outputs runs on a side stream into page-locked memory and the chunk
     # encoding + file writes (the library's threads, straight from that buffer: zarr_io.write_from) on a small pool, while the
     # next blocks are predicted.
-    WRITERS = 4
+    WRITERS = 8
     pool = cf.ThreadPoolExecutor(max_workers=WRITERS, thread_name_prefix="bsmi-write")
     pinned, copy_streams = {}, {}
 

@@ -677,19 +677,17 @@ class SlabSegmenter:
 
     def node_table(self):
         """RAG nodes of the slab's blocks {id, position (voxels of the slab), size} (watershed_frags.py:230-246)."""
-        ids, pos, size = [], [], []
-        sizes = self.sizes.cpu().numpy()
-        sums = self.sums.cpu().numpy()
-        for k, (b, _) in enumerate(self.boxes):
-            n = int(self.block_nums[k])
-            if n == 0:
-                continue
-            ids.append(np.arange(1, n + 1, dtype=np.uint64) + np.uint64(self.block_ids[k] * self.nvb))
-            size.append(sizes[k, :n])
-            pos.append(np.asarray(b, np.float64) + sums[k, :n].astype(np.float64) / sizes[k, :n, None])
-        if not ids:
+        nums = np.asarray([int(n) for n in self.block_nums], dtype=np.int64)
+        if nums.sum() == 0:
             return np.zeros(0, np.uint64), np.zeros((0, 3)), np.zeros(0, np.int64)
-        return np.concatenate(ids), np.concatenate(pos), np.concatenate(size)
+        # only the used prefix of every block's table leaves the device (the tables are label_cap entries per block: 1 GB for the
+        # 512 blocks of a 1024^3 volume, of which 30 MB are nodes)
+        used = torch.arange(self.label_cap, device=self.dev)[None, :] < torch.from_numpy(nums).to(self.dev)[:, None]
+        sizes = self.sizes[used].cpu().numpy()
+        sums = self.sums[used].cpu().numpy().astype(np.float64)
+        first = np.repeat(np.asarray([b for b, _ in self.boxes], np.float64), nums, axis=0)
+        ids = np.concatenate([np.arange(1, n + 1, dtype=np.uint64) + np.uint64(bid * self.nvb) for n, bid in zip(nums, self.block_ids) if n])
+        return ids, first + sums / sizes[:, None], sizes
 
     def stitch(self):
         """post/watershed.py:155-203: every rank's nodes and scored edges meet on rank 0, which runs the connected

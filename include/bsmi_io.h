@@ -94,6 +94,14 @@ int bsmi_chunks_read_into(const bsmi_codec *codec, int n, const bsmi_chunk_copy 
 int bsmi_chunks_write_from(const bsmi_codec *codec, int n, const bsmi_chunk_copy *copies, const int64_t chunk_shape[4],
                            int itemsize, const void *fill_value, int *status, int threads);
 
+/* The region adjacency graph of a segmented volume as an SQLite file (the `db` table of the reference's segment config,
+ * post/watershed.py:100-117; nodes as post/blockwise/watershed_frags.py:230-246 writes them, edges with their merge scores
+ * as waterz_agglom.py:165-170): tables nodes(id PRIMARY KEY, z, y, x, size) and edges(u, v, merge_score, PRIMARY KEY (u, v)),
+ * a NaN score stored as NULL (never merged).  positions [n_nodes][3] world units, edges [n_edges][2].  libsqlite3.so.0 is
+ * loaded at run time; BSMI_ERR_MISSING if it cannot be. */
+int bsmi_rag_write_sqlite(const char *path, uint64_t n_nodes, const uint64_t *ids, const double *positions, const int64_t *sizes,
+                          uint64_t n_edges, const uint64_t *edges, const float *scores);
+
 #ifdef __cplusplus
 }
 #endif

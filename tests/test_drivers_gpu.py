@@ -190,6 +190,38 @@ remove_debris = 12
     for a, b in zip(written, written5):
         assert np.array_equal(open_ds(a)[:], open_ds(b)[:]), (a, b)
 
+    # a device too small for the volume (missing 4; the reference streams any volume block by block,
+    # post/watershed.py:75-203): `hbm_budget_gb` between what two and what three layers of blocks need -> passes of ONE layer
+    # (each holding the layer above it for context), fragments through the store, one global stitch, relabel pass by pass:
+    # the datasets, the LUTs and the database of the resident run, bit for bit
+    from bootstrapper_amd.volume import SlabSegmenter
+    need = [SlabSegmenter.hbm_bytes((min(nl * 8, 20), 150, 130), (1, 8, 8), 2, nl * 9) for nl in (2, 3)]
+    cfg6 = tmp_path / "seg6.toml"
+    cfg6.write_text(cfg.read_text().replace("blockwise = true", f"blockwise = true\nhbm_budget_gb = {(need[0] + need[1]) / 2 / 2**30:.6f}")
+                    .replace("fragments\"", "fragments_st\"").replace("segmentations\"", "segmentations_st\"").replace("rag.db", "rag_st.db"))
+    import bootstrapper_amd.post.watershed as W
+    calls = []
+    orig = W._waterz_streamed
+    W._waterz_streamed = lambda *a, **k: (calls.append(a[-1]), orig(*a, **k))[1]
+    try:
+        written6 = run_segmentation(str(cfg6), "ws")
+    finally:
+        W._waterz_streamed = orig
+    assert calls == [1]                                           # one layer per pass
+    for a, b in zip(written, written6):
+        assert np.array_equal(open_ds(a)[:], open_ds(b)[:]), (a, b)
+    lut6 = np.load(os.path.join(store, "luts_st", os.path.basename(written6[1]) + ".npz"))["fragment_segment_lut"]
+    assert np.array_equal(lut6, lut)
+    con = sqlite3.connect(str(tmp_path / "rag_st.db"))
+    assert con.execute("SELECT COUNT(*) FROM edges").fetchone()[0] == len(E)
+    assert [r[0] for r in con.execute("SELECT id FROM nodes ORDER BY id").fetchall()] == nodes.tolist()
+    assert con.execute("SELECT COUNT(*) FROM edges WHERE merge_score IS NULL").fetchone()[0] == int(np.isnan(Sc).sum())
+    con.close()
+    with pytest.raises(MemoryError):                              # not even two layers
+        cfg7 = tmp_path / "seg7.toml"
+        cfg7.write_text(cfg6.read_text().replace(f"hbm_budget_gb = {(need[0] + need[1]) / 2 / 2**30:.6f}", "hbm_budget_gb = 0.001"))
+        run_segmentation(str(cfg7), "ws")
+
     # block_shape = "roi": one block, no context (post/watershed.py:357-363), same machinery
     cfg2 = tmp_path / "seg2.toml"
     cfg2.write_text(cfg.read_text().replace("blockwise = true", 'blockwise = true\nblock_shape = "roi"')

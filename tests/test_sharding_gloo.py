@@ -119,7 +119,7 @@ def _volume_worker(rank, world, port, q):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world", [2, 3])
+@pytest.mark.parametrize("world", [2, 3, 8])
 def test_slab_exchange_and_stitch_gloo(world):
     """The communication of bootstrapper_amd.volume on CPU tensors: slab faces to the z-neighbours, edges to rank 0, LUT back."""
     ctx = mp.get_context("spawn")
@@ -173,7 +173,7 @@ def _grid_worker(rank, world, port, q, grid):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("grid", [(2, 2), (1, 3), (3, 2)])
+@pytest.mark.parametrize("grid", [(2, 2), (1, 3), (3, 2), (8, 1), (2, 4)])   # the last two: the eight ranks of one MI355X node
 def test_face_exchange_on_a_rank_grid_gloo(grid):
     """The two-phase face exchange of SlabSegmenter on a (Rz, Ry) grid of ranks: every box ends with its whole context
     margin, edges and corners (the diagonal neighbour's voxels) included, zeros beyond the volume."""
