@@ -271,7 +271,7 @@ def drivers_leg(raw_box, sd, precision):
         with open(seg_toml, "w") as f:
             f.write(f'affs_dataset = "{store}/predictions/1/3d_affs"\nfragments_dataset = "{store}/fragments"\n'
                     f'seg_dataset_prefix = "{store}/segmentations"\nblockwise = true\nblock_shape = {list(OUT_BLOCK)}\n'
-                    f'context = {list(SEG_CONTEXT)}\nlanes = 16\n[db]\ndb_file = "{tmp}/rag.db"\n[ws_params]\nthresholds = {THRESHOLDS}\n'
+                    f'context = {list(SEG_CONTEXT)}\n[db]\ndb_file = "{tmp}/rag.db"\n[ws_params]\nthresholds = {THRESHOLDS}\n'
                     f'min_seed_distance = 10\nfilter_fragments = {FILTER_FRAGMENTS}\nremove_debris = {REMOVE_DEBRIS}\n')
         t0 = time.perf_counter()
         run_prediction(pred_toml, "01", precision=precision)

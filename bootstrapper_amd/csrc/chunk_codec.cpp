@@ -19,6 +19,7 @@
 #include <zlib.h>
 
 #include <atomic>
+#include <mutex>
 #include <cerrno>
 #include <cstdint>
 #include <cstdio>
@@ -659,6 +660,42 @@ bool write_file_atomic(const char* path, const uint8_t* data, size_t n, int* err
   return true;
 }
 
+// Scratch buffers of the worker threads.  run_pool starts its threads per request, so a `thread_local` vector is a fresh
+// allocation in every one of them: 16 MB of chunk image + 16 MB of encoder output per chunk, every page of it faulted in and
+// zeroed before use (the 32 GB of fragments + segmentations of a 1024^3 volume went at 125 MB/s per thread that way).  The
+// buffers are handed out from a process-wide free list instead and keep their pages.
+class ScratchPool {
+ public:
+  std::vector<uint8_t> take(size_t n) {
+    std::vector<uint8_t> v;
+    {
+      std::lock_guard<std::mutex> g(mu_);
+      size_t best = free_.size();
+      for (size_t i = 0; i < free_.size(); ++i)
+        if (free_[i].capacity() >= n && (best == free_.size() || free_[i].capacity() < free_[best].capacity())) best = i;
+      if (best == free_.size() && !free_.empty()) best = free_.size() - 1;
+      if (best < free_.size()) { v = std::move(free_[best]); free_.erase(free_.begin() + (long)best); }
+    }
+    if (v.size() < n) v.resize(n);
+    return v;
+  }
+  void give(std::vector<uint8_t>&& v) {
+    std::lock_guard<std::mutex> g(mu_);
+    if (free_.size() < 256) free_.push_back(std::move(v));
+  }
+ private:
+  std::mutex mu_;
+  std::vector<std::vector<uint8_t>> free_;
+};
+ScratchPool g_scratch;
+struct Scratch {   // a buffer of at least n bytes for the life of the object
+  std::vector<uint8_t> v;
+  explicit Scratch(size_t n) : v(g_scratch.take(n)) {}
+  ~Scratch() { g_scratch.give(std::move(v)); }
+  uint8_t* data() { return v.data(); }
+  size_t size() const { return v.size(); }
+};
+
 template <class F>
 void run_pool(int n, int threads, F&& body) {
   if (threads < 1) threads = 1;
@@ -793,10 +830,11 @@ int bsmi_chunks_read_into(const bsmi_codec* codec, int n, const bsmi_chunk_copy*
   }
   std::vector<std::string> msgs((size_t)n);
   run_pool(n, threads, [&](int i) {
-    static thread_local std::vector<uint8_t> file, plain;
     const bsmi_chunk_copy& c = copies[i];
     Region r;
     region_of(c, chunk_shape, itemsize, &r);
+    Scratch filebuf(r.chunk_bytes + 4096);
+    std::vector<uint8_t>& file = filebuf.v;
     int err = 0;
     if (!read_file(c.path, file, &err)) {
       if (err != ENOENT) { status[i] = BSMI_ERR_INVALID; msgs[i] = std::string(c.path) + ": " + strerror(err); return; }
@@ -804,9 +842,9 @@ int bsmi_chunks_read_into(const bsmi_codec* codec, int n, const bsmi_chunk_copy*
       for_rows(c, r, [&](size_t, uint8_t* host) { fill_bytes(host, r.row_bytes, fill, r.item); });
       return;
     }
-    plain.resize(r.chunk_bytes);
+    Scratch plain(r.chunk_bytes);
     size_t len = 0;
-    status[i] = decode_any(codec, file.data(), file.size(), plain.data(), plain.size(), &len, r.need);
+    status[i] = decode_any(codec, file.data(), file.size(), plain.data(), r.chunk_bytes, &len, r.need);
     if (status[i] != BSMI_OK) { msgs[i] = std::string(c.path) + ": " + bsmi_last_error(); return; }
     if (len != r.chunk_bytes) {
       status[i] = BSMI_ERR_INVALID;
@@ -832,11 +870,11 @@ int bsmi_chunks_write_from(const bsmi_codec* codec, int n, const bsmi_chunk_copy
   }
   std::vector<std::string> msgs((size_t)n);
   run_pool(n, threads, [&](int i) {
-    static thread_local std::vector<uint8_t> file, plain, enc;
+    std::vector<uint8_t> file;   // (read-modify-write only)
     const bsmi_chunk_copy& c = copies[i];
     Region r;
     region_of(c, chunk_shape, itemsize, &r);
-    plain.resize(r.chunk_bytes);
+    Scratch plain(r.chunk_bytes);
     bool whole = true;
     for (int d = 0; d < 4; ++d) whole &= c.start[d] == 0 && c.extent[d] == r.cs[d];
     status[i] = BSMI_OK;
@@ -847,7 +885,7 @@ int bsmi_chunks_write_from(const bsmi_codec* codec, int n, const bsmi_chunk_copy
       int err = 0;
       if (c.read_modify_write && read_file(c.path, file, &err)) {
         size_t len = 0;
-        int rc = decode_any(codec, file.data(), file.size(), plain.data(), plain.size(), &len);
+        int rc = decode_any(codec, file.data(), file.size(), plain.data(), r.chunk_bytes, &len);
         if (rc != BSMI_OK || len != r.chunk_bytes) {
           status[i] = BSMI_ERR_INVALID;
           msgs[i] = std::string(c.path) + ": existing chunk cannot be read back: " + (rc != BSMI_OK ? bsmi_last_error() : "wrong size");
@@ -862,9 +900,9 @@ int bsmi_chunks_write_from(const bsmi_codec* codec, int n, const bsmi_chunk_copy
       if (!have) fill_bytes(plain.data(), r.chunk_bytes, fill, r.item);
     }
     for_rows(c, r, [&](size_t off, uint8_t* host) { memcpy(plain.data() + off, host, r.row_bytes); });
-    enc.resize(bound_any(codec, r.chunk_bytes));
+    Scratch enc(bound_any(codec, r.chunk_bytes));
     size_t len = 0;
-    status[i] = encode_any(codec, plain.data(), r.chunk_bytes, enc.data(), enc.size(), &len);
+    status[i] = encode_any(codec, plain.data(), r.chunk_bytes, enc.data(), bound_any(codec, r.chunk_bytes), &len);
     if (status[i] != BSMI_OK) { msgs[i] = std::string(c.path) + ": " + bsmi_last_error(); return; }
     int err = 0;
     if (!write_file_atomic(c.path, enc.data(), len, &err)) {

@@ -395,6 +395,8 @@ def waterz_pipeline(config, device=None, rank=0, world=1, group=None, grid=None,
     def warm():
         torch.cuda.set_device(seg.dev)
         with _trace.span("segment: lanes and slab-sized kernels warmed beside the read"):
+            seg.segs.zero_()     # first touch of the stitch's outputs (26 + 8.6 GB for a 1024^3 volume)
+            seg._fr.zero_()
             try:
                 seg.prime()
             except Exception:  # noqa: BLE001 - a warm-up on half-read data: an overflow there means nothing
@@ -444,7 +446,7 @@ def waterz_pipeline(config, device=None, rank=0, world=1, group=None, grid=None,
 
     # RAG to the database (rank 0 gathers nodes and all edges, scored or not: post/watershed.py:100-117 db config)
     import concurrent.futures as cf
-    aux = cf.ThreadPoolExecutor(max_workers=2, thread_name_prefix="bsmi-aux")   # the database and the LUT files, beside the stitch
+    aux = cf.ThreadPoolExecutor(max_workers=4, thread_name_prefix="bsmi-aux")   # the database and the LUT files, beside the stitch
     aux_jobs = []
     ids, pos, size = seg.node_table()
     pos = np.asarray(roi[0], np.float64) + (pos + np.array([z0, y0, 0], np.float64)) * np.asarray(voxel_size, np.float64)

@@ -242,8 +242,10 @@ class SlabSegmenter:
         # streams of its own (one rank under `--force-dist`: 20 lanes 55.3 Mvoxels/s, predict 34.5 ms per block; 16 lanes
         # 65.0, 28.9 ms), so a rank of an RCCL job stops at 16.
         import torch.distributed as dist
-        if int(n_lanes) > 16 and dist.is_available() and dist.is_initialized() and "nccl" in str(dist.get_backend()):
-            n_lanes = 16
+        import os
+        dist_cap = int(os.environ.get("BSMI_DIST_LANES", "16"))   # (experiments: more lanes under RCCL with a larger GPU_MAX_HW_QUEUES)
+        if int(n_lanes) > dist_cap and dist.is_available() and dist.is_initialized() and "nccl" in str(dist.get_backend()):
+            n_lanes = dist_cap
         for stream in lane_streams(self.dev, max(1, min(int(n_lanes), K))):
             self.lanes.append(dict(engine=SegEngine(read, self.dev.index), stream=stream,
                                    a=torch.empty((3,) + read, dtype=torch.uint8, device=self.dev),
