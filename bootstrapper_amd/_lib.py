@@ -139,6 +139,9 @@ def _load():
                                    C.POINTER(C.c_size_t), C.POINTER(i32), i32]),
         "bsmi_chunks_write": (i32, [C.POINTER(Codec), i32, C.POINTER(C.c_char_p), C.POINTER(vp), C.POINTER(C.c_size_t),
                                     C.POINTER(i32), i32]),
+        "bsmi_blosc_dev_frame_bound": (C.c_size_t, [C.c_size_t]),
+        "bsmi_blosc_dev_scratch_bytes": (C.c_size_t, [i32, C.c_size_t]),
+        "bsmi_blosc_encode_dev_u64": (i32, [i32, vp, C.c_int64, C.c_int64, i32, i64p, i64p, i64p, vp, C.c_size_t, vp, C.c_size_t, vp, vp]),
         "bsmi_rag_write_sqlite": (i32, [C.c_char_p, C.c_uint64, vp, vp, vp, C.c_uint64, vp, vp]),
         "bsmi_chunks_read_into": (i32, [C.POINTER(Codec), i32, C.POINTER(ChunkCopy), i64p, i32, vp, C.POINTER(i32), i32]),
         "bsmi_chunks_write_from": (i32, [C.POINTER(Codec), i32, C.POINTER(ChunkCopy), i64p, i32, vp, C.POINTER(i32), i32]),

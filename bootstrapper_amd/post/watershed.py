@@ -220,16 +220,91 @@ class _LayerWriter:
         self.pool = cf.ThreadPoolExecutor(max_workers=IO_WORKERS, thread_name_prefix="bsmi-write")
         self.streams = {}
         self.pinned = {}   # thread -> page-locked staging buffer (a pageable destination makes the runtime stage the copy itself)
+        self.devbuf = {}   # thread -> (scratch, frame slots, frame sizes) of the device-side Blosc encoder
         self.futures = []
         self.torch = torch
 
+    @staticmethod
+    def _device_frames_ok(ds, z, y, part):
+        """can this piece's chunks be made into Blosc frames on the device (csrc/blosc_dev.hip)?  The dataset must be what
+        `prepare_ds` creates by default for ids (Blosc lz4, byte shuffle, 8-byte items, whole 256 KiB blocks per chunk), the piece
+        must start on chunk boundaries and reach the array's end or a chunk boundary."""
+        import os as _os
+        from .. import _lib
+        if _os.environ.get("BSMI_DEVICE_FRAMES", "1") == "0" or len(ds.shape) != 3 or ds.dtype.itemsize != 8:
+            return False
+        c = ds.codec
+        if c.id != _lib.CODEC_BLOSC or c.cname != _lib.BLOSC_LZ4 or c.shuffle != 1 or c.blocksize not in (0, 256 * 1024) or c.level == 0:
+            return False
+        if ds.chunk_nbytes % (256 * 1024) or ds.chunk_nbytes // (256 * 1024) > 1024 or (ds.fill_value not in (0, None)):
+            return False
+        cz, cy, cx = ds.chunks
+        if z % cz or y % cy or part.stride(2) != 1:
+            return False
+        return all((o + e) % c_ == 0 or o + e == n for o, e, c_, n in ((z, part.shape[0], cz, ds.shape[0]), (y, part.shape[1], cy, ds.shape[1])))             and part.shape[2] == ds.shape[2]
+
+    def _write_device_frames(self, ds, part, z, y, st, tid):
+        """the piece's chunks as Blosc frames made on the device: two launches, the frame sizes and then the frames themselves
+        (a few percent of the piece) come to the host, the files are written from there"""
+        import ctypes as C
+        import os as _os
+        from .. import _lib
+        torch = self.torch
+        cz, cy, cx = ds.chunks
+        grid = [(iz, iy, ix) for iz in range(0, part.shape[0], cz) for iy in range(0, part.shape[1], cy) for ix in range(0, part.shape[2], cx)]
+        n = len(grid)
+        origins = (C.c_int64 * (3 * n))(*[v for g in grid for v in g])
+        extents = (C.c_int64 * (3 * n))(*[min(c_, s - o) for g in grid for o, c_, s in zip(g, (cz, cy, cx), part.shape)])
+        slot = int(_lib.lib.bsmi_blosc_dev_frame_bound(ds.chunk_nbytes))
+        slot = (slot + 255) // 256 * 256
+        need_s = int(_lib.lib.bsmi_blosc_dev_scratch_bytes(n, ds.chunk_nbytes))
+        bufs = self.devbuf.get(tid)
+        if bufs is None or bufs[0].numel() < need_s or bufs[1].numel() < n * slot:
+            bufs = self.devbuf[tid] = (torch.empty(need_s, dtype=torch.uint8, device=self.dev), torch.empty(n * slot, dtype=torch.uint8, device=self.dev),
+                                       torch.empty(max(n, 64), dtype=torch.int32, device=self.dev))
+        scratch, frames, sizes = bufs
+        if sizes.numel() < n:
+            sizes = torch.empty(n, dtype=torch.int32, device=self.dev)
+            self.devbuf[tid] = (scratch, frames, sizes)
+        shape3 = (C.c_int64 * 3)(cz, cy, cx)
+        _lib.check(_lib.lib.bsmi_blosc_encode_dev_u64(self.dev.index, C.c_void_p(part.data_ptr()), part.stride(0), part.stride(1), n, origins, extents, shape3,
+                                                       C.c_void_p(scratch.data_ptr()), need_s, C.c_void_p(frames.data_ptr()), slot, C.c_void_p(sizes.data_ptr()),
+                                                       C.c_void_p(st.cuda_stream)))
+        with torch.cuda.stream(st):
+            host_sizes = sizes[:n].to("cpu", non_blocking=False).numpy().astype(np.int64)
+        total = int(host_sizes.sum())
+        buf = self.pinned.get(tid)
+        if buf is None or buf.numel() < total:
+            if buf is not None:
+                _PINNED.give(buf)
+            buf = self.pinned[tid] = _PINNED.take(total)
+        offs = np.concatenate([[0], np.cumsum(host_sizes)])
+        with torch.cuda.stream(st):
+            for i in range(n):
+                buf[int(offs[i]):int(offs[i + 1])].copy_(frames[i * slot:i * slot + int(host_sizes[i])], non_blocking=True)
+        st.synchronize()
+        host = buf.numpy()
+        zi, yi = z // cz, y // cy
+        for i, (iz, iy, ix) in enumerate(grid):
+            path = ds._chunk_path((zi + iz // cz, yi + iy // cy, ix // cx))
+            tmp = f"{path}.tmp{_os.getpid()}.{tid % 100000}"
+            with open(tmp, "wb") as f:
+                f.write(memoryview(host[int(offs[i]):int(offs[i + 1])]))
+            _os.replace(tmp, path)
+
     def _write(self, ds, src, za, zb, ya, yb, z0, y0, ready):
         import threading
+        from .. import _trace
         torch = self.torch
         ready.synchronize()   # host-side wait (a stream parked behind a device-side wait costs the running kernels, DESIGN 6)
         tid = threading.get_ident()
         st = self.streams.setdefault(tid, torch.cuda.Stream(self.dev))
         part = src[za:zb, ya:yb]
+        if self._device_frames_ok(ds, z0 + za, y0 + ya, part):
+            with _trace.span("writer: frames made on the device + files written", True):
+                os.makedirs(ds.path, exist_ok=True)
+                self._write_device_frames(ds, part, z0 + za, y0 + ya, st, tid)
+            return
         nbytes = part.numel() * part.element_size()
         buf = self.pinned.get(tid)
         if buf is None or buf.numel() < nbytes:
@@ -242,7 +317,6 @@ class _LayerWriter:
             done = torch.cuda.Event()
             done.record(st)
         done.synchronize()
-        from .. import _trace
         with _trace.span("writer: encode + write", True):
             ds.write_from((slice(z0 + za, z0 + zb), slice(y0 + ya, y0 + yb)), host.numpy().view(np.uint64))
 

@@ -94,6 +94,23 @@ int bsmi_chunks_read_into(const bsmi_codec *codec, int n, const bsmi_chunk_copy 
 int bsmi_chunks_write_from(const bsmi_codec *codec, int n, const bsmi_chunk_copy *copies, const int64_t chunk_shape[4],
                            int itemsize, const void *fill_value, int *status, int threads);
 
+/* Blosc frames of a DEVICE-resident volume of 8-byte items (fragment / segment ids), made on the device (csrc/blosc_dev.hip):
+ * what `array[roi] = data` on a Zarr dataset with zarr-python's default compressor produces (Blosc-1, lz4, byte shuffle, 256 KiB
+ * split blocks; reference post/watershed.py:319-354, post/blockwise/watershed_frags.py:222-226) without taking the 8 bytes per
+ * voxel across PCIe and through the host's encoder: only the frames, a few percent of the volume, leave the device.
+ * src_dev[z * stride_z + y * stride_y + x] (strides in elements) is the volume; chunk i starts at origins[3 i ..] (voxels,
+ * relative to src_dev), extents[3 i ..] <= chunk_shape of it exist (the rest of the chunk is fill value 0: chunks that overhang
+ * the array).  chunk_shape: whole 256 KiB blocks (chunk bytes a multiple of 262 144, e.g. 128^3 or 8 x 64 x 64 items).
+ * frames_dev: n_chunks slots of slot_bytes >= bsmi_blosc_dev_frame_bound(chunk bytes); frame_sizes_dev[i] = bytes of frame i.
+ * scratch_dev: bsmi_blosc_dev_scratch_bytes(n_chunks, chunk bytes).  Asynchronous on `stream`; origins / extents are host arrays
+ * that must stay valid until the stream has passed the call.  Any Blosc-1 reader decodes the frames (the LZ4 blocks use matches
+ * at offset 1 only; liblz4 would pack label volumes about twice as tight). */
+size_t bsmi_blosc_dev_frame_bound(size_t chunk_bytes);
+size_t bsmi_blosc_dev_scratch_bytes(int n_chunks, size_t chunk_bytes);
+int bsmi_blosc_encode_dev_u64(int device, const uint64_t *src_dev, int64_t stride_z, int64_t stride_y, int n_chunks,
+                              const int64_t *origins, const int64_t *extents, const int64_t chunk_shape[3], void *scratch_dev,
+                              size_t scratch_bytes, void *frames_dev, size_t slot_bytes, uint32_t *frame_sizes_dev, void *stream);
+
 /* The region adjacency graph of a segmented volume as an SQLite file (the `db` table of the reference's segment config,
  * post/watershed.py:100-117; nodes as post/blockwise/watershed_frags.py:230-246 writes them, edges with their merge scores
  * as waterz_agglom.py:165-170): tables nodes(id PRIMARY KEY, z, y, x, size) and edges(u, v, merge_score, PRIMARY KEY (u, v)),

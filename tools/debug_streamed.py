@@ -20,6 +20,8 @@ fragments_dataset = "{store}/fragmentsNAME"
 seg_dataset_prefix = "{store}/segmentationsNAME"
 blockwise = true
 EXTRA
+[db]
+db_file = "TMP/ragNAME.db"
 [ws_params]
 thresholds = [0.3, 0.45]
 min_seed_distance = 4
@@ -30,7 +32,7 @@ need = [SlabSegmenter.hbm_bytes((min(nl * 8, 20), 150, 130), (1, 8, 8), 2, nl * 
 outs = {}
 for name, extra in (("res", ""), ("st", f"hbm_budget_gb = {(need[0] + need[1]) / 2 / 2**30:.6f}")):
     cfg = tmp + f"/{name}.toml"
-    open(cfg, "w").write(base.replace("NAME", "_" + name).replace("EXTRA", extra))
+    open(cfg, "w").write(base.replace("NAME", "_" + name).replace("EXTRA", extra).replace("TMP", tmp))
     outs[name] = run_segmentation(cfg, "ws")
 for a_, b_ in zip(outs["res"], outs["st"]):
     x, y = open_ds(a_)[:], open_ds(b_)[:]
