@@ -313,13 +313,19 @@ static int pack_wino(bsmi_unet* h, PassSite& p, int ci) {
   pw.Npad = round_up(p.cout, tile_bn(pw.tile));
   wino_units(pw.Cv, pw.units);
   {
-    std::vector<uint16_t> packed;
     size_t image_elems = 0, batch_elems = 0;
-    wino_pack_weights(wm.data.data(), p.cout, cin_m, pw.cin_of_v, pw.Npad, pw.units, packed, image_elems, batch_elems, pw.m);
+    static const bool on_host = [] { const char* e = getenv("BSMI_WINO_PACK_HOST"); return e && e[0] == '1'; }();
+    if (on_host) {   // (the host form of the transform: kept as the cross-check of the device one, tests/test_fullsize_gpu.py)
+      std::vector<uint16_t> packed;
+      wino_pack_weights(wm.data.data(), p.cout, cin_m, pw.cin_of_v, pw.Npad, pw.units, packed, image_elems, batch_elems, pw.m);
+      BSMI_HIP(hipMalloc(&pw.w, packed.size() * 2));
+      BSMI_HIP(hipMemcpy(pw.w, packed.data(), packed.size() * 2, hipMemcpyHostToDevice));
+    } else {
+      const int rc = wino_pack_weights_dev(wm.data.data(), p.cout, cin_m, pw.cin_of_v, pw.Npad, pw.units, pw.m, &pw.w, image_elems, batch_elems);
+      if (rc) return rc;
+    }
     pw.lo_image_bytes = image_elems * 2;
     pw.batch_bytes = batch_elems * 2;
-    BSMI_HIP(hipMalloc(&pw.w, packed.size() * 2));
-    BSMI_HIP(hipMemcpy(pw.w, packed.data(), packed.size() * 2, hipMemcpyHostToDevice));
   }
   // the cropped 1x1x1 residual branch of the last stage: its K-steps alone
   pw.res_entries.clear();

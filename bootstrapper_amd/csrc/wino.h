@@ -66,4 +66,9 @@ void wino_units(int Cv, std::vector<WinoUnit>& out);
 void wino_pack_weights(const float* w, int cout, int cin, const std::vector<int>& cin_of_v, int Npad, const std::vector<WinoUnit>& units,
                        std::vector<uint16_t>& packed, size_t& image_elems, size_t& batch_elems, int m = 2);
 
+// The same images made on the device from the stage's raw weights (uploaded for the call): *image_dev = hi image then lo image
+// (hipMalloc'ed, the caller frees it); bit for bit what wino_pack_weights makes.
+int wino_pack_weights_dev(const float* w, int cout, int cin, const std::vector<int>& cin_of_v, int Npad, const std::vector<WinoUnit>& units, int m,
+                          void** image_dev, size_t& image_elems, size_t& batch_elems);
+
 }  // namespace bsmi

@@ -766,4 +766,97 @@ void wino_pack_weights(const float* w, int cout, int cin, const std::vector<int>
   });
 }
 
+
+// The same on the device (round 4): the transformed weights of the 1500 -> 1500 stage are 36 x 3 x 1500 x 1536 (hi, lo) pairs,
+// 1 GB that the host computed on 16 threads and then uploaded -- 0.8 s of `bs predict`'s start.  Here the stage's raw weights go
+// up (243 MB) and a kernel writes the images: one thread per (unit, output channel, channel of the unit), G g G^T in double
+// without contraction (the host's operation order: the images are the same bit for bit), rounded to f32, split into (hi, lo).
+struct WinoPackDev {
+  const float* w;        // OIDHW f32
+  const int* cin_of_v;   // V channel -> input channel, -1: pad
+  const int* unit_kz;    // per unit: z tap, or -1 for a dummy unit
+  const int* unit_vc0;
+  uint16_t* image;       // hi image, then lo image
+  size_t image_elems, batch_elems;
+  int cout, cin, Npad, nunits, T;
+};
+__global__ __launch_bounds__(256) void wino_pack_kernel(const WinoPackDev a) {
+#pragma clang fp contract(off)
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t total = (size_t)(a.nunits / kUnitsPerStep) * a.cout * 32;
+  if (i >= total) return;
+  const int kk = (int)(i & 15), j = (int)((i >> 4) & 1);
+  const size_t r = i >> 5;
+  const int n = (int)(r % a.cout);
+  const size_t s = r / a.cout;
+  const int u = (int)(s * kUnitsPerStep + j);
+  const int kz = a.unit_kz[u];
+  if (kz < 0) return;
+  const int c = a.cin_of_v[a.unit_vc0[u] + kk];
+  if (c < 0) return;
+  const float* g = a.w + (((size_t)n * a.cin + c) * 3 + kz) * 9;
+  double gd[9];
+#pragma unroll
+  for (int k = 0; k < 9; ++k) gd[k] = (double)g[k];
+  const double aa = 0.70710678118654752440, bb = 1.41421356237309504880;
+  const double G4[6][3] = {{1, 0, 0}, {2. / 3, 2. / 3 * aa, 1. / 3}, {2. / 3, -2. / 3 * aa, 1. / 3}, {1. / 12, bb / 12, 1. / 6}, {1. / 12, -bb / 12, 1. / 6}, {0, 0, 1}};
+  const double G2[4][3] = {{1, 0, 0}, {.5, .5, .5}, {.5, -.5, .5}, {0, 0, 1}};
+  const int T = a.T;
+  double t[6][3];
+  for (int xi = 0; xi < T; ++xi)
+    for (int kx = 0; kx < 3; ++kx) {
+      const double g0 = T == 6 ? G4[xi][0] : G2[xi][0], g1 = T == 6 ? G4[xi][1] : G2[xi][1], g2 = T == 6 ? G4[xi][2] : G2[xi][2];
+      t[xi][kx] = g0 * gd[kx] + g1 * gd[3 + kx] + g2 * gd[6 + kx];
+    }
+  for (int xi = 0; xi < T; ++xi)
+    for (int nu = 0; nu < T; ++nu) {
+      const double g0 = T == 6 ? G4[nu][0] : G2[nu][0], g1 = T == 6 ? G4[nu][1] : G2[nu][1], g2 = T == 6 ? G4[nu][2] : G2[nu][2];
+      const float v = (float)(t[xi][0] * g0 + t[xi][1] * g1 + t[xi][2] * g2);
+      const size_t idx = (size_t)(T * xi + nu) * a.batch_elems + (s * a.Npad + n) * 32 + j * 16 + kk;
+      const uint16_t hi = to_bf16(v);
+      a.image[idx] = hi;
+      a.image[a.image_elems + idx] = to_bf16(v - __uint_as_float((uint32_t)hi << 16));
+    }
+}
+
+int wino_pack_weights_dev(const float* w, int cout, int cin, const std::vector<int>& cin_of_v, int Npad, const std::vector<WinoUnit>& units, int m,
+                          void** image_dev, size_t& image_elems, size_t& batch_elems) {
+  const size_t nsteps = units.size() / kUnitsPerStep;
+  const int T = m + 2, nbatch = T * T;
+  batch_elems = nsteps * (size_t)Npad * 32;
+  image_elems = nbatch * batch_elems + (size_t)kWeightRowSlack * 32;
+  uint16_t* image = nullptr;
+  BSMI_HIP(hipMalloc((void**)&image, 2 * image_elems * sizeof(uint16_t)));
+  hipError_t err = hipMemsetAsync(image, 0, 2 * image_elems * sizeof(uint16_t), nullptr);
+  float* wd = nullptr;
+  int* meta = nullptr;
+  std::vector<int> hm(cin_of_v);
+  const size_t o_kz = hm.size();
+  for (const WinoUnit& u : units) hm.push_back(u.dummy ? -1 : u.kz);
+  const size_t o_vc = hm.size();
+  for (const WinoUnit& u : units) hm.push_back(u.dummy ? 0 : u.vc0);
+  const size_t wbytes = (size_t)cout * cin * 27 * sizeof(float);
+  if (err == hipSuccess) err = hipMalloc((void**)&wd, wbytes);
+  if (err == hipSuccess) err = hipMalloc((void**)&meta, hm.size() * sizeof(int));
+  if (err == hipSuccess) err = hipMemcpy(wd, w, wbytes, hipMemcpyHostToDevice);
+  if (err == hipSuccess) err = hipMemcpy(meta, hm.data(), hm.size() * sizeof(int), hipMemcpyHostToDevice);
+  if (err == hipSuccess) {
+    WinoPackDev a;
+    a.w = wd; a.cin_of_v = meta; a.unit_kz = meta + o_kz; a.unit_vc0 = meta + o_vc; a.image = image;
+    a.image_elems = image_elems; a.batch_elems = batch_elems; a.cout = cout; a.cin = cin; a.Npad = Npad; a.nunits = (int)units.size(); a.T = T;
+    const size_t total = nsteps * (size_t)cout * 32;
+    hipLaunchKernelGGL(wino_pack_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, nullptr, a);
+    err = hipGetLastError();
+    if (err == hipSuccess) err = hipDeviceSynchronize();
+  }
+  if (wd) (void)hipFree(wd);
+  if (meta) (void)hipFree(meta);
+  if (err != hipSuccess) {
+    (void)hipFree(image);
+    BSMI_HIP(err);
+  }
+  *image_dev = image;
+  return BSMI_OK;
+}
+
 }  // namespace bsmi

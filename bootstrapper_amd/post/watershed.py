@@ -459,7 +459,7 @@ def waterz_pipeline(config, device=None, rank=0, world=1, group=None, grid=None,
                         grid=grid, total_rows=rows, row0=ys[ry], obj_group=obj_group,
                         cc_inclusive=bool(config.get("cc_inclusive", True)), queue_bins_formula=config.get("queue_bins_formula", "n_minus_1"),
                         epsilon_agglomerate=frag_params["epsilon_agglomerate"], sigma=frag_params["sigma"],
-                        noise_eps=frag_params["noise_eps"], bias=frag_params["bias"], seed_eps=frag_params["seed_eps"])
+                        noise_eps=frag_params["noise_eps"], bias=frag_params["bias"], seed_eps=frag_params["seed_eps"], lazy_outputs=True)
     t_slab.__exit__(None, None, None)
     # The lanes' workspaces, the slab-sized reductions and the relabel kernels are touched for the first time while the
     # affinities stream in (SlabSegmenter.prime: block 0's two tasks on every lane, a collect and a stitch, on whatever the slab
@@ -468,13 +468,19 @@ def waterz_pipeline(config, device=None, rank=0, world=1, group=None, grid=None,
 
     def warm():
         torch.cuda.set_device(seg.dev)
-        with _trace.span("segment: lanes and slab-sized kernels warmed beside the read"):
-            seg.segs.zero_()     # first touch of the stitch's outputs (26 + 8.6 GB for a 1024^3 volume)
-            seg._fr.zero_()
+        with _trace.span("segment: stitch buffers allocated, lanes warmed beside the read"):
+            seg.ensure_outputs(one=True)     # the interior copy of the fragments and ONE segmentation: allocated and touched here,
+            seg._fr.zero_()                  # beside the read, not in front of it (8.6 GB each for a 1024^3 volume)
+            seg._one.zero_()
             try:
-                seg.prime()
+                seg.prime_lanes()
             except Exception:  # noqa: BLE001 - a warm-up on half-read data: an overflow there means nothing
                 pass
+            for lane in seg.lanes:   # ... and its sticky overflow flags are read (= cleared) before the real run
+                try:
+                    lane["engine"].status()
+                except Exception:  # noqa: BLE001
+                    pass
     warm_thread = threading.Thread(target=warm, name="bsmi-warm") if world == 1 else None   # (several ranks: prime's stitch is collective)
     if warm_thread is not None:
         warm_thread.start()
@@ -544,17 +550,11 @@ def waterz_pipeline(config, device=None, rank=0, world=1, group=None, grid=None,
 
     # global segmentation: thresholded connected components -> LUT -> relabel (post/watershed.py:155-203)
     written = [frags_name]
-    with _trace.span("segment: stitch (connected components, LUT, relabel)"):
-        segs = seg.stitch()
-    if seg.nodes.size == 0:
-        writer.drain()
-        writer.close()
-        for j in aux_jobs:
-            j.result()
-        aux.shutdown()
-        return written
     lut_dir = config["lut_dir"]
-    for t, threshold in enumerate(thresholds):
+
+    def emit(t, seg_t):
+        """threshold t's segmentation (in the segmenter's one buffer): LUT file, dataset, chunks written before the buffer is reused"""
+        threshold = thresholds[t]
         params = {"merge_function": merge_function, "threshold": threshold, **frag_params}
         name = build_name(params)
         recorded = {"method": "ws", "blockwise": blockwise, **params}
@@ -567,8 +567,20 @@ def waterz_pipeline(config, device=None, rank=0, world=1, group=None, grid=None,
             prepare_ds(seg_name, shape=total_shape, **common)
             dump_params(seg_name, recorded)
         barrier()
-        writer.submit(open_ds(seg_name, "r+"), segs[t], z0, y0)
+        writer.submit(open_ds(seg_name, "r+"), seg_t, z0, y0)
+        writer.drain()
         written.append(seg_name)
+    with _trace.span("segment: stitch (connected components, LUT), relabel and write threshold by threshold"):
+        has_nodes = sum(int(n) for n in seg.block_nums) > 0 or world > 1
+        if has_nodes:
+            seg.stitch(consume=emit)
+    if not has_nodes or seg.nodes.size == 0:
+        writer.drain()
+        writer.close()
+        for j in aux_jobs:
+            j.result()
+        aux.shutdown()
+        return written[:1]
     with _trace.span("segment: wait for the dataset writers"):
         writer.drain()
     writer.close()
@@ -623,7 +635,8 @@ def _waterz_streamed(config, affs, mask, device, thresholds, merge_function, blo
                                 label_cap=int(config.get("label_cap", 1 << 16)), edge_cap=int(config.get("edge_cap", 1 << 17)),
                                 total_rows=rows, epsilon_agglomerate=frag_params["epsilon_agglomerate"], sigma=frag_params["sigma"],
                                 noise_eps=frag_params["noise_eps"], bias=frag_params["bias"], seed_eps=frag_params["seed_eps"],
-                                cc_inclusive=bool(config.get("cc_inclusive", True)), queue_bins_formula=config.get("queue_bins_formula", "n_minus_1"))
+                                cc_inclusive=bool(config.get("cc_inclusive", True)), queue_bins_formula=config.get("queue_bins_formula", "n_minus_1"),
+                                lazy_outputs=True)
             _fill_affinities(seg, affs, origin, z0, mask, 0)
             if carry is not None:
                 seg.frags[:ctx[0]].copy_(carry)    # the margin below: the previous pass's last `context` sections of fragments

@@ -156,7 +156,8 @@ class SlabSegmenter:
                  fragments_in_xy=True, min_seed_distance=10, filter_fragments=0.0, remove_debris=0, discretize_queue=256,
                  n_lanes=8, device=0, rank=0, world=1, group=None, edge_cap=1 << 17, label_cap=1 << 16, exchange_affs=True,
                  epsilon_agglomerate=0.0, sigma=None, noise_eps=None, bias=None, noise_seed=0, seed_eps=None,
-                 grid=None, total_rows=None, row0=0, obj_group=None, host_scores=True, cc_inclusive=True, queue_bins_formula="n_minus_1"):
+                 grid=None, total_rows=None, row0=0, obj_group=None, host_scores=True, cc_inclusive=True, queue_bins_formula="n_minus_1",
+                 lazy_outputs=False):
         """slab_shape: this rank's box of the volume (whole blocks but for the volume's far faces).  The ranks form a grid
         `grid` = (Rz, Ry) over z and y (default: (world, 1), slabs of block layers), rank = rz * Ry + ry; the volume has
         `total_layers` block layers and `total_rows` block rows, this rank's first ones are `layer0`, `row0`.
@@ -225,8 +226,12 @@ class SlabSegmenter:
         self.frags = torch.zeros(padded, dtype=torch.int64, device=self.dev)
         # outputs of the stitch, allocated with the slab: a first stitch that allocates them pays for it inside whatever times
         # the pipeline (whole 1024^3 volume: 26 GB of segmentations + 8.6 GB of interior fragments, a second of hipMalloc)
-        self.segs = torch.empty((len(self.thresholds),) + self.shape, dtype=torch.int64, device=self.dev)
-        self._fr = torch.empty(self.shape, dtype=torch.int64, device=self.dev)
+        # (lazy_outputs: a driver that writes the segmentations out threshold by threshold -- `stitch(consume=...)` -- needs one
+        # of them at a time and allocates it beside its reads: `ensure_outputs`)
+        self.segs = self._fr = self._one = None
+        if not lazy_outputs:
+            self.segs = torch.empty((len(self.thresholds),) + self.shape, dtype=torch.int64, device=self.dev)
+            self._fr = torch.empty(self.shape, dtype=torch.int64, device=self.dev)
         self.nums = torch.zeros(K, dtype=torch.int64, device=self.dev)
         self.sizes = torch.zeros((K, self.label_cap), dtype=torch.int64, device=self.dev)
         self.sums = torch.zeros((K, self.label_cap, 3), dtype=torch.int64, device=self.dev)
@@ -691,17 +696,36 @@ class SlabSegmenter:
         ids = np.concatenate([np.arange(1, n + 1, dtype=np.uint64) + np.uint64(bid * self.nvb) for n, bid in zip(nums, self.block_ids) if n])
         return ids, first + sums / sizes[:, None], sizes
 
-    def stitch(self):
+    def ensure_outputs(self, one=False):
+        """the stitch's buffers, if the constructor left them out: the interior copy of the fragments and all segmentations
+        (one = False) or a single segmentation buffer (one = True)"""
+        if self._fr is None:
+            self._fr = torch.empty(self.shape, dtype=torch.int64, device=self.dev)
+        if one and self._one is None:
+            self._one = torch.empty(self.shape, dtype=torch.int64, device=self.dev)
+        if not one and self.segs is None:
+            self.segs = torch.empty((len(self.thresholds),) + self.shape, dtype=torch.int64, device=self.dev)
+
+    def stitch(self, consume=None):
         """post/watershed.py:155-203: every rank's nodes and scored edges meet on rank 0, which runs the connected
-        components per threshold; the LUT comes back and every rank relabels its slab.  -> segs [thresholds][Z][Y][X]."""
+        components per threshold; the LUT comes back and every rank relabels its slab.  -> segs [thresholds][Z][Y][X].
+        consume(t, seg): the segmentations one at a time in ONE buffer (a driver that writes them out: 8 B per voxel of device
+        memory instead of 8 B per voxel and threshold); `consume` must be done with the buffer when it returns."""
         nodes = np.concatenate([np.arange(1, int(n) + 1, dtype=np.uint64) + np.uint64(bid * self.nvb)
                                 for n, bid in zip(self.block_nums, self.block_ids)] or [np.zeros(0, np.uint64)])
         # score < t  <=>  score <= the float32 just below t: the strict rule through the same library call
         thr = self.thresholds if self.cc_inclusive else [float(np.nextafter(np.float32(t), np.float32(-np.inf))) for t in self.thresholds]
         self.nodes, self.luts = gather_and_stitch(nodes, self.rag_edges, self.rag_scores, thr, self.rank, self.world, self.obj_group)
+        self.ensure_outputs(one=consume is not None)
         fr = self._fr
         fr.copy_(self.interior(self.frags))
         keys = torch.from_numpy(self.nodes.view(np.int64)).to(self.dev)
+        if consume is not None:
+            for t, comp in enumerate(self.luts):
+                lut_relabel(fr, keys, torch.from_numpy(comp.view(np.int64)).to(self.dev), out=self._one)
+                torch.cuda.current_stream(self.dev).synchronize()
+                consume(t, self._one)
+            return None
         if 1 <= len(self.luts) <= 8:   # every threshold's LUT in one pass over the fragments
             from .post.engine import lut_relabel_multi
             lut_relabel_multi(fr, keys, torch.from_numpy(np.stack([c.view(np.int64) for c in self.luts])).to(self.dev), out=self.segs)
@@ -718,6 +742,12 @@ class SlabSegmenter:
         # ... and of every lane's workspace: a lane's hash tables, heaps and scratch volumes are fresh allocations whose
         # first touch (page-table set-up) would otherwise fall into the first job -- 20-30 ms of the driver's 20-block job
         # on some boxes.  One block's two tasks on the still empty slab per lane: trivial work, every buffer touched.
+        self.prime_lanes()
+        self._collect()
+        return self.stitch()
+
+    def prime_lanes(self):
+        """block 0's two tasks on every lane (whatever the slab holds): every lane's workspace touched, every kernel loaded"""
         if len(self.boxes):
             for i in range(len(self.lanes)):
                 self._lane_load = [1] * len(self.lanes)
@@ -727,8 +757,8 @@ class SlabSegmenter:
                 self._lane_load[i] = 0
                 self._launch_scores(0)
             self._lane_load = [0] * len(self.lanes)
-        self._collect()
-        return self.stitch()
+            for lane in self.lanes:
+                lane["stream"].synchronize()
 
     def run(self, ready=None, overlap=False):
         if ready is not None and not overlap:

@@ -189,6 +189,8 @@ def test_full_net_volume_pipeline_vs_cpu_blockwise():
     ("F(4x4) on every stage, upsampled maps materialised", {"BSMI_WINO": "2", "BSMI_WINO4": "2", "BSMI_FUSE_UP": "0"}),
     ("F(4x4) on every stage, batched persistent launches with split-K tails", {"BSMI_WINO": "2", "BSMI_WINO4": "2", "BSMI_SK_GRID": "8", "BSMI_TILE_EFF": "0.01,0.01,0.01,1,0.01"}),
     ("no F(4x4) stage: F(2x2) where the default rule has Winograd stages", {"BSMI_WINO4": "0"}),
+    ("Winograd weight images transformed on the host (the device transform's cross-check), every stage F(4x4)", {"BSMI_WINO_PACK_HOST": "1", "BSMI_WINO": "2"}),
+    ("... and F(2x2)", {"BSMI_WINO_PACK_HOST": "1", "BSMI_WINO": "2", "BSMI_WINO4": "0"}),
     ("halo-resident form (conv_h16.hip) on every stage of at most 64 output channels", {"BSMI_H16": "2"}),
     ("halo-resident form on every such stage, the first ConvPass included", {"BSMI_H16": "2", "BSMI_FUSED_FIRST": "0", "BSMI_WINO": "0"}),
     ("no halo-resident stage", {"BSMI_H16": "0"}),

@@ -11,6 +11,7 @@ rng = np.random.default_rng(21)
 shape = (20, 150, 130)
 a = gaussian_filter(rng.random((3,) + shape), sigma=(0, 1, 3, 3))
 affs = ((a - a.min()) / (a.max() - a.min()) * 255).astype(np.uint8)
+affs[:, :, :40, :50] = 0
 store = tmp + "/vol.zarr"
 ds = prepare_ds(store + "/affs", affs.shape, offset=(40, 8, 16), voxel_size=(40, 4, 4), chunk_shape=(3, 8, 64, 64), dtype=np.uint8,
                 axis_names=["c^", "z", "y", "x"], units=["nm"] * 3, compressor="zlib")
