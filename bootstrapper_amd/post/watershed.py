@@ -460,6 +460,10 @@ def waterz_pipeline(config, device=None, rank=0, world=1, group=None, grid=None,
                         cc_inclusive=bool(config.get("cc_inclusive", True)), queue_bins_formula=config.get("queue_bins_formula", "n_minus_1"),
                         epsilon_agglomerate=frag_params["epsilon_agglomerate"], sigma=frag_params["sigma"],
                         noise_eps=frag_params["noise_eps"], bias=frag_params["bias"], seed_eps=frag_params["seed_eps"], lazy_outputs=True)
+    # the stitch's buffers: the interior copy of the fragments and ONE segmentation (written out threshold by threshold: 8.6 GB
+    # each for a 1024^3 volume, where all thresholds at once were 26 GB).  Allocated here, not beside the read: the runtime
+    # serialises an allocation with the reader's host-to-device copies (measured: the read 0.55 -> 1.5 s)
+    seg.ensure_outputs(one=True)
     t_slab.__exit__(None, None, None)
     # The lanes' workspaces, the slab-sized reductions and the relabel kernels are touched for the first time while the
     # affinities stream in (SlabSegmenter.prime: block 0's two tasks on every lane, a collect and a stitch, on whatever the slab
@@ -468,10 +472,7 @@ def waterz_pipeline(config, device=None, rank=0, world=1, group=None, grid=None,
 
     def warm():
         torch.cuda.set_device(seg.dev)
-        with _trace.span("segment: stitch buffers allocated, lanes warmed beside the read"):
-            seg.ensure_outputs(one=True)     # the interior copy of the fragments and ONE segmentation: allocated and touched here,
-            seg._fr.zero_()                  # beside the read, not in front of it (8.6 GB each for a 1024^3 volume)
-            seg._one.zero_()
+        with _trace.span("segment: lanes warmed beside the read"):
             try:
                 seg.prime_lanes()
             except Exception:  # noqa: BLE001 - a warm-up on half-read data: an overflow there means nothing
@@ -481,7 +482,7 @@ def waterz_pipeline(config, device=None, rank=0, world=1, group=None, grid=None,
                     lane["engine"].status()
                 except Exception:  # noqa: BLE001
                     pass
-    warm_thread = threading.Thread(target=warm, name="bsmi-warm") if world == 1 else None   # (several ranks: prime's stitch is collective)
+    warm_thread = threading.Thread(target=warm, name="bsmi-warm") if world == 1 and os.environ.get("BSMI_SEG_WARM", "1") != "0" else None
     if warm_thread is not None:
         warm_thread.start()
     with _trace.span("segment: affinities read into the slab"):

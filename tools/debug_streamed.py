@@ -44,3 +44,18 @@ for a_, b_ in zip(outs["res"], outs["st"]):
             if d[z].any():
                 idx = np.argwhere(d[z])
                 print("  z", z, "n", int(d[z].sum()), "y", idx[:, 0].min(), idx[:, 0].max(), "x", idx[:, 1].min(), idx[:, 1].max(), "e.g.", x[z][tuple(idx[0])], y[z][tuple(idx[0])])
+
+# block_shape = "roi" with and without the warm-up thread, against the CPU composition
+from oracle.blockwise_ref import cpu_blockwise
+fr2, _, _, _, segs2 = cpu_blockwise(affs, shape, (0, 0, 0), 4, 0.35, 12, [0.3, 0.45])
+for warm in ("1", "0"):
+    os.environ["BSMI_SEG_WARM"] = warm
+    cfg = tmp + f"/roi{warm}.toml"
+    open(cfg, "w").write(base.replace("NAME", "_roi" + warm).replace("EXTRA", 'block_shape = "roi"').replace("TMP", tmp))
+    out = run_segmentation(cfg, "ws")
+    x = open_ds(out[0])[:]
+    d = x != fr2
+    print("roi warm", warm, "fragments", "differ" if d.any() else "equal", int(d.sum()), "nonzero got/ref", int((x > 0).sum()), int((fr2 > 0).sum()), "max", x.max(), fr2.max())
+    if d.any():
+        zs = [z for z in range(x.shape[0]) if d[z].any()]
+        print("   z with differences", zs[:30])
