@@ -657,6 +657,11 @@ def _waterz_streamed(config, affs, mask, device, thresholds, merge_function, blo
             all_edges.append(seg.rag_edges[own]); all_scores.append(seg.rag_scores[own])
             nz = min(total_shape[0], b * bz) - z0
             inner = seg.interior(seg.frags)
+            if os.environ.get("BSMI_STREAM_DEBUG"):
+                import sys
+                print(f"[streamed] pass {a}..{b}: slab {tuple(seg.shape)} z0 {z0} nz {nz} blocks {len(seg.boxes)} block_nums {[int(n) for n in seg.block_nums]} "
+                      f"affs nonzero per z {[int(v) for v in (seg.interior(seg.affs) > 0).sum(dim=(0, 2, 3)).tolist()]} frags nonzero per z "
+                      f"{[int(v) for v in (inner > 0).sum(dim=(1, 2)).tolist()]}", file=sys.stderr, flush=True)
             writer.submit(frag_ds, inner[:nz], z0, 0)
             if top:
                 carry = seg.frags[nz:nz + ctx[0]].clone()
