@@ -285,6 +285,10 @@ class _LayerWriter:
         st.synchronize()
         host = buf.numpy()
         zi, yi = z // cz, y // cy
+        if os.environ.get("BSMI_STREAM_DEBUG"):
+            import sys
+            print(f"[frames] z {z} y {y} part {tuple(part.shape)} strides {part.stride()} n {n} sizes {host_sizes.tolist()[:6]} nonzero in part {int((part != 0).sum())} "
+                  f"first path {ds._chunk_path((zi, yi, 0))}", file=sys.stderr, flush=True)
         for i, (iz, iy, ix) in enumerate(grid):
             path = ds._chunk_path((zi + iz // cz, yi + iy // cy, ix // cx))
             tmp = f"{path}.tmp{_os.getpid()}.{tid % 100000}"
@@ -666,6 +670,10 @@ def _waterz_streamed(config, affs, mask, device, thresholds, merge_function, blo
             if top:
                 carry = seg.frags[nz:nz + ctx[0]].clone()
             writer.drain()      # the slab goes away with the pass
+            if os.environ.get("BSMI_STREAM_DEBUG"):
+                import sys
+                back = open_ds(frags_name)[:]
+                print(f"[streamed]   store after the pass: nonzero per z {[int(v) for v in (back > 0).sum(axis=(1, 2))]}", file=sys.stderr, flush=True)
             del seg, inner
             torch.cuda.empty_cache()
     check_task_states(states)
