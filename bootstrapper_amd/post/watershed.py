@@ -645,6 +645,7 @@ def _waterz_streamed(config, affs, mask, device, thresholds, merge_function, blo
             _fill_affinities(seg, affs, origin, z0, mask, 0)
             if carry is not None:
                 seg.frags[:ctx[0]].copy_(carry)    # the margin below: the previous pass's last `context` sections of fragments
+                torch.cuda.current_stream(dev).synchronize()   # (the lanes read it from their own streams)
             st = seg.run_blocks_accounted()
             for k, v in st.items():
                 # the layer above is counted by the pass that finishes it

@@ -257,6 +257,10 @@ class SlabSegmenter:
                                    f=torch.empty(read, dtype=torch.int64, device=self.dev),
                                    lab=torch.empty(tuple(min(b, s) for b, s in zip(self.block, self.shape)), dtype=torch.int64,
                                                    device=self.dev)))
+        # The zero fills of the slab above are queued on the CURRENT stream; what fills the slab next runs on other streams (the
+        # readers' copy streams, the lanes): without this wait a fill could land on top of data (found with the streamed driver,
+        # whose third pass read affinities into a slab whose memset had not run yet: an all-zero block layer)
+        torch.cuda.current_stream(self.dev).synchronize()
         self.nodes = None
         self.rag_edges = self.rag_scores = None
         self.luts = None
