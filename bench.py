@@ -63,7 +63,7 @@ HBM_PEAK_BYTES = 8.0e12
 # HBM-side bytes per conv launch cannot be counted inside this process: they come from the committed
 # rocprofv3 PMC passes of the same kernels on the same block (tools/pmc_traffic.py; FETCH_SIZE and WRITE_SIZE
 # in separate passes, KiB -> bytes, FETCH_SIZE doubled for gfx950 wide reads as the guide prescribes).
-TRAFFIC_PROFILES = {"bf16x3": os.path.join(ROOT, "profiles", "r03_conv_traffic_pmc_bf16x3.json"),
+TRAFFIC_PROFILES = {"bf16x3": os.path.join(ROOT, "profiles", "r04_conv_traffic_pmc_bf16x3.json"),
                     "bf16": os.path.join(ROOT, "profiles", "r01_g_conv_traffic_pmc.json")}
 
 
@@ -76,7 +76,7 @@ def pmc_traffic(precision):
         return None, None
 
 
-SQ_PROFILES = {"bf16x3": os.path.join(ROOT, "profiles", "r03_conv_sq_pmc_bf16x3.json"),
+SQ_PROFILES = {"bf16x3": os.path.join(ROOT, "profiles", "r04_conv_sq_pmc_bf16x3.json"),
                "bf16": os.path.join(ROOT, "profiles", "r01_g_conv_sq_pmc.json")}
 
 
@@ -645,7 +645,7 @@ def main():
                      "peak_note": MFMA_PEAK_NOTE[args.precision],
                      "traffic": traffic, "traffic_unit": "bytes per launch (memory side of L2, Infinity-Cache hits included)",
                      "traffic_source": traffic_src,
-                     "kernel": "every convolution stage of the U-Net: bsmi::conv_igemm_kernel / conv_igemm_sk_kernel launches, conv_h16_kernel for five of the six stages with at most 64 output channels and, for the five stages in Winograd F(2x2,3x3) form, wino_in_kernel + the batched conv_igemm_sk_kernel launch + wino_out_kernel (their time is inside the stage's; FLOPs are the direct convolution's)",
+                     "kernel": "every convolution stage of the U-Net: bsmi::conv_igemm_kernel / conv_igemm_sk_kernel launches, conv_h16_kernel for four of the six stages with at most 64 output channels and, for the seven stages in Winograd F(4x4,3x3) form, wino4_in_kernel + the batched conv_igemm_sk_kernel launch (36 batches) + wino4_out_kernel (their time is inside the stage's; FLOPs are the direct convolution's: see executed_mfma_frac)",
                      "launches": int(conv_launches), "avg_launch_ms": conv_ms / max(conv_launches, 1),
                      "timed": f"HIP events around every launch of every {max(1, args.profile_every)}. block of the timed region",
                      # the multiplies the matrix pipe was actually given (tile padding, all 16 / 36 batches of a Winograd stage, three bf16

@@ -18,12 +18,12 @@ R=$GRAFT_REPO_ROOT
 OUT=$R/gpurun_out/$1
 mkdir -p $OUT
 cd $R
-python3 bench.py > $OUT/bench_default_output.log 2>&1
 python3 bench.py --gpus 1 --steps 20 --warmup 5 > $OUT/bench_driver_form_output.log 2>&1
+python3 bench.py --no-drivers --no-train --no-whole-volume > $OUT/bench_default_output.log 2>&1
 python3 tools/probe_unet.py bf16x3 > $OUT/probe_unet_bf16x3.log 2>&1
 python3 bench.py --mode train > $OUT/train_default_output.log 2>&1
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o b -- python3 $R/bench.py --no-drivers --no-train > $OUT/bench_default_rocprof_output.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o b -- python3 $R/bench.py --no-drivers --no-train --no-whole-volume > $OUT/bench_default_rocprof_output.log 2>&1
 find $OUT/stats -name '*kernel_trace.csv' -delete
 cd $R
 bash tools/run_pmc_passes.sh gpurun_out/$1/pmc bf16x3

@@ -36,7 +36,7 @@ def main():
     kernels = {}
     tot_l = tot_f = tot_w = 0
     for name in sorted(set(f) | set(w)):
-        if "conv_" not in name and "wino_" not in name and "first_pass" not in name:
+        if "conv_" not in name and "wino" not in name and "first_pass" not in name:
             continue
         n = f.get(name, [0, 0])[0] or w.get(name, [0, 0])[0]
         fb = f.get(name, [0, 0.0])[1] * 1024 * 2
