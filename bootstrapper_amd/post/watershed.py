@@ -186,7 +186,8 @@ def _fill_affinities(seg, affs, origin, z0, mask=None, y0=0):
         tid = threading.get_ident()
         if tid not in staging:
             staging[tid] = _PINNED.take(nch * step * full[1] * full[2])
-            streams[tid] = torch.cuda.Stream(seg.dev)
+            from ..volume import io_stream
+            streams[tid] = io_stream(seg.dev)
         ext = tuple(h - l for l, h in zip(lo, hi))
         host = staging[tid][:nch * ext[0] * ext[1] * ext[2]].view((nch,) + ext)
         from .. import _trace
@@ -302,7 +303,10 @@ class _LayerWriter:
         torch = self.torch
         ready.synchronize()   # host-side wait (a stream parked behind a device-side wait costs the running kernels)
         tid = threading.get_ident()
-        st = self.streams.setdefault(tid, torch.cuda.Stream(self.dev))
+        if tid not in self.streams:
+            from ..volume import io_stream
+            self.streams[tid] = io_stream(self.dev)
+        st = self.streams[tid]
         part = src[za:zb, ya:yb]
         if self._device_frames_ok(ds, z0 + za, y0 + ya, part):
             with _trace.span("writer: frames made on the device + files written", True):

@@ -191,7 +191,8 @@ def predict_blocks(cfg, rank=0, world=1, device=None, precision="bf16x3"):
     def load_inputs():
         try:
             torch.cuda.set_device(device)
-            st = torch.cuda.Stream(dev)
+            from .volume import io_stream
+            st = io_stream(dev)
             run = max(1, min(out_shape[0], (256 << 20) // max(1, int(np.prod(vols[0].shape[1:])) * len(vols) * vols[0].element_size())))
             bufs = [torch.empty((t.shape[0], run) + tuple(t.shape[2:]), dtype=t.dtype, pin_memory=True) for _, t, _ in plans]
             for za in range(z_lo, z_hi, run):
@@ -262,7 +263,8 @@ def predict_blocks(cfg, rank=0, world=1, device=None, precision="bf16x3"):
         tid = threading.get_ident()   # processor polls for the whole forward pass, at the predict stream's expense
         if tid not in pinned:
             pinned[tid] = [torch.empty(t.shape, dtype=t.dtype, pin_memory=True) for t in u8]
-            copy_streams[tid] = torch.cuda.Stream(dev)
+            from .volume import io_stream
+            copy_streams[tid] = io_stream(dev)
         host = []
         with torch.cuda.stream(copy_streams[tid]):
             for buf, t in zip(pinned[tid], u8):

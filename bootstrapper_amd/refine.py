@@ -29,28 +29,39 @@ def _empty_copy(in_ds, out_array):
     return prepare_ds(out_array, **keep)
 
 
-def _tiles(in_ds, tile=512):
+def _tile_rows(in_ds):
+    """rows (y) of a tile: whole rows of x (what the dataset writers want: `post.watershed._LayerWriter`), whole chunks, and a
+    section of fewer than 2^20 voxels (bsmi_seg_create)"""
+    ny, nx = in_ds.shape[1], in_ds.shape[2]
+    cy = int(in_ds.chunks[1])
+    most = max(1, ((1 << 20) - 1) // max(1, nx))
+    return ny if ny <= most else max(cy if cy <= most else most, most // cy * cy)
+
+
+def _tiles(in_ds, tile=None):
     nz, ny, nx = in_ds.shape
     cz = int(in_ds.chunks[0])
+    rows = _tile_rows(in_ds) if tile is None else tile
     for iz in range(0, nz, cz):
-        for iy in range(0, ny, tile):
-            for ix in range(0, nx, tile):
-                yield iz, (slice(iz, min(iz + cz, nz)), slice(iy, min(iy + tile, ny)), slice(ix, min(ix + tile, nx)))
+        for iy in range(0, ny, rows):
+            yield iz, (slice(iz, min(iz + cz, nz)), slice(iy, min(iy + rows, ny)), slice(0, nx))
 
 
 class _Device:
-    def __init__(self, in_ds, device=0, tile=512):   # a workspace takes sections of fewer than 2^20 voxels (bsmi_seg_create)
+    def __init__(self, in_ds, device=0):
         import torch
         from .post.engine import SegEngine
         self.torch = torch
         self.dev = torch.device("cuda", device)
         cz = int(in_ds.chunks[0])
-        self.engine = SegEngine((min(cz, in_ds.shape[0]), min(tile, in_ds.shape[1]), min(tile, in_ds.shape[2])), device)
-        self.tile_edge = tile
+        if in_ds.shape[2] >= (1 << 20):
+            raise NotImplementedError("rows of 2^20 voxels or more")
+        self.engine = SegEngine((min(cz, in_ds.shape[0]), min(_tile_rows(in_ds), in_ds.shape[1]), in_ds.shape[2]), device)
+        self.tile_edge = None
 
         # tiles read for the object table stay on the device for the pass that writes the filtered copy (a rule is evaluated
         # between two passes over the same volume: the second read and decode of a dataset that fits is saved)
-        self.kept, self.kept_bytes, self.budget = {}, 0, 8 << 30
+        self.kept, self.kept_bytes, self.budget = {}, 0, 10 << 30
 
     def upload(self, block):
         return self.torch.from_numpy(np.ascontiguousarray(block).astype(np.uint64).view(np.int64)).to(self.dev)
@@ -93,6 +104,18 @@ def _apply_mapping(in_ds, out_array, keys, vals, device=0, holder=None):
     order = np.argsort(keys, kind="stable")
     k = d.torch.from_numpy(np.asarray(keys, np.uint64)[order].view(np.int64)).to(d.dev)
     v = d.torch.from_numpy(np.asarray(vals, np.uint64)[order].view(np.int64)).to(d.dev)
+    if in_ds.dtype == np.uint64:
+        # write-behind through the dataset writer of `bs segment`: Blosc frames made on the device where the dataset allows
+        # (csrc/blosc_dev.hip), files written on a pool while the next tiles are relabelled
+        from .post.watershed import _LayerWriter
+        writer = _LayerWriter(d.dev, int(in_ds.chunks[0]))
+        try:
+            for _, sl in _tiles(in_ds, d.tile_edge):
+                writer.submit(out_ds, lut_relabel(d.tile(in_ds, sl), k, v), sl[0].start, sl[1].start)
+            writer.drain()
+        finally:
+            writer.close()
+        return out_ds
     for _, sl in _tiles(in_ds, d.tile_edge):
         lab = d.tile(in_ds, sl)
         out_ds[sl] = lut_relabel(lab, k, v).cpu().numpy().view(np.uint64).astype(in_ds.dtype)

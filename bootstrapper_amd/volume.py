@@ -142,6 +142,22 @@ def lane_streams(device, n):
     return pool[:n]
 
 
+_IO_NEXT = {}
+
+
+def io_stream(device):
+    """A stream for a driver's copy / encode helper thread (write-behind of `bs predict`, the readers and dataset writers of
+    `bs segment`): one of the lane streams, dealt round robin.  The helpers move data while the lanes are idle (before and after
+    the block stages), and a stream of their own each would be more hardware queues than the runtime keeps (GPU_MAX_HW_QUEUES =
+    24: 20 lanes + the predict and default streams; bench.py's `drivers` leg, in a process that had used all of them, ran `bs
+    predict` 15 % slower with eight fresh copy streams)."""
+    dev = torch.device(device)
+    pool = lane_streams(dev, 8)
+    i = _IO_NEXT.get(dev, 0)
+    _IO_NEXT[dev] = (i + 1) % len(pool)
+    return pool[i]
+
+
 def predict_stream(device):
     dev = torch.device(device)
     if dev not in _PREDICT_STREAMS:
