@@ -736,9 +736,14 @@ def main():
         del pipe, segs
         pipe = segs = None
         torch.cuda.empty_cache()
-        out["whole_volume"] = whole_volume_leg(model, vol, args, dev, local_rank, rank, world, obj_group, use_dist, seg_kw, barrier,
-                                               flops_block, peak, check=(rank == 0 and world == 1 and not args.no_cpu_baseline))
-        out["config"]["whole_volume"] = out["whole_volume"]["what"]
+        try:
+            out["whole_volume"] = whole_volume_leg(model, vol, args, dev, local_rank, rank, world, obj_group, use_dist, seg_kw, barrier,
+                                                   flops_block, peak, check=(rank == 0 and world == 1 and not args.no_cpu_baseline))
+            out["config"]["whole_volume"] = out["whole_volume"]["what"]
+        except Exception as exc:  # noqa: BLE001 - the headline above stands; with several ranks a failure of one rank ends the job
+            if world > 1:
+                raise
+            out["whole_volume"] = {"error": f"{type(exc).__name__}: {exc}"}
     elif not args.no_segment and not args.no_whole_volume and edge % world == 0:
         out["whole_volume"] = {"what": "the timed region above IS the whole volume", "Mvoxels_per_s": value, "seconds": dt}
     if rank == 0 and world == 1 and not args.no_train:
