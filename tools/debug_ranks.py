@@ -1,0 +1,36 @@
+"""Dev tool: VolumePipeline (real net, predict + segment) on a 4x2x2-block job as one rank and as two ranks (gloo, sharing cuda:0):
+are the affinities, fragments and segmentations the same?   one rank:  python tools/debug_ranks.py OUT
+two ranks: python -m torch.distributed.run --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29655 tools/debug_ranks.py OUT"""
+import os, sys
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "24")
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch, torch.distributed as dist
+import bench
+from bootstrapper_amd.unet import Model
+from bootstrapper_amd.synth import synthetic_state_dict, synthetic_volume
+from bootstrapper_amd.volume import VolumePipeline
+out = sys.argv[1]
+world = int(os.environ.get("WORLD_SIZE", "1")); rank = int(os.environ.get("RANK", "0"))
+if world > 1:
+    dist.init_process_group("gloo")
+torch.cuda.set_device(0)
+model = Model(bench.NET_CONFIG, device=0, precision="bf16x3").load_state_dict(synthetic_state_dict(bench.NET_CONFIG, 0))
+vol = synthetic_volume((512, 256, 256), seed=0, device=torch.device("cuda", 0))
+job = (4 // world, 2, 2)
+pipe = VolumePipeline(model, bench.OUT_BLOCK, bench.CONTEXT, job, bench.SEG_CONTEXT, bench.THRESHOLDS, n_lanes=8, device=0, rank=rank, world=world,
+                      min_seed_distance=10, filter_fragments=0.1, remove_debris=64)
+segs = pipe.run(vol)
+a = pipe.seg.interior(pipe.seg.affs).cpu().numpy(); f = pipe.seg.interior(pipe.seg.frags).cpu().numpy(); s = segs.cpu().numpy()
+np.savez(os.path.join(out, f"w{world}_r{rank}.npz"), affs=a, frags=f, segs=s)
+if world > 1:
+    dist.barrier(); dist.destroy_process_group()
+if world == 2 and rank == 0 and os.path.exists(os.path.join(out, "w1_r0.npz")):
+    one = np.load(os.path.join(out, "w1_r0.npz"))
+    p0, p1 = np.load(os.path.join(out, "w2_r0.npz")), np.load(os.path.join(out, "w2_r1.npz"))
+    for key, ax in (("affs", 1), ("frags", 0), ("segs", 1)):
+        two = np.concatenate([p0[key], p1[key]], axis=ax)
+        d = two != one[key]
+        print(key, "equal" if not d.any() else f"DIFFER {int(d.sum())}", flush=True)
+        if d.any():
+            idx = np.argwhere(d)
+            print("   first", idx[0], "last", idx[-1], "z range", idx[:, -3].min(), idx[:, -3].max())
