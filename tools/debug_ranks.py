@@ -15,8 +15,9 @@ if world > 1:
     dist.init_process_group("gloo")
 torch.cuda.set_device(0)
 model = Model(bench.NET_CONFIG, device=0, precision="bf16x3").load_state_dict(synthetic_state_dict(bench.NET_CONFIG, 0))
-vol = synthetic_volume((512, 256, 256), seed=0, device=torch.device("cuda", 0))
-job = (4 // world, 2, 2)
+L = int(os.environ.get("LAYERS", "4"))
+vol = synthetic_volume((128 * L, 256, 256), seed=0, device=torch.device("cuda", 0))
+job = (L // world, 2, 2)
 pipe = VolumePipeline(model, bench.OUT_BLOCK, bench.CONTEXT, job, bench.SEG_CONTEXT, bench.THRESHOLDS, n_lanes=8, device=0, rank=rank, world=world,
                       min_seed_distance=10, filter_fragments=0.1, remove_debris=64)
 segs = pipe.run(vol)
