@@ -20,7 +20,18 @@ vol = synthetic_volume((128 * L, 256, 256), seed=0, device=torch.device("cuda", 
 job = (L // world, 2, 2)
 pipe = VolumePipeline(model, bench.OUT_BLOCK, bench.CONTEXT, job, bench.SEG_CONTEXT, bench.THRESHOLDS, n_lanes=8, device=0, rank=rank, world=world,
                       min_seed_distance=10, filter_fragments=0.1, remove_debris=64)
-segs = pipe.run(vol)
+import hashlib
+print(f"rank {rank}/{world}: volume sha1 {hashlib.sha1(vol.cpu().numpy().tobytes()).hexdigest()[:12]}", flush=True)
+if world > 1 and os.environ.get("SERIAL") == "1":
+    # the ranks predict one after the other (no two processes on the card at the same time)
+    for turn in range(world):
+        if turn == rank:
+            ready = pipe.predict(vol)
+            ready[-1].synchronize()
+        dist.barrier()
+    segs = pipe.seg.run(ready, False)
+else:
+    segs = pipe.run(vol)
 a = pipe.seg.interior(pipe.seg.affs).cpu().numpy(); f = pipe.seg.interior(pipe.seg.frags).cpu().numpy(); s = segs.cpu().numpy()
 np.savez(os.path.join(out, f"w{world}_r{rank}.npz"), affs=a, frags=f, segs=s)
 if world > 1:
