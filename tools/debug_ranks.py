@@ -36,11 +36,11 @@ a = pipe.seg.interior(pipe.seg.affs).cpu().numpy(); f = pipe.seg.interior(pipe.s
 np.savez(os.path.join(out, f"w{world}_r{rank}.npz"), affs=a, frags=f, segs=s)
 if world > 1:
     dist.barrier(); dist.destroy_process_group()
-if world == 2 and rank == 0 and os.path.exists(os.path.join(out, "w1_r0.npz")):
+if world > 1 and rank == 0 and os.path.exists(os.path.join(out, "w1_r0.npz")):
     one = np.load(os.path.join(out, "w1_r0.npz"))
-    p0, p1 = np.load(os.path.join(out, "w2_r0.npz")), np.load(os.path.join(out, "w2_r1.npz"))
+    parts = [np.load(os.path.join(out, f"w{world}_r{r}.npz")) for r in range(world)]
     for key, ax in (("affs", 1), ("frags", 0), ("segs", 1)):
-        two = np.concatenate([p0[key], p1[key]], axis=ax)
+        two = np.concatenate([p[key] for p in parts], axis=ax)
         d = two != one[key]
         print(key, "equal" if not d.any() else f"DIFFER {int(d.sum())}", flush=True)
         if d.any():
