@@ -44,5 +44,8 @@ if world > 1 and rank == 0 and os.path.exists(os.path.join(out, "w1_r0.npz")):
         d = two != one[key]
         print(key, "equal" if not d.any() else f"DIFFER {int(d.sum())}", flush=True)
         if d.any():
+            if key == "affs":
+                dd = np.abs(two.astype(np.int16) - one[key].astype(np.int16))
+                print("   largest |difference| of the u8 affinities", int(dd.max()), "mean over the differing", float(dd[d].mean()), "histogram 1/2/3+", int((dd == 1).sum()), int((dd == 2).sum()), int((dd >= 3).sum()))
             idx = np.argwhere(d)
             print("   first", idx[0], "last", idx[-1], "z range", idx[:, -3].min(), idx[:, -3].max())
