@@ -66,3 +66,19 @@ def dump_params(store, params):
 def dump_lut_params(lut_path, params):
     with open(f"{lut_path}.json", "w") as f:
         json.dump({k: _plain(v) for k, v in params.items()}, f, indent=2)
+
+
+def save_npz(path, compresslevel=1, **arrays):
+    """`numpy.savez_compressed(path, **arrays)` with a chosen deflate level: the same `.npz` container (a zip archive of `.npy`
+    members, read back by `numpy.load`), written at level 1 -- the fragment-segment LUT of a 1024^3 volume is 15 MB per threshold
+    and numpy's fixed level 6 took 0.4 s of `bs segment`'s 3 s for each; level 1 takes 0.08 s and 10 % more bytes."""
+    import io
+    import zipfile
+    import numpy as np
+    if not path.endswith(".npz"):
+        path += ".npz"
+    with zipfile.ZipFile(path, "w", compression=zipfile.ZIP_DEFLATED, compresslevel=compresslevel, allowZip64=True) as zf:
+        for name, arr in arrays.items():
+            buf = io.BytesIO()
+            np.lib.format.write_array(buf, np.asanyarray(arr), allow_pickle=False)
+            zf.writestr(name + ".npy", buf.getvalue())

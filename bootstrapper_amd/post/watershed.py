@@ -571,7 +571,8 @@ def waterz_pipeline(config, device=None, rank=0, world=1, group=None, grid=None,
         if rank == 0:
             os.makedirs(lut_dir, exist_ok=True)
             lut_path = os.path.join(lut_dir, name)
-            aux_jobs.append(aux.submit(np.savez_compressed, lut_path + ".npz", fragment_segment_lut=np.array([seg.nodes, seg.luts[t]])))
+            from .naming import save_npz
+            aux_jobs.append(aux.submit(save_npz, lut_path + ".npz", fragment_segment_lut=np.array([seg.nodes, seg.luts[t]])))
             dump_lut_params(lut_path, recorded)
             prepare_ds(seg_name, shape=total_shape, **common)
             dump_params(seg_name, recorded)
@@ -705,7 +706,8 @@ def _waterz_streamed(config, affs, mask, device, thresholds, merge_function, blo
         recorded = {"method": "ws", "blockwise": blockwise, **params}
         seg_name = os.path.join(config["seg_dataset_prefix"], name)
         os.makedirs(lut_dir, exist_ok=True)
-        np.savez_compressed(os.path.join(lut_dir, name) + ".npz", fragment_segment_lut=np.array([nodes, luts[t]]))
+        from .naming import save_npz
+        save_npz(os.path.join(lut_dir, name) + ".npz", fragment_segment_lut=np.array([nodes, luts[t]]))
         dump_lut_params(os.path.join(lut_dir, name), recorded)
         prepare_ds(seg_name, shape=total_shape, **common)
         dump_params(seg_name, recorded)
