@@ -286,10 +286,6 @@ class _LayerWriter:
         st.synchronize()
         host = buf.numpy()
         zi, yi = z // cz, y // cy
-        if os.environ.get("BSMI_STREAM_DEBUG"):
-            import sys
-            print(f"[frames] z {z} y {y} part {tuple(part.shape)} strides {part.stride()} n {n} sizes {host_sizes.tolist()[:6]} nonzero in part {int((part != 0).sum())} "
-                  f"first path {ds._chunk_path((zi, yi, 0))}", file=sys.stderr, flush=True)
         for i, (iz, iy, ix) in enumerate(grid):
             path = ds._chunk_path((zi + iz // cz, yi + iy // cy, ix // cx))
             tmp = f"{path}.tmp{_os.getpid()}.{tid % 100000}"
@@ -667,19 +663,10 @@ def _waterz_streamed(config, affs, mask, device, thresholds, merge_function, blo
             all_edges.append(seg.rag_edges[own]); all_scores.append(seg.rag_scores[own])
             nz = min(total_shape[0], b * bz) - z0
             inner = seg.interior(seg.frags)
-            if os.environ.get("BSMI_STREAM_DEBUG"):
-                import sys
-                print(f"[streamed] pass {a}..{b}: slab {tuple(seg.shape)} z0 {z0} nz {nz} blocks {len(seg.boxes)} block_nums {[int(n) for n in seg.block_nums]} "
-                      f"affs nonzero per z {[int(v) for v in (seg.interior(seg.affs) > 0).sum(dim=(0, 2, 3)).tolist()]} frags nonzero per z "
-                      f"{[int(v) for v in (inner > 0).sum(dim=(1, 2)).tolist()]}", file=sys.stderr, flush=True)
             writer.submit(frag_ds, inner[:nz], z0, 0)
             if top:
                 carry = seg.frags[nz:nz + ctx[0]].clone()
             writer.drain()      # the slab goes away with the pass
-            if os.environ.get("BSMI_STREAM_DEBUG"):
-                import sys
-                back = open_ds(frags_name)[:]
-                print(f"[streamed]   store after the pass: nonzero per z {[int(v) for v in (back > 0).sum(axis=(1, 2))]}", file=sys.stderr, flush=True)
             del seg, inner
             torch.cuda.empty_cache()
     check_task_states(states)

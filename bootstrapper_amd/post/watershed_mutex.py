@@ -247,7 +247,8 @@ def volara_pipeline(config, device=0):
     else:
         segment = np.zeros(0, np.uint64)
     os.makedirs(lut_dir, exist_ok=True)
-    np.savez_compressed(lut_name + ".npz", fragment_segment_lut=np.stack([ids, segment]) if len(ids) else np.zeros((2, 0), np.uint64))
+    from .naming import save_npz
+    save_npz(lut_name + ".npz", fragment_segment_lut=np.stack([ids, segment]) if len(ids) else np.zeros((2, 0), np.uint64))
     dump_lut_params(lut_name, {"method": "mws", "blockwise": blockwise, **seg_params})
 
     # ---- Relabel (watershed_mutex.py:163-172)
