@@ -18,7 +18,7 @@ model = Model(bench.NET_CONFIG, device=0, precision="bf16x3").load_state_dict(sy
 L = int(os.environ.get("LAYERS", "4"))
 vol = synthetic_volume((128 * L, 256, 256), seed=0, device=torch.device("cuda", 0))
 job = (L // world, 2, 2)
-pipe = VolumePipeline(model, bench.OUT_BLOCK, bench.CONTEXT, job, bench.SEG_CONTEXT, bench.THRESHOLDS, n_lanes=8, device=0, rank=rank, world=world,
+pipe = VolumePipeline(model, bench.OUT_BLOCK, bench.CONTEXT, job, bench.SEG_CONTEXT, bench.THRESHOLDS, n_lanes=int(os.environ.get("LANES", "8")), device=0, rank=rank, world=world,
                       min_seed_distance=10, filter_fragments=0.1, remove_debris=64)
 import hashlib
 print(f"rank {rank}/{world}: volume sha1 {hashlib.sha1(vol.cpu().numpy().tobytes()).hexdigest()[:12]}", flush=True)
