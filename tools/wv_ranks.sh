@@ -1,7 +1,4 @@
-# Dev tool: one rank vs four ranks that share the card (tools/debug_ranks.py), concurrently and with the predict stages one at a time
-mkdir -p /tmp/dr; export LAYERS=4
-for L in 1 8; do
-  export LANES=$L
-  python tools/debug_ranks.py /tmp/dr 2>&1 | grep sha1 > /dev/null
-  for i in 1 2 3; do echo "-- 4 ranks concurrent, $L lane(s) each, run $i"; python -m torch.distributed.run --nnodes=1 --nproc-per-node 4 --master-addr 127.0.0.1 --master-port 2968$i tools/debug_ranks.py /tmp/dr 2>&1 | grep "affs\|largest"; done
+# Dev tool: bisect which launches are not safe beside another engine of the same process (tools/debug_two_streams.py)
+for cfg in "X=1" "BSMI_WINO=0" "BSMI_WINO=0 BSMI_H16=0 BSMI_FUSED_FIRST=0 BSMI_USE_BOX=0" "BSMI_WINO=0 BSMI_H16=0 BSMI_FUSED_FIRST=0 BSMI_USE_BOX=0 BSMI_SK_GRID=0" "BSMI_WINO=0 BSMI_H16=0 BSMI_FUSED_FIRST=0 BSMI_USE_BOX=0 BSMI_SK_GRID=0 BSMI_WAVES8=0" "BSMI_WINO=0 BSMI_H16=0 BSMI_FUSED_FIRST=0 BSMI_USE_BOX=0 BSMI_SK_GRID=0 BSMI_X3_FUSED=0" "PREC=bf16 BSMI_H16=0 BSMI_FUSED_FIRST=0 BSMI_USE_BOX=0 BSMI_SK_GRID=0 BSMI_USE_RH=0" "PREC=bf16 BSMI_H16=0 BSMI_FUSED_FIRST=0 BSMI_USE_BOX=0 BSMI_SK_GRID=0 BSMI_USE_RH=0 BSMI_WAVES8=0"; do
+  echo "== $cfg"; env $cfg timeout -k 10 120 python tools/debug_two_streams.py 2>&1 | grep "differ\|rror" | tail -2
 done
