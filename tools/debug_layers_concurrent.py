@@ -19,6 +19,9 @@ m0.predict_u8(A); torch.cuda.synchronize()
 prof0 = m0.read_profile()
 nsteps = len([p for p in prof0 if p[0] != 4])
 ref = [m0.debug_activation(s) for s in range(nsteps)]
+ref_u8 = m0.predict_u8(A)[0].clone(); torch.cuda.synchronize()
+if os.environ.get('PROFILE_OFF', '1') == '1':
+    m0.profile(False)
 stop = False
 def burn():
     torch.cuda.set_device(0)
@@ -29,8 +32,9 @@ t = threading.Thread(target=burn); t.start(); time.sleep(1.0)
 s0 = torch.cuda.Stream()
 for trial in range(3):
     with torch.cuda.stream(s0):
-        m0.predict_u8(A); s0.synchronize()
-    prof = m0.read_profile()
+        u = m0.predict_u8(A)[0]; s0.synchronize()
+    print(f'trial {trial}: final u8 differing voxels', int((u != ref_u8).sum()), flush=True)
+    prof = prof0
     first = None
     for s in range(nsteps):
         got = m0.debug_activation(s)
