@@ -424,3 +424,26 @@ int launch_extract_block_reflect(const uint8_t* vol, const int64_t vs[3], const 
 }
 
 }  // namespace bsmi
+
+// ---- development aid: an LDS canary ---------------------------------------------------------------------------------------
+// Workgroups that fill their LDS with a pattern, idle, and check it: run beside an engine on another stream, they tell whether
+// any co-resident kernel writes outside its own LDS allocation (the concurrent-forward defect).
+namespace bsmi {
+__global__ void lds_canary_kernel(int words, int spins, unsigned long long* mismatches) {
+  extern __shared__ uint32_t canary[];
+  const uint32_t tag = 0xC0DE0000u ^ (blockIdx.x * 2654435761u);
+  for (int i = threadIdx.x; i < words; i += blockDim.x) canary[i] = tag + (uint32_t)i;
+  __syncthreads();
+  for (int s = 0; s < spins; ++s) __builtin_amdgcn_s_sleep(127);
+  __syncthreads();
+  unsigned long long bad = 0;
+  for (int i = threadIdx.x; i < words; i += blockDim.x) bad += canary[i] != tag + (uint32_t)i;
+  if (bad) atomicAdd(mismatches, bad);
+}
+}  // namespace bsmi
+
+extern "C" int bsmi_debug_lds_canary(int lds_bytes, int blocks, int spins, unsigned long long* mismatches_dev, void* stream) {
+  if (lds_bytes < 4 || lds_bytes > 64 * 1024 || blocks < 1 || !mismatches_dev) return BSMI_ERR_INVALID;
+  hipLaunchKernelGGL(bsmi::lds_canary_kernel, dim3((unsigned)blocks), dim3(64), (size_t)lds_bytes, (hipStream_t)stream, lds_bytes / 4, spins, mismatches_dev);
+  return hipGetLastError() == hipSuccess ? BSMI_OK : BSMI_ERR_HIP;
+}

@@ -208,6 +208,10 @@ int bsmi_unet_profile_totals(bsmi_unet *h, double ms_by_type[5], double flops_by
  * bsmi_unet_profile_totals says how fast the layer was computed, this one how busy the MFMA units were -- a Winograd stage
  * computes a layer with fewer multiplies than the algorithmic count has. */
 int bsmi_unet_profile_executed(bsmi_unet *h, double *executed_flops, int reset);
+/* Development aid: `blocks` one-wave workgroups that fill `lds_bytes` of LDS with a pattern, idle for `spins` x 127 x 64 clocks
+ * and check it; *mismatches_dev (device uint64, caller-zeroed) counts words that changed.  Run beside an engine on another
+ * stream: does a co-resident kernel write outside its own LDS allocation? */
+int bsmi_debug_lds_canary(int lds_bytes, int blocks, int spins, unsigned long long *mismatches_dev, void *stream);
 
 /* Development aid: the output tensor of launch `step` of the last forward (launch order as in
  * bsmi_unet_profile_read), as float32 channels-last [D][H][W][C] on the host, whatever the precision mode stores
