@@ -239,7 +239,7 @@ def check_edges(gpu_edges, gpu_scores, cpu_edges, cpu_scores, sub, job):
     return blocks, n_edges, bad
 
 
-def drivers_leg(raw_box, sd, precision):
+def drivers_leg(raw_box, sd, precision, model=None, vol=None, origin=(0, 0, 0)):
     """`bs predict` + `bs segment --ws` (blockwise) as a user runs them, on an on-disk Zarr store holding the same box of
     blocks: checkpoint load, chunk decode / encode (Blosc lz4, the zarr default), file reads and writes included.  Outside
     the timed region; `raw_box`: uint8 host array of the job's output extent (the drivers reflect-pad at its faces)."""
@@ -276,6 +276,29 @@ def drivers_leg(raw_box, sd, precision):
         t0 = time.perf_counter()
         run_prediction(pred_toml, "01", precision=precision)
         t_pred = time.perf_counter() - t0
+        # what `bs predict` stored against the engine called directly on the same blocks (the command predicts while its
+        # write-behind threads copy, encode and write the blocks before: nothing of that may show in the data)
+        pred_check = None
+        if model is not None:
+            vol = torch.from_numpy(raw_box).to(torch.device("cuda", model.device))   # the store's extent: the drivers reflect-pad at ITS faces
+            origin = (0, 0, 0)
+            from bootstrapper_amd.unet import extract_block_reflect
+            from bootstrapper_amd.zarr_io import open_ds
+            pds = open_ds(f"{store}/predictions/1/3d_affs")
+            nb = [s // b for s, b in zip(raw_box.shape, OUT_BLOCK)]
+            picks = sorted({(0, 0, 0), (nb[0] - 1, nb[1] - 1, nb[2] - 1), (nb[0] // 2, nb[1] // 2, nb[2] // 2), (0, nb[1] - 1, nb[2] // 2),
+                            (nb[0] - 1, 0, nb[2] - 1), (nb[0] // 2, 0, 0)})
+            in_block = tuple(o + 2 * c for o, c in zip(OUT_BLOCK, CONTEXT))
+            differ = 0
+            for b in picks:
+                off = [origin[d] + b[d] * OUT_BLOCK[d] - CONTEXT[d] for d in range(3)]
+                want = model.predict_u8(extract_block_reflect(vol, off, in_block))[0].cpu().numpy()
+                got = pds[(slice(None),) + tuple(slice(b[d] * OUT_BLOCK[d], (b[d] + 1) * OUT_BLOCK[d]) for d in range(3))]
+                differ += not np.array_equal(got, want)
+            pred_check = {"blocks_compared": len(picks), "blocks_differing": differ,
+                          "what": "the prediction dataset `bs predict` wrote against the engine called on the same blocks: all six channels, bit for bit"}
+            if differ:
+                raise SystemExit(f"parity (drivers): {differ} of {len(picks)} sampled blocks of the prediction dataset differ from the engine's own prediction")
         t0 = time.perf_counter()
         written = run_segmentation(seg_toml, "ws")
         t_seg = time.perf_counter() - t0
@@ -302,7 +325,7 @@ def drivers_leg(raw_box, sd, precision):
                 "blocks": int(nvox // int(np.prod(OUT_BLOCK))), "predict_seconds": t_pred, "segment_seconds": t_seg, "filter_seconds": t_filter,
                 "Mvoxels_per_s": nvox / (t_pred + t_seg) / 1e6, "predict_Mvoxels_per_s": nvox / t_pred / 1e6,
                 "segment_Mvoxels_per_s": nvox / t_seg / 1e6, "round_Mvoxels_per_s": nvox / (t_pred + t_seg + t_filter) / 1e6,
-                "datasets_written": len(written) + 1 + (1 if filtered else 0), "filter_error": filter_error,
+                "datasets_written": len(written) + 1 + (1 if filtered else 0), "filter_error": filter_error, "prediction_check": pred_check,
                 "store_bytes": du(store), "tmp_dir": os.path.dirname(tmp) or tmp}
     finally:
         shutil.rmtree(tmp, ignore_errors=True)
@@ -767,7 +790,7 @@ def main():
         pipe = segs = None
         torch.cuda.empty_cache()
         try:
-            out["drivers"] = drivers_leg(box, sd, args.precision)
+            out["drivers"] = drivers_leg(box, sd, args.precision, model, vol, (0, 0, 0) if whole else pipe_origin)
         except Exception as exc:  # noqa: BLE001
             import traceback
             out["drivers"] = {"error": f"{type(exc).__name__}: {exc}", "traceback": traceback.format_exc()[-1500:], "Mvoxels_per_s": 0.0}

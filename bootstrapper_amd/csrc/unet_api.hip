@@ -14,6 +14,7 @@
 #include <cstring>
 #include <map>
 #include <memory>
+#include <mutex>
 #include <vector>
 #include <chrono>
 #include <thread>
@@ -1349,6 +1350,36 @@ static int harvest(bsmi_unet* h, Plan* plan) {
   return BSMI_OK;
 }
 
+// One forward pass in flight per GPU and process.  Two forward passes of the bf16-family engine that overlap on one GPU -- two
+// handles on two streams -- corrupt each other's results (up to 40 levels of the u8 affinities in nearly every
+// prediction; mechanism not established; one pass at a time is bit-reproducible).  Nothing in this repository overlaps them, but a
+// caller with two Model instances could: a forward on another stream than the previous one first waits, on the device, for that
+// one's last launch (an event recorded at the end of every forward).  Passes on ONE stream are ordered anyway and pay nothing but
+// the event record.  Other PROCESSES on the same GPU cannot be chained this way: one predicting process per GPU.
+namespace {
+std::mutex g_chain_mu;
+struct ChainState { hipEvent_t done = nullptr; hipStream_t last = nullptr; bool any = false; };
+ChainState g_chain[16];
+}  // namespace
+struct ForwardChain {
+  std::unique_lock<std::mutex> lock{g_chain_mu};
+};
+static int forward_chain_enter(int device, hipStream_t s) {
+  if (device < 0 || device >= 16) return BSMI_OK;
+  ChainState& c = g_chain[device];
+  if (c.any && c.last != s) BSMI_HIP(hipStreamWaitEvent(s, c.done, 0));
+  return BSMI_OK;
+}
+static int forward_chain_leave(int device, hipStream_t s) {
+  if (device < 0 || device >= 16) return BSMI_OK;
+  ChainState& c = g_chain[device];
+  if (!c.done) BSMI_HIP(hipEventCreateWithFlags(&c.done, hipEventDisableTiming));
+  BSMI_HIP(hipEventRecord(c.done, s));
+  c.last = s;
+  c.any = true;
+  return BSMI_OK;
+}
+
 // The first ConvPass can run as one launch (first_pass.hip): one raw channel, two 3x3x3 convs, at most 16 feature maps.
 static bool first_pass_eligible(const bsmi_unet* h) {
   if (h->cfg.in_channels != 1 || h->l_conv.empty()) return false;
@@ -1675,6 +1706,8 @@ int bsmi_unet_forward(bsmi_unet* h, int precision, const void* raw_dev, int raw_
   if (rc) return rc;
   BSMI_HIP(hipSetDevice(h->device));
   hipStream_t s = (hipStream_t)stream;
+  ForwardChain chain_guard;   // (holds the process-wide lock of the chain until the launches are queued)
+  if ((rc = forward_chain_enter(h->device, s))) return rc;
   Plan* plan_ptr = nullptr;
   rc = get_plan(h, precision, in_shape, &plan_ptr);
   if (rc) return rc;
@@ -1780,7 +1813,7 @@ int bsmi_unet_forward(bsmi_unet* h, int precision, const void* raw_dev, int raw_
     ++step_idx;
   }
   if (prof) plan.inflight.push_back(std::move(plan.events));
-  return BSMI_OK;
+  return forward_chain_leave(h->device, s);
 }
 
 int bsmi_unet_debug_activation(bsmi_unet* h, int step, int what, int64_t shape_out[4], float* host_out, uint64_t capacity) {
