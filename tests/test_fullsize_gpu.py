@@ -260,3 +260,34 @@ def test_cremi_single_block_96_predict_and_segment():
     assert int(mx.item()) == ref_max and np.array_equal(frags.cpu().numpy().astype(np.uint64), ref_frags)
     for t, r in enumerate(S.agglomerate_mean_u8(a, ref_frags, [0.2, 0.35, 0.5])):
         assert np.array_equal(segs[t].cpu().numpy().astype(np.uint64), r)
+
+
+def test_two_engines_of_one_process_side_by_side():
+    """Two handles predicting on two streams at the same time (round 4, DESIGN.md section 5: overlapping forward passes of the
+    bf16-family engine corrupted each other in nearly every prediction): every forward waits for the previous one of the process
+    on that GPU (`forward_chain_enter`), so each prediction is what it is alone, bit for bit."""
+    import threading
+    from bootstrapper_amd.unet import Model
+    from bootstrapper_amd.synth import synthetic_state_dict, synthetic_volume
+    from tests.test_lib_cpu import AFFS_NET_CONFIG as NC
+    sd = synthetic_state_dict(NC, 0)
+    models = [Model(NC, precision="bf16x3").load_state_dict(sd) for _ in range(2)]
+    raw = synthetic_volume((156, 220, 220), 0)
+    torch.cuda.synchronize()
+    ref = models[0].predict_u8(raw)[0].clone()
+    torch.cuda.synchronize()
+    assert torch.equal(ref, models[1].predict_u8(raw)[0])
+    streams = [torch.cuda.Stream() for _ in models]
+    bad = [0, 0]
+
+    def work(i):
+        torch.cuda.set_device(0)
+        with torch.cuda.stream(streams[i]):
+            for _ in range(40):
+                u = models[i].predict_u8(raw)[0]
+                streams[i].synchronize()
+                bad[i] += not torch.equal(u, ref)
+    threads = [threading.Thread(target=work, args=(i,)) for i in range(2)]
+    [t.start() for t in threads]
+    [t.join() for t in threads]
+    assert bad == [0, 0], bad
