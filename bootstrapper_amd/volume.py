@@ -821,14 +821,6 @@ class VolumePipeline:
                                  remove_debris, 256, n_lanes if segment else 1, device, rank, world, group, obj_group=obj_group)
         self.segment = bool(segment)
         self.overlap = bool(overlap)
-        if self.overlap and getattr(model, "precision", None) != _lib.PREC_F32:
-            # Kernels that run beside a bf16-family forward pass on the same GPU are not safe (overlapping
-            # forward passes corrupt each other, and an f32 engine beside a bf16x3 one is corrupted too): the lanes would flood
-            # and merge while the next blocks are predicted.  Stage by stage instead; `overlap` stays for the f32 mode.
-            import warnings
-            warnings.warn("VolumePipeline(overlap=True) with a bf16 / bf16x3 model: segmentation kernels beside the forward passes are not "
-                          "safe on this engine (DESIGN.md section 5); running stage by stage", RuntimeWarning, stacklevel=2)
-            self.overlap = False
         self.t_predict = 0.0
 
     def predict(self, volume_u8):
