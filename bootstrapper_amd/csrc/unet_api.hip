@@ -1364,14 +1364,18 @@ ChainState g_chain[16];
 struct ForwardChain {
   std::unique_lock<std::mutex> lock{g_chain_mu};
 };
+static bool forward_chain_on() {   // BSMI_FORWARD_CHAIN=0: off (dev: the reproducers of the defect)
+  static const bool on = [] { const char* e = getenv("BSMI_FORWARD_CHAIN"); return !(e && e[0] == '0'); }();
+  return on;
+}
 static int forward_chain_enter(int device, hipStream_t s) {
-  if (device < 0 || device >= 16) return BSMI_OK;
+  if (device < 0 || device >= 16 || !forward_chain_on()) return BSMI_OK;
   ChainState& c = g_chain[device];
   if (c.any && c.last != s) BSMI_HIP(hipStreamWaitEvent(s, c.done, 0));
   return BSMI_OK;
 }
 static int forward_chain_leave(int device, hipStream_t s) {
-  if (device < 0 || device >= 16) return BSMI_OK;
+  if (device < 0 || device >= 16 || !forward_chain_on()) return BSMI_OK;
   ChainState& c = g_chain[device];
   if (!c.done) BSMI_HIP(hipEventCreateWithFlags(&c.done, hipEventDisableTiming));
   BSMI_HIP(hipEventRecord(c.done, s));
