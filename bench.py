@@ -675,6 +675,11 @@ def main():
                      # products per product of the split mode) against the DENSE peak of the pipe: a Winograd stage computes its layer
                      # with 2.25x (F(2x2)) or 4x (F(4x4)) fewer multiplies than `achieved` counts, so `frac` can pass what the pipe could
                      # do on the direct form; this figure cannot
+                     "frac_note": ("frac = algorithmic TFLOP/s of the DIRECT convolution / (dense bf16 MFMA peak / 3), the ceiling of the split-bf16 direct form; "
+                                   "the Winograd F(4x4) stages compute their layers with a quarter of the multiplies, so frac may pass 1: the pipe's own "
+                                   "utilisation is executed_mfma_frac, and frac_of_dense_peak prices the same algorithmic rate against the hardware's 2500 TFLOP/s"
+                                   if args.precision == "bf16x3" else "frac = algorithmic TFLOP/s of the direct convolution / dense MFMA peak of the dtype"),
+                     "frac_of_dense_peak": achieved / (BF16_DENSE_PEAK_TFLOPS if args.precision != "f32" else MFMA_PEAK_TFLOPS["f32"]),
                      "executed_tflops": executed_flops / (conv_ms * 1e-3) / 1e12 if conv_ms > 0 else 0.0,
                      "executed_mfma_frac": (executed_flops / (conv_ms * 1e-3) / 1e12 / (BF16_DENSE_PEAK_TFLOPS if args.precision != "f32" else MFMA_PEAK_TFLOPS["f32"])) if conv_ms > 0 else 0.0,
                      "mfma_busy_pmc": pmc_mfma_busy(args.precision),
