@@ -1246,7 +1246,9 @@ TileCfg choose_tile(int cout) {
 
 template <typename T, int BM, int BN, int WM, int WN, int MS = 32, int CUT = 0>
 static int launch_one(const ConvArgs& a, hipStream_t stream, float* sk_ws, int sk_grid) {
-  constexpr int smem = 4 * (BM + BN) * kStepRowBytes;
+  constexpr int smem_need = 4 * (BM + BN) * kStepRowBytes;
+  // BSMI_LDS_PAD_KB (dev): every launch asks for at least this much LDS, e.g. 84: no two of these workgroups share a CU
+  static const int smem = [] { const char* e = getenv("BSMI_LDS_PAD_KB"); const int pad = e ? atoi(e) * 1024 : 0; return pad > smem_need ? std::min(pad, 160 * 1024) : smem_need; }();
   static DeviceOnce once;
   static bool sk_ok = true;
   auto kern = conv_igemm_kernel<T, BM, BN, WM, WN, MS, CUT>;
@@ -1276,7 +1278,7 @@ static int launch_one(const ConvArgs& a, hipStream_t stream, float* sk_ws, int s
   // 5.01 rounds of 512, and the five tiles of the sixth had a tenth of the launch to themselves: 2.62 -> 2.51 ms in the
   // persistent form; with a last round that is more than half full the plain launch is as fast or faster (60 -> 60: 0.54 / 0.57)
   static const bool sk64 = [] { const char* e = getenv("BSMI_X3_SK64"); return !(e && e[0] == '0'); }();
-  const bool two_per_cu = IsFused<T>::value && BN == 64 && 2 * smem <= 160 * 1024 && sk64;
+  const bool two_per_cu = IsFused<T>::value && BN == 64 && 2 * smem <= 160 * 1024 && sk64;  // (smem: with a dev pad, one per CU)
   const int grid_sk = two_per_cu ? 2 * sk_grid : sk_grid;
   const int rounds = ceil_div(ntiles, grid_sk > 0 ? grid_sk : 1);
   const bool thin_tail = grid_sk > 0 && 2 * (ntiles % grid_sk) < grid_sk;
