@@ -9,7 +9,11 @@ from bootstrapper_amd.synth import synthetic_state_dict, synthetic_volume
 prec = os.environ.get("PREC", "bf16x3")
 N = int(os.environ.get("ENGINES", "2"))
 sd = synthetic_state_dict(bench.NET_CONFIG, 0)
-models = [Model(bench.NET_CONFIG, device=0, precision=prec).load_state_dict(sd) for _ in range(N)]
+models = []; spacers = []
+for _ in range(N):
+    models.append(Model(bench.NET_CONFIG, device=0, precision=prec).load_state_dict(sd))
+    if os.environ.get("SPACER_MB"): spacers.append(torch.zeros(int(os.environ["SPACER_MB"]) << 20, dtype=torch.uint8, device="cuda:0"))
+ACTIVE = [int(x) for x in os.environ.get("ACTIVE", ",".join(map(str, range(N)))).split(",")]
 vol = synthetic_volume((256, 256, 256), seed=0, device=torch.device("cuda", 0))
 A = extract_block_reflect(vol, [10, 20, 30], (156, 220, 220))
 torch.cuda.synchronize()
@@ -29,6 +33,6 @@ def work(i):
             d = (u.int() - refs[0].int()).abs().max().item()
             cnt[i] += 1
             if d: bad[i] += 1; worst[i] = max(worst[i], d)
-th = [threading.Thread(target=work, args=(i,)) for i in range(N)]
+th = [threading.Thread(target=work, args=(i,)) for i in ACTIVE]
 [t.start() for t in th]; [t.join() for t in th]
 print(f"{prec}, {N} engines of one process side by side: {bad} of {cnt} predictions differ (largest u8 difference {worst})", flush=True)
