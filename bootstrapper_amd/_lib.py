@@ -130,6 +130,7 @@ def _load():
         "bsmi_unet_set_persistent_grid": (i32, [p, C.c_int]),
         "bsmi_unet_profile_executed": (i32, [p, C.POINTER(C.c_double), C.c_int]),
         "bsmi_debug_lds_canary": (i32, [i32, i32, i32, vp, vp]),
+        "bsmi_debug_check_guards": (i32, []),
         "bsmi_stream_create_cu_mask": (i32, [C.c_int, vp, C.c_int, C.POINTER(C.c_void_p)]),
         "bsmi_stream_destroy": (i32, [C.c_int, vp]),
         # include/bsmi_io.h

@@ -26,6 +26,8 @@
 #include <cstring>
 #include <vector>
 
+#include "dev_guard.h"  // last: routes hipMalloc / hipFree through the guarded allocator (BSMI_GUARD_MB)
+
 namespace bsmi {
 
 typedef short bf16x8_t __attribute__((ext_vector_type(8)));

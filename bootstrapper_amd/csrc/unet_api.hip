@@ -22,6 +22,8 @@
 #include "unet_internal.h"
 #include "unet_ops.h"
 
+#include "dev_guard.h"  // last: routes hipMalloc / hipFree through the guarded allocator (BSMI_GUARD_MB)
+
 namespace bsmi {
 
 static thread_local std::string g_err;

@@ -16,6 +16,8 @@
 
 #include <cstring>
 
+#include "dev_guard.h"  // last: routes hipMalloc / hipFree through the guarded allocator (BSMI_GUARD_MB)
+
 namespace bsmi {
 
 typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
