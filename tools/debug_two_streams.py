@@ -12,7 +12,10 @@ sd = synthetic_state_dict(bench.NET_CONFIG, 0)
 models = []; spacers = []
 for _ in range(N):
     models.append(Model(bench.NET_CONFIG, device=0, precision=prec).load_state_dict(sd))
-    if os.environ.get("SPACER_MB"): spacers.append(torch.zeros(int(os.environ["SPACER_MB"]) << 20, dtype=torch.uint8, device="cuda:0"))
+    if os.environ.get("SPACER_MB") and not os.environ.get("SPACER_AFTER"): spacers.append(torch.zeros(int(os.environ["SPACER_MB"]) << 20, dtype=torch.uint8, device="cuda:0"))
+if os.environ.get("SPACER_AFTER"): spacers.append(torch.zeros(int(os.environ["SPACER_MB"]) << 20, dtype=torch.uint8, device="cuda:0"))
+if os.environ.get("SPACER_FREE"):
+    spacers.clear(); torch.cuda.empty_cache()
 ACTIVE = [int(x) for x in os.environ.get("ACTIVE", ",".join(map(str, range(N)))).split(",")]
 vol = synthetic_volume((256, 256, 256), seed=0, device=torch.device("cuda", 0))
 A = extract_block_reflect(vol, [10, 20, 30], (156, 220, 220))
