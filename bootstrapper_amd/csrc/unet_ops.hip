@@ -345,25 +345,37 @@ int launch_upsample_crop(int precision, const void* in, void* out, int D, int H,
 // ---- sigmoid head: ConvPass(C, dims, [[1,1,1]], "Sigmoid") ----------------------------
 // reference model.py:54-56 + unet.py:63-76: sigmoid((W1 z + b1) + (W2 z + b2)); f32 math.
 // hw: [cout][2][cin] (conv_pass.0 then residual.0), hb: [cout][2].
-template <typename T, bool SP = false>
-__global__ void head_kernel(const T* z, int cpad, int cin, int cout, const float* hw, const float* hb,
-                            float* out_f32, uint8_t* out_u8, size_t nvox) {
-  extern __shared__ float sw[];
-  float* sb = sw + cout * 2 * cin;
-  for (int i = threadIdx.x; i < cout * 2 * cin; i += blockDim.x) sw[i] = hw[i];
+// No private array with a run-time index: the thread's CPAD input channels stay in registers (the loops over channels are
+// unrolled at compile time, the head's real channel count only masks them).  The earlier form kept them in scratch memory,
+// and a kernel with a scratch segment is what two forward passes side by side on one card corrupted.
+template <typename T, bool SP, int CPAD>
+__global__ void __launch_bounds__(256) head_kernel(const T* z, int cin, int cout, const float* hw, const float* hb,
+                                                   float* out_f32, uint8_t* out_u8, size_t nvox) {
+  extern __shared__ float sw[];  // [cout][2][CPAD], zero beyond cin; then [cout][2] biases
+  float* sb = sw + cout * 2 * CPAD;
+  for (int i = threadIdx.x; i < cout * 2 * CPAD; i += blockDim.x) {
+    const int c = i % CPAD;
+    sw[i] = c < cin ? hw[(i / CPAD) * cin + c] : 0.f;
+  }
   for (int i = threadIdx.x; i < cout * 2; i += blockDim.x) sb[i] = hb[i];
   __syncthreads();
   const size_t v = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (v >= nvox) return;
-  float f[64];
   constexpr int N = Vec<T>::N;
-  for (int c = 0; c < cpad && c < 64; c += N) load_vec<T, SP>(z, v * cpad + c, f + c);
+  static_assert(CPAD % N == 0, "channel padding is a multiple of the vector width");
+  float f[CPAD];
+#pragma unroll
+  for (int c = 0; c < CPAD; c += N) load_vec<T, SP>(z, v * CPAD + c, f + c);
   for (int o = 0; o < cout; ++o) {
+    const float* w1 = sw + (o * 2 + 0) * CPAD;
+    const float* w2 = sw + (o * 2 + 1) * CPAD;
     float s1 = 0.f, s2 = 0.f;
-    for (int c = 0; c < cin; ++c) {
-      s1 = fmaf(sw[(o * 2 + 0) * cin + c], f[c], s1);
-      s2 = fmaf(sw[(o * 2 + 1) * cin + c], f[c], s2);
-    }
+#pragma unroll
+    for (int c = 0; c < CPAD; ++c)
+      if (c < cin) {  // uniform; keeps the sums those of the cin real channels, in order
+        s1 = fmaf(w1[c], f[c], s1);
+        s2 = fmaf(w2[c], f[c], s2);
+      }
     const float y = (s1 + sb[o * 2]) + (s2 + sb[o * 2 + 1]);
     const float sg = 1.0f / (1.0f + expf(-y));
     if (out_f32) out_f32[(size_t)o * nvox + v] = sg;
@@ -372,21 +384,31 @@ __global__ void head_kernel(const T* z, int cpad, int cin, int cout, const float
   }
 }
 
+template <typename T, bool SP>
+static int launch_head_t(const T* z, int cpad, int cin, int cout, const float* hw, const float* hb, float* out_f32, uint8_t* out_u8,
+                         size_t nvox, hipStream_t s) {
+  const int bs = 256;
+  const size_t smem = (size_t)(cout * 2 * cpad + cout * 2) * sizeof(float);
+  const unsigned grid = (unsigned)ceil_div64((int64_t)nvox, bs);
+  switch (cpad) {
+#define BSMI_HEAD_CASE(CP)                                                                                                       \
+  case CP:                                                                                                                       \
+    hipLaunchKernelGGL((head_kernel<T, SP, CP>), dim3(grid), dim3(bs), smem, s, z, cin, cout, hw, hb, out_f32, out_u8, nvox);     \
+    break;
+    BSMI_HEAD_CASE(16) BSMI_HEAD_CASE(32) BSMI_HEAD_CASE(48) BSMI_HEAD_CASE(64)  // multiples of kChanPad
+#undef BSMI_HEAD_CASE
+    default: BSMI_FAIL(BSMI_ERR_INVALID, "head kernel: %d padded input channels (a multiple of 16 up to 64 expected)", cpad);
+  }
+  BSMI_HIP(hipGetLastError());
+  return BSMI_OK;
+}
+
 int launch_head(int precision, const void* z, int cpad, int cin, int cout, const float* hw,
                 const float* hb, float* out_f32, uint8_t* out_u8, size_t nvox, hipStream_t s) {
   if (cpad > 64) BSMI_FAIL(BSMI_ERR_INVALID, "head kernel supports at most 64 input channels (got %d)", cpad);
-  const int bs = 256;
-  const size_t smem = (size_t)(cout * 2 * cin + cout * 2) * sizeof(float);
-  const unsigned grid = (unsigned)ceil_div64((int64_t)nvox, bs);
-  if (precision == BSMI_PREC_F32)
-    hipLaunchKernelGGL(head_kernel<float>, dim3(grid), dim3(bs), smem, s, (const float*)z, cpad, cin, cout, hw, hb, out_f32, out_u8, nvox);
-  else if (precision == BSMI_PREC_BF16X3)
-    hipLaunchKernelGGL((head_kernel<uint16_t, true>), dim3(grid), dim3(bs), smem, s, (const uint16_t*)z, cpad, cin, cout, hw, hb, out_f32,
-                       out_u8, nvox);
-  else
-    hipLaunchKernelGGL(head_kernel<uint16_t>, dim3(grid), dim3(bs), smem, s, (const uint16_t*)z, cpad, cin, cout, hw, hb, out_f32, out_u8, nvox);
-  BSMI_HIP(hipGetLastError());
-  return BSMI_OK;
+  if (precision == BSMI_PREC_F32) return launch_head_t<float, false>((const float*)z, cpad, cin, cout, hw, hb, out_f32, out_u8, nvox, s);
+  if (precision == BSMI_PREC_BF16X3) return launch_head_t<uint16_t, true>((const uint16_t*)z, cpad, cin, cout, hw, hb, out_f32, out_u8, nvox, s);
+  return launch_head_t<uint16_t, false>((const uint16_t*)z, cpad, cin, cout, hw, hb, out_f32, out_u8, nvox, s);
 }
 
 // ---- reflect-padded block read ---------------------------------------------------------
