@@ -446,32 +446,42 @@ static int launch_rh_one(const RhArgs& a, hipStream_t stream, float* sk_ws, int 
   constexpr int smem = 2 * HP * kRhNW * 16 * kStepRowBytes + 4 * BN * kStepRowBytes;
   static_assert(smem <= 160 * 1024 - 64, "LDS budget");
   static DeviceOnce once;
-  static bool sk_ok = true;
+  // the persistent form of the 320-column tile needs more registers than a wave has (it spilled, and was refused below at
+  // run time): it is not compiled at all -- no kernel of the library carries a scratch segment (tests/test_kernel_resources.py)
+  constexpr bool has_sk = BN >= 256 && BN < 320;
+  static bool sk_ok = has_sk;
   auto kern = conv_rh_kernel<T, BN, WM, WN, HP>;
-  auto kern_sk = conv_rh_sk_kernel<T, BN, WM, WN, HP>;
+  using SkFn = decltype(&conv_rh_sk_kernel<T, BN, WM, WN, HP>);
+  SkFn kern_sk = nullptr;
+  if constexpr (has_sk) kern_sk = conv_rh_sk_kernel<T, BN, WM, WN, HP>;
   const int rc_once = once.run([&]() -> int {
     BSMI_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
-    BSMI_HIP(hipFuncSetAttribute((const void*)kern_sk, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
     hipFuncAttributes fa;  // scratch traffic would break the counted vmcnt waits (see conv_igemm.hip)
     BSMI_HIP(hipFuncGetAttributes(&fa, (const void*)kern));
     if (fa.localSizeBytes != 0)
       BSMI_FAIL(BSMI_ERR_STATE, "raster-halo conv kernel BN=%d was compiled with %zu bytes of scratch: counted vmcnt waits are unsafe", BN,
                 (size_t)fa.localSizeBytes);
-    BSMI_HIP(hipFuncGetAttributes(&fa, (const void*)kern_sk));
-    sk_ok = fa.localSizeBytes == 0;
+    if constexpr (has_sk) {
+      BSMI_HIP(hipFuncSetAttribute((const void*)kern_sk, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
+      BSMI_HIP(hipFuncGetAttributes(&fa, (const void*)kern_sk));
+      sk_ok = fa.localSizeBytes == 0;
+    }
     return BSMI_OK;
   });
   if (rc_once) return rc_once;
   const int ntiles = ceil_div(a.Q, 256) * (a.Npad / BN);
   const int rounds = ceil_div(ntiles, sk_grid > 0 ? sk_grid : 1);
-  if (sk_ws && sk_ok && sk_grid >= 8 && BN >= 256 && ntiles % sk_grid != 0 && rounds <= 16 && (size_t)256 * BN <= kStreamKTileElems) {
-    int* counters = (int*)(sk_ws + (size_t)sk_grid * kStreamKTileElems);
-    hipLaunchKernelGGL(kern_sk, dim3(sk_grid), dim3(64 * kRhNW), smem, stream, a, sk_ws, counters);
-    hipLaunchKernelGGL((conv_rh_fixup_kernel<T, BN, WM, WN>), dim3(sk_grid / 8, 8, (256 / WM / 32) * (BN / WN / 32)), dim3(64 * kRhNW),
-                       0, stream, a, (const float*)sk_ws, sk_grid, counters);
-  } else {
-    hipLaunchKernelGGL(kern, dim3(ntiles), dim3(64 * kRhNW), smem, stream, a);
+  bool persistent = false;
+  if constexpr (has_sk) {
+    if (sk_ws && sk_ok && sk_grid >= 8 && ntiles % sk_grid != 0 && rounds <= 16 && (size_t)256 * BN <= kStreamKTileElems) {
+      int* counters = (int*)(sk_ws + (size_t)sk_grid * kStreamKTileElems);
+      hipLaunchKernelGGL(kern_sk, dim3(sk_grid), dim3(64 * kRhNW), smem, stream, a, sk_ws, counters);
+      hipLaunchKernelGGL((conv_rh_fixup_kernel<T, BN, WM, WN>), dim3(sk_grid / 8, 8, (256 / WM / 32) * (BN / WN / 32)), dim3(64 * kRhNW),
+                         0, stream, a, (const float*)sk_ws, sk_grid, counters);
+      persistent = true;
+    }
   }
+  if (!persistent) hipLaunchKernelGGL(kern, dim3(ntiles), dim3(64 * kRhNW), smem, stream, a);
   BSMI_HIP(hipGetLastError());
   return BSMI_OK;
 }

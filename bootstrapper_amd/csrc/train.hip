@@ -117,11 +117,13 @@ __global__ __launch_bounds__(256) void pack_weights_x3_t_kernel(const float* __r
   const int tid = threadIdx.x;
   const int nt = NT ? NT : ugw / 2;
   const int u0 = blockIdx.x * ugw, n0 = blockIdx.y * PK_NB;
-  for (int i = tid; i < ugw; i += 256) {
-    PackUnit pu{};
-    pu.wbase = -1;
-    if (u0 + i < nunits) pu = units[u0 + i];
-    su[i] = pu;
+  for (int i = tid; i < ugw; i += 256) {  // (straight into LDS: a local copy of the struct was a scratch segment)
+    if (u0 + i < nunits) {
+      su[i] = units[u0 + i];
+    } else {
+      su[i] = PackUnit{};
+      su[i].wbase = -1;
+    }
   }
   __syncthreads();
   const int per_n = 32 * nt;

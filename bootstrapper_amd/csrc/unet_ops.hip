@@ -384,12 +384,49 @@ __global__ void __launch_bounds__(256) head_kernel(const T* z, int cin, int cout
   }
 }
 
+#ifdef BSMI_HEAD_SCRATCH
+// Dev build only (make CXXFLAGS_EXTRA=-DBSMI_HEAD_SCRATCH OUT=../libbsmi_headscratch.so BUILD=build_hs): the head kernel as it was
+// until round 4, its channels in a private array with a run-time index = a 272-byte scratch segment per lane.  This is the
+// reproducer of the concurrent-forward defect (tools/debug_two_streams.py with BSMI_LIB pointing at that build).
+template <typename T, bool SP>
+__global__ void head_scratch_kernel(const T* z, int cpad, int cin, int cout, const float* hw, const float* hb, float* out_f32, uint8_t* out_u8,
+                                    size_t nvox) {
+  extern __shared__ float sw[];
+  float* sb = sw + cout * 2 * cin;
+  for (int i = threadIdx.x; i < cout * 2 * cin; i += blockDim.x) sw[i] = hw[i];
+  for (int i = threadIdx.x; i < cout * 2; i += blockDim.x) sb[i] = hb[i];
+  __syncthreads();
+  const size_t v = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (v >= nvox) return;
+  float f[64];
+  constexpr int N = Vec<T>::N;
+  for (int c = 0; c < cpad && c < 64; c += N) load_vec<T, SP>(z, v * cpad + c, f + c);
+  for (int o = 0; o < cout; ++o) {
+    float s1 = 0.f, s2 = 0.f;
+    for (int c = 0; c < cin; ++c) {
+      s1 = fmaf(sw[(o * 2 + 0) * cin + c], f[c], s1);
+      s2 = fmaf(sw[(o * 2 + 1) * cin + c], f[c], s2);
+    }
+    const float y = (s1 + sb[o * 2]) + (s2 + sb[o * 2 + 1]);
+    const float sg = 1.0f / (1.0f + expf(-y));
+    if (out_f32) out_f32[(size_t)o * nvox + v] = sg;
+    if (out_u8) out_u8[(size_t)o * nvox + v] = (uint8_t)(sg * 255.0f);
+  }
+}
+#endif
+
 template <typename T, bool SP>
 static int launch_head_t(const T* z, int cpad, int cin, int cout, const float* hw, const float* hb, float* out_f32, uint8_t* out_u8,
                          size_t nvox, hipStream_t s) {
   const int bs = 256;
   const size_t smem = (size_t)(cout * 2 * cpad + cout * 2) * sizeof(float);
   const unsigned grid = (unsigned)ceil_div64((int64_t)nvox, bs);
+#ifdef BSMI_HEAD_SCRATCH
+  hipLaunchKernelGGL((head_scratch_kernel<T, SP>), dim3(grid), dim3(bs), (size_t)(cout * 2 * cin + cout * 2) * sizeof(float), s, z, cpad, cin, cout,
+                     hw, hb, out_f32, out_u8, nvox);
+  BSMI_HIP(hipGetLastError());
+  return BSMI_OK;
+#endif
   switch (cpad) {
 #define BSMI_HEAD_CASE(CP)                                                                                                       \
   case CP:                                                                                                                       \

@@ -782,6 +782,9 @@ struct WinoPackDev {
   size_t image_elems, batch_elems;
   int cout, cin, Npad, nunits, T;
 };
+// T (4 or 6) is a compile-time constant: t[][] and the rows of G are indexed by unrolled loops only and stay in registers.
+// (With T read from the arguments they lived in a 160-byte scratch segment; no kernel of the network engine has one now.)
+template <int T>
 __global__ __launch_bounds__(256) void wino_pack_kernel(const WinoPackDev a) {
 #pragma clang fp contract(off)
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -800,17 +803,20 @@ __global__ __launch_bounds__(256) void wino_pack_kernel(const WinoPackDev a) {
   double gd[9];
 #pragma unroll
   for (int k = 0; k < 9; ++k) gd[k] = (double)g[k];
-  const double aa = 0.70710678118654752440, bb = 1.41421356237309504880;
-  const double G4[6][3] = {{1, 0, 0}, {2. / 3, 2. / 3 * aa, 1. / 3}, {2. / 3, -2. / 3 * aa, 1. / 3}, {1. / 12, bb / 12, 1. / 6}, {1. / 12, -bb / 12, 1. / 6}, {0, 0, 1}};
-  const double G2[4][3] = {{1, 0, 0}, {.5, .5, .5}, {.5, -.5, .5}, {0, 0, 1}};
-  const int T = a.T;
-  double t[6][3];
+  constexpr double aa = 0.70710678118654752440, bb = 1.41421356237309504880;
+  constexpr double G4[6][3] = {{1, 0, 0}, {2. / 3, 2. / 3 * aa, 1. / 3}, {2. / 3, -2. / 3 * aa, 1. / 3}, {1. / 12, bb / 12, 1. / 6}, {1. / 12, -bb / 12, 1. / 6}, {0, 0, 1}};
+  constexpr double G2[6][3] = {{1, 0, 0}, {.5, .5, .5}, {.5, -.5, .5}, {0, 0, 1}, {0, 0, 0}, {0, 0, 0}};
+  double t[T][3];
+#pragma unroll
   for (int xi = 0; xi < T; ++xi)
+#pragma unroll
     for (int kx = 0; kx < 3; ++kx) {
       const double g0 = T == 6 ? G4[xi][0] : G2[xi][0], g1 = T == 6 ? G4[xi][1] : G2[xi][1], g2 = T == 6 ? G4[xi][2] : G2[xi][2];
       t[xi][kx] = g0 * gd[kx] + g1 * gd[3 + kx] + g2 * gd[6 + kx];
     }
+#pragma unroll
   for (int xi = 0; xi < T; ++xi)
+#pragma unroll
     for (int nu = 0; nu < T; ++nu) {
       const double g0 = T == 6 ? G4[nu][0] : G2[nu][0], g1 = T == 6 ? G4[nu][1] : G2[nu][1], g2 = T == 6 ? G4[nu][2] : G2[nu][2];
       const float v = (float)(t[xi][0] * g0 + t[xi][1] * g1 + t[xi][2] * g2);
@@ -847,7 +853,8 @@ int wino_pack_weights_dev(const float* w, int cout, int cin, const std::vector<i
     a.w = wd; a.cin_of_v = meta; a.unit_kz = meta + o_kz; a.unit_vc0 = meta + o_vc; a.image = image;
     a.image_elems = image_elems; a.batch_elems = batch_elems; a.cout = cout; a.cin = cin; a.Npad = Npad; a.nunits = (int)units.size(); a.T = T;
     const size_t total = nsteps * (size_t)cout * 32;
-    hipLaunchKernelGGL(wino_pack_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, nullptr, a);
+    if (T == 6) hipLaunchKernelGGL(wino_pack_kernel<6>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, nullptr, a);
+    else hipLaunchKernelGGL(wino_pack_kernel<4>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, nullptr, a);
     err = hipGetLastError();
     if (err == hipSuccess) err = hipDeviceSynchronize();
   }
