@@ -1352,12 +1352,12 @@ static int harvest(bsmi_unet* h, Plan* plan) {
   return BSMI_OK;
 }
 
-// One forward pass in flight per GPU and process.  Two forward passes of the bf16-family engine that overlap on one GPU -- two
-// handles on two streams -- corrupt each other's results (up to 40 levels of the u8 affinities in nearly every
-// prediction; mechanism not established; one pass at a time is bit-reproducible).  Nothing in this repository overlaps them, but a
-// caller with two Model instances could: a forward on another stream than the previous one first waits, on the device, for that
-// one's last launch (an event recorded at the end of every forward).  Passes on ONE stream are ordered anyway and pay nothing but
-// the event record.  Other PROCESSES on the same GPU cannot be chained this way: one predicting process per GPU.
+// Opt-in (BSMI_FORWARD_CHAIN=1): one forward pass in flight per GPU and process.  Round 4 found predictions corrupted when two
+// forward passes overlapped on one GPU (two handles on two streams, or two processes): the victim was the head kernel, the only
+// launch of a pass with a scratch segment (272 bytes per lane); every other launch's output was intact.  The
+// head kernel keeps its channels in registers now and no kernel of the engine has a scratch segment (tests/test_kernel_resources.py),
+// so passes may overlap.  The chain stays as a diagnostic: a forward on another stream than the previous one first waits, on the
+// device, for that one's last launch (an event recorded at the end of every forward).
 namespace {
 std::mutex g_chain_mu;
 struct ChainState { hipEvent_t done = nullptr; hipStream_t last = nullptr; bool any = false; };
@@ -1366,8 +1366,8 @@ ChainState g_chain[16];
 struct ForwardChain {
   std::unique_lock<std::mutex> lock{g_chain_mu};
 };
-static bool forward_chain_on() {   // BSMI_FORWARD_CHAIN=0: off (dev: the reproducers of the defect)
-  static const bool on = [] { const char* e = getenv("BSMI_FORWARD_CHAIN"); return !(e && e[0] == '0'); }();
+static bool forward_chain_on() {   // BSMI_FORWARD_CHAIN=1: on.  Off by default since the head kernel lost its scratch segment (the trigger)
+  static const bool on = [] { const char* e = getenv("BSMI_FORWARD_CHAIN"); return e && e[0] == '1'; }();
   return on;
 }
 static int forward_chain_enter(int device, hipStream_t s) {

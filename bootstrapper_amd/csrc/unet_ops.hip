@@ -398,9 +398,12 @@ __global__ void head_scratch_kernel(const T* z, int cpad, int cin, int cout, con
   __syncthreads();
   const size_t v = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (v >= nvox) return;
-  float f[64];
+#ifndef BSMI_HEAD_SCRATCH_N
+#define BSMI_HEAD_SCRATCH_N 64  // (16: a small scratch segment, for the question whether its size matters; cpad must be 16 then)
+#endif
+  float f[BSMI_HEAD_SCRATCH_N];
   constexpr int N = Vec<T>::N;
-  for (int c = 0; c < cpad && c < 64; c += N) load_vec<T, SP>(z, v * cpad + c, f + c);
+  for (int c = 0; c < cpad && c < BSMI_HEAD_SCRATCH_N; c += N) load_vec<T, SP>(z, v * cpad + c, f + c);
   for (int o = 0; o < cout; ++o) {
     float s1 = 0.f, s2 = 0.f;
     for (int c = 0; c < cin; ++c) {

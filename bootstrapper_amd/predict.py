@@ -279,33 +279,16 @@ def predict_blocks(cfg, rank=0, world=1, device=None, precision="bf16x3"):
 
     inflight, redo = [], []
 
-    # Workers that SHARE a GPU (more workers than cards: the reference deals worker w to GPU w % num_gpus, predict.py:46-49) take
-    # turns at the device: forward passes of different processes that overlap on one GPU corrupt each other,
-    # and processes cannot be chained by events like the streams of one process.  A lock file per device, held from the launch of a
-    # block's forward pass until it has finished; a worker's reads, copies, encoding and writes still overlap the other's passes.
-    shared = world > max(1, torch.cuda.device_count())
-    lock_file = None
-    if shared:
-        import fcntl
-        import tempfile
-        lock_file = open(os.path.join(tempfile.gettempdir(), f"bsmi_predict_gpu{device}.lock"), "a+")
-
     def predict_and_submit(blk):
         await_sections(blk)
         chans = [read_block(v, blk) for v in vols]
         if two_d:  # section z of the stack sees sections z .. z + adj - 1 of the read block as its channels
             chans = [c[i:i + out_shape[0]] for c in chans for i in range(adj)]
-        if shared:
-            fcntl.flock(lock_file, fcntl.LOCK_EX)
-        try:
-            u8 = model.predict_u8(chans[0] if len(chans) == 1 else torch.stack(chans))
-            ready = torch.cuda.Event()
-            ready.record(torch.cuda.current_stream(dev))
-            if shared:
-                ready.synchronize()
-        finally:
-            if shared:
-                fcntl.flock(lock_file, fcntl.LOCK_UN)
+        # (workers that share a GPU -- the reference deals worker w to GPU w % num_gpus, predict.py:46-49 -- simply overlap on it:
+        # the kernel whose scratch segment two overlapping passes corrupted is gone)
+        u8 = model.predict_u8(chans[0] if len(chans) == 1 else torch.stack(chans))
+        ready = torch.cuda.Event()
+        ready.record(torch.cuda.current_stream(dev))
         hi = [min(out_shape[d], roi_vox[d] - blk[d]) for d in range(3)]
         return pool.submit(write_block, blk, hi, u8, ready)
 
@@ -336,8 +319,6 @@ def predict_blocks(cfg, rank=0, world=1, device=None, precision="bf16x3"):
         pool.shutdown()
         load_future.result()
         side.shutdown()
-        if lock_file is not None:
-            lock_file.close()
         _trace.report()
     return state
 

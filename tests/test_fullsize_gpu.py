@@ -263,9 +263,10 @@ def test_cremi_single_block_96_predict_and_segment():
 
 
 def test_two_engines_of_one_process_side_by_side():
-    """Two handles predicting on two streams at the same time (round 4, DESIGN.md section 5: overlapping forward passes of the
-    bf16-family engine corrupted each other in nearly every prediction): every forward waits for the previous one of the process
-    on that GPU (`forward_chain_enter`), so each prediction is what it is alone, bit for bit."""
+    """Two handles predicting on two streams at the same time, really overlapping (no forward chain): each prediction is what it
+    is alone, bit for bit.  Round 4, DESIGN.md section 5: with a head kernel that kept its channels in a scratch segment, nearly
+    every prediction of this test was wrong."""
+    assert os.environ.get("BSMI_FORWARD_CHAIN") != "1"
     import threading
     from bootstrapper_amd.unet import Model
     from bootstrapper_amd.synth import synthetic_state_dict, synthetic_volume
