@@ -110,6 +110,7 @@ def _load():
         "bsmi_rag_merge_scores_host": (i32, [i32, vp, vp, vp, vp, C.c_float, i32, vp, i32]),
         "bsmi_rag_merge_scores_host_rule": (i32, [i32, vp, vp, vp, vp, C.c_float, i32, i32, vp, i32]),
         "bsmi_unet_train_set_arithmetic": (i32, [p, i32]),
+        "bsmi_unet_train_set_deterministic": (i32, [p, i32]),
         "bsmi_unet_train_begin": (i32, [p, i64p]),
         "bsmi_unet_train_forward_backward": (i32, [p, vp, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_float), vp]),
         "bsmi_unet_train_num_params": (i32, [p, C.POINTER(C.c_uint64)]),

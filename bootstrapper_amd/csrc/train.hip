@@ -189,8 +189,11 @@ __global__ void pack_head_kernel(const float* __restrict__ params, long long wc,
 
 // WeightedMSELoss, pass 1: sums[0] += sum of w (p - t)^2 over w > 0, sums[1] += count(w > 0), sums[2] += sum over all,
 // sums[3] += count(scale != 0)
+// `part` (deterministic mode): instead of the atomics every workgroup leaves its four sums in part[block][4] (its waves folded
+// in wave order) and fold_kernel adds the workgroups in index order.
 __global__ void loss_sums_kernel(const float* __restrict__ p, const float* __restrict__ t, const float* __restrict__ w, size_t n,
-                                 double* __restrict__ sums) {
+                                 double* __restrict__ sums, double* __restrict__ part) {
+  __shared__ double wave_sums[16][4];
   double s_mask = 0, s_all = 0;
   unsigned long long c_mask = 0, c_nz = 0;
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
@@ -206,11 +209,41 @@ __global__ void loss_sums_kernel(const float* __restrict__ p, const float* __res
     c_mask += __shfl_down(c_mask, o);
     c_nz += __shfl_down(c_nz, o);
   }
+  if (part) {
+    if ((threadIdx.x & 63) == 0) {
+      double* ws = wave_sums[threadIdx.x >> 6];
+      ws[0] = s_mask; ws[1] = (double)c_mask; ws[2] = s_all; ws[3] = (double)c_nz;
+    }
+    __syncthreads();
+    if (threadIdx.x < 4) {
+      double acc = 0;
+      for (int wv = 0; wv < (int)(blockDim.x >> 6); ++wv) acc += wave_sums[wv][threadIdx.x];
+      part[(size_t)blockIdx.x * 4 + threadIdx.x] = acc;
+    }
+    return;
+  }
   if ((threadIdx.x & 63) == 0) {
     atomicAdd(&sums[0], s_mask);
     atomicAdd(&sums[1], (double)c_mask);
     atomicAdd(&sums[2], s_all);
     atomicAdd(&sums[3], (double)c_nz);
+  }
+}
+
+// Ordered fold of per-workgroup partial sums (deterministic mode): out[i] (+)= part[0][i] + part[1][i] + ... in that order, one
+// thread per column i < width; rows are `stride` values apart.  The same bits whatever order the workgroups ran in.
+template <typename T>
+__global__ void fold_kernel(const T* __restrict__ part, int nparts, int stride, int width, T* __restrict__ out0, T* __restrict__ out1, int assign) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= width) return;
+  T acc = 0;
+  for (int pidx = 0; pidx < nparts; ++pidx) acc += part[(size_t)pidx * stride + i];
+  if (assign) {
+    out0[i] = acc;
+    if (out1) out1[i] = acc;
+  } else {
+    out0[i] += acc;
+    if (out1) out1[i] += acc;
   }
 }
 
@@ -231,12 +264,43 @@ __global__ void loss_grad_kernel(const float* __restrict__ p, const float* __res
 // dWc, dWr += dlogit z^T; dbc, dbr += dlogit.  One thread per voxel, block-level reduction of the weight gradients.
 __global__ void head_bwd_kernel(const float* __restrict__ z, int zc, const float* __restrict__ p, const float* __restrict__ dp, size_t nvox,
                                 int cin, int cout, const float* __restrict__ hw, float* __restrict__ dz, float* __restrict__ gwc,
-                                float* __restrict__ gwr, float* __restrict__ gbc, float* __restrict__ gbr) {
-  extern __shared__ float red[];  // [cout * cin + cout]
+                                float* __restrict__ gwr, float* __restrict__ gbc, float* __restrict__ gbr, float* __restrict__ part) {
+  extern __shared__ float red[];  // [cout * cin + cout]; deterministic mode: one such row per wave
   const int nred = cout * cin + cout;
   for (int i = threadIdx.x; i < nred; i += blockDim.x) red[i] = 0.f;
   __syncthreads();
   const size_t v = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (part) {
+    // deterministic mode: every product is summed over the wave by a fixed shuffle tree (lanes past the end hold zeros), the
+    // waves in wave order, and the workgroup's row goes to part[block][nred] for fold_kernel: no atomics anywhere
+    const bool live = v < nvox;
+    const size_t vv = live ? v : 0;
+    float* mine = red + (threadIdx.x >> 6) * nred;
+    for (int c = 0; c < cin; ++c) {
+      float acc = 0.f;
+      for (int o = 0; o < cout; ++o) {
+        const float pp = p[(size_t)o * nvox + vv];
+        acc += (hw[(o * 2 + 0) * cin + c] + hw[(o * 2 + 1) * cin + c]) * (dp[(size_t)o * nvox + vv] * pp * (1.f - pp));
+      }
+      if (live) dz[v * zc + c] += acc;
+    }
+    for (int o = 0; o < cout; ++o) {
+      const float pp = p[(size_t)o * nvox + vv];
+      const float dlo = live ? dp[(size_t)o * nvox + vv] * pp * (1.f - pp) : 0.f;
+      for (int c = 0; c <= cin; ++c) {  // c == cin: the bias column
+        float t = c < cin ? dlo * z[vv * zc + c] : dlo;
+        for (int off = 32; off > 0; off >>= 1) t += __shfl_down(t, off);
+        if ((threadIdx.x & 63) == 0) mine[c < cin ? o * cin + c : cout * cin + o] = t;
+      }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < nred; i += blockDim.x) {
+      float acc = 0.f;
+      for (int wv = 0; wv < (int)(blockDim.x >> 6); ++wv) acc += red[wv * nred + i];
+      part[(size_t)blockIdx.x * nred + i] = acc;
+    }
+    return;
+  }
   if (v < nvox) {
     float zz[32], dl[16];
     for (int c = 0; c < cin; ++c) zz[c] = z[v * zc + c];
@@ -367,7 +431,7 @@ __global__ void split_to_f32_kernel(const uint4* __restrict__ src, float4* __res
 
 // column sums of the interior of a padded tensor: out[c0 + c] += sum over voxels of g[..][c0 + c], c < Cc (Cc <= 1024)
 __global__ void colsum_kernel(const float* __restrict__ g, int D, int H, int W, int C, int c0, int Cc, int pz, int py, int px, int nreal,
-                              float* __restrict__ out0, float* __restrict__ out1) {
+                              float* __restrict__ out0, float* __restrict__ out1, float* __restrict__ part) {
   const int Hp = H + 2 * py, Wp = W + 2 * px;
   const int lanes = blockDim.x / Cc;  // voxels handled side by side
   if ((int)threadIdx.x >= lanes * Cc) return;
@@ -386,6 +450,10 @@ __global__ void colsum_kernel(const float* __restrict__ g, int D, int H, int W, 
     }
     if (x < W) a0 += gl[(size_t)x * C];
     acc += a0 + a1;
+  }
+  if (part) {  // deterministic mode: part[block * lanes + lane group][C] for fold_kernel
+    part[((size_t)blockIdx.x * lanes + threadIdx.x / Cc) * C + c] = acc;
+    return;
   }
   if (c < nreal && acc != 0.f) {
     atomicAdd(&out0[c], acc);
@@ -663,6 +731,7 @@ struct WgradPk {
   float* dwt;       // tap-major workspace [ntap][N][cin_total]
   int cin_total, cbase, ntap;
   int lines_per_block, zsplit;
+  size_t zstride;   // deterministic mode: line range z adds into its own copy of the workspace, dwt + z * zstride (0: one copy)
 };
 
 template <int KX, int FNW, int FCW>
@@ -691,6 +760,9 @@ __global__ __launch_bounds__(256, 2) void wgrad_x3_kernel(const WgradPk a) {
   const int unit = (seq / trows) * 8 + xcd;
   if (unit >= ntiles * a.zsplit) return;  // (uniform; the grid is padded to 8 x trows)
   const int tile = unit % ntiles, zblk = unit / ntiles;
+  // deterministic mode: this line range's own copy of the workspace -- one contributor per element, wgrad_finish_kernel adds the
+  // copies in z order (the atomicAdd below then adds to a zero and is exact whatever the order of the workgroups)
+  float* const dwt_z = a.dwt + (size_t)zblk * a.zstride;
   const int nt = tile / nblocks_c, ct = tile - nt * nblocks_c;
   const int tz = trow / a.ky, ty = trow - tz * a.ky;
   const int nbase = nt * TN, cbase = ct * TC;
@@ -839,7 +911,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_x3_kernel(const WgradPk a) {
           const int nn = nbase + (wn * FNW + i) * 16 + 4 * lq + r;
           // tap-major: the 16 lanes of a row are 64 contiguous bytes (in the OIDHW gradient they are 4 ntap bytes apart,
           // one cache line per lane)
-          if (nn < a.N && acc[t][i][j][r] != 0.f) atomicAdd(&a.dwt[((size_t)tap * a.N + nn) * a.cin_total + a.cbase + c], acc[t][i][j][r]);
+          if (nn < a.N && acc[t][i][j][r] != 0.f) atomicAdd(&dwt_z[((size_t)tap * a.N + nn) * a.cin_total + a.cbase + c], acc[t][i][j][r]);
         }
       }
   }
@@ -847,25 +919,32 @@ __global__ __launch_bounds__(256, 2) void wgrad_x3_kernel(const WgradPk a) {
 
 // dw[n][c][tap] += dwt[tap][n][c]; dwt = 0 (ready for the next step).  A block takes 256 consecutive (n, c): the tap planes
 // are read coalesced over (n, c), transposed through LDS and added into the OIDHW gradient as one contiguous run.
-__global__ __launch_bounds__(256) void wgrad_finish_kernel(float* __restrict__ dwt, float* __restrict__ dw, size_t nc, int ntap) {
+// nz, zstride (deterministic mode): the workspace is nz copies, one per line range of the launches; they are added in z order.
+__global__ __launch_bounds__(256) void wgrad_finish_kernel(float* __restrict__ dwt, float* __restrict__ dw, size_t nc, int ntap, int nz,
+                                                           size_t zstride) {
   __shared__ float tile[256 * 28];
   const size_t i0 = (size_t)blockIdx.x * 256;
   const int n = (int)min((size_t)256, nc - i0);
   const int tid = threadIdx.x;
+  auto take = [&](int t) -> float {  // the sum over the copies, each left zero
+    float acc = 0.f;
+    for (int z = 0; z < nz; ++z) {
+      float* q = dwt + (size_t)z * zstride + (size_t)t * nc + i0 + tid;
+      const float v = *q;
+      if (v != 0.f) { acc += v; *q = 0.f; }
+    }
+    return acc;
+  };
   if (ntap > 27) {  // (no such kernel in the model family; plain form)
     if (tid < n)
       for (int t = 0; t < ntap; ++t) {
-        const float v = dwt[(size_t)t * nc + i0 + tid];
-        if (v != 0.f) { dw[(i0 + tid) * ntap + t] += v; dwt[(size_t)t * nc + i0 + tid] = 0.f; }
+        const float v = take(t);
+        if (v != 0.f) dw[(i0 + tid) * ntap + t] += v;
       }
     return;
   }
   if (tid < n)
-    for (int t = 0; t < ntap; ++t) {
-      const float v = dwt[(size_t)t * nc + i0 + tid];
-      tile[tid * 28 + t] = v;
-      if (v != 0.f) dwt[(size_t)t * nc + i0 + tid] = 0.f;
-    }
+    for (int t = 0; t < ntap; ++t) tile[tid * 28 + t] = take(t);
   __syncthreads();
   const int total = n * ntap;
   float* d = dw + i0 * ntap;
@@ -905,8 +984,10 @@ static int launch_wgrad_x3_t(WgradPk a, hipStream_t s) {
   const int nlines = a.Do * a.Ho, trows = a.kz * a.ky;
   const int blocks_nc = ((a.N + TN - 1) / TN) * ((a.C + TC - 1) / TC);
   int zsplit = std::max(1, std::min(nlines, 4096 / std::max(1, blocks_nc * trows)));
+  const int zcap = a.zsplit;  // deterministic mode: the copies of the workspace the caller has room for
   a.lines_per_block = (nlines + zsplit - 1) / zsplit;
   a.zsplit = (nlines + a.lines_per_block - 1) / a.lines_per_block;
+  if (a.zstride && a.zsplit > zcap) BSMI_FAIL(BSMI_ERR_STATE, "weight-gradient launch cut into %d line ranges, workspace for %d", a.zsplit, zcap);
   const int units = blocks_nc * a.zsplit;
   hipLaunchKernelGGL((wgrad_x3_kernel<KX, FNW, FCW>), dim3((units + 7) / 8 * 8 * trows), dim3(256), smem, s, a);
   return BSMI_OK;
@@ -993,6 +1074,58 @@ __global__ void upsample_bwd_kernel(const float* __restrict__ dout, float* __res
   }
 }
 
+// The same as a gather (deterministic mode): one thread per INPUT voxel and channel walks the outputs that interpolated from it, in
+// z, y, x order, and adds their shares in that order -- no atomics.  Along one axis input j is the lower neighbour (i0) of the
+// outputs whose source coordinate lies in [j, j + 1) and the upper one (i1) of those in [j - 1, j): 2 f candidates.
+__global__ void upsample_bwd_gather_kernel(const float* __restrict__ dout, float* __restrict__ din, int Di, int Hi, int Wi, int C, int Do, int Ho,
+                                           int Wo, int fz, int fy, int fx, int oz, int oy, int ox) {
+  const size_t total = (size_t)Di * Hi * Wi * C;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int c = (int)(i % C);
+    size_t v = i / C;
+    const int jx = (int)(v % Wi); v /= Wi;
+    const int jy = (int)(v % Hi);
+    const int jz = (int)(v / Hi);
+    // share of output position p (upsampled coordinate) that input j gets along one axis: (1 - w1) if i0 == j, + w1 if i1 == j
+    auto share = [](int p, int f, int n, int j, float& lo, float& hi) {
+      float s = ((float)p + 0.5f) / (float)f - 0.5f;
+      s = s < 0.f ? 0.f : s;
+      const int i0 = (int)s, i1 = i0 + (i0 < n - 1 ? 1 : 0);
+      const float w1 = s - (float)i0;
+      lo = i0 == j ? 1.f - w1 : 0.f;
+      hi = i1 == j ? w1 : 0.f;
+    };
+    float acc = 0.f;
+    const int pz0 = max(oz, jz * fz - fz), pz1 = min(oz + Do, jz * fz + 2 * fz);
+    const int py0 = max(oy, jy * fy - fy), py1 = min(oy + Ho, jy * fy + 2 * fy);
+    const int px0 = max(ox, jx * fx - fx), px1 = min(ox + Wo, jx * fx + 2 * fx);
+    for (int pz = pz0; pz < pz1; ++pz) {
+      float zl, zh;
+      share(pz, fz, Di, jz, zl, zh);
+      if (zl == 0.f && zh == 0.f) continue;
+      for (int py = py0; py < py1; ++py) {
+        float yl, yh;
+        share(py, fy, Hi, jy, yl, yh);
+        if (yl == 0.f && yh == 0.f) continue;
+        for (int px = px0; px < px1; ++px) {
+          float xl, xh;
+          share(px, fx, Wi, jx, xl, xh);
+          if (xl == 0.f && xh == 0.f) continue;
+          const float g = dout[(((size_t)(pz - oz) * Ho + (py - oy)) * Wo + (px - ox)) * C + c];
+          if (g == 0.f) continue;
+          // the eight products of the scatter form, in its order (k = 0 .. 7: z bit 4, y bit 2, x bit 1), those that land on j
+#pragma unroll
+          for (int k = 0; k < 8; ++k) {
+            const float wt = ((k & 4) ? zh : zl) * ((k & 2) ? yh : yl) * ((k & 1) ? xh : xl);
+            if (wt != 0.f) acc += g * wt;
+          }
+        }
+      }
+    }
+    if (acc != 0.f) din[i] += acc;
+  }
+}
+
 // torch.optim.Adam (no weight decay, no amsgrad) on flat buffers; gscale folds the 1 / world_size of a summed all-reduce
 __global__ void adam_kernel(float* __restrict__ w, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v, size_t n, float lr,
                             float beta1, float beta2, float eps, float bc1, float bc2_sqrt, float gscale) {
@@ -1068,6 +1201,11 @@ struct TrainState {
   float* gt = nullptr;  // tap-major workspace of the split-bf16 weight gradients (same offsets as g; zero between steps)
   char *pk_g = nullptr, *pk_x = nullptr;  // packed operands of the split-bf16 weight gradient (grown on first use)
   size_t pk_g_bytes = 0, pk_x_bytes = 0;
+  // deterministic mode (bsmi_unet_train_set_deterministic): per-line-range copies of one weight tensor's tap-major workspace
+  // (zero between launches, like gt), per-workgroup partial sums of the bias / head / loss reductions
+  char *gt_det = nullptr, *det_part = nullptr;
+  size_t gt_det_bytes = 0, det_part_bytes = 0;
+  double* loss_part = nullptr;       // [512][4]
   int adam_t = 0;
   // Gradient groups: the parameters of one ConvPass / head are one contiguous range of the flat buffers (their keys share
   // a prefix and the buffers follow the sorted keys); a group's gradients are final once the backward pass has left its
@@ -1105,6 +1243,8 @@ void free_train_state(bsmi_unet* h) {
   for (void* p : h->train->allocs) (void)hipFree(p);
   if (h->train->pk_g) (void)hipFree(h->train->pk_g);
   if (h->train->pk_x) (void)hipFree(h->train->pk_x);
+  if (h->train->gt_det) (void)hipFree(h->train->gt_det);
+  if (h->train->det_part) (void)hipFree(h->train->det_part);
   delete h->train;
   h->train = nullptr;
 }
@@ -1631,6 +1771,25 @@ int bsmi_unet_train_set_arithmetic(bsmi_unet* h, int split_bf16) {
   return BSMI_OK;
 }
 
+int bsmi_unet_train_set_deterministic(bsmi_unet* h, int on) {
+  if (!h) BSMI_FAIL(BSMI_ERR_INVALID, "null handle");
+  h->train_det = on ? 1 : 0;
+  return BSMI_OK;
+}
+
+// a scratch buffer of the training state that only grows (first steps); zero_new: a grown buffer starts as zeros
+static int grow_buf(hipStream_t s, char** buf, size_t* have, size_t need, bool zero_new) {
+  if (need <= *have) return BSMI_OK;
+  BSMI_HIP(hipStreamSynchronize(s));
+  if (*buf) BSMI_HIP(hipFree(*buf));
+  *buf = nullptr;
+  *have = 0;
+  BSMI_HIP(hipMalloc((void**)buf, need + 4096));
+  if (zero_new) BSMI_HIP(hipMemset(*buf, 0, need + 4096));
+  *have = need;
+  return BSMI_OK;
+}
+
 int bsmi_unet_train_begin(bsmi_unet* h, const int64_t in_shape[3]) {
   if (!h || !in_shape) BSMI_FAIL(BSMI_ERR_INVALID, "null argument");
   if (!h->finalized[BSMI_PREC_F32]) BSMI_FAIL(BSMI_ERR_STATE, "bsmi_unet_finalize(BSMI_PREC_F32) first: training runs in fp32");
@@ -1661,6 +1820,7 @@ int bsmi_unet_train_begin(bsmi_unet* h, const int64_t in_shape[3]) {
     BSMI_HIP(hipMemcpy(ts->w + pr.off, h->weights[pr.key].data.data(), pr.count * sizeof(float), hipMemcpyHostToDevice));
   if ((rc = talloc(ts.get(), (void**)&ts->zero_bias, 2048 * sizeof(float), true))) return rc;
   if ((rc = talloc(ts.get(), (void**)&ts->loss_sums, 4 * sizeof(double), true))) return rc;
+  if ((rc = talloc(ts.get(), (void**)&ts->loss_part, 512 * 4 * sizeof(double), true))) return rc;
   if ((rc = talloc(ts.get(), (void**)&ts->loss_dev, sizeof(float), true))) return rc;
 
   Plan& plan = *ts->plan;
@@ -1797,6 +1957,7 @@ int bsmi_unet_train_forward_backward(bsmi_unet* h, const float* raw_dev, const f
   hipStream_t s = (hipStream_t)stream;
   Plan& plan = *ts->plan;
   const int nheads = (int)h->heads.size();
+  const bool det = h->train_det != 0;
   // forward (the inference engine), sigmoid outputs kept for the loss
   h->train_forward = true;  // CONV steps with a split-bf16 form run it (PlanStep::tx3)
   int rc = bsmi_unet_forward(h, BSMI_PREC_F32, raw_dev, BSMI_RAW_F32, ts->in_shape, ts->head_out.data(), nullptr, stream);
@@ -1810,7 +1971,9 @@ int bsmi_unet_train_forward_backward(bsmi_unet* h, const float* raw_dev, const f
   for (int hd = 0; hd < nheads; ++hd) {
     const size_t n = ts->out_vox * h->heads[hd].cout;
     BSMI_HIP(hipMemsetAsync(ts->loss_sums, 0, 4 * sizeof(double), s));
-    hipLaunchKernelGGL(loss_sums_kernel, dim3(512), dim3(256), 0, s, (const float*)ts->head_out[hd], targets_dev[hd], weights_dev[hd], n, ts->loss_sums);
+    hipLaunchKernelGGL(loss_sums_kernel, dim3(512), dim3(256), 0, s, (const float*)ts->head_out[hd], targets_dev[hd], weights_dev[hd], n, ts->loss_sums,
+                       det ? ts->loss_part : (double*)nullptr);
+    if (det) hipLaunchKernelGGL(fold_kernel<double>, dim3(1), dim3(64), 0, s, (const double*)ts->loss_part, 512, 4, 4, ts->loss_sums, (double*)nullptr, 1);
     hipLaunchKernelGGL(loss_grad_kernel, dim3(512), dim3(256), 0, s, (const float*)ts->head_out[hd], targets_dev[hd], weights_dev[hd], n,
                        (const double*)ts->loss_sums, ts->head_dp[hd], ts->loss_dev);
   }
@@ -1828,15 +1991,30 @@ int bsmi_unet_train_forward_backward(bsmi_unet* h, const float* raw_dev, const f
         float* gbr = ts->g + param_off(ts, pre + ".residual.0.bias");
         if (hd.cin > 32 || hd.cout > 16) BSMI_FAIL(BSMI_ERR_INVALID, "head backward: at most 32 input and 16 output channels");
         const size_t nv = ts->out_vox;
-        hipLaunchKernelGGL(head_bwd_kernel, dim3((unsigned)((nv + 255) / 256)), dim3(256), (hd.cout * hd.cin + hd.cout) * sizeof(float), s,
+        const int nred = hd.cout * hd.cin + hd.cout;
+        const unsigned hblocks = (unsigned)((nv + 255) / 256);
+        if (det && (rc = grow_buf(s, &ts->det_part, &ts->det_part_bytes, (size_t)hblocks * nred * sizeof(float), false))) return rc;
+        hipLaunchKernelGGL(head_bwd_kernel, dim3(hblocks), dim3(256), (size_t)(det ? 4 : 1) * nred * sizeof(float), s,
                            (const float*)st.in.ptr, st.in.Cpad, (const float*)ts->head_out[st.head], (const float*)ts->head_dp[st.head], nv, hd.cin,
-                           hd.cout, (const float*)hd.hw, (float*)dz.ptr, gwc, gwr, gbc, gbr);
+                           hd.cout, (const float*)hd.hw, (float*)dz.ptr, gwc, gwr, gbc, gbr, det ? (float*)ts->det_part : (float*)nullptr);
+        if (det) {  // the workgroups' rows in index order: weights, then biases
+          const int nw = hd.cout * hd.cin;
+          hipLaunchKernelGGL(fold_kernel<float>, dim3((nw + 63) / 64), dim3(64), 0, s, (const float*)ts->det_part, (int)hblocks, nred, nw, gwc, gwr, 0);
+          hipLaunchKernelGGL(fold_kernel<float>, dim3(1), dim3(64), 0, s, (const float*)ts->det_part + nw, (int)hblocks, nred, hd.cout, gbc, gbr, 0);
+        }
         BSMI_HIP(hipEventRecord(ts->groups[ts->group_of[hd.prefix]].ev, s));
         break;
       }
       case PlanStep::UP: {
         TDesc din = ts->grad_of[st.in.ptr], dout = ts->grad_of[st.out.ptr];
         const size_t total = (size_t)st.out.D * st.out.H * st.out.W * st.out.Cpad;
+        if (det) {
+          const size_t total_in = (size_t)st.in.D * st.in.H * st.in.W * st.in.Cpad;
+          hipLaunchKernelGGL(upsample_bwd_gather_kernel, dim3((unsigned)std::min<size_t>((total_in + 255) / 256, 65536)), dim3(256), 0, s,
+                             (const float*)dout.ptr, (float*)din.ptr, st.in.D, st.in.H, st.in.W, st.in.Cpad, st.out.D, st.out.H, st.out.W, st.f[0],
+                             st.f[1], st.f[2], st.o[0], st.o[1], st.o[2]);
+          break;
+        }
         hipLaunchKernelGGL(upsample_bwd_kernel, dim3((unsigned)std::min<size_t>((total + 255) / 256, 16384)), dim3(256), 0, s, (const float*)dout.ptr,
                            (float*)din.ptr, st.in.D, st.in.H, st.in.W, st.in.Cpad, st.out.D, st.out.H, st.out.W, st.f[0], st.f[1], st.f[2], st.o[0],
                            st.o[1], st.o[2]);
@@ -1861,7 +2039,7 @@ int bsmi_unet_train_forward_backward(bsmi_unet* h, const float* raw_dev, const f
         float* gb = ts->g + param_off(ts, base + ".bias");
         float* gbr = last ? ts->g + param_off(ts, p.prefix + ".residual.0.bias") : nullptr;
         static const bool fuse_colsum = env_on("BSMI_TRAIN_FUSE_COLSUM");
-        if (fuse_colsum) {
+        if (fuse_colsum && !det) {
           // the bias gradient (column sums of g) in the same pass: a grid whose stride is a multiple of the channel groups keeps a
           // thread on its four channels; few workgroups, each ends with one atomic per channel
           const int c4n = st.out.Cpad / 4;
@@ -1882,8 +2060,16 @@ int bsmi_unet_train_forward_backward(bsmi_unet* h, const float* raw_dev, const f
           for (int c0 = 0; c0 < st.out.Cpad; c0 += 512) {
             const int Cc = std::min(512, st.out.Cpad - c0);
             const int threads = std::max(Cc, 256 / Cc * Cc);
+            const int lanes = threads / Cc;
+            if (det && (rc = grow_buf(s, &ts->det_part, &ts->det_part_bytes, (size_t)256 * lanes * st.out.Cpad * sizeof(float), false))) return rc;
             hipLaunchKernelGGL(colsum_kernel, dim3(256), dim3(threads), 0, s, (const float*)cb.gp.ptr, st.out.D, st.out.H, st.out.W, st.out.Cpad, c0, Cc,
-                               cb.P[0], cb.P[1], cb.P[2], p.cout, gb, gbr);
+                               cb.P[0], cb.P[1], cb.P[2], p.cout, gb, gbr, det ? (float*)ts->det_part : (float*)nullptr);
+            if (det) {  // the real channels of this chunk, rows in index order
+              const int wd = std::min(Cc, p.cout - c0);
+              if (wd > 0)
+                hipLaunchKernelGGL(fold_kernel<float>, dim3((wd + 63) / 64), dim3(64), 0, s, (const float*)ts->det_part + c0, 256 * lanes, st.out.Cpad, wd,
+                                   gb + c0, gbr ? gbr + c0 : (float*)nullptr, 0);
+            }
           }
         }
         // weight gradients
@@ -1892,22 +2078,36 @@ int bsmi_unet_train_forward_backward(bsmi_unet* h, const float* raw_dev, const f
         const int cin_total = ci == 0 ? p.cin[0] + (p.nslots > 1 ? p.cin[1] : 0) : p.cout;
         bool used_x3 = false, g_packed = false;
         int x3_rc = BSMI_OK;
+        // deterministic mode: the launches of one weight tensor add into per-line-range copies of its workspace (det_nz of them,
+        // det_numel floats apart, in ts->gt_det), which the finish kernel adds in order
+        int det_nz = 1;
+        size_t det_numel = 0;
         auto finish = [&](float* dw, int ct, const int* kk) {  // after the launches of one weight tensor
           if (!used_x3) return;
           const size_t nc = (size_t)p.cout * ct;
-          hipLaunchKernelGGL(wgrad_finish_kernel, dim3((unsigned)((nc + 255) / 256)), dim3(256), 0, s, ts->gt + (dw - ts->g), dw, nc,
-                             kk[0] * kk[1] * kk[2]);
+          if (det)
+            hipLaunchKernelGGL(wgrad_finish_kernel, dim3((unsigned)((nc + 255) / 256)), dim3(256), 0, s, (float*)ts->gt_det, dw, nc, kk[0] * kk[1] * kk[2],
+                               det_nz, det_numel);
+          else
+            hipLaunchKernelGGL(wgrad_finish_kernel, dim3((unsigned)((nc + 255) / 256)), dim3(256), 0, s, ts->gt + (dw - ts->g), dw, nc,
+                               kk[0] * kk[1] * kk[2], 1, (size_t)0);
           used_x3 = false;
         };
-        auto grow = [&](char** buf, size_t* have, size_t need) -> int {  // first steps only
-          if (need <= *have) return BSMI_OK;
-          BSMI_HIP(hipStreamSynchronize(s));
-          if (*buf) BSMI_HIP(hipFree(*buf));
-          *buf = nullptr;
-          *have = 0;
-          BSMI_HIP(hipMalloc((void**)buf, need + 4096));
-          *have = need;
-          return BSMI_OK;
+        auto grow = [&](char** buf, size_t* have, size_t need) -> int { return grow_buf(s, buf, have, need, false); };  // first steps only
+        // the line ranges launch_wgrad_x3_t will cut a slot's launch into (its arithmetic)
+        auto x3_zsplit = [&](int N, int C, int nlines, int trows) {
+          const int TN = wgrad_tile_n(N), TC = wgrad_tile_c(C);
+          const int blocks_nc = ((N + TN - 1) / TN) * ((C + TC - 1) / TC);
+          const int zs = std::max(1, std::min(nlines, 4096 / std::max(1, blocks_nc * trows)));
+          const int lpb = (nlines + zs - 1) / zs;
+          return (nlines + lpb - 1) / lpb;
+        };
+        auto det_prepare = [&](int ct, const int* kk, const int* slot_c, int nsl) -> int {  // before the launches of one weight tensor
+          if (!det || !ts->gt) return BSMI_OK;
+          det_numel = (size_t)kk[0] * kk[1] * kk[2] * p.cout * ct;
+          det_nz = 1;
+          for (int sl = 0; sl < nsl; ++sl) det_nz = std::max(det_nz, x3_zsplit(p.cout, slot_c[sl], st.out.D * st.out.H, kk[0] * kk[1]));
+          return grow_buf(s, &ts->gt_det, &ts->gt_det_bytes, (size_t)det_nz * det_numel * sizeof(float), true);
         };
         // split-bf16 form (wgrad_x3_kernel): pack g once per conv stage, x per launch
         auto wgrad_x3 = [&](const WgradArgs& a) -> int {
@@ -1933,7 +2133,9 @@ int bsmi_unet_train_forward_backward(bsmi_unet* h, const float* raw_dev, const f
           WgradPk k;
           k.gp = ts->pk_g; k.xp = ts->pk_x; k.Np = Np; k.Cp = Cp; k.gpl = gpl;
           k.Do = a.Do; k.Ho = a.Ho; k.Hil = Hil; k.N = a.N; k.C = a.C; k.kz = a.kz; k.ky = a.ky;
-          k.dwt = a.dwt; k.cin_total = a.cin_total; k.cbase = a.cbase; k.ntap = a.ntap; k.lines_per_block = 0; k.zsplit = 1;
+          k.dwt = det ? (float*)ts->gt_det : a.dwt; k.cin_total = a.cin_total; k.cbase = a.cbase; k.ntap = a.ntap; k.lines_per_block = 0; k.zsplit = 1;
+          k.zstride = det ? det_numel : 0;
+          if (det) k.zsplit = det_nz;
           return a.kx == 1 ? launch_wgrad_x3_k<1>(k, s) : launch_wgrad_x3_k<3>(k, s);
         };
         auto wgrad = [&](const TDesc& x, const int* org, int C, int cbase, float* dw, int ct, const int* kk) {
@@ -1957,6 +2159,7 @@ int bsmi_unet_train_forward_backward(bsmi_unet* h, const float* raw_dev, const f
           const bool tiled = a.N > 32 && a.C > 32;  // narrow layers: the per-wave form wastes fewer MFMAs on padding
           const int blocks_nc = tiled ? ((a.N + 127) / 128) * ((a.C + 127) / 128) : ((a.N + 31) / 32) * ((a.C + 63) / 64);
           int zsplit = std::max(1, std::min(nlines, (tiled ? 2048 : 8192) / std::max(1, blocks_nc * trows)));
+          if (det) zsplit = 1;  // the f32 forms add straight into dw: one workgroup per element = one (exact) addition to a zero
           a.lines_per_block = (nlines + zsplit - 1) / zsplit;
           zsplit = (nlines + a.lines_per_block - 1) / a.lines_per_block;
           const dim3 grid(blocks_nc, trows, zsplit);
@@ -1977,6 +2180,10 @@ int bsmi_unet_train_forward_backward(bsmi_unet* h, const float* raw_dev, const f
           }
         };
         float* dwm = ts->g + param_off(ts, base + ".weight");
+        {
+          const int one_slot[1] = {p.cout};
+          if ((rc = det_prepare(cin_total, k, ci == 0 ? p.cin : one_slot, ci == 0 ? p.nslots : 1))) return rc;
+        }
         if (ci == 0) {
           int cbase = 0;
           for (int sl = 0; sl < p.nslots; ++sl) {
@@ -1997,6 +2204,7 @@ int bsmi_unet_train_forward_backward(bsmi_unet* h, const float* raw_dev, const f
           const int ones[3] = {1, 1, 1};
           const int rin = p.cin[0] + (p.nslots > 1 ? p.cin[1] : 0);
           int cbase = 0;
+          if ((rc = det_prepare(rin, ones, p.cin, p.nslots))) return rc;
           for (int sl = 0; sl < p.nslots; ++sl) {
             int org[3];
             for (int d = 0; d < 3; ++d) org[d] = st.so[first_slot + sl][d] + crop[d] / 2;

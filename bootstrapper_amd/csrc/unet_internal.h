@@ -208,6 +208,7 @@ struct bsmi_unet {
   bsmi::TrainState* train = nullptr;  // train.hip
   bool train_forward = false;         // the forward pass of a training step is running (PlanStep::tx3)
   int train_split = 1;                // bsmi_unet_train_set_arithmetic
+  int train_det = 0;                  // bsmi_unet_train_set_deterministic: ordered reductions instead of float atomics
   bsmi::FirstPassWeights first_pass;     // first_pass.hip: weights of the fused first ConvPass (bf16 mode)
   bsmi::FirstPassWeights first_pass_x3;  // ... and of the split-bf16 mode
 };

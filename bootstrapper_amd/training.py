@@ -186,10 +186,11 @@ class _DevBuf:
 
 
 class Trainer:
-    def __init__(self, model, in_shape, lr=0.5e-4, betas=(0.9, 0.999), eps=1e-8, arithmetic="split-bf16"):
+    def __init__(self, model, in_shape, lr=0.5e-4, betas=(0.9, 0.999), eps=1e-8, arithmetic="split-bf16", deterministic=False):
         """model: bootstrapper_amd.unet.Model with weights loaded; in_shape: (D, H, W) of the training block.
         arithmetic: "split-bf16" (default: the convolutions multiply f32 operands as bf16 hi + lo pairs on the bf16 matrix
-        pipe, f32 accumulation; tensors, loss, gradients and Adam are fp32) or "f32" (exact f32 MFMA, about half the speed)."""
+        pipe, f32 accumulation; tensors, loss, gradients and Adam are fp32) or "f32" (exact f32 MFMA, about half the speed).
+        deterministic: every reduction of the step in a fixed order instead of float atomics -- two runs give the same bits."""
         if arithmetic not in ("split-bf16", "f32"):
             raise ValueError(f"arithmetic must be 'split-bf16' or 'f32', not {arithmetic!r}")
         self.arithmetic = arithmetic
@@ -198,6 +199,8 @@ class Trainer:
         self.lr, self.betas, self.eps = float(lr), (float(betas[0]), float(betas[1])), float(eps)
         model._finalize(_lib.PREC_F32)
         check(lib.bsmi_unet_train_set_arithmetic(model._h, 1 if arithmetic == "split-bf16" else 0))
+        check(lib.bsmi_unet_train_set_deterministic(model._h, 1 if deterministic else 0))
+        self.deterministic = bool(deterministic)
         check(lib.bsmi_unet_train_begin(model._h, _lib.i64x3(self.in_shape)))
         n = C.c_uint64()
         check(lib.bsmi_unet_train_num_params(model._h, C.byref(n)))

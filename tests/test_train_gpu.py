@@ -17,7 +17,7 @@ def _net_config(meta):
             "kernel_size_up": [[[3, 3, 3], [3, 3, 3]]] * 3, "outputs": outs}
 
 
-@pytest.mark.parametrize("arithmetic", ["f32", "split-bf16"])
+@pytest.mark.parametrize("arithmetic", ["f32", "split-bf16", "f32+deterministic", "split-bf16+deterministic"])
 @pytest.mark.parametrize("tag", ["affs_f4i2", "affs_f3i3_lr1e-2", "mtlsd_f4i2"])
 def test_training_step_vs_reference_goldens(golden_dir, tag, arithmetic):
     """arithmetic "f32": exact f32 MFMA, the reference's own arithmetic.  "split-bf16" (the default of Trainer): the
@@ -29,12 +29,14 @@ def test_training_step_vs_reference_goldens(golden_dir, tag, arithmetic):
     go the other way (f32: a twentieth of a step)."""
     from bootstrapper_amd.unet import Model
     from bootstrapper_amd.training import Trainer
+    deterministic = arithmetic.endswith("+deterministic")  # the ordered reductions (bsmi_unet_train_set_deterministic): same goldens
+    arithmetic = arithmetic.split("+")[0]
     grad_tol, step_tol = (1e-4, 5e-2) if arithmetic == "f32" else (1e-2, 2.1)
     d = np.load(os.path.join(golden_dir, f"train_{tag}.npz"))
     meta = json.loads(bytes(d["config"]).decode())
     sd = {k[3:]: d[k] for k in d.files if k.startswith("w0:")}
     m = Model(_net_config(meta), precision="f32").load_state_dict(sd)
-    tr = Trainer(m, meta["in_shape"], lr=meta["lr"], arithmetic=arithmetic)
+    tr = Trainer(m, meta["in_shape"], lr=meta["lr"], arithmetic=arithmetic, deterministic=deterministic)
     nh = len(m.heads)
     raw = torch.from_numpy(d["x"]).cuda()
     targets = [torch.from_numpy(d[f"gt{i}"][0]).cuda() for i in range(nh)]
@@ -59,6 +61,50 @@ def test_training_step_vs_reference_goldens(golden_dir, tag, arithmetic):
             assert np.abs(got - ref).max() <= 1e-5 * max(1.0, np.abs(ref).max()) + meta["lr"] * step_tol, (step, k)
     print("largest relative gradient error:", max(worst))
     tr.close()
+
+
+@pytest.mark.parametrize("arithmetic", ["split-bf16", "f32"])
+def test_deterministic_step_is_bit_reproducible(arithmetic):
+    """Trainer(deterministic=True): two runs of two steps (forward, backward, Adam) of the full net on the same inputs give the
+    same BITS -- loss, every gradient, every parameter -- like the reference's CPU path.  The default mode
+    orders its float atomics by chance: it agrees with the deterministic one to 1e-4 of the largest gradient, not bitwise."""
+    from bootstrapper_amd.unet import Model
+    from bootstrapper_amd.training import Trainer
+    from bootstrapper_amd.synth import synthetic_state_dict
+    from tests.test_lib_cpu import AFFS_NET_CONFIG as NC
+    sd = synthetic_state_dict(NC, 0)
+    shape = (32, 196, 196)
+    rng = np.random.default_rng(1)
+    x = torch.from_numpy((rng.random(shape, dtype=np.float32) * 2 - 1).astype(np.float32)).cuda()
+    gt = w = None
+    runs = []
+    for deterministic in (True, True, False):
+        m = Model(NC, precision="f32").load_state_dict(sd)
+        tr = Trainer(m, shape, lr=1e-3, arithmetic=arithmetic, deterministic=deterministic)
+        if gt is None:
+            out = (6,) + tuple(tr.out_shape)
+            gt = torch.from_numpy((rng.random(out) > 0.5).astype(np.float32)).cuda()
+            wn = rng.random(out).astype(np.float32)
+            wn[rng.random(out) < 0.2] = 0
+            w = torch.from_numpy(wn).cuda()
+        rec = []
+        for step in range(2):
+            loss = tr.forward_backward(x, [gt], [w])
+            rec.append((np.float64(loss), tr.grads.cpu().numpy().copy()))
+            tr.optimizer_step()
+            torch.cuda.synchronize()
+            rec.append((None, tr.params.cpu().numpy().copy()))
+        runs.append(rec)
+        tr.close()
+        del m
+    a, b, c = runs
+    for i, ((la, ta), (lb, tb)) in enumerate(zip(a, b)):
+        assert la is None or la.tobytes() == lb.tobytes(), (i, la, lb)
+        assert ta.tobytes() == tb.tobytes(), f"record {i}: {int((ta != tb).sum())} of {ta.size} values differ between two deterministic runs"
+    # the default mode against the deterministic one: the same step up to the order of the additions
+    (la, ga), (lc, gc) = a[0], c[0]
+    assert abs(la - lc) < 1e-6 * max(1.0, abs(la))
+    assert np.abs(ga - gc).max() < 1e-4 * np.abs(ga).max()
 
 
 def test_data_parallel_two_ranks(tmp_path, golden_dir):
