@@ -334,7 +334,7 @@ def drivers_leg(raw_box, sd, precision, model=None, vol=None, origin=(0, 0, 0)):
 TRAIN_SHAPE = (32, 196, 196)
 
 
-def train_run(dev, local_rank, rank, world, arithmetic, steps, warmup):
+def train_run(dev, local_rank, rank, world, arithmetic, steps, warmup, deterministic=False):
     """`steps` training steps of the full 3d_affs net on the reference's training block -> (seconds, last loss, first-step gradients, forward FLOPs)"""
     import torch.distributed as dist
     from bootstrapper_amd.unet import Model
@@ -347,7 +347,7 @@ def train_run(dev, local_rank, rank, world, arithmetic, steps, warmup):
         if world > 1:
             dist.barrier()
     model = Model(NET_CONFIG, device=local_rank, precision="f32").load_state_dict(synthetic_state_dict(NET_CONFIG, 0))
-    tr = Trainer(model, shape, arithmetic=arithmetic)
+    tr = Trainer(model, shape, arithmetic=arithmetic, deterministic=deterministic)
     g = torch.Generator(device=dev).manual_seed(rank)
     out = (6,) + tuple(tr.out_shape)
     batch = {"raw": torch.rand(shape, generator=g, device=dev) * 2 - 1,
@@ -378,12 +378,18 @@ def train_leg(dev, local_rank):
     f32, and how far the first-step gradients of the two are apart."""
     dt, loss, grads, fwd = train_run(dev, local_rank, 0, 1, "split-bf16", 10, 2)
     dt32, loss32, grads32, _ = train_run(dev, local_rank, 0, 1, "f32", 4, 1)
+    # Trainer(deterministic=True): ordered folds instead of float atomics; twice, to report that the two runs end on the same bits
+    dtd, lossd, gradsd, _ = train_run(dev, local_rank, 0, 1, "split-bf16", 10, 2, deterministic=True)
+    _, lossd2, gradsd2, _ = train_run(dev, local_rank, 0, 1, "split-bf16", 10, 2, deterministic=True)
     step_flops = 3.0 * fwd
     return {"what": "3d_affs U-Net (94.7M params) forward + WeightedMSELoss + backward + Adam, block (32,196,196) -> (6,4,104,104), batch 1; "
                     "`bench.py --mode train` is the full line",
             "split-bf16": {"ms_per_step": dt / 10 * 1e3, "samples_per_s": 10 / dt, "tflops": step_flops * 10 / dt / 1e12,
                            "frac_of_split_peak": step_flops * 10 / dt / 1e12 / X3_PEAK, "last_loss": loss},
             "f32": {"ms_per_step": dt32 / 4 * 1e3, "samples_per_s": 4 / dt32, "tflops": step_flops * 4 / dt32 / 1e12, "last_loss": loss32},
+            "split-bf16 deterministic": {"ms_per_step": dtd / 10 * 1e3, "last_loss": lossd,
+                                         "two_runs_bit_equal": bool(torch.equal(gradsd, gradsd2) and lossd == lossd2),
+                                         "max_gradient_difference_to_default_rel": float((gradsd - grads).abs().max() / grads.abs().max())},
             "max_gradient_difference_rel": float((grads - grads32).abs().max() / grads32.abs().max())}
 
 
