@@ -1173,6 +1173,7 @@ struct ConvBwd {  // backward data of one CONV plan step
   TileCfg dtile = TILE_256x32;
   TDesc dcat;            // its output when the pass input is a crop / concat (stage 0), else the previous stage's gradient
   bool scatter = false;
+  hipEvent_t ev_g = nullptr;  // the padded gradient is written: the weight-gradient stream may start on this stage
 };
 
 // (PlanStep::tx3's type, unet_internal.h)
@@ -1206,6 +1207,8 @@ struct TrainState {
   char *gt_det = nullptr, *det_part = nullptr;
   size_t gt_det_bytes = 0, det_part_bytes = 0;
   double* loss_part = nullptr;       // [512][4]
+  hipStream_t wstream = nullptr;     // the weight gradients' own stream (null: BSMI_TRAIN_WSTREAM=0, everything on the caller's)
+  hipEvent_t ev_join = nullptr;      // its last launch of a backward pass
   int adam_t = 0;
   // Gradient groups: the parameters of one ConvPass / head are one contiguous range of the flat buffers (their keys share
   // a prefix and the buffers follow the sorted keys); a group's gradients are final once the backward pass has left its
@@ -1240,6 +1243,10 @@ void free_train_state(bsmi_unet* h) {
     for (PlanStep& st : h->train->plan->steps) st.tx3 = nullptr;
   for (auto& g : h->train->groups)
     if (g.ev) (void)hipEventDestroy(g.ev);
+  for (auto& cb : h->train->convs)
+    if (cb.ev_g) (void)hipEventDestroy(cb.ev_g);
+  if (h->train->ev_join) (void)hipEventDestroy(h->train->ev_join);
+  if (h->train->wstream) (void)hipStreamDestroy(h->train->wstream);
   for (void* p : h->train->allocs) (void)hipFree(p);
   if (h->train->pk_g) (void)hipFree(h->train->pk_g);
   if (h->train->pk_x) (void)hipFree(h->train->pk_x);
@@ -1923,6 +1930,12 @@ int bsmi_unet_train_begin(bsmi_unet* h, const int64_t in_shape[3]) {
     for (auto& g : ts->groups) covered += g.count;
     if (covered != ts->nparams) BSMI_FAIL(BSMI_ERR_STATE, "training plan: gradient groups cover %zu of %zu parameters", covered, ts->nparams);
   }
+  if (env_on("BSMI_TRAIN_WSTREAM")) {
+    BSMI_HIP(hipStreamCreateWithFlags(&ts->wstream, hipStreamNonBlocking));
+    BSMI_HIP(hipEventCreateWithFlags(&ts->ev_join, hipEventDisableTiming));
+    for (size_t i = 0; i < ts->convs.size(); ++i)
+      if (plan.steps[i].type == PlanStep::CONV) BSMI_HIP(hipEventCreateWithFlags(&ts->convs[i].ev_g, hipEventDisableTiming));
+  }
   h->train = ts.release();
   return run_pack_jobs(h->train, nullptr) || hipDeviceSynchronize() != hipSuccess ? BSMI_ERR_HIP : BSMI_OK;
 }
@@ -2072,7 +2085,15 @@ int bsmi_unet_train_forward_backward(bsmi_unet* h, const float* raw_dev, const f
             }
           }
         }
-        // weight gradients
+        // weight gradients: on their own stream (ts->wstream), beside the input-gradient launch of this stage and whatever the main
+        // stream does next -- they only read g (ready: the event below) and forward activations, and write dW.  Many launches of
+        // the step have too few tiles for the card; two chains of them side by side fill it better.  BSMI_TRAIN_WSTREAM=0: one stream.
+        hipStream_t sw = s;
+        if (ts->wstream) {
+          sw = ts->wstream;
+          BSMI_HIP(hipEventRecord(cb.ev_g, s));
+          BSMI_HIP(hipStreamWaitEvent(sw, cb.ev_g, 0));
+        }
         const int64_t gsx = cb.gp.Cpad, gsy = (int64_t)cb.gp.W * gsx, gsz = (int64_t)cb.gp.H * gsy;
         const float* ginterior = (const float*)cb.gp.ptr + cb.P[0] * gsz + cb.P[1] * gsy + cb.P[2] * gsx;
         const int cin_total = ci == 0 ? p.cin[0] + (p.nslots > 1 ? p.cin[1] : 0) : p.cout;
@@ -2086,14 +2107,14 @@ int bsmi_unet_train_forward_backward(bsmi_unet* h, const float* raw_dev, const f
           if (!used_x3) return;
           const size_t nc = (size_t)p.cout * ct;
           if (det)
-            hipLaunchKernelGGL(wgrad_finish_kernel, dim3((unsigned)((nc + 255) / 256)), dim3(256), 0, s, (float*)ts->gt_det, dw, nc, kk[0] * kk[1] * kk[2],
+            hipLaunchKernelGGL(wgrad_finish_kernel, dim3((unsigned)((nc + 255) / 256)), dim3(256), 0, sw, (float*)ts->gt_det, dw, nc, kk[0] * kk[1] * kk[2],
                                det_nz, det_numel);
           else
-            hipLaunchKernelGGL(wgrad_finish_kernel, dim3((unsigned)((nc + 255) / 256)), dim3(256), 0, s, ts->gt + (dw - ts->g), dw, nc,
+            hipLaunchKernelGGL(wgrad_finish_kernel, dim3((unsigned)((nc + 255) / 256)), dim3(256), 0, sw, ts->gt + (dw - ts->g), dw, nc,
                                kk[0] * kk[1] * kk[2], 1, (size_t)0);
           used_x3 = false;
         };
-        auto grow = [&](char** buf, size_t* have, size_t need) -> int { return grow_buf(s, buf, have, need, false); };  // first steps only
+        auto grow = [&](char** buf, size_t* have, size_t need) -> int { return grow_buf(sw, buf, have, need, false); };  // first steps only
         // the line ranges launch_wgrad_x3_t will cut a slot's launch into (its arithmetic)
         auto x3_zsplit = [&](int N, int C, int nlines, int trows) {
           const int TN = wgrad_tile_n(N), TC = wgrad_tile_c(C);
@@ -2107,7 +2128,7 @@ int bsmi_unet_train_forward_backward(bsmi_unet* h, const float* raw_dev, const f
           det_numel = (size_t)kk[0] * kk[1] * kk[2] * p.cout * ct;
           det_nz = 1;
           for (int sl = 0; sl < nsl; ++sl) det_nz = std::max(det_nz, x3_zsplit(p.cout, slot_c[sl], st.out.D * st.out.H, kk[0] * kk[1]));
-          return grow_buf(s, &ts->gt_det, &ts->gt_det_bytes, (size_t)det_nz * det_numel * sizeof(float), true);
+          return grow_buf(sw, &ts->gt_det, &ts->gt_det_bytes, (size_t)det_nz * det_numel * sizeof(float), true);
         };
         // split-bf16 form (wgrad_x3_kernel): pack g once per conv stage, x per launch
         auto wgrad_x3 = [&](const WgradArgs& a) -> int {
@@ -2120,7 +2141,7 @@ int bsmi_unet_train_forward_backward(bsmi_unet* h, const float* raw_dev, const f
             if ((rc2 = grow(&ts->pk_g, &ts->pk_g_bytes, need))) return rc2;
             const size_t items = ((size_t)nlines * gpl + 1) * Np;
             if (items >= ((size_t)1 << 31)) return BSMI_ERR_INVALID;
-            hipLaunchKernelGGL(wgrad_pack_kernel, dim3((unsigned)std::min<size_t>((items + 255) / 256, 65536)), dim3(256), 0, s, a.g, a.gsz, a.gsy,
+            hipLaunchKernelGGL(wgrad_pack_kernel, dim3((unsigned)std::min<size_t>((items + 255) / 256, 65536)), dim3(256), 0, sw, a.g, a.gsz, a.gsy,
                                a.gsx, a.Do, a.Ho, a.Wo, a.N, Np, gpl, 1, 1, (u32x4_t*)ts->pk_g);
             g_packed = true;
           }
@@ -2128,7 +2149,7 @@ int bsmi_unet_train_forward_backward(bsmi_unet* h, const float* raw_dev, const f
           if ((rc2 = grow(&ts->pk_x, &ts->pk_x_bytes, needx))) return rc2;
           const size_t itemsx = (size_t)Dil * Hil * gpl * Cp;
           if (itemsx >= ((size_t)1 << 31)) return BSMI_ERR_INVALID;
-          hipLaunchKernelGGL(wgrad_pack_kernel, dim3((unsigned)std::min<size_t>((itemsx + 255) / 256, 65536)), dim3(256), 0, s, a.x, a.xsz, a.xsy, a.xsx,
+          hipLaunchKernelGGL(wgrad_pack_kernel, dim3((unsigned)std::min<size_t>((itemsx + 255) / 256, 65536)), dim3(256), 0, sw, a.x, a.xsz, a.xsy, a.xsx,
                              Dil, Hil, a.Wo + a.kx - 1, a.C, Cp, gpl, xvec, 0, (u32x4_t*)ts->pk_x);
           WgradPk k;
           k.gp = ts->pk_g; k.xp = ts->pk_x; k.Np = Np; k.Cp = Cp; k.gpl = gpl;
@@ -2136,7 +2157,7 @@ int bsmi_unet_train_forward_backward(bsmi_unet* h, const float* raw_dev, const f
           k.dwt = det ? (float*)ts->gt_det : a.dwt; k.cin_total = a.cin_total; k.cbase = a.cbase; k.ntap = a.ntap; k.lines_per_block = 0; k.zsplit = 1;
           k.zstride = det ? det_numel : 0;
           if (det) k.zsplit = det_nz;
-          return a.kx == 1 ? launch_wgrad_x3_k<1>(k, s) : launch_wgrad_x3_k<3>(k, s);
+          return a.kx == 1 ? launch_wgrad_x3_k<1>(k, sw) : launch_wgrad_x3_k<3>(k, sw);
         };
         auto wgrad = [&](const TDesc& x, const int* org, int C, int cbase, float* dw, int ct, const int* kk) {
           WgradArgs a;
@@ -2165,17 +2186,17 @@ int bsmi_unet_train_forward_backward(bsmi_unet* h, const float* raw_dev, const f
           const dim3 grid(blocks_nc, trows, zsplit);
           if (tiled) {
             switch (a.kx) {
-              case 1: hipLaunchKernelGGL(wgrad_tiled_kernel<1>, grid, dim3(256), 0, s, a); break;
-              case 2: hipLaunchKernelGGL(wgrad_tiled_kernel<2>, grid, dim3(256), 0, s, a); break;
-              case 3: hipLaunchKernelGGL(wgrad_tiled_kernel<3>, grid, dim3(256), 0, s, a); break;
+              case 1: hipLaunchKernelGGL(wgrad_tiled_kernel<1>, grid, dim3(256), 0, sw, a); break;
+              case 2: hipLaunchKernelGGL(wgrad_tiled_kernel<2>, grid, dim3(256), 0, sw, a); break;
+              case 3: hipLaunchKernelGGL(wgrad_tiled_kernel<3>, grid, dim3(256), 0, sw, a); break;
               default: return;
             }
             return;
           }
           switch (a.kx) {
-            case 1: hipLaunchKernelGGL(wgrad_kernel<1>, grid, dim3(64), 0, s, a); break;
-            case 2: hipLaunchKernelGGL(wgrad_kernel<2>, grid, dim3(64), 0, s, a); break;
-            case 3: hipLaunchKernelGGL(wgrad_kernel<3>, grid, dim3(64), 0, s, a); break;
+            case 1: hipLaunchKernelGGL(wgrad_kernel<1>, grid, dim3(64), 0, sw, a); break;
+            case 2: hipLaunchKernelGGL(wgrad_kernel<2>, grid, dim3(64), 0, sw, a); break;
+            case 3: hipLaunchKernelGGL(wgrad_kernel<3>, grid, dim3(64), 0, sw, a); break;
             default: return;  // checked in bsmi_unet_train_begin
           }
         };
@@ -2236,13 +2257,18 @@ int bsmi_unet_train_forward_backward(bsmi_unet* h, const float* raw_dev, const f
             }
           }
         }
-        if (ci == 0) BSMI_HIP(hipEventRecord(ts->groups[ts->group_of[p.prefix]].ev, s));  // the pass's gradients are final
+        // the pass's gradients are final when its last weight gradient is (its bias gradients were written before ev_g)
+        if (ci == 0) BSMI_HIP(hipEventRecord(ts->groups[ts->group_of[p.prefix]].ev, ts->wstream ? ts->wstream : s));
         break;
       }
       default: break;
     }
   }
   BSMI_HIP(hipGetLastError());
+  if (ts->wstream) {  // the caller's stream ends the pass after the last weight gradient
+    BSMI_HIP(hipEventRecord(ts->ev_join, ts->wstream));
+    BSMI_HIP(hipStreamWaitEvent(s, ts->ev_join, 0));
+  }
   if (loss_host) {
     BSMI_HIP(hipMemcpyAsync(loss_host, ts->loss_dev, sizeof(float), hipMemcpyDeviceToHost, s));
     BSMI_HIP(hipStreamSynchronize(s));
