@@ -1156,6 +1156,7 @@ struct PackJob {  // one packed weight image that must follow the parameters
   uint32_t *dst_hi = nullptr, *dst_lo = nullptr;  // fused split-bf16 image instead (units of 16 channels)
   int window = 2;  // units of one 32-channel chunk (taps x 2): the thread order of pack_weights_x3_kernel
   bool shadowed = false;  // f32 image of a forward launch that trains in its split-bf16 form (make_forward_x3)
+  bool backward = false;  // image of an input-gradient launch: first read in the backward pass (packed on the side stream)
   // bias image (forward launches only)
   long long b0 = -1, b1 = -1;
   float* bias_dst = nullptr;
@@ -1209,6 +1210,8 @@ struct TrainState {
   double* loss_part = nullptr;       // [512][4]
   hipStream_t wstream = nullptr;     // the weight gradients' own stream (null: BSMI_TRAIN_WSTREAM=0, everything on the caller's)
   hipEvent_t ev_join = nullptr;      // its last launch of a backward pass
+  hipEvent_t ev_adam = nullptr, ev_packed = nullptr;  // optimizer step done / input-gradient images repacked on the side stream
+  bool packed_pending = false;
   int adam_t = 0;
   // Gradient groups: the parameters of one ConvPass / head are one contiguous range of the flat buffers (their keys share
   // a prefix and the buffers follow the sorted keys); a group's gradients are final once the backward pass has left its
@@ -1246,6 +1249,8 @@ void free_train_state(bsmi_unet* h) {
   for (auto& cb : h->train->convs)
     if (cb.ev_g) (void)hipEventDestroy(cb.ev_g);
   if (h->train->ev_join) (void)hipEventDestroy(h->train->ev_join);
+  if (h->train->ev_adam) (void)hipEventDestroy(h->train->ev_adam);
+  if (h->train->ev_packed) (void)hipEventDestroy(h->train->ev_packed);
   if (h->train->wstream) (void)hipStreamDestroy(h->train->wstream);
   for (void* p : h->train->allocs) (void)hipFree(p);
   if (h->train->pk_g) (void)hipFree(h->train->pk_g);
@@ -1331,9 +1336,11 @@ static int make_forward_job(bsmi_unet* h, TrainState* ts, PassSite& p, int ci) {
 // `lazy_f32`: leave out the f32 weight image of a forward launch that runs in its split-bf16 form during training
 // (PackJob::shadowed); the images are then stale until train_refresh_f32_images, which an f32 inference call on the same
 // handle triggers (unet_api.hip) -- the bias images and everything the step itself reads are always current.
-static int run_pack_jobs(TrainState* ts, hipStream_t s, bool lazy_f32 = false, bool only_shadowed = false) {
+// which: 0 every image, 1 those the forward pass reads, 2 those only the backward pass reads
+static int run_pack_jobs(TrainState* ts, hipStream_t s, bool lazy_f32 = false, bool only_shadowed = false, int which = 0) {
   for (const PackJob& j : ts->jobs) {
     if (only_shadowed && !j.shadowed) continue;
+    if (which && j.backward != (which == 2)) continue;
     const size_t total = (size_t)j.nunits * j.Npad;
     if (j.dst_hi) {
       const int ugw = std::max(2, j.window);
@@ -1630,6 +1637,7 @@ static int make_dgrad(bsmi_unet* h, TrainState* ts, ConvBwd& cb, const ConvBwd* 
     job.dst_lo = (uint32_t*)((char*)wdev + wimg);
     job.window = kUnitsPerStep * ntap;
   }
+  job.backward = true;
   ts->jobs.push_back(job);
   if (Npad > 2048) BSMI_FAIL(BSMI_ERR_INVALID, "dgrad launch wider than the zero-bias buffer");
   if (x3 && with_res && !last_cb->gps) BSMI_FAIL(BSMI_ERR_STATE, "training plan: the residual source has no split copy");
@@ -1933,6 +1941,8 @@ int bsmi_unet_train_begin(bsmi_unet* h, const int64_t in_shape[3]) {
   if (env_on("BSMI_TRAIN_WSTREAM")) {
     BSMI_HIP(hipStreamCreateWithFlags(&ts->wstream, hipStreamNonBlocking));
     BSMI_HIP(hipEventCreateWithFlags(&ts->ev_join, hipEventDisableTiming));
+    BSMI_HIP(hipEventCreateWithFlags(&ts->ev_adam, hipEventDisableTiming));
+    BSMI_HIP(hipEventCreateWithFlags(&ts->ev_packed, hipEventDisableTiming));
     for (size_t i = 0; i < ts->convs.size(); ++i)
       if (plan.steps[i].type == PlanStep::CONV) BSMI_HIP(hipEventCreateWithFlags(&ts->convs[i].ev_g, hipEventDisableTiming));
   }
@@ -1991,6 +2001,10 @@ int bsmi_unet_train_forward_backward(bsmi_unet* h, const float* raw_dev, const f
                        (const double*)ts->loss_sums, ts->head_dp[hd], ts->loss_dev);
   }
   // backward through the plan
+  if (ts->packed_pending) {  // the input-gradient images of the last optimizer step (packed on the side stream)
+    BSMI_HIP(hipStreamWaitEvent(s, ts->ev_packed, 0));
+    ts->packed_pending = false;
+  }
   for (size_t i = plan.steps.size(); i-- > 0;) {
     const PlanStep& st = plan.steps[i];
     switch (st.type) {
@@ -2339,7 +2353,20 @@ int bsmi_unet_train_adam_step(bsmi_unet* h, float lr, float beta1, float beta2, 
   const float bc2 = 1.f - powf(beta2, (float)ts->adam_t);
   hipLaunchKernelGGL(adam_kernel, dim3(1024), dim3(256), 0, s, ts->w, (const float*)ts->g, ts->m, ts->v, ts->nparams, lr, beta1, beta2, eps, bc1, sqrtf(bc2),
                      grad_scale);
-  int rc = run_pack_jobs(ts, s, /*lazy_f32=*/true);
+  int rc;
+  if (ts->wstream) {
+    // the images of the input-gradient launches are first read in the NEXT backward pass: they are packed on the side stream,
+    // beside the forward images here and the forward pass that follows (bsmi_unet_train_forward_backward waits for ev_packed
+    // before its backward pass)
+    BSMI_HIP(hipEventRecord(ts->ev_adam, s));
+    BSMI_HIP(hipStreamWaitEvent(ts->wstream, ts->ev_adam, 0));
+    if ((rc = run_pack_jobs(ts, ts->wstream, true, false, 2))) return rc;
+    BSMI_HIP(hipEventRecord(ts->ev_packed, ts->wstream));
+    ts->packed_pending = true;
+    rc = run_pack_jobs(ts, s, true, false, 1);
+  } else {
+    rc = run_pack_jobs(ts, s, /*lazy_f32=*/true);
+  }
   if (rc) return rc;
   for (HeadSite& hd : h->heads) {
     const std::string pre = hd.prefix;
