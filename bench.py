@@ -413,7 +413,7 @@ def train_main(args):
     from bootstrapper_amd.training import Trainer
     from bootstrapper_amd.synth import synthetic_state_dict
     def run(arithmetic, steps, warmup):
-        return train_run(dev, local_rank, rank, world, arithmetic, steps, warmup)
+        return train_run(dev, local_rank, rank, world, arithmetic, steps, warmup, deterministic=args.train_deterministic)
 
     dt, loss, grads, fwd = run(args.train_arithmetic, args.steps, args.warmup)
     step_flops = 3.0 * fwd  # forward + input gradients + weight gradients
@@ -514,6 +514,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--mode", default="predict", choices=["predict", "train"],
                     help="predict = the headline predict + segment benchmark; train = training-step samples/s (secondary)")
+    ap.add_argument("--train-deterministic", action="store_true", help="--mode train: Trainer(deterministic=True), ordered reductions")
     ap.add_argument("--train-arithmetic", default="split-bf16", choices=["split-bf16", "f32"],
                     help="--mode train: split-bf16 (default; convolutions as bf16 hi + lo products) or f32 (exact f32 MFMA)")
     ap.add_argument("--gpus", type=int, default=1)

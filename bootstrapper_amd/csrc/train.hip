@@ -233,17 +233,34 @@ __global__ void loss_sums_kernel(const float* __restrict__ p, const float* __res
 // Ordered fold of per-workgroup partial sums (deterministic mode): out[i] (+)= part[0][i] + part[1][i] + ... in that order, one
 // thread per column i < width; rows are `stride` values apart.  The same bits whatever order the workgroups ran in.
 template <typename T>
-__global__ void fold_kernel(const T* __restrict__ part, int nparts, int stride, int width, T* __restrict__ out0, T* __restrict__ out1, int assign) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= width) return;
+__global__ __launch_bounds__(1024) void fold_kernel(const T* __restrict__ part, int nparts, int stride, int width, T* __restrict__ out0,
+                                                    T* __restrict__ out1, int assign) {
+  // a workgroup = 32 columns x 32 chunk lanes: lane l adds rows l, l + 32, l + 64, ... in that order, then the 32 lanes' sums are
+  // added in lane order -- a fixed tree, whatever the order the partial results were produced in
+  __shared__ T lanes[32][33];
+  const int col = threadIdx.x & 31, l = threadIdx.x >> 5;
+  const int i = blockIdx.x * 32 + col;
   T acc = 0;
-  for (int pidx = 0; pidx < nparts; ++pidx) acc += part[(size_t)pidx * stride + i];
+  if (i < width) {
+    int pidx = l;
+    for (; pidx + 96 < nparts; pidx += 128) {  // four loads in flight, added in row order
+      const T a0 = part[(size_t)pidx * stride + i], a1 = part[(size_t)(pidx + 32) * stride + i];
+      const T a2 = part[(size_t)(pidx + 64) * stride + i], a3 = part[(size_t)(pidx + 96) * stride + i];
+      acc += a0; acc += a1; acc += a2; acc += a3;
+    }
+    for (; pidx < nparts; pidx += 32) acc += part[(size_t)pidx * stride + i];
+  }
+  lanes[l][col] = acc;
+  __syncthreads();
+  if (l != 0 || i >= width) return;
+  T sum = 0;
+  for (int k = 0; k < 32; ++k) sum += lanes[k][col];
   if (assign) {
-    out0[i] = acc;
-    if (out1) out1[i] = acc;
+    out0[i] = sum;
+    if (out1) out1[i] = sum;
   } else {
-    out0[i] += acc;
-    if (out1) out1[i] += acc;
+    out0[i] += sum;
+    if (out1) out1[i] += sum;
   }
 }
 
@@ -434,7 +451,7 @@ __global__ void colsum_kernel(const float* __restrict__ g, int D, int H, int W, 
                               float* __restrict__ out0, float* __restrict__ out1, float* __restrict__ part) {
   const int Hp = H + 2 * py, Wp = W + 2 * px;
   const int lanes = blockDim.x / Cc;  // voxels handled side by side
-  if ((int)threadIdx.x >= lanes * Cc) return;
+  if ((int)threadIdx.x >= lanes * Cc) return;  // (none: the launcher's block size is a multiple of Cc)
   const int c = c0 + (int)threadIdx.x % Cc;
   // one line of the interior per lane group and trip: no division per element (64-bit ones cost more than the load)
   const int nrows = D * H;
@@ -451,8 +468,15 @@ __global__ void colsum_kernel(const float* __restrict__ g, int D, int H, int W, 
     if (x < W) a0 += gl[(size_t)x * C];
     acc += a0 + a1;
   }
-  if (part) {  // deterministic mode: part[block * lanes + lane group][C] for fold_kernel
-    part[((size_t)blockIdx.x * lanes + threadIdx.x / Cc) * C + c] = acc;
+  if (part) {  // deterministic mode: the lane groups in index order, then part[block][C] for fold_kernel
+    extern __shared__ float cs_red[];  // [lanes][Cc]
+    cs_red[threadIdx.x] = acc;
+    __syncthreads();
+    if ((int)threadIdx.x < Cc) {
+      float sum = 0.f;
+      for (int lg = 0; lg < lanes; ++lg) sum += cs_red[lg * Cc + threadIdx.x];
+      part[(size_t)blockIdx.x * C + c] = sum;
+    }
     return;
   }
   if (c < nreal && acc != 0.f) {
@@ -1996,7 +2020,7 @@ int bsmi_unet_train_forward_backward(bsmi_unet* h, const float* raw_dev, const f
     BSMI_HIP(hipMemsetAsync(ts->loss_sums, 0, 4 * sizeof(double), s));
     hipLaunchKernelGGL(loss_sums_kernel, dim3(512), dim3(256), 0, s, (const float*)ts->head_out[hd], targets_dev[hd], weights_dev[hd], n, ts->loss_sums,
                        det ? ts->loss_part : (double*)nullptr);
-    if (det) hipLaunchKernelGGL(fold_kernel<double>, dim3(1), dim3(64), 0, s, (const double*)ts->loss_part, 512, 4, 4, ts->loss_sums, (double*)nullptr, 1);
+    if (det) hipLaunchKernelGGL(fold_kernel<double>, dim3(1), dim3(1024), 0, s, (const double*)ts->loss_part, 512, 4, 4, ts->loss_sums, (double*)nullptr, 1);
     hipLaunchKernelGGL(loss_grad_kernel, dim3(512), dim3(256), 0, s, (const float*)ts->head_out[hd], targets_dev[hd], weights_dev[hd], n,
                        (const double*)ts->loss_sums, ts->head_dp[hd], ts->loss_dev);
   }
@@ -2026,8 +2050,8 @@ int bsmi_unet_train_forward_backward(bsmi_unet* h, const float* raw_dev, const f
                            hd.cout, (const float*)hd.hw, (float*)dz.ptr, gwc, gwr, gbc, gbr, det ? (float*)ts->det_part : (float*)nullptr);
         if (det) {  // the workgroups' rows in index order: weights, then biases
           const int nw = hd.cout * hd.cin;
-          hipLaunchKernelGGL(fold_kernel<float>, dim3((nw + 63) / 64), dim3(64), 0, s, (const float*)ts->det_part, (int)hblocks, nred, nw, gwc, gwr, 0);
-          hipLaunchKernelGGL(fold_kernel<float>, dim3(1), dim3(64), 0, s, (const float*)ts->det_part + nw, (int)hblocks, nred, hd.cout, gbc, gbr, 0);
+          hipLaunchKernelGGL(fold_kernel<float>, dim3((nw + 31) / 32), dim3(1024), 0, s, (const float*)ts->det_part, (int)hblocks, nred, nw, gwc, gwr, 0);
+          hipLaunchKernelGGL(fold_kernel<float>, dim3((hd.cout + 31) / 32), dim3(1024), 0, s, (const float*)ts->det_part + nw, (int)hblocks, nred, hd.cout, gbc, gbr, 0);
         }
         BSMI_HIP(hipEventRecord(ts->groups[ts->group_of[hd.prefix]].ev, s));
         break;
@@ -2088,13 +2112,14 @@ int bsmi_unet_train_forward_backward(bsmi_unet* h, const float* raw_dev, const f
             const int Cc = std::min(512, st.out.Cpad - c0);
             const int threads = std::max(Cc, 256 / Cc * Cc);
             const int lanes = threads / Cc;
-            if (det && (rc = grow_buf(s, &ts->det_part, &ts->det_part_bytes, (size_t)256 * lanes * st.out.Cpad * sizeof(float), false))) return rc;
-            hipLaunchKernelGGL(colsum_kernel, dim3(256), dim3(threads), 0, s, (const float*)cb.gp.ptr, st.out.D, st.out.H, st.out.W, st.out.Cpad, c0, Cc,
+            if (det && (rc = grow_buf(s, &ts->det_part, &ts->det_part_bytes, (size_t)256 * st.out.Cpad * sizeof(float), false))) return rc;
+            if (threads != lanes * Cc) BSMI_FAIL(BSMI_ERR_STATE, "column sums: block of %d threads for %d channels", threads, Cc);
+            hipLaunchKernelGGL(colsum_kernel, dim3(256), dim3(threads), det ? (size_t)threads * sizeof(float) : 0, s, (const float*)cb.gp.ptr, st.out.D, st.out.H, st.out.W, st.out.Cpad, c0, Cc,
                                cb.P[0], cb.P[1], cb.P[2], p.cout, gb, gbr, det ? (float*)ts->det_part : (float*)nullptr);
             if (det) {  // the real channels of this chunk, rows in index order
               const int wd = std::min(Cc, p.cout - c0);
               if (wd > 0)
-                hipLaunchKernelGGL(fold_kernel<float>, dim3((wd + 63) / 64), dim3(64), 0, s, (const float*)ts->det_part + c0, 256 * lanes, st.out.Cpad, wd,
+                hipLaunchKernelGGL(fold_kernel<float>, dim3((wd + 31) / 32), dim3(1024), 0, s, (const float*)ts->det_part + c0, 256, st.out.Cpad, wd,
                                    gb + c0, gbr ? gbr + c0 : (float*)nullptr, 0);
             }
           }
