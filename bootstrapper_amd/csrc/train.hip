@@ -979,6 +979,48 @@ __global__ __launch_bounds__(256) void wgrad_finish_kernel(float* __restrict__ d
   }
 }
 
+// The same for the deterministic mode's nz copies: 1024 threads = 256 (n, c) x 4 tap groups (a narrow layer is ONE workgroup here
+// and its launches were cut into many line ranges: 27 taps x nz dependent loads per thread took milliseconds); four copies are in
+// flight at a time and are added in z order.
+constexpr int kDetMaxRanges = 32;  // line ranges per launch in the deterministic mode (launch_wgrad_x3_t)
+__global__ __launch_bounds__(1024) void wgrad_finish_det_kernel(float* __restrict__ dwt, float* __restrict__ dw, size_t nc, int ntap, int nz,
+                                                                size_t zstride) {
+  __shared__ float tile[256 * 28];
+  const size_t i0 = (size_t)blockIdx.x * 256;
+  const int n = (int)min((size_t)256, nc - i0);
+  const int tid = threadIdx.x & 255, tg = threadIdx.x >> 8;
+  if (tid < n)
+    for (int t = tg; t < ntap; t += 4) {
+      float* q = dwt + (size_t)t * nc + i0 + tid;
+      float acc = 0.f;
+      int z = 0;
+      for (; z + 3 < nz; z += 4) {
+        float* q0 = q + (size_t)z * zstride;
+        const float v0 = q0[0], v1 = q0[zstride], v2 = q0[2 * zstride], v3 = q0[3 * zstride];
+        acc += v0; acc += v1; acc += v2; acc += v3;
+        if (v0 != 0.f) q0[0] = 0.f;
+        if (v1 != 0.f) q0[zstride] = 0.f;
+        if (v2 != 0.f) q0[2 * zstride] = 0.f;
+        if (v3 != 0.f) q0[3 * zstride] = 0.f;
+      }
+      for (; z < nz; ++z) {
+        float* q0 = q + (size_t)z * zstride;
+        const float v = *q0;
+        acc += v;
+        if (v != 0.f) *q0 = 0.f;
+      }
+      tile[tid * 28 + t] = acc;
+    }
+  __syncthreads();
+  const int total = n * ntap;
+  float* d = dw + i0 * ntap;
+  for (int k = threadIdx.x; k < total; k += 1024) {
+    const int i = k / ntap, t = k - i * ntap;
+    const float v = tile[i * 28 + t];
+    if (v != 0.f) d[k] += v;
+  }
+}
+
 // Which convolutions of the step run as split-bf16 launches: all of them under bsmi_unet_train_set_arithmetic(h, 1)
 // (the default); BSMI_WGRAD_X3 / BSMI_DGRAD_X3 / BSMI_FWD_X3 = 0 take single ones back to f32 (dev knobs, read at begin).
 static bool env_on(const char* name) {
@@ -1008,6 +1050,7 @@ static int launch_wgrad_x3_t(WgradPk a, hipStream_t s) {
   const int nlines = a.Do * a.Ho, trows = a.kz * a.ky;
   const int blocks_nc = ((a.N + TN - 1) / TN) * ((a.C + TC - 1) / TC);
   int zsplit = std::max(1, std::min(nlines, 4096 / std::max(1, blocks_nc * trows)));
+  if (a.zstride) zsplit = std::min(zsplit, kDetMaxRanges);
   const int zcap = a.zsplit;  // deterministic mode: the copies of the workspace the caller has room for
   a.lines_per_block = (nlines + zsplit - 1) / zsplit;
   a.zsplit = (nlines + a.lines_per_block - 1) / a.lines_per_block;
@@ -2145,9 +2188,10 @@ int bsmi_unet_train_forward_backward(bsmi_unet* h, const float* raw_dev, const f
         auto finish = [&](float* dw, int ct, const int* kk) {  // after the launches of one weight tensor
           if (!used_x3) return;
           const size_t nc = (size_t)p.cout * ct;
+          if (det && kk[0] * kk[1] * kk[2] > 27) { x3_rc = BSMI_ERR_INVALID; bsmi::set_error("deterministic weight gradients: kernels of at most 27 taps"); return; }
           if (det)
-            hipLaunchKernelGGL(wgrad_finish_kernel, dim3((unsigned)((nc + 255) / 256)), dim3(256), 0, sw, (float*)ts->gt_det, dw, nc, kk[0] * kk[1] * kk[2],
-                               det_nz, det_numel);
+            hipLaunchKernelGGL(wgrad_finish_det_kernel, dim3((unsigned)((nc + 255) / 256)), dim3(1024), 0, sw, (float*)ts->gt_det, dw, nc,
+                               kk[0] * kk[1] * kk[2], det_nz, det_numel);
           else
             hipLaunchKernelGGL(wgrad_finish_kernel, dim3((unsigned)((nc + 255) / 256)), dim3(256), 0, sw, ts->gt + (dw - ts->g), dw, nc,
                                kk[0] * kk[1] * kk[2], 1, (size_t)0);
@@ -2158,7 +2202,7 @@ int bsmi_unet_train_forward_backward(bsmi_unet* h, const float* raw_dev, const f
         auto x3_zsplit = [&](int N, int C, int nlines, int trows) {
           const int TN = wgrad_tile_n(N), TC = wgrad_tile_c(C);
           const int blocks_nc = ((N + TN - 1) / TN) * ((C + TC - 1) / TC);
-          const int zs = std::max(1, std::min(nlines, 4096 / std::max(1, blocks_nc * trows)));
+          const int zs = std::min(kDetMaxRanges, std::max(1, std::min(nlines, 4096 / std::max(1, blocks_nc * trows))));
           const int lpb = (nlines + zs - 1) / zs;
           return (nlines + lpb - 1) / lpb;
         };
