@@ -126,7 +126,8 @@ int bsmi_unet_train_set_arithmetic(bsmi_unet *h, int split_bf16);
 /* set_deterministic (any time; default 0): 1 = every reduction of the step that float atomics would order by chance -- the loss
  *   sums, the head's and the biases' gradients, the weight gradients of launches cut into line ranges, the transposed
  *   interpolation -- is done as per-workgroup partial results added in index order: two runs of a step on the same inputs give
- *   the same bits (gradients, loss, parameters after Adam), like the reference's CPU path.  Costs a few per cent of the step. */
+ *   the same bits (gradients, loss, parameters after Adam), like the reference's CPU path.  Costs about an eighth of the step
+ *   (21.2 against 18.7 ms on the (32,196,196) block). */
 int bsmi_unet_train_set_deterministic(bsmi_unet *h, int on);
 int bsmi_unet_train_begin(bsmi_unet *h, const int64_t in_shape[3]);
 int bsmi_unet_train_forward_backward(bsmi_unet *h, const float *raw_dev, const float *const *targets_dev,
