@@ -301,8 +301,10 @@ def run_training(config_file, device=0, batches=None, log=print):
         log(f"resuming from {ckpt}")
     else:
         model.load_state_dict(default_init(net_config, seed=42))
-    # `arithmetic` (an addition to the reference's train config): "split-bf16" (default) or "f32", see training.Trainer
-    trainer = Trainer(model, net_config["input_shape"], arithmetic=config.get("arithmetic", "split-bf16"))
+    # `arithmetic`, `deterministic` (additions to the reference's train config): "split-bf16" (default) or "f32"; ordered
+    # reductions so that two runs from the same state give the same bits (default false), see training.Trainer
+    trainer = Trainer(model, net_config["input_shape"], arithmetic=config.get("arithmetic", "split-bf16"),
+                      deterministic=bool(config.get("deterministic", False)))
     if ckpt and load_optimizer_state(trainer, ckpt):
         log(f"optimizer state restored (step {trainer.step_count()})")
     if batches is None:
