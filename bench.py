@@ -376,18 +376,19 @@ def train_run(dev, local_rank, rank, world, arithmetic, steps, warmup, determini
 def train_leg(dev, local_rank):
     """The training step beside the headline (default run, one GPU): 10 steps in the default split-bf16 arithmetic, 4 in exact
     f32, and how far the first-step gradients of the two are apart."""
-    dt, loss, grads, fwd = train_run(dev, local_rank, 0, 1, "split-bf16", 10, 2)
+    NS = 20  # steps timed after 5 untimed ones (the first steps grow scratch buffers and ramp the clocks: 10 after 2 read 1.2 ms high)
+    dt, loss, grads, fwd = train_run(dev, local_rank, 0, 1, "split-bf16", NS, 5)
     dt32, loss32, grads32, _ = train_run(dev, local_rank, 0, 1, "f32", 4, 1)
     # Trainer(deterministic=True): ordered folds instead of float atomics; twice, to report that the two runs end on the same bits
-    dtd, lossd, gradsd, _ = train_run(dev, local_rank, 0, 1, "split-bf16", 10, 2, deterministic=True)
-    _, lossd2, gradsd2, _ = train_run(dev, local_rank, 0, 1, "split-bf16", 10, 2, deterministic=True)
+    dtd, lossd, gradsd, _ = train_run(dev, local_rank, 0, 1, "split-bf16", NS, 5, deterministic=True)
+    _, lossd2, gradsd2, _ = train_run(dev, local_rank, 0, 1, "split-bf16", NS, 5, deterministic=True)
     step_flops = 3.0 * fwd
     return {"what": "3d_affs U-Net (94.7M params) forward + WeightedMSELoss + backward + Adam, block (32,196,196) -> (6,4,104,104), batch 1; "
                     "`bench.py --mode train` is the full line",
-            "split-bf16": {"ms_per_step": dt / 10 * 1e3, "samples_per_s": 10 / dt, "tflops": step_flops * 10 / dt / 1e12,
-                           "frac_of_split_peak": step_flops * 10 / dt / 1e12 / X3_PEAK, "last_loss": loss},
+            "split-bf16": {"ms_per_step": dt / NS * 1e3, "samples_per_s": NS / dt, "tflops": step_flops * NS / dt / 1e12,
+                           "frac_of_split_peak": step_flops * NS / dt / 1e12 / X3_PEAK, "last_loss": loss},
             "f32": {"ms_per_step": dt32 / 4 * 1e3, "samples_per_s": 4 / dt32, "tflops": step_flops * 4 / dt32 / 1e12, "last_loss": loss32},
-            "split-bf16 deterministic": {"ms_per_step": dtd / 10 * 1e3, "last_loss": lossd,
+            "split-bf16 deterministic": {"ms_per_step": dtd / NS * 1e3, "last_loss": lossd,
                                          "two_runs_bit_equal": bool(torch.equal(gradsd, gradsd2) and lossd == lossd2),
                                          "max_gradient_difference_to_default_rel": float((gradsd - grads).abs().max() / grads.abs().max())},
             "max_gradient_difference_rel": float((grads - grads32).abs().max() / grads32.abs().max())}
@@ -547,7 +548,9 @@ def main():
     args = ap.parse_args()
     if args.mode == "train":
         if "--steps" not in sys.argv:
-            args.steps = 10
+            args.steps = 20
+        if "--warmup" not in sys.argv:
+            args.warmup = 5  # the first steps grow scratch buffers and ramp the clocks
         return train_main(args)
 
     rank = int(os.environ.get("RANK", "0"))
