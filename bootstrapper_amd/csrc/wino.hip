@@ -415,11 +415,18 @@ __device__ __forceinline__ void store_split4(uint16_t* base, size_t e, int hf, c
 }
 
 // CH (2 or 4) channels of a split tensor at element index e: sub-vector `sub` of the 8-channel group
+// The two lanes that share an 8-channel group (CH = 4: neighbouring lanes, sub = lane parity) move it as ONE 16-byte access
+// each -- the even lane the hi vector, the odd lane the lo vector -- and swap halves through a DPP move: a wave's access is
+// 1 KiB of whole cache lines instead of two accesses that each touch every other 16 bytes.
+__device__ __forceinline__ uint32_t swap_pair(uint32_t v) { return (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0xB1, 0xF, 0xF, true); }  // quad_perm [1,0,3,2]
 template <int CH>
 __device__ __forceinline__ void load_split_n(const uint16_t* base, size_t e, int sub, float* f) {
   const uint16_t* p = base + 2 * e + CH * sub;
   if constexpr (CH == 4) {
-    const u32x2_t h = *(const u32x2_t*)p, l = *(const u32x2_t*)(p + 8);
+    const u32x4_t mine = *(const u32x4_t*)(base + 2 * e + 8 * sub);  // even lane: hi of the 8 channels, odd lane: lo
+    const uint32_t r0 = swap_pair(sub ? mine.x : mine.z), r1 = swap_pair(sub ? mine.y : mine.w);
+    const u32x2_t h = {sub ? r0 : mine.x, sub ? r1 : mine.y}, l = {sub ? mine.z : r0, sub ? mine.w : r1};
+    (void)p;
     f[0] = __uint_as_float(h.x << 16) + __uint_as_float(l.x << 16);
     f[1] = __uint_as_float(h.x & 0xffff0000u) + __uint_as_float(l.x & 0xffff0000u);
     f[2] = __uint_as_float(h.y << 16) + __uint_as_float(l.y << 16);
@@ -442,8 +449,10 @@ __device__ __forceinline__ void store_split_n(uint16_t* base, size_t e, int sub,
   if constexpr (CH == 4) {
     const u32x2_t hv = {(uint32_t)hb[0] | ((uint32_t)hb[1] << 16), (uint32_t)hb[2] | ((uint32_t)hb[3] << 16)};
     const u32x2_t lv = {(uint32_t)lb[0] | ((uint32_t)lb[1] << 16), (uint32_t)lb[2] | ((uint32_t)lb[3] << 16)};
-    *(u32x2_t*)p = hv;
-    *(u32x2_t*)(p + 8) = lv;
+    const uint32_t r0 = swap_pair(sub ? hv.x : lv.x), r1 = swap_pair(sub ? hv.y : lv.y);  // the odd lane's hi / the even lane's lo
+    const u32x4_t out = {sub ? r0 : hv.x, sub ? r1 : hv.y, sub ? lv.x : r0, sub ? lv.y : r1};
+    *(u32x4_t*)(base + 2 * e + 8 * sub) = out;
+    (void)p;
   } else {
     *(uint32_t*)p = (uint32_t)hb[0] | ((uint32_t)hb[1] << 16);
     *(uint32_t*)(p + 8) = (uint32_t)lb[0] | ((uint32_t)lb[1] << 16);
@@ -470,7 +479,7 @@ __device__ __forceinline__ void bt4_apply_n(const float (*d)[CH], float (*r)[CH]
 // reaches outputs that are never stored.  CH = 4 needs 280 registers -- ONE wave per SIMD, and the kernel waited on memory for
 // half of its cycles at 3.7 TB/s; CH = 2 (BSMI_WINO_IN_CH) halves the per-thread state.
 template <int CH>
-__global__ __launch_bounds__(256, CH == 2 ? 3 : 1) void wino4_in_kernel(const WinoInArgs a, int src, size_t total) {
+__global__ __launch_bounds__(256) void wino4_in_kernel(const WinoInArgs a, int src, size_t total) {
   const unsigned nb = gridDim.x, q = nb >> 3, r = nb & 7, xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
   const unsigned blk = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + j;
   const size_t i = (size_t)blk * blockDim.x + threadIdx.x;
@@ -712,8 +721,8 @@ int launch_wino_in(const WinoInArgs& a, hipStream_t s) {
     // F(4x4): the last tile row / column may overhang by up to three voxels (clamped reads); more than that is a planning error
     if (m == 4 && (a.oy[q] < 0 || a.ox[q] < 0 || a.oy[q] + 4 * a.Ty + 2 > a.H[q] * upf + 3 || a.ox[q] + 4 * a.Tx + 2 > a.W[q] * upf + 3))
       BSMI_FAIL(BSMI_ERR_INVALID, "winograd input transform: F(4x4) tiles leave source %d by more than a tile's overhang", q);
-    // BSMI_WINO_IN_CH: channels per thread of the plain F(4x4) input transform (2, the default, or 4)
-    static const int in_ch = [] { const char* e = getenv("BSMI_WINO_IN_CH"); return e && e[0] == '4' ? 4 : 2; }();
+    // BSMI_WINO_IN_CH: channels per thread of the plain F(4x4) input transform (4, the default, or 2)
+    static const int in_ch = [] { const char* e = getenv("BSMI_WINO_IN_CH"); return e && e[0] == '2' ? 2 : 4; }();
     const bool plain4 = m == 4 && a.upf[q] <= 0;
     const size_t total = (size_t)a.Dv * a.Ty * (a.Cpad[q] / (plain4 ? in_ch : (m == 4 ? 4 : 8)));  // one thread per (z, tile row, 8 / 4 / 2 channels)
     const dim3 grid((unsigned)((total + 255) / 256));
