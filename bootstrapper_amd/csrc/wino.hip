@@ -414,79 +414,16 @@ __device__ __forceinline__ void store_split4(uint16_t* base, size_t e, int hf, c
   *(u32x2_t*)(p + 8) = lv;
 }
 
-// CH (2 or 4) channels of a split tensor at element index e: sub-vector `sub` of the 8-channel group
-// The two lanes that share an 8-channel group (CH = 4: neighbouring lanes, sub = lane parity) move it as ONE 16-byte access
-// each -- the even lane the hi vector, the odd lane the lo vector -- and swap halves through a DPP move: a wave's access is
-// 1 KiB of whole cache lines instead of two accesses that each touch every other 16 bytes.
-__device__ __forceinline__ uint32_t swap_pair(uint32_t v) { return (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0xB1, 0xF, 0xF, true); }  // quad_perm [1,0,3,2]
-template <int CH>
-__device__ __forceinline__ void load_split_n(const uint16_t* base, size_t e, int sub, float* f) {
-  const uint16_t* p = base + 2 * e + CH * sub;
-  if constexpr (CH == 4) {
-    const u32x4_t mine = *(const u32x4_t*)(base + 2 * e + 8 * sub);  // even lane: hi of the 8 channels, odd lane: lo
-    const uint32_t r0 = swap_pair(sub ? mine.x : mine.z), r1 = swap_pair(sub ? mine.y : mine.w);
-    const u32x2_t h = {sub ? r0 : mine.x, sub ? r1 : mine.y}, l = {sub ? mine.z : r0, sub ? mine.w : r1};
-    (void)p;
-    f[0] = __uint_as_float(h.x << 16) + __uint_as_float(l.x << 16);
-    f[1] = __uint_as_float(h.x & 0xffff0000u) + __uint_as_float(l.x & 0xffff0000u);
-    f[2] = __uint_as_float(h.y << 16) + __uint_as_float(l.y << 16);
-    f[3] = __uint_as_float(h.y & 0xffff0000u) + __uint_as_float(l.y & 0xffff0000u);
-  } else {
-    const uint32_t h = *(const uint32_t*)p, l = *(const uint32_t*)(p + 8);
-    f[0] = __uint_as_float(h << 16) + __uint_as_float(l << 16);
-    f[1] = __uint_as_float(h & 0xffff0000u) + __uint_as_float(l & 0xffff0000u);
-  }
-}
-template <int CH>
-__device__ __forceinline__ void store_split_n(uint16_t* base, size_t e, int sub, const float* f) {
-  uint16_t* p = base + 2 * e + CH * sub;
-  uint16_t hb[CH], lb[CH];
-#pragma unroll
-  for (int k = 0; k < CH; ++k) {
-    hb[k] = to_bf16(f[k]);
-    lb[k] = to_bf16(f[k] - __uint_as_float((uint32_t)hb[k] << 16));
-  }
-  if constexpr (CH == 4) {
-    const u32x2_t hv = {(uint32_t)hb[0] | ((uint32_t)hb[1] << 16), (uint32_t)hb[2] | ((uint32_t)hb[3] << 16)};
-    const u32x2_t lv = {(uint32_t)lb[0] | ((uint32_t)lb[1] << 16), (uint32_t)lb[2] | ((uint32_t)lb[3] << 16)};
-    const uint32_t r0 = swap_pair(sub ? hv.x : lv.x), r1 = swap_pair(sub ? hv.y : lv.y);  // the odd lane's hi / the even lane's lo
-    const u32x4_t out = {sub ? r0 : hv.x, sub ? r1 : hv.y, sub ? lv.x : r0, sub ? lv.y : r1};
-    *(u32x4_t*)(base + 2 * e + 8 * sub) = out;
-    (void)p;
-  } else {
-    *(uint32_t*)p = (uint32_t)hb[0] | ((uint32_t)hb[1] << 16);
-    *(uint32_t*)(p + 8) = (uint32_t)lb[0] | ((uint32_t)lb[1] << 16);
-  }
-}
-// r = B^T d for one column of six values, CH channels each
-template <int CH>
-__device__ __forceinline__ void bt4_apply_n(const float (*d)[CH], float (*r)[CH]) {
-#pragma unroll
-  for (int k = 0; k < CH; ++k) {
-    const float e = 2.f * d[2][k] - d[4][k], o = kR2 * (d[1][k] - 0.5f * d[3][k]);
-    const float e2 = 2.f * d[4][k] - d[2][k], o2 = kR2 * (2.f * d[3][k] - d[1][k]);
-    r[0][k] = d[0][k] - 2.5f * d[2][k] + d[4][k];
-    r[1][k] = e + o;
-    r[2][k] = e - o;
-    r[3][k] = e2 + o2;
-    r[4][k] = e2 - o2;
-    r[5][k] = d[1][k] - 2.5f * d[3][k] + d[5][k];
-  }
-}
-
-// One thread: CH channels along one row of tiles (z, ty); neighbouring tiles share two of their six input columns, whose
+// One thread: 4 channels along one row of tiles (z, ty); neighbouring tiles share two of their six input columns, whose
 // row transforms are kept.  Rows / columns past the source (overhanging last tiles) are clamped: whatever they hold only
-// reaches outputs that are never stored.  CH = 4 needs 280 registers -- ONE wave per SIMD, and the kernel waited on memory for
-// half of its cycles at 3.7 TB/s; CH = 2 (BSMI_WINO_IN_CH) halves the per-thread state.
-template <int CH>
+// reaches outputs that are never stored.
 __global__ __launch_bounds__(256) void wino4_in_kernel(const WinoInArgs a, int src, size_t total) {
   const unsigned nb = gridDim.x, q = nb >> 3, r = nb & 7, xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
   const unsigned blk = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + j;
   const size_t i = (size_t)blk * blockDim.x + threadIdx.x;
   if (i >= total) return;
-  constexpr int SUBS = 8 / CH;  // threads per 8-channel group
-  const int ncg = a.Cpad[src] / CH;
-  const int cg = (int)(i % ncg), cv = cg / SUBS, hf = cg % SUBS;
+  const int ncg = a.Cpad[src] >> 2;
+  const int cg = (int)(i % ncg), cv = cg >> 1, hf = cg & 1;
   const size_t t = i / ncg;
   const int ty = (int)(t % a.Ty);
   const int z = (int)(t / a.Ty);
@@ -502,14 +439,14 @@ __global__ __launch_bounds__(256) void wino4_in_kernel(const WinoInArgs a, int s
   uint16_t* V = (uint16_t*)a.V;
   const size_t plane = (size_t)a.Dv * a.Ty * a.Tx * a.Cv;
   const size_t e_out = (((size_t)z * a.Ty + ty) * a.Tx) * a.Cv + a.cv0[src] + 8 * cv;
-  float col[6][6][CH];  // col[c][xi]: (B^T d)[xi] of input column 4 tx + c
+  float col[6][6][4];  // col[c][xi]: (B^T d)[xi] of input column 4 tx + c
   auto load_col = [&](int c, int x) __attribute__((always_inline)) {
     x += a.ox[src];
     x = x < W - 1 ? x : W - 1;
-    float d[6][CH];
+    float d[6][4];
 #pragma unroll
-    for (int rr = 0; rr < 6; ++rr) load_split_n<CH>(sp, erow[rr] + (size_t)x * C, hf, d[rr]);
-    bt4_apply_n<CH>(d, col[c]);
+    for (int rr = 0; rr < 6; ++rr) load_split4(sp, erow[rr] + (size_t)x * C, hf, d[rr]);
+    bt4_apply(d, col[c]);
   };
   load_col(0, 0);
   load_col(1, 1);
@@ -519,19 +456,19 @@ __global__ __launch_bounds__(256) void wino4_in_kernel(const WinoInArgs a, int s
     const size_t e0 = e_out + (size_t)tx * a.Cv;
 #pragma unroll
     for (int xi = 0; xi < 6; ++xi) {
-      float in[6][CH], v[6][CH];
+      float in[6][4], v[6][4];
 #pragma unroll
       for (int c = 0; c < 6; ++c)
 #pragma unroll
-        for (int k = 0; k < CH; ++k) in[c][k] = col[c][xi][k];
-      bt4_apply_n<CH>(in, v);
+        for (int k = 0; k < 4; ++k) in[c][k] = col[c][xi][k];
+      bt4_apply(in, v);
 #pragma unroll
-      for (int nu = 0; nu < 6; ++nu) store_split_n<CH>(V, (size_t)(6 * xi + nu) * plane + e0, hf, v[nu]);
+      for (int nu = 0; nu < 6; ++nu) store_split4(V, (size_t)(6 * xi + nu) * plane + e0, hf, v[nu]);
     }
 #pragma unroll
     for (int xi = 0; xi < 6; ++xi)
 #pragma unroll
-      for (int k = 0; k < CH; ++k) {
+      for (int k = 0; k < 4; ++k) {
         col[0][xi][k] = col[4][xi][k];
         col[1][xi][k] = col[5][xi][k];
       }
@@ -721,10 +658,7 @@ int launch_wino_in(const WinoInArgs& a, hipStream_t s) {
     // F(4x4): the last tile row / column may overhang by up to three voxels (clamped reads); more than that is a planning error
     if (m == 4 && (a.oy[q] < 0 || a.ox[q] < 0 || a.oy[q] + 4 * a.Ty + 2 > a.H[q] * upf + 3 || a.ox[q] + 4 * a.Tx + 2 > a.W[q] * upf + 3))
       BSMI_FAIL(BSMI_ERR_INVALID, "winograd input transform: F(4x4) tiles leave source %d by more than a tile's overhang", q);
-    // BSMI_WINO_IN_CH: channels per thread of the plain F(4x4) input transform (4, the default, or 2)
-    static const int in_ch = [] { const char* e = getenv("BSMI_WINO_IN_CH"); return e && e[0] == '2' ? 2 : 4; }();
-    const bool plain4 = m == 4 && a.upf[q] <= 0;
-    const size_t total = (size_t)a.Dv * a.Ty * (a.Cpad[q] / (plain4 ? in_ch : (m == 4 ? 4 : 8)));  // one thread per (z, tile row, 8 / 4 / 2 channels)
+    const size_t total = (size_t)a.Dv * a.Ty * (a.Cpad[q] / (m == 4 ? 4 : 8));  // one thread per (z, tile row, 8 resp. 4 channels)
     const dim3 grid((unsigned)((total + 255) / 256));
     if (a.upf[q] > 0) {
       if (a.upf[q] != 2 || a.oy[q] < 0 || a.ox[q] < 0) BSMI_FAIL(BSMI_ERR_INVALID, "winograd input transform: only a factor-2 upsampling can be fused");
@@ -739,8 +673,7 @@ int launch_wino_in(const WinoInArgs& a, hipStream_t s) {
       else if (par == 2) hipLaunchKernelGGL((wino_in_up_kernel<1, 0>), grid, dim3(256), 0, s, a, q, total);
       else hipLaunchKernelGGL((wino_in_up_kernel<1, 1>), grid, dim3(256), 0, s, a, q, total);
     } else if (m == 4) {
-      if (in_ch == 4) hipLaunchKernelGGL(wino4_in_kernel<4>, grid, dim3(256), 0, s, a, q, total);
-      else hipLaunchKernelGGL(wino4_in_kernel<2>, grid, dim3(256), 0, s, a, q, total);
+      hipLaunchKernelGGL(wino4_in_kernel, grid, dim3(256), 0, s, a, q, total);
     } else {
       hipLaunchKernelGGL(wino_in_kernel, grid, dim3(256), 0, s, a, q, total);
     }
