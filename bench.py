@@ -536,6 +536,7 @@ def main():
     ap.add_argument("--overlap-lanes", type=int, default=3, help="--overlap: lanes that take tasks while blocks are still being predicted")
     ap.add_argument("--no-segment", action="store_true", help="predict only (diagnostic; not the headline metric)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--pred-lanes", type=int, default=1, help="engines whose forward passes overlap (block k on engine k mod K)")
     ap.add_argument("--no-modes", action="store_true", help="skip the per-precision predict lines (speed and error of f32 / bf16x3 / bf16)")
     ap.add_argument("--no-train", action="store_true", help="skip the `train` leg (ms per training step in both arithmetics)")
     ap.add_argument("--no-drivers", action="store_true", help="skip the `drivers` leg (bs predict + bs segment on an on-disk Zarr store of the whole volume)")
@@ -596,6 +597,8 @@ def main():
 
     sd = synthetic_state_dict(NET_CONFIG, 0)
     model = Model(NET_CONFIG, device=local_rank, precision=args.precision).load_state_dict(sd)
+    # predict lanes: engines with the same weights whose forward passes overlap (VolumePipeline); `model` is lane 0
+    engines = [model] + [Model(NET_CONFIG, device=local_rank, precision=args.precision).load_state_dict(sd) for _ in range(max(1, args.pred_lanes) - 1)]
     in_block = tuple(o + 2 * c for o, c in zip(OUT_BLOCK, CONTEXT))
     flops_block = model.flops(in_block)
     nvox_block = int(np.prod(OUT_BLOCK))
@@ -613,9 +616,9 @@ def main():
     # warm-up: `warmup` blocks through every stage (kernel images, workspaces of the block shapes, process-group channels)
     seg_kw = dict(min_seed_distance=10, filter_fragments=FILTER_FRAGMENTS, remove_debris=REMOVE_DEBRIS)
     # (the timed pipeline's slabs are allocated first, so that nothing but the barrier lies between the warm-up and the timed region)
-    pipe = VolumePipeline(model, OUT_BLOCK, CONTEXT, job, SEG_CONTEXT, THRESHOLDS, n_lanes=args.seg_lanes, device=local_rank,
+    pipe = VolumePipeline(engines, OUT_BLOCK, CONTEXT, job, SEG_CONTEXT, THRESHOLDS, n_lanes=args.seg_lanes, device=local_rank,
                           rank=rank, world=world, segment=not args.no_segment, overlap=args.overlap, obj_group=obj_group, **seg_kw)
-    warm = VolumePipeline(model, OUT_BLOCK, CONTEXT, (max(1, args.warmup), 1, 1), SEG_CONTEXT, THRESHOLDS, n_lanes=args.seg_lanes,
+    warm = VolumePipeline(engines, OUT_BLOCK, CONTEXT, (max(len(engines), args.warmup), 1, 1), SEG_CONTEXT, THRESHOLDS, n_lanes=args.seg_lanes,
                           device=local_rank, rank=rank, world=world, segment=not args.no_segment, obj_group=obj_group, **seg_kw)
     if not args.no_segment:
         pipe.seg.overlap_lanes = args.overlap_lanes

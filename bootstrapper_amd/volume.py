@@ -158,11 +158,13 @@ def io_stream(device):
     return pool[i]
 
 
-def predict_stream(device):
+def predict_stream(device, lane=0):
+    """the stream of predict lane `lane` (0: THE predict stream) of a device"""
     dev = torch.device(device)
-    if dev not in _PREDICT_STREAMS:
-        _PREDICT_STREAMS[dev] = torch.cuda.Stream(dev, priority=-1)
-    return _PREDICT_STREAMS[dev]
+    key = dev if lane == 0 else (dev, int(lane))
+    if key not in _PREDICT_STREAMS:
+        _PREDICT_STREAMS[key] = torch.cuda.Stream(dev, priority=-1)
+    return _PREDICT_STREAMS[key]
 
 
 class SlabSegmenter:
@@ -803,8 +805,13 @@ class VolumePipeline:
                  min_seed_distance=10, filter_fragments=0.0, remove_debris=0, n_lanes=20, device=0, rank=0, world=1,
                  group=None, job_origin=(0, 0, 0), segment=True, overlap=False, obj_group=None):
         """job_blocks: (layers per rank, blocks in y, blocks in x): the job is `world` such slabs stacked along z,
-        its first voxel at `job_origin` of the raw volume."""
-        self.model = model
+        its first voxel at `job_origin` of the raw volume.
+        model: a Model, or a list of Models with the same weights = PREDICT LANES: block k is predicted by engine k mod K on that
+        engine's own stream, so that the forward passes of K blocks overlap -- the memory-bound launches of one pass (Winograd
+        transforms, pooling, the narrow stages) beside the matrix launches of another.  (Each engine has its own activation
+        buffers; overlapping passes are safe since round 4)"""
+        self.models = list(model) if isinstance(model, (list, tuple)) else [model]
+        model = self.model = self.models[0]
         self.out_block = tuple(int(b) for b in out_block)
         self.net_context = tuple(int(c) for c in net_context)
         self.in_block = tuple(o + 2 * c for o, c in zip(self.out_block, self.net_context))
@@ -816,6 +823,7 @@ class VolumePipeline:
         slab = tuple(g * b for g, b in zip(self.job_blocks, self.out_block))
         self.origin = (int(job_origin[0]) + self.rank * slab[0], int(job_origin[1]), int(job_origin[2]))
         self.pred_stream = predict_stream(self.dev)
+        self.pred_streams = [predict_stream(self.dev, i) for i in range(len(self.models))]
         self.seg = SlabSegmenter(slab, self.out_block, seg_context if segment else (0, 0, 0), self.job_blocks[0] * self.world,
                                  self.job_blocks[0] * self.rank, thresholds, True, min_seed_distance, filter_fragments,
                                  remove_debris, 256, n_lanes if segment else 1, device, rank, world, group, obj_group=obj_group)
@@ -829,16 +837,32 @@ class VolumePipeline:
         predict stream; -> one event per block."""
         from .unet import extract_block_reflect
         ready = []
-        with torch.cuda.stream(self.pred_stream):
-            self._t0 = torch.cuda.Event(enable_timing=True)
-            self._t0.record(self.pred_stream)
-            for k, (b, _) in enumerate(self.seg.boxes):
+        K = len(self.models)
+        n = len(self.seg.boxes)
+        self._t0 = torch.cuda.Event(enable_timing=True)
+        self._t0.record(self.pred_stream)
+        for lane in range(1, K):  # the other lanes start where the predict stream is now
+            self.pred_streams[lane].wait_event(self._t0)
+        for k, (b, _) in enumerate(self.seg.boxes):
+            lane = k % K
+            st = self.pred_streams[lane]
+            with torch.cuda.stream(st):
                 off = [o + lo - c for o, lo, c in zip(self.origin, b, self.net_context)]
                 raw = extract_block_reflect(volume_u8, off, self.in_block)
-                u8 = self.model.predict_u8(raw)
+                u8 = self.models[lane].predict_u8(raw)
                 self.seg.write_view(k).copy_(u8[0][:3])
-                ev = torch.cuda.Event(enable_timing=(k + 1 == len(self.seg.boxes)))
-                ev.record(self.pred_stream)
+                last = k + 1 == n
+                if last and K > 1:
+                    # ready[-1] is also "every block is predicted" (run(), bench.py): recorded on the predict stream, after the
+                    # last block of every lane
+                    for j in range(max(0, n - K), n - 1):
+                        self.pred_stream.wait_event(ready[j])
+                    done = torch.cuda.Event()
+                    done.record(st)
+                    self.pred_stream.wait_event(done)
+                    st = self.pred_stream
+                ev = torch.cuda.Event(enable_timing=last)
+                ev.record(st)
                 ready.append(ev)
         return ready
 
