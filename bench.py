@@ -536,7 +536,8 @@ def main():
     ap.add_argument("--overlap-lanes", type=int, default=3, help="--overlap: lanes that take tasks while blocks are still being predicted")
     ap.add_argument("--no-segment", action="store_true", help="predict only (diagnostic; not the headline metric)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--pred-lanes", type=int, default=1, help="engines whose forward passes overlap (block k on engine k mod K)")
+    ap.add_argument("--pred-lanes", type=int, default=2,
+                    help="engines whose forward passes overlap, block k on engine k mod K (measured on 64 blocks: 1 lane 96.4, 2 lanes 103.6, 3 lanes 96.7 Mvoxels/s)")
     ap.add_argument("--no-modes", action="store_true", help="skip the per-precision predict lines (speed and error of f32 / bf16x3 / bf16)")
     ap.add_argument("--no-train", action="store_true", help="skip the `train` leg (ms per training step in both arithmetics)")
     ap.add_argument("--no-drivers", action="store_true", help="skip the `drivers` leg (bs predict + bs segment on an on-disk Zarr store of the whole volume)")
@@ -626,17 +627,21 @@ def main():
     del warm
     if not args.no_segment:
         pipe.seg.prime()   # the slab-sized reductions / relabel kernels once, on the empty slab
-    model.profile(max(1, args.profile_every))
-    model.profile_totals(reset=True)
-    model.profile_executed(reset=True)
+    for m in engines:
+        m.profile(max(1, args.profile_every))
+        m.profile_totals(reset=True)
+        m.profile_executed(reset=True)
     barrier()
     t0 = time.perf_counter()
     segs = pipe.run(vol)
     barrier()
     dt = time.perf_counter() - t0
-    totals = model.profile_totals(reset=True)
-    executed_flops = model.profile_executed(reset=True)
-    model.profile(False)
+    totals, executed_flops = None, 0.0
+    for m in engines:  # the profiled launches of every predict lane together
+        t = m.profile_totals(reset=True)
+        totals = t if totals is None else {k: tuple(a + b for a, b in zip(totals[k], t[k])) for k in t}
+        executed_flops += m.profile_executed(reset=True)
+        m.profile(False)
     t_pred, t_seg = pipe.t_predict, 0.0
     if not args.no_segment:
         # the segmentation half on its own (outside the timed region: there it overlaps the predict stream): the same
@@ -660,6 +665,12 @@ def main():
     peak = MFMA_PEAK_TFLOPS[args.precision]
     traffic, traffic_src = pmc_traffic(args.precision)
     achieved = conv_flops / (conv_ms * 1e-3) / 1e12 if conv_ms > 0 else 0.0
+    # K predict lanes: a launch shares the card with the launches of the other lanes, so its own duration says what ONE lane gets.
+    # How many forward passes were in flight on average = (all engines' profiled launch time, scaled to every block) / predict time
+    unet_ms = sum(v[0] for v in totals.values())
+    per_lane = [len(range(lane, args.steps, len(engines))) for lane in range(len(engines))]   # blocks of each lane
+    profiled_blocks = max(1, sum(-(-n // max(1, args.profile_every)) for n in per_lane))       # every lane profiles every Nth of ITS passes
+    in_flight = (unet_ms / profiled_blocks * args.steps) / (t_pred * 1e3) if t_pred > 0 else 1.0
     nvox = world * args.steps * nvox_block
     value = nvox / dt / 1e6
     out = {
@@ -697,6 +708,11 @@ def main():
                      "executed_mfma_frac": (executed_flops / (conv_ms * 1e-3) / 1e12 / (BF16_DENSE_PEAK_TFLOPS if args.precision != "f32" else MFMA_PEAK_TFLOPS["f32"])) if conv_ms > 0 else 0.0,
                      "mfma_busy_pmc": pmc_mfma_busy(args.precision),
                      "algorithmic_tflop_per_block": flops_block / 1e12,
+                     "predict_lanes": len(engines), "passes_in_flight": in_flight,
+                     "chip_achieved": achieved * in_flight, "chip_frac": achieved * in_flight / peak,
+                     "chip_note": ("with K > 1 predict lanes a launch shares the card with launches of the other lanes' forward passes: achieved / frac / "
+                                   "avg_launch_ms / executed_mfma_frac are per launch (what rocprofv3 sees), chip_* = per launch x passes_in_flight "
+                                   "(passes_in_flight = all lanes' launch time / predict wall time)"),
                      "other_unet_ms_per_block": sum(totals[k][0] for k in ("input", "pool", "upsample", "head")) / max(args.steps, 1)},
     }
     if not args.no_segment:
@@ -778,7 +794,7 @@ def main():
         pipe = segs = None
         torch.cuda.empty_cache()
         try:
-            out["whole_volume"] = whole_volume_leg(model, vol, args, dev, local_rank, rank, world, obj_group, use_dist, seg_kw, barrier,
+            out["whole_volume"] = whole_volume_leg(engines, vol, args, dev, local_rank, rank, world, obj_group, use_dist, seg_kw, barrier,
                                                    flops_block, peak, check=(rank == 0 and world == 1 and not args.no_cpu_baseline))
             out["config"]["whole_volume"] = out["whole_volume"]["what"]
         except Exception as exc:  # noqa: BLE001 - the headline above stands; with several ranks a failure of one rank ends the job

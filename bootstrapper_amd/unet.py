@@ -134,6 +134,7 @@ class Model:
     # -- weights -----------------------------------------------------------------------
     def load_state_dict(self, state_dict):
         """Strict, like torch's: unknown or missing keys raise (at finalize)."""
+        self._state_dict = state_dict  # kept (a reference) for clone()
         for k, v in state_dict.items():
             if hasattr(v, "detach"):
                 v = v.detach().cpu().numpy()
@@ -146,6 +147,16 @@ class Model:
         self._finalized.clear()
         self._finalize(self.precision)
         return self
+
+    def clone(self):
+        """A second engine with the same weights on the same device: its own activation buffers, so that its forward passes can
+        overlap this one's (predict lanes, volume.VolumePipeline / predict.py)."""
+        sd = getattr(self, "_state_dict", None)
+        if sd is None:
+            raise RuntimeError("clone(): no weights loaded")
+        other = Model(self.net_config, device=self.device, precision={v: k for k, v in PRECISIONS.items()}[self.precision])
+        other.stack_infer = self.stack_infer
+        return other.load_state_dict(sd)
 
     def load_checkpoint(self, checkpoint):
         """predict.py:98-107: accept `ckpt` or `ckpt.ckpt`; take state_dict / model_state_dict /
