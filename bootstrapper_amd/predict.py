@@ -284,7 +284,7 @@ def predict_blocks(cfg, rank=0, world=1, device=None, precision="bf16x3"):
     # memory-bound launches of one beside the matrix launches of the other (+7 % on the resident pipeline).
     # The further engines are packed on a side thread while the first one already predicts.
     from .volume import predict_stream
-    n_lanes = max(1, int(cfg.get("pred_lanes", 2)))
+    n_lanes = max(1, int(cfg.get("pred_lanes", os.environ.get("BSMI_PRED_LANES", 2))))
     engines, lane_streams = [model], [torch.cuda.current_stream(dev)]
     clones = [side.submit(lambda: (torch.cuda.set_device(device), model.clone())[1]) for _ in range(n_lanes - 1)]
     counter = [0]
