@@ -293,7 +293,7 @@ def predict_blocks(cfg, rank=0, world=1, device=None, precision="bf16x3"):
         await_sections(blk)
         while clones and clones[0].done():
             engines.append(clones.pop(0).result())
-            lane_streams.append(predict_stream(dev, len(engines)))   # (lane 0 of volume.py is the resident pipeline's own stream)
+            lane_streams.append(predict_stream(dev, len(engines) - 1))   # volume.py's predict-lane streams (one set per process: hardware queues are few)
         lane = counter[0] % len(engines)
         counter[0] += 1
         with torch.cuda.stream(lane_streams[lane]):
