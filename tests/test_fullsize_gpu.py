@@ -164,6 +164,12 @@ def test_full_net_volume_pipeline_vs_cpu_blockwise():
         assert np.array_equal(segs[t].cpu().numpy().view(np.uint64), segs_ref[t]), thr[t]
     counts = [len(np.unique(s)) for s in segs_ref]
     assert counts[0] >= counts[1] >= counts[2] and counts[2] < len(nodes)
+    # predict lanes: the same job with two engines whose forward passes overlap (block k on engine k mod 2) -- same bits
+    pipe2 = VolumePipeline([m, m.clone()], (128, 128, 128), (14, 46, 46), (2, 2, 2), (16, 16, 16), thr, min_seed_distance=10,
+                           filter_fragments=0.1, remove_debris=64, n_lanes=8)
+    segs2 = pipe2.run(vol)
+    assert torch.equal(pipe2.seg.interior(pipe2.seg.affs), pipe.seg.interior(pipe.seg.affs))
+    assert torch.equal(segs2, segs)
 
 
 @pytest.mark.parametrize("variant,env", [
