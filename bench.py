@@ -643,6 +643,27 @@ def main():
         executed_flops += m.profile_executed(reset=True)
         m.profile(False)
     t_pred, t_seg = pipe.t_predict, 0.0
+    single_lane = None
+    if len(engines) > 1:
+        # the same launches with the card to themselves (outside the timed region): eight blocks on lane 0 alone, every launch timed
+        from bootstrapper_amd.unet import extract_block_reflect
+        in_block = tuple(o + 2 * c for o, c in zip(OUT_BLOCK, CONTEXT))
+        model.profile(1)
+        model.profile_totals(reset=True)
+        model.profile_executed(reset=True)
+        with torch.cuda.stream(pipe.pred_stream):
+            for i in range(8):
+                model.predict_u8(extract_block_reflect(vol, [pipe.origin[0] - CONTEXT[0], pipe.origin[1] - CONTEXT[1], pipe.origin[2] - CONTEXT[2] + 128 * (i % 2)], in_block))
+        torch.cuda.synchronize(dev)
+        t1l = model.profile_totals(reset=True)
+        ex1 = model.profile_executed(reset=True)
+        model.profile(False)
+        ms1, fl1, n1 = t1l["conv"]
+        if ms1 > 0:
+            dense = BF16_DENSE_PEAK_TFLOPS if args.precision != "f32" else MFMA_PEAK_TFLOPS["f32"]
+            single_lane = {"achieved": fl1 / (ms1 * 1e-3) / 1e12, "frac": fl1 / (ms1 * 1e-3) / 1e12 / MFMA_PEAK_TFLOPS[args.precision],
+                           "avg_launch_ms": ms1 / max(n1, 1), "launches": int(n1), "executed_mfma_frac": ex1 / (ms1 * 1e-3) / 1e12 / dense,
+                           "what": "eight blocks on one lane alone after the timed region: the per-launch figures without another forward pass beside them"}
     if not args.no_segment:
         # the segmentation half on its own (outside the timed region: there it overlaps the predict stream): the same
         # slab of affinities again, from fragments to the relabelled volumes; must reproduce the timed run's result
@@ -708,6 +729,7 @@ def main():
                      "executed_mfma_frac": (executed_flops / (conv_ms * 1e-3) / 1e12 / (BF16_DENSE_PEAK_TFLOPS if args.precision != "f32" else MFMA_PEAK_TFLOPS["f32"])) if conv_ms > 0 else 0.0,
                      "mfma_busy_pmc": pmc_mfma_busy(args.precision),
                      "algorithmic_tflop_per_block": flops_block / 1e12,
+                     "single_lane": single_lane,
                      "predict_lanes": len(engines), "passes_in_flight": in_flight,
                      "chip_achieved": achieved * in_flight, "chip_frac": achieved * in_flight / peak,
                      "chip_note": ("with K > 1 predict lanes a launch shares the card with launches of the other lanes' forward passes: achieved / frac / "
