@@ -2417,6 +2417,7 @@ int bsmi_seg_create(int device, const int64_t max_shape[3], bsmi_seg** out) {
   BSMI_HIP(hipMemset(g.counters, 0, 8 * sizeof(uint32_t)));
   BSMI_HIP(hipMemset(g.sticky, 0, sizeof(uint32_t)));
   BSMI_HIP(hipMemset(h->frag.flags, 0, 4 * sizeof(uint32_t)));
+  BSMI_HIP(hipDeviceSynchronize());  // the fills ran on the null stream; the lanes' streams are non-blocking and would not wait for them
   *out = h;
   return BSMI_OK;
 }

@@ -1867,7 +1867,10 @@ static int grow_buf(hipStream_t s, char** buf, size_t* have, size_t need, bool z
   *buf = nullptr;
   *have = 0;
   BSMI_HIP(hipMalloc((void**)buf, need + 4096));
-  if (zero_new) BSMI_HIP(hipMemset(*buf, 0, need + 4096));
+  // on the stream that uses the buffer: hipMemset runs on the null stream, which a non-blocking stream (the weight gradients' own)
+  // does not wait for -- a launch could add into the buffer before the fill had passed (seen: two "deterministic" runs 2 974
+  // gradient values apart, once in four test-suite runs)
+  if (zero_new) BSMI_HIP(hipMemsetAsync(*buf, 0, need + 4096, s));
   *have = need;
   return BSMI_OK;
 }

@@ -1415,6 +1415,8 @@ int get_plan(bsmi_unet* h, int precision, const int64_t in_shape[3], Plan** out)
     plan->fused_first = fp_ready && first_pass_eligible(h) && ps.size() > 3 &&
                         ps[0].type == PlanStep::INPUT && ps[1].type == PlanStep::CONV && ps[2].type == PlanStep::CONV &&
                         ps[1].site == &h->l_conv[0] && ps[2].site == &h->l_conv[0] && ps[2].out.Cpad == 16;
+    // the planner's uploads and fills (hipMemcpy / hipMemsetAsync on the null stream) before any launch on a caller's non-blocking stream
+    BSMI_HIP(hipDeviceSynchronize());
     it = h->plans.emplace(key, std::move(plan)).first;
   }
   *out = it->second.get();
@@ -1749,7 +1751,8 @@ int bsmi_unet_forward(bsmi_unet* h, int precision, const void* raw_dev, int raw_
       h->sk_grid = h->sk_request >= 0 ? h->sk_request : prop.multiProcessorCount / 8 * 8;
       if (const char* g = getenv("BSMI_SK_GRID")) h->sk_grid = std::max(8, atoi(g) / 8 * 8);  // tests: force cuts on small nets
       BSMI_HIP(hipMalloc((void**)&h->sk_ws, stream_k_ws_bytes(h->sk_grid)));
-      BSMI_HIP(hipMemset((char*)h->sk_ws + stream_k_ws_bytes(h->sk_grid) - 64, 0, 64));
+      // (on the forward's own stream: a fill on the null stream is not ordered before launches on a non-blocking stream)
+      BSMI_HIP(hipMemsetAsync((char*)h->sk_ws + stream_k_ws_bytes(h->sk_grid) - 64, 0, 64, s));
     }
   }
   // f32 inference on a handle that is training: the f32 images of the launches that train in their split-bf16 form are
