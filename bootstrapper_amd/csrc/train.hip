@@ -1318,7 +1318,7 @@ void free_train_state(bsmi_unet* h) {
   if (h->train->ev_join) (void)hipEventDestroy(h->train->ev_join);
   if (h->train->ev_adam) (void)hipEventDestroy(h->train->ev_adam);
   if (h->train->ev_packed) (void)hipEventDestroy(h->train->ev_packed);
-  if (h->train->wstream) (void)hipStreamDestroy(h->train->wstream);
+  // (wstream is the device's side stream, shared by every training state of the process: not destroyed here)
   for (void* p : h->train->allocs) (void)hipFree(p);
   if (h->train->pk_g) (void)hipFree(h->train->pk_g);
   if (h->train->pk_x) (void)hipFree(h->train->pk_x);
@@ -2009,7 +2009,15 @@ int bsmi_unet_train_begin(bsmi_unet* h, const int64_t in_shape[3]) {
     if (covered != ts->nparams) BSMI_FAIL(BSMI_ERR_STATE, "training plan: gradient groups cover %zu of %zu parameters", covered, ts->nparams);
   }
   if (env_on("BSMI_TRAIN_WSTREAM")) {
-    BSMI_HIP(hipStreamCreateWithFlags(&ts->wstream, hipStreamNonBlocking));
+    // ONE side stream per device and process, kept: the runtime has few hardware queues (GPU_MAX_HW_QUEUES), a process that
+    // already runs 20 segmentation lanes and two predict lanes shares queues from the next stream on, and a stream per Trainer
+    // (bench.py builds four) left later work in the process measurably slower
+    static std::mutex mu;
+    static hipStream_t side[16] = {nullptr};
+    std::lock_guard<std::mutex> lk(mu);
+    const int d = h->device >= 0 && h->device < 16 ? h->device : 0;
+    if (!side[d]) BSMI_HIP(hipStreamCreateWithFlags(&side[d], hipStreamNonBlocking));
+    ts->wstream = side[d];
     BSMI_HIP(hipEventCreateWithFlags(&ts->ev_join, hipEventDisableTiming));
     BSMI_HIP(hipEventCreateWithFlags(&ts->ev_adam, hipEventDisableTiming));
     BSMI_HIP(hipEventCreateWithFlags(&ts->ev_packed, hipEventDisableTiming));

@@ -185,6 +185,9 @@ class _DevBuf:
         self.__cuda_array_interface__ = {"shape": (n,), "typestr": "<f4", "data": (ptr, False), "version": 2}
 
 
+_COMM_STREAMS = {}
+
+
 class Trainer:
     def __init__(self, model, in_shape, lr=0.5e-4, betas=(0.9, 0.999), eps=1e-8, arithmetic="split-bf16", deterministic=False):
         """model: bootstrapper_amd.unet.Model with weights loaded; in_shape: (D, H, W) of the training block.
@@ -217,7 +220,17 @@ class Trainer:
         offs, cnts = (C.c_uint64 * ng.value)(), (C.c_uint64 * ng.value)()
         check(lib.bsmi_unet_train_grad_groups(model._h, ng.value, C.byref(ng), offs, cnts))
         self.grad_groups = [(int(o), int(c)) for o, c in zip(offs, cnts)]   # in the order the backward pass finishes them
-        self.comm_stream = torch.cuda.Stream(dev)
+        self._comm_stream = None   # made when a reduction first needs it: a stream costs a hardware queue (few; volume.py)
+
+    @property
+    def comm_stream(self):
+        """the side stream the gradient groups are all-reduced on (one per device and process)"""
+        if self._comm_stream is None:
+            dev = torch.device("cuda", self.model.device)
+            if dev not in _COMM_STREAMS:
+                _COMM_STREAMS[dev] = torch.cuda.Stream(dev)
+            self._comm_stream = _COMM_STREAMS[dev]
+        return self._comm_stream
 
     def _stream(self):
         return C.c_void_p(torch.cuda.current_stream(torch.device("cuda", self.model.device)).cuda_stream)
