@@ -513,7 +513,7 @@ def whole_volume_leg(model, vol, args, dev, local_rank, rank, world, obj_group, 
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--mode", default="predict", choices=["predict", "train"],
+    ap.add_argument("--mode", default="predict", choices=["predict", "train", "train-leg"],
                     help="predict = the headline predict + segment benchmark; train = training-step samples/s (secondary)")
     ap.add_argument("--train-deterministic", action="store_true", help="--mode train: Trainer(deterministic=True), ordered reductions")
     ap.add_argument("--train-arithmetic", default="split-bf16", choices=["split-bf16", "f32"],
@@ -548,6 +548,13 @@ def main():
     ap.add_argument("--cpu-predict-blocks", type=int, default=2)
     ap.add_argument("--cpu-segment-blocks", type=int, default=16)
     args = ap.parse_args()
+    if args.mode == "train-leg":  # the default run's `train` object, printed by a child process of that run
+        if not torch.cuda.is_available():
+            raise SystemExit("bench.py needs an MI355X: there is no CPU fallback for the HIP path")
+        lr = int(os.environ.get("LOCAL_RANK", "0"))
+        torch.cuda.set_device(lr)
+        print(json.dumps(train_leg(torch.device("cuda", lr), lr)), flush=True)
+        return
     if args.mode == "train":
         if "--steps" not in sys.argv:
             args.steps = 20
@@ -825,13 +832,6 @@ def main():
             out["whole_volume"] = {"error": f"{type(exc).__name__}: {exc}"}
     elif not args.no_segment and not args.no_whole_volume and edge % world == 0:
         out["whole_volume"] = {"what": "the timed region above IS the whole volume", "Mvoxels_per_s": value, "seconds": dt}
-    if rank == 0 and world == 1 and not args.no_train:
-        pipe = segs = None
-        torch.cuda.empty_cache()
-        try:
-            out["train"] = train_leg(dev, local_rank)
-        except Exception as exc:  # noqa: BLE001 - a secondary leg: its failure is reported in the line, the headline stands
-            out["train"] = {"error": f"{type(exc).__name__}: {exc}"}
     if rank == 0 and world == 1 and not args.no_drivers and not args.no_segment:
         # the commands a user runs, on the whole volume as an on-disk Zarr store (the box of `--steps` blocks when the volume's
         # datasets would not fit the temporary directory)
@@ -854,6 +854,23 @@ def main():
         resident = out.get("whole_volume", {}).get("Mvoxels_per_s") if whole else value
         out["drivers"]["resident_Mvoxels_per_s"] = resident
         out["drivers"]["frac_of_resident"] = out["drivers"]["Mvoxels_per_s"] / resident if resident else None
+    if rank == 0 and world == 1 and not args.no_train:
+        # The training step beside the headline: LAST, and in a process of its own (a child: `--mode train-leg`).  In this process,
+        # after 20 segmentation lanes, two predict lanes and their workspaces, the step's second stream gained nothing (21.6 ms
+        # against 18.5 alone) and the four trainers' 40 GB of frees left the legs after it slower (`bs segment` spent 1.3 s
+        # allocating its slab instead of 0.03): measured both ways in round 4.
+        pipe = segs = vol = None
+        torch.cuda.empty_cache()
+        try:
+            import subprocess
+            r = subprocess.run([sys.executable, os.path.abspath(__file__), "--mode", "train-leg"], capture_output=True, text=True, timeout=900,
+                               env=dict(os.environ, LOCAL_RANK=str(local_rank)))
+            lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+            if r.returncode != 0 or not lines:
+                raise RuntimeError(f"train leg exited {r.returncode}: {r.stderr[-600:]}")
+            out["train"] = json.loads(lines[-1])
+        except Exception as exc:  # noqa: BLE001 - a secondary leg: its failure is reported in the line, the headline stands
+            out["train"] = {"error": f"{type(exc).__name__}: {exc}"}
     if rank == 0:
         print(json.dumps(out), flush=True)
     if use_dist:
