@@ -278,8 +278,7 @@ def drivers_leg(raw_box, sd, precision, model=None, vol=None, origin=(0, 0, 0)):
         t_pred = time.perf_counter() - t0
         # what `bs predict` stored against the engine called directly on the same blocks (the command predicts while its
         # write-behind threads copy, encode and write the blocks before: nothing of that may show in the data)
-        pred_check = None
-        if model is not None:
+        def check_predictions(model):
             vol = torch.from_numpy(raw_box).to(torch.device("cuda", model.device))   # the store's extent: the drivers reflect-pad at ITS faces
             origin = (0, 0, 0)
             from bootstrapper_amd.unet import extract_block_reflect
@@ -295,10 +294,11 @@ def drivers_leg(raw_box, sd, precision, model=None, vol=None, origin=(0, 0, 0)):
                 want = model.predict_u8(extract_block_reflect(vol, off, in_block))[0].cpu().numpy()
                 got = pds[(slice(None),) + tuple(slice(b[d] * OUT_BLOCK[d], (b[d] + 1) * OUT_BLOCK[d]) for d in range(3))]
                 differ += not np.array_equal(got, want)
-            pred_check = {"blocks_compared": len(picks), "blocks_differing": differ,
-                          "what": "the prediction dataset `bs predict` wrote against the engine called on the same blocks: all six channels, bit for bit"}
             if differ:
                 raise SystemExit(f"parity (drivers): {differ} of {len(picks)} sampled blocks of the prediction dataset differ from the engine's own prediction")
+            return {"blocks_compared": len(picks), "blocks_differing": differ,
+                    "what": "the prediction dataset `bs predict` wrote against the engine called on the same blocks: all six channels, bit for bit"}
+        pred_check = check_predictions(model) if model is not None and model != "late" else None
         t0 = time.perf_counter()
         written = run_segmentation(seg_toml, "ws")
         t_seg = time.perf_counter() - t0
@@ -315,6 +315,9 @@ def drivers_leg(raw_box, sd, precision, model=None, vol=None, origin=(0, 0, 0)):
         except Exception as exc:  # noqa: BLE001 - reported in the line; the two commands the leg is about have run
             filtered, filter_error = None, f"{type(exc).__name__}: {exc}"
         t_filter = time.perf_counter() - t0
+        if model == "late":  # a process of its own for the commands: its engine is built only now
+            from bootstrapper_amd.unet import Model
+            pred_check = check_predictions(Model(NET_CONFIG, device=torch.cuda.current_device(), precision=precision).load_state_dict(sd))
 
         def du(path):
             return sum(os.path.getsize(os.path.join(d, f)) for d, _, fs in os.walk(path) for f in fs)
@@ -513,7 +516,7 @@ def whole_volume_leg(model, vol, args, dev, local_rank, rank, world, obj_group, 
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--mode", default="predict", choices=["predict", "train", "train-leg"],
+    ap.add_argument("--mode", default="predict", choices=["predict", "train", "train-leg", "drivers-leg"],
                     help="predict = the headline predict + segment benchmark; train = training-step samples/s (secondary)")
     ap.add_argument("--train-deterministic", action="store_true", help="--mode train: Trainer(deterministic=True), ordered reductions")
     ap.add_argument("--train-arithmetic", default="split-bf16", choices=["split-bf16", "f32"],
@@ -548,6 +551,16 @@ def main():
     ap.add_argument("--cpu-predict-blocks", type=int, default=2)
     ap.add_argument("--cpu-segment-blocks", type=int, default=16)
     args = ap.parse_args()
+    if args.mode == "drivers-leg":  # the default run's `drivers` object on the whole volume, printed by a child process of that run
+        if not torch.cuda.is_available():
+            raise SystemExit("bench.py needs an MI355X: there is no CPU fallback for the HIP path")
+        from bootstrapper_amd.synth import synthetic_state_dict, synthetic_volume
+        lr = int(os.environ.get("LOCAL_RANK", "0"))
+        torch.cuda.set_device(lr)
+        box = synthetic_volume((args.volume,) * 3, seed=0, device=torch.device("cuda", lr)).cpu().numpy()
+        torch.cuda.empty_cache()
+        print(json.dumps(drivers_leg(box, synthetic_state_dict(NET_CONFIG, 0), args.precision, "late")), flush=True)
+        return
     if args.mode == "train-leg":  # the default run's `train` object, printed by a child process of that run
         if not torch.cuda.is_available():
             raise SystemExit("bench.py needs an MI355X: there is no CPU fallback for the HIP path")
@@ -846,7 +859,22 @@ def main():
         pipe = segs = None
         torch.cuda.empty_cache()
         try:
-            out["drivers"] = drivers_leg(box, sd, args.precision, model, vol, (0, 0, 0) if whole else pipe_origin)
+            if whole and not os.environ.get("BSMI_BENCH_DRIVERS_INPROC"):
+                # as a user runs the commands: in a process of their own (a child of this one).  In THIS process -- after the resident
+                # pipelines' 50 GB of slabs were allocated and freed -- `bs segment` spent 1.3 s allocating its slab where a fresh
+                # process spends 0.03 s, and the leg read 0.65-0.87 of resident from run to run
+                import subprocess
+                box = None
+                r = subprocess.run([sys.executable, os.path.abspath(__file__), "--mode", "drivers-leg", "--precision", args.precision,
+                                    "--volume", str(args.volume)], capture_output=True, text=True, timeout=1200,
+                                   env=dict(os.environ, LOCAL_RANK=str(local_rank)))
+                lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+                if r.returncode != 0 or not lines:
+                    raise RuntimeError(f"drivers leg exited {r.returncode}: {r.stderr[-800:]}")
+                out["drivers"] = json.loads(lines[-1])
+                out["drivers"]["process"] = "child"
+            else:
+                out["drivers"] = drivers_leg(box, sd, args.precision, model, vol, (0, 0, 0) if whole else pipe_origin)
         except Exception as exc:  # noqa: BLE001
             import traceback
             out["drivers"] = {"error": f"{type(exc).__name__}: {exc}", "traceback": traceback.format_exc()[-1500:], "Mvoxels_per_s": 0.0}
