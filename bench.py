@@ -580,6 +580,34 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+    # The two side legs of the default one-GPU run -- the drivers on the whole volume as an on-disk store, the training step -- run
+    # FIRST, each in a process of its own, while this process has not touched the GPU yet: that is how a user runs those commands
+    # (one process, the card to itself).  Measured in round 4: inside this process after its resident pipelines `bs segment` spent 1.3 s
+    # allocating its slab (0.03 s alone) and the training step's second stream gained nothing (21.6 against 18.5 ms); in a child
+    # beside this process's 23 idle hardware queues `bs segment` took 3.9 s instead of 2.0.
+    side_legs = {}
+    if rank == 0 and world == 1 and not args.force_dist and not os.environ.get("BSMI_BENCH_LEGS_INPROC"):
+        import shutil
+        import subprocess
+        tmp_root = os.environ.get("BSMI_BENCH_TMP") or __import__("tempfile").gettempdir()
+
+        def child(mode, timeout):
+            try:
+                r = subprocess.run([sys.executable, os.path.abspath(__file__), "--mode", mode, "--precision", args.precision, "--volume", str(args.volume)],
+                                   capture_output=True, text=True, timeout=timeout, env=dict(os.environ, LOCAL_RANK=str(local_rank)))
+                lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+                if r.returncode != 0 or not lines:
+                    raise RuntimeError(f"exit code {r.returncode}: {r.stderr[-800:]}")
+                d = json.loads(lines[-1])
+                d["process"] = "a child of the bench run, before the run touched the GPU"
+                return d
+            except Exception as exc:  # noqa: BLE001 - a secondary leg: its failure is reported in the line, the headline stands
+                return {"error": f"{type(exc).__name__}: {exc}"}
+        whole_fits = shutil.disk_usage(tmp_root).free > 14 * args.volume ** 3 and not args.drivers_box
+        if not args.no_drivers and not args.no_segment and whole_fits:
+            side_legs["drivers"] = child("drivers-leg", 1500)
+        if not args.no_train:
+            side_legs["train"] = child("train-leg", 900)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: there is no CPU fallback for the HIP path")
     if args.backend == "gloo":  # rehearsal on a box with fewer GPUs than ranks: the ranks share the GPUs there are
@@ -845,9 +873,16 @@ def main():
             out["whole_volume"] = {"error": f"{type(exc).__name__}: {exc}"}
     elif not args.no_segment and not args.no_whole_volume and edge % world == 0:
         out["whole_volume"] = {"what": "the timed region above IS the whole volume", "Mvoxels_per_s": value, "seconds": dt}
-    if rank == 0 and world == 1 and not args.no_drivers and not args.no_segment:
-        # the commands a user runs, on the whole volume as an on-disk Zarr store (the box of `--steps` blocks when the volume's
-        # datasets would not fit the temporary directory)
+    if "drivers" in side_legs:
+        out["drivers"] = side_legs["drivers"]
+        out["drivers"].setdefault("Mvoxels_per_s", 0.0)
+        out["drivers"]["whole_volume"] = True
+        resident = out.get("whole_volume", {}).get("Mvoxels_per_s")
+        out["drivers"]["resident_Mvoxels_per_s"] = resident
+        out["drivers"]["frac_of_resident"] = out["drivers"]["Mvoxels_per_s"] / resident if resident else None
+    elif rank == 0 and world == 1 and not args.no_drivers and not args.no_segment:
+        # in this process: the box of `--steps` blocks when the volume's datasets would not fit the temporary directory (or
+        # BSMI_BENCH_LEGS_INPROC / --force-dist)
         import shutil
         tmp_root = os.environ.get("BSMI_BENCH_TMP") or __import__("tempfile").gettempdir()
         whole = shutil.disk_usage(tmp_root).free > 14 * args.volume ** 3 and not args.drivers_box
@@ -859,22 +894,7 @@ def main():
         pipe = segs = None
         torch.cuda.empty_cache()
         try:
-            if whole and not os.environ.get("BSMI_BENCH_DRIVERS_INPROC"):
-                # as a user runs the commands: in a process of their own (a child of this one).  In THIS process -- after the resident
-                # pipelines' 50 GB of slabs were allocated and freed -- `bs segment` spent 1.3 s allocating its slab where a fresh
-                # process spends 0.03 s, and the leg read 0.65-0.87 of resident from run to run
-                import subprocess
-                box = None
-                r = subprocess.run([sys.executable, os.path.abspath(__file__), "--mode", "drivers-leg", "--precision", args.precision,
-                                    "--volume", str(args.volume)], capture_output=True, text=True, timeout=1200,
-                                   env=dict(os.environ, LOCAL_RANK=str(local_rank)))
-                lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
-                if r.returncode != 0 or not lines:
-                    raise RuntimeError(f"drivers leg exited {r.returncode}: {r.stderr[-800:]}")
-                out["drivers"] = json.loads(lines[-1])
-                out["drivers"]["process"] = "child"
-            else:
-                out["drivers"] = drivers_leg(box, sd, args.precision, model, vol, (0, 0, 0) if whole else pipe_origin)
+            out["drivers"] = drivers_leg(box, sd, args.precision, model, vol, (0, 0, 0) if whole else pipe_origin)
         except Exception as exc:  # noqa: BLE001
             import traceback
             out["drivers"] = {"error": f"{type(exc).__name__}: {exc}", "traceback": traceback.format_exc()[-1500:], "Mvoxels_per_s": 0.0}
@@ -882,21 +902,13 @@ def main():
         resident = out.get("whole_volume", {}).get("Mvoxels_per_s") if whole else value
         out["drivers"]["resident_Mvoxels_per_s"] = resident
         out["drivers"]["frac_of_resident"] = out["drivers"]["Mvoxels_per_s"] / resident if resident else None
-    if rank == 0 and world == 1 and not args.no_train:
-        # The training step beside the headline: LAST, and in a process of its own (a child: `--mode train-leg`).  In this process,
-        # after 20 segmentation lanes, two predict lanes and their workspaces, the step's second stream gained nothing (21.6 ms
-        # against 18.5 alone) and the four trainers' 40 GB of frees left the legs after it slower (`bs segment` spent 1.3 s
-        # allocating its slab instead of 0.03): measured both ways in round 4.
+    if "train" in side_legs:
+        out["train"] = side_legs["train"]
+    elif rank == 0 and world == 1 and not args.no_train:
         pipe = segs = vol = None
         torch.cuda.empty_cache()
         try:
-            import subprocess
-            r = subprocess.run([sys.executable, os.path.abspath(__file__), "--mode", "train-leg"], capture_output=True, text=True, timeout=900,
-                               env=dict(os.environ, LOCAL_RANK=str(local_rank)))
-            lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
-            if r.returncode != 0 or not lines:
-                raise RuntimeError(f"train leg exited {r.returncode}: {r.stderr[-600:]}")
-            out["train"] = json.loads(lines[-1])
+            out["train"] = train_leg(dev, local_rank)
         except Exception as exc:  # noqa: BLE001 - a secondary leg: its failure is reported in the line, the headline stands
             out["train"] = {"error": f"{type(exc).__name__}: {exc}"}
     if rank == 0:
