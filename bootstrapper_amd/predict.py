@@ -285,6 +285,8 @@ def predict_blocks(cfg, rank=0, world=1, device=None, precision="bf16x3"):
     # The further engines are packed on a side thread while the first one already predicts.
     from .volume import predict_stream
     n_lanes = max(1, int(cfg.get("pred_lanes", os.environ.get("BSMI_PRED_LANES", 2))))
+    if len(mine) < 64 and "pred_lanes" not in cfg:
+        n_lanes = 1  # a second engine costs 0.4 s of packing on the side thread: a job of a second or two does not earn it back
     engines, lane_streams = [model], [torch.cuda.current_stream(dev)]
     clones = [side.submit(lambda: (torch.cuda.set_device(device), model.clone())[1]) for _ in range(n_lanes - 1)]
     counter = [0]
