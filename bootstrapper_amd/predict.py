@@ -74,9 +74,10 @@ def get_pred_config(config_file, setup_id, **kwargs):
     if roi_offset is None:
         roi_offset, roi_shape = list(in_ds.roi[0]), list(in_ds.roi[1])
     outputs = output_dataset_names(checkpoint, config["output_datasets_prefix"], net_config, config.get("chain_str", ""))
+    extra = {"pred_lanes": int(config["pred_lanes"])} if "pred_lanes" in config else {}  # an addition to the reference's keys (predict_blocks)
     return dict(setup_dir=setup_dir, checkpoint=checkpoint, net_config=net_config, input_datasets=input_datasets,
                 output_datasets=outputs, output_roi=(roi_offset, roi_shape), voxel_size=list(voxel_size),
-                num_workers=config.get("num_workers", 1), num_gpus=config.get("num_gpus", 1), **rois)
+                num_workers=config.get("num_workers", 1), num_gpus=config.get("num_gpus", 1), **extra, **rois)
 
 
 def prepare_outputs(cfg, in_ds):

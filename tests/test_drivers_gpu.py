@@ -476,6 +476,12 @@ def test_cremi_shaped_volume_full_net_then_blockwise_segment_and_filter(tmp_path
     out = open_ds(store + "/predictions/3000/3d_affs")
     assert out.shape == (6, 125, ny, nx) and out.chunks == (6, 125, 128, 128) and out.offset == (0, oy * 4, ox * 4)
     got = out[:]
+    # the same job with two predict lanes (`pred_lanes`: two engines, blocks dealt alternately, their forward passes overlapping): same bits
+    cfg2 = tmp_path / "pred_lanes.toml"
+    cfg2.write_text(cfg.read_text().replace(f'output_datasets_prefix = "{store}/predictions"', f'output_datasets_prefix = "{store}/predictions_lanes"')
+                    + "pred_lanes = 2\n")
+    run_prediction(str(cfg2), "03")
+    assert np.array_equal(open_ds(store + "/predictions_lanes/3000/3d_affs")[:], got)
     full = np.pad(raw, [(14, 14 + 128), (46, 46 + 128), (46, 46 + 128)], mode="reflect")
     torch.set_num_threads(min(16, os.cpu_count() or 1))
     for (y, x) in ((0, 0), (128, 256), (256, 128)):          # a corner block, two blocks that overhang the ROI
