@@ -1276,6 +1276,7 @@ struct TrainState {
   size_t gt_det_bytes = 0, det_part_bytes = 0;
   double* loss_part = nullptr;       // [512][4]
   hipStream_t wstream = nullptr;     // the weight gradients' own stream (null: BSMI_TRAIN_WSTREAM=0, everything on the caller's)
+  bool own_wstream = false;
   hipEvent_t ev_join = nullptr;      // its last launch of a backward pass
   hipEvent_t ev_adam = nullptr, ev_packed = nullptr;  // optimizer step done / input-gradient images repacked on the side stream
   bool packed_pending = false;
@@ -1319,6 +1320,7 @@ void free_train_state(bsmi_unet* h) {
   if (h->train->ev_adam) (void)hipEventDestroy(h->train->ev_adam);
   if (h->train->ev_packed) (void)hipEventDestroy(h->train->ev_packed);
   // (wstream is the device's side stream, shared by every training state of the process: not destroyed here)
+  if (h->train->own_wstream && h->train->wstream) (void)hipStreamDestroy(h->train->wstream);
   for (void* p : h->train->allocs) (void)hipFree(p);
   if (h->train->pk_g) (void)hipFree(h->train->pk_g);
   if (h->train->pk_x) (void)hipFree(h->train->pk_x);
@@ -2015,9 +2017,13 @@ int bsmi_unet_train_begin(bsmi_unet* h, const int64_t in_shape[3]) {
     static std::mutex mu;
     static hipStream_t side[16] = {nullptr};
     std::lock_guard<std::mutex> lk(mu);
-    const int d = h->device >= 0 && h->device < 16 ? h->device : 0;
-    if (!side[d]) BSMI_HIP(hipStreamCreateWithFlags(&side[d], hipStreamNonBlocking));
-    ts->wstream = side[d];
+    if (h->device >= 0 && h->device < 16) {
+      if (!side[h->device]) BSMI_HIP(hipStreamCreateWithFlags(&side[h->device], hipStreamNonBlocking));
+      ts->wstream = side[h->device];
+    } else {  // (no such node; a stream of the state's own, destroyed with it)
+      BSMI_HIP(hipStreamCreateWithFlags(&ts->wstream, hipStreamNonBlocking));
+      ts->own_wstream = true;
+    }
     BSMI_HIP(hipEventCreateWithFlags(&ts->ev_join, hipEventDisableTiming));
     BSMI_HIP(hipEventCreateWithFlags(&ts->ev_adam, hipEventDisableTiming));
     BSMI_HIP(hipEventCreateWithFlags(&ts->ev_packed, hipEventDisableTiming));
