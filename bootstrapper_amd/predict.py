@@ -291,10 +291,11 @@ def predict_blocks(cfg, rank=0, world=1, device=None, precision="bf16x3"):
     engines, lane_streams = [model], [torch.cuda.current_stream(dev)]
     clones = [side.submit(lambda: (torch.cuda.set_device(device), model.clone())[1]) for _ in range(n_lanes - 1)]
     counter = [0]
+    wait_clones = os.environ.get("BSMI_PRED_LANES_WAIT") == "1"   # tests: every lane from the first block on
 
     def predict_and_submit(blk):
         await_sections(blk)
-        while clones and clones[0].done():
+        while clones and (wait_clones or clones[0].done()):
             engines.append(clones.pop(0).result())
             lane_streams.append(predict_stream(dev, len(engines) - 1))   # volume.py's predict-lane streams (one set per process: hardware queues are few)
         lane = counter[0] % len(engines)

@@ -441,7 +441,7 @@ def test_predict_two_workers_failure_injection_and_worker_script(tmp_path, golde
     assert np.array_equal(open_ds(store + "/by_worker/3d_affs")[:], one)
 
 
-def test_cremi_shaped_volume_full_net_then_blockwise_segment_and_filter(tmp_path):
+def test_cremi_shaped_volume_full_net_then_blockwise_segment_and_filter(tmp_path, monkeypatch):
     """BASELINE configs 2 and 5 in one chain, on a CREMI-shaped synthetic volume (125 x 1250 x 1250 voxels of (40,4,4) nm,
     examples/cremi/README.md:19-24): `run_prediction` with the full 3d_affs network in 128^3 blocks over a sub-ROI
     (a single layer of blocks that overhangs the 125 sections, and overhangs the ROI in y and x: writes are clipped),
@@ -480,7 +480,9 @@ def test_cremi_shaped_volume_full_net_then_blockwise_segment_and_filter(tmp_path
     cfg2 = tmp_path / "pred_lanes.toml"
     cfg2.write_text(cfg.read_text().replace(f'output_datasets_prefix = "{store}/predictions"', f'output_datasets_prefix = "{store}/predictions_lanes"')
                     + "pred_lanes = 2\n")
+    monkeypatch.setenv("BSMI_PRED_LANES_WAIT", "1")   # the second engine from the first block on (else it joins when its weights are packed)
     run_prediction(str(cfg2), "03")
+    monkeypatch.delenv("BSMI_PRED_LANES_WAIT")
     assert np.array_equal(open_ds(store + "/predictions_lanes/3000/3d_affs")[:], got)
     full = np.pad(raw, [(14, 14 + 128), (46, 46 + 128), (46, 46 + 128)], mode="reflect")
     torch.set_num_threads(min(16, os.cpu_count() or 1))
