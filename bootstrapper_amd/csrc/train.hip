@@ -1224,6 +1224,7 @@ struct PackJob {  // one packed weight image that must follow the parameters
   int window = 2;  // units of one 32-channel chunk (taps x 2): the thread order of pack_weights_x3_kernel
   bool shadowed = false;  // f32 image of a forward launch that trains in its split-bf16 form (make_forward_x3)
   bool backward = false;  // image of an input-gradient launch: first read in the backward pass (packed on the side stream)
+  bool late = false;      // forward image of a wide stage, first read a millisecond into the forward pass (side stream as well)
   // bias image (forward launches only)
   long long b0 = -1, b1 = -1;
   float* bias_dst = nullptr;
@@ -1254,6 +1255,7 @@ struct TrainFwdX3 {  // a forward CONV step as a fused split-bf16 launch
   size_t src_g8[kMaxConvTensors] = {0, 0, 0};
   void* out_split = nullptr;  // the launch's result, turned into the step's f32 output tensor afterwards
   size_t out_g8 = 0;
+  bool late = false;          // its weight image is packed on the side stream after an optimizer step (TrainState::ev_fwd_packed)
 };
 
 struct TrainState {
@@ -1279,7 +1281,9 @@ struct TrainState {
   bool own_wstream = false;
   hipEvent_t ev_join = nullptr;      // its last launch of a backward pass
   hipEvent_t ev_adam = nullptr, ev_packed = nullptr;  // optimizer step done / input-gradient images repacked on the side stream
-  bool packed_pending = false;
+  hipEvent_t ev_fwd_packed = nullptr;                  // the wide stages' forward images repacked there
+  bool packed_pending = false, fwd_packed_pending = false;
+  bool wstream_wanted = false;                         // BSMI_TRAIN_WSTREAM at begin (known before the stream itself is made)
   int adam_t = 0;
   // Gradient groups: the parameters of one ConvPass / head are one contiguous range of the flat buffers (their keys share
   // a prefix and the buffers follow the sorted keys); a group's gradients are final once the backward pass has left its
@@ -1319,6 +1323,7 @@ void free_train_state(bsmi_unet* h) {
   if (h->train->ev_join) (void)hipEventDestroy(h->train->ev_join);
   if (h->train->ev_adam) (void)hipEventDestroy(h->train->ev_adam);
   if (h->train->ev_packed) (void)hipEventDestroy(h->train->ev_packed);
+  if (h->train->ev_fwd_packed) (void)hipEventDestroy(h->train->ev_fwd_packed);
   // (wstream is the device's side stream, shared by every training state of the process: not destroyed here)
   if (h->train->own_wstream && h->train->wstream) (void)hipStreamDestroy(h->train->wstream);
   for (void* p : h->train->allocs) (void)hipFree(p);
@@ -1405,11 +1410,13 @@ static int make_forward_job(bsmi_unet* h, TrainState* ts, PassSite& p, int ci) {
 // `lazy_f32`: leave out the f32 weight image of a forward launch that runs in its split-bf16 form during training
 // (PackJob::shadowed); the images are then stale until train_refresh_f32_images, which an f32 inference call on the same
 // handle triggers (unet_api.hip) -- the bias images and everything the step itself reads are always current.
-// which: 0 every image, 1 those the forward pass reads, 2 those only the backward pass reads
+// which: 0 every image, 1 those the forward pass reads first, 2 those only the backward pass reads, 3 the wide stages' forward images
 static int run_pack_jobs(TrainState* ts, hipStream_t s, bool lazy_f32 = false, bool only_shadowed = false, int which = 0) {
   for (const PackJob& j : ts->jobs) {
     if (only_shadowed && !j.shadowed) continue;
-    if (which && j.backward != (which == 2)) continue;
+    if (which == 1 && (j.backward || j.late)) continue;   // early forward images
+    if (which == 2 && !j.backward) continue;              // input-gradient images
+    if (which == 3 && !j.late) continue;                  // late forward images
     const size_t total = (size_t)j.nunits * j.Npad;
     if (j.dst_hi) {
       const int ugw = std::max(2, j.window);
@@ -1514,6 +1521,10 @@ static int make_forward_x3(bsmi_unet* h, TrainState* ts, PlanStep& st) {
   job.dst_hi = (uint32_t*)wdev;
   job.dst_lo = (uint32_t*)(wdev + wimg);
   job.window = kUnitsPerStep * (int)ntap;
+  // the wide stages' images (2.4 M weights and more: 0.5 of the 0.6 ms of forward packing) are not read before the forward pass
+  // has done its first, narrow stages: packed on the side stream, the forward pass waits for them where it first needs one
+  job.late = ts->wstream_wanted && (size_t)job.nunits * job.Npad * 16 >= ((size_t)2 << 20);
+  fx->late = job.late;
   ts->jobs.push_back(job);
   ConvArgs& a = fx->a;
   memset(&a, 0, sizeof a);
@@ -1572,6 +1583,10 @@ int train_refresh_f32_images(bsmi_unet* h, hipStream_t s) {
 
 int train_forward_conv_x3(bsmi_unet* h, const PlanStep& st, hipStream_t s) {
   const TrainFwdX3& fx = *st.tx3;
+  if (fx.late && h->train && h->train->fwd_packed_pending) {  // the first wide stage after an optimizer step: its image comes from the side stream
+    BSMI_HIP(hipStreamWaitEvent(s, h->train->ev_fwd_packed, 0));
+    h->train->fwd_packed_pending = false;
+  }
   for (int sl = 0; sl < fx.nconv_src; ++sl)
     if (fx.src_f32[sl])
       hipLaunchKernelGGL(f32_to_split_kernel, dim3((unsigned)std::min<size_t>((fx.src_g8[sl] + 255) / 256, 16384)), dim3(256), 0, s,
@@ -1883,6 +1898,7 @@ int bsmi_unet_train_begin(bsmi_unet* h, const int64_t in_shape[3]) {
   BSMI_HIP(hipSetDevice(h->device));
   free_train_state(h);
   std::unique_ptr<TrainState> ts(new TrainState);
+  ts->wstream_wanted = env_on("BSMI_TRAIN_WSTREAM");
   for (int d = 0; d < 3; ++d) ts->in_shape[d] = in_shape[d];
   int rc = get_plan(h, BSMI_PREC_F32, in_shape, &ts->plan);
   if (rc) return rc;
@@ -2027,6 +2043,7 @@ int bsmi_unet_train_begin(bsmi_unet* h, const int64_t in_shape[3]) {
     BSMI_HIP(hipEventCreateWithFlags(&ts->ev_join, hipEventDisableTiming));
     BSMI_HIP(hipEventCreateWithFlags(&ts->ev_adam, hipEventDisableTiming));
     BSMI_HIP(hipEventCreateWithFlags(&ts->ev_packed, hipEventDisableTiming));
+    BSMI_HIP(hipEventCreateWithFlags(&ts->ev_fwd_packed, hipEventDisableTiming));
     for (size_t i = 0; i < ts->convs.size(); ++i)
       if (plan.steps[i].type == PlanStep::CONV) BSMI_HIP(hipEventCreateWithFlags(&ts->convs[i].ev_g, hipEventDisableTiming));
   }
@@ -2446,6 +2463,9 @@ int bsmi_unet_train_adam_step(bsmi_unet* h, float lr, float beta1, float beta2, 
     // before its backward pass)
     BSMI_HIP(hipEventRecord(ts->ev_adam, s));
     BSMI_HIP(hipStreamWaitEvent(ts->wstream, ts->ev_adam, 0));
+    if ((rc = run_pack_jobs(ts, ts->wstream, true, false, 3))) return rc;
+    BSMI_HIP(hipEventRecord(ts->ev_fwd_packed, ts->wstream));
+    ts->fwd_packed_pending = true;
     if ((rc = run_pack_jobs(ts, ts->wstream, true, false, 2))) return rc;
     BSMI_HIP(hipEventRecord(ts->ev_packed, ts->wstream));
     ts->packed_pending = true;
