@@ -198,6 +198,7 @@ class Trainer:
             raise ValueError(f"arithmetic must be 'split-bf16' or 'f32', not {arithmetic!r}")
         self.arithmetic = arithmetic
         self.model = model
+        model._state_dict = None   # the handle's weights are about to change: Model.clone() must not hand out the loaded ones
         self.in_shape = tuple(int(s) for s in in_shape)
         self.lr, self.betas, self.eps = float(lr), (float(betas[0]), float(betas[1])), float(eps)
         model._finalize(_lib.PREC_F32)
