@@ -25,6 +25,8 @@
 #include "unet_internal.h"
 #include "unet_ops.h"
 
+#include "dev_guard.h"  // last: routes hipMalloc / hipFree through the guarded allocator (BSMI_GUARD_MB)
+
 namespace bsmi {
 
 typedef float f32x16_t __attribute__((ext_vector_type(16)));
