@@ -23,6 +23,8 @@
 #include "../../include/bsmi.h"
 #include "common.h"
 
+#include "dev_guard.h"  // last: routes hipMalloc / hipFree through the guarded allocator (BSMI_GUARD_MB)
+
 namespace bsmi {
 namespace {
 

@@ -23,6 +23,8 @@
 
 #include "common.h"
 
+#include "dev_guard.h"  // last: routes hipMalloc / hipFree through the guarded allocator (BSMI_GUARD_MB)
+
 namespace bsmi {
 // agglo_host.cpp: the merge loop of the histogram-quantile scorers
 void host_agglomerate_hist(uint32_t nn, uint32_t ne, const uint32_t* eu, const uint32_t* ev, uint32_t* hist, int quantile,

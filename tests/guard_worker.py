@@ -42,4 +42,15 @@ for det in (False, True):
     assert bad == 0, f"{bad} guard zones written to (deterministic={det})"
     tr.close()
     del m
+# the segmentation engines' workspaces (seeds, floods, region graphs, merge loops, sorts): a box of 1 x 2 x 2 blocks, predict + segment
+from bootstrapper_amd.volume import VolumePipeline
+m = Model(NC).load_state_dict(sd)
+vol = synthetic_volume((128, 256, 256), 0)
+pipe = VolumePipeline([m, m.clone()], (128, 128, 128), (14, 46, 46), (1, 2, 2), (16, 16, 16), [0.2, 0.35, 0.5], min_seed_distance=10,
+                      filter_fragments=0.1, remove_debris=64, n_lanes=4)
+segs = pipe.run(vol)
+torch.cuda.synchronize()
+assert int(segs.max()) > 1000
+bad = _lib.lib.bsmi_debug_check_guards()
+assert bad == 0, f"{bad} guard zones written to (predict + segment)"
 print("guards intact", flush=True)
