@@ -218,7 +218,8 @@ int bsmi_unet_profile_executed(bsmi_unet *h, double *executed_flops, int reset);
  * and check it; *mismatches_dev (device uint64, caller-zeroed) counts words that changed.  Run beside an engine on another
  * stream: does a co-resident kernel write outside its own LDS allocation? */
 int bsmi_debug_lds_canary(int lds_bytes, int blocks, int spins, unsigned long long *mismatches_dev, void *stream);
-/* Development aid: with BSMI_GUARD_MB=<n> in the environment every device allocation of the network engine lies between
+/* Development aid: with BSMI_GUARD_MB=<n> in the environment every device allocation of the network engine, the training state and
+ * the segmentation engines lies between
  * two n-MiB zones of 0xFF bytes (csrc/dev_guard.h): a read past a buffer that reaches a result turns it into NaNs, and this
  * call counts the zones something WROTE into (0 = intact, each hit reported on stderr; -1 = HIP error; 0 when unset). */
 int bsmi_debug_check_guards(void);
